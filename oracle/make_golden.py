@@ -1,0 +1,303 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by executing the REFERENCE's own code.
+
+TEST INFRASTRUCTURE.  Runs in the build container only: imports
+/root/reference/GeneralTools/{misc_fun,math_func,layer_func}.py unmodified
+through `oracle/tf1_shim.py` (TensorFlow itself is absent) and records inputs
+and outputs of the hot-path functions as small fixtures.  The fixtures are
+data (seeded inputs + reference outputs), never reference source text.
+
+    python oracle/make_golden.py            # writes tests/golden/
+
+Each fixture carries fp32 outputs (`*_f32`, what the reference computes) and
+fp64 outputs (`*_f64`, same code with the shim in double precision: the value
+every fp32 implementation is measured against).
+"""
+import os
+import sys
+import zlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, 'tests', 'golden')
+REFERENCE = '/root/reference'
+
+sys.path.insert(0, HERE)
+import tf1_shim as tf  # noqa: E402
+
+tf.install()
+sys.path.insert(0, REFERENCE)
+from GeneralTools.misc_fun import FLAGS  # noqa: E402
+from GeneralTools import math_func as ref_math  # noqa: E402
+from GeneralTools import layer_func as ref_layer  # noqa: E402
+
+FLAGS.SILENT_MODE = True
+DT = {'f32': torch.float32, 'f64': torch.float64}
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+# ---------------------------------------------------------------------------
+# 1. pairwise distance + rep / rmb losses (math_func.py:767, 1288, 1356, 2088)
+# ---------------------------------------------------------------------------
+def mmd_inputs(B, d, sig_gen, sig_x, offset, seed):
+    rs = np.random.RandomState(seed)
+    s_gen = (rs.randn(B, d) * sig_gen).astype(np.float32)
+    s_x = (rs.randn(B, d) * sig_x + offset).astype(np.float32)
+    return s_gen, s_x
+
+
+def run_mmd(loss_type, s_gen_np, s_x_np, rep_weights, tag):
+    out = {}
+    B = s_gen_np.shape[0]
+    for key, dt in DT.items():
+        tf.set_dtype(dt)
+        tf.STATE.reset()
+        sg = torch.tensor(s_gen_np, dtype=dt, requires_grad=True)
+        sx = torch.tensor(s_x_np, dtype=dt, requires_grad=True)
+        dgg, dgd, ddd = ref_math.get_squared_dist(sg, sx)
+        lg, ld = ref_math.GANLoss(False).apply(sg, sx, loss_type, batch_size=B, d=s_gen_np.shape[1],
+                                               rep_weights=list(rep_weights))
+        glg = torch.autograd.grad(lg, [sg, sx], retain_graph=True)
+        gld = torch.autograd.grad(ld, [sg, sx])
+        out.update({'loss_gen_' + key: npy(lg), 'loss_dis_' + key: npy(ld),
+                    'dLg_dsgen_' + key: npy(glg[0]), 'dLg_dsx_' + key: npy(glg[1]),
+                    'dLd_dsgen_' + key: npy(gld[0]), 'dLd_dsx_' + key: npy(gld[1])})
+        if B <= 64:
+            out.update({'dist_gg_' + key: npy(dgg), 'dist_gd_' + key: npy(dgd), 'dist_dd_' + key: npy(ddd)})
+        m = float(B)
+        k = lambda dist: ref_math.matrix_mean_wo_diagonal(torch.exp(-dist / 2.0), m)
+        out.update({'e_kxx_' + key: npy(k(dgg)), 'e_kxy_' + key: npy(k(dgd)), 'e_kyy_' + key: npy(k(ddd))})
+        if key == 'f32':
+            out['mask_gg_lt_lb'] = npy(dgg < 0.25)
+            out['mask_dd_gt_ub'] = npy(ddd > 4.0)
+            out['mask_gd_gt_ub'] = npy(dgd > 4.0)
+            off = ~np.eye(B, dtype=bool)
+            margin = min(np.abs(npy(dgg)[off] - 0.25).min(), np.abs(npy(ddd)[off] - 4.0).min(),
+                         np.abs(npy(dgd) - 4.0).min())
+            out['threshold_margin'] = np.float64(margin)
+    out.update({'s_gen': s_gen_np, 's_x': s_x_np, 'rep_weights': np.asarray(rep_weights, np.float64),
+                'loss_type': np.asarray(loss_type)})
+    return out
+
+
+def make_mmd():
+    cases = []
+    # (B, sigma_gen, sigma_x, offset) - typical D-output scales of SURVEY 8(d)
+    for B in (8, 64, 128):
+        for loss_type in ('rep', 'rmb'):
+            for (sg, sx, off) in ((0.25, 0.3, 0.1), (0.05, 0.05, 0.02), (1.0, 1.0, 0.2)):
+                cases.append((B, loss_type, sg, sx, off, (0.0, -1.0)))
+    cases.append((64, 'rep', 0.25, 0.3, 0.1, (-1.0, -2.0)))       # math_func.py:2116 alternative weights
+    cases.append((64, 'rmb', 0.5, 0.6, 0.1, (-1.0, -2.0)))
+    cases.append((64, 'rmb', 0.5, 0.6, 0.1, (1.0, 0.0)))          # w0>0 branch: k_xy upper bound
+    n = 0
+    for (B, loss_type, sg, sx, off, w) in cases:
+        seed = 0
+        while True:                                               # reject near-threshold seeds
+            s_gen, s_x = mmd_inputs(B, 16, sg, sx, off, 1000 * n + seed)
+            fx = run_mmd(loss_type, s_gen, s_x, w, '')
+            if fx['threshold_margin'] > 1e-4:
+                break
+            seed += 1
+        name = 'mmd_{}_B{}_c{:02d}.npz'.format(loss_type, B, n)
+        np.savez_compressed(os.path.join(OUT, name), **fx)
+        n += 1
+    print('mmd fixtures:', n)
+
+
+# ---------------------------------------------------------------------------
+# 2. layers through the reference's Net / Routine (layer_func.py)
+# ---------------------------------------------------------------------------
+def build_routine(designs, net_name, input_shape):
+    net = ref_layer.Net(designs, net_name=net_name, data_format=FLAGS.IMAGE_FORMAT, num_class=0)
+    r = ref_layer.Routine(net)
+    r.add_input_layers([64] + list(input_shape), [0])
+    r.seq_links(list(range(net.num_layers)))
+    r.add_output_layers([net.num_layers - 1])
+    return r
+
+
+def snapshot():
+    return {k: npy(v).copy() for k, v in tf.STATE.variables.items()}
+
+
+def run_net_case(designs, net_name, input_shape, batch, seed, n_steps=2):
+    """forward + backward of a small net with a random upstream gradient, `n_steps` consecutive
+    evaluations (SN in_rand / BN moving stats are updated between them)."""
+    rs = np.random.RandomState(seed)
+    x_np = rs.uniform(-1, 1, size=[batch] + list(input_shape)).astype(np.float32)
+    out = {'x': x_np}
+    init = None
+    for key, dt in DT.items():
+        tf.set_dtype(dt)
+        tf.STATE.reset()
+        tf.STATE.rng = np.random.RandomState(seed + 1)
+        r = build_routine(designs, net_name, input_shape)
+        x = torch.tensor(x_np, dtype=dt, requires_grad=True)
+        y = r({'x': x}, is_training=True)['x']                     # creates the variables
+        if init is None:
+            init = snapshot()                                      # fp32 initial values
+            for k, v in init.items():
+                out['init/' + k] = v.astype(np.float32)
+            dy_np = np.random.RandomState(seed + 2).randn(*y.shape).astype(np.float32)
+            out['dy'] = dy_np
+        # restart from the recorded fp32 initial values in this dtype
+        for k, v in tf.STATE.variables.items():
+            with torch.no_grad():
+                v.copy_(torch.tensor(init[k], dtype=dt))
+        tf.STATE.update_ops = []
+        for step in range(n_steps):
+            r = build_routine(designs, net_name, input_shape)
+            x = torch.tensor(x_np, dtype=dt, requires_grad=True)
+            y = r({'x': x}, is_training=True)['x']
+            names = list(tf.STATE.trainable)
+            vs = [tf.STATE.variables[n] for n in names]
+            grads = torch.autograd.grad((y * torch.tensor(out['dy'], dtype=dt)).sum(), [x] + vs)
+            pre = 'step{}/'.format(step)
+            out[pre + 'y_' + key] = npy(y).astype(np.float32)
+            if key == 'f64':                      # fp64 truth, stored as float32 to keep fixtures small
+                out[pre + 'dx_f64'] = npy(grads[0]).astype(np.float32)
+                for n, g in zip(names, grads[1:]):
+                    out[pre + 'grad/' + n + '_f64'] = npy(g).astype(np.float32)
+            for layer in r.net.layers:
+                kn = layer.ops['kernel'].kernel_norm
+                if kn is not None:
+                    out[pre + 'sigma/' + layer.layer_scope + '_' + key] = npy(kn)
+            tf.run_update_ops()
+            for k, v in tf.STATE.variables.items():
+                if (k.endswith('in_rand') or '/moving_' in k) and key == 'f64':
+                    out[pre + 'after/' + k + '_f64'] = npy(v).astype(np.float32)
+    return out
+
+
+def make_layers():
+    ak = float(np.power(64.0, 0.125))
+    cases = {
+        # D-style SN conv layers: k3s1 (use_u) and k4s2 (not use_u), + dense SN head with C,H,W flatten
+        'dis_small': ([{'name': 'l1_f32', 'out': 8, 'act': 'lrelu', 'act_k': ak, 'w_nm': 's'},
+                       {'name': 'l2_ds', 'out': 16, 'act': 'lrelu', 'act_k': ak, 'w_nm': 's', 'kernel': 4, 'strides': 2},
+                       {'name': 'l3', 'out': 16, 'act': 'lrelu', 'act_k': ak, 'w_nm': 's'},
+                       {'name': 'l4_ds', 'out': 32, 'act': 'lrelu', 'act_k': ak, 'w_nm': 's', 'kernel': 4, 'strides': 2,
+                        'out_reshape': [4 * 4 * 32]},
+                       {'name': 'l5_s', 'out': 16, 'op': 'd', 'act_k': ak, 'bias': 'b', 'w_nm': 's'}],
+                      'dis', [3, 16, 16], 6),
+        # G-style: dense -> reshape -> tc+BN+relu x2 -> conv+tanh
+        'gen_small': ([{'name': 'l1', 'out': 32 * 4 * 4, 'op': 'd', 'act': 'linear', 'act_nm': None,
+                        'out_reshape': [32, 4, 4]},
+                       {'name': 'l2_up', 'out': 16, 'op': 'tc', 'act': 'relu', 'act_nm': 'bn', 'kernel': 4, 'strides': 2},
+                       {'name': 'l3_up', 'out': 8, 'op': 'tc', 'act': 'relu', 'act_nm': 'bn', 'kernel': 4, 'strides': 2},
+                       {'name': 'l4_t', 'out': 3, 'act': 'tanh'}],
+                      'gen', [24], 6),
+        # STL-style first G layer: dense + BN + relu on a 2-D tensor (my_test_stl.py:12)
+        'gen_stl_head': ([{'name': 'l1', 'out': 16 * 3 * 3, 'op': 'd', 'act': 'relu', 'act_nm': 'bn',
+                           'out_reshape': [16, 3, 3]},
+                          {'name': 'l2_up', 'out': 8, 'op': 'tc', 'act': 'relu', 'act_nm': 'bn', 'kernel': 4,
+                           'strides': 2}],
+                         'gen', [20], 5),
+        # single full-width-ish SN layers to exercise channel counts that are not tile multiples
+        'dis_odd': ([{'name': 'l1', 'out': 24, 'act': 'lrelu', 'act_k': ak, 'w_nm': 's'},
+                     {'name': 'l2', 'out': 40, 'act': 'lrelu', 'act_k': ak, 'w_nm': 's', 'kernel': 4, 'strides': 2}],
+                    'dis', [5, 12, 12], 3),
+    }
+    for name, (designs, net_name, in_shape, batch) in cases.items():
+        fx = run_net_case(designs, net_name, in_shape, batch, seed=zlib.crc32(name.encode()) % 1000)
+        fx['designs_repr'] = np.asarray(repr(designs))
+        fx['input_shape'] = np.asarray(in_shape)
+        np.savez_compressed(os.path.join(OUT, 'net_{}.npz'.format(name)), **fx)
+    print('net fixtures:', len(cases))
+
+
+# ---------------------------------------------------------------------------
+# 3. full G+D step on a width/8 CIFAR-shaped net, 3 consecutive steps
+# ---------------------------------------------------------------------------
+from tiny_arch import tiny_architecture  # noqa: E402
+
+
+def tf_adam_inplace(var, g, m, v, t, lr, b1=0.5, b2=0.999, eps=1e-8):
+    """tf.train.AdamOptimizer update (graph_func.py:525-526 hyper-parameters).  graph_func.py needs
+    tf.contrib + sessions and is not importable through the shim, so these 4 lines are restated."""
+    lr_t = lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+    m.mul_(b1).add_(g, alpha=1.0 - b1)
+    v.mul_(b2).add_(g * g, alpha=1.0 - b2)
+    with torch.no_grad():
+        var.sub_(lr_t * m / (torch.sqrt(v) + eps))
+
+
+def make_step(loss_type, B=8, n_steps=3, lr=(5e-4, 2e-4), store_grads=True):
+    arch = tiny_architecture()
+    out = {'lr': np.asarray(lr), 'loss_type': np.asarray(loss_type), 'B': np.asarray(B)}
+    rs = np.random.RandomState(77)
+    zs = rs.randn(n_steps, B, arch['code'][0][0]).astype(np.float32)
+    reals = rs.uniform(-1, 1, size=(n_steps, B, 3, 32, 32)).astype(np.float32)
+    out['z'], out['real'] = zs, reals
+    init = None
+    for key, dt in DT.items():
+        tf.set_dtype(dt)
+        tf.STATE.reset()
+        tf.STATE.rng = np.random.RandomState(5)
+
+        def build():
+            g = build_routine(arch['generator'], 'gen', [arch['code'][0][0]])
+            d = build_routine(arch['discriminator'], 'dis', list(arch['input'][0]))
+            return g, d
+        G, D = build()
+        D({'x': torch.cat([torch.tensor(reals[0], dtype=dt), G({'x': torch.tensor(zs[0], dtype=dt)})['x']], 0)})
+        if init is None:
+            init = snapshot()
+            for k, v in init.items():
+                out['init/' + k] = v.astype(np.float32)
+        for k, v in tf.STATE.variables.items():
+            with torch.no_grad():
+                v.copy_(torch.tensor(init[k], dtype=dt))
+        tf.STATE.update_ops = []
+        adam = {}
+        for step in range(n_steps):
+            G, D = build()                                           # "re-trace the graph"
+            z, real = torch.tensor(zs[step], dtype=dt), torch.tensor(reals[step], dtype=dt)
+            gen = G({'x': z}, is_training=True)['x']                 # my_sngan.py:277
+            dis_out = D({'x': torch.cat([real, gen], 0)}, is_training=True)['x']     # my_sngan.py:278
+            s_x, s_gen = tf.split(dis_out, 2, 0)                     # my_sngan.py:279
+            lg, ld = ref_math.GANLoss(False).apply(s_gen, s_x, loss_type, batch_size=B, d=16,
+                                                   rep_weights=[0.0, -1.0])          # my_sngan.py:284-286
+            vd = tf.get_collection(tf.GraphKeys.TRAINABLE_VARIABLES, 'dis')
+            vg = tf.get_collection(tf.GraphKeys.TRAINABLE_VARIABLES, 'gen')
+            gd = torch.autograd.grad(ld, vd, retain_graph=True)      # my_sngan.py:302
+            gg = torch.autograd.grad(lg, vg)                         # my_sngan.py:304
+            pre = 'step{}/'.format(step)
+            out[pre + 'loss_gen_' + key], out[pre + 'loss_dis_' + key] = npy(lg), npy(ld)
+            out[pre + 's_x_' + key], out[pre + 's_gen_' + key] = npy(s_x), npy(s_gen)
+            if key == 'f64' and step in (0, n_steps - 1) and store_grads:
+                out[pre + 'gen_f64'] = npy(gen).astype(np.float32)
+                for v, g in list(zip(vd, gd)) + list(zip(vg, gg)):
+                    out[pre + 'grad/' + v.tf_name + '_f64'] = npy(g).astype(np.float32)
+            for layer in D.net.layers:
+                out[pre + 'sigma/' + layer.layer_scope + '_' + key] = npy(layer.ops['kernel'].kernel_norm)
+            # apply both Adam updates, then the UPDATE_OPS (values were computed before any write)
+            for lr_i, vs, gs in ((lr[0], vd, gd), (lr[1], vg, gg)):
+                for v, g in zip(vs, gs):
+                    m, vv = adam.setdefault(v.tf_name, (torch.zeros_like(v), torch.zeros_like(v)))
+                    tf_adam_inplace(v, g, m, vv, step + 1, lr_i)
+            tf.run_update_ops()
+        if key == 'f64':
+            for k, v in tf.STATE.variables.items():
+                out['final/' + k + '_f64'] = npy(v).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, 'step_tiny_{}.npz'.format(loss_type)), **out)
+    print('step fixture:', loss_type)
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    make_mmd()
+    make_layers()
+    make_step('rep')
+    make_step('rmb', store_grads=False)
+    total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print('tests/golden total bytes:', total)

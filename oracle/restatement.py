@@ -1,0 +1,444 @@
+"""CPU restatement of the reference's SN-DCGAN + repulsive-MMD training step.
+
+TEST INFRASTRUCTURE.  Only `tests/`, `__graft_entry__.smoke()` and
+`bench.py`'s `cpu_baseline` leg may import this module; the product path
+(`mmd-gan_amd/`) never does and fails loudly without its HIP library.
+
+This is a from-scratch restatement (torch-CPU tensors as the array library,
+fp32 or fp64 selectable) of exactly the slice of richardwth/MMD-GAN that
+SURVEY.md section 8 puts on the hot path.  Every function cites the reference
+file:line it follows (paths relative to /root/reference).  It is pinned against
+the reference's own code, executed through `oracle/tf1_shim.py`, by the golden
+vectors in `tests/golden/` (`oracle/make_golden.py` writes them,
+`tests/test_oracle_golden.py` checks them).  The reference itself ships no
+tests or golden vectors, so those fixtures are the pin.
+
+Layouts here are the reference's: activations NCHW (misc_fun.py:50-51), conv
+kernels HWIO `[k,k,Cin,Cout]`, transposed-conv kernels `[k,k,Cout,Cin]`
+(layer_func.py:584,595), dense kernels `[in,out]`; variable names as TF scopes
+give them (`dis/l2_ds/kernel/kernel`, `.../kernel/SN/in_rand`, `.../bias/bias`,
+`gen/l2_up/BN/BN/gamma` ...).
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+EPSI = 1e-10            # misc_fun.py:29 FLAGS.EPSI
+BN_EPS = 1e-3           # tf.layers.batch_normalization default epsilon (layer_func.py:960)
+BN_MOMENTUM = 0.99      # tf.layers.batch_normalization default momentum
+LRELU_ALPHA = 0.1       # layer_func.py:112
+
+
+# ---------------------------------------------------------------------------
+# architecture dict -> layer specs (layer_func.py:1189-1275, 2118-2151, 2221-2391)
+# ---------------------------------------------------------------------------
+_TEMPLATE = {'name': None, 'type': 'default', 'op': 'c', 'out': None, 'bias': 'b',
+             'act': 'linear', 'act_nm': None, 'act_k': False, 'w_nm': None, 'w_p': None,
+             'kernel': 3, 'strides': 1, 'dilation': 1, 'padding': 'SAME', 'scale': None,
+             'in_reshape': None, 'out_reshape': None, 'aux': None}
+
+
+def layer_defaults(design):
+    """update_layer_design, layer_func.py:1230-1247 (defaults; BN drops the bias)."""
+    d = dict(_TEMPLATE)
+    d.update(design)
+    if d['act_nm'] in ('bn', 'BN') and d['bias'] in ('b', 'bias'):
+        d['bias'] = None
+    if d['op'] == 'tc':
+        d['scale'] = None
+    if d['op'] not in ('d', 'c', 'tc'):
+        raise AttributeError('layer op {} not supported.'.format(d['op']))
+    if d['type'] != 'default':
+        raise NotImplementedError('{} is not implemented.'.format(d['type']))
+    return d
+
+
+def _same_out(size, stride):
+    return -(-size // stride)          # math_func.py:172-193 ('SAME')
+
+
+def build_net(designs, input_shape, net_name):
+    """Net + Routine.add_input_layers/seq_links shape inference (layer_func.py:2118,2221,2349).
+
+    input_shape excludes the batch dimension: [z] or [C,H,W].  Returns a list of spec dicts."""
+    specs, shape = [], list(input_shape)
+    for design in designs:
+        d = layer_defaults(design)
+        if d['in_reshape'] is not None:
+            shape = list(d['in_reshape'])
+        s = {'design': d, 'scope': '{}/{}'.format(net_name, d['name']), 'in_shape': list(shape)}
+        if d['op'] == 'd':                                   # layer_func.py:576-578
+            assert len(shape) == 1, '{}: dense layer needs a flat input'.format(s['scope'])
+            s['kernel_shape'] = [shape[0], d['out']]
+            out = [d['out']]
+        elif d['op'] == 'c':                                 # layer_func.py:579-589
+            c, h, w = shape
+            s['kernel_shape'] = [d['kernel'], d['kernel'], c, d['out']]
+            out = [d['out'], _same_out(h, d['strides']), _same_out(w, d['strides'])]
+        else:                                                # 'tc', layer_func.py:590-600
+            c, h, w = shape
+            s['kernel_shape'] = [d['kernel'], d['kernel'], d['out'], c]
+            out = [d['out'], h * d['strides'], w * d['strides']]
+        s['op_out_shape'] = list(out)
+        if d['w_nm'] == 's':                                 # math_func.py:481-486, 512-528
+            if d['op'] == 'd':
+                use_u = shape[0] <= d['out']
+                s['sn_x_shape'] = [1, shape[0]] if use_u else [1, d['out']]
+            else:
+                use_u = int(np.prod(shape)) <= int(np.prod(out))
+                if d['op'] == 'c':
+                    s['sn_x_shape'] = [1] + (list(shape) if use_u else list(out))
+                else:
+                    s['sn_x_shape'] = [1] + (list(out) if use_u else list(shape))
+            s['use_u'] = use_u
+            if not isinstance(d['act_k'], (float, int)) or d['act_k'] is False:
+                # layer_func.py:835: act_k=False passes isinstance(int) and zeroes the kernel;
+                # every shipped config sets act_k, and the build rejects the quirk
+                raise ValueError('{}: w_nm="s" needs a numeric act_k'.format(s['scope']))
+        if d['out_reshape'] is not None:
+            out = list(d['out_reshape'])
+        s['out_shape'] = list(out)
+        specs.append(s)
+        shape = list(out)
+    return specs
+
+
+# ---------------------------------------------------------------------------
+# initialisers (layer_func.py:14-80; TF variance_scaling fan rules)
+# ---------------------------------------------------------------------------
+def _trunc_normal(rng, shape, stddev):
+    out = rng.randn(*shape)
+    bad = np.abs(out) > 2.0
+    while bad.any():
+        out[bad] = rng.randn(int(bad.sum()))
+        bad = np.abs(out) > 2.0
+    return out * stddev
+
+
+def init_kernel(rng, shape, act):
+    """weight_initializer 'default' mode (layer_func.py:27-52).  TF computes fan_in from
+    shape[-2] and fan_out from shape[-1] times the receptive field, for every op (tc quirk)."""
+    receptive = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+    fan_in, fan_out = shape[-2] * receptive, shape[-1] * receptive
+    if act == 'relu':
+        return _trunc_normal(rng, shape, math.sqrt(2.0 / fan_in))
+    if act == 'lrelu':
+        return _trunc_normal(rng, shape, math.sqrt(2.0 / 1.01 / fan_in))
+    limit = math.sqrt(3.0 / ((fan_in + fan_out) / 2.0))
+    return rng.uniform(-limit, limit, size=shape)
+
+
+def init_params(specs, rng, dtype=torch.float32):
+    """all variables of one net, in TF creation order, reference names and layouts."""
+    p = OrderedDict()
+    for s in specs:
+        d, sc = s['design'], s['scope']
+        p[sc + '/kernel/kernel'] = torch.as_tensor(init_kernel(rng, s['kernel_shape'], d['act']), dtype=dtype)
+        if d['w_nm'] == 's':                                          # math_func.py:565-567
+            p[sc + '/kernel/SN/in_rand'] = torch.as_tensor(_trunc_normal(rng, s['sn_x_shape'], 1.0), dtype=dtype)
+        if d['bias'] is not None:                                     # layer_func.py:745-747
+            p[sc + '/bias/bias'] = torch.as_tensor(_trunc_normal(rng, [s['op_out_shape'][0]], 1e-5), dtype=dtype)
+        if d['act_nm'] in ('bn', 'BN'):                               # layer_func.py:953-966
+            c = s['op_out_shape'][0]
+            p[sc + '/BN/BN/gamma'] = torch.ones(c, dtype=dtype)
+            p[sc + '/BN/BN/beta'] = torch.zeros(c, dtype=dtype)
+            p[sc + '/BN/BN/moving_mean'] = torch.zeros(c, dtype=dtype)
+            p[sc + '/BN/BN/moving_variance'] = torch.ones(c, dtype=dtype)
+    return p
+
+
+def trainable_names(params):
+    return [n for n in params if not (n.endswith('in_rand') or '/moving_' in n)]
+
+
+# ---------------------------------------------------------------------------
+# linear operators (layer_func.py:909-928; SURVEY A.4 semantics)
+# ---------------------------------------------------------------------------
+def conv2d_same(x, w_hwio, stride):
+    """tf.nn.conv2d(x, W[k,k,Cin,Cout], 'SAME', NCHW): cross-correlation, pad_before = total//2."""
+    k = w_hwio.shape[0]
+
+    def pads(size):
+        total = max((_same_out(size, stride) - 1) * stride + k - size, 0)
+        return total // 2, total - total // 2
+    (pt, pb), (pl, pr) = pads(x.shape[2]), pads(x.shape[3])
+    return F.conv2d(F.pad(x, (pl, pr, pt, pb)), w_hwio.permute(3, 2, 0, 1), stride=stride)
+
+
+def conv2d_transpose_same(v, w, out_hw, stride):
+    """tf.nn.conv2d_transpose(v, W[k,k,Cout,Cin], 'SAME'): the input-gradient of conv2d_same."""
+    k = w.shape[0]
+    oh, ow = out_hw
+
+    def pads(size):
+        total = max((_same_out(size, stride) - 1) * stride + k - size, 0)
+        return total // 2, total - total // 2
+    (pt, pb), (pl, pr) = pads(oh), pads(ow)
+    full = F.conv_transpose2d(v, w.permute(3, 2, 0, 1), stride=stride)
+    fh, fw = full.shape[2], full.shape[3]
+    if fh < oh + pt + pb or fw < ow + pl + pr:
+        full = F.pad(full, (0, max(ow + pl + pr - fw, 0), 0, max(oh + pt + pb - fh, 0)))
+    return full[:, :, pt:pt + oh, pl:pl + ow]
+
+
+# ---------------------------------------------------------------------------
+# spectral normalisation (math_func.py:470-569, 661-672, 674-746)
+# ---------------------------------------------------------------------------
+def _l2(x):
+    return torch.sqrt(torch.sum(x * x))                      # tf.norm(axis=None), math_func.py:651
+
+
+def sn_power_iteration(w, x, spec):
+    """one power-iteration step.  Returns (sigma, x_update).  sigma = ||F(x)|| from the
+    PRE-update x (math_func.py:668-670); x is a constant (non-trainable variable)."""
+    d = spec['design']
+    if d['op'] == 'd':
+        if 1 in w.shape:                                     # math_func.py:702-704
+            return _l2(w), x
+        if spec['use_u']:
+            fwd, bwd = (lambda t: t @ w), (lambda t: t @ w.t())          # math_func.py:583-602
+        else:
+            fwd, bwd = (lambda t: t @ w.t()), (lambda t: t @ w)
+    else:
+        stride = d['strides']
+        in_hw = spec['in_shape'][1:] if d['op'] == 'c' else spec['op_out_shape'][1:]
+        conv = lambda t: conv2d_same(t, w, stride)                       # math_func.py:604-619
+        conv_t = lambda t: conv2d_transpose_same(t, w, in_hw, stride)    # math_func.py:621-637
+        fwd, bwd = (conv, conv_t) if spec['use_u'] else (conv_t, conv)   # math_func.py:527-528
+    u = fwd(x)
+    sigma = _l2(u)
+    y = u / (sigma + EPSI)                                   # math_func.py:659
+    xb = bwd(y)
+    x_update = xb / (_l2(xb) + EPSI)
+    return sigma, x_update.detach()
+
+
+# ---------------------------------------------------------------------------
+# forward pass of one net (layer_func.py:870-928, 946-966, 1646-1685, 2078-2100)
+# ---------------------------------------------------------------------------
+def _act(x, name):
+    if name == 'linear':
+        return x
+    if name == 'relu':
+        return torch.relu(x)
+    if name == 'lrelu':
+        return torch.where(x > 0, x, x * LRELU_ALPHA)        # layer_func.py:104-112
+    if name == 'tanh':
+        return torch.tanh(x)
+    raise NotImplementedError('Function {} is not implemented.'.format(name))
+
+
+def net_forward(specs, params, x, is_training=True, collect=None):
+    """returns (output, updates) - updates maps variable name -> new value (the UPDATE_OPS of
+    graph_func.py:848: SN in_rand assignments and BN moving statistics)."""
+    updates = OrderedDict()
+    for s in specs:
+        d, sc = s['design'], s['scope']
+        n = x.shape[0]
+        if d['in_reshape'] is not None:
+            x = x.reshape([n] + list(d['in_reshape']))
+        assert list(x.shape[1:]) == s['in_shape'], \
+            '{}: the input shape {} does not match existed shape {}.'.format(sc, list(x.shape[1:]), s['in_shape'])
+        w = params[sc + '/kernel/kernel']
+        if d['w_nm'] == 's':                                  # layer_func.py:884-887, 913
+            sigma, x_new = sn_power_iteration(w, params[sc + '/kernel/SN/in_rand'], s)
+            updates[sc + '/kernel/SN/in_rand'] = x_new
+            w = w * (d['act_k'] / sigma)
+            if collect is not None:
+                collect[sc + '/sigma'] = sigma.detach()
+        if d['op'] == 'd':
+            x = x @ w
+        elif d['op'] == 'c':
+            x = conv2d_same(x, w, d['strides'])
+        else:
+            x = conv2d_transpose_same(x, w, s['op_out_shape'][1:], d['strides'])
+        if d['bias'] is not None:                             # layer_func.py:946-950
+            b = params[sc + '/bias/bias']
+            x = x + (b.reshape(1, -1, 1, 1) if x.dim() == 4 else b)
+        if d['act_nm'] in ('bn', 'BN'):                       # layer_func.py:953-966, SURVEY A.4
+            axis_shape = [1, -1, 1, 1] if x.dim() == 4 else [1, -1]
+            dims = [0, 2, 3] if x.dim() == 4 else [0]
+            if is_training:
+                mean = x.mean(dim=dims)
+                var = ((x - mean.reshape(axis_shape)) ** 2).mean(dim=dims)
+                cnt = x.numel() // x.shape[1]
+                var_u = var * (cnt / max(cnt - 1.0, 1.0)) if x.dim() == 4 else var
+                mm, mv = params[sc + '/BN/BN/moving_mean'], params[sc + '/BN/BN/moving_variance']
+                updates[sc + '/BN/BN/moving_mean'] = (mm * BN_MOMENTUM + mean.detach() * (1 - BN_MOMENTUM))
+                updates[sc + '/BN/BN/moving_variance'] = (mv * BN_MOMENTUM + var_u.detach() * (1 - BN_MOMENTUM))
+            else:
+                mean, var = params[sc + '/BN/BN/moving_mean'], params[sc + '/BN/BN/moving_variance']
+            x = (x - mean.reshape(axis_shape)) / torch.sqrt(var.reshape(axis_shape) + BN_EPS)
+            x = x * params[sc + '/BN/BN/gamma'].reshape(axis_shape) + params[sc + '/BN/BN/beta'].reshape(axis_shape)
+        x = _act(x, d['act'])
+        if collect is not None:
+            collect[sc + '/out'] = x.detach()
+        if d['out_reshape'] is not None:                      # C,H,W order flatten (my_test_cifar.py:36)
+            x = x.reshape([n] + list(d['out_reshape']))
+    return x, updates
+
+
+# ---------------------------------------------------------------------------
+# pairwise distances and the repulsive / bounded MMD losses
+# ---------------------------------------------------------------------------
+def get_squared_dist(x, y):
+    """math_func.py:799-840, mode 'xxxyyy': Gram form, diag from the Gram matrix, clamp at 0."""
+    xxt, xyt, yyt = x @ x.t(), x @ y.t(), y @ y.t()
+    dx, dy = torch.diagonal(xxt), torch.diagonal(yyt)
+    zero = torch.zeros((), dtype=x.dtype)
+    dist_xx = torch.maximum(dx[:, None] - 2.0 * xxt + dx[None, :], zero)
+    dist_xy = torch.maximum(dx[:, None] - 2.0 * xyt + dy[None, :], zero)
+    dist_yy = torch.maximum(dy[:, None] - 2.0 * yyt + dy[None, :], zero)
+    return dist_xx, dist_xy, dist_yy
+
+
+def matrix_mean_wo_diagonal(m, num_row):
+    """math_func.py:1064: (sum - trace)/(m(m-1)), also for the cross block."""
+    return (torch.sum(m) - torch.sum(torch.diagonal(m))) / (num_row * (num_row - 1.0))
+
+
+def mmd_g(dist_xx, dist_xy, dist_yy, batch_size, sigma=1.0, custom_weights=None):
+    """math_func.py:1312-1343 (no bounds)."""
+    k_xx = torch.exp(-dist_xx / (2.0 * sigma ** 2))
+    k_yy = torch.exp(-dist_yy / (2.0 * sigma ** 2))
+    k_xy = torch.exp(-dist_xy / (2.0 * sigma ** 2))
+    m = float(batch_size)
+    e_kxx, e_kxy, e_kyy = (matrix_mean_wo_diagonal(k, m) for k in (k_xx, k_xy, k_yy))
+    stats = {'kxx': e_kxx, 'kxy': e_kxy, 'kyy': e_kyy}
+    mmd1 = e_kxx + e_kyy - 2.0 * e_kxy
+    if custom_weights is None:
+        return mmd1, None, stats
+    assert custom_weights[0] - custom_weights[1] == 1.0, 'w[0]-w[1] must be 1'
+    mmd2 = custom_weights[0] * e_kxy - e_kxx - custom_weights[1] * e_kyy
+    return mmd1, mmd2, stats
+
+
+def mmd_g_bounded(dist_xx, dist_xy, dist_yy, batch_size, sigma=1.0, lower_bound=0.25, upper_bound=4.0,
+                  custom_weights=(0.0, -1.0)):
+    """math_func.py:1380-1422."""
+    s2 = 2.0 * sigma ** 2
+    lb = torch.tensor(lower_bound, dtype=dist_xx.dtype)
+    ub = torch.tensor(upper_bound, dtype=dist_xx.dtype)
+    k_xx, k_yy, k_xy = torch.exp(-dist_xx / s2), torch.exp(-dist_yy / s2), torch.exp(-dist_xy / s2)
+    k_xx_b = torch.exp(-torch.maximum(dist_xx, lb) / s2)
+    k_xy_b = torch.exp(-torch.minimum(dist_xy, ub) / s2) if custom_weights[0] > 0 else k_xy
+    if custom_weights[1] > 0:
+        k_yy_b = torch.exp(-torch.maximum(dist_yy, lb) / s2)
+    else:
+        k_yy_b = torch.exp(-torch.minimum(dist_yy, ub) / s2)
+    m = float(batch_size)
+    e_kxx, e_kxy, e_kyy = (matrix_mean_wo_diagonal(k, m) for k in (k_xx, k_xy, k_yy))
+    e_kxx_b, e_kyy_b = matrix_mean_wo_diagonal(k_xx_b, m), matrix_mean_wo_diagonal(k_yy_b, m)
+    e_kxy_b = matrix_mean_wo_diagonal(k_xy_b, m) if custom_weights[0] < 0 else e_kxy
+    assert custom_weights[0] - custom_weights[1] == 1.0, 'w[0]-w[1] must be 1'
+    mmd1 = e_kxx + e_kyy - 2.0 * e_kxy
+    mmd2 = custom_weights[0] * e_kxy_b - e_kxx_b - custom_weights[1] * e_kyy_b
+    stats = {'kxx': e_kxx, 'kxy': e_kxy, 'kyy': e_kyy, 'kxx_b': e_kxx_b, 'kyy_b': e_kyy_b}
+    return mmd1, mmd2, stats
+
+
+def gan_loss(score_gen, score_data, loss_type, batch_size, rep_weights=(0.0, -1.0)):
+    """GANLoss.__call__ for the hot-path loss names (math_func.py:2556-2658, 2505-2550).
+    x = generated scores, y = real scores (my_sngan.py:284-286).  Returns
+    (loss_gen, loss_dis, stats)."""
+    if loss_type in ('rep', 'rep_mmd_g'):
+        d = get_squared_dist(score_gen, score_data)
+        return mmd_g(*d, batch_size, sigma=1.0, custom_weights=list(rep_weights))
+    if loss_type in ('rmb', 'rep_b', 'rep_mmd_b'):
+        d = get_squared_dist(score_gen, score_data)
+        return mmd_g_bounded(*d, batch_size, sigma=1.0, lower_bound=0.25, upper_bound=4.0,
+                             custom_weights=list(rep_weights))
+    raise NotImplementedError('Not implemented.')
+
+
+def mmd_masks(score_gen, score_data, lower_bound=0.25, upper_bound=4.0):
+    """the bit-exact index masks of SURVEY A.3: clamp-active sets of the rmb loss."""
+    dxx, dxy, dyy = get_squared_dist(score_gen, score_data)
+    return {'xx_lt_lb': dxx < lower_bound, 'yy_gt_ub': dyy > upper_bound, 'xy_gt_ub': dxy > upper_bound}
+
+
+# ---------------------------------------------------------------------------
+# TF-Adam (graph_func.py:518-527; tf.train.AdamOptimizer semantics)
+# ---------------------------------------------------------------------------
+class AdamTF:
+    def __init__(self, names, params, lr, beta1=0.5, beta2=0.999, eps=1e-8):
+        self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
+        self.m = {n: torch.zeros_like(params[n]) for n in names}
+        self.v = {n: torch.zeros_like(params[n]) for n in names}
+        self.t = 0
+
+    def apply(self, params, grads):
+        self.t += 1
+        lr_t = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        for n, g in grads.items():
+            self.m[n] = self.b1 * self.m[n] + (1.0 - self.b1) * g
+            self.v[n] = self.b2 * self.v[n] + (1.0 - self.b2) * g * g
+            params[n] = params[n] - lr_t * self.m[n] / (torch.sqrt(self.v[n]) + self.eps)
+
+
+# ---------------------------------------------------------------------------
+# one training step (my_sngan.py:271-323, 424-425; graph_func.py:851-854)
+# ---------------------------------------------------------------------------
+class OracleGan:
+    """G + D + losses + two TF-Adam optimisers; one `step` = one sess.run of graph_func.py:853."""
+
+    def __init__(self, architecture, loss_type='rep', lr_list=(5e-4, 2e-4), rep_weights=(0.0, -1.0),
+                 seed=0, dtype=torch.float32, params=None):
+        self.arch, self.loss_type, self.rep_weights, self.dtype = architecture, loss_type, rep_weights, dtype
+        self.code_size = architecture['code'][0][0]
+        self.gen_specs = build_net(architecture['generator'], [self.code_size], 'gen')
+        self.dis_specs = build_net(architecture['discriminator'], list(architecture['input'][0]), 'dis')
+        assert self.gen_specs[-1]['out_shape'] == list(architecture['input'][0])
+        rng = np.random.RandomState(seed)
+        self.params = OrderedDict()
+        self.params.update(init_params(self.gen_specs, rng, dtype))
+        self.params.update(init_params(self.dis_specs, rng, dtype))
+        if params is not None:
+            for k, v in params.items():
+                assert k in self.params and list(self.params[k].shape) == list(v.shape), k
+                self.params[k] = torch.as_tensor(np.asarray(v), dtype=dtype).clone()
+        names = trainable_names(self.params)
+        self.dis_names = [n for n in names if n.startswith('dis')]      # my_sngan.py:301
+        self.gen_names = [n for n in names if n.startswith('gen')]      # my_sngan.py:303
+        self.opt_d = AdamTF(self.dis_names, self.params, lr_list[0])
+        self.opt_g = AdamTF(self.gen_names, self.params, lr_list[1])
+        self.global_step = 0
+
+    def forward_losses(self, z, real, collect=None):
+        p = self.params
+        gen, up_g = net_forward(self.gen_specs, p, z, True, collect)
+        dis_out, up_d = net_forward(self.dis_specs, p, torch.cat([real, gen], 0), True, collect)   # my_sngan.py:278
+        b = z.shape[0]
+        s_x, s_gen = dis_out[:b], dis_out[b:]                                                    # my_sngan.py:279
+        loss_gen, loss_dis, stats = gan_loss(s_gen, s_x, self.loss_type, b, self.rep_weights)
+        updates = OrderedDict(up_g)
+        updates.update(up_d)
+        return loss_gen, loss_dis, stats, updates, (gen, s_x, s_gen)
+
+    def grads(self, z, real, collect=None):
+        leaves = {n: self.params[n].detach().clone().requires_grad_(True)
+                  for n in self.dis_names + self.gen_names}
+        saved = dict(self.params)
+        self.params.update(leaves)
+        try:
+            loss_gen, loss_dis, stats, updates, aux = self.forward_losses(z, real, collect)
+            gd = torch.autograd.grad(loss_dis, [leaves[n] for n in self.dis_names], retain_graph=True)
+            gg = torch.autograd.grad(loss_gen, [leaves[n] for n in self.gen_names])
+        finally:
+            self.params.update(saved)
+        return (loss_gen.detach(), loss_dis.detach(), stats, updates,
+                dict(zip(self.dis_names, gd)), dict(zip(self.gen_names, gg)), aux)
+
+    def step(self, z, real):
+        """losses are pre-update values; D and G update simultaneously from one forward
+        (SURVEY 3.1); all reads precede all writes for the UPDATE_OPS."""
+        loss_gen, loss_dis, stats, updates, gd, gg, _ = self.grads(z, real)
+        self.opt_d.apply(self.params, gd)
+        self.opt_g.apply(self.params, gg)
+        for n, v in updates.items():
+            self.params[n] = v
+        self.global_step += 1                                  # my_sngan.py:424
+        return float(loss_gen), float(loss_dis)

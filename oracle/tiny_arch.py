@@ -1,0 +1,23 @@
+"""width/8 CIFAR-shaped architecture dict used by the full-step golden fixture (test infrastructure)."""
+import numpy as np
+
+
+def tiny_architecture(loss_base=4):
+    ak = float(np.power(64.0, 0.125))
+    s = 's'
+    return {'input': [(3, 32, 32)], 'code': [(32, 'linear')],
+            'generator': [{'name': 'l1', 'out': 64 * 4 * 4, 'op': 'd', 'act': 'linear', 'act_nm': None,
+                           'out_reshape': [64, 4, 4]},
+                          {'name': 'l2_up', 'out': 32, 'op': 'tc', 'act': 'relu', 'act_nm': 'bn', 'kernel': 4, 'strides': 2},
+                          {'name': 'l3_up', 'out': 16, 'op': 'tc', 'act': 'relu', 'act_nm': 'bn', 'kernel': 4, 'strides': 2},
+                          {'name': 'l4_up', 'out': 8, 'op': 'tc', 'act': 'relu', 'act_nm': 'bn', 'kernel': 4, 'strides': 2},
+                          {'name': 'l5_t32', 'out': 3, 'act': 'tanh'}],
+            'discriminator': [{'name': 'l1_f32', 'out': 8, 'act': 'lrelu', 'act_k': ak, 'w_nm': s},
+                              {'name': 'l2_ds', 'out': 16, 'act': 'lrelu', 'act_k': ak, 'w_nm': s, 'kernel': 4, 'strides': 2},
+                              {'name': 'l3', 'out': 16, 'act': 'lrelu', 'act_k': ak, 'w_nm': s},
+                              {'name': 'l4_ds', 'out': 32, 'act': 'lrelu', 'act_k': ak, 'w_nm': s, 'kernel': 4, 'strides': 2},
+                              {'name': 'l5', 'out': 32, 'act': 'lrelu', 'act_k': ak, 'w_nm': s},
+                              {'name': 'l6_ds', 'out': 64, 'act': 'lrelu', 'act_k': ak, 'w_nm': s, 'kernel': 4, 'strides': 2},
+                              {'name': 'l7', 'out': 64, 'op': 'c', 'act': 'lrelu', 'act_k': ak, 'w_nm': s,
+                               'out_reshape': [4 * 4 * 64]},
+                              {'name': 'l8_s', 'out': 16, 'op': 'd', 'act_k': ak, 'bias': 'b', 'w_nm': s}]}

@@ -1,0 +1,34 @@
+"""shared helpers for the parity tests (oracle = checker, never the thing measured)."""
+import ast
+import glob
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+# Tolerances (BASELINE.json north_star): fp32 MMD loss and conv activations within 1e-4
+# relative; index masks bit-exact.  "relative" for a tensor = max|a-b| / max|b|.
+RTOL = 1e-4
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    scale = np.max(np.abs(b))
+    if scale == 0.0:
+        return float(np.max(np.abs(a)))
+    return float(np.max(np.abs(a - b)) / scale)
+
+
+def golden(pattern):
+    return sorted(glob.glob(os.path.join(GOLDEN, pattern)))
+
+
+def load(path):
+    z = np.load(path, allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def designs_of(fx):
+    return ast.literal_eval(str(fx['designs_repr']))

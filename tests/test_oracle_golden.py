@@ -1,0 +1,134 @@
+"""The oracle (oracle/restatement.py, oracle/mmd_oracle.c) against the golden vectors that
+oracle/make_golden.py produced by running the reference's own code.  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import RTOL, designs_of, golden, load, rel_err
+from oracle import c_oracle, restatement as R
+
+MMD = golden('mmd_*.npz')
+NETS = golden('net_*.npz')
+
+
+@pytest.mark.parametrize('path', MMD, ids=[p.split('/')[-1] for p in MMD])
+@pytest.mark.parametrize('prec', ['f32', 'f64'])
+def test_mmd_restatement_matches_reference(path, prec):
+    fx = load(path)
+    dt = torch.float32 if prec == 'f32' else torch.float64
+    sg = torch.tensor(fx['s_gen'], dtype=dt, requires_grad=True)
+    sx = torch.tensor(fx['s_x'], dtype=dt, requires_grad=True)
+    B = sg.shape[0]
+    lg, ld, stats = R.gan_loss(sg, sx, str(fx['loss_type']), B, tuple(fx['rep_weights']))
+    tol = 2e-5 if prec == 'f32' else 1e-12
+    assert abs(float(lg) - float(fx['loss_gen_' + prec])) <= tol * max(abs(float(fx['loss_gen_' + prec])), 1e-3)
+    assert abs(float(ld) - float(fx['loss_dis_' + prec])) <= tol * max(abs(float(fx['loss_dis_' + prec])), 1e-3)
+    glg = torch.autograd.grad(lg, [sg, sx], retain_graph=True)
+    gld = torch.autograd.grad(ld, [sg, sx], allow_unused=True)
+    for got, key in ((glg[0], 'dLg_dsgen_'), (glg[1], 'dLg_dsx_'), (gld[0], 'dLd_dsgen_'), (gld[1], 'dLd_dsx_')):
+        got = np.zeros_like(fx[key + prec]) if got is None else got.numpy()
+        assert rel_err(got, fx[key + prec]) <= (1e-4 if prec == 'f32' else 1e-10)
+    if prec == 'f32':                                   # bit-exact index masks
+        m = R.mmd_masks(sg.detach(), sx.detach())
+        assert np.array_equal(m['xx_lt_lb'].numpy(), fx['mask_gg_lt_lb'])
+        assert np.array_equal(m['yy_gt_ub'].numpy(), fx['mask_dd_gt_ub'])
+        assert np.array_equal(m['xy_gt_ub'].numpy(), fx['mask_gd_gt_ub'])
+
+
+@pytest.mark.parametrize('path', MMD, ids=[p.split('/')[-1] for p in MMD])
+def test_mmd_c_oracle_matches_reference(path):
+    fx = load(path)
+    w = tuple(float(v) for v in fx['rep_weights'])
+    for prec, dt in (('f32', np.float32), ('f64', np.float64)):
+        out = c_oracle.mmd(fx['s_gen'], fx['s_x'], str(fx['loss_type']), w, dtype=dt)
+        ltol = 5e-4 if prec == 'f32' else 1e-11   # two correct fp32 evaluations of the Gram form differ by this much
+        # the losses are differences of O(1) kernel means (cancellation): an fp32 sequential sum
+        # over B*B terms carries ~1e-5 of the mean's scale, whatever the loss's own size
+        escale = max(float(fx['e_kxx_' + prec]), float(fx['e_kyy_' + prec]), float(fx['e_kxy_' + prec]))
+        floor = 1e-5 * escale if prec == 'f32' else 1e-13
+        for name in ('loss_gen', 'loss_dis'):
+            ref = float(fx[name + '_' + prec])
+            assert abs(float(out[name]) - ref) <= ltol * abs(ref) + floor, (name, prec)
+        gtol = 1e-4 if prec == 'f32' else 1e-9
+        for i, key in enumerate(('dLg_dsgen_', 'dLg_dsx_', 'dLd_dsgen_', 'dLd_dsx_')):
+            assert rel_err(out['grads'][i], fx[key + prec]) <= gtol, (key, prec)
+        assert rel_err(out['stats'][:3], [fx['e_kxx_' + prec], fx['e_kxy_' + prec], fx['e_kyy_' + prec]]) <= ltol
+    # masks: the C oracle in fp32 reproduces the reference's fp32 clamp sets exactly when the
+    # threshold margin exceeds fp32 rounding of the distance (fixtures guarantee > 1e-4)
+    out = c_oracle.mmd(fx['s_gen'], fx['s_x'], str(fx['loss_type']), w, dtype=np.float32)
+    assert np.array_equal(out['masks'][0], fx['mask_gg_lt_lb'])
+    assert np.array_equal(out['masks'][1], fx['mask_gd_gt_ub'])
+    assert np.array_equal(out['masks'][2], fx['mask_dd_gt_ub'])
+
+
+@pytest.mark.parametrize('path', NETS, ids=[p.split('/')[-1] for p in NETS])
+def test_net_restatement_matches_reference(path):
+    fx = load(path)
+    designs = designs_of(fx)
+    net_name = [k for k in fx if k.startswith('init/')][0].split('/')[1]
+    specs = R.build_net(designs, [int(v) for v in fx['input_shape']], net_name)
+    for prec, dt in (('f32', torch.float32), ('f64', torch.float64)):
+        params = {k[len('init/'):]: torch.tensor(v, dtype=dt) for k, v in fx.items() if k.startswith('init/')}
+        names = R.trainable_names(params)
+        for step in range(2):
+            pre = 'step%d/' % step
+            leaves = {n: params[n].clone().requires_grad_(True) for n in names}
+            p = dict(params)
+            p.update(leaves)
+            x = torch.tensor(fx['x'], dtype=dt, requires_grad=True)
+            col = {}
+            y, updates = R.net_forward(specs, p, x, True, col)
+            tol = 5e-5 if prec == 'f32' else 1e-6        # f64 fixtures are stored as float32
+            assert rel_err(y.detach().numpy(), fx[pre + 'y_' + prec]) <= tol
+            for k in fx:
+                if k.startswith(pre + 'sigma/') and k.endswith(prec):
+                    scope = k[len(pre + 'sigma/'):-len('_' + prec)]
+                    assert abs(float(col[scope + '/sigma']) - float(fx[k])) <= tol * float(fx[k])
+            if prec == 'f64':
+                g = torch.autograd.grad((y * torch.tensor(fx['dy'], dtype=dt)).sum(), [x] + [leaves[n] for n in names])
+                assert rel_err(g[0].numpy(), fx[pre + 'dx_f64']) <= 1e-6
+                for n, gi in zip(names, g[1:]):
+                    assert rel_err(gi.numpy(), fx[pre + 'grad/' + n + '_f64']) <= 1e-6, n
+                for n, v in updates.items():
+                    assert rel_err(v.numpy(), fx[pre + 'after/' + n + '_f64']) <= 1e-6, n
+            for n, v in updates.items():
+                params[n] = v
+
+
+@pytest.mark.parametrize('loss_type', ['rep', 'rmb'])
+def test_full_step_restatement_matches_reference(loss_type):
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
+    fx = load(golden('step_tiny_%s.npz' % loss_type)[0])
+    from tiny_arch import tiny_architecture
+    arch = tiny_architecture()
+    init = {k[len('init/'):]: v for k, v in fx.items() if k.startswith('init/')}
+    for prec, dt in (('f32', torch.float32), ('f64', torch.float64)):
+        gan = R.OracleGan(arch, loss_type, tuple(fx['lr']), dtype=dt, params=init)
+        for step in range(3):
+            z, real = torch.tensor(fx['z'][step], dtype=dt), torch.tensor(fx['real'][step], dtype=dt)
+            pre = 'step%d/' % step
+            if prec == 'f64' and (pre + 'grad/dis/l1_f32/kernel/kernel_f64') in fx:
+                lg, ld, stats, upd, gd, gg, aux = gan.grads(z, real)
+                for n, g in list(gd.items()) + list(gg.items()):
+                    ref = fx[pre + 'grad/' + n + '_f64']
+                    if step == 0:
+                        # un-normalised SN start vectors make D's step-0 outputs
+                        # ~1e-14, the kernel values 1 - O(1e-28) and every gradient <1e-12, gated by the sign of
+                        # rounding-noise distances (max(.,0) of +-1e-28), in the reference too: only magnitude is checkable
+                        assert np.abs(ref).max() < 1e-12 and np.abs(g.numpy()).max() < 1e-12, n
+                        continue
+                    # dL/d(last bias) is exactly 0 analytically (the loss sees only score
+                    # differences): allow an absolute floor tied to the net's gradient scale
+                    gscale = max(np.abs(fx[pre + 'grad/' + m + '_f64']).max() for m in (gd if n in gd else gg))
+                    assert np.abs(g.numpy() - ref).max() <= 2e-6 * np.abs(ref).max() + 1e-9 * gscale, (step, n)
+            lg, ld = gan.step(z, real)
+            for got, name in ((lg, 'loss_gen_'), (ld, 'loss_dis_')):
+                ref = float(fx[pre + name + prec])
+                tol = 2e-4 if prec == 'f32' else 1e-9
+                assert abs(got - ref) <= tol * max(abs(ref), 1e-6), (step, name, got, ref)
+        if prec == 'f64':
+            for k, v in fx.items():
+                if k.startswith('final/'):
+                    n = k[len('final/'):-len('_f64')]
+                    assert rel_err(gan.params[n].numpy(), v) <= 2e-6, n
