@@ -1,0 +1,165 @@
+/* libmmdgan_hip - C ABI of the MI355X (gfx950) hot path of MMD-GAN training.
+ *
+ * The reference (richardwth/MMD-GAN, TensorFlow 1.x) has NO native code and no FFI: its seam is
+ * the Python API.  This header is therefore the boundary the build's own
+ * Python host code (mmd-gan_amd/mmdgan_hip/, mirroring GeneralTools/ and DeepLearning/) binds with
+ * ctypes; each entry cites the reference call site (file:line under /root/reference) whose stock
+ * TF op it replaces.  INTEGRATION.md shows the binding stub.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; every function returns 0 on success or a negative
+ *     MMDGAN_E_* code and never throws; mmdgan_last_error() gives the thread-local message.
+ *   - the CALLER owns all device memory (torch allocates); the library allocates nothing.
+ *     Scratch is passed in explicitly (sizes from the *_workspace_bytes queries).
+ *   - every call is asynchronous and ordered on the hipStream_t passed as `stream` (void*; NULL =
+ *     the default stream).  No call synchronises the device.
+ *   - activations are NHWC fp32; conv kernels HWIO `[R,S,C,K]` exactly as the reference stores
+ *     them (layer_func.py:584), transposed-conv kernels `[R,S,Kout,Cin]` (layer_func.py:595),
+ *     dense kernels `[in,out]` (layer_func.py:577).
+ *   - "scale" arguments are DEVICE pointers to one float (NULL = 1.0): the spectral-norm multiplier
+ *     act_k/sigma (layer_func.py:886-887) is consumed from device memory, never read by the host.
+ */
+#ifndef MMDGAN_HIP_H
+#define MMDGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMDGAN_OK 0
+#define MMDGAN_E_ARG (-1)      /* bad argument (shape, enum, null pointer) */
+#define MMDGAN_E_LAUNCH (-2)   /* hipLaunch / runtime error */
+#define MMDGAN_E_UNSUPPORTED (-3)
+
+/* activation enum - layer_func.py:104-151 (lrelu alpha = 0.1, layer_func.py:112) */
+#define MMDGAN_ACT_LINEAR 0
+#define MMDGAN_ACT_RELU 1
+#define MMDGAN_ACT_LRELU 2
+#define MMDGAN_ACT_TANH 3
+
+/* loss enum - math_func.py:2644-2647 */
+#define MMDGAN_LOSS_REP 0
+#define MMDGAN_LOSS_RMB 1
+
+const char *mmdgan_last_error(void);
+int mmdgan_version(void);
+/* 1 if a gfx950 device is visible to this process, 0 otherwise (never an error) */
+int mmdgan_device_ok(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolution family.  Geometry: input [N,H,W,C], kernel [R,R,C,K], stride, 'SAME' padding with
+ * pad_before = max((ceil(H/stride)-1)*stride + R - H, 0)/2 (tf.nn.conv2d, layer_func.py:914),
+ * output [N,P,Q,K], P = ceil(H/stride).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int N, H, W, C;    /* input  (NHWC) */
+    int K;             /* output channels */
+    int R;             /* square kernel size */
+    int stride;
+} mmdgan_conv_geom;
+
+/* y = act(scale * conv(x, w) + bias)                       tf.nn.conv2d      layer_func.py:913-916
+ * also the input-gradient of a transposed conv (with dact_of != NULL, see below).
+ * If dact_of != NULL the epilogue is the BACKWARD form  y = scale*conv(x,w) * act'(dact_of)  where
+ * dact_of holds the forward OUTPUT of the activation `act` at the same coordinates as y. */
+int mmdgan_conv2d_fwd(const mmdgan_conv_geom *g, const float *x, const float *w, const float *bias,
+                      const float *scale, int act, const float *dact_of, float *y, void *stream);
+
+/* dx = scale * conv_input_grad(dy, w) [* act'(dact_of)]      autodiff of conv2d, my_sngan.py:302-304
+ * Forward form (dact_of == NULL): dx = act(scale*conv_transpose(dy,w) + bias)
+ *                                                          tf.nn.conv2d_transpose layer_func.py:926
+ * g describes the CONV whose input-gradient this is: dy is [N,P,Q,K], dx is [N,H,W,C]. */
+int mmdgan_conv2d_dgrad(const mmdgan_conv_geom *g, const float *dy, const float *w, const float *bias,
+                        const float *scale, int act, const float *dact_of, float *dx, void *stream);
+
+/* dw[R,R,C,K] = sum over pixels x (x) dy                   autodiff of conv2d / conv2d_transpose
+ * dw is overwritten. */
+int mmdgan_conv2d_wgrad(const mmdgan_conv_geom *g, const float *x, const float *dy, float *dw, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense (tf.matmul, layer_func.py:909-911).  Row-major.  trans flags as in BLAS:
+ *   C[M,N] = act(scale * op(A) op(B) + bias[N]),  op(A) is [M,K], op(B) is [K,N].
+ * ---------------------------------------------------------------------------------------------- */
+int mmdgan_gemm(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
+                const float *bias, const float *scale, int act, const float *dact_of, float *C, int ldc,
+                void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Column reductions / elementwise helpers
+ * ---------------------------------------------------------------------------------------------- */
+/* out[c] = sum_r x[r, c]  (bias gradient = column sum of the upstream gradient)  layer_func.py:946 */
+int mmdgan_colsum(const float *x, long rows, int cols, float *out, void *stream);
+/* out[0] = sum_i a[i]*b[i]  (double accumulation) */
+int mmdgan_dot(const float *a, const float *b, long n, float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batch norm, training mode, NHWC / [rows, C]          tf.layers.batch_normalization
+ *   layer_func.py:960-966: momentum .99, eps 1e-3, biased batch variance for normalisation,
+ *   moving_variance updated with the unbiased variance when the input is 4-D (fused kernel).
+ * fwd: y = act((x - mean)/sqrt(var+eps) * gamma + beta); writes save_mean/save_invstd [C] and
+ *      new_moving_mean/var (may alias the inputs' storage: all reads precede all writes).
+ * bwd: dx, dgamma, dbeta from dy (gradient w.r.t. y, i.e. AFTER the activation), y.
+ * workspace: mmdgan_bn_workspace_bytes(C) bytes of device scratch (double partial sums).
+ * ---------------------------------------------------------------------------------------------- */
+size_t mmdgan_bn_workspace_bytes(int C);
+int mmdgan_bn_fwd_train(const float *x, long rows, int C, const float *gamma, const float *beta, float eps,
+                        float momentum, int unbiased_moving_var, int act, float *y, float *save_mean,
+                        float *save_invstd, const float *moving_mean, const float *moving_var,
+                        float *new_moving_mean, float *new_moving_var, void *workspace, void *stream);
+int mmdgan_bn_fwd_infer(const float *x, long rows, int C, const float *gamma, const float *beta, float eps,
+                        int act, const float *moving_mean, const float *moving_var, float *y, void *stream);
+int mmdgan_bn_bwd(const float *x, const float *y, const float *dy, long rows, int C, const float *gamma,
+                  const float *save_mean, const float *save_invstd, int act, float *dx, float *dgamma,
+                  float *dbeta, void *workspace, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Spectral normalisation helpers (math_func.py:639-672).  The linear maps themselves are the
+ * batch-1 conv / dgrad / gemm entries above; these are the norm steps between them.
+ *   sn_norm:      out_norm[0] = ||v||_2 ; if v_normalised != NULL: v_normalised = v / (||v|| + 1e-10)
+ *   sn_scale:     scale_out[0] = act_k / sigma[0]                      layer_func.py:886-887
+ *   sn_wgrad_fixup: dw = scale*G - (scale/sigma) * <G,W> * dsigma_dw   (SURVEY A.2), in place on G.
+ *                 `dot` is a device scalar holding <G,W>.
+ * ---------------------------------------------------------------------------------------------- */
+int mmdgan_sn_norm(const float *v, long n, float *out_norm, float *v_normalised, void *stream);
+int mmdgan_sn_scale(const float *sigma, float act_k, float *scale_out, void *stream);
+int mmdgan_sn_wgrad_fixup(float *g_inout, const float *dsigma_dw, const float *dot, const float *sigma,
+                          const float *scale, long n, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pairwise squared distances + Gaussian kernel + repulsive ('rep') / bounded ('rmb') MMD losses,
+ * forward and backward in one launch (the B x B matrices never touch HBM).
+ *   math_func.py: get_squared_dist :799-840, matrix_mean_wo_diagonal :1064, mmd_g :1312-1343,
+ *   mmd_g_bounded :1380-1422, GANLoss._repulsive_mmd_g_(bounded_) :2505-2550.
+ *   s_gen, s_x   [B,d]  discriminator scores of generated / real samples (x = gen, y = real)
+ *   out_scalars  [8]    loss_gen, loss_dis, e_kxx, e_kxy, e_kyy, e_kxx_b, e_kyy_b, reserved
+ *   grads        [4,B,d] dLgen/ds_gen, dLgen/ds_x, dLdis/ds_gen, dLdis/ds_x   (NULL = forward only)
+ *   masks        [3,B,B] bytes: dist_gg < lb, dist_gd > ub, dist_dd > ub       (NULL = skip)
+ *   dist         [3,B,B] dist_gg, dist_gd, dist_dd                             (NULL = skip)
+ *   workspace    mmdgan_mmd_workspace_bytes(B, d) bytes of device scratch
+ * ---------------------------------------------------------------------------------------------- */
+size_t mmdgan_mmd_workspace_bytes(int B, int d);
+int mmdgan_mmd_loss(const float *s_gen, const float *s_x, int B, int d, int loss_type, float w0, float w1,
+                    float lower_bound, float upper_bound, float *out_scalars, float *grads,
+                    unsigned char *masks, float *dist, void *workspace, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * TF-semantics Adam over a list of tensors in one launch          graph_func.py:518-527
+ *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ *   p -= lr_t * m / (sqrt(v) + eps)
+ * ptrs is a DEVICE array of 4*n_tensors pointers (p, g, m, v per tensor), sizes a DEVICE array of
+ * n_tensors element counts; grad_scale multiplies g first (1/world_size after a sum all-reduce).
+ * ---------------------------------------------------------------------------------------------- */
+int mmdgan_adam_multi(const void *const *ptrs, const long *sizes, int n_tensors, long max_size, float lr,
+                      float beta1, float beta2, float eps, int step, float grad_scale, void *stream);
+
+/* layout seam helpers: NCHW <-> NHWC (the reference API speaks NCHW, misc_fun.py:50-51) */
+int mmdgan_nchw_to_nhwc(const float *src, float *dst, int N, int C, int H, int W, void *stream);
+int mmdgan_nhwc_to_nchw(const float *src, float *dst, int N, int C, int H, int W, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMDGAN_HIP_H */

@@ -1,0 +1,182 @@
+// Batch normalisation over [rows, C] (NHWC flattened), training and inference, with the following
+// activation fused.  Replaces tf.layers.batch_normalization(axis=1, training, fused=True) at
+// layer_func.py:960-966 (TF defaults momentum .99, eps 1e-3) and its autodiff.
+//
+// HBM-bound.  Statistics are column sums accumulated in double (products of floats are exact in
+// double, so E[x^2]-mean^2 carries no fp32 cancellation): kernel A writes per-chunk partial sums
+// to the workspace, kernel B combines them per channel in fixed order (deterministic), kernel C
+// applies.  x is read twice, y written once.
+#include "common.h"
+
+namespace mmdgan {
+
+constexpr int kBnMaxSplits = 256;
+
+// partial[(split*2 + which)*C + c], which 0: sum a, 1: sum b
+template <int MODE>   // 0: a = x, b = x*x      1: a = dz, b = dz*xhat  (dz = dy*act'(y))
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                         const float *__restrict__ dy, long rows, int C,
+                                                         long rows_per_split, const float *mean, const float *invstd,
+                                                         int act, double *partial) {
+    __shared__ double red[2][4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const long r0 = (long)blockIdx.y * rows_per_split;
+    long r1 = r0 + rows_per_split;
+    if (r1 > rows) r1 = rows;
+    double sa = 0, sb = 0;
+    if (c < C) {
+        float mu = 0.f, is = 0.f;
+        if (MODE == 1) { mu = mean[c]; is = invstd[c]; }
+        for (long r = r0 + rl; r < r1; r += 4) {
+            const long o = r * C + c;
+            if (MODE == 0) {
+                const double v = (double)x[o];
+                sa += v; sb += v * v;
+            } else {
+                const float dz = dy[o] * act_bwd_from_out(y[o], act);
+                const float xh = (x[o] - mu) * is;
+                sa += (double)dz; sb += (double)dz * (double)xh;
+            }
+        }
+    }
+    red[0][rl][cl] = sa; red[1][rl][cl] = sb;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        partial[((size_t)blockIdx.y * 2 + 0) * C + c] = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+        partial[((size_t)blockIdx.y * 2 + 1) * C + c] = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_finish_kernel(const double *partial, int splits, long rows, int C,
+                                                              float eps, float momentum, int unbiased, float *save_mean,
+                                                              float *save_invstd, const float *mm, const float *mv,
+                                                              float *new_mm, float *new_mv) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0, s2 = 0;
+    for (int k = 0; k < splits; ++k) { s += partial[((size_t)k * 2) * C + c]; s2 += partial[((size_t)k * 2 + 1) * C + c]; }
+    const double n = (double)rows, mean = s / n;
+    double var = s2 / n - mean * mean;            // biased batch variance
+    if (var < 0) var = 0;
+    save_mean[c] = (float)mean;
+    save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (new_mm) {
+        const double var_u = unbiased ? var * (n / (n > 1 ? n - 1.0 : 1.0)) : var;
+        const float om = mm[c], ov = mv[c];       // reads precede writes (buffers may alias)
+        new_mm[c] = om * momentum + (float)mean * (1.f - momentum);
+        new_mv[c] = ov * momentum + (float)var_u * (1.f - momentum);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__ x, long total, int C,
+                                                       const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                       const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                       float eps_for_var, int use_var, int act, float *__restrict__ y) {
+    const long stride = (long)gridDim.x * 256;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {
+        const int c = o % C;
+        const float is = use_var ? rsqrtf(invstd[c] + eps_for_var) : invstd[c];   // infer: invstd holds the variance
+        y[o] = act_fwd((x[o] - mean[c]) * is * gamma[c] + beta[c], act);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const double *partial, int splits, int C, float *dgamma,
+                                                            float *dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0, s2 = 0;
+    for (int k = 0; k < splits; ++k) { s += partial[((size_t)k * 2) * C + c]; s2 += partial[((size_t)k * 2 + 1) * C + c]; }
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)s2;
+}
+
+// dx = gamma*invstd*(dz - dbeta/n - xhat*dgamma/n)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                           const float *__restrict__ dy, long total, long rows, int C,
+                                                           const float *__restrict__ gamma, const float *__restrict__ mean,
+                                                           const float *__restrict__ invstd, const float *__restrict__ dgamma,
+                                                           const float *__restrict__ dbeta, int act, float *__restrict__ dx) {
+    const float invn = 1.0f / (float)rows;
+    const long stride = (long)gridDim.x * 256;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {
+        const int c = o % C;
+        const float dz = dy[o] * act_bwd_from_out(y[o], act);
+        const float xh = (x[o] - mean[c]) * invstd[c];
+        dx[o] = gamma[c] * invstd[c] * (dz - dbeta[c] * invn - xh * dgamma[c] * invn);
+    }
+}
+
+static int bn_splits(long rows, int C, long *rows_per_split) {
+    const int cblocks = (C + 63) / 64;
+    long splits = 1024 / cblocks;
+    if (splits > kBnMaxSplits) splits = kBnMaxSplits;
+    if (splits < 1) splits = 1;
+    long rps = (rows + splits - 1) / splits;
+    if (rps < 8) rps = 8;
+    splits = (rows + rps - 1) / rps;
+    *rows_per_split = rps;
+    return (int)splits;
+}
+
+}  // namespace mmdgan
+
+using namespace mmdgan;
+
+extern "C" size_t mmdgan_bn_workspace_bytes(int C) { return C < 1 ? 0 : (size_t)kBnMaxSplits * 2 * C * sizeof(double); }
+
+extern "C" int mmdgan_bn_fwd_train(const float *x, long rows, int C, const float *gamma, const float *beta, float eps,
+                                   float momentum, int unbiased_moving_var, int act, float *y, float *save_mean,
+                                   float *save_invstd, const float *moving_mean, const float *moving_var,
+                                   float *new_moving_mean, float *new_moving_var, void *workspace, void *stream) {
+    MMDGAN_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && workspace, "bn_fwd_train: null pointer");
+    MMDGAN_REQUIRE(rows >= 1 && C >= 1, "bn_fwd_train: bad shape");
+    MMDGAN_REQUIRE(!new_moving_mean || (moving_mean && moving_var && new_moving_var), "bn_fwd_train: moving stats");
+    hipStream_t st = (hipStream_t)stream;
+    long rps;
+    const int splits = bn_splits(rows, C, &rps);
+    double *part = (double *)workspace;
+    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3((C + 63) / 64, splits), dim3(256), 0, st, x, nullptr, nullptr, rows, C,
+                       rps, nullptr, nullptr, 0, part);
+    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, splits, rows, C, eps,
+                       momentum, unbiased_moving_var, save_mean, save_invstd, moving_mean, moving_var, new_moving_mean,
+                       new_moving_var);
+    const long total = rows * C;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, total, C, gamma, beta, save_mean,
+                       save_invstd, 0.f, 0, act, y);
+    return check_launch("bn_fwd_train");
+}
+
+extern "C" int mmdgan_bn_fwd_infer(const float *x, long rows, int C, const float *gamma, const float *beta, float eps,
+                                   int act, const float *moving_mean, const float *moving_var, float *y, void *stream) {
+    MMDGAN_REQUIRE(x && gamma && beta && y && moving_mean && moving_var && rows >= 1 && C >= 1, "bn_fwd_infer: bad arguments");
+    const long total = rows * C;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, total, C, gamma,
+                       beta, moving_mean, moving_var, eps, 1, act, y);
+    return check_launch("bn_fwd_infer");
+}
+
+extern "C" int mmdgan_bn_bwd(const float *x, const float *y, const float *dy, long rows, int C, const float *gamma,
+                             const float *save_mean, const float *save_invstd, int act, float *dx, float *dgamma,
+                             float *dbeta, void *workspace, void *stream) {
+    MMDGAN_REQUIRE(x && y && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && workspace,
+                   "bn_bwd: null pointer");
+    MMDGAN_REQUIRE(rows >= 1 && C >= 1, "bn_bwd: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    long rps;
+    const int splits = bn_splits(rows, C, &rps);
+    double *part = (double *)workspace;
+    hipLaunchKernelGGL(bn_partial_kernel<1>, dim3((C + 63) / 64, splits), dim3(256), 0, st, x, y, dy, rows, C, rps,
+                       save_mean, save_invstd, act, part);
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, splits, C, dgamma, dbeta);
+    const long total = rows * C;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, dy, total, rows, C, gamma,
+                       save_mean, save_invstd, dgamma, dbeta, act, dx);
+    return check_launch("bn_bwd");
+}

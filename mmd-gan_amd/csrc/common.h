@@ -1,0 +1,80 @@
+// Shared host/device helpers for libmmdgan_hip (gfx950 only; no portability layers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mmdgan_hip.h"
+
+namespace mmdgan {
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr float kLreluAlpha = 0.1f;   // layer_func.py:112
+constexpr float kEpsi = 1e-10f;       // misc_fun.py:29 FLAGS.EPSI
+
+void set_error(const char *fmt, ...);
+
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return MMDGAN_E_LAUNCH;
+    }
+    return MMDGAN_OK;
+}
+
+#define MMDGAN_REQUIRE(cond, ...)            \
+    do {                                     \
+        if (!(cond)) {                       \
+            mmdgan::set_error(__VA_ARGS__);  \
+            return MMDGAN_E_ARG;             \
+        }                                    \
+    } while (0)
+
+// forward activation (layer_func.py:104-151)
+__device__ __forceinline__ float act_fwd(float v, int act) {
+    switch (act) {
+        case MMDGAN_ACT_RELU: return v > 0.f ? v : 0.f;
+        case MMDGAN_ACT_LRELU: return v > 0.f ? v : v * kLreluAlpha;
+        case MMDGAN_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+// derivative of the activation expressed through its OUTPUT y (lrelu alpha>0 keeps the sign)
+__device__ __forceinline__ float act_bwd_from_out(float y, int act) {
+    switch (act) {
+        case MMDGAN_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case MMDGAN_ACT_LRELU: return y > 0.f ? 1.f : kLreluAlpha;
+        case MMDGAN_ACT_TANH: return 1.f - y * y;
+        default: return 1.f;
+    }
+}
+
+// 'SAME' geometry of tf.nn.conv2d
+struct ConvDims {
+    int N, H, W, C, K, R, stride, P, Q, pad;
+};
+inline ConvDims conv_dims(const mmdgan_conv_geom &g) {
+    ConvDims d;
+    d.N = g.N; d.H = g.H; d.W = g.W; d.C = g.C; d.K = g.K; d.R = g.R; d.stride = g.stride;
+    d.P = (g.H + g.stride - 1) / g.stride;
+    d.Q = (g.W + g.stride - 1) / g.stride;
+    int total = (d.P - 1) * g.stride + g.R - g.H;
+    if (total < 0) total = 0;
+    d.pad = total / 2;
+    return d;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace mmdgan

@@ -1,0 +1,53 @@
+// C-ABI entry points of the convolution family: validate, then dispatch to the MFMA implicit-GEMM
+// kernels (conv_igemm.hip) when the geometry is tile-aligned, else to the direct kernels.
+#include <stdlib.h>
+
+#include "conv_internal.h"
+
+using namespace mmdgan;
+
+namespace {
+int validate(const mmdgan_conv_geom *g, const char *what) {
+    MMDGAN_REQUIRE(g, "%s: null geometry", what);
+    MMDGAN_REQUIRE(g->N >= 1 && g->H >= 1 && g->W >= 1 && g->C >= 1 && g->K >= 1, "%s: bad shape", what);
+    MMDGAN_REQUIRE(g->R >= 1 && g->R <= 7 && g->stride >= 1 && g->stride <= g->R, "%s: bad kernel %d / stride %d", what,
+                   g->R, g->stride);
+    return MMDGAN_OK;
+}
+// MMDGAN_FORCE_DIRECT=1 routes everything to the direct kernels (A/B debugging aid)
+bool force_direct() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MMDGAN_FORCE_DIRECT"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+}  // namespace
+
+extern "C" int mmdgan_conv2d_fwd(const mmdgan_conv_geom *g, const float *x, const float *w, const float *bias,
+                                 const float *scale, int act, const float *dact_of, float *y, void *stream) {
+    if (int rc = validate(g, "conv2d_fwd")) return rc;
+    MMDGAN_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
+    MMDGAN_REQUIRE(act >= MMDGAN_ACT_LINEAR && act <= MMDGAN_ACT_TANH, "conv2d_fwd: unknown activation %d", act);
+    const ConvDims d = conv_dims(*g);
+    const ConvEpilogue ep{bias, scale, dact_of, act};
+    if (!force_direct() && igemm_fwd_ok(d)) return igemm_fwd(d, ep, x, w, y, (hipStream_t)stream);
+    return direct_fwd(d, ep, x, w, y, (hipStream_t)stream);
+}
+
+extern "C" int mmdgan_conv2d_dgrad(const mmdgan_conv_geom *g, const float *dy, const float *w, const float *bias,
+                                   const float *scale, int act, const float *dact_of, float *dx, void *stream) {
+    if (int rc = validate(g, "conv2d_dgrad")) return rc;
+    MMDGAN_REQUIRE(dy && w && dx, "conv2d_dgrad: null pointer");
+    MMDGAN_REQUIRE(act >= MMDGAN_ACT_LINEAR && act <= MMDGAN_ACT_TANH, "conv2d_dgrad: unknown activation %d", act);
+    const ConvDims d = conv_dims(*g);
+    const ConvEpilogue ep{bias, scale, dact_of, act};
+    if (!force_direct() && igemm_dgrad_ok(d)) return igemm_dgrad(d, ep, dy, w, dx, (hipStream_t)stream);
+    return direct_dgrad(d, ep, dy, w, dx, (hipStream_t)stream);
+}
+
+extern "C" int mmdgan_conv2d_wgrad(const mmdgan_conv_geom *g, const float *x, const float *dy, float *dw, void *stream) {
+    if (int rc = validate(g, "conv2d_wgrad")) return rc;
+    MMDGAN_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
+    const ConvDims d = conv_dims(*g);
+    if (!force_direct() && igemm_wgrad_ok(d)) return igemm_wgrad(d, x, dy, dw, (hipStream_t)stream);
+    return direct_wgrad(d, x, dy, dw, (hipStream_t)stream);
+}

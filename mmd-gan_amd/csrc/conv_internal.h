@@ -1,0 +1,30 @@
+// internal declarations shared by the convolution translation units
+#pragma once
+#include "common.h"
+
+namespace mmdgan {
+
+// epilogue shared by every conv/dgrad kernel: forward form act(v + bias) or backward form
+// (v + bias) * act'(dact[o]);  v arrives already multiplied by the SN scale.
+struct ConvEpilogue {
+    const float *bias, *scale, *dact;
+    int act;
+    __device__ __forceinline__ float apply(float v, int ch, long o) const {
+        if (bias) v += bias[ch];
+        return dact ? v * act_bwd_from_out(dact[o], act) : act_fwd(v, act);
+    }
+};
+
+int direct_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, float *y, hipStream_t st);
+int direct_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, float *dx, hipStream_t st);
+int direct_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st);
+
+// MFMA implicit-GEMM path (conv_igemm.hip); *_ok() say whether a geometry is eligible
+bool igemm_fwd_ok(const ConvDims &d);
+bool igemm_dgrad_ok(const ConvDims &d);
+bool igemm_wgrad_ok(const ConvDims &d);
+int igemm_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, float *y, hipStream_t st);
+int igemm_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, float *dx, hipStream_t st);
+int igemm_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st);
+
+}  // namespace mmdgan

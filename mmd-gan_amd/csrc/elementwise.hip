@@ -1,0 +1,198 @@
+// HBM-bound helpers: column sums, dot, spectral-norm norm/scale/fix-up steps, TF-Adam, layout seam.
+// All are streaming kernels: float4 accesses where the layout allows, grid-stride loops capped at
+// ~2048 blocks, double accumulation for reductions.
+#include "common.h"
+
+namespace mmdgan {
+
+// ---------------------------------------------------------------------------------------------
+// out[c] += sum over a row chunk of x[r,c]; out is zeroed by a memset node first.
+// block = 64 columns x 4 row lanes.
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, long rows, int cols,
+                                                     long rows_per_block, float *out) {
+    __shared__ double red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    double acc = 0;
+    if (c < cols)
+        for (long r = r0 + rl; r < r1; r += 4) acc += (double)x[r * cols + c];
+    red[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        double t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        atomicAdd(out + c, (float)t);
+    }
+}
+
+__global__ __launch_bounds__(256) void dot_kernel(const float *__restrict__ a, const float *__restrict__ b, long n,
+                                                  float *out) {
+    __shared__ double red[4];
+    double acc = 0;
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) acc += (double)a[i] * (double)b[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (float)(red[0] + red[1] + red[2] + red[3]));
+}
+
+// ---------------------------------------------------------------------------------------------
+// ||v||_2 and v/(||v||+1e-10) in ONE block (SN vectors are <= 64K elements): deterministic, no
+// inter-block traffic.  math_func.py:651,659.
+__global__ __launch_bounds__(1024) void sn_norm_kernel(const float *__restrict__ v, long n, float *out_norm,
+                                                       float *vn) {
+    __shared__ double red[16];
+    __shared__ float s_norm;
+    double acc = 0;
+    for (long i = threadIdx.x; i < n; i += 1024) acc += (double)v[i] * (double)v[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        s_norm = (float)sqrt(t);
+        if (out_norm) out_norm[0] = s_norm;
+    }
+    __syncthreads();
+    if (vn) {
+        const float inv = 1.0f / (s_norm + kEpsi);
+        for (long i = threadIdx.x; i < n; i += 1024) vn[i] = v[i] * inv;
+    }
+}
+
+__global__ void sn_scale_kernel(const float *sigma, float act_k, float *out) { out[0] = act_k / sigma[0]; }
+
+// dw = scale*G - (scale/sigma)*<G,W>*dsigma_dw   
+__global__ __launch_bounds__(256) void sn_fixup_kernel(float *__restrict__ g, const float *__restrict__ ds,
+                                                       const float *dot, const float *sigma, const float *scale,
+                                                       long n) {
+    const float sc = scale[0];
+    const float c2 = sc / sigma[0] * dot[0];
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) g[i] = sc * g[i] - c2 * ds[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// TF-Adam (graph_func.py:525-526 / tf.train.AdamOptimizer): epsilon OUTSIDE the bias correction.
+__global__ __launch_bounds__(256) void adam_kernel(const void *const *ptrs, const long *sizes, float lr_t,
+                                                   float b1, float b2, float eps, float gscale) {
+    const int t = blockIdx.y;
+    const long n = sizes[t];
+    float *p = (float *)ptrs[4 * t];
+    const float *g = (const float *)ptrs[4 * t + 1];
+    float *m = (float *)ptrs[4 * t + 2], *v = (float *)ptrs[4 * t + 3];
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                           int N, int C, int HW) {
+    const long total = (long)N * C * HW;
+    const long stride = (long)gridDim.x * 256;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {   // o indexes dst (NHWC)
+        const int c = o % C;
+        const long t = o / C;
+        const int hw = t % HW;
+        const long n = t / HW;
+        dst[o] = src[(n * C + c) * HW + hw];
+    }
+}
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                           int N, int C, int HW) {
+    const long total = (long)N * C * HW;
+    const long stride = (long)gridDim.x * 256;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {   // o indexes dst (NCHW)
+        const int hw = o % HW;
+        const long t = o / HW;
+        const int c = t % C;
+        const long n = t / C;
+        dst[o] = src[(n * HW + hw) * C + c];
+    }
+}
+
+static inline int grid_for(long n, int per_block = 256, int cap = 2048) {
+    long b = (n + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+}  // namespace mmdgan
+
+using namespace mmdgan;
+
+extern "C" int mmdgan_colsum(const float *x, long rows, int cols, float *out, void *stream) {
+    MMDGAN_REQUIRE(x && out && rows >= 1 && cols >= 1, "colsum: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, sizeof(float) * cols, st) != hipSuccess) return check_launch("colsum memset");
+    const int cblocks = (cols + 63) / 64;
+    long splits = 1024 / cblocks;
+    if (splits < 1) splits = 1;
+    long rpb = (rows + splits - 1) / splits;
+    if (rpb < 16) rpb = 16;
+    splits = (rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(colsum_kernel, dim3(cblocks, (unsigned)splits), dim3(256), 0, st, x, rows, cols, rpb, out);
+    return check_launch("colsum");
+}
+
+extern "C" int mmdgan_dot(const float *a, const float *b, long n, float *out, void *stream) {
+    MMDGAN_REQUIRE(a && b && out && n >= 1, "dot: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) return check_launch("dot memset");
+    hipLaunchKernelGGL(dot_kernel, dim3(grid_for(n, 1024, 1024)), dim3(256), 0, st, a, b, n, out);
+    return check_launch("dot");
+}
+
+extern "C" int mmdgan_sn_norm(const float *v, long n, float *out_norm, float *v_normalised, void *stream) {
+    MMDGAN_REQUIRE(v && n >= 1 && (out_norm || v_normalised), "sn_norm: bad arguments");
+    hipLaunchKernelGGL(sn_norm_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, v, n, out_norm, v_normalised);
+    return check_launch("sn_norm");
+}
+
+extern "C" int mmdgan_sn_scale(const float *sigma, float act_k, float *scale_out, void *stream) {
+    MMDGAN_REQUIRE(sigma && scale_out, "sn_scale: null pointer");
+    hipLaunchKernelGGL(sn_scale_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sigma, act_k, scale_out);
+    return check_launch("sn_scale");
+}
+
+extern "C" int mmdgan_sn_wgrad_fixup(float *g_inout, const float *dsigma_dw, const float *dot, const float *sigma,
+                                     const float *scale, long n, void *stream) {
+    MMDGAN_REQUIRE(g_inout && dsigma_dw && dot && sigma && scale && n >= 1, "sn_wgrad_fixup: bad arguments");
+    hipLaunchKernelGGL(sn_fixup_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g_inout, dsigma_dw, dot,
+                       sigma, scale, n);
+    return check_launch("sn_wgrad_fixup");
+}
+
+extern "C" int mmdgan_adam_multi(const void *const *ptrs, const long *sizes, int n_tensors, long max_size, float lr,
+                                 float beta1, float beta2, float eps, int step, float grad_scale, void *stream) {
+    MMDGAN_REQUIRE(ptrs && sizes && n_tensors >= 1 && max_size >= 1 && step >= 1, "adam_multi: bad arguments");
+    // lr_t in double on the host: lr*sqrt(1-b2^t)/(1-b1^t)
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(max_size, 256, 1024), n_tensors), dim3(256), 0, (hipStream_t)stream,
+                       ptrs, sizes, (float)lr_t, beta1, beta2, eps, grad_scale);
+    return check_launch("adam_multi");
+}
+
+extern "C" int mmdgan_nchw_to_nhwc(const float *src, float *dst, int N, int C, int H, int W, void *stream) {
+    MMDGAN_REQUIRE(src && dst && N >= 1 && C >= 1 && H >= 1 && W >= 1, "nchw_to_nhwc: bad arguments");
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long)N * C * H * W)), dim3(256), 0, (hipStream_t)stream, src,
+                       dst, N, C, H * W);
+    return check_launch("nchw_to_nhwc");
+}
+extern "C" int mmdgan_nhwc_to_nchw(const float *src, float *dst, int N, int C, int H, int W, void *stream) {
+    MMDGAN_REQUIRE(src && dst && N >= 1 && C >= 1 && H >= 1 && W >= 1, "nhwc_to_nchw: bad arguments");
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((long)N * C * H * W)), dim3(256), 0, (hipStream_t)stream, src,
+                       dst, N, C, H * W);
+    return check_launch("nhwc_to_nchw");
+}

@@ -1,0 +1,117 @@
+// Dense layers (tf.matmul, layer_func.py:909-911) and their gradients, plus the dense power
+// iteration of spectral norm (math_func.py:583-602).  These are the skinny GEMMs of the model
+// (G l1: [B,128]x[128,8192]; D l8: [2B,8192]x[8192,16]) - under 0.1 % of the step's FLOPs and
+// bound by streaming the weight matrix once, so this is an LDS-tiled fp32 VALU kernel with
+// split-K for the K >> M*N shapes rather than an MFMA kernel.
+//   C[M,N] = act(scale * op(A) op(B) + bias)           (or * act'(dact_of) in backward form)
+#include "common.h"
+
+namespace mmdgan {
+
+constexpr int GT = 64;   // tile M = N
+constexpr int GK = 16;   // tile K
+
+struct GemmArgs {
+    const float *A, *B, *bias, *scale, *dact;
+    float *C;
+    int M, N, K, lda, ldb, ldc, transA, transB, act, ksplit, kchunk;
+};
+
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    __shared__ float As[GK][GT + 4];
+    __shared__ float Bs[GK][GT + 4];
+    const int tid = threadIdx.x;
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const int kbeg = blockIdx.z * g.kchunk;
+    int kend = kbeg + g.kchunk;
+    if (kend > g.K) kend = g.K;
+    const int tm = (tid >> 4) * 4, tn = (tid & 15) * 4;
+    float acc[4][4] = {};
+    for (int k0 = kbeg; k0 < kend; k0 += GK) {
+        // 64x16 elements per operand = 1024 -> 4 per thread
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + e * 256;
+            {   // A tile: element (m, k)
+                int m, k;
+                if (g.transA) { m = idx & 63; k = idx >> 6; } else { k = idx & 15; m = idx >> 4; }
+                const int gm = m0 + m, gk = k0 + k;
+                float v = 0.f;
+                if (gm < g.M && gk < kend) v = g.transA ? g.A[(size_t)gk * g.lda + gm] : g.A[(size_t)gm * g.lda + gk];
+                As[k][m] = v;
+            }
+            {   // B tile: element (k, n)
+                int n, k;
+                if (g.transB) { k = idx & 15; n = idx >> 4; } else { n = idx & 63; k = idx >> 6; }
+                const int gn = n0 + n, gk = k0 + k;
+                float v = 0.f;
+                if (gn < g.N && gk < kend) v = g.transB ? g.B[(size_t)gn * g.ldb + gk] : g.B[(size_t)gk * g.ldb + gn];
+                Bs[k][n] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < GK; ++k) {
+            const float4 a = *reinterpret_cast<const float4 *>(&As[k][tm]);
+            const float4 b = *reinterpret_cast<const float4 *>(&Bs[k][tn]);
+            const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    const float sc = g.scale ? g.scale[0] : 1.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gm = m0 + tm + i;
+        if (gm >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gn = n0 + tn + j;
+            if (gn >= g.N) continue;
+            const size_t o = (size_t)gm * g.ldc + gn;
+            float v = acc[i][j] * sc;
+            if (g.ksplit > 1) {                       // linear epilogue only: partial sums via atomics
+                if (g.bias && blockIdx.z == 0) v += g.bias[gn];
+                atomicAdd(g.C + o, v);
+            } else {
+                if (g.bias) v += g.bias[gn];
+                g.C[o] = g.dact ? v * act_bwd_from_out(g.dact[o], g.act) : act_fwd(v, g.act);
+            }
+        }
+    }
+}
+
+}  // namespace mmdgan
+
+using namespace mmdgan;
+
+extern "C" int mmdgan_gemm(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
+                           const float *bias, const float *scale, int act, const float *dact_of, float *C, int ldc,
+                           void *stream) {
+    MMDGAN_REQUIRE(A && B && C, "gemm: null pointer");
+    MMDGAN_REQUIRE(M >= 1 && N >= 1 && K >= 1, "gemm: bad shape %dx%dx%d", M, N, K);
+    MMDGAN_REQUIRE(act >= MMDGAN_ACT_LINEAR && act <= MMDGAN_ACT_TANH, "gemm: unknown activation %d", act);
+    hipStream_t st = (hipStream_t)stream;
+    GemmArgs g;
+    g.A = A; g.B = B; g.bias = bias; g.scale = scale; g.dact = dact_of; g.C = C;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.transA = transA; g.transB = transB; g.act = act;
+    const int tiles = ((M + GT - 1) / GT) * ((N + GT - 1) / GT);
+    int ksplit = 1;
+    if (act == MMDGAN_ACT_LINEAR && !dact_of && tiles < 128 && K >= 512 && ldc == N) {
+        ksplit = 256 / tiles;
+        const int maxs = K / 128;
+        if (ksplit > maxs) ksplit = maxs;
+        if (ksplit < 1) ksplit = 1;
+    }
+    int kchunk = (K + ksplit - 1) / ksplit;
+    kchunk = (kchunk + GK - 1) / GK * GK;
+    ksplit = (K + kchunk - 1) / kchunk;
+    g.ksplit = ksplit; g.kchunk = kchunk;
+    if (ksplit > 1 && hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, st) != hipSuccess)
+        return check_launch("gemm memset");
+    hipLaunchKernelGGL(gemm_kernel, dim3((N + GT - 1) / GT, (M + GT - 1) / GT, ksplit), dim3(256), 0, st, g);
+    return check_launch("gemm");
+}

@@ -1,0 +1,261 @@
+// Fused pairwise squared distance + Gaussian kernel + repulsive / bounded MMD loss, forward and
+// backward, for gfx950.  One launch; the three B x B matrices live only in registers.
+//
+// Replaces (reference, /root/reference/GeneralTools/math_func.py):
+//   get_squared_dist  :799-840  (Gram form: d_i - 2 <a_i,b_j> + d_j, diag taken from the Gram
+//                                matrix, clamped at 0 - reproduced literally so that the rmb clamp
+//                                masks are bit-identical)
+//   matrix_mean_wo_diagonal :1064, mmd_g :1312-1343, mmd_g_bounded :1380-1422,
+//   GANLoss._repulsive_mmd_g_ / _bounded_ :2505-2550, and TF autodiff of all of it.
+//
+// Mapping (wave = 64 lanes): one wave owns one row i; lane l owns column j = tile*64 + l.  A block
+// (4 waves = 4 rows) stages a 64-row tile of s_gen and s_x in LDS (row stride d+1: conflict-free
+// when every lane walks its own row), each wave evaluates the four distances
+// (x_i,x_j) (x_i,y_j) (y_i,x_j) (y_i,y_j) with k-ordered fmaf chains, exponentiates, accumulates
+// the kernel sums in double and the four gradient rows in 64 float accumulators per lane, then
+// reduce-scatters them over the wave with 63 __shfl_xor steps (lane l ends up owning gradient
+// element l).  This is O(B^2 d) VALU work on O(B d) bytes: not GEMM-shaped, no MFMA.
+// Per-block partial sums go to the workspace; the last block to arrive (agent-scope release /
+// acquire, placement independent) reduces them in block order and writes the 8 output scalars.
+#include "common.h"
+
+namespace mmdgan {
+
+constexpr int kMmdRows = 4;     // rows (waves) per block
+constexpr int kMmdTile = 64;    // columns per tile = one per lane
+constexpr int kMmdMaxD = 256;   // LDS: 2 * 64 * (d+1) * 4 B <= 131 KB
+constexpr int kMmdKC = 16;      // gradient k-chunk (64 accumulators = 4 vectors x 16)
+constexpr int kNumSums = 5;     // kxx kxy kyy kxx_b kyy_b
+
+struct MmdArgs {
+    const float *x, *y;   // s_gen, s_x
+    int B, d, loss_type;
+    float w0, w1, lb, ub;
+    double *partials;     // [gridDim.x][kNumSums]
+    unsigned *counter;
+    float *out, *grads, *dist;
+    unsigned char *masks;
+};
+
+__device__ __forceinline__ float dotk(const float *a, const float *b, int d) {
+    float acc = 0.f;
+    for (int k = 0; k < d; ++k) acc = fmaf(a[k], b[k], acc);
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void mmd_kernel(MmdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int d = a.d, ld = d + 1;
+    float *tx = smem;                       // [64][ld]
+    float *ty = tx + kMmdTile * ld;         // [64][ld]
+    float *rx = ty + kMmdTile * ld;         // [4][d]   this block's rows of s_gen
+    float *ry = rx + kMmdRows * d;          // [4][d]
+    // 2*64*(d+1) + 8*d floats is even, so the double area is 8-byte aligned; the ticket lives in
+    // the dynamic region too (a static __shared__ would shift the dynamic base off alignment)
+    double *bsum = reinterpret_cast<double *>(ry + kMmdRows * d);
+    unsigned &s_ticket = *reinterpret_cast<unsigned *>(bsum + kMmdRows * kNumSums);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = a.B;
+    const int i = blockIdx.x * kMmdRows + wave;
+    const bool row_ok = i < B;
+
+    for (int t = tid; t < kMmdRows * d; t += 256) {
+        int r = t / d, k = t - r * d, gi = blockIdx.x * kMmdRows + r;
+        rx[t] = gi < B ? a.x[(size_t)gi * d + k] : 0.f;
+        ry[t] = gi < B ? a.y[(size_t)gi * d + k] : 0.f;
+    }
+    __syncthreads();
+    const float *xi = rx + wave * d, *yi = ry + wave * d;
+    const float nxi = dotk(xi, xi, d), nyi = dotk(yi, yi, d);     // diag_part of the Gram matrices
+
+    const float m = (float)B;
+    const float inv = 1.0f / (m * (m - 1.0f));
+    const bool rmb = a.loss_type == MMDGAN_LOSS_RMB;
+    const bool yy_lower = a.w1 > 0.f;                             // math_func.py:1391-1394
+    // coefficients of e(K_xx), e(K_xy), e(K_yy): loss_gen = (1,-2,1); loss_dis = (-1, w0, -w1)
+    const float cg_xx = 1.f, cg_xy = -2.f, cg_yy = 1.f;
+    const float cd_xx = -1.f, cd_xy = a.w0, cd_yy = -a.w1;
+
+    double s_xx = 0, s_xy = 0, s_yy = 0, s_xxb = 0, s_yyb = 0;
+    const int ntiles = (B + kMmdTile - 1) / kMmdTile;
+    const int nchunks = a.grads ? (d + kMmdKC - 1) / kMmdKC : 1;
+
+    for (int kc = 0; kc < nchunks; ++kc) {
+        float acc[64];
+#pragma unroll
+        for (int t = 0; t < 64; ++t) acc[t] = 0.f;
+        const int k0 = kc * kMmdKC;
+
+        for (int jt = 0; jt < ntiles; ++jt) {
+            __syncthreads();
+            for (int t = tid; t < kMmdTile * d; t += 256) {
+                int r = t / d, k = t - r * d, gj = jt * kMmdTile + r;
+                tx[r * ld + k] = gj < B ? a.x[(size_t)gj * d + k] : 0.f;
+                ty[r * ld + k] = gj < B ? a.y[(size_t)gj * d + k] : 0.f;
+            }
+            __syncthreads();
+            const int j = jt * kMmdTile + lane;
+            const float *xj = tx + lane * ld, *yj = ty + lane * ld;
+            const bool valid = row_ok && j < B;
+            const bool off = valid && j != i;
+
+            const float nxj = dotk(xj, xj, d), nyj = dotk(yj, yj, d);
+            const float g_xx = dotk(xi, xj, d), g_xy = dotk(xi, yj, d);
+            const float g_yx = dotk(xj, yi, d), g_yy = dotk(yi, yj, d);
+            // math_func.py:805,833-834: max(d_i - 2*gram + d_j, 0)
+            const float r_xx = (nxi - 2.0f * g_xx) + nxj, r_xy = (nxi - 2.0f * g_xy) + nyj;
+            const float r_yx = (nxj - 2.0f * g_yx) + nyi, r_yy = (nyi - 2.0f * g_yy) + nyj;
+            const float D_xx = fmaxf(r_xx, 0.f), D_xy = fmaxf(r_xy, 0.f);
+            const float D_yx = fmaxf(r_yx, 0.f), D_yy = fmaxf(r_yy, 0.f);
+            const float K_xx = expf(-D_xx / 2.0f), K_xy = expf(-D_xy / 2.0f);
+            const float K_yx = expf(-D_yx / 2.0f), K_yy = expf(-D_yy / 2.0f);
+
+            if (kc == 0) {
+                if (off) {
+                    s_xx += (double)K_xx; s_xy += (double)K_xy; s_yy += (double)K_yy;
+                    if (rmb) {
+                        s_xxb += (double)expf(-fmaxf(D_xx, a.lb) / 2.0f);                        // :1386
+                        s_yyb += (double)(yy_lower ? expf(-fmaxf(D_yy, a.lb) / 2.0f)
+                                                   : expf(-fminf(D_yy, a.ub) / 2.0f));          // :1391-1394
+                    }
+                }
+                if (valid) {
+                    const size_t n2 = (size_t)B * B, o = (size_t)i * B + j;
+                    if (a.dist) { a.dist[o] = D_xx; a.dist[n2 + o] = D_xy; a.dist[2 * n2 + o] = D_yy; }
+                    if (a.masks) {
+                        a.masks[o] = D_xx < a.lb; a.masks[n2 + o] = D_xy > a.ub; a.masks[2 * n2 + o] = D_yy > a.ub;
+                    }
+                }
+            }
+            if (a.grads) {
+                // dK/dD = -K/2; max(.,0) passes the gradient where the raw value is positive;
+                // clamp-active entries of the bounded loss pass none
+                const float p_xx = (off && r_xx > 0.f) ? 1.f : 0.f, p_xy = (off && r_xy > 0.f) ? 1.f : 0.f;
+                const float p_yx = (off && r_yx > 0.f) ? 1.f : 0.f, p_yy = (off && r_yy > 0.f) ? 1.f : 0.f;
+                float b_xx = p_xx, b_yy = p_yy;
+                if (rmb) {
+                    b_xx = (D_xx > a.lb) ? p_xx : 0.f;
+                    b_yy = (yy_lower ? (D_yy > a.lb) : (D_yy < a.ub)) ? p_yy : 0.f;
+                }
+                const float Ag = -2.f * cg_xx * inv * K_xx * p_xx, Bg = -cg_xy * inv * K_xy * p_xy;
+                const float Cg = -2.f * cg_yy * inv * K_yy * p_yy, Eg = -cg_xy * inv * K_yx * p_yx;
+                const float Ad = -2.f * cd_xx * inv * K_xx * b_xx, Bd = -cd_xy * inv * K_xy * p_xy;
+                const float Cd = -2.f * cd_yy * inv * K_yy * b_yy, Ed = -cd_xy * inv * K_yx * p_yx;
+#pragma unroll
+                for (int k = 0; k < kMmdKC; ++k) {
+                    if (k0 + k < d) {
+                        const float xik = xi[k0 + k], yik = yi[k0 + k], xjk = xj[k0 + k], yjk = yj[k0 + k];
+                        const float dxx = xik - xjk, dxy = xik - yjk, dyy = yik - yjk, dyx = yik - xjk;
+                        acc[k] += Ag * dxx + Bg * dxy;           // dLgen/dx_i
+                        acc[16 + k] += Cg * dyy + Eg * dyx;      // dLgen/dy_i
+                        acc[32 + k] += Ad * dxx + Bd * dxy;      // dLdis/dx_i
+                        acc[48 + k] += Cd * dyy + Ed * dyx;      // dLdis/dy_i
+                    }
+                }
+            }
+        }
+        if (a.grads) {
+            // reduce-scatter over the wave: after the step with distance h, a lane whose bit h is
+            // set keeps the upper half of the live accumulators; lane l ends owning element l.
+#pragma unroll
+            for (int h = 32; h > 0; h >>= 1) {
+                const bool up = (lane & h) != 0;
+#pragma unroll
+                for (int t = 0; t < h; ++t) {
+                    const float keep = up ? acc[t + h] : acc[t];
+                    const float send = up ? acc[t] : acc[t + h];
+                    acc[t] = keep + __shfl_xor(send, h, 64);
+                }
+            }
+            const int vec = lane >> 4, k = k0 + (lane & 15);
+            if (row_ok && k < d) a.grads[((size_t)vec * B + i) * d + k] = acc[0];
+        }
+    }
+
+    // ---- kernel-sum reduction: wave -> block -> grid (last block finalises) -------------------
+    double sums[kNumSums] = {s_xx, s_xy, s_yy, s_xxb, s_yyb};
+#pragma unroll
+    for (int q = 0; q < kNumSums; ++q) sums[q] = wave_sum(sums[q]);
+    __syncthreads();
+    if (lane == 0)
+        for (int q = 0; q < kNumSums; ++q) bsum[wave * kNumSums + q] = sums[q];
+    __syncthreads();
+    if (tid == 0) {
+        for (int q = 0; q < kNumSums; ++q) {
+            double t = 0;
+            for (int w = 0; w < kMmdRows; ++w) t += bsum[w * kNumSums + q];
+            a.partials[(size_t)blockIdx.x * kNumSums + q] = t;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_ticket = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (s_ticket != gridDim.x - 1) return;
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    if (wave == 0) {
+        double tot[kNumSums];
+#pragma unroll
+        for (int q = 0; q < kNumSums; ++q) {
+            double t = 0;
+            for (int b = lane; b < (int)gridDim.x; b += 64) t += a.partials[(size_t)b * kNumSums + q];
+            tot[q] = wave_sum(t);
+        }
+        if (lane == 0) {
+            const double denom = (double)B * ((double)B - 1.0);
+            const double e_xx = tot[0] / denom, e_xy = tot[1] / denom, e_yy = tot[2] / denom;
+            const double e_xxb = rmb ? tot[3] / denom : e_xx, e_yyb = rmb ? tot[4] / denom : e_yy;
+            // math_func.py:1341-1342,1421; e_kxy_b == e_kxy for every admissible weight pair (:1402)
+            a.out[0] = (float)(e_xx + e_yy - 2.0 * e_xy);
+            a.out[1] = (float)((double)a.w0 * e_xy - e_xxb - (double)a.w1 * e_yyb);
+            a.out[2] = (float)e_xx; a.out[3] = (float)e_xy; a.out[4] = (float)e_yy;
+            a.out[5] = (float)e_xxb; a.out[6] = (float)e_yyb; a.out[7] = 0.f;
+            __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+static size_t mmd_lds_bytes(int d) {
+    size_t fl = 2 * (size_t)kMmdTile * (d + 1) + 2 * (size_t)kMmdRows * d;       // always even
+    return fl * sizeof(float) + (kMmdRows * kNumSums + 1) * sizeof(double);
+}
+
+}  // namespace mmdgan
+
+using namespace mmdgan;
+
+extern "C" size_t mmdgan_mmd_workspace_bytes(int B, int d) {
+    (void)d;
+    if (B < 1) return 0;
+    size_t blocks = ((size_t)B + kMmdRows - 1) / kMmdRows;
+    return 64 + blocks * kNumSums * sizeof(double);    // [counter | pad][partials]
+}
+
+extern "C" int mmdgan_mmd_loss(const float *s_gen, const float *s_x, int B, int d, int loss_type, float w0, float w1,
+                               float lower_bound, float upper_bound, float *out_scalars, float *grads,
+                               unsigned char *masks, float *dist, void *workspace, void *stream) {
+    MMDGAN_REQUIRE(s_gen && s_x && out_scalars && workspace, "mmd_loss: null pointer");
+    MMDGAN_REQUIRE(B >= 2, "mmd_loss: batch_size must be >= 2 (got %d)", B);
+    MMDGAN_REQUIRE(d >= 1 && d <= kMmdMaxD, "mmd_loss: d must be in [1,%d] (got %d)", kMmdMaxD, d);
+    MMDGAN_REQUIRE(loss_type == MMDGAN_LOSS_REP || loss_type == MMDGAN_LOSS_RMB, "mmd_loss: unknown loss %d", loss_type);
+    MMDGAN_REQUIRE(w0 - w1 == 1.0f, "w[0]-w[1] must be 1");       // math_func.py:1340
+    hipStream_t st = (hipStream_t)stream;
+    MmdArgs a;
+    a.x = s_gen; a.y = s_x; a.B = B; a.d = d; a.loss_type = loss_type;
+    a.w0 = w0; a.w1 = w1; a.lb = lower_bound; a.ub = upper_bound;
+    a.counter = (unsigned *)workspace;
+    a.partials = (double *)((char *)workspace + 64);
+    a.out = out_scalars; a.grads = grads; a.masks = masks; a.dist = dist;
+    if (hipMemsetAsync(a.counter, 0, 64, st) != hipSuccess) return check_launch("mmd_loss memset");
+    const int blocks = (B + kMmdRows - 1) / kMmdRows;
+    const size_t lds = mmd_lds_bytes(d);
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void *)mmd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(mmd_kernel, dim3(blocks), dim3(256), lds, st, a);
+    return check_launch("mmd_loss");
+}

@@ -1,0 +1,72 @@
+"""ctypes loader for mmd-gan_amd/lib/libmmdgan_hip.so (include/mmdgan_hip.h)."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libmmdgan_hip.so')
+
+c_fp = ctypes.c_void_p      # device pointers travel as integers (tensor.data_ptr())
+
+
+class ConvGeom(ctypes.Structure):
+    _fields_ = [('N', ctypes.c_int), ('H', ctypes.c_int), ('W', ctypes.c_int), ('C', ctypes.c_int),
+                ('K', ctypes.c_int), ('R', ctypes.c_int), ('stride', ctypes.c_int)]
+
+
+# name -> (restype, argtypes); must list every symbol include/mmdgan_hip.h declares
+_I, _L, _F, _P = ctypes.c_int, ctypes.c_long, ctypes.c_float, c_fp
+_G = ctypes.POINTER(ConvGeom)
+SIGNATURES = {
+    'mmdgan_last_error': (ctypes.c_char_p, []),
+    'mmdgan_version': (_I, []),
+    'mmdgan_device_ok': (_I, []),
+    'mmdgan_conv2d_fwd': (_I, [_G, _P, _P, _P, _P, _I, _P, _P, _P]),
+    'mmdgan_conv2d_dgrad': (_I, [_G, _P, _P, _P, _P, _I, _P, _P, _P]),
+    'mmdgan_conv2d_wgrad': (_I, [_G, _P, _P, _P, _P]),
+    'mmdgan_gemm': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P]),
+    'mmdgan_colsum': (_I, [_P, _L, _I, _P, _P]),
+    'mmdgan_dot': (_I, [_P, _P, _L, _P, _P]),
+    'mmdgan_bn_workspace_bytes': (ctypes.c_size_t, [_I]),
+    'mmdgan_bn_fwd_train': (_I, [_P, _L, _I, _P, _P, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'mmdgan_bn_fwd_infer': (_I, [_P, _L, _I, _P, _P, _F, _I, _P, _P, _P, _P]),
+    'mmdgan_bn_bwd': (_I, [_P, _P, _P, _L, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    'mmdgan_sn_norm': (_I, [_P, _L, _P, _P, _P]),
+    'mmdgan_sn_scale': (_I, [_P, _F, _P, _P]),
+    'mmdgan_sn_wgrad_fixup': (_I, [_P, _P, _P, _P, _P, _L, _P]),
+    'mmdgan_mmd_workspace_bytes': (ctypes.c_size_t, [_I, _I]),
+    'mmdgan_mmd_loss': (_I, [_P, _P, _I, _I, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P]),
+    'mmdgan_adam_multi': (_I, [_P, _P, _I, _L, _F, _F, _F, _F, _I, _F, _P]),
+    'mmdgan_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    'mmdgan_nhwc_to_nchw': (_I, [_P, _P, _I, _I, _I, _I, _P]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """load the library or raise loudly - there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            'libmmdgan_hip.so is missing at %s - build it with `python mmd-gan_amd/build_ext.py` '
+            '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)        # AttributeError if the .so lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().mmdgan_last_error().decode()
+        if rc == -1:
+            raise ValueError('%s: %s' % (what, msg))
+        raise HipLibraryError('%s failed (rc=%d): %s' % (what, rc, msg))

@@ -1,0 +1,262 @@
+"""Thin torch-tensor wrappers over the C ABI (include/mmdgan_hip.h).
+
+torch is plumbing here: it owns device memory and the stream; every function below launches a
+hand-written HIP kernel through ctypes and fails loudly if the library or a gfx950 device is
+missing.  Activations are NHWC fp32 tensors, kernels are in the reference's HWIO layout.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvGeom, check
+
+ACT = {'linear': 0, 'relu': 1, 'lrelu': 2, 'tanh': 3}
+LOSS = {'rep': 0, 'rep_mmd_g': 0, 'rmb': 1, 'rep_b': 1, 'rep_mmd_b': 1}
+
+_device_checked = False
+
+
+def require_device():
+    """the HIP path is the only path: no device or no library is an error, never a fallback."""
+    global _device_checked
+    lib = _lib.load()
+    if not _device_checked:
+        if not torch.cuda.is_available() or lib.mmdgan_device_ok() != 1:
+            raise _lib.HipLibraryError('no gfx950 (MI355X) device visible: the HIP path cannot run and there is no '
+                                       'CPU fallback')
+        _device_checked = True
+    return lib
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), 'expected a contiguous fp32 CUDA tensor'
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def act_id(name):
+    if name not in ACT:
+        raise NotImplementedError('Function {} is not implemented.'.format(name))   # layer_func.py:149
+    return ACT[name]
+
+
+def geom(N, H, W, C, K, R, stride):
+    return ConvGeom(N, H, W, C, K, R, stride)
+
+
+def out_hw(H, W, stride):
+    return -(-H // stride), -(-W // stride)
+
+
+# ------------------------------------------------------------------------------------------------
+def conv2d_fwd(x, w, stride, bias=None, scale=None, act='linear', dact_of=None, out=None):
+    """x [N,H,W,C], w [R,R,C,K] -> y [N,P,Q,K] = act(scale*conv(x,w)+bias) (layer_func.py:913-916)"""
+    lib = require_device()
+    N, H, W, C = x.shape
+    R, K = w.shape[0], w.shape[3]
+    assert w.shape[2] == C
+    P, Q = out_hw(H, W, stride)
+    y = out if out is not None else torch.empty((N, P, Q, K), device=x.device, dtype=torch.float32)
+    g = geom(N, H, W, C, K, R, stride)
+    check(lib.mmdgan_conv2d_fwd(ctypes.byref(g), _p(x), _p(w), _p(bias), _p(scale), act_id(act), _p(dact_of), _p(y),
+                                _stream()), 'conv2d_fwd')
+    return y
+
+
+def conv2d_dgrad(dy, w, in_hw, stride, bias=None, scale=None, act='linear', dact_of=None, out=None):
+    """dy [N,P,Q,K], w [R,R,C,K] -> dx [N,H,W,C]; forward form = tf.nn.conv2d_transpose (layer_func.py:926)"""
+    lib = require_device()
+    N, P, Q, K = dy.shape
+    R, C = w.shape[0], w.shape[2]
+    assert w.shape[3] == K
+    H, W = in_hw
+    assert out_hw(H, W, stride) == (P, Q)
+    dx = out if out is not None else torch.empty((N, H, W, C), device=dy.device, dtype=torch.float32)
+    g = geom(N, H, W, C, K, R, stride)
+    check(lib.mmdgan_conv2d_dgrad(ctypes.byref(g), _p(dy), _p(w), _p(bias), _p(scale), act_id(act), _p(dact_of), _p(dx),
+                                  _stream()), 'conv2d_dgrad')
+    return dx
+
+
+def conv2d_wgrad(x, dy, R, stride, out=None):
+    """x [N,H,W,C], dy [N,P,Q,K] -> dw [R,R,C,K]"""
+    lib = require_device()
+    N, H, W, C = x.shape
+    K = dy.shape[3]
+    dw = out if out is not None else torch.empty((R, R, C, K), device=x.device, dtype=torch.float32)
+    g = geom(N, H, W, C, K, R, stride)
+    check(lib.mmdgan_conv2d_wgrad(ctypes.byref(g), _p(x), _p(dy), _p(dw), _stream()), 'conv2d_wgrad')
+    return dw
+
+
+def gemm(a, b, trans_a=False, trans_b=False, bias=None, scale=None, act='linear', dact_of=None, out=None):
+    """C = act(scale * op(a) op(b) + bias), row-major 2-D tensors (tf.matmul, layer_func.py:911)"""
+    lib = require_device()
+    M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    K2, N = (b.shape[1], b.shape[0]) if trans_b else b.shape
+    assert K == K2, (a.shape, b.shape, trans_a, trans_b)
+    c = out if out is not None else torch.empty((M, N), device=a.device, dtype=torch.float32)
+    check(lib.mmdgan_gemm(int(trans_a), int(trans_b), M, N, K, _p(a), a.shape[1], _p(b), b.shape[1], _p(bias), _p(scale),
+                          act_id(act), _p(dact_of), _p(c), N, _stream()), 'gemm')
+    return c
+
+
+def colsum(x2d, out=None):
+    lib = require_device()
+    rows, cols = x2d.shape
+    o = out if out is not None else torch.empty(cols, device=x2d.device, dtype=torch.float32)
+    check(lib.mmdgan_colsum(_p(x2d), rows, cols, _p(o), _stream()), 'colsum')
+    return o
+
+
+def dot(a, b, out=None):
+    lib = require_device()
+    o = out if out is not None else torch.empty(1, device=a.device, dtype=torch.float32)
+    check(lib.mmdgan_dot(_p(a), _p(b), a.numel(), _p(o), _stream()), 'dot')
+    return o
+
+
+# ------------------------------------------------------------------------------------------------
+_bn_ws = {}
+
+
+def _bn_workspace(C, device):
+    key = (C, device)
+    if key not in _bn_ws:
+        n = _lib.load().mmdgan_bn_workspace_bytes(C)
+        _bn_ws[key] = torch.empty(n, device=device, dtype=torch.uint8)
+    return _bn_ws[key]
+
+
+def bn_fwd_train(x2d, gamma, beta, moving_mean, moving_var, act='linear', eps=1e-3, momentum=0.99, unbiased=True,
+                 new_moving_mean=None, new_moving_var=None):
+    """x2d [rows, C].  Returns (y, save_mean, save_invstd, new_moving_mean, new_moving_var)."""
+    lib = require_device()
+    rows, C = x2d.shape
+    y = torch.empty_like(x2d)
+    mean = torch.empty(C, device=x2d.device, dtype=torch.float32)
+    invstd = torch.empty_like(mean)
+    nmm = new_moving_mean if new_moving_mean is not None else torch.empty_like(mean)
+    nmv = new_moving_var if new_moving_var is not None else torch.empty_like(mean)
+    ws = _bn_workspace(C, x2d.device)
+    check(lib.mmdgan_bn_fwd_train(_p(x2d), rows, C, _p(gamma), _p(beta), eps, momentum, int(unbiased), act_id(act), _p(y),
+                                  _p(mean), _p(invstd), _p(moving_mean), _p(moving_var), _p(nmm), _p(nmv),
+                                  ws.data_ptr(), _stream()), 'bn_fwd_train')
+    return y, mean, invstd, nmm, nmv
+
+
+def bn_fwd_infer(x2d, gamma, beta, moving_mean, moving_var, act='linear', eps=1e-3):
+    lib = require_device()
+    rows, C = x2d.shape
+    y = torch.empty_like(x2d)
+    check(lib.mmdgan_bn_fwd_infer(_p(x2d), rows, C, _p(gamma), _p(beta), eps, act_id(act), _p(moving_mean),
+                                  _p(moving_var), _p(y), _stream()), 'bn_fwd_infer')
+    return y
+
+
+def bn_bwd(x2d, y2d, dy2d, gamma, save_mean, save_invstd, act='linear', dgamma=None, dbeta=None):
+    lib = require_device()
+    rows, C = x2d.shape
+    dx = torch.empty_like(x2d)
+    dgamma = dgamma if dgamma is not None else torch.empty(C, device=x2d.device, dtype=torch.float32)
+    dbeta = dbeta if dbeta is not None else torch.empty(C, device=x2d.device, dtype=torch.float32)
+    ws = _bn_workspace(C, x2d.device)
+    check(lib.mmdgan_bn_bwd(_p(x2d), _p(y2d), _p(dy2d), rows, C, _p(gamma), _p(save_mean), _p(save_invstd), act_id(act),
+                            _p(dx), _p(dgamma), _p(dbeta), ws.data_ptr(), _stream()), 'bn_bwd')
+    return dx, dgamma, dbeta
+
+
+# ------------------------------------------------------------------------------------------------
+def sn_norm(v, normalise=True, out_norm=None, out_v=None):
+    lib = require_device()
+    norm = out_norm if out_norm is not None else torch.empty(1, device=v.device, dtype=torch.float32)
+    vn = (out_v if out_v is not None else torch.empty_like(v)) if normalise else None
+    check(lib.mmdgan_sn_norm(_p(v), v.numel(), _p(norm), _p(vn), _stream()), 'sn_norm')
+    return norm, vn
+
+
+def sn_scale(sigma, act_k, out=None):
+    lib = require_device()
+    o = out if out is not None else torch.empty(1, device=sigma.device, dtype=torch.float32)
+    check(lib.mmdgan_sn_scale(_p(sigma), float(act_k), _p(o), _stream()), 'sn_scale')
+    return o
+
+
+def sn_wgrad_fixup(g, dsigma_dw, dot_gw, sigma, scale):
+    lib = require_device()
+    check(lib.mmdgan_sn_wgrad_fixup(_p(g), _p(dsigma_dw), _p(dot_gw), _p(sigma), _p(scale), g.numel(), _stream()),
+          'sn_wgrad_fixup')
+    return g
+
+
+# ------------------------------------------------------------------------------------------------
+_mmd_ws = {}
+
+
+def mmd_loss(s_gen, s_x, loss_type='rep', rep_weights=(0.0, -1.0), lower_bound=0.25, upper_bound=4.0,
+             need_grads=True, need_masks=False, need_dist=False):
+    """fused pairwise-distance / Gaussian-kernel / rep|rmb loss (math_func.py:2505-2550).
+    Returns dict(scalars[8] = loss_gen, loss_dis, e_kxx, e_kxy, e_kyy, e_kxx_b, e_kyy_b, 0;
+                 grads[4,B,d], masks[3,B,B] (bool), dist[3,B,B])."""
+    lib = require_device()
+    if loss_type not in LOSS:
+        raise NotImplementedError('Not implemented.')                            # math_func.py:2651
+    B, d = s_gen.shape
+    assert s_x.shape == s_gen.shape
+    dev = s_gen.device
+    key = (B, d, dev)
+    if key not in _mmd_ws:
+        _mmd_ws[key] = torch.zeros(lib.mmdgan_mmd_workspace_bytes(B, d), device=dev, dtype=torch.uint8)
+    out = torch.empty(8, device=dev, dtype=torch.float32)
+    grads = torch.empty((4, B, d), device=dev, dtype=torch.float32) if need_grads else None
+    masks = torch.empty((3, B, B), device=dev, dtype=torch.uint8) if need_masks else None
+    dist = torch.empty((3, B, B), device=dev, dtype=torch.float32) if need_dist else None
+    check(lib.mmdgan_mmd_loss(_p(s_gen), _p(s_x), B, d, LOSS[loss_type], float(rep_weights[0]), float(rep_weights[1]),
+                              float(lower_bound), float(upper_bound), _p(out), _p(grads),
+                              masks.data_ptr() if masks is not None else None, _p(dist), _mmd_ws[key].data_ptr(),
+                              _stream()), 'mmd_loss')
+    return {'scalars': out, 'grads': grads, 'masks': masks.bool() if masks is not None else None, 'dist': dist}
+
+
+# ------------------------------------------------------------------------------------------------
+class AdamGroup:
+    """one flat-arena group for mmdgan_adam_multi: params / grads / m / v are lists of tensors."""
+
+    def __init__(self, params, grads, ms, vs):
+        dev = params[0].device
+        ptrs = []
+        for p, g, m, v in zip(params, grads, ms, vs):
+            ptrs += [_p(p), _p(g), _p(m), _p(v)]
+        self.keep = (params, grads, ms, vs)
+        self.ptrs = torch.tensor(ptrs, dtype=torch.int64, device=dev)
+        self.sizes = torch.tensor([p.numel() for p in params], dtype=torch.int64, device=dev)
+        self.n = len(params)
+        self.max_size = max(p.numel() for p in params)
+
+    def step(self, lr, step, beta1=0.5, beta2=0.999, eps=1e-8, grad_scale=1.0):
+        lib = require_device()
+        check(lib.mmdgan_adam_multi(self.ptrs.data_ptr(), self.sizes.data_ptr(), self.n, self.max_size, float(lr),
+                                    float(beta1), float(beta2), float(eps), int(step), float(grad_scale), _stream()),
+              'adam_multi')
+
+
+def nchw_to_nhwc(x):
+    lib = require_device()
+    N, C, H, W = x.shape
+    y = torch.empty((N, H, W, C), device=x.device, dtype=torch.float32)
+    check(lib.mmdgan_nchw_to_nhwc(_p(x), _p(y), N, C, H, W, _stream()), 'nchw_to_nhwc')
+    return y
+
+
+def nhwc_to_nchw(x):
+    lib = require_device()
+    N, H, W, C = x.shape
+    y = torch.empty((N, C, H, W), device=x.device, dtype=torch.float32)
+    check(lib.mmdgan_nhwc_to_nchw(_p(x), _p(y), N, C, H, W, _stream()), 'nhwc_to_nchw')
+    return y

@@ -1,0 +1,293 @@
+"""GPU parity tests: every C-ABI op against the oracle (oracle/restatement.py, oracle/mmd_oracle.c)
+and against the golden vectors generated from the reference.  The oracle is the checker only."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import RTOL, golden, load, rel_err
+from oracle import c_oracle, restatement as R
+
+pytestmark = pytest.mark.gpu
+
+MMD = golden('mmd_*.npz')
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from mmdgan_hip import ops as o
+    o.require_device()
+    return o
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).cuda()
+
+
+def nhwc(t):          # NCHW torch/np -> NHWC cuda
+    return dev(np.transpose(np.asarray(t), (0, 2, 3, 1)))
+
+
+def to_nchw(t):
+    return np.transpose(t.cpu().numpy(), (0, 3, 1, 2))
+
+
+# ---------------------------------------------------------------------------------------------
+# fused pairwise / MMD loss
+# ---------------------------------------------------------------------------------------------
+def loss_tol(ref64, escale):
+    """north_star: loss within 1e-4 relative.  The losses are differences of kernel means of size
+    `escale`; fp32 inputs/exp leave an absolute floor of a few ulp of escale that no fp32
+    implementation (the reference included) can beat - see test_reference_fp32_noise_floor."""
+    return RTOL * abs(ref64) + 4e-7 * escale
+
+
+@pytest.mark.parametrize('path', MMD, ids=[p.split('/')[-1] for p in MMD])
+def test_mmd_loss_matches_reference_golden(ops, path):
+    fx = load(path)
+    w = tuple(float(v) for v in fx['rep_weights'])
+    out = ops.mmd_loss(dev(fx['s_gen']), dev(fx['s_x']), str(fx['loss_type']), w, need_grads=True, need_masks=True,
+                       need_dist=True)
+    sc = out['scalars'].cpu().numpy().astype(np.float64)
+    escale = max(float(fx['e_kxx_f64']), float(fx['e_kxy_f64']), float(fx['e_kyy_f64']))
+    for idx, name in ((0, 'loss_gen'), (1, 'loss_dis')):
+        ref = float(fx[name + '_f64'])
+        assert abs(sc[idx] - ref) <= loss_tol(ref, escale), (name, sc[idx], ref)
+    for idx, name in ((2, 'e_kxx'), (3, 'e_kxy'), (4, 'e_kyy')):
+        ref = float(fx[name + '_f64'])
+        assert abs(sc[idx] - ref) <= 1e-5 * abs(ref) + 1e-12, (name, sc[idx], ref)
+    g = out['grads'].cpu().numpy()
+    for i, key in enumerate(('dLg_dsgen_f64', 'dLg_dsx_f64', 'dLd_dsgen_f64', 'dLd_dsx_f64')):
+        assert rel_err(g[i], fx[key]) <= RTOL, key
+    # pairwise index masks: bit-exact against the reference's fp32 clamp sets
+    m = out['masks'].cpu().numpy()
+    assert np.array_equal(m[0], fx['mask_gg_lt_lb'])
+    assert np.array_equal(m[1], fx['mask_gd_gt_ub'])
+    assert np.array_equal(m[2], fx['mask_dd_gt_ub'])
+    if 'dist_gg_f64' in fx:
+        d = out['dist'].cpu().numpy()
+        for i, key in enumerate(('dist_gg_f64', 'dist_gd_f64', 'dist_dd_f64')):
+            assert np.max(np.abs(d[i] - fx[key])) <= 1e-5 * max(1.0, np.max(fx[key])), key
+        assert np.all(np.diagonal(d[0]) == 0.0) and np.all(np.diagonal(d[2]) == 0.0)
+
+
+@pytest.mark.parametrize('B,d,loss_type', [(64, 16, 'rep'), (64, 16, 'rmb'), (100, 16, 'rmb'), (257, 7, 'rep'),
+                                           (1024, 16, 'rmb'), (64, 40, 'rep'), (2, 16, 'rep'), (3, 1, 'rmb')])
+def test_mmd_loss_matches_c_oracle(ops, B, d, loss_type):
+    rs = np.random.RandomState(B * 31 + d)
+    s_gen = (rs.randn(B, d) * 0.25).astype(np.float32)
+    s_x = (rs.randn(B, d) * 0.3 + 0.1).astype(np.float32)
+    ref = c_oracle.mmd(s_gen, s_x, loss_type, (0.0, -1.0), dtype=np.float64)
+    out = ops.mmd_loss(dev(s_gen), dev(s_x), loss_type, (0.0, -1.0), need_grads=True)
+    sc = out['scalars'].cpu().numpy().astype(np.float64)
+    escale = float(np.max(ref['stats'][:3]))
+    assert abs(sc[0] - ref['loss_gen']) <= loss_tol(ref['loss_gen'], escale)
+    assert abs(sc[1] - ref['loss_dis']) <= loss_tol(ref['loss_dis'], escale)
+    assert rel_err(sc[2:7], ref['stats']) <= 1e-5
+    g = out['grads'].cpu().numpy()
+    for i in range(4):
+        assert rel_err(g[i], ref['grads'][i]) <= RTOL, i
+
+
+def test_mmd_size_independent_properties(ops):
+    """at the benchmark's full sweep sizes: permutation invariance, x<->y symmetry of loss_gen,
+    zero loss_gen for identical sets, translation invariance."""
+    rs = np.random.RandomState(3)
+    B, d = 4096, 16
+    a = (rs.randn(B, d) * 0.25).astype(np.float32)
+    b = (rs.randn(B, d) * 0.3 + 0.1).astype(np.float32)
+    base = ops.mmd_loss(dev(a), dev(b), 'rep', need_grads=False)['scalars'].cpu().numpy()
+    perm = rs.permutation(B)
+    # the cross block drops pairs (i,i): permuting BOTH sets identically keeps every term
+    p = ops.mmd_loss(dev(a[perm]), dev(b[perm]), 'rep', need_grads=False)['scalars'].cpu().numpy()
+    assert abs(p[0] - base[0]) <= 2e-6 * max(abs(base[0]), 1e-3) + 1e-7
+    sw = ops.mmd_loss(dev(b), dev(a), 'rep', need_grads=False)['scalars'].cpu().numpy()
+    assert abs(sw[0] - base[0]) <= 2e-6 * max(abs(base[0]), 1e-3) + 1e-7       # loss_gen symmetric
+    assert abs(sw[2] - base[4]) <= 1e-6 and abs(sw[4] - base[2]) <= 1e-6       # e_kxx <-> e_kyy
+    same = ops.mmd_loss(dev(a), dev(a), 'rep', need_grads=False)['scalars'].cpu().numpy()
+    # identical sets: e_kxx = e_kyy, e_kxy = the same sum (the dropped diagonal is the same set)
+    assert abs(same[0]) <= 1e-6
+    sh = ops.mmd_loss(dev(a + 0.5), dev(b + 0.5), 'rep', need_grads=False)['scalars'].cpu().numpy()
+    assert abs(sh[0] - base[0]) <= 1e-4 * abs(base[0]) + 1e-6
+
+
+def test_mmd_errors(ops):
+    z = torch.zeros(8, 16).cuda()
+    with pytest.raises(NotImplementedError, match='Not implemented.'):          # math_func.py:2651
+        ops.mmd_loss(z, z, 'hinge')
+    with pytest.raises(ValueError, match=r'w\[0\]-w\[1\] must be 1'):            # math_func.py:1340
+        ops.mmd_loss(z, z, 'rep', rep_weights=(0.5, 0.0))
+    with pytest.raises(ValueError):
+        ops.mmd_loss(z[:1], z[:1], 'rep')
+
+
+# ---------------------------------------------------------------------------------------------
+# convolution family vs the oracle's linear operators
+# ---------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # N, H, W, C, K, R, stride
+    (2, 8, 8, 3, 8, 3, 1), (3, 12, 12, 5, 24, 3, 1), (3, 12, 12, 24, 40, 4, 2), (2, 9, 7, 4, 6, 3, 1),
+    (4, 32, 32, 3, 64, 3, 1),            # D l1
+    (4, 32, 32, 64, 3, 3, 1),            # G l5
+    (4, 32, 32, 64, 128, 4, 2),          # D l2
+    (4, 16, 16, 128, 128, 3, 1),         # D l3
+    (8, 8, 8, 256, 512, 4, 2),           # D l6
+    (8, 4, 4, 512, 512, 3, 1),           # D l7
+    (1, 16, 16, 128, 128, 3, 1),         # SN batch-1
+    (1, 4, 4, 512, 512, 3, 1),
+    (2, 24, 24, 64, 128, 4, 2),          # STL-like
+    (3, 6, 6, 256, 256, 3, 1),
+]
+
+
+def conv_data(case, seed=0):
+    N, H, W, C, K, R, s = case
+    rs = np.random.RandomState(seed)
+    x = rs.uniform(-1, 1, (N, C, H, W)).astype(np.float32)
+    w = (rs.randn(R, R, C, K) / np.sqrt(R * R * C)).astype(np.float32)
+    b = (rs.randn(K) * 0.1).astype(np.float32)
+    return x, w, b
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv2d_fwd(ops, case):
+    N, H, W, C, K, ksz, s = case
+    x, w, b = conv_data(case)
+    sc = np.float32(0.37)
+    for act in ('linear', 'lrelu', 'tanh'):
+        ref = R._act(R.conv2d_same(torch.tensor(x, dtype=torch.float64), torch.tensor(w, dtype=torch.float64), s) * float(sc)
+                     + torch.tensor(b, dtype=torch.float64).reshape(1, -1, 1, 1), act).numpy()
+        y = ops.conv2d_fwd(nhwc(x), dev(w), s, bias=dev(b), scale=dev([sc]), act=act)
+        assert rel_err(to_nchw(y), ref) <= RTOL, act
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv2d_dgrad_and_wgrad(ops, case):
+    N, H, W, C, K, ksz, s = case
+    x, w, _ = conv_data(case, 1)
+    P, Q = -(-H // s), -(-W // s)
+    rs = np.random.RandomState(5)
+    dy = rs.randn(N, K, P, Q).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    yt = R.conv2d_same(xt, wt, s)
+    gx, gw = torch.autograd.grad((yt * torch.tensor(dy, dtype=torch.float64)).sum(), [xt, wt])
+    dx = ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s)
+    assert rel_err(to_nchw(dx), gx.numpy()) <= RTOL
+    dw = ops.conv2d_wgrad(nhwc(x), nhwc(dy), ksz, s)
+    assert rel_err(dw.cpu().numpy(), gw.numpy()) <= RTOL
+    # backward epilogue form: scale * dgrad * lrelu'(y_prev)
+    yprev = rs.randn(N, C, H, W).astype(np.float32)
+    ref = 0.5 * gx.numpy() * np.where(yprev > 0, 1.0, 0.1)
+    dx2 = ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s, scale=dev([0.5]), act='lrelu', dact_of=nhwc(yprev))
+    assert rel_err(to_nchw(dx2), ref) <= RTOL
+
+
+@pytest.mark.parametrize('case', [(4, 4, 4, 512, 256, 4, 2), (3, 8, 8, 256, 128, 4, 2), (2, 16, 16, 128, 64, 4, 2),
+                                  (3, 4, 4, 32, 16, 4, 2), (2, 3, 3, 16, 8, 4, 2)],
+                         ids=lambda c: str(c))
+def test_conv2d_transpose_forward_form(ops, case):
+    """G 'tc' layers (layer_func.py:917-928): tf.nn.conv2d_transpose == dgrad of the conv whose
+    kernel is [R,R,Cout_tc,Cin_tc]."""
+    N, h, w_, cin, cout, R_, s = case
+    rs = np.random.RandomState(11)
+    v = rs.randn(N, cin, h, w_).astype(np.float32)
+    k = (rs.randn(R_, R_, cout, cin) / np.sqrt(R_ * R_ * cin / 4)).astype(np.float32)
+    ref = torch.relu(R.conv2d_transpose_same(torch.tensor(v, dtype=torch.float64), torch.tensor(k, dtype=torch.float64),
+                                             (h * s, w_ * s), s)).numpy()
+    y = ops.conv2d_dgrad(nhwc(v), dev(k), (h * s, w_ * s), s, act='relu')
+    assert rel_err(to_nchw(y), ref) <= RTOL
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,N,K,ta,tb', [(64, 8192, 128, False, False), (128, 16, 8192, False, False),
+                                         (128, 8192, 16, False, True), (8192, 16, 128, True, False),
+                                         (128, 8192, 64, True, False), (1, 8192, 16, False, True),
+                                         (1, 16, 8192, False, False), (37, 53, 29, False, False),
+                                         (37, 53, 29, True, True)])
+def test_gemm(ops, M, N, K, ta, tb):
+    rs = np.random.RandomState(M + N + K)
+    a = rs.randn(*((K, M) if ta else (M, K))).astype(np.float32)
+    b = rs.randn(*((N, K) if tb else (K, N))).astype(np.float32)
+    bias = rs.randn(N).astype(np.float32)
+    A = a.T if ta else a
+    Bm = b.T if tb else b
+    ref = (A.astype(np.float64) @ Bm.astype(np.float64)) * 0.7 + bias
+    c = ops.gemm(dev(a), dev(b), ta, tb, bias=dev(bias), scale=dev([0.7]))
+    assert rel_err(c.cpu().numpy(), ref) <= RTOL
+    c2 = ops.gemm(dev(a), dev(b), ta, tb, bias=dev(bias), scale=dev([0.7]), act='relu')
+    assert rel_err(c2.cpu().numpy(), np.maximum(ref, 0)) <= RTOL
+
+
+def test_colsum_dot_layout(ops):
+    rs = np.random.RandomState(0)
+    x = rs.randn(5000, 70).astype(np.float32)
+    assert rel_err(ops.colsum(dev(x)).cpu().numpy(), x.astype(np.float64).sum(0)) <= 1e-5
+    a, b = rs.randn(100003).astype(np.float32), rs.randn(100003).astype(np.float32)
+    assert abs(float(ops.dot(dev(a), dev(b)).item()) - float(a.astype(np.float64) @ b.astype(np.float64))) <= 1e-3
+    t = rs.randn(3, 5, 7, 9).astype(np.float32)
+    y = ops.nchw_to_nhwc(dev(t))
+    assert np.array_equal(y.cpu().numpy(), np.transpose(t, (0, 2, 3, 1)))
+    assert np.array_equal(ops.nhwc_to_nchw(y).cpu().numpy(), t)
+
+
+@pytest.mark.parametrize('rows,C,act,four_d', [(64 * 64, 256, 'relu', True), (64 * 1024, 64, 'relu', True),
+                                               (64, 2304, 'relu', False), (100, 7, 'linear', True)])
+def test_batch_norm(ops, rows, C, act, four_d):
+    rs = np.random.RandomState(rows + C)
+    x = (rs.randn(rows, C) * 1.7 + 0.4).astype(np.float32)
+    gamma, beta = rs.uniform(0.5, 1.5, C).astype(np.float32), rs.randn(C).astype(np.float32) * 0.2
+    mm, mv = rs.randn(C).astype(np.float32) * 0.1, rs.uniform(0.5, 2, C).astype(np.float32)
+    dy = rs.randn(rows, C).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    gt = torch.tensor(gamma, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(beta, dtype=torch.float64, requires_grad=True)
+    mean = xt.mean(0)
+    var = ((xt - mean) ** 2).mean(0)
+    yt = R._act((xt - mean) / torch.sqrt(var + R.BN_EPS) * gt + bt, act)
+    gx, gg, gb = torch.autograd.grad((yt * torch.tensor(dy, dtype=torch.float64)).sum(), [xt, gt, bt])
+    y, smean, sinv, nmm, nmv = ops.bn_fwd_train(dev(x), dev(gamma), dev(beta), dev(mm), dev(mv), act=act, unbiased=four_d)
+    assert rel_err(y.cpu().numpy(), yt.detach().numpy()) <= RTOL
+    var_u = var.detach().numpy() * (rows / (rows - 1.0)) if four_d else var.detach().numpy()
+    assert rel_err(nmm.cpu().numpy(), mm * 0.99 + mean.detach().numpy() * 0.01) <= 1e-5
+    assert rel_err(nmv.cpu().numpy(), mv * 0.99 + var_u * 0.01) <= 1e-5
+    dx, dgamma, dbeta = ops.bn_bwd(dev(x), y, dev(dy), dev(gamma), smean, sinv, act=act)
+    assert rel_err(dx.cpu().numpy(), gx.numpy()) <= RTOL
+    assert rel_err(dgamma.cpu().numpy(), gg.numpy()) <= RTOL
+    assert rel_err(dbeta.cpu().numpy(), gb.numpy()) <= RTOL
+    yi = ops.bn_fwd_infer(dev(x), dev(gamma), dev(beta), dev(mm), dev(mv), act=act)
+    ref = R._act((torch.tensor(x, dtype=torch.float64) - torch.tensor(mm, dtype=torch.float64))
+                 / torch.sqrt(torch.tensor(mv, dtype=torch.float64) + R.BN_EPS) * gt.detach() + bt.detach(), act)
+    assert rel_err(yi.cpu().numpy(), ref.numpy()) <= RTOL
+
+
+def test_sn_helpers_and_adam(ops):
+    rs = np.random.RandomState(9)
+    v = rs.randn(32768).astype(np.float32)
+    norm, vn = ops.sn_norm(dev(v))
+    n64 = np.sqrt((v.astype(np.float64) ** 2).sum())
+    assert abs(norm.item() - n64) <= 1e-6 * n64
+    assert rel_err(vn.cpu().numpy(), v / (n64 + 1e-10)) <= 1e-6
+    sc = ops.sn_scale(norm, 1.6818)
+    assert abs(sc.item() - 1.6818 / n64) <= 1e-6 * (1.6818 / n64)
+    g, ds, wgt = (rs.randn(5000).astype(np.float32) for _ in range(3))
+    dot = ops.dot(dev(g), dev(wgt))
+    sigma = dev([2.5])
+    scale = ops.sn_scale(sigma, 1.5)
+    out = ops.sn_wgrad_fixup(dev(g), dev(ds), dot, sigma, scale)
+    ref = 0.6 * g - (0.6 / 2.5) * float(g.astype(np.float64) @ wgt.astype(np.float64)) * ds
+    assert rel_err(out.cpu().numpy(), ref) <= 1e-5
+    # TF-Adam, 3 steps, two tensors, against the oracle's AdamTF
+    ps = [rs.randn(1000).astype(np.float32), rs.randn(77).astype(np.float32)]
+    params = {'a': torch.tensor(ps[0]), 'b': torch.tensor(ps[1])}
+    opt = R.AdamTF(['a', 'b'], params, 5e-4)
+    dp = [dev(p) for p in ps]
+    dg = [torch.zeros_like(p) for p in dp]
+    grp = ops.AdamGroup(dp, dg, [torch.zeros_like(p) for p in dp], [torch.zeros_like(p) for p in dp])
+    for step in range(1, 4):
+        gs = [rs.randn(1000).astype(np.float32) * 1e-3, rs.randn(77).astype(np.float32)]
+        for t, gnp in zip(dg, gs):
+            t.copy_(torch.tensor(gnp))
+        grp.step(5e-4, step)
+        opt.apply(params, {'a': torch.tensor(gs[0]), 'b': torch.tensor(gs[1])})
+    assert rel_err(dp[0].cpu().numpy(), params['a'].numpy()) <= 1e-6
+    assert rel_err(dp[1].cpu().numpy(), params['b'].numpy()) <= 1e-6

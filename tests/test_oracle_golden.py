@@ -132,3 +132,22 @@ def test_full_step_restatement_matches_reference(loss_type):
                 if k.startswith('final/'):
                     n = k[len('final/'):-len('_f64')]
                     assert rel_err(gan.params[n].numpy(), v) <= 2e-6, n
+
+
+def test_reference_fp32_noise_floor():
+    """Why the GPU loss tolerance carries an absolute floor: the reference's OWN fp32 evaluation
+    (torch-CPU under the shim) misses its fp64 evaluation by more than 1e-4 of the loss on the
+    small-loss fixtures, i.e. by ~1e-4 of the kernel-mean scale.  The HIP kernel accumulates the
+    kernel sums in double and skips the diagonal, so it is held to 1e-4*|loss| + 4e-7*scale
+    (tests/test_ops_gpu.py::loss_tol), far tighter than fp32-vs-fp32 agreement."""
+    worst_rel_loss, worst_rel_scale = 0.0, 0.0
+    for path in MMD:
+        fx = load(path)
+        escale = max(float(fx['e_kxx_f64']), float(fx['e_kxy_f64']), float(fx['e_kyy_f64']))
+        for name in ('loss_gen', 'loss_dis'):
+            err = abs(float(fx[name + '_f32']) - float(fx[name + '_f64']))
+            worst_rel_scale = max(worst_rel_scale, err / escale)
+            if float(fx[name + '_f64']) != 0.0:
+                worst_rel_loss = max(worst_rel_loss, err / abs(float(fx[name + '_f64'])))
+    assert worst_rel_loss > 1e-4          # the reference's fp32 path itself is outside 1e-4
+    assert worst_rel_scale < 1e-3
