@@ -151,9 +151,13 @@ int mmdgan_mmd_loss(const float *s_gen, const float *s_x, int B, int d, int loss
  *   p -= lr_t * m / (sqrt(v) + eps)
  * ptrs is a DEVICE array of 4*n_tensors pointers (p, g, m, v per tensor), sizes a DEVICE array of
  * n_tensors element counts; grad_scale multiplies g first (1/world_size after a sum all-reduce).
+ * Step count t: if step_counter (DEVICE int*) is non-NULL it is incremented on the device and used
+ * (hipGraph-capturable: nothing host-computed changes between replays), else `step` is used.
+ * lr_t_scratch: one DEVICE float of scratch.
  * ---------------------------------------------------------------------------------------------- */
 int mmdgan_adam_multi(const void *const *ptrs, const long *sizes, int n_tensors, long max_size, float lr,
-                      float beta1, float beta2, float eps, int step, float grad_scale, void *stream);
+                      float beta1, float beta2, float eps, int step, int *step_counter, float *lr_t_scratch,
+                      float grad_scale, void *stream);
 
 /* layout seam helpers: NCHW <-> NHWC (the reference API speaks NCHW, misc_fun.py:50-51) */
 int mmdgan_nchw_to_nhwc(const float *src, float *dst, int N, int C, int H, int W, void *stream);

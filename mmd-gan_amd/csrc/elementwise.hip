@@ -77,8 +77,17 @@ __global__ __launch_bounds__(256) void sn_fixup_kernel(float *__restrict__ g, co
 
 // ---------------------------------------------------------------------------------------------
 // TF-Adam (graph_func.py:525-526 / tf.train.AdamOptimizer): epsilon OUTSIDE the bias correction.
-__global__ __launch_bounds__(256) void adam_kernel(const void *const *ptrs, const long *sizes, float lr_t,
+// one thread: (optionally) advance the device step counter and derive lr_t in double, so the whole
+// update is hipGraph-capturable (no host-computed value changes between replays)
+__global__ void adam_prepare_kernel(int *step_counter, int step_host, float lr, float b1, float b2, float *lr_t_out) {
+    int t = step_host;
+    if (step_counter) { t = step_counter[0] + 1; step_counter[0] = t; }
+    lr_t_out[0] = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(const void *const *ptrs, const long *sizes, const float *lr_t_ptr,
                                                    float b1, float b2, float eps, float gscale) {
+    const float lr_t = lr_t_ptr[0];
     const int t = blockIdx.y;
     const long n = sizes[t];
     float *p = (float *)ptrs[4 * t];
@@ -175,12 +184,14 @@ extern "C" int mmdgan_sn_wgrad_fixup(float *g_inout, const float *dsigma_dw, con
 }
 
 extern "C" int mmdgan_adam_multi(const void *const *ptrs, const long *sizes, int n_tensors, long max_size, float lr,
-                                 float beta1, float beta2, float eps, int step, float grad_scale, void *stream) {
-    MMDGAN_REQUIRE(ptrs && sizes && n_tensors >= 1 && max_size >= 1 && step >= 1, "adam_multi: bad arguments");
-    // lr_t in double on the host: lr*sqrt(1-b2^t)/(1-b1^t)
-    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(max_size, 256, 1024), n_tensors), dim3(256), 0, (hipStream_t)stream,
-                       ptrs, sizes, (float)lr_t, beta1, beta2, eps, grad_scale);
+                                 float beta1, float beta2, float eps, int step, int *step_counter, float *lr_t_scratch,
+                                 float grad_scale, void *stream) {
+    MMDGAN_REQUIRE(ptrs && sizes && lr_t_scratch && n_tensors >= 1 && max_size >= 1, "adam_multi: bad arguments");
+    MMDGAN_REQUIRE(step_counter || step >= 1, "adam_multi: step must be >= 1 when no device counter is given");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, st, step_counter, step, lr, beta1, beta2, lr_t_scratch);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(max_size, 256, 1024), n_tensors), dim3(256), 0, st, ptrs, sizes,
+                       lr_t_scratch, beta1, beta2, eps, grad_scale);
     return check_launch("adam_multi");
 }
 

@@ -1,0 +1,700 @@
+"""The G+D training step as a fixed schedule of HIP kernel launches.
+
+This is the build's restatement of the reference's graph (SURVEY.md sections 3.1, 8(a) rows A1-A11):
+  architecture dict -> layer specs       layer_func.py:1189-1275, 2118-2151, 2221-2391
+  G forward, D forward on [real ; fake]  my_sngan.py:271-279
+  SN power iteration per D layer         math_func.py:661-672, 739-744
+  rep / rmb loss                         math_func.py:2505-2550
+  two gradient passes + TF-Adam          my_sngan.py:301-305, 424-425, graph_func.py:518-527
+  UPDATE_OPS (SN vectors, BN stats)      graph_func.py:848-853
+
+There is no autograd and no tracing: the step is static, so the host issues the same kernel
+sequence every time (and can capture it into one hipGraph).  torch supplies device memory, the
+stream and the z sampler only.
+
+MI355X-first choices
+  * NHWC activations; every weight lives in ONE flat arena per network (params / grads / Adam m /
+    Adam v are four flat buffers) so Adam is one launch and the data-parallel all-reduce is a
+    handful of large buckets over xGMI instead of 29 small ones.
+  * D sees real and fake as the two halves of one 2B batch buffer; G's last layer writes its
+    output straight into the second half (the reference's concat/split copies are gone).
+  * loss_gen is back-propagated through D on the fake half only (the reference's TF graph also
+    pushes zeros through the real half - same result, 1/7 less work).
+  * the reference's NCHW layout shows up only at the API seam: dense weights next to a
+    [C,H,W] reshape are stored with their rows/columns permuted so that the NHWC view is free;
+    get_variables()/set_variables() convert to and from the reference's names and layouts.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ops
+
+_TEMPLATE = {'name': None, 'type': 'default', 'op': 'c', 'out': None, 'bias': 'b',
+             'act': 'linear', 'act_nm': None, 'act_k': False, 'w_nm': None, 'w_p': None,
+             'kernel': 3, 'strides': 1, 'dilation': 1, 'padding': 'SAME', 'scale': None,
+             'in_reshape': None, 'out_reshape': None, 'aux': None}
+_ACTS = ('linear', 'relu', 'lrelu', 'tanh')
+
+
+def _trunc_normal(rng, shape, stddev):
+    out = rng.randn(*shape)
+    bad = np.abs(out) > 2.0
+    while bad.any():
+        out[bad] = rng.randn(int(bad.sum()))
+        bad = np.abs(out) > 2.0
+    return (out * stddev).astype(np.float32)
+
+
+def _chw_perm(c, h, w):
+    """P with native[(h,w,c) flat] = ref[(c,h,w) flat][P]"""
+    return np.arange(c * h * w).reshape(c, h, w).transpose(1, 2, 0).reshape(-1)
+
+
+class LayerSpec:
+    """one layer of a Net after update_layer_design defaults and shape inference."""
+
+    def __init__(self, design, net_name, in_shape_ref):
+        d = dict(_TEMPLATE)
+        d.update(design)
+        if d['act_nm'] in ('bn', 'BN') and d['bias'] in ('b', 'bias'):     # layer_func.py:1241-1242
+            d['bias'] = None
+        self.scope = '{}/{}'.format(net_name, d['name'])
+        if d['type'] != 'default':
+            raise NotImplementedError('{}: {} is not implemented.'.format(self.scope, d['type']))   # :2067
+        if d['op'] not in ('d', 'c', 'tc'):
+            raise AttributeError('layer op {} not supported.'.format(d['op']))                      # :1275
+        if d['act'] not in _ACTS:
+            raise NotImplementedError('Function {} is not implemented.'.format(d['act']))           # :149
+        if d['act_nm'] not in (None, 'bn', 'BN'):
+            raise NotImplementedError('{}: {} not implemented'.format(self.scope, d['act_nm']))     # :1561
+        if d['w_nm'] not in (None, 's'):
+            raise NotImplementedError('{}: {} method not implemented'.format(self.scope, d['w_nm']))  # :824
+        if d['in_reshape'] is not None or d['scale'] is not None or d['dilation'] != 1 or d['padding'] != 'SAME':
+            raise NotImplementedError('{}: in_reshape / scale / dilation / VALID are outside the hot path'.format(self.scope))
+        self.op, self.act, self.name = d['op'], d['act'], d['name']
+        self.bn = d['act_nm'] in ('bn', 'BN')
+        self.has_bias = d['bias'] is not None
+        self.sn = d['w_nm'] == 's'
+        self.act_k = d['act_k']
+        if self.sn and (self.act_k is False or not isinstance(self.act_k, (float, int))):
+            # layer_func.py:835 would silently multiply the kernel by False (= 0); documented deviation
+            raise ValueError('{}: w_nm="s" needs a numeric act_k'.format(self.scope))
+        self.R, self.stride, self.out = d['kernel'], d['strides'], d['out']
+        self.in_shape_ref = list(in_shape_ref)          # [F] or [C,H,W]
+        if self.op == 'd':
+            assert len(in_shape_ref) == 1, '{}: the input shape {} does not match a dense layer'.format(self.scope, in_shape_ref)
+            self.kernel_shape = [in_shape_ref[0], self.out]
+            out = [self.out]
+        elif self.op == 'c':
+            c, h, w = in_shape_ref
+            self.kernel_shape = [self.R, self.R, c, self.out]
+            out = [self.out, -(-h // self.stride), -(-w // self.stride)]
+        else:
+            c, h, w = in_shape_ref
+            self.kernel_shape = [self.R, self.R, self.out, c]
+            out = [self.out, h * self.stride, w * self.stride]
+        self.op_out_ref = out
+        self.channels = out[0]
+        if self.sn:                                                        # math_func.py:481-486, 512-528
+            if self.op == 'd':
+                self.use_u = in_shape_ref[0] <= self.out
+                self.sn_x_ref = [1, in_shape_ref[0]] if self.use_u else [1, self.out]
+            else:
+                self.use_u = int(np.prod(in_shape_ref)) <= int(np.prod(out))
+                if self.op == 'c':
+                    self.sn_x_ref = [1] + (list(in_shape_ref) if self.use_u else list(out))
+                else:
+                    raise NotImplementedError('{}: spectral norm on tc layers is outside the hot path'.format(self.scope))
+        self.out_reshape = d['out_reshape']
+        self.out_shape_ref = list(self.out_reshape) if self.out_reshape is not None else list(out)
+        assert int(np.prod(self.out_shape_ref)) == int(np.prod(out)), \
+            '{}: the output shape {} does not match existed shape {}.'.format(self.scope, out, self.out_shape_ref)
+        # permutations at the NCHW<->NHWC seam (None = identity)
+        self.row_perm = None      # dense input features were a flattened [C,H,W] tensor
+        self.col_perm = None      # dense output features become a [C,H,W] tensor
+        if self.op == 'd' and self.out_reshape is not None and len(self.out_reshape) == 3:
+            self.col_perm = _chw_perm(*self.out_reshape)
+
+
+def build_specs(designs, input_shape_ref, net_name):
+    specs, shape, prev = [], list(input_shape_ref), None
+    for design in designs:
+        s = LayerSpec(design, net_name, shape)
+        if s.op == 'd' and prev is not None and len(prev.op_out_ref) == 3:
+            s.row_perm = _chw_perm(*prev.op_out_ref)                       # e.g. D l7 -> l8 (my_test_cifar.py:36)
+        specs.append(s)
+        shape, prev = s.out_shape_ref, s
+    return specs
+
+
+class _Arena:
+    """flat fp32 arena with named views."""
+
+    def __init__(self, entries, device):
+        self.offsets, n = OrderedDict(), 0
+        for name, shape in entries:
+            size = int(np.prod(shape))
+            self.offsets[name] = (n, size, tuple(shape))
+            n += (size + 3) // 4 * 4                   # keep every view 16-byte aligned
+        self.size = n
+        self.flat = torch.zeros(max(n, 4), dtype=torch.float32, device=device)
+
+    def view(self, name, flat=None):
+        o, size, shape = self.offsets[name]
+        return (self.flat if flat is None else flat)[o:o + size].view(shape)
+
+    def like(self):
+        return torch.zeros_like(self.flat)
+
+
+class Network:
+    """parameters, state and per-layer buffers of one net (G or D)."""
+
+    def __init__(self, specs, device, rng):
+        self.specs, self.device = specs, device
+        entries = []
+        for s in specs:
+            entries.append((s.scope + '/kernel/kernel', s.kernel_shape))
+            if s.has_bias:
+                entries.append((s.scope + '/bias/bias', [s.channels]))
+            if s.bn:
+                nfeat = s.out if s.op == 'd' else s.channels
+                entries.append((s.scope + '/BN/BN/gamma', [nfeat]))
+                entries.append((s.scope + '/BN/BN/beta', [nfeat]))
+        self.arena = _Arena(entries, device)
+        self.params = self.arena.flat
+        self.grads, self.adam_m, self.adam_v = self.arena.like(), self.arena.like(), self.arena.like()
+        self.opt = ops.AdamGroup([self.params], [self.grads], [self.adam_m], [self.adam_v])
+        self.state = OrderedDict()                      # non-trainable: SN vectors, BN moving stats
+        for s in specs:
+            if s.sn:
+                self.state[s.scope + '/kernel/SN/in_rand'] = torch.zeros(self._sn_native_shape(s), device=device)
+                self.state[s.scope + '/kernel/SN/in_rand#next'] = torch.zeros(self._sn_native_shape(s), device=device)
+                for k in ('sigma', 'scale', 'dot'):
+                    self.state[s.scope + '#' + k] = torch.zeros(1, device=device)
+                self.state[s.scope + '#dsigma'] = torch.zeros(s.kernel_shape, device=device)
+            if s.bn:
+                nfeat = s.out if s.op == 'd' else s.channels
+                self.state[s.scope + '/BN/BN/moving_mean'] = torch.zeros(nfeat, device=device)
+                self.state[s.scope + '/BN/BN/moving_variance'] = torch.ones(nfeat, device=device)
+        self.init_variables(rng)
+
+    # ---- names / layouts -------------------------------------------------------------------
+    @staticmethod
+    def _sn_native_shape(s):
+        r = s.sn_x_ref
+        return [1, r[2], r[3], r[1]] if len(r) == 4 else list(r)
+
+    def p(self, name):
+        return self.arena.view(name)
+
+    def g(self, name):
+        return self.arena.view(name, self.grads)
+
+    def variable_names(self, trainable_only=False):
+        names = list(self.arena.offsets)
+        if not trainable_only:
+            names += [k for k in self.state if '#' not in k]
+        return names
+
+    def _spec_of(self, name):
+        for s in self.specs:
+            if name.startswith(s.scope + '/'):
+                return s
+        raise KeyError(name)
+
+    def _to_native(self, name, ref):
+        """reference layout (numpy) -> native layout (numpy)"""
+        s = self._spec_of(name)
+        ref = np.asarray(ref, dtype=np.float32)
+        if name.endswith('in_rand'):
+            if ref.ndim == 4:
+                return np.ascontiguousarray(ref.transpose(0, 2, 3, 1))
+            perm = s.row_perm if (s.op == 'd' and s.use_u) else s.col_perm
+            return ref[:, perm] if perm is not None else ref
+        if name.endswith('kernel/kernel') and s.op == 'd':
+            if s.row_perm is not None:
+                ref = ref[s.row_perm, :]
+            if s.col_perm is not None:
+                ref = ref[:, s.col_perm]
+            return np.ascontiguousarray(ref)
+        if s.op == 'd' and s.col_perm is not None and ref.ndim == 1:      # bias / BN vectors of a reshaped dense
+            return np.ascontiguousarray(ref[s.col_perm])
+        return ref
+
+    def _to_ref(self, name, nat):
+        s = self._spec_of(name)
+        nat = np.asarray(nat, dtype=np.float32)
+        if name.endswith('in_rand'):
+            if nat.ndim == 4:
+                return np.ascontiguousarray(nat.transpose(0, 3, 1, 2))
+            perm = s.row_perm if (s.op == 'd' and s.use_u) else s.col_perm
+            if perm is not None:
+                out = np.empty_like(nat)
+                out[:, perm] = nat
+                return out
+            return nat
+        if name.endswith('kernel/kernel') and s.op == 'd':
+            out = nat
+            if s.col_perm is not None:
+                t = np.empty_like(out)
+                t[:, s.col_perm] = out
+                out = t
+            if s.row_perm is not None:
+                t = np.empty_like(out)
+                t[s.row_perm, :] = out
+                out = t
+            return out
+        if s.op == 'd' and s.col_perm is not None and nat.ndim == 1:
+            out = np.empty_like(nat)
+            out[s.col_perm] = nat
+            return out
+        return nat
+
+    def set_variable(self, name, ref_value):
+        nat = torch.as_tensor(self._to_native(name, ref_value), device=self.device)
+        dst = self.arena.view(name) if name in self.arena.offsets else self.state[name]
+        assert tuple(dst.shape) == tuple(nat.shape), (name, tuple(dst.shape), tuple(nat.shape))
+        dst.copy_(nat)
+
+    def get_variable(self, name, grad=False):
+        if name in self.arena.offsets:
+            t = self.arena.view(name, self.grads if grad else None)
+        else:
+            t = self.state[name]
+        return self._to_ref(name, t.detach().cpu().numpy())
+
+    # ---- initialisers: weight_initializer 'default' (layer_func.py:27-52), bias 1e-5 (:747) --
+    def init_variables(self, rng):
+        for s in self.specs:
+            shape = s.kernel_shape
+            receptive = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+            fan_in, fan_out = shape[-2] * receptive, shape[-1] * receptive   # TF fan rule (tc quirk)
+            if s.act == 'relu':
+                w = _trunc_normal(rng, shape, math.sqrt(2.0 / fan_in))
+            elif s.act == 'lrelu':
+                w = _trunc_normal(rng, shape, math.sqrt(2.0 / 1.01 / fan_in))
+            else:
+                lim = math.sqrt(3.0 / ((fan_in + fan_out) / 2.0))
+                w = rng.uniform(-lim, lim, size=shape).astype(np.float32)
+            self.set_variable(s.scope + '/kernel/kernel', w)
+            if s.sn:                                                        # math_func.py:565-567: NOT normalised
+                self.set_variable(s.scope + '/kernel/SN/in_rand', _trunc_normal(rng, s.sn_x_ref, 1.0))
+            if s.has_bias:
+                n = s.out if s.op == 'd' else s.channels
+                self.set_variable(s.scope + '/bias/bias', _trunc_normal(rng, [n], 1e-5))
+            if s.bn:
+                n = s.out if s.op == 'd' else s.channels
+                self.set_variable(s.scope + '/BN/BN/gamma', np.ones(n, np.float32))
+                self.set_variable(s.scope + '/BN/BN/beta', np.zeros(n, np.float32))
+
+
+def _native_shape(shape_ref, batch):
+    return [batch, shape_ref[1], shape_ref[2], shape_ref[0]] if len(shape_ref) == 3 else [batch, shape_ref[0]]
+
+
+class GanEngine:
+    """G + D + loss + two TF-Adam optimisers; `step()` = one sess.run of graph_func.py:853."""
+
+    def __init__(self, architecture, loss_type='rep', lr_list=(5e-4, 2e-4), rep_weights=(0.0, -1.0),
+                 batch_size=64, seed=0, device=None, dist_group=None, use_graph=False):
+        ops.require_device()
+        if loss_type not in ops.LOSS:
+            raise NotImplementedError('Not implemented.')                   # math_func.py:2651
+        assert rep_weights[0] - rep_weights[1] == 1.0, 'w[0]-w[1] must be 1'   # math_func.py:1340
+        self.device = torch.device(device if device is not None else 'cuda')
+        self.arch, self.loss_type, self.rep_weights = architecture, loss_type, tuple(rep_weights)
+        self.lr_d, self.lr_g = float(lr_list[0]), float(lr_list[1])
+        self.B = int(batch_size)
+        self.code_size = architecture['code'][0][0]
+        self.in_shape_ref = list(architecture['input'][0])
+        rng = np.random.RandomState(seed)
+        self.gen = Network(build_specs(architecture['generator'], [self.code_size], 'gen'), self.device, rng)
+        self.dis = Network(build_specs(architecture['discriminator'], self.in_shape_ref, 'dis'), self.device, rng)
+        if self.gen.specs[-1].out_shape_ref != self.in_shape_ref:
+            raise AssertionError('gen: the output shape {} does not match existed shape {}.'.format(
+                self.gen.specs[-1].out_shape_ref, self.in_shape_ref))
+        self.score_size = self.dis.specs[-1].out
+        self.global_step = 0
+        self.dist_group = dist_group
+        self.world = 1
+        if dist_group is not None:
+            import torch.distributed as tdist
+            self.world = tdist.get_world_size(dist_group)
+        self._alloc(self.B)
+        self.losses = torch.zeros(8, device=self.device)       # filled by the loss kernel each step
+        self.use_graph, self._graph = use_graph, None
+        self._static_z = torch.zeros(self.B, self.code_size, device=self.device)
+        self._static_real = torch.zeros(_native_shape(self.in_shape_ref, self.B), device=self.device)
+
+    # ---------------------------------------------------------------------------------------
+    def _alloc(self, B):
+        """all per-step buffers, allocated once (graph capture needs static addresses)."""
+        dev = self.device
+        self.buf = {}
+        c, h, w = self.in_shape_ref
+        self.buf['dis_in'] = torch.zeros(2 * B, h, w, c, device=dev)          # [real ; fake]
+        for net, batch in ((self.gen, B), (self.dis, 2 * B)):
+            for s in net.specs:
+                shp = _native_shape(s.op_out_ref, batch)
+                if s.bn:
+                    self.buf[s.scope + '#raw'] = torch.zeros(shp, device=dev)
+                    self.buf[s.scope + '#dy'] = torch.zeros(shp, device=dev)      # gradient w.r.t. the BN+act output
+                    nfeat = shp[-1]
+                    self.buf[s.scope + '#mean'] = torch.zeros(nfeat, device=dev)
+                    self.buf[s.scope + '#invstd'] = torch.zeros(nfeat, device=dev)
+                is_gen_out = net is self.gen and s is self.gen.specs[-1]
+                self.buf[s.scope + '#y'] = self.buf['dis_in'][B:] if is_gen_out else torch.zeros(shp, device=dev)
+                # gradient w.r.t. the layer's pre-activation output (after act'), D also for the G pass
+                self.buf[s.scope + '#dz'] = torch.zeros(shp, device=dev)
+                if net is self.dis:
+                    self.buf[s.scope + '#dz_g'] = torch.zeros(_native_shape(s.op_out_ref, B), device=dev)
+        self.buf['d_fake'] = torch.zeros(B, h, w, c, device=dev)
+        self.buf['ds_d'] = torch.zeros(2 * B, self.score_size, device=dev)
+        # SN scratch per D layer
+        for s in self.dis.specs:
+            if s.sn:
+                u_shape = self._sn_u_shape(s)
+                self.buf[s.scope + '#u'] = torch.zeros(u_shape, device=dev)
+                self.buf[s.scope + '#un'] = torch.zeros(u_shape, device=dev)
+                self.buf[s.scope + '#xb'] = torch.zeros_like(self.dis.state[s.scope + '/kernel/SN/in_rand'])
+                self.buf[s.scope + '#xbnorm'] = torch.zeros(1, device=dev)
+
+    @staticmethod
+    def _sn_u_shape(s):
+        if s.op == 'd':
+            return [1, s.out] if s.use_u else [1, s.kernel_shape[0]]
+        c, h, w = s.in_shape_ref
+        k, p, q = s.op_out_ref
+        return [1, p, q, k] if s.use_u else [1, h, w, c]
+
+    # ---------------------------------------------------------------------------------------
+    # spectral norm: one power-iteration step per D layer (math_func.py:661-672)
+    # ---------------------------------------------------------------------------------------
+    def _sn_step(self, s):
+        net, b = self.dis, self.buf
+        w = net.p(s.scope + '/kernel/kernel')
+        x = net.state[s.scope + '/kernel/SN/in_rand']
+        x_next = net.state[s.scope + '/kernel/SN/in_rand#next']
+        sigma, scale = net.state[s.scope + '#sigma'], net.state[s.scope + '#scale']
+        dsig = net.state[s.scope + '#dsigma']
+        u, un, xb = b[s.scope + '#u'], b[s.scope + '#un'], b[s.scope + '#xb']
+        if s.op == 'd':
+            if 1 in s.kernel_shape:                                          # math_func.py:702-704
+                ops.sn_norm(w.view(-1), True, out_norm=sigma, out_v=dsig.view(-1))
+                x_next.copy_(x)
+            elif s.use_u:
+                ops.gemm(x, w, out=u)                                        # u = x W          [1,out]
+                ops.sn_norm(u.view(-1), True, out_norm=sigma, out_v=un.view(-1))
+                ops.gemm(un, w, trans_b=True, out=xb)                        # y W^T            [1,in]
+                ops.sn_norm(xb.view(-1), True, out_norm=b[s.scope + '#xbnorm'], out_v=x_next.view(-1))
+                ops.gemm(x, un, trans_a=True, out=dsig)                      # dsigma/dW = x^T y
+            else:
+                ops.gemm(x, w, trans_b=True, out=u)                          # u = x W^T        [1,in]
+                ops.sn_norm(u.view(-1), True, out_norm=sigma, out_v=un.view(-1))
+                ops.gemm(un, w, out=xb)                                      # y W              [1,out]
+                ops.sn_norm(xb.view(-1), True, out_norm=b[s.scope + '#xbnorm'], out_v=x_next.view(-1))
+                ops.gemm(un, x, trans_a=True, out=dsig)                      # dsigma/dW = y^T x
+        else:
+            c, h, wd = s.in_shape_ref
+            if s.use_u:
+                ops.conv2d_fwd(x, w, s.stride, out=u)
+                ops.sn_norm(u.view(-1), True, out_norm=sigma, out_v=un.view(-1))
+                ops.conv2d_dgrad(un, w, (h, wd), s.stride, out=xb)
+                ops.sn_norm(xb.view(-1), True, out_norm=b[s.scope + '#xbnorm'], out_v=x_next.view(-1))
+                ops.conv2d_wgrad(x, un, s.R, s.stride, out=dsig)
+            else:
+                ops.conv2d_dgrad(x, w, (h, wd), s.stride, out=u)
+                ops.sn_norm(u.view(-1), True, out_norm=sigma, out_v=un.view(-1))
+                ops.conv2d_fwd(un, w, s.stride, out=xb)
+                ops.sn_norm(xb.view(-1), True, out_norm=b[s.scope + '#xbnorm'], out_v=x_next.view(-1))
+                ops.conv2d_wgrad(un, x, s.R, s.stride, out=dsig)
+        ops.sn_scale(sigma, s.act_k, out=scale)                              # layer_func.py:886-887
+        return scale
+
+    # ---------------------------------------------------------------------------------------
+    def _layer_forward(self, net, s, x, is_training, scale):
+        b = self.buf
+        w = net.p(s.scope + '/kernel/kernel')
+        bias = net.p(s.scope + '/bias/bias') if s.has_bias else None
+        y = b[s.scope + '#y']
+        n = x.shape[0]
+        y = y[:n] if y.shape[0] != n else y
+        fused_act = 'linear' if s.bn else s.act
+        tgt = (b[s.scope + '#raw'][:n] if s.bn else y)
+        if s.op == 'd':
+            ops.gemm(x.reshape(n, -1), w, bias=bias, scale=scale, act=fused_act, out=tgt.view(n, -1))
+        elif s.op == 'c':
+            ops.conv2d_fwd(x, w, s.stride, bias=bias, scale=scale, act=fused_act, out=tgt)
+        else:
+            ops.conv2d_dgrad(x, w, (tgt.shape[1], tgt.shape[2]), s.stride, bias=bias, scale=scale, act=fused_act, out=tgt)
+        if s.bn:
+            gamma, beta = net.p(s.scope + '/BN/BN/gamma'), net.p(s.scope + '/BN/BN/beta')
+            mm, mv = net.state[s.scope + '/BN/BN/moving_mean'], net.state[s.scope + '/BN/BN/moving_variance']
+            raw2d = tgt.view(-1, tgt.shape[-1])
+            lib = ops.require_device()
+            ws = ops._bn_workspace(raw2d.shape[1], raw2d.device)
+            if is_training:
+                ops.check(lib.mmdgan_bn_fwd_train(
+                    raw2d.data_ptr(), raw2d.shape[0], raw2d.shape[1], gamma.data_ptr(), beta.data_ptr(), 1e-3, 0.99,
+                    int(tgt.dim() == 4), ops.act_id(s.act), y.data_ptr(), b[s.scope + '#mean'].data_ptr(),
+                    b[s.scope + '#invstd'].data_ptr(), mm.data_ptr(), mv.data_ptr(), mm.data_ptr(), mv.data_ptr(),
+                    ws.data_ptr(), ops._stream()), 'bn_fwd_train')
+            else:
+                ops.check(lib.mmdgan_bn_fwd_infer(
+                    raw2d.data_ptr(), raw2d.shape[0], raw2d.shape[1], gamma.data_ptr(), beta.data_ptr(), 1e-3,
+                    ops.act_id(s.act), mm.data_ptr(), mv.data_ptr(), y.data_ptr(), ops._stream()), 'bn_fwd_infer')
+        return y
+
+    def generate(self, z, is_training=False):
+        """G(z) -> NHWC images (the fake half of D's input buffer when the batch is B)."""
+        x = z
+        for s in self.gen.specs:
+            x = self._layer_forward(self.gen, s, x, is_training, None)
+            if s.out_reshape is not None:
+                x = x.view(_native_shape(s.out_shape_ref, x.shape[0]))
+        return x
+
+    # ---------------------------------------------------------------------------------------
+    def _forward(self, z, real):
+        B, b = self.B, self.buf
+        b['dis_in'][:B].copy_(real)
+        self.generate(z, is_training=True)                                   # writes dis_in[B:]
+        x = b['dis_in']
+        self._scales = {}
+        for s in self.dis.specs:
+            scale = self._sn_step(s) if s.sn else None
+            self._scales[s.scope] = scale
+            x = self._layer_forward(self.dis, s, x, True, scale)
+            if s.out_reshape is not None:
+                x = x.view(_native_shape(s.out_shape_ref, x.shape[0]))
+        scores = x                                                           # [2B, d]; s_x = [:B], s_gen = [B:]
+        lib = ops.require_device()
+        key = (B, self.score_size, self.device)
+        if key not in ops._mmd_ws:
+            ops._mmd_ws[key] = torch.zeros(lib.mmdgan_mmd_workspace_bytes(B, self.score_size), device=self.device,
+                                           dtype=torch.uint8)
+        if 'mmd_grads' not in b:
+            b['mmd_grads'] = torch.zeros(4, B, self.score_size, device=self.device)
+        ops.check(lib.mmdgan_mmd_loss(scores[B:].data_ptr(), scores[:B].data_ptr(), B, self.score_size,
+                                      ops.LOSS[self.loss_type], self.rep_weights[0], self.rep_weights[1], 0.25, 4.0,
+                                      self.losses.data_ptr(), b['mmd_grads'].data_ptr(), None, None,
+                                      ops._mmd_ws[key].data_ptr(), ops._stream()), 'mmd_loss')
+        return scores
+
+    # ---------------------------------------------------------------------------------------
+    def _backward_dis(self):
+        """loss_dis -> D parameters (batch 2B), and loss_gen -> d(fake images) (fake half, dgrad only)."""
+        B, b, net = self.B, self.buf, self.dis
+        g = b['mmd_grads']                                                   # dLg/dsg, dLg/dsx, dLd/dsg, dLd/dsx
+        specs = net.specs
+        # ---- D pass: upstream [dLd/ds_x ; dLd/ds_gen] (real rows first, my_sngan.py:278-279)
+        b['ds_d'][:B].copy_(g[3])
+        b['ds_d'][B:].copy_(g[2])
+        dz = b['ds_d']
+        for li in range(len(specs) - 1, -1, -1):
+            s = specs[li]
+            x_in = b['dis_in'] if li == 0 else b[specs[li - 1].scope + '#y']
+            w = net.p(s.scope + '/kernel/kernel')
+            gw = net.g(s.scope + '/kernel/kernel')
+            scale = self._scales[s.scope]
+            dz2d = dz.reshape(-1, dz.shape[-1])
+            if s.has_bias:
+                ops.colsum(dz2d, out=net.g(s.scope + '/bias/bias'))
+            if s.op == 'd':
+                ops.gemm(x_in.reshape(2 * B, -1), dz2d, trans_a=True, out=gw)
+            else:
+                ops.conv2d_wgrad(x_in, dz, s.R, s.stride, out=gw)
+            if s.sn:                                                         # SURVEY A.2 fix-up
+                dot = net.state[s.scope + '#dot']
+                ops.dot(gw.view(-1), w.view(-1), out=dot)
+                ops.sn_wgrad_fixup(gw.view(-1), net.state[s.scope + '#dsigma'].view(-1), dot,
+                                   net.state[s.scope + '#sigma'], scale)
+            if li > 0:
+                prev = specs[li - 1]
+                dprev = b[prev.scope + '#dz']
+                yprev = b[prev.scope + '#y']
+                if s.op == 'd':
+                    ops.gemm(dz2d, w, trans_b=True, scale=scale, act=prev.act, dact_of=yprev.view(2 * B, -1),
+                             out=dprev.view(2 * B, -1))
+                else:
+                    ops.conv2d_dgrad(dz, w, (yprev.shape[1], yprev.shape[2]), s.stride, scale=scale, act=prev.act,
+                                     dact_of=yprev, out=dprev)
+                dz = dprev
+        # ---- G pass through D: fake half only, dgrad only
+        dz = g[0]                                                            # dLgen/ds_gen [B, d]
+        gen_last = self.gen.specs[-1]
+        for li in range(len(specs) - 1, -1, -1):
+            s = specs[li]
+            w = net.p(s.scope + '/kernel/kernel')
+            scale = self._scales[s.scope]
+            if li > 0:
+                prev = specs[li - 1]
+                yprev, act_prev, out = b[prev.scope + '#y'][B:], prev.act, b[prev.scope + '#dz_g']
+            else:
+                # below D l1 sits G's output: apply G's last activation derivative (tanh') unless G ends in BN
+                yprev, out = b['dis_in'][B:], b['d_fake']
+                act_prev = 'linear' if gen_last.bn else gen_last.act
+            if s.op == 'd':
+                ops.gemm(dz.reshape(B, -1), w, trans_b=True, scale=scale, act=act_prev, dact_of=yprev.reshape(B, -1),
+                         out=out.view(B, -1))
+            else:
+                ops.conv2d_dgrad(dz, w, (yprev.shape[1], yprev.shape[2]), s.stride, scale=scale, act=act_prev,
+                                 dact_of=yprev, out=out)
+            dz = out
+        return dz                                                            # gradient w.r.t. G's last pre-activation
+
+    def _backward_gen(self, dz, z):
+        B, b, net = self.B, self.buf, self.gen
+        specs = net.specs
+        for li in range(len(specs) - 1, -1, -1):
+            s = specs[li]
+            in_shape = _native_shape(s.in_shape_ref, B)
+            x_in = (z if li == 0 else b[specs[li - 1].scope + '#y']).view(in_shape)
+            w = net.p(s.scope + '/kernel/kernel')
+            gw = net.g(s.scope + '/kernel/kernel')
+            if s.bn:                                                         # dz is d/d(BN output after act)
+                raw, y = b[s.scope + '#raw'], b[s.scope + '#y']
+                lib = ops.require_device()
+                C = raw.shape[-1]
+                ws = ops._bn_workspace(C, raw.device)
+                draw = b[s.scope + '#dz']
+                ops.check(lib.mmdgan_bn_bwd(
+                    raw.data_ptr(), y.data_ptr(), dz.data_ptr(), raw.numel() // C, C,
+                    net.p(s.scope + '/BN/BN/gamma').data_ptr(), b[s.scope + '#mean'].data_ptr(),
+                    b[s.scope + '#invstd'].data_ptr(), ops.act_id(s.act), draw.data_ptr(),
+                    net.g(s.scope + '/BN/BN/gamma').data_ptr(), net.g(s.scope + '/BN/BN/beta').data_ptr(),
+                    ws.data_ptr(), ops._stream()), 'bn_bwd')
+                dz = draw
+            dz = dz.view(_native_shape(s.op_out_ref, B))
+            if s.has_bias:
+                ops.colsum(dz.view(-1, dz.shape[-1]), out=net.g(s.scope + '/bias/bias'))
+            if s.op == 'd':
+                ops.gemm(x_in, dz, trans_a=True, out=gw)
+            elif s.op == 'c':
+                ops.conv2d_wgrad(x_in, dz, s.R, s.stride, out=gw)
+            else:                                                            # tc: W[R,R,Cout,Cin]; y = dgrad(v, W)
+                ops.conv2d_wgrad(dz, x_in, s.R, s.stride, out=gw)
+            if li > 0:
+                prev = specs[li - 1]
+                # a BN layer below gets d/d(its activated output) and applies act' itself in bn_bwd;
+                # otherwise the epilogue multiplies by act'(y_prev) and the result is d/d(pre-activation)
+                yprev = b[prev.scope + '#y'].view(in_shape)
+                act_prev, dact = ('linear', None) if prev.bn else (prev.act, yprev)
+                dprev = b[prev.scope + ('#dy' if prev.bn else '#dz')].view(in_shape)
+                if s.op == 'd':
+                    ops.gemm(dz, w, trans_b=True, act=act_prev, dact_of=dact, out=dprev)
+                elif s.op == 'c':
+                    ops.conv2d_dgrad(dz, w, (in_shape[1], in_shape[2]), s.stride, act=act_prev, dact_of=dact, out=dprev)
+                else:                                                        # d/dv of dgrad(v, W) = conv(dz, W)
+                    ops.conv2d_fwd(dz, w, s.stride, act=act_prev, dact_of=dact, out=dprev)
+                dz = dprev
+
+    # ---------------------------------------------------------------------------------------
+    def _allreduce(self, net):
+        if self.dist_group is None or self.world == 1:
+            return
+        import torch.distributed as tdist
+        tdist.all_reduce(net.grads, op=tdist.ReduceOp.SUM, group=self.dist_group)
+
+    def _update(self):
+        gs = 1.0 / self.world
+        self.dis.opt.step(self.lr_d, grad_scale=gs)
+        self.gen.opt.step(self.lr_g, grad_scale=gs)
+        for s in self.dis.specs:                                             # UPDATE_OPS: x <- x' (reads preceded writes)
+            if s.sn:
+                self.dis.state[s.scope + '/kernel/SN/in_rand'].copy_(self.dis.state[s.scope + '/kernel/SN/in_rand#next'])
+
+    def _step_body(self, z, real):
+        self._forward(z, real)
+        dz = self._backward_dis()
+        self._allreduce(self.dis)
+        self._backward_gen(dz, z)
+        self._allreduce(self.gen)
+        self._update()
+
+    def step(self, real_nhwc=None, z=None):
+        """one training step; returns nothing on the host (losses stay in self.losses on the device:
+        [0] loss_gen, [1] loss_dis, [2..6] e_kxx e_kxy e_kyy e_kxx_b e_kyy_b, pre-update values)."""
+        if z is None:
+            self._static_z.normal_()                                         # my_sngan.py:123-124
+        else:
+            self._static_z.copy_(z)
+        if real_nhwc is not None:
+            self._static_real.copy_(real_nhwc)
+        if self.use_graph and self.dist_group is None:
+            if self._graph is None:
+                self._capture()
+            else:
+                self._graph.replay()
+        else:
+            self._step_body(self._static_z, self._static_real)
+        self.global_step += 1                                                # tied to the D update, my_sngan.py:424
+
+    def _capture(self):
+        # warm-up on a side stream (allocates lazily-created buffers), then capture one step
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        snap = self._snapshot()
+        with torch.cuda.stream(s):
+            self._step_body(self._static_z, self._static_real)
+        torch.cuda.current_stream().wait_stream(s)
+        self._restore(snap)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._step_body(self._static_z, self._static_real)
+        self._restore(snap)
+        self._graph.replay()
+
+    def _snapshot(self):
+        out = []
+        for net in (self.gen, self.dis):
+            out.append([net.params.clone(), net.adam_m.clone(), net.adam_v.clone(), net.opt.step_counter.clone(),
+                        {k: v.clone() for k, v in net.state.items()}])
+        return out
+
+    def _restore(self, snap):
+        for net, (p, m, v, t, st) in zip((self.gen, self.dis), snap):
+            net.params.copy_(p); net.adam_m.copy_(m); net.adam_v.copy_(v); net.opt.step_counter.copy_(t)
+            for k, val in st.items():
+                net.state[k].copy_(val)
+
+    # ---------------------------------------------------------------------------------------
+    # reference-layout import / export (checkpoint keys follow TF scopes)
+    # ---------------------------------------------------------------------------------------
+    def variable_names(self, trainable_only=False):
+        return self.gen.variable_names(trainable_only) + self.dis.variable_names(trainable_only)
+
+    def _net_of(self, name):
+        return self.gen if name.startswith('gen/') else self.dis
+
+    def set_variables(self, values):
+        for k, v in values.items():
+            self._net_of(k).set_variable(k, v)
+
+    def get_variables(self, names=None, grad=False):
+        names = names if names is not None else self.variable_names(trainable_only=grad)
+        return OrderedDict((k, self._net_of(k).get_variable(k, grad=grad)) for k in names)
+
+    def sigmas(self):
+        return OrderedDict((s.scope, float(self.dis.state[s.scope + '#sigma'].item())) for s in self.dis.specs if s.sn)
+
+    def state_dict(self):
+        sd = {'global_step': self.global_step, 'variables': self.get_variables()}
+        for tag, net in (('gen', self.gen), ('dis', self.dis)):
+            sd[tag + '/adam_m'] = net.adam_m.cpu()
+            sd[tag + '/adam_v'] = net.adam_v.cpu()
+            sd[tag + '/adam_t'] = int(net.opt.step_counter.item())
+        return sd
+
+    def load_state_dict(self, sd):
+        self.set_variables(sd['variables'])
+        self.global_step = int(sd['global_step'])
+        for tag, net in (('gen', self.gen), ('dis', self.dis)):
+            net.adam_m.copy_(sd[tag + '/adam_m'])
+            net.adam_v.copy_(sd[tag + '/adam_v'])
+            net.opt.step_counter.fill_(int(sd[tag + '/adam_t']))
+        self._graph = None

@@ -238,12 +238,16 @@ class AdamGroup:
         self.sizes = torch.tensor([p.numel() for p in params], dtype=torch.int64, device=dev)
         self.n = len(params)
         self.max_size = max(p.numel() for p in params)
+        self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)     # device-side t (graph-capturable)
+        self.lr_t = torch.zeros(1, dtype=torch.float32, device=dev)
 
-    def step(self, lr, step, beta1=0.5, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    def step(self, lr, step=None, beta1=0.5, beta2=0.999, eps=1e-8, grad_scale=1.0):
+        """step=None: use and advance the device-side counter; else use the given host step."""
         lib = require_device()
         check(lib.mmdgan_adam_multi(self.ptrs.data_ptr(), self.sizes.data_ptr(), self.n, self.max_size, float(lr),
-                                    float(beta1), float(beta2), float(eps), int(step), float(grad_scale), _stream()),
-              'adam_multi')
+                                    float(beta1), float(beta2), float(eps), int(step or 0),
+                                    self.step_counter.data_ptr() if step is None else None, self.lr_t.data_ptr(),
+                                    float(grad_scale), _stream()), 'adam_multi')
 
 
 def nchw_to_nhwc(x):

@@ -276,6 +276,7 @@ def net_forward(specs, params, x, is_training=True, collect=None):
         x = _act(x, d['act'])
         if collect is not None:
             collect[sc + '/out'] = x.detach()
+            collect[sc + '/out_live'] = x              # graph-attached (tests differentiate w.r.t. it)
         if d['out_reshape'] is not None:                      # C,H,W order flatten (my_test_cifar.py:36)
             x = x.reshape([n] + list(d['out_reshape']))
     return x, updates

@@ -1,0 +1,154 @@
+"""Full G+D training step on the GPU against (a) the golden vectors produced by the reference's
+own code (width/8 CIFAR-shaped net, 3 consecutive steps) and (b) the oracle restatement run live
+on a mid-size net.  The oracle is the checker only."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import RTOL, golden, load
+from oracle import restatement as R
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
+from tiny_arch import tiny_architecture  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def nhwc(a):
+    return torch.as_tensor(np.ascontiguousarray(np.transpose(a, (0, 2, 3, 1)))).cuda()
+
+
+def close(got, ref, rtol, floor):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    return np.max(np.abs(got - ref)) <= rtol * np.max(np.abs(ref)) + floor
+
+
+@pytest.mark.parametrize('loss_type', ['rep', 'rmb'])
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_step_matches_reference_golden(loss_type, use_graph):
+    from mmdgan_hip.engine import GanEngine
+    fx = load(golden('step_tiny_%s.npz' % loss_type)[0])
+    B = int(fx['B'])
+    eng = GanEngine(tiny_architecture(), loss_type, tuple(fx['lr']), batch_size=B, use_graph=use_graph)
+    eng.set_variables({k[len('init/'):]: v for k, v in fx.items() if k.startswith('init/')})
+    n_steps = fx['z'].shape[0]
+    for step in range(n_steps):
+        eng.step(nhwc(fx['real'][step]), torch.as_tensor(fx['z'][step]).cuda())
+        pre = 'step%d/' % step
+        losses = eng.losses.cpu().numpy().astype(np.float64)
+        escale = float(max(losses[2:5]))
+        for idx, name in ((0, 'loss_gen'), (1, 'loss_dis')):
+            ref = float(fx[pre + name + '_f64'])
+            assert abs(losses[idx] - ref) <= RTOL * abs(ref) + 4e-7 * escale, (step, name, losses[idx], ref)
+        for k, v in fx.items():                      # spectral norms of every D layer, every step
+            if k.startswith(pre + 'sigma/') and k.endswith('_f64'):
+                scope = k[len(pre + 'sigma/'):-len('_f64')]
+                assert abs(eng.sigmas()[scope] - float(v)) <= RTOL * float(v), (step, scope)
+    pre = 'step%d/' % (n_steps - 1)
+    if (pre + 'grad/dis/l1_f32/kernel/kernel_f64') in fx:          # gradients of the last step
+        grads = eng.get_variables(grad=True)
+        gscale = {net: max(np.abs(fx[pre + 'grad/' + n + '_f64']).max() for n in grads if n.startswith(net))
+                  for net in ('gen', 'dis')}
+        for n, g in grads.items():
+            ref = fx[pre + 'grad/' + n + '_f64']
+            # floor: dL/d(last D bias) is analytically 0; allow 1e-6 of the net's gradient scale
+            assert close(g, ref, RTOL, 1e-6 * gscale[n[:3]]), (n, np.abs(g - ref).max(), np.abs(ref).max())
+    final = eng.get_variables()
+    for n, v in final.items():                                     # weights, SN vectors, BN moving stats
+        if n == 'dis/l8_s/bias/bias':
+            # the loss sees only score DIFFERENCES, so dL/d(last bias) == 0 analytically; what every
+            # implementation (the reference too) feeds Adam there is rounding noise ~1e-17, which Adam
+            # normalises into +-lr-sized random steps.  Not comparable; bounded instead.
+            assert np.abs(v - fx['init/' + n]).max() <= 3.5 * float(fx['lr'][0])
+            continue
+        ref = fx['final/' + n + '_f64']
+        # Adam turns gradient noise below eps into O(lr) steps only where |g| ~ 1e-8; weights move by
+        # <= 3*lr in 3 steps, so compare at 1e-4 of the tensor scale plus 2% of one lr step
+        assert close(v, ref, RTOL, 0.02 * float(fx['lr'].max())), (n, np.abs(v - ref).max(), np.abs(ref).max())
+
+
+def mid_architecture():
+    ak = float(np.power(64.0, 0.125))
+    s = 's'
+    return {'input': [(3, 32, 32)], 'code': [(64, 'linear')],
+            'generator': [{'name': 'l1', 'out': 128 * 4 * 4, 'op': 'd', 'act': 'relu', 'act_nm': 'bn', 'out_reshape': [128, 4, 4]},
+                          {'name': 'l2_up', 'out': 64, 'op': 'tc', 'act': 'relu', 'act_nm': 'bn', 'kernel': 4, 'strides': 2},
+                          {'name': 'l3_up', 'out': 64, 'op': 'tc', 'act': 'relu', 'act_nm': 'bn', 'kernel': 4, 'strides': 2},
+                          {'name': 'l4_up', 'out': 64, 'op': 'tc', 'act': 'relu', 'act_nm': 'bn', 'kernel': 4, 'strides': 2},
+                          {'name': 'l5_t32', 'out': 3, 'act': 'tanh'}],
+            'discriminator': [{'name': 'l1_f32', 'out': 64, 'act': 'lrelu', 'act_k': ak, 'w_nm': s},
+                              {'name': 'l2_ds', 'out': 64, 'act': 'lrelu', 'act_k': ak, 'w_nm': s, 'kernel': 4, 'strides': 2},
+                              {'name': 'l3', 'out': 128, 'act': 'lrelu', 'act_k': ak, 'w_nm': s},
+                              {'name': 'l4_ds', 'out': 128, 'act': 'lrelu', 'act_k': ak, 'w_nm': s, 'kernel': 4, 'strides': 2,
+                               'out_reshape': [8 * 8 * 128]},
+                              {'name': 'l5_s', 'out': 16, 'op': 'd', 'act_k': ak, 'bias': 'b', 'w_nm': s}]}
+
+
+@pytest.mark.parametrize('loss_type', ['rep', 'rmb'])
+def test_step_matches_oracle_mfma_path(loss_type):
+    """channel counts here are tile multiples, so the MFMA implicit-GEMM kernels (not the direct
+    ones) carry the conv stack.  4 steps against the fp64 oracle; before every step the engine's
+    variables are re-synchronised to the oracle's (an fp32 and an fp64 Adam trajectory separate
+    chaotically, which would test nothing), then scores, losses, every gradient and every
+    updated variable of that step are compared."""
+    from mmdgan_hip.engine import GanEngine
+    arch, B = mid_architecture(), 16
+    eng = GanEngine(arch, loss_type, (5e-4, 2e-4), batch_size=B, seed=3)
+    ora = R.OracleGan(arch, loss_type, (5e-4, 2e-4), dtype=torch.float64, params=eng.get_variables())
+    rs = np.random.RandomState(42)
+    last_bias = 'dis/l5_s/bias/bias'                    # analytically zero gradient, see above
+    for step in range(4):
+        z = rs.randn(B, 64).astype(np.float32)
+        real = rs.uniform(-1, 1, (B, 3, 32, 32)).astype(np.float32)
+        prev_vars = {k: v.numpy().copy() for k, v in ora.params.items()}
+        eng.set_variables(prev_vars)
+        zt, rt = torch.tensor(z, dtype=torch.float64), torch.tensor(real, dtype=torch.float64)
+        lg, ld, stats, upd, gd, gg, (gen, s_x, s_gen) = ora.grads(zt, rt)
+        ora.step(zt, rt)
+        eng.step(nhwc(real), torch.as_tensor(z).cuda())
+        # D scores = the deepest conv-stack activations: the 1e-4 bar of BASELINE.json
+        scores = eng.buf['dis/l5_s#y'].cpu().numpy()
+        assert close(scores[:B], s_x.detach().numpy(), RTOL, 0.0), step
+        assert close(scores[B:], s_gen.detach().numpy(), RTOL, 0.0), step
+        fake = np.transpose(eng.buf['dis_in'][B:].cpu().numpy(), (0, 3, 1, 2))
+        assert close(fake, gen.detach().numpy(), RTOL, 0.0), step
+        # losses: differences of O(1) kernel means (condition number escale/|loss| ~ 100 here), so
+        # activation error e shows up as ~e*escale: 1e-4*|loss| plus 1e-5 of the kernel-mean scale
+        losses = eng.losses.cpu().numpy().astype(np.float64)
+        escale = float(max(losses[2:5]))
+        assert abs(losses[0] - float(lg)) <= RTOL * abs(float(lg)) + 1e-5 * escale, (step, losses[0], float(lg))
+        assert abs(losses[1] - float(ld)) <= RTOL * abs(float(ld)) + 1e-5 * escale, (step, losses[1], float(ld))
+        if step == 0:
+            continue                                    # step-0 gradients are rounding noise
+        grads = eng.get_variables(grad=True)
+        ref_g = dict(gd)
+        ref_g.update(gg)
+        for net in ('gen', 'dis'):
+            gscale = max(float(ref_g[n].abs().max()) for n in grads if n.startswith(net))
+            for n in grads:
+                if n.startswith(net) and n != last_bias:
+                    # L2-relative, not max-abs: one ReLU mask flip at an element whose BN output is
+                    # ~1e-7 (fp32 vs fp64 rounding; measured: 1 of 1M elements) moves a handful of
+                    # gradient entries by ~1e-3 of the max and leaves the rest at ~2e-6
+                    r = ref_g[n].numpy()
+                    l2 = np.linalg.norm(grads[n].astype(np.float64) - r) / (np.linalg.norm(r) + 1e-6 * gscale)
+                    assert l2 <= 5e-3, (step, n, l2)
+                    assert close(grads[n], r, 2e-2, 1e-4 * gscale), (step, n)
+        final = eng.get_variables()
+        for n, v in final.items():
+            if n == last_bias:
+                continue
+            ref = ora.params[n].numpy()
+            if n.endswith('in_rand') or '/moving_' in n:          # UPDATE_OPS state: no optimiser in between
+                assert close(v, ref, RTOL, 0.0), (step, n)
+            else:
+                # Adam divides by sqrt(v): an entry whose gradient is below the mask-flip noise moves by
+                # up to +-lr in either implementation, so compare the UPDATE in L2 (TF-Adam itself is
+                # checked exactly in test_ops_gpu.py::test_sn_helpers_and_adam)
+                before = prev_vars[n]
+                du, dr = v.astype(np.float64) - before, ref - before
+                assert np.linalg.norm(du - dr) <= 0.1 * np.linalg.norm(dr) + 1e-12, (step, n)
+                assert np.abs(v - ref).max() <= 2.5 * 5e-4, (step, n)
