@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Benchmark of the MMD-GAN hot path on MI355X: one step = one G+D training step (G fwd, D fwd on
+[real;fake], SN power iteration, rep loss, both backward passes, both TF-Adam updates, SN/BN state
+updates) of the CIFAR-10-shaped 32x32 DCGAN-SN at batch 64 per GPU (BASELINE.json configs[1]),
+synthetic data resident in HBM.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0: metric images/sec (whole job), ms_per_step, `roofline` (fp32-MFMA
+bound: algorithmic FLOPs of the step B*(3 F_G + 7 F_D) over the HIP-event step time, and the same
+for the single dominant kernel launch) and `cpu_baseline` (the oracle restatement timed on the
+host cores, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(ROOT, 'mmd-gan_amd'), ROOT]
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md (f32-input MFMA = vector peak)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--config', default='cifar', choices=['cifar', 'stl', 'celeba'])
+    ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: 64; 128 for celeba)')
+    ap.add_argument('--loss', default='rep', choices=['rep', 'rmb'])
+    ap.add_argument('--no-graph', action='store_true', help='issue launches eagerly instead of one hipGraph')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-steps', type=int, default=3)
+    return ap.parse_args()
+
+
+def dominant_kernel_probe(eng, reps=20):
+    """HIP-event timing of the single heaviest launch of the step, issued on the stream it normally
+    runs on: the weight gradient of the widest 3x3 D layer at batch 2B (D l5 for CIFAR)."""
+    from mmdgan_hip import ops
+    best = None
+    for s in eng.dis.specs:
+        if s.op == 'c' and s.R == 3 and s.stride == 1 and s.in_shape_ref[0] >= 64:
+            c, h, w = s.in_shape_ref
+            flops = 2.0 * 2 * eng.B * h * w * s.R * s.R * c * s.out
+            if best is None or flops >= best[1]:
+                best = (s, flops)
+    if best is None:
+        return None
+    s, flops = best
+    li = eng.dis.specs.index(s)
+    x = eng.buf[eng.dis.specs[li - 1].scope + '#y']
+    dz = eng.buf[s.scope + '#dz']
+    gw = torch.empty(s.kernel_shape, device=x.device)
+    for _ in range(3):
+        ops.conv2d_wgrad(x, dz, s.R, s.stride, out=gw)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.conv2d_wgrad(x, dz, s.R, s.stride, out=gw)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    return {'kernel': 'igemm_wgrad(%s: %dx%dx%d->%d, batch %d)' % (s.scope, h, w, c, s.out, 2 * eng.B),
+            'flops': flops, 'ms': ms, 'tflops': flops / ms / 1e9}
+
+
+def cpu_baseline(arch, lr, loss, B, steps):
+    """the oracle restatement (fp32 torch-CPU) of the same step on the host cores: a reported
+    baseline, not the optimisation target."""
+    from oracle import restatement as R
+    threads = torch.get_num_threads()
+    gan = R.OracleGan(arch, loss, tuple(lr), dtype=torch.float32, seed=0)
+    rs = np.random.RandomState(1234)
+    real = torch.tensor(rs.uniform(-1, 1, (B,) + tuple(arch['input'][0])).astype(np.float32))
+    z = torch.tensor(rs.randn(B, arch['code'][0][0]).astype(np.float32))
+    gan.step(z, real)                                   # warm-up (allocator, oneDNN primitive cache)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gan.step(z, real)
+    dt = time.perf_counter() - t0
+    return {'value': B * steps / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'sample': '%d G+D steps of the same %dx%d B=%d workload, oracle/restatement.py fp32 on torch-CPU '
+                      '(%.1f s)' % (steps, arch['input'][0][1], arch['input'][0][2], B, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % args.gpus)
+    torch.cuda.set_device(local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))     # RCCL over xGMI
+        group = dist.group.WORLD
+
+    import configs
+    from mmdgan_hip.engine import GanEngine
+    arch, lr = configs.CONFIGS[args.config]()
+    B = args.batch or (128 if args.config == 'celeba' else 64)
+    eng = GanEngine(arch, args.loss, lr, batch_size=B, seed=0, dist_group=group,
+                    use_graph=not args.no_graph)
+    if world > 1:
+        from mmdgan_hip import dist as mdist
+        mdist.broadcast_state(eng, group)                # identical weights / SN vectors on every replica
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(1234 + rank)
+    c, h, w = arch['input'][0]
+    real = torch.empty(B, h, w, c, device='cuda').uniform_(-1, 1, generator=gen)    # synthetic, resident in HBM
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.step(real)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        eng.step(real)
+    ev1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1) / args.steps
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = eng.losses.cpu().numpy()
+    assert np.all(np.isfinite(losses)), 'Model diverged with loss = NaN'               # graph_func.py:856
+
+    if rank == 0:
+        fg, fd = configs.flops_per_image(arch)
+        flops_step = B * (3.0 * fg + 7.0 * fd)
+        ms_per_step = dt / args.steps * 1e3
+        achieved = flops_step / (ev_ms * 1e-3) / 1e12
+        out = {
+            'metric': 'images/sec/node (G+D step), CIFAR-10 32x32 B=64' if args.config == 'cifar'
+                      else 'images/sec/node (G+D step), %s B=%d' % (args.config, B),
+            'value': B * world * args.steps / dt, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s %dx%d DCGAN-SN, batch %d per GPU, %s loss, lr %g/%g, TF-Adam, one G+D step'
+                                   % (args.config, h, w, B, args.loss, lr[0], lr[1]),
+                       'global_batch': B * world, 'parallelism': 'dp%d' % world, 'hip_graph': not args.no_graph},
+            'loss_gen': float(losses[0]), 'loss_dis': float(losses[1]),
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                         'scope': 'whole step: B*(3*F_G+7*F_D) = %.1f GFLOP over the HIP-event step time %.3f ms'
+                                  % (flops_step / 1e9, ev_ms)},
+        }
+        probe = dominant_kernel_probe(eng)
+        if probe:
+            out['roofline']['dominant_kernel'] = {
+                'name': probe['kernel'], 'gflop_per_launch': probe['flops'] / 1e9, 'ms_per_launch': probe['ms'],
+                'achieved': probe['tflops'], 'frac': probe['tflops'] / PEAK_FP32_MFMA_TFLOPS}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(arch, lr, args.loss, B, args.cpu_steps)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

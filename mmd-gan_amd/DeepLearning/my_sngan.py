@@ -1,0 +1,138 @@
+"""SNGan: the reference's model class (DeepLearning/my_sngan.py:31-690) over the HIP engine.
+
+Kept: constructor and method signatures (my_sngan.py:31-70, 364-365, 499-502, 602), the
+architecture-dict and loss-name vocabulary, the step semantics (one simultaneous D+G update per
+step from one forward pass) and the error behaviour for bad arguments.  Not kept:
+TF graphs/sessions, summaries, the tfrecord reader and the Inception scorer (SURVEY.md section 8
+marks them out of scope); `mdl_score` says so instead of pretending.
+"""
+from math import gcd
+
+import numpy as np
+import torch
+
+from GeneralTools.misc_fun import FLAGS
+from GeneralTools.graph_func import prepare_folder
+from mmdgan_hip import ops
+from mmdgan_hip.engine import GanEngine
+
+
+class SNGan(object):
+    def __init__(self, architecture, num_class=0, loss_type='logistic', optimizer='adam', do_summary=True,
+                 do_summary_image=True, num_summary_image=8, image_transpose=False, **kwargs):
+        self.optimizer_type = ['sgd', 'momentum', 'adam', 'rmsprop']
+        self.data_format = FLAGS.IMAGE_FORMAT
+        self.architecture, self.loss_type, self.optimizer = architecture, loss_type, optimizer
+        self.num_class = num_class
+        self.channels, self.height, self.width = architecture['input'][0]
+        self.input_size = int(np.prod(architecture['input'][0]))
+        self.code_size = architecture['code'][0][0]
+        self.score_size = architecture['discriminator'][-1]['out']
+        self.do_summary, self.do_summary_image, self.num_summary_image = do_summary, do_summary_image, num_summary_image
+        self.loss_names = '<loss_gen>, <loss_dis>'
+        self.global_step = None
+        self.step_per_epoch = None
+        self.sample_same_class = False
+        self.force_print = True
+        self.rep_weights = kwargs['rep_weights'] if 'rep_weights' in kwargs else [0.0, -1.0]
+        self.penalty_weight = kwargs['mmd_g_scale'] if 'mmd_g_scale' in kwargs else 0.1
+        if image_transpose:
+            raise NotImplementedError('image_transpose is outside the hot path')
+        if num_class > 1:
+            raise NotImplementedError('conditional models are outside the hot path')
+        if loss_type not in ops.LOSS:
+            raise NotImplementedError('Not implemented.')                      # math_func.py:2651
+        if optimizer != 'adam':
+            raise NotImplementedError('only the adam branch of opt_config is on the hot path (graph_func.py:518-527)')
+        self.engine = None
+        self.dist_group = kwargs.get('dist_group')
+
+    # --------------------------------------------------------------------------------------
+    def init_net(self, lr_list, batch_size, seed=0):
+        """G and D with their optimisers (my_sngan.py:85-108, 412-415)."""
+        if self.engine is None or self.engine.B != batch_size:
+            self.engine = GanEngine(self.architecture, self.loss_type, lr_list, tuple(self.rep_weights),
+                                    batch_size=batch_size, seed=seed, dist_group=self.dist_group,
+                                    use_graph=self.dist_group is None)
+        else:
+            self.engine.lr_d, self.engine.lr_g = float(lr_list[0]), float(lr_list[1])
+        return self.engine
+
+    def get_data_batch(self, filename, batch_size, num_instance):
+        """returns fn() -> NHWC fp32 batch on the device, values in [-1, 1] (input_func.py:839)."""
+        dev = torch.device('cuda')
+        shape = (batch_size, self.height, self.width, self.channels)
+        if FLAGS.SYNTHETIC_DATA:
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(1234)
+            buf = torch.empty(shape, device=dev)
+            return lambda: buf.uniform_(-1, 1, generator=gen)
+        path = FLAGS.DEFAULT_IN + (filename if isinstance(filename, str) else filename[0]) + '.npy'
+        try:
+            data = np.load(path, mmap_mode='r')           # uint8 [N, C, H, W], the converters' pixel layout
+        except OSError:
+            raise FileNotFoundError('{} not found: the tfrecord reader is outside the hot path; provide a uint8 '
+                                    '[N,C,H,W] .npy or set FLAGS.SYNTHETIC_DATA = True'.format(path))
+        rs = np.random.RandomState(0)
+
+        def next_batch():
+            idx = np.sort(rs.randint(0, min(num_instance, data.shape[0]), batch_size))
+            x = torch.as_tensor(np.ascontiguousarray(data[idx])).to(dev).float().div_(127.5).sub_(1.0)
+            return ops.nchw_to_nhwc(x.contiguous())
+        return next_batch
+
+    # --------------------------------------------------------------------------------------
+    def training(self, filename, agent, num_instance, lr_list, end_lr=1e-7, max_step=None, batch_size=64,
+                 sample_same_class=False, num_threads=7, gpu='/gpu:0'):
+        self.step_per_epoch = int(np.floor(num_instance / batch_size))
+        self.sample_same_class = sample_same_class
+        if max_step >= self.step_per_epoch:
+            file_repeat = int(batch_size / gcd(num_instance, batch_size))     # my_sngan.py:383-385
+        else:
+            if isinstance(filename, str) or (isinstance(filename, (list, tuple)) and len(filename) == 1):
+                raise AttributeError('max_step should be larger than step_per_epoch when there is a single file.')
+            file_repeat = 1
+        FLAGS.print('Num Instance: {}; Num Class: {}; Batch: {}; File_repeat: {}'.format(
+            num_instance, self.num_class, batch_size, file_repeat))
+        eng = self.init_net(lr_list, batch_size)
+        next_batch = self.get_data_batch(filename, batch_size, num_instance)
+        FLAGS.print('Shape of input batch: {}'.format([batch_size, self.channels, self.height, self.width]))
+        FLAGS.print('loss_list name: {}.'.format(self.loss_names))
+
+        def step_fn():
+            eng.step(next_batch())              # z ~ N(0,1) sampled on the device (my_sngan.py:123-124)
+
+        def read_losses():
+            lg, ld = eng.losses[:2].tolist()
+            return lg, ld
+        agent.train([step_fn], read_losses, eng, max_step, self.step_per_epoch, None, None,
+                    force_print=self.force_print)
+        self.global_step = eng.global_step
+        self.force_print = False
+
+    # --------------------------------------------------------------------------------------
+    def eval_sampling(self, filename, sub_folder, mesh_num=None, mesh_mode=0, if_invert=False, code_x=None,
+                      code_y=None, real_sample=False, sample_same_class=False, get_dis_score=False, do_embedding=False,
+                      do_sprite=True, ckpt_file=None, num_threads=7):
+        """G(code_x) with BN moving statistics, clipped to [-1,1]; returns NCHW numpy (my_sngan.py:499-581).
+        The sprite/embedding writers are cosmetic and outside the hot path: the array is saved as .npy."""
+        if self.engine is None:
+            raise RuntimeError('eval_sampling: train (or load) a model first')
+        n = int(np.prod(mesh_num)) if mesh_num is not None else self.engine.B
+        if code_x is None:
+            code_x = np.random.randn(n, self.code_size).astype(np.float32)
+        code_x = torch.as_tensor(np.asarray(code_x, np.float32)).cuda()
+        outs = []
+        for i in range(0, code_x.shape[0], self.engine.B):
+            z = code_x[i:i + self.engine.B].contiguous()
+            img = self.engine.generate(z, is_training=False)
+            outs.append(ops.nhwc_to_nchw(img.contiguous()).clamp_(-1, 1).cpu().numpy())
+        x_gen = np.concatenate(outs, 0)
+        if do_sprite:
+            _, summary_folder, _ = prepare_folder(filename, sub_folder=sub_folder)
+            np.save('{}/{}_step_{}.npy'.format(summary_folder, filename, self.engine.global_step), x_gen)
+        return x_gen
+
+    def mdl_score(self, filename, sub_folder, batch_size, num_batch=10, model='v1', ckpt_file=None, num_threads=7):
+        raise NotImplementedError('mdl_score needs the frozen Inception-v1 graph (graph_func.py:1748-1799), which '
+                                  'is not in the repository and is outside the hot path (SURVEY.md section 8)')

@@ -1,0 +1,71 @@
+"""Loss-side API of the reference's math_func.py, served by the fused HIP kernel.
+
+Kept names and signatures: get_squared_dist (math_func.py:767) and GANLoss (:2088) with
+.apply(score_gen, score_data, loss_type, **kwargs) -> (loss_gen, loss_dis); matrix_mean_wo_diagonal
+(:1048), mmd_g (:1288) and mmd_g_bounded (:1356) are fused inside the kernel and have no separate
+entry (the B x B matrices they take are never materialised).  Inputs are [B, d] fp32 CUDA tensors; results are
+device tensors (no host synchronisation).  Only the hot-path loss names are implemented ('rep',
+'rmb' and their aliases, math_func.py:2644-2647); every other name raises exactly as the
+reference does for an unknown one.
+"""
+from mmdgan_hip import ops
+
+_NOT_ON_HOT_PATH = {'logistic', '', 'hinge', 'wasserstein', 'fixed_g', 'mmd_g', 'mgb', 'fixed_t', 'mmd_t',
+                    'mmd_g_mix', 'fixed_g_mix', 'sgm', 'rand_g', 'rgb', 'rand_g_mix', 'sym_rg_mix', 'sym_rg',
+                    'sym_rand_g', 'instance_noise', 'ins_noise', 'rep_gp', 'rep_ds', 'rmb_gp', 'rmb_ds', 'test'}
+
+
+def get_squared_dist(x, y=None, scale=None, z_score=False, mode='xxxyyy', name='squared_dist',
+                     do_summary=False, scope_prefix=''):
+    """pairwise squared distances in the reference's Gram form (math_func.py:799-840)."""
+    if x.dim() > 2:
+        raise AttributeError('get_dist: Input must be a matrix.')
+    if scale is not None or z_score:
+        raise NotImplementedError('get_squared_dist: scale / z_score are outside the hot path')
+    if y is None:
+        mode, y = 'xx', x
+    if mode not in ('xx', 'xy', 'xxxy', 'xxxyyy'):
+        raise AttributeError('Mode {} not supported'.format(mode))
+    d = ops.mmd_loss(x.contiguous(), y.contiguous(), 'rep', need_grads=False, need_dist=True)['dist']
+    return {'xx': d[0], 'xy': d[1], 'xxxy': (d[0], d[1]), 'xxxyyy': (d[0], d[1], d[2])}[mode]
+
+
+class GANLoss(object):
+    def __init__(self, do_summary=False):
+        self.do_summary = do_summary
+        self.score_gen = self.score_data = None
+        self.batch_size = self.num_scores = None
+        self.loss_gen = self.loss_dis = None
+        self.dis_penalty = self.dis_scale = None
+        self.debug_register = None
+        self.repulsive_weights = [0.0, -1.0]          # math_func.py:2115
+        self.grads = None                             # [4,B,d]: dLg/dsg, dLg/dsx, dLd/dsg, dLd/dsx
+        self.stats = None                             # e_kxx, e_kxy, e_kyy, e_kxx_b, e_kyy_b
+
+    def __call__(self, score_gen, score_data, loss_type='logistic', **kwargs):
+        self.score_gen, self.score_data = score_gen, score_data
+        for key, attr in (('batch_size', 'batch_size'), ('d', 'num_scores'), ('dis_penalty', 'dis_penalty'),
+                          ('dis_scale', 'dis_scale'), ('rep_weights', 'repulsive_weights')):
+            if key in kwargs:
+                setattr(self, attr, kwargs[key])
+        if loss_type in {'rep', 'rmb'} | ops.LOSS.keys():
+            assert self.batch_size is not None, 'GANLoss: batch_size must be provided'   # math_func.py:2592
+        if loss_type not in ops.LOSS:
+            if loss_type in _NOT_ON_HOT_PATH:
+                raise NotImplementedError('Not implemented.')     # outside SURVEY section 8 scope
+            raise NotImplementedError('Not implemented.')         # math_func.py:2651
+        w = self.repulsive_weights
+        assert w[0] - w[1] == 1.0, 'w[0]-w[1] must be 1'          # math_func.py:1340
+        out = ops.mmd_loss(score_gen.contiguous(), score_data.contiguous(), loss_type, tuple(w), need_grads=True)
+        self.loss_gen, self.loss_dis = out['scalars'][0], out['scalars'][1]
+        self.stats, self.grads = out['scalars'][2:7], out['grads']
+        if self.dis_penalty is not None:
+            self.loss_dis = self.loss_dis + self.dis_penalty
+        return self.loss_gen, self.loss_dis
+
+    def apply(self, score_gen, score_data, loss_type='logistic', **kwargs):
+        return self.__call__(score_gen, score_data, loss_type=loss_type, **kwargs)
+
+    def get_register(self):
+        registered_info, self.debug_register = self.debug_register, None
+        return registered_info

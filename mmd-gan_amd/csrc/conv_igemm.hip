@@ -43,8 +43,19 @@ struct TileCfg {
     static constexpr int SMEM_FLOATS = 2 * BK * (LDA + LDB);
 };
 
-__device__ __forceinline__ float4 ldg4(const float *p, bool ok) {
-    return ok ? *reinterpret_cast<const float4 *>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+// Gathers go through buffer loads: the hardware range check returns 0 for an offset beyond
+// num_records, so zero padding ('SAME' borders, ragged last tile) is an offset select instead of a
+// divergent branch around the load.  The descriptor is built from kernel arguments only
+// (wave-uniform, so no waterfall loop is generated).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOOB = 0x80000000u;          // every tensor here is < 2 GiB
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *base, long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 bufld4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
 // k-contiguous source element f of a ROWS x BK tile: row = f/4, kq = f%4; transposing store
@@ -84,39 +95,43 @@ __device__ __forceinline__ void mma_stage(const float *As, const float *Bs, f32x
 
 // generic main loop: P supplies load_a/load_b (global -> registers for one stage) and says
 // whether each operand is k-contiguous (transposing LDS store) or m-contiguous.
+// `smem` must be the kernel's own __shared__ array: buffers are addressed by arithmetic on that
+// base (never through an array of pointers), so the compiler keeps the LDS address space and
+// emits ds_read/ds_write - a pointer table degrades every access to flat_load/flat_store.
 template <int BM, int BN, class P>
 __device__ __forceinline__ void mainloop(P &p, int s_begin, int s_end, float *smem,
                                          f32x16 (&acc)[TileCfg<BM, BN>::TM][TileCfg<BM, BN>::TN]) {
     using T = TileCfg<BM, BN>;
+    constexpr int A_BUF = BK * T::LDA, B_BUF = BK * T::LDB, B_OFF = 2 * A_BUF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    float *As[2] = {smem, smem + BK * T::LDA};
-    float *Bs[2] = {smem + 2 * BK * T::LDA, smem + 2 * BK * T::LDA + BK * T::LDB};
     float4 ra[T::A_F4], rb[T::B_F4];
-    auto store = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < T::A_F4; ++i) {
-            if (P::A_KC) sts_kc(As[buf], T::LDA, tid + 256 * i, ra[i]);
-            else sts_mc<BM>(As[buf], T::LDA, tid + 256 * i, ra[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < T::B_F4; ++i) {
-            if (P::B_KC) sts_kc(Bs[buf], T::LDB, tid + 256 * i, rb[i]);
-            else sts_mc<BN>(Bs[buf], T::LDB, tid + 256 * i, rb[i]);
-        }
-    };
     if (s_begin >= s_end) return;
     p.load_a(s_begin, ra);
     p.load_b(s_begin, rb);
-    store(0);
+#define MMDGAN_STORE_STAGE(BUF)                                                                          \
+    {                                                                                                    \
+        float *As_ = smem + (BUF) * A_BUF;                                                               \
+        float *Bs_ = smem + B_OFF + (BUF) * B_BUF;                                                       \
+        _Pragma("unroll") for (int i = 0; i < T::A_F4; ++i) {                                            \
+            if (P::A_KC) sts_kc(As_, T::LDA, tid + 256 * i, ra[i]);                                      \
+            else sts_mc<BM>(As_, T::LDA, tid + 256 * i, ra[i]);                                          \
+        }                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < T::B_F4; ++i) {                                            \
+            if (P::B_KC) sts_kc(Bs_, T::LDB, tid + 256 * i, rb[i]);                                      \
+            else sts_mc<BN>(Bs_, T::LDB, tid + 256 * i, rb[i]);                                          \
+        }                                                                                                \
+    }
+    MMDGAN_STORE_STAGE(0)
     __syncthreads();
     for (int s = s_begin; s < s_end; ++s) {
         const int buf = (s - s_begin) & 1;
         const bool more = s + 1 < s_end;
         if (more) { p.load_a(s + 1, ra); p.load_b(s + 1, rb); }
-        mma_stage<BM, BN>(As[buf], Bs[buf], acc, wm, wn, lane);
-        if (more) store(buf ^ 1);
+        mma_stage<BM, BN>(smem + buf * A_BUF, smem + B_OFF + buf * B_BUF, acc, wm, wn, lane);
+        if (more) MMDGAN_STORE_STAGE(buf ^ 1)
         __syncthreads();
     }
+#undef MMDGAN_STORE_STAGE
 }
 
 // C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -142,26 +157,27 @@ struct FwdProblem {
     static constexpr bool A_KC = true, B_KC = false;
     using T = TileCfg<BM, BN>;
     ConvDims d;
-    const float *x, *w;
+    __amdgpu_buffer_rsrc_t rx, rw;
     int n0;
-    const float *abase[T::A_F4];
-    int ah0[T::A_F4], aw0[T::A_F4];
-    bool aok[T::A_F4];
+    unsigned abase[T::A_F4];          // byte offset of (n, 0, 0, kq*4)
+    int ah0[T::A_F4], aw0[T::A_F4];   // ah0 = INT_MIN/2 marks a row beyond M
     __device__ void init(const ConvDims &dd, const float *x_, const float *w_, int m0, int n0_, long M) {
-        d = dd; x = x_; w = w_; n0 = n0_;
+        d = dd; n0 = n0_;
+        rx = make_rsrc(x_, (long)d.N * d.H * d.W * d.C * 4);
+        rw = make_rsrc(w_, (long)d.R * d.R * d.C * d.K * 4);
 #pragma unroll
         for (int i = 0; i < T::A_F4; ++i) {
             const int f = threadIdx.x + 256 * i;
             const long m = (long)m0 + (f >> 2);
-            aok[i] = m < M;
-            const long mm = aok[i] ? m : 0;
+            const bool ok = m < M;
+            const long mm = ok ? m : 0;
             const int q = mm % d.Q;
             const long t = mm / d.Q;
             const int p = t % d.P;
             const int n = t / d.P;
-            ah0[i] = p * d.stride - d.pad;
+            ah0[i] = ok ? p * d.stride - d.pad : -(1 << 28);
             aw0[i] = q * d.stride - d.pad;
-            abase[i] = x + (long)n * d.H * d.W * d.C + (f & 3) * 4;
+            abase[i] = (unsigned)(((long)n * d.H * d.W * d.C + (f & 3) * 4) * 4);
         }
     }
     __device__ __forceinline__ void load_a(int s, float4 (&ra)[T::A_F4]) const {
@@ -171,8 +187,9 @@ struct FwdProblem {
 #pragma unroll
         for (int i = 0; i < T::A_F4; ++i) {
             const int h = ah0[i] + r, ww = aw0[i] + t;
-            const bool ok = aok[i] && h >= 0 && h < d.H && ww >= 0 && ww < d.W;
-            ra[i] = ldg4(abase[i] + ((long)h * d.W + ww) * d.C + c0, ok);
+            const bool ok = h >= 0 && h < d.H && ww >= 0 && ww < d.W;
+            const unsigned off = abase[i] + (unsigned)(((h * d.W + ww) * d.C + c0) * 4);
+            ra[i] = bufld4(rx, ok ? off : kOOB);
         }
     }
     __device__ __forceinline__ void load_b(int s, float4 (&rb)[T::B_F4]) const {
@@ -180,7 +197,7 @@ struct FwdProblem {
         for (int i = 0; i < T::B_F4; ++i) {
             const int f = threadIdx.x + 256 * i;
             const int k = f / (BN / 4), c4 = f % (BN / 4);
-            rb[i] = *reinterpret_cast<const float4 *>(w + (long)(s * BK + k) * d.K + n0 + c4 * 4);
+            rb[i] = bufld4(rw, (unsigned)((((s * BK + k) * d.K) + n0 + c4 * 4) * 4));
         }
     }
 };
@@ -229,15 +246,16 @@ struct DgradProblem {
     static constexpr bool A_KC = true, B_KC = true;
     using T = TileCfg<BM, BN>;
     ConvDims d;
-    const float *dy, *w;
+    __amdgpu_buffer_rsrc_t rdy, rw;
     int TT, rbase, tbase, pbase, qbase;
-    const float *abase[T::A_F4];
+    unsigned abase[T::A_F4];
     int ahh[T::A_F4], aww[T::A_F4];
-    bool aok[T::A_F4];
-    const float *bbase[T::B_F4];
+    unsigned bbase[T::B_F4];
     __device__ void init(const ConvDims &dd, const float *dy_, const float *w_, int m0, int n0, int ph, int pw, int Hh,
                          int Ww, long M) {
-        d = dd; dy = dy_; w = w_;
+        d = dd;
+        rdy = make_rsrc(dy_, (long)d.N * d.P * d.Q * d.K * 4);
+        rw = make_rsrc(w_, (long)d.R * d.R * d.C * d.K * 4);
         TT = d.R / d.stride;
         rbase = (ph + d.pad) % d.stride; tbase = (pw + d.pad) % d.stride;
         pbase = (ph + d.pad) / d.stride; qbase = (pw + d.pad) / d.stride;
@@ -245,18 +263,18 @@ struct DgradProblem {
         for (int i = 0; i < T::A_F4; ++i) {
             const int f = threadIdx.x + 256 * i;
             const long m = (long)m0 + (f >> 2);
-            aok[i] = m < M;
-            const long mm = aok[i] ? m : 0;
+            const bool ok = m < M;
+            const long mm = ok ? m : 0;
             aww[i] = mm % Ww;
             const long t = mm / Ww;
-            ahh[i] = t % Hh;
+            ahh[i] = ok ? (int)(t % Hh) : -(1 << 28);
             const int n = t / Hh;
-            abase[i] = dy + (long)n * d.P * d.Q * d.K + (f & 3) * 4;
+            abase[i] = (unsigned)(((long)n * d.P * d.Q * d.K + (f & 3) * 4) * 4);
         }
 #pragma unroll
         for (int i = 0; i < T::B_F4; ++i) {
             const int f = threadIdx.x + 256 * i;
-            bbase[i] = w + (long)(n0 + (f >> 2)) * d.K + (f & 3) * 4;     // + tap*C*K + co0 per stage
+            bbase[i] = (unsigned)(((long)(n0 + (f >> 2)) * d.K + (f & 3) * 4) * 4);     // + tap*C*K + co0 per stage
         }
     }
     __device__ __forceinline__ void load_a(int s, float4 (&ra)[T::A_F4]) const {
@@ -266,8 +284,9 @@ struct DgradProblem {
 #pragma unroll
         for (int i = 0; i < T::A_F4; ++i) {
             const int p = ahh[i] + pbase - jr, q = aww[i] + qbase - jt;
-            const bool ok = aok[i] && p >= 0 && p < d.P && q >= 0 && q < d.Q;
-            ra[i] = ldg4(abase[i] + ((long)p * d.Q + q) * d.K + co0, ok);
+            const bool ok = p >= 0 && p < d.P && q >= 0 && q < d.Q;
+            const unsigned off = abase[i] + (unsigned)(((p * d.Q + q) * d.K + co0) * 4);
+            ra[i] = bufld4(rdy, ok ? off : kOOB);
         }
     }
     __device__ __forceinline__ void load_b(int s, float4 (&rb)[T::B_F4]) const {
@@ -275,9 +294,9 @@ struct DgradProblem {
         const int tap = k0 / d.K, co0 = k0 - tap * d.K;
         const int jr = tap / TT, jt = tap - jr * TT;
         const int r = rbase + jr * d.stride, t = tbase + jt * d.stride;
-        const long off = (long)(r * d.R + t) * d.C * d.K + co0;
+        const unsigned off = (unsigned)((((r * d.R + t) * d.C) * d.K + co0) * 4);
 #pragma unroll
-        for (int i = 0; i < T::B_F4; ++i) rb[i] = *reinterpret_cast<const float4 *>(bbase[i] + off);
+        for (int i = 0; i < T::B_F4; ++i) rb[i] = bufld4(rw, bbase[i] + off);
     }
 };
 
@@ -332,11 +351,13 @@ struct WgradProblem {
     static constexpr bool A_KC = false, B_KC = false;
     using T = TileCfg<BM, BN>;
     ConvDims d;
-    const float *x, *dy;
+    __amdgpu_buffer_rsrc_t rx, rdy;
     int r, t, c0, n0;
     long M;
     __device__ void init(const ConvDims &dd, const float *x_, const float *dy_, int i0, int n0_, long M_) {
-        d = dd; x = x_; dy = dy_; n0 = n0_; M = M_;
+        d = dd; n0 = n0_; M = M_;
+        rx = make_rsrc(x_, (long)d.N * d.H * d.W * d.C * 4);
+        rdy = make_rsrc(dy_, (long)d.N * d.P * d.Q * d.K * 4);
         const int tap = i0 / d.C;
         c0 = i0 - tap * d.C;
         r = tap / d.R; t = tap - r * d.R;
@@ -355,7 +376,8 @@ struct WgradProblem {
             const long n = u / d.P;
             const int h = p * d.stride - d.pad + r, ww = q * d.stride - d.pad + t;
             ok = ok && h >= 0 && h < d.H && ww >= 0 && ww < d.W;
-            ra[i] = ldg4(x + ((n * d.H + h) * d.W + ww) * d.C + c0 + c4 * 4, ok);
+            const unsigned off = (unsigned)((((n * d.H + h) * d.W + ww) * d.C + c0 + c4 * 4) * 4);
+            ra[i] = bufld4(rx, ok ? off : kOOB);
         }
     }
     __device__ __forceinline__ void load_b(int s, float4 (&rb)[T::B_F4]) const {
@@ -364,7 +386,7 @@ struct WgradProblem {
             const int f = threadIdx.x + 256 * i;
             const int k = f / (BN / 4), c4 = f % (BN / 4);
             const long m = (long)s * BK + k;
-            rb[i] = ldg4(dy + m * d.K + n0 + c4 * 4, m < M);
+            rb[i] = bufld4(rdy, m < M ? (unsigned)((m * d.K + n0 + c4 * 4) * 4) : kOOB);
         }
     }
 };

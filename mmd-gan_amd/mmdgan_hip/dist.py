@@ -1,0 +1,60 @@
+"""Data-parallel replicas: one process per GPU, gradients averaged with RCCL over xGMI.
+
+The reference is single-GPU; its dormant tower helper (graph_func.py:69-94, SynTower.average_grads)
+defines the semantics kept here: every replica computes loss and gradients on its own batch (the
+MMD statistic stays per-replica), gradients are AVERAGED, variables are
+shared.  SN vectors and BN moving statistics need no communication: they are deterministic
+functions of identical weights / per-replica statistics.
+
+Gradients live in one flat fp32 arena per network, so the exchange is a few large buckets.
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is bound by one link, so
+buckets are kept large (default 32 MiB) - latency, not bandwidth, is what many small buckets
+would pay.  The functions here are device-agnostic (tests run them on CPU tensors over gloo).
+"""
+import torch
+import torch.distributed as tdist
+
+DEFAULT_BUCKET_BYTES = 32 << 20
+
+
+def buckets(numel, bucket_bytes=DEFAULT_BUCKET_BYTES, elem_bytes=4):
+    """[(start, end), ...] covering [0, numel) in chunks of at most bucket_bytes."""
+    per = max(1, bucket_bytes // elem_bytes)
+    return [(s, min(numel, s + per)) for s in range(0, numel, per)]
+
+
+def allreduce_sum_async(flat, group=None, bucket_bytes=DEFAULT_BUCKET_BYTES):
+    """start a SUM all-reduce of `flat` bucket by bucket; returns the work handles.  The caller
+    divides by the world size (the Adam kernel's grad_scale does it for free)."""
+    works = []
+    for s, e in buckets(flat.numel(), bucket_bytes, flat.element_size()):
+        works.append(tdist.all_reduce(flat[s:e], op=tdist.ReduceOp.SUM, group=group, async_op=True))
+    return works
+
+
+def wait_all(works):
+    for w in works:
+        w.wait()
+
+
+def average_(flat, group=None, bucket_bytes=DEFAULT_BUCKET_BYTES):
+    """blocking mean over replicas, in place (used by tests and by hosts without fused scaling)."""
+    wait_all(allreduce_sum_async(flat, group, bucket_bytes))
+    flat.div_(tdist.get_world_size(group))
+    return flat
+
+
+def broadcast_state(eng, group=None, src=0):
+    """make every replica start from rank `src`'s weights, Adam moments, SN vectors and BN stats."""
+    for net in (eng.gen, eng.dis):
+        for t in (net.params, net.adam_m, net.adam_v, net.opt.step_counter):
+            tdist.broadcast(t, src=src, group=group)
+        for k in sorted(net.state):
+            tdist.broadcast(net.state[k], src=src, group=group)
+
+
+def shard_of(n_items, rank, world):
+    """contiguous shard [lo, hi) of n_items for this rank (synthetic-data / dataset sharding)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)

@@ -324,6 +324,7 @@ class GanEngine:
         if dist_group is not None:
             import torch.distributed as tdist
             self.world = tdist.get_world_size(dist_group)
+        self._pending = []
         self._alloc(self.B)
         self.losses = torch.zeros(8, device=self.device)       # filled by the loss kernel each step
         self.use_graph, self._graph = use_graph, None
@@ -595,12 +596,18 @@ class GanEngine:
 
     # ---------------------------------------------------------------------------------------
     def _allreduce(self, net):
+        """start the bucketed SUM all-reduce of one network's gradient arena (RCCL, its own stream);
+        it overlaps with whatever backward work is issued next and is awaited before Adam."""
         if self.dist_group is None or self.world == 1:
             return
-        import torch.distributed as tdist
-        tdist.all_reduce(net.grads, op=tdist.ReduceOp.SUM, group=self.dist_group)
+        from . import dist as mdist
+        self._pending += mdist.allreduce_sum_async(net.grads, self.dist_group)
 
     def _update(self):
+        if self._pending:
+            from . import dist as mdist
+            mdist.wait_all(self._pending)
+            self._pending = []
         gs = 1.0 / self.world
         self.dis.opt.step(self.lr_d, grad_scale=gs)
         self.gen.opt.step(self.lr_g, grad_scale=gs)
