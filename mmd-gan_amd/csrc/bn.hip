@@ -52,10 +52,13 @@ __global__ __launch_bounds__(256) void bn_stats_finish_kernel(const double *part
                                                               float eps, float momentum, int unbiased, float *save_mean,
                                                               float *save_invstd, const float *mm, const float *mv,
                                                               float *new_mm, float *new_mv) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    // one wave per channel: lanes stride over the splits, then a wave reduction (fixed order)
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double s = 0, s2 = 0;
-    for (int k = 0; k < splits; ++k) { s += partial[((size_t)k * 2) * C + c]; s2 += partial[((size_t)k * 2 + 1) * C + c]; }
+    for (int k = lane; k < splits; k += 64) { s += partial[((size_t)k * 2) * C + c]; s2 += partial[((size_t)k * 2 + 1) * C + c]; }
+    s = wave_sum(s); s2 = wave_sum(s2);
+    if (lane != 0) return;
     const double n = (double)rows, mean = s / n;
     double var = s2 / n - mean * mean;            // biased batch variance
     if (var < 0) var = 0;
@@ -83,10 +86,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__
 
 __global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const double *partial, int splits, int C, float *dgamma,
                                                             float *dbeta) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double s = 0, s2 = 0;
-    for (int k = 0; k < splits; ++k) { s += partial[((size_t)k * 2) * C + c]; s2 += partial[((size_t)k * 2 + 1) * C + c]; }
+    for (int k = lane; k < splits; k += 64) { s += partial[((size_t)k * 2) * C + c]; s2 += partial[((size_t)k * 2 + 1) * C + c]; }
+    s = wave_sum(s); s2 = wave_sum(s2);
+    if (lane != 0) return;
     dbeta[c] = (float)s;
     dgamma[c] = (float)s2;
 }
@@ -138,7 +143,7 @@ extern "C" int mmdgan_bn_fwd_train(const float *x, long rows, int C, const float
     double *part = (double *)workspace;
     hipLaunchKernelGGL(bn_partial_kernel<0>, dim3((C + 63) / 64, splits), dim3(256), 0, st, x, nullptr, nullptr, rows, C,
                        rps, nullptr, nullptr, 0, part);
-    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, splits, rows, C, eps,
+    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, splits, rows, C, eps,
                        momentum, unbiased_moving_var, save_mean, save_invstd, moving_mean, moving_var, new_moving_mean,
                        new_moving_var);
     const long total = rows * C;
@@ -172,7 +177,7 @@ extern "C" int mmdgan_bn_bwd(const float *x, const float *y, const float *dy, lo
     double *part = (double *)workspace;
     hipLaunchKernelGGL(bn_partial_kernel<1>, dim3((C + 63) / 64, splits), dim3(256), 0, st, x, y, dy, rows, C, rps,
                        save_mean, save_invstd, act, part);
-    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, splits, C, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, splits, C, dgamma, dbeta);
     const long total = rows * C;
     long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;

@@ -1,5 +1,6 @@
 // C-ABI entry points of the convolution family: validate, then dispatch to the MFMA implicit-GEMM
-// kernels (conv_igemm.hip) when the geometry is tile-aligned, else to the direct kernels.
+// kernels (conv_igemm.hip) when the geometry is tile-aligned, to the thin first/last-layer kernels
+// (conv_thin.hip) when one channel count is tiny, else to the generic direct kernels.
 #include <stdlib.h>
 
 #include "conv_internal.h"
@@ -30,6 +31,7 @@ extern "C" int mmdgan_conv2d_fwd(const mmdgan_conv_geom *g, const float *x, cons
     const ConvDims d = conv_dims(*g);
     const ConvEpilogue ep{bias, scale, dact_of, act};
     if (!force_direct() && igemm_fwd_ok(d)) return igemm_fwd(d, ep, x, w, y, (hipStream_t)stream);
+    if (!force_direct() && (thin_fwd_in_ok(d) || thin_fwd_out_ok(d))) return thin_fwd(d, ep, x, w, y, (hipStream_t)stream);
     return direct_fwd(d, ep, x, w, y, (hipStream_t)stream);
 }
 
@@ -41,6 +43,8 @@ extern "C" int mmdgan_conv2d_dgrad(const mmdgan_conv_geom *g, const float *dy, c
     const ConvDims d = conv_dims(*g);
     const ConvEpilogue ep{bias, scale, dact_of, act};
     if (!force_direct() && igemm_dgrad_ok(d)) return igemm_dgrad(d, ep, dy, w, dx, (hipStream_t)stream);
+    if (!force_direct() && (thin_dgrad_in_ok(d) || thin_dgrad_out_ok(d)))
+        return thin_dgrad(d, ep, dy, w, dx, (hipStream_t)stream);
     return direct_dgrad(d, ep, dy, w, dx, (hipStream_t)stream);
 }
 
@@ -49,5 +53,6 @@ extern "C" int mmdgan_conv2d_wgrad(const mmdgan_conv_geom *g, const float *x, co
     MMDGAN_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
     const ConvDims d = conv_dims(*g);
     if (!force_direct() && igemm_wgrad_ok(d)) return igemm_wgrad(d, x, dy, dw, (hipStream_t)stream);
+    if (!force_direct() && thin_wgrad_ok(d)) return thin_wgrad(d, x, dy, dw, (hipStream_t)stream);
     return direct_wgrad(d, x, dy, dw, (hipStream_t)stream);
 }

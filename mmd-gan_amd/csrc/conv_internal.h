@@ -19,6 +19,16 @@ int direct_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const 
 int direct_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, float *dx, hipStream_t st);
 int direct_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st);
 
+// thin first/last-layer kernels (conv_thin.hip)
+bool thin_fwd_in_ok(const ConvDims &d);
+bool thin_fwd_out_ok(const ConvDims &d);
+bool thin_dgrad_in_ok(const ConvDims &d);
+bool thin_dgrad_out_ok(const ConvDims &d);
+bool thin_wgrad_ok(const ConvDims &d);
+int thin_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, float *y, hipStream_t st);
+int thin_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, float *dx, hipStream_t st);
+int thin_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st);
+
 // MFMA implicit-GEMM path (conv_igemm.hip); *_ok() say whether a geometry is eligible
 bool igemm_fwd_ok(const ConvDims &d);
 bool igemm_dgrad_ok(const ConvDims &d);

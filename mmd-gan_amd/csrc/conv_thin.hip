@@ -1,0 +1,244 @@
+// Thin-layer convolution kernels: the first D layer (3 -> 64 channels) and the last G layer
+// (64 -> 3), forward and both gradients.  Their im2col depth (27) or output width (3) would waste
+// >90 % of an MFMA tile and together they are 0.2 % of the step's FLOPs, so they are HBM-bound
+// VALU kernels built around three patterns:
+//   thin_in   few input values per output pixel (<= 64 = taps x thin channels), wide output:
+//             weights in LDS as [tap*i][n], each thread owns one pixel x 16 consecutive outputs
+//             (4 x float4 stores).                       -> D l1 forward, G l5 input-gradient
+//   thin_out  wide reduction (taps x C, C % 4 == 0), <= 4 outputs per pixel: one thread per
+//             pixel, float4 activation loads, weights broadcast from LDS as [tap][j][i].
+//                                                        -> G l5 forward, D l1 input-gradient
+//   thin_wgrad  dw[tap][c][k] with one of C, K thin: a block walks a chunk of pixels, lane = wide
+//             channel (coalesced), the 4 waves split the thin (tap, channel) entries, partial
+//             sums are combined with fp32 atomics.       -> D l1 / G l5 weight-gradient
+#include "conv_internal.h"
+
+namespace mmdgan {
+
+constexpr int kThinMaxRed = 64;     // thin_in: taps * thin channels
+constexpr int kThinMaxOut = 4;      // thin_out: outputs per pixel
+
+// input pixel feeding output pixel (oy, ox) through tap (r, t); false if outside / not on the grid
+template <bool DGRAD>
+__device__ __forceinline__ bool tap_source(const ConvDims &d, int oy, int ox, int r, int t, int &iy, int &ix) {
+    if (!DGRAD) {
+        iy = oy * d.stride - d.pad + r;
+        ix = ox * d.stride - d.pad + t;
+        return iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
+    }
+    const int hy = oy + d.pad - r, hx = ox + d.pad - t;
+    if (hy < 0 || hx < 0 || hy % d.stride || hx % d.stride) return false;
+    iy = hy / d.stride; ix = hx / d.stride;
+    return iy < d.P && ix < d.Q;
+}
+
+// ---------------------------------------------------------------------------------------------
+// thin_in: out[px][n] = sum_{tap, i < CI} in[src(px, tap)][i] * W(tap, i, n)
+//   forward : in = x [N,H,W,CI=C],   out = y  [N,P,Q,NW=K], W(tap,i,n) = w[tap][i][n]
+//   dgrad   : in = dy [N,P,Q,CI=K],  out = dx [N,H,W,NW=C], W(tap,i,n) = w[tap][n][i]
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void thin_in_kernel(ConvDims d, ConvEpilogue ep, const float *__restrict__ in,
+                                                      const float *__restrict__ w, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float ws[];                // [tap*CI + i][NW]
+    const int CI = DGRAD ? d.K : d.C, NW = DGRAD ? d.C : d.K;
+    const int OH = DGRAD ? d.H : d.P, OW = DGRAD ? d.W : d.Q;
+    const int IH = DGRAD ? d.P : d.H, IW = DGRAD ? d.Q : d.W;
+    const int taps = d.R * d.R, red = taps * CI;
+    for (int e = threadIdx.x; e < red * NW; e += 256) {
+        const int n = e % NW, ti = e / NW, i = ti % CI, tap = ti / CI;
+        ws[e] = DGRAD ? w[((long)tap * d.C + n) * d.K + i] : w[((long)tap * d.C + i) * d.K + n];
+    }
+    __syncthreads();
+    const int groups = NW / 16;
+    const long total = (long)d.N * OH * OW * groups;
+    const float sc = ep.scale ? ep.scale[0] : 1.f;
+    for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+        const int g = gid % groups;
+        long px = gid / groups;
+        const int ox = px % OW;
+        const long u = px / OW;
+        const int oy = u % OH;
+        const long n = u / OH;
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+        for (int r = 0; r < d.R; ++r)
+            for (int t = 0; t < d.R; ++t) {
+                int iy, ix;
+                if (!tap_source<DGRAD>(d, oy, ox, r, t, iy, ix)) continue;
+                const float *ip = in + ((n * IH + iy) * IW + ix) * CI;
+                const float *wp = ws + (long)((r * d.R + t) * CI) * NW + g * 16;
+                for (int i = 0; i < CI; ++i) {
+                    const float v = ip[i];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 wv = *reinterpret_cast<const float4 *>(wp + i * NW + q * 4);
+                        acc[q * 4 + 0] = fmaf(v, wv.x, acc[q * 4 + 0]);
+                        acc[q * 4 + 1] = fmaf(v, wv.y, acc[q * 4 + 1]);
+                        acc[q * 4 + 2] = fmaf(v, wv.z, acc[q * 4 + 2]);
+                        acc[q * 4 + 3] = fmaf(v, wv.w, acc[q * 4 + 3]);
+                    }
+                }
+            }
+        const long o = px * NW + g * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 v;
+            v.x = ep.apply(acc[q * 4 + 0] * sc, g * 16 + q * 4 + 0, o + q * 4 + 0);
+            v.y = ep.apply(acc[q * 4 + 1] * sc, g * 16 + q * 4 + 1, o + q * 4 + 1);
+            v.z = ep.apply(acc[q * 4 + 2] * sc, g * 16 + q * 4 + 2, o + q * 4 + 2);
+            v.w = ep.apply(acc[q * 4 + 3] * sc, g * 16 + q * 4 + 3, o + q * 4 + 3);
+            *reinterpret_cast<float4 *>(out + o + q * 4) = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// thin_out: out[px][j < NJ] = sum_{tap, i < CW} in[src(px, tap)][i] * W(tap, j, i),  CW % 4 == 0
+//   forward : in = x,  out = y  [..,NJ=K], W(tap,j,i) = w[tap][i][j]
+//   dgrad   : in = dy, out = dx [..,NJ=C], W(tap,j,i) = w[tap][j][i]
+template <bool DGRAD>
+__global__ __launch_bounds__(128) void thin_out_kernel(ConvDims d, ConvEpilogue ep, const float *__restrict__ in,
+                                                       const float *__restrict__ w, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float ws[];                // [tap][j][CW]
+    const int CW = DGRAD ? d.K : d.C, NJ = DGRAD ? d.C : d.K;
+    const int OH = DGRAD ? d.H : d.P, OW = DGRAD ? d.W : d.Q;
+    const int IH = DGRAD ? d.P : d.H, IW = DGRAD ? d.Q : d.W;
+    const int taps = d.R * d.R;
+    for (int e = threadIdx.x; e < taps * NJ * CW; e += 128) {
+        const int i = e % CW, tj = e / CW, j = tj % NJ, tap = tj / NJ;
+        ws[e] = DGRAD ? w[((long)tap * d.C + j) * d.K + i] : w[((long)tap * d.C + i) * d.K + j];
+    }
+    __syncthreads();
+    const long total = (long)d.N * OH * OW;
+    const float sc = ep.scale ? ep.scale[0] : 1.f;
+    for (long px = (long)blockIdx.x * 128 + threadIdx.x; px < total; px += (long)gridDim.x * 128) {
+        const int ox = px % OW;
+        const long u = px / OW;
+        const int oy = u % OH;
+        const long n = u / OH;
+        float acc[kThinMaxOut] = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < d.R; ++r)
+            for (int t = 0; t < d.R; ++t) {
+                int iy, ix;
+                if (!tap_source<DGRAD>(d, oy, ox, r, t, iy, ix)) continue;
+                const float4 *ip = reinterpret_cast<const float4 *>(in + ((n * IH + iy) * IW + ix) * CW);
+                const float4 *wp = reinterpret_cast<const float4 *>(ws + (long)((r * d.R + t) * NJ) * CW);
+                for (int i4 = 0; i4 < CW / 4; ++i4) {
+                    const float4 v = ip[i4];
+#pragma unroll
+                    for (int j = 0; j < kThinMaxOut; ++j)
+                        if (j < NJ) {
+                            const float4 wv = wp[j * (CW / 4) + i4];
+                            acc[j] = fmaf(v.x, wv.x, fmaf(v.y, wv.y, fmaf(v.z, wv.z, fmaf(v.w, wv.w, acc[j]))));
+                        }
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < kThinMaxOut; ++j)
+            if (j < NJ) out[px * NJ + j] = ep.apply(acc[j] * sc, j, px * NJ + j);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// thin_wgrad: dw[tap][c][k] += sum over a pixel chunk.  lane = wide channel (64 per block.y),
+// the block's 4 waves split the thin entries e = tap*T + thin_channel round-robin (<= 8 each).
+template <bool WIDE_K>
+__global__ __launch_bounds__(256) void thin_wgrad_kernel(ConvDims d, const float *__restrict__ x,
+                                                         const float *__restrict__ dy, float *dw, long pix_per_block) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int T = WIDE_K ? d.C : d.K, WIDE = WIDE_K ? d.K : d.C;
+    const int wide = blockIdx.y * 64 + lane;
+    const int entries = d.R * d.R * T;
+    const long npix = (long)d.N * d.P * d.Q;
+    const long p0 = (long)blockIdx.x * pix_per_block;
+    const long p1 = p0 + pix_per_block < npix ? p0 + pix_per_block : npix;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (wide < WIDE) {
+        for (long pix = p0; pix < p1; ++pix) {
+            const int q = pix % d.Q;
+            const long u = pix / d.Q;
+            const int p = u % d.P;
+            const long n = u / d.P;
+            const float dyw = WIDE_K ? dy[pix * d.K + wide] : 0.f;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int e = wave + 4 * s;
+                if (e >= entries) break;
+                const int tap = e / T, th = e - tap * T;
+                const int r = tap / d.R, t = tap - r * d.R;
+                const int h = p * d.stride - d.pad + r, ww = q * d.stride - d.pad + t;
+                if (h < 0 || h >= d.H || ww < 0 || ww >= d.W) continue;
+                const long xo = ((n * d.H + h) * d.W + ww) * d.C;
+                if (WIDE_K) acc[s] = fmaf(x[xo + th], dyw, acc[s]);                  // x broadcast, dy coalesced
+                else acc[s] = fmaf(x[xo + wide], dy[pix * d.K + th], acc[s]);          // x coalesced, dy broadcast
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int e = wave + 4 * s;
+            if (e >= entries) break;
+            const int tap = e / T, th = e - tap * T;
+            const long o = WIDE_K ? ((long)tap * d.C + th) * d.K + wide : ((long)tap * d.C + wide) * d.K + th;
+            atomicAdd(dw + o, acc[s]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+bool thin_fwd_in_ok(const ConvDims &d) { return d.R * d.R * d.C <= kThinMaxRed && d.K % 16 == 0 && d.K <= 256 && d.C < 16; }
+bool thin_dgrad_in_ok(const ConvDims &d) { return d.R * d.R * d.K <= kThinMaxRed && d.C % 16 == 0 && d.C <= 256 && d.K < 16; }
+bool thin_fwd_out_ok(const ConvDims &d) { return d.K <= kThinMaxOut && d.C % 4 == 0 && d.R * d.R * d.K * d.C * 4 <= 60 * 1024; }
+bool thin_dgrad_out_ok(const ConvDims &d) { return d.C <= kThinMaxOut && d.K % 4 == 0 && d.R * d.R * d.K * d.C * 4 <= 60 * 1024; }
+bool thin_wgrad_ok(const ConvDims &d) {
+    return (d.R * d.R * d.C <= 32 && d.K >= 16) || (d.R * d.R * d.K <= 32 && d.C >= 16);
+}
+
+static unsigned blocks_for(long work, int per_block, int cap) {
+    long b = (work + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (unsigned)b;
+}
+
+int thin_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, float *y, hipStream_t st) {
+    if (thin_fwd_in_ok(d)) {
+        const long work = (long)d.N * d.P * d.Q * (d.K / 16);
+        hipLaunchKernelGGL(thin_in_kernel<false>, dim3(blocks_for(work, 256, 4096)), dim3(256),
+                           sizeof(float) * d.R * d.R * d.C * d.K, st, d, ep, x, w, y);
+    } else {
+        const long work = (long)d.N * d.P * d.Q;
+        const size_t lds = sizeof(float) * d.R * d.R * d.K * d.C;
+        hipLaunchKernelGGL(thin_out_kernel<false>, dim3(blocks_for(work, 128, 4096)), dim3(128), lds, st, d, ep, x, w, y);
+    }
+    return check_launch("conv2d_fwd(thin)");
+}
+int thin_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, float *dx, hipStream_t st) {
+    if (thin_dgrad_in_ok(d)) {
+        const long work = (long)d.N * d.H * d.W * (d.C / 16);
+        hipLaunchKernelGGL(thin_in_kernel<true>, dim3(blocks_for(work, 256, 4096)), dim3(256),
+                           sizeof(float) * d.R * d.R * d.C * d.K, st, d, ep, dy, w, dx);
+    } else {
+        const long work = (long)d.N * d.H * d.W;
+        const size_t lds = sizeof(float) * d.R * d.R * d.K * d.C;
+        hipLaunchKernelGGL(thin_out_kernel<true>, dim3(blocks_for(work, 128, 4096)), dim3(128), lds, st, d, ep, dy, w, dx);
+    }
+    return check_launch("conv2d_dgrad(thin)");
+}
+int thin_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st) {
+    const long nout = (long)d.R * d.R * d.C * d.K;
+    if (hipMemsetAsync(dw, 0, sizeof(float) * nout, st) != hipSuccess) return check_launch("conv2d_wgrad memset");
+    const bool wide_k = d.R * d.R * d.C <= 32 && d.K >= 16;
+    const int wide = wide_k ? d.K : d.C;
+    const long npix = (long)d.N * d.P * d.Q;
+    const int ychunks = (wide + 63) / 64;
+    long xblocks = 1024 / ychunks;
+    long ppb = (npix + xblocks - 1) / xblocks;
+    if (ppb < 64) ppb = 64;
+    xblocks = (npix + ppb - 1) / ppb;
+    if (wide_k) hipLaunchKernelGGL(thin_wgrad_kernel<true>, dim3((unsigned)xblocks, ychunks), dim3(256), 0, st, d, x, dy, dw, ppb);
+    else hipLaunchKernelGGL(thin_wgrad_kernel<false>, dim3((unsigned)xblocks, ychunks), dim3(256), 0, st, d, x, dy, dw, ppb);
+    return check_launch("conv2d_wgrad(thin)");
+}
+
+}  // namespace mmdgan
