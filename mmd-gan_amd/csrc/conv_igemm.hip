@@ -9,8 +9,8 @@
 //
 // Structure (one 256-thread workgroup = 4 waves in a 2x2 grid over a BM x BN output tile):
 //   * im2col is never materialised: each thread owns fixed rows of the A (activation) tile,
-//     decomposes the pixel index once, and per K-stage (BK = 16 consecutive channels of ONE
-//     filter tap, which is why C % 16 == 0 is required) turns the tap into an address or a zero.
+//     decomposes the pixel index once, and per K-stage (BK = 32 consecutive channels of ONE
+//     filter tap, which is why C % 32 == 0 is required) turns the tap into an address or a zero.
 //   * global -> registers (float4, coalesced along the channel axis) for stage s+1 is issued
 //     before the MFMAs of stage s; registers -> LDS after them; LDS is double-buffered so there
 //     is one barrier per stage.
@@ -31,12 +31,18 @@ namespace mmdgan {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;
-constexpr int PADL = 4;
+constexpr int BK = 32;             // K depth of one LDS stage: 16 MFMA k-pairs between barriers
+constexpr int KQ = BK / 4;         // float4 per k-contiguous row
+// LDS row stride of a [k][m] tile.  m-contiguous sources are stored with ds_write_b128, so the row
+// must stay 16-byte aligned (+4).  k-contiguous sources are transposed with 4 ds_write_b32 per
+// float4: lanes of a wave differ in (row, k-chunk) and land on bank (k*LD + row) % 32, which is
+// conflict-free exactly when LD == 1 (mod 8) - measured: +4 padding there cost a 4-way conflict
+// on every store (SQ_LDS_BANK_CONFLICT 1.5e8 cycles per launch vs 0).
+constexpr int ld_of(int cols, bool kc) { return kc ? cols + 1 : cols + 4; }
 
-template <int BM, int BN>
+template <int BM, int BN, bool AKC = false, bool BKC = false>
 struct TileCfg {
-    static constexpr int LDA = BM + PADL, LDB = BN + PADL;
+    static constexpr int LDA = ld_of(BM, AKC), LDB = ld_of(BN, BKC);
     static constexpr int WM = BM / 2, WN = BN / 2;
     static constexpr int TM = WM / 32, TN = WN / 32;
     static constexpr int A_F4 = BM * BK / 4 / 256, B_F4 = BN * BK / 4 / 256;
@@ -58,9 +64,9 @@ __device__ __forceinline__ float4 bufld4(__amdgpu_buffer_rsrc_t r, unsigned byte
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-// k-contiguous source element f of a ROWS x BK tile: row = f/4, kq = f%4; transposing store
+// k-contiguous source element f of a ROWS x BK tile: row = f/KQ, kq = f%KQ; transposing store
 __device__ __forceinline__ void sts_kc(float *S, int LD, int f, const float4 &v) {
-    const int row = f >> 2, k = (f & 3) * 4;
+    const int row = f / KQ, k = (f % KQ) * 4;
     S[(k + 0) * LD + row] = v.x;
     S[(k + 1) * LD + row] = v.y;
     S[(k + 2) * LD + row] = v.z;
@@ -73,65 +79,101 @@ __device__ __forceinline__ void sts_mc(float *S, int LD, int f, const float4 &v)
     *reinterpret_cast<float4 *>(&S[k * LD + c4 * 4]) = v;
 }
 
-template <int BM, int BN>
-__device__ __forceinline__ void mma_stage(const float *As, const float *Bs, f32x16 (&acc)[TileCfg<BM, BN>::TM][TileCfg<BM, BN>::TN],
-                                          int wm, int wn, int lane) {
-    using T = TileCfg<BM, BN>;
-    const int kh = lane >> 5, l31 = lane & 31;
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-        float a[T::TM], b[T::TN];
-#pragma unroll
-        for (int mi = 0; mi < T::TM; ++mi) a[mi] = As[(kk + kh) * T::LDA + wm * T::WM + mi * 32 + l31];
-#pragma unroll
-        for (int ni = 0; ni < T::TN; ++ni) b[ni] = Bs[(kk + kh) * T::LDB + wn * T::WN + ni * 32 + l31];
-#pragma unroll
-        for (int mi = 0; mi < T::TM; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < T::TN; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-    }
-}
-
-// generic main loop: P supplies load_a/load_b (global -> registers for one stage) and says
-// whether each operand is k-contiguous (transposing LDS store) or m-contiguous.
+// Main loop, software-pipelined by hand.  Per K-stage s (BK = 32 deep, NKP = 16 MFMA k-pairs):
+//   C(s)    MFMAs on LDS buffer s&1, operand fragments read PF k-pairs ahead of their use
+//   W(s+1)  registers -> LDS buffer (s+1)&1 of the tile that was fetched during stage s-1
+//   G(s+2)  global -> registers (buffer loads) of the tile after that
+// CDNA issues a wave's instructions in order and a v_mfma_f32_32x32x2_f32 holds the matrix pipe
+// for 64 cycles, so everything that is not an MFMA is cut into 2*(A_F4+B_F4) small pieces and one
+// piece is placed behind the MFMAs of each k-pair, where it issues in the shadow of the pipe;
+// __builtin_amdgcn_sched_barrier(0) after every k-pair keeps hipcc from re-clumping them (left
+// alone it moves all address arithmetic / loads / LDS stores outside the MFMA run and the pipe
+// idles: measured 111 us -> see DESIGN.md for the ablation).  One barrier per stage.
+// P supplies load_a1/load_b1 (one float4 of the stage tile, global -> register) and says whether
+// each operand is k-contiguous in memory (transposing LDS store) or m-contiguous (ds_write_b128).
 // `smem` must be the kernel's own __shared__ array: buffers are addressed by arithmetic on that
-// base (never through an array of pointers), so the compiler keeps the LDS address space and
-// emits ds_read/ds_write - a pointer table degrades every access to flat_load/flat_store.
+// base (never through an array of pointers) so the LDS address space survives and ds_read/ds_write
+// are emitted - a pointer table degraded every access to flat_load/flat_store.
 template <int BM, int BN, class P>
 __device__ __forceinline__ void mainloop(P &p, int s_begin, int s_end, float *smem,
                                          f32x16 (&acc)[TileCfg<BM, BN>::TM][TileCfg<BM, BN>::TN]) {
-    using T = TileCfg<BM, BN>;
+    using T = TileCfg<BM, BN, P::A_KC, P::B_KC>;
     constexpr int A_BUF = BK * T::LDA, B_BUF = BK * T::LDB, B_OFF = 2 * A_BUF;
+    constexpr int NKP = BK / 2, PF = 4, NP = T::A_F4 + T::B_F4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int kh = lane >> 5, l31 = lane & 31;
     float4 ra[T::A_F4], rb[T::B_F4];
     if (s_begin >= s_end) return;
-    p.load_a(s_begin, ra);
-    p.load_b(s_begin, rb);
-#define MMDGAN_STORE_STAGE(BUF)                                                                          \
-    {                                                                                                    \
-        float *As_ = smem + (BUF) * A_BUF;                                                               \
-        float *Bs_ = smem + B_OFF + (BUF) * B_BUF;                                                       \
-        _Pragma("unroll") for (int i = 0; i < T::A_F4; ++i) {                                            \
-            if (P::A_KC) sts_kc(As_, T::LDA, tid + 256 * i, ra[i]);                                      \
-            else sts_mc<BM>(As_, T::LDA, tid + 256 * i, ra[i]);                                          \
-        }                                                                                                \
-        _Pragma("unroll") for (int i = 0; i < T::B_F4; ++i) {                                            \
-            if (P::B_KC) sts_kc(Bs_, T::LDB, tid + 256 * i, rb[i]);                                      \
-            else sts_mc<BN>(Bs_, T::LDB, tid + 256 * i, rb[i]);                                          \
-        }                                                                                                \
-    }
-    MMDGAN_STORE_STAGE(0)
+#define MMDGAN_W_A(DST, I) { if (P::A_KC) sts_kc(DST, T::LDA, tid + 256 * (I), ra[I]); else sts_mc<BM>(DST, T::LDA, tid + 256 * (I), ra[I]); }
+#define MMDGAN_W_B(DST, I) { if (P::B_KC) sts_kc(DST, T::LDB, tid + 256 * (I), rb[I]); else sts_mc<BN>(DST, T::LDB, tid + 256 * (I), rb[I]); }
+#pragma unroll
+    for (int i = 0; i < T::A_F4; ++i) ra[i] = p.load_a1(s_begin, i);
+#pragma unroll
+    for (int i = 0; i < T::B_F4; ++i) rb[i] = p.load_b1(s_begin, i);
+#pragma unroll
+    for (int i = 0; i < T::A_F4; ++i) MMDGAN_W_A(smem, i)
+#pragma unroll
+    for (int i = 0; i < T::B_F4; ++i) MMDGAN_W_B(smem + B_OFF, i)
+#pragma unroll
+    for (int i = 0; i < T::A_F4; ++i) ra[i] = p.load_a1(s_begin + 1, i);
+#pragma unroll
+    for (int i = 0; i < T::B_F4; ++i) rb[i] = p.load_b1(s_begin + 1, i);
     __syncthreads();
+    const float *ap0 = smem + kh * T::LDA + wm * T::WM + l31;
+    const float *bp0 = smem + B_OFF + kh * T::LDB + wn * T::WN + l31;
     for (int s = s_begin; s < s_end; ++s) {
         const int buf = (s - s_begin) & 1;
-        const bool more = s + 1 < s_end;
-        if (more) { p.load_a(s + 1, ra); p.load_b(s + 1, rb); }
-        mma_stage<BM, BN>(smem + buf * A_BUF, smem + B_OFF + buf * B_BUF, acc, wm, wn, lane);
-        if (more) MMDGAN_STORE_STAGE(buf ^ 1)
-        __syncthreads();
+        const float *ap = ap0 + buf * A_BUF, *bp = bp0 + buf * B_BUF;
+        float *An = smem + (buf ^ 1) * A_BUF, *Bn = smem + B_OFF + (buf ^ 1) * B_BUF;
+        float fa[NKP][T::TM], fb[NKP][T::TN];
+#define MMDGAN_FRAG(J)                                                                                  \
+    {                                                                                                   \
+        _Pragma("unroll") for (int mi = 0; mi < T::TM; ++mi) fa[J][mi] = ap[2 * (J) * T::LDA + mi * 32]; \
+        _Pragma("unroll") for (int ni = 0; ni < T::TN; ++ni) fb[J][ni] = bp[2 * (J) * T::LDB + ni * 32]; \
     }
-#undef MMDGAN_STORE_STAGE
+#ifdef MMDGAN_ABLATE_FRAG
+#pragma unroll
+        for (int j = 0; j < NKP; ++j) {
+#pragma unroll
+            for (int mi = 0; mi < T::TM; ++mi) fa[j][mi] = (float)(s + j + mi + lane);
+#pragma unroll
+            for (int ni = 0; ni < T::TN; ++ni) fb[j][ni] = (float)(s - j + ni + lane);
+        }
+#else
+#pragma unroll
+        for (int j = 0; j < PF; ++j) MMDGAN_FRAG(j)
+#endif
+#pragma unroll
+        for (int j = 0; j < NKP; ++j) {
+#ifndef MMDGAN_ABLATE_FRAG
+            if (j + PF < NKP) MMDGAN_FRAG(j + PF)
+#endif
+#pragma unroll
+            for (int mi = 0; mi < T::TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < T::TN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j][mi], fb[j][ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 2 * NP; ++q) {
+                if ((q * NKP) / (2 * NP) != j) continue;
+#ifndef MMDGAN_ABLATE_STORE
+                if (q < T::A_F4) MMDGAN_W_A(An, q)
+                else if (q < NP) MMDGAN_W_B(Bn, q - T::A_F4)
+#endif
+#ifndef MMDGAN_ABLATE_GLOBAL
+                if (q >= NP && q < NP + T::A_F4) ra[q - NP] = p.load_a1(s + 2, q - NP);
+                else if (q >= NP + T::A_F4) rb[q - NP - T::A_F4] = p.load_b1(s + 2, q - NP - T::A_F4);
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef MMDGAN_FRAG
+#ifndef MMDGAN_ABLATE_BARRIER
+        __syncthreads();
+#endif
+    }
+#undef MMDGAN_W_A
+#undef MMDGAN_W_B
 }
 
 // C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -168,7 +210,7 @@ struct FwdProblem {
 #pragma unroll
         for (int i = 0; i < T::A_F4; ++i) {
             const int f = threadIdx.x + 256 * i;
-            const long m = (long)m0 + (f >> 2);
+            const long m = (long)m0 + f / KQ;
             const bool ok = m < M;
             const long mm = ok ? m : 0;
             const int q = mm % d.Q;
@@ -177,28 +219,22 @@ struct FwdProblem {
             const int n = t / d.P;
             ah0[i] = ok ? p * d.stride - d.pad : -(1 << 28);
             aw0[i] = q * d.stride - d.pad;
-            abase[i] = (unsigned)(((long)n * d.H * d.W * d.C + (f & 3) * 4) * 4);
+            abase[i] = (unsigned)(((long)n * d.H * d.W * d.C + (f % KQ) * 4) * 4);
         }
     }
-    __device__ __forceinline__ void load_a(int s, float4 (&ra)[T::A_F4]) const {
+    __device__ __forceinline__ float4 load_a1(int s, int i) const {
         const int k0 = s * BK;
         const int tap = k0 / d.C, c0 = k0 - tap * d.C;
         const int r = tap / d.R, t = tap - r * d.R;
-#pragma unroll
-        for (int i = 0; i < T::A_F4; ++i) {
-            const int h = ah0[i] + r, ww = aw0[i] + t;
-            const bool ok = h >= 0 && h < d.H && ww >= 0 && ww < d.W;
-            const unsigned off = abase[i] + (unsigned)(((h * d.W + ww) * d.C + c0) * 4);
-            ra[i] = bufld4(rx, ok ? off : kOOB);
-        }
+        const int h = ah0[i] + r, ww = aw0[i] + t;
+        const bool ok = h >= 0 && h < d.H && ww >= 0 && ww < d.W && r < d.R;
+        const unsigned off = abase[i] + (unsigned)(((h * d.W + ww) * d.C + c0) * 4);
+        return bufld4(rx, ok ? off : kOOB);
     }
-    __device__ __forceinline__ void load_b(int s, float4 (&rb)[T::B_F4]) const {
-#pragma unroll
-        for (int i = 0; i < T::B_F4; ++i) {
-            const int f = threadIdx.x + 256 * i;
-            const int k = f / (BN / 4), c4 = f % (BN / 4);
-            rb[i] = bufld4(rw, (unsigned)((((s * BK + k) * d.K) + n0 + c4 * 4) * 4));
-        }
+    __device__ __forceinline__ float4 load_b1(int s, int i) const {
+        const int f = threadIdx.x + 256 * i;
+        const int k = f / (BN / 4), c4 = f % (BN / 4);
+        return bufld4(rw, (unsigned)((((s * BK + k) * d.K) + n0 + c4 * 4) * 4));     // beyond the last stage: OOB -> 0
     }
 };
 
@@ -207,7 +243,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(ConvDims d, ConvEpilogue
                                                         const float *__restrict__ w, float *__restrict__ y,
                                                         int stages_per_split) {
     using T = TileCfg<BM, BN>;
-    __shared__ __attribute__((aligned(16))) float smem[T::SMEM_FLOATS];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const long M = (long)d.N * d.P * d.Q;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int nstages = d.R * d.R * d.C / BK;
@@ -262,41 +298,37 @@ struct DgradProblem {
 #pragma unroll
         for (int i = 0; i < T::A_F4; ++i) {
             const int f = threadIdx.x + 256 * i;
-            const long m = (long)m0 + (f >> 2);
+            const long m = (long)m0 + f / KQ;
             const bool ok = m < M;
             const long mm = ok ? m : 0;
             aww[i] = mm % Ww;
             const long t = mm / Ww;
             ahh[i] = ok ? (int)(t % Hh) : -(1 << 28);
             const int n = t / Hh;
-            abase[i] = (unsigned)(((long)n * d.P * d.Q * d.K + (f & 3) * 4) * 4);
+            abase[i] = (unsigned)(((long)n * d.P * d.Q * d.K + (f % KQ) * 4) * 4);
         }
 #pragma unroll
         for (int i = 0; i < T::B_F4; ++i) {
             const int f = threadIdx.x + 256 * i;
-            bbase[i] = (unsigned)(((long)(n0 + (f >> 2)) * d.K + (f & 3) * 4) * 4);     // + tap*C*K + co0 per stage
+            bbase[i] = (unsigned)(((long)(n0 + f / KQ) * d.K + (f % KQ) * 4) * 4);     // + tap*C*K + co0 per stage
         }
     }
-    __device__ __forceinline__ void load_a(int s, float4 (&ra)[T::A_F4]) const {
+    __device__ __forceinline__ float4 load_a1(int s, int i) const {
         const int k0 = s * BK;
         const int tap = k0 / d.K, co0 = k0 - tap * d.K;
         const int jr = tap / TT, jt = tap - jr * TT;
-#pragma unroll
-        for (int i = 0; i < T::A_F4; ++i) {
-            const int p = ahh[i] + pbase - jr, q = aww[i] + qbase - jt;
-            const bool ok = p >= 0 && p < d.P && q >= 0 && q < d.Q;
-            const unsigned off = abase[i] + (unsigned)(((p * d.Q + q) * d.K + co0) * 4);
-            ra[i] = bufld4(rdy, ok ? off : kOOB);
-        }
+        const int p = ahh[i] + pbase - jr, q = aww[i] + qbase - jt;
+        const bool ok = p >= 0 && p < d.P && q >= 0 && q < d.Q && jr < TT;
+        const unsigned off = abase[i] + (unsigned)(((p * d.Q + q) * d.K + co0) * 4);
+        return bufld4(rdy, ok ? off : kOOB);
     }
-    __device__ __forceinline__ void load_b(int s, float4 (&rb)[T::B_F4]) const {
+    __device__ __forceinline__ float4 load_b1(int s, int i) const {
         const int k0 = s * BK;
         const int tap = k0 / d.K, co0 = k0 - tap * d.K;
         const int jr = tap / TT, jt = tap - jr * TT;
         const int r = rbase + jr * d.stride, t = tbase + jt * d.stride;
         const unsigned off = (unsigned)((((r * d.R + t) * d.C) * d.K + co0) * 4);
-#pragma unroll
-        for (int i = 0; i < T::B_F4; ++i) rb[i] = bufld4(rw, bbase[i] + off);
+        return bufld4(rw, jr < TT ? bbase[i] + off : kOOB);
     }
 };
 
@@ -305,7 +337,7 @@ __global__ __launch_bounds__(256) void igemm_dgrad_kernel(ConvDims d, ConvEpilog
                                                           const float *__restrict__ w, float *__restrict__ dx,
                                                           int nsplit, int stages_per_split) {
     using T = TileCfg<BM, BN>;
-    __shared__ __attribute__((aligned(16))) float smem[T::SMEM_FLOATS];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int phase = blockIdx.z / nsplit, split = blockIdx.z - phase * nsplit;
     const int ph = phase / d.stride, pw = phase - ph * d.stride;
     const int Hh = (d.H - ph + d.stride - 1) / d.stride, Ww = (d.W - pw + d.stride - 1) / d.stride;
@@ -362,32 +394,26 @@ struct WgradProblem {
         c0 = i0 - tap * d.C;
         r = tap / d.R; t = tap - r * d.R;
     }
-    __device__ __forceinline__ void load_a(int s, float4 (&ra)[T::A_F4]) const {
-#pragma unroll
-        for (int i = 0; i < T::A_F4; ++i) {
-            const int f = threadIdx.x + 256 * i;
-            const int k = f / (BM / 4), c4 = f % (BM / 4);
-            const long m = (long)s * BK + k;
-            bool ok = m < M;
-            const long mm = ok ? m : 0;
-            const int q = mm % d.Q;
-            const long u = mm / d.Q;
-            const int p = u % d.P;
-            const long n = u / d.P;
-            const int h = p * d.stride - d.pad + r, ww = q * d.stride - d.pad + t;
-            ok = ok && h >= 0 && h < d.H && ww >= 0 && ww < d.W;
-            const unsigned off = (unsigned)((((n * d.H + h) * d.W + ww) * d.C + c0 + c4 * 4) * 4);
-            ra[i] = bufld4(rx, ok ? off : kOOB);
-        }
+    __device__ __forceinline__ float4 load_a1(int s, int i) const {
+        const int f = threadIdx.x + 256 * i;
+        const int k = f / (BM / 4), c4 = f % (BM / 4);
+        const long m = (long)s * BK + k;
+        bool ok = m < M;
+        const int mm = ok ? (int)m : 0;
+        const int q = mm % d.Q;
+        const int u = mm / d.Q;
+        const int p = u % d.P;
+        const int n = u / d.P;
+        const int h = p * d.stride - d.pad + r, ww = q * d.stride - d.pad + t;
+        ok = ok && h >= 0 && h < d.H && ww >= 0 && ww < d.W;
+        const unsigned off = (unsigned)((((n * d.H + h) * d.W + ww) * d.C + c0 + c4 * 4) * 4);
+        return bufld4(rx, ok ? off : kOOB);
     }
-    __device__ __forceinline__ void load_b(int s, float4 (&rb)[T::B_F4]) const {
-#pragma unroll
-        for (int i = 0; i < T::B_F4; ++i) {
-            const int f = threadIdx.x + 256 * i;
-            const int k = f / (BN / 4), c4 = f % (BN / 4);
-            const long m = (long)s * BK + k;
-            rb[i] = bufld4(rdy, m < M ? (unsigned)((m * d.K + n0 + c4 * 4) * 4) : kOOB);
-        }
+    __device__ __forceinline__ float4 load_b1(int s, int i) const {
+        const int f = threadIdx.x + 256 * i;
+        const int k = f / (BN / 4), c4 = f % (BN / 4);
+        const long m = (long)s * BK + k;
+        return bufld4(rdy, m < M ? (unsigned)(((int)m * d.K + n0 + c4 * 4) * 4) : kOOB);
     }
 };
 
@@ -396,7 +422,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(ConvDims d, const floa
                                                           const float *__restrict__ dy, float *__restrict__ dw,
                                                           int stages_per_split) {
     using T = TileCfg<BM, BN>;
-    __shared__ __attribute__((aligned(16))) float smem[T::SMEM_FLOATS];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const long M = (long)d.N * d.P * d.Q;
     const int i0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int nstages = (int)((M + BK - 1) / BK);
@@ -425,8 +451,22 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(ConvDims d, const floa
 // ------------------------------------------------------------------------------------------------
 constexpr int kTargetBlocks = 256;      // one workgroup per CU at least
 
+template <int BM, int BN>
+constexpr size_t smem_bytes() { return sizeof(float) * TileCfg<BM, BN>::SMEM_FLOATS; }
+
+// the 128x128 tile needs 67.6 KB of LDS (> the 64 KB default cap): raise the cap once per kernel
+static void raise_lds_caps() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    const int cap = (int)smem_bytes<128, 128>();
+    (void)hipFuncSetAttribute((const void *)igemm_fwd_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute((const void *)igemm_dgrad_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute((const void *)igemm_wgrad_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+}
+
 bool igemm_fwd_ok(const ConvDims &d) { return d.C % BK == 0 && d.K % 64 == 0 && d.R * d.R * d.C >= 64; }
-bool igemm_dgrad_ok(const ConvDims &d) { return d.K % BK == 0 && d.C % 64 == 0 && d.R % d.stride == 0 && d.K >= 16; }
+bool igemm_dgrad_ok(const ConvDims &d) { return d.K % BK == 0 && d.C % 64 == 0 && d.R % d.stride == 0; }
 bool igemm_wgrad_ok(const ConvDims &d) { return d.C % 64 == 0 && d.K % 64 == 0; }
 
 static void pick_tile(long M, int N, int &bm, int &bn) {
@@ -444,12 +484,13 @@ static void pick_tile(long M, int N, int &bm, int &bn) {
 static int pick_split(long tiles, int nstages, bool allowed) {
     if (!allowed || tiles >= kTargetBlocks / 2) return 1;
     int s = (int)(kTargetBlocks / tiles);
-    const int maxs = nstages / 8;                // keep >= 8 stages (128 deep) per split
+    const int maxs = nstages / 4;                // keep >= 4 stages (128 deep) per split
     if (s > maxs) s = maxs;
     return s < 1 ? 1 : s;
 }
 
 int igemm_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, float *y, hipStream_t st) {
+    raise_lds_caps();
     const long M = (long)d.N * d.P * d.Q;
     int bm, bn;
     pick_tile(M, d.K, bm, bn);
@@ -460,13 +501,14 @@ int igemm_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const f
     split = (nstages + sps - 1) / sps;
     if (split > 1 && hipMemsetAsync(y, 0, sizeof(float) * M * d.K, st) != hipSuccess) return check_launch("conv2d_fwd memset");
     const dim3 grid((unsigned)((M + bm - 1) / bm), d.K / bn, split);
-    if (bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_fwd_kernel<128, 128>), grid, dim3(256), 0, st, d, ep, x, w, y, sps);
-    else if (bm == 128) hipLaunchKernelGGL((igemm_fwd_kernel<128, 64>), grid, dim3(256), 0, st, d, ep, x, w, y, sps);
-    else hipLaunchKernelGGL((igemm_fwd_kernel<64, 64>), grid, dim3(256), 0, st, d, ep, x, w, y, sps);
+    if (bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_fwd_kernel<128, 128>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, ep, x, w, y, sps);
+    else if (bm == 128) hipLaunchKernelGGL((igemm_fwd_kernel<128, 64>), grid, dim3(256), (smem_bytes<128, 64>()), st, d, ep, x, w, y, sps);
+    else hipLaunchKernelGGL((igemm_fwd_kernel<64, 64>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, ep, x, w, y, sps);
     return check_launch("conv2d_fwd(igemm)");
 }
 
 int igemm_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, float *dx, hipStream_t st) {
+    raise_lds_caps();
     const int s = d.stride;
     const int Hh = (d.H + s - 1) / s, Ww = (d.W + s - 1) / s;       // largest phase
     const long M = (long)d.N * Hh * Ww;
@@ -482,13 +524,14 @@ int igemm_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, cons
     if (split > 1 && hipMemsetAsync(dx, 0, sizeof(float) * (long)d.N * d.H * d.W * d.C, st) != hipSuccess)
         return check_launch("conv2d_dgrad memset");
     const dim3 grid((unsigned)((M + bm - 1) / bm), d.C / bn, s * s * split);
-    if (bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_dgrad_kernel<128, 128>), grid, dim3(256), 0, st, d, ep, dy, w, dx, split, sps);
-    else if (bm == 128) hipLaunchKernelGGL((igemm_dgrad_kernel<128, 64>), grid, dim3(256), 0, st, d, ep, dy, w, dx, split, sps);
-    else hipLaunchKernelGGL((igemm_dgrad_kernel<64, 64>), grid, dim3(256), 0, st, d, ep, dy, w, dx, split, sps);
+    if (bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_dgrad_kernel<128, 128>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, ep, dy, w, dx, split, sps);
+    else if (bm == 128) hipLaunchKernelGGL((igemm_dgrad_kernel<128, 64>), grid, dim3(256), (smem_bytes<128, 64>()), st, d, ep, dy, w, dx, split, sps);
+    else hipLaunchKernelGGL((igemm_dgrad_kernel<64, 64>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, ep, dy, w, dx, split, sps);
     return check_launch("conv2d_dgrad(igemm)");
 }
 
 int igemm_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st) {
+    raise_lds_caps();
     const long M = (long)d.N * d.P * d.Q;
     const int rows = d.R * d.R * d.C;
     int bm = 64, bn = 64;
@@ -498,7 +541,7 @@ int igemm_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, h
     int split = 1;
     if (tiles < kTargetBlocks) {
         split = (int)((2 * kTargetBlocks + tiles - 1) / tiles);
-        const int maxs = nstages / 8 > 0 ? nstages / 8 : 1;
+        const int maxs = nstages / 4 > 0 ? nstages / 4 : 1;
         if (split > maxs) split = maxs;
     }
     int sps = (nstages + split - 1) / split;
@@ -506,8 +549,8 @@ int igemm_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, h
     if (split > 1 && hipMemsetAsync(dw, 0, sizeof(float) * (long)rows * d.K, st) != hipSuccess)
         return check_launch("conv2d_wgrad memset");
     const dim3 grid(rows / bm, d.K / bn, split);
-    if (bm == 128) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128>), grid, dim3(256), 0, st, d, x, dy, dw, sps);
-    else hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64>), grid, dim3(256), 0, st, d, x, dy, dw, sps);
+    if (bm == 128) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, x, dy, dw, sps);
+    else hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, x, dy, dw, sps);
     return check_launch("conv2d_wgrad(igemm)");
 }
 

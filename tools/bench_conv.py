@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""per-layer conv kernel timings (HIP events) for the CIFAR B=64 step: TFLOP/s per launch."""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, 'mmd-gan_amd'), ROOT]
+from mmdgan_hip import ops
+ops.require_device()
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+# (name, N, H, W, C, K, R, stride)
+LAYERS = [('D l2', 2 * B, 32, 32, 64, 128, 4, 2), ('D l3', 2 * B, 16, 16, 128, 128, 3, 1),
+          ('D l4', 2 * B, 16, 16, 128, 256, 4, 2), ('D l5', 2 * B, 8, 8, 256, 256, 3, 1),
+          ('D l6', 2 * B, 8, 8, 256, 512, 4, 2), ('D l7', 2 * B, 4, 4, 512, 512, 3, 1),
+          # G tc layers expressed as the conv whose dgrad they are: conv input = tc output
+          ('G l2 (tc)', B, 8, 8, 256, 512, 4, 2), ('G l3 (tc)', B, 16, 16, 128, 256, 4, 2),
+          ('G l4 (tc)', B, 32, 32, 64, 128, 4, 2)]
+def timeit(fn, reps=20):
+    for _ in range(3): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+print('%-10s %8s | %14s | %14s | %14s' % ('layer', 'GFLOP', 'fwd us (TF)', 'dgrad us (TF)', 'wgrad us (TF)'))
+tot = [0, 0, 0]
+for name, N, H, W, C, K, R, s in LAYERS:
+    P, Q = -(-H // s), -(-W // s)
+    x = torch.randn(N, H, W, C, device='cuda'); w = torch.randn(R, R, C, K, device='cuda') * 0.05
+    dy = torch.randn(N, P, Q, K, device='cuda'); y = torch.empty(N, P, Q, K, device='cuda')
+    dx = torch.empty_like(x); dw = torch.empty_like(w); bias = torch.zeros(K, device='cuda')
+    fl = 2.0 * N * P * Q * K * R * R * C
+    t = [timeit(lambda: ops.conv2d_fwd(x, w, s, bias=bias, act='lrelu', out=y)),
+         timeit(lambda: ops.conv2d_dgrad(dy, w, (H, W), s, act='lrelu', dact_of=x, out=dx)),
+         timeit(lambda: ops.conv2d_wgrad(x, dy, R, s, out=dw))]
+    for i in range(3): tot[i] += t[i]
+    print('%-10s %8.2f | %7.1f (%5.1f) | %7.1f (%5.1f) | %7.1f (%5.1f)' % (
+        name, fl / 1e9, t[0] * 1e3, fl / t[0] / 1e9, t[1] * 1e3, fl / t[1] / 1e9, t[2] * 1e3, fl / t[2] / 1e9))
+print('sum us: fwd %.0f dgrad %.0f wgrad %.0f' % tuple(v * 1e3 for v in tot))
