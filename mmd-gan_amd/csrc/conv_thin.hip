@@ -141,47 +141,59 @@ __global__ __launch_bounds__(128) void thin_out_kernel(ConvDims d, ConvEpilogue 
 }
 
 // ---------------------------------------------------------------------------------------------
-// thin_wgrad: dw[tap][c][k] += sum over a pixel chunk.  lane = wide channel (64 per block.y),
-// the block's 4 waves split the thin entries e = tap*T + thin_channel round-robin (<= 8 each).
+// thin_wgrad: dw[tap][c][k] += sum over a chunk of output rows.  lane = wide channel (64 per
+// block.y), the block's 4 waves split the thin entries e = tap*T + thin_channel round-robin
+// (<= 8 each).  A block walks whole output rows (n, p) with incremental addresses: per pixel one
+// coalesced load of the wide operand is shared by the wave's entries and the thin operand is a
+// wave-uniform (broadcast) load, so the inner loop is ~3 instructions per entry.
 template <bool WIDE_K>
 __global__ __launch_bounds__(256) void thin_wgrad_kernel(ConvDims d, const float *__restrict__ x,
-                                                         const float *__restrict__ dy, float *dw, long pix_per_block) {
+                                                         const float *__restrict__ dy, float *dw, int rows_per_block) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int T = WIDE_K ? d.C : d.K, WIDE = WIDE_K ? d.K : d.C;
     const int wide = blockIdx.y * 64 + lane;
     const int entries = d.R * d.R * T;
-    const long npix = (long)d.N * d.P * d.Q;
-    const long p0 = (long)blockIdx.x * pix_per_block;
-    const long p1 = p0 + pix_per_block < npix ? p0 + pix_per_block : npix;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (wide < WIDE) {
-        for (long pix = p0; pix < p1; ++pix) {
-            const int q = pix % d.Q;
-            const long u = pix / d.Q;
-            const int p = u % d.P;
-            const long n = u / d.P;
-            const float dyw = WIDE_K ? dy[pix * d.K + wide] : 0.f;
+    const int nrows = d.N * d.P;
+    const int row0 = blockIdx.x * rows_per_block;
+    const int row1 = min(nrows, row0 + rows_per_block);
+    if (wide >= WIDE) return;
+    int er[8], et[8], eth[8];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const int e = wave + 4 * s;
-                if (e >= entries) break;
-                const int tap = e / T, th = e - tap * T;
-                const int r = tap / d.R, t = tap - r * d.R;
-                const int h = p * d.stride - d.pad + r, ww = q * d.stride - d.pad + t;
-                if (h < 0 || h >= d.H || ww < 0 || ww >= d.W) continue;
-                const long xo = ((n * d.H + h) * d.W + ww) * d.C;
-                if (WIDE_K) acc[s] = fmaf(x[xo + th], dyw, acc[s]);                  // x broadcast, dy coalesced
-                else acc[s] = fmaf(x[xo + wide], dy[pix * d.K + th], acc[s]);          // x coalesced, dy broadcast
-            }
-        }
+    for (int s = 0; s < 8; ++s) {
+        const int e = wave + 4 * s;
+        const int tap = e / T;
+        eth[s] = e - tap * T;
+        er[s] = tap / d.R;
+        et[s] = tap - er[s] * d.R;
+    }
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int row = row0; row < row1; ++row) {
+        const int n = row / d.P, p = row - n * d.P;
+        const float *dyrow = dy + (long)row * d.Q * d.K;
+        int xbase[8];          // offset of x[n, h, 0, 0] for each entry's tap row, or -1
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const int e = wave + 4 * s;
-            if (e >= entries) break;
-            const int tap = e / T, th = e - tap * T;
-            const long o = WIDE_K ? ((long)tap * d.C + th) * d.K + wide : ((long)tap * d.C + wide) * d.K + th;
-            atomicAdd(dw + o, acc[s]);
+            const int h = p * d.stride - d.pad + er[s];
+            xbase[s] = (wave + 4 * s < entries && h >= 0 && h < d.H) ? ((n * d.H + h) * d.W) * d.C : -1;
         }
+        for (int q = 0; q < d.Q; ++q) {
+            const float dyw = WIDE_K ? dyrow[q * d.K + wide] : 0.f;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int ww = q * d.stride - d.pad + et[s];
+                if (xbase[s] < 0 || ww < 0 || ww >= d.W) continue;
+                if (WIDE_K) acc[s] = fmaf(x[xbase[s] + ww * d.C + eth[s]], dyw, acc[s]);            // x broadcast
+                else acc[s] = fmaf(x[xbase[s] + ww * d.C + wide], dyrow[q * d.K + eth[s]], acc[s]);   // dy broadcast
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int e = wave + 4 * s;
+        if (e >= entries) break;
+        const int tap = e / T;
+        const long o = WIDE_K ? ((long)tap * d.C + eth[s]) * d.K + wide : ((long)tap * d.C + wide) * d.K + eth[s];
+        atomicAdd(dw + o, acc[s]);
     }
 }
 
@@ -230,14 +242,13 @@ int thin_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hi
     if (hipMemsetAsync(dw, 0, sizeof(float) * nout, st) != hipSuccess) return check_launch("conv2d_wgrad memset");
     const bool wide_k = d.R * d.R * d.C <= 32 && d.K >= 16;
     const int wide = wide_k ? d.K : d.C;
-    const long npix = (long)d.N * d.P * d.Q;
+    const int nrows = d.N * d.P;
     const int ychunks = (wide + 63) / 64;
-    long xblocks = 1024 / ychunks;
-    long ppb = (npix + xblocks - 1) / xblocks;
-    if (ppb < 64) ppb = 64;
-    xblocks = (npix + ppb - 1) / ppb;
-    if (wide_k) hipLaunchKernelGGL(thin_wgrad_kernel<true>, dim3((unsigned)xblocks, ychunks), dim3(256), 0, st, d, x, dy, dw, ppb);
-    else hipLaunchKernelGGL(thin_wgrad_kernel<false>, dim3((unsigned)xblocks, ychunks), dim3(256), 0, st, d, x, dy, dw, ppb);
+    int rpb = (nrows * ychunks + 2047) / 2048;           // ~2048 blocks: 8 per CU
+    if (rpb < 1) rpb = 1;
+    const int xblocks = (nrows + rpb - 1) / rpb;
+    if (wide_k) hipLaunchKernelGGL(thin_wgrad_kernel<true>, dim3(xblocks, ychunks), dim3(256), 0, st, d, x, dy, dw, rpb);
+    else hipLaunchKernelGGL(thin_wgrad_kernel<false>, dim3(xblocks, ychunks), dim3(256), 0, st, d, x, dy, dw, rpb);
     return check_launch("conv2d_wgrad(thin)");
 }
 
