@@ -48,6 +48,12 @@ const char *mmdgan_last_error(void);
 int mmdgan_version(void);
 /* 1 if a gfx950 device is visible to this process, 0 otherwise (never an error) */
 int mmdgan_device_ok(void);
+/* Optional caller-owned device scratch (the library itself allocates nothing).  Kernels that would
+ * otherwise combine per-workgroup partial results with contended atomics (thin-layer weight
+ * gradients) write their partials here and reduce them in a second pass when the registered region
+ * is large enough; without it they fall back to atomics.  One region per process; calls that use it
+ * must be ordered on one stream.  ptr == NULL unregisters. */
+int mmdgan_set_workspace(void *ptr, size_t bytes);
 
 /* ------------------------------------------------------------------------------------------------
  * Convolution family.  Geometry: input [N,H,W,C], kernel [R,R,C,K], stride, 'SAME' padding with

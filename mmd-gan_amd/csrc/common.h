@@ -14,6 +14,7 @@ constexpr float kLreluAlpha = 0.1f;   // layer_func.py:112
 constexpr float kEpsi = 1e-10f;       // misc_fun.py:29 FLAGS.EPSI
 
 void set_error(const char *fmt, ...);
+void *workspace(size_t need);     // caller-registered scratch (mmdgan_set_workspace) or nullptr
 
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();

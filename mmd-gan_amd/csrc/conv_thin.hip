@@ -148,53 +148,124 @@ __global__ __launch_bounds__(128) void thin_out_kernel(ConvDims d, ConvEpilogue 
 // wave-uniform (broadcast) load, so the inner loop is ~3 instructions per entry.
 template <bool WIDE_K>
 __global__ __launch_bounds__(256) void thin_wgrad_kernel(ConvDims d, const float *__restrict__ x,
-                                                         const float *__restrict__ dy, float *dw, int rows_per_block) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                                         const float *__restrict__ dy, float *dw, int rows_per_block,
+                                                         float *partials) {
+    // lane = (pixel group pg = lane/16, 4 consecutive wide channels w4 = lane%16): one float4 load
+    // instruction covers 4 pixels x 64 wide channels - the kernel is bound by the NUMBER of vector
+    // memory instructions, not by bytes (one-pixel-per-instruction measured 250 us on D l1).
+    // WIDE_K  (thin C): slot s <-> entry e = wave + 4 s = (tap, c): 8 slots, x is a per-pixel scalar
+    // !WIDE_K (thin K): slot g <-> tap = wave + 4 g (3 taps per wave); the K (<= 4) outputs of a tap
+    //                   share one x load
+    constexpr int NS = WIDE_K ? 8 : 3, NT = WIDE_K ? 1 : 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pg = lane >> 4, w4 = lane & 15;
     const int T = WIDE_K ? d.C : d.K, WIDE = WIDE_K ? d.K : d.C;
-    const int wide = blockIdx.y * 64 + lane;
-    const int entries = d.R * d.R * T;
+    const int wide = blockIdx.y * 64 + w4 * 4;
+    const int taps = d.R * d.R;
+    const int entries = taps * T;
     const int nrows = d.N * d.P;
     const int row0 = blockIdx.x * rows_per_block;
     const int row1 = min(nrows, row0 + rows_per_block);
-    if (wide >= WIDE) return;
-    int er[8], et[8], eth[8];
+    const bool wide_ok = wide < WIDE;
+    int er[NS], et[NS], eth[NS];
+    bool live[NS];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int s = 0; s < NS; ++s) {
         const int e = wave + 4 * s;
-        const int tap = e / T;
-        eth[s] = e - tap * T;
+        const int tap = WIDE_K ? e / T : e;
+        live[s] = WIDE_K ? e < entries : tap < taps;
+        eth[s] = WIDE_K ? e - tap * T : 0;
         er[s] = tap / d.R;
         et[s] = tap - er[s] * d.R;
     }
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float4 acc[NS][NT];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int k = 0; k < NT; ++k) acc[s][k] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int row = row0; row < row1; ++row) {
         const int n = row / d.P, p = row - n * d.P;
         const float *dyrow = dy + (long)row * d.Q * d.K;
-        int xbase[8];          // offset of x[n, h, 0, 0] for each entry's tap row, or -1
+        int xbase[NS];          // offset of x[n, h, 0, 0] for each slot's tap row, or -1
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
+        for (int s = 0; s < NS; ++s) {
             const int h = p * d.stride - d.pad + er[s];
-            xbase[s] = (wave + 4 * s < entries && h >= 0 && h < d.H) ? ((n * d.H + h) * d.W) * d.C : -1;
+            xbase[s] = (live[s] && wide_ok && h >= 0 && h < d.H) ? ((n * d.H + h) * d.W) * d.C : -1;
         }
-        for (int q = 0; q < d.Q; ++q) {
-            const float dyw = WIDE_K ? dyrow[q * d.K + wide] : 0.f;
+        for (int q = pg; q < d.Q; q += 4) {
+            float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);      // the wide operand of this pixel (WIDE_K: dy)
+            float tv[NT];                                       // thin dy values (!WIDE_K)
+            if (WIDE_K) { if (wide_ok) wv = *reinterpret_cast<const float4 *>(dyrow + q * d.K + wide); }
+            else {
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
+                for (int k = 0; k < NT; ++k) tv[k] = k < T ? dyrow[q * d.K + k] : 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
                 const int ww = q * d.stride - d.pad + et[s];
                 if (xbase[s] < 0 || ww < 0 || ww >= d.W) continue;
-                if (WIDE_K) acc[s] = fmaf(x[xbase[s] + ww * d.C + eth[s]], dyw, acc[s]);            // x broadcast
-                else acc[s] = fmaf(x[xbase[s] + ww * d.C + wide], dyrow[q * d.K + eth[s]], acc[s]);   // dy broadcast
+                if (WIDE_K) {
+                    const float xv = x[xbase[s] + ww * d.C + eth[s]];
+                    acc[s][0].x = fmaf(xv, wv.x, acc[s][0].x); acc[s][0].y = fmaf(xv, wv.y, acc[s][0].y);
+                    acc[s][0].z = fmaf(xv, wv.z, acc[s][0].z); acc[s][0].w = fmaf(xv, wv.w, acc[s][0].w);
+                } else {
+                    const float4 xv = *reinterpret_cast<const float4 *>(x + xbase[s] + ww * d.C + wide);
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) {
+                        acc[s][k].x = fmaf(xv.x, tv[k], acc[s][k].x); acc[s][k].y = fmaf(xv.y, tv[k], acc[s][k].y);
+                        acc[s][k].z = fmaf(xv.z, tv[k], acc[s][k].z); acc[s][k].w = fmaf(xv.w, tv[k], acc[s][k].w);
+                    }
+                }
             }
         }
     }
+    // combine the 4 pixel groups (lanes l, l^16, l^32, l^48), then one atomic per output from pg == 0
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const int e = wave + 4 * s;
-        if (e >= entries) break;
-        const int tap = e / T;
-        const long o = WIDE_K ? ((long)tap * d.C + eth[s]) * d.K + wide : ((long)tap * d.C + wide) * d.K + eth[s];
-        atomicAdd(dw + o, acc[s]);
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            float v[4] = {acc[s][k].x, acc[s][k].y, acc[s][k].z, acc[s][k].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                v[c] += __shfl_xor(v[c], 16, 64);
+                v[c] += __shfl_xor(v[c], 32, 64);
+            }
+            if (pg == 0 && live[s] && wide_ok && (WIDE_K || k < T)) {
+                const int tap = er[s] * d.R + et[s];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const long o = WIDE_K ? ((long)tap * d.C + eth[s]) * d.K + wide + c : ((long)tap * d.C + wide + c) * d.K + k;
+                    // every (wave, slot, lane) owns its outputs exclusively within a block: with a
+                    // workspace the block's partial is a plain store and a second pass sums blocks
+                    if (partials) partials[(long)blockIdx.x * ((long)taps * d.C * d.K) + o] = v[c];
+                    else atomicAdd(dw + o, v[c]);
+                }
+            }
+        }
     }
+}
+
+// dw[o] = sum_b partials[b][o]: 64 outputs per block (coalesced across lanes), the 4 waves split the
+// partial blocks, 8 independent loads in flight per lane, LDS combine - no dependent load chain.
+__global__ __launch_bounds__(256) void thin_wgrad_reduce_kernel(const float *__restrict__ partials, int nblocks, long nout,
+                                                                float *__restrict__ dw) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long o = (long)blockIdx.x * 64 + lane;
+    float acc = 0.f;
+    if (o < nout) {
+        int b = wave;
+        for (; b + 28 < nblocks; b += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partials[(long)(b + 4 * u) * nout + o];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; b < nblocks; b += 4) acc += partials[(long)b * nout + o];
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && o < nout) dw[o] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -203,7 +274,7 @@ bool thin_dgrad_in_ok(const ConvDims &d) { return d.R * d.R * d.K <= kThinMaxRed
 bool thin_fwd_out_ok(const ConvDims &d) { return d.K <= kThinMaxOut && d.C % 4 == 0 && d.R * d.R * d.K * d.C * 4 <= 60 * 1024; }
 bool thin_dgrad_out_ok(const ConvDims &d) { return d.C <= kThinMaxOut && d.K % 4 == 0 && d.R * d.R * d.K * d.C * 4 <= 60 * 1024; }
 bool thin_wgrad_ok(const ConvDims &d) {
-    return (d.R * d.R * d.C <= 32 && d.K >= 16) || (d.R * d.R * d.K <= 32 && d.C >= 16);
+    return (d.R * d.R * d.C <= 32 && d.K >= 16 && d.K % 4 == 0) || (d.R * d.R <= 12 && d.K <= 4 && d.C >= 16 && d.C % 4 == 0);
 }
 
 static unsigned blocks_for(long work, int per_block, int cap) {
@@ -239,16 +310,22 @@ int thin_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const
 }
 int thin_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st) {
     const long nout = (long)d.R * d.R * d.C * d.K;
-    if (hipMemsetAsync(dw, 0, sizeof(float) * nout, st) != hipSuccess) return check_launch("conv2d_wgrad memset");
     const bool wide_k = d.R * d.R * d.C <= 32 && d.K >= 16;
     const int wide = wide_k ? d.K : d.C;
     const int nrows = d.N * d.P;
     const int ychunks = (wide + 63) / 64;
-    int rpb = (nrows * ychunks + 2047) / 2048;           // ~2048 blocks: 8 per CU
+    int rpb = (nrows * ychunks + 511) / 512;             // ~512 blocks: every block ends with one atomic per output,
+                                                         // 2048 blocks made those 1728 addresses the bottleneck
     if (rpb < 1) rpb = 1;
     const int xblocks = (nrows + rpb - 1) / rpb;
-    if (wide_k) hipLaunchKernelGGL(thin_wgrad_kernel<true>, dim3(xblocks, ychunks), dim3(256), 0, st, d, x, dy, dw, rpb);
-    else hipLaunchKernelGGL(thin_wgrad_kernel<false>, dim3(xblocks, ychunks), dim3(256), 0, st, d, x, dy, dw, rpb);
+    // measured: 512 blocks x 1728 contended fp32 atomics cost 125-265 us; partials + reduce ~15 us
+    float *partials = (float *)workspace(sizeof(float) * nout * xblocks);
+    if (!partials && hipMemsetAsync(dw, 0, sizeof(float) * nout, st) != hipSuccess) return check_launch("conv2d_wgrad memset");
+    if (wide_k) hipLaunchKernelGGL(thin_wgrad_kernel<true>, dim3(xblocks, ychunks), dim3(256), 0, st, d, x, dy, dw, rpb, partials);
+    else hipLaunchKernelGGL(thin_wgrad_kernel<false>, dim3(xblocks, ychunks), dim3(256), 0, st, d, x, dy, dw, rpb, partials);
+    if (partials)
+        hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3((unsigned)((nout + 63) / 64)), dim3(256), 0, st, partials, xblocks,
+                           nout, dw);
     return check_launch("conv2d_wgrad(thin)");
 }
 

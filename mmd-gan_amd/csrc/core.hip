@@ -9,6 +9,9 @@ void set_error(const char *fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+static void *g_ws = nullptr;
+static size_t g_ws_bytes = 0;
+void *workspace(size_t need) { return (g_ws && need <= g_ws_bytes) ? g_ws : nullptr; }
 }  // namespace mmdgan
 
 extern "C" const char *mmdgan_last_error(void) { return mmdgan::g_err; }
@@ -19,4 +22,9 @@ extern "C" int mmdgan_device_ok(void) {
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, 0) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return strncmp(p.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+extern "C" int mmdgan_set_workspace(void *ptr, size_t bytes) {
+    mmdgan::g_ws = ptr;
+    mmdgan::g_ws_bytes = ptr ? bytes : 0;
+    return MMDGAN_OK;
 }

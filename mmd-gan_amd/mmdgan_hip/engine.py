@@ -325,6 +325,8 @@ class GanEngine:
             import torch.distributed as tdist
             self.world = tdist.get_world_size(dist_group)
         self._pending = []
+        if ops._workspace is None:
+            ops.set_workspace(device=self.device)
         self._alloc(self.B)
         self.losses = torch.zeros(8, device=self.device)       # filled by the loss kernel each step
         self.use_graph, self._graph = use_graph, None

@@ -29,6 +29,18 @@ def require_device():
     return lib
 
 
+_workspace = None
+
+
+def set_workspace(nbytes=32 << 20, device=None):
+    """register a torch-owned scratch buffer with the library (mmdgan_set_workspace)."""
+    global _workspace
+    lib = require_device()
+    _workspace = torch.empty(nbytes, dtype=torch.uint8, device=device or 'cuda')
+    check(lib.mmdgan_set_workspace(_workspace.data_ptr(), nbytes), 'set_workspace')
+    return _workspace
+
+
 def _p(t):
     if t is None:
         return None

@@ -6,14 +6,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, 'mmd-gan_amd'), ROOT]
 from mmdgan_hip import ops
 ops.require_device()
+ops.set_workspace()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 # (name, N, H, W, C, K, R, stride)
+ONLY = sys.argv[2] if len(sys.argv) > 2 else ''
 LAYERS = [('D l2', 2 * B, 32, 32, 64, 128, 4, 2), ('D l3', 2 * B, 16, 16, 128, 128, 3, 1),
           ('D l4', 2 * B, 16, 16, 128, 256, 4, 2), ('D l5', 2 * B, 8, 8, 256, 256, 3, 1),
           ('D l6', 2 * B, 8, 8, 256, 512, 4, 2), ('D l7', 2 * B, 4, 4, 512, 512, 3, 1),
           # G tc layers expressed as the conv whose dgrad they are: conv input = tc output
           ('G l2 (tc)', B, 8, 8, 256, 512, 4, 2), ('G l3 (tc)', B, 16, 16, 128, 256, 4, 2),
-          ('G l4 (tc)', B, 32, 32, 64, 128, 4, 2)]
+          ('G l4 (tc)', B, 32, 32, 64, 128, 4, 2),
+          ('D l1 thin', 2 * B, 32, 32, 3, 64, 3, 1), ('D l1 (B)', B, 32, 32, 3, 64, 3, 1), ('G l5 thin', B, 32, 32, 64, 3, 3, 1)]
 def timeit(fn, reps=20):
     for _ in range(3): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -24,6 +27,7 @@ def timeit(fn, reps=20):
 print('%-10s %8s | %14s | %14s | %14s' % ('layer', 'GFLOP', 'fwd us (TF)', 'dgrad us (TF)', 'wgrad us (TF)'))
 tot = [0, 0, 0]
 for name, N, H, W, C, K, R, s in LAYERS:
+    if ONLY and ONLY not in name: continue
     P, Q = -(-H // s), -(-W // s)
     x = torch.randn(N, H, W, C, device='cuda'); w = torch.randn(R, R, C, K, device='cuda') * 0.05
     dy = torch.randn(N, P, Q, K, device='cuda'); y = torch.empty(N, P, Q, K, device='cuda')
