@@ -54,6 +54,13 @@ int mmdgan_device_ok(void);
  * is large enough; without it they fall back to atomics.  One region per process; calls that use it
  * must be ordered on one stream.  ptr == NULL unregisters. */
 int mmdgan_set_workspace(void *ptr, size_t bytes);
+/* Several entries accumulate into their output with atomics (split reductions, column sums, dot)
+ * and zero it first with an internal memset node.  A caller that zeroes those outputs itself - e.g.
+ * one memset over a whole gradient arena per step instead of ~40 small ones - sets this to 1 and the
+ * internal memsets are skipped; the outputs MUST then be zero on entry.  In this mode conv2d_fwd /
+ * conv2d_dgrad split their reduction (and so accumulate) only for batch-1 geometries (N == 1, the
+ * spectral-norm power iteration) and gemm only for outputs <= 1 MiB with K >= 512.  Default 0. */
+int mmdgan_set_outputs_prezeroed(int on);
 
 /* ------------------------------------------------------------------------------------------------
  * Convolution family.  Geometry: input [N,H,W,C], kernel [R,R,C,K], stride, 'SAME' padding with

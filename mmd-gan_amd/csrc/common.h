@@ -14,7 +14,11 @@ constexpr float kLreluAlpha = 0.1f;   // layer_func.py:112
 constexpr float kEpsi = 1e-10f;       // misc_fun.py:29 FLAGS.EPSI
 
 void set_error(const char *fmt, ...);
-void *workspace(size_t need);     // caller-registered scratch (mmdgan_set_workspace) or nullptr
+void *workspace(size_t need);
+bool outputs_prezeroed();         // mmdgan_set_outputs_prezeroed: skip internal zeroing memsets
+inline hipError_t zero_output(void *p, size_t bytes, hipStream_t st) {
+    return outputs_prezeroed() ? hipSuccess : hipMemsetAsync(p, 0, bytes, st);
+}     // caller-registered scratch (mmdgan_set_workspace) or nullptr
 
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();

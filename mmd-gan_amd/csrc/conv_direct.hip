@@ -111,7 +111,7 @@ int direct_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, con
 }
 int direct_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st) {
     const long nout = (long)d.R * d.R * d.C * d.K;
-    if (hipMemsetAsync(dw, 0, sizeof(float) * nout, st) != hipSuccess) return check_launch("conv2d_wgrad memset");
+    if (zero_output(dw, sizeof(float) * nout, st) != hipSuccess) return check_launch("conv2d_wgrad memset");
     const long npix = (long)d.N * d.P * d.Q;
     const int oblocks = (int)((nout + 255) / 256);
     long splits = 2048 / oblocks;

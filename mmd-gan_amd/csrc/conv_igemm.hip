@@ -496,10 +496,12 @@ int igemm_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const f
     pick_tile(M, d.K, bm, bn);
     const int nstages = d.R * d.R * d.C / BK;
     const long tiles = ((M + bm - 1) / bm) * (d.K / bn);
-    int split = pick_split(tiles, nstages, ep.act == MMDGAN_ACT_LINEAR && !ep.dact);
+    // with caller-side zeroing only the batch-1 (spectral-norm power iteration) launches may split
+    const bool may_split = ep.act == MMDGAN_ACT_LINEAR && !ep.dact && (!outputs_prezeroed() || d.N == 1);
+    int split = pick_split(tiles, nstages, may_split);
     int sps = (nstages + split - 1) / split;
     split = (nstages + sps - 1) / sps;
-    if (split > 1 && hipMemsetAsync(y, 0, sizeof(float) * M * d.K, st) != hipSuccess) return check_launch("conv2d_fwd memset");
+    if (split > 1 && zero_output(y, sizeof(float) * M * d.K, st) != hipSuccess) return check_launch("conv2d_fwd memset");
     const dim3 grid((unsigned)((M + bm - 1) / bm), d.K / bn, split);
     if (bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_fwd_kernel<128, 128>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, ep, x, w, y, sps);
     else if (bm == 128) hipLaunchKernelGGL((igemm_fwd_kernel<128, 64>), grid, dim3(256), (smem_bytes<128, 64>()), st, d, ep, x, w, y, sps);
@@ -518,10 +520,11 @@ int igemm_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, cons
     const long tiles = ((M + bm - 1) / bm) * (d.C / bn) * s * s;
     const int TT = d.R / s;
     const int nstages = TT * TT * d.K / BK;
-    int split = pick_split(tiles, nstages, ep.act == MMDGAN_ACT_LINEAR && !ep.dact);
+    const bool may_split = ep.act == MMDGAN_ACT_LINEAR && !ep.dact && (!outputs_prezeroed() || d.N == 1);
+    int split = pick_split(tiles, nstages, may_split);
     int sps = (nstages + split - 1) / split;
     split = (nstages + sps - 1) / sps;
-    if (split > 1 && hipMemsetAsync(dx, 0, sizeof(float) * (long)d.N * d.H * d.W * d.C, st) != hipSuccess)
+    if (split > 1 && zero_output(dx, sizeof(float) * (long)d.N * d.H * d.W * d.C, st) != hipSuccess)
         return check_launch("conv2d_dgrad memset");
     const dim3 grid((unsigned)((M + bm - 1) / bm), d.C / bn, s * s * split);
     if (bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_dgrad_kernel<128, 128>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, ep, dy, w, dx, split, sps);
@@ -546,7 +549,7 @@ int igemm_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, h
     }
     int sps = (nstages + split - 1) / split;
     split = (nstages + sps - 1) / sps;
-    if (split > 1 && hipMemsetAsync(dw, 0, sizeof(float) * (long)rows * d.K, st) != hipSuccess)
+    if (split > 1 && zero_output(dw, sizeof(float) * (long)rows * d.K, st) != hipSuccess)
         return check_launch("conv2d_wgrad memset");
     const dim3 grid(rows / bm, d.K / bn, split);
     if (bm == 128) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, x, dy, dw, sps);

@@ -11,6 +11,8 @@ void set_error(const char *fmt, ...) {
 }
 static void *g_ws = nullptr;
 static size_t g_ws_bytes = 0;
+static bool g_prezeroed = false;
+bool outputs_prezeroed() { return g_prezeroed; }
 void *workspace(size_t need) { return (g_ws && need <= g_ws_bytes) ? g_ws : nullptr; }
 }  // namespace mmdgan
 
@@ -26,5 +28,9 @@ extern "C" int mmdgan_device_ok(void) {
 extern "C" int mmdgan_set_workspace(void *ptr, size_t bytes) {
     mmdgan::g_ws = ptr;
     mmdgan::g_ws_bytes = ptr ? bytes : 0;
+    return MMDGAN_OK;
+}
+extern "C" int mmdgan_set_outputs_prezeroed(int on) {
+    mmdgan::g_prezeroed = on != 0;
     return MMDGAN_OK;
 }

@@ -144,7 +144,7 @@ using namespace mmdgan;
 extern "C" int mmdgan_colsum(const float *x, long rows, int cols, float *out, void *stream) {
     MMDGAN_REQUIRE(x && out && rows >= 1 && cols >= 1, "colsum: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(out, 0, sizeof(float) * cols, st) != hipSuccess) return check_launch("colsum memset");
+    if (zero_output(out, sizeof(float) * cols, st) != hipSuccess) return check_launch("colsum memset");
     const int cblocks = (cols + 63) / 64;
     long splits = 1024 / cblocks;
     if (splits < 1) splits = 1;
@@ -158,7 +158,7 @@ extern "C" int mmdgan_colsum(const float *x, long rows, int cols, float *out, vo
 extern "C" int mmdgan_dot(const float *a, const float *b, long n, float *out, void *stream) {
     MMDGAN_REQUIRE(a && b && out && n >= 1, "dot: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) return check_launch("dot memset");
+    if (zero_output(out, sizeof(float), st) != hipSuccess) return check_launch("dot memset");
     hipLaunchKernelGGL(dot_kernel, dim3(grid_for(n, 1024, 1024)), dim3(256), 0, st, a, b, n, out);
     return check_launch("dot");
 }

@@ -100,7 +100,8 @@ extern "C" int mmdgan_gemm(int transA, int transB, int M, int N, int K, const fl
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.transA = transA; g.transB = transB; g.act = act;
     const int tiles = ((M + GT - 1) / GT) * ((N + GT - 1) / GT);
     int ksplit = 1;
-    if (act == MMDGAN_ACT_LINEAR && !dact_of && tiles < 128 && K >= 512 && ldc == N) {
+    if (act == MMDGAN_ACT_LINEAR && !dact_of && tiles < 128 && K >= 512 && ldc == N &&
+        (!outputs_prezeroed() || (size_t)M * N * 4 <= (1u << 20))) {
         ksplit = 256 / tiles;
         const int maxs = K / 128;
         if (ksplit > maxs) ksplit = maxs;
@@ -110,7 +111,7 @@ extern "C" int mmdgan_gemm(int transA, int transB, int M, int N, int K, const fl
     kchunk = (kchunk + GK - 1) / GK * GK;
     ksplit = (K + kchunk - 1) / kchunk;
     g.ksplit = ksplit; g.kchunk = kchunk;
-    if (ksplit > 1 && hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, st) != hipSuccess)
+    if (ksplit > 1 && zero_output(C, sizeof(float) * (size_t)M * N, st) != hipSuccess)
         return check_launch("gemm memset");
     hipLaunchKernelGGL(gemm_kernel, dim3((N + GT - 1) / GT, (M + GT - 1) / GT, ksplit), dim3(256), 0, st, g);
     return check_launch("gemm");

@@ -248,7 +248,7 @@ extern "C" int mmdgan_mmd_loss(const float *s_gen, const float *s_x, int B, int 
     a.counter = (unsigned *)workspace;
     a.partials = (double *)((char *)workspace + 64);
     a.out = out_scalars; a.grads = grads; a.masks = masks; a.dist = dist;
-    if (hipMemsetAsync(a.counter, 0, 64, st) != hipSuccess) return check_launch("mmd_loss memset");
+    if (zero_output(a.counter, 64, st) != hipSuccess) return check_launch("mmd_loss memset");
     const int blocks = (B + kMmdRows - 1) / kMmdRows;
     const size_t lds = mmd_lds_bytes(d);
     static bool attr_set = false;

@@ -169,13 +169,22 @@ class Network:
         self.grads, self.adam_m, self.adam_v = self.arena.like(), self.arena.like(), self.arena.like()
         self.opt = ops.AdamGroup([self.params], [self.grads], [self.adam_m], [self.adam_v])
         self.state = OrderedDict()                      # non-trainable: SN vectors, BN moving stats
+        # everything the SN chain accumulates into with atomics (split reductions, dot) lives in ONE
+        # scratch arena so that the step zeroes it with a single memset
+        sn_entries = []
+        for s in specs:
+            if s.sn:
+                sn_entries += [(s.scope + '#u', self._sn_u_shape(s)), (s.scope + '#xb', self._sn_native_shape(s)),
+                               (s.scope + '#dsigma', s.kernel_shape), (s.scope + '#dot', [1])]
+        self.sn_scratch = _Arena(sn_entries, device)
         for s in specs:
             if s.sn:
                 self.state[s.scope + '/kernel/SN/in_rand'] = torch.zeros(self._sn_native_shape(s), device=device)
                 self.state[s.scope + '/kernel/SN/in_rand#next'] = torch.zeros(self._sn_native_shape(s), device=device)
-                for k in ('sigma', 'scale', 'dot'):
+                for k in ('sigma', 'scale'):
                     self.state[s.scope + '#' + k] = torch.zeros(1, device=device)
-                self.state[s.scope + '#dsigma'] = torch.zeros(s.kernel_shape, device=device)
+                for k in ('dot', 'dsigma', 'u', 'xb'):
+                    self.state[s.scope + '#' + k] = self.sn_scratch.view(s.scope + '#' + k)
             if s.bn:
                 nfeat = s.out if s.op == 'd' else s.channels
                 self.state[s.scope + '/BN/BN/moving_mean'] = torch.zeros(nfeat, device=device)
@@ -187,6 +196,14 @@ class Network:
     def _sn_native_shape(s):
         r = s.sn_x_ref
         return [1, r[2], r[3], r[1]] if len(r) == 4 else list(r)
+
+    @staticmethod
+    def _sn_u_shape(s):
+        if s.op == 'd':
+            return [1, s.out] if s.use_u else [1, s.kernel_shape[0]]
+        c, h, w = s.in_shape_ref
+        k, p, q = s.op_out_ref
+        return [1, p, q, k] if s.use_u else [1, h, w, c]
 
     def p(self, name):
         return self.arena.view(name)
@@ -357,22 +374,20 @@ class GanEngine:
                     self.buf[s.scope + '#dz_g'] = torch.zeros(_native_shape(s.op_out_ref, B), device=dev)
         self.buf['d_fake'] = torch.zeros(B, h, w, c, device=dev)
         self.buf['ds_d'] = torch.zeros(2 * B, self.score_size, device=dev)
-        # SN scratch per D layer
+        # SN scratch per D layer (u / xb live in the network's zero-once-per-step arena)
         for s in self.dis.specs:
             if s.sn:
-                u_shape = self._sn_u_shape(s)
-                self.buf[s.scope + '#u'] = torch.zeros(u_shape, device=dev)
-                self.buf[s.scope + '#un'] = torch.zeros(u_shape, device=dev)
-                self.buf[s.scope + '#xb'] = torch.zeros_like(self.dis.state[s.scope + '/kernel/SN/in_rand'])
+                self.buf[s.scope + '#u'] = self.dis.state[s.scope + '#u']
+                self.buf[s.scope + '#un'] = torch.zeros_like(self.dis.state[s.scope + '#u'])
+                self.buf[s.scope + '#xb'] = self.dis.state[s.scope + '#xb']
                 self.buf[s.scope + '#xbnorm'] = torch.zeros(1, device=dev)
-
-    @staticmethod
-    def _sn_u_shape(s):
-        if s.op == 'd':
-            return [1, s.out] if s.use_u else [1, s.kernel_shape[0]]
-        c, h, w = s.in_shape_ref
-        k, p, q = s.op_out_ref
-        return [1, p, q, k] if s.use_u else [1, h, w, c]
+        # buffers some kernel accumulates into with atomics: zeroed once at the start of every step
+        # (4 memset nodes instead of one per kernel, see mmdgan_set_outputs_prezeroed)
+        self._zero_each_step = [self.gen.grads, self.dis.grads, self.dis.sn_scratch.flat]
+        for net in (self.gen, self.dis):
+            for s in net.specs:          # dense outputs whose K is long enough for the split-K gemm path
+                if s.op == 'd' and s.kernel_shape[0] >= 512:
+                    self._zero_each_step.append(self.buf[s.scope + ('#raw' if s.bn else '#y')])
 
     # ---------------------------------------------------------------------------------------
     # spectral norm: one power-iteration step per D layer (math_func.py:661-672)
@@ -618,12 +633,19 @@ class GanEngine:
                 self.dis.state[s.scope + '/kernel/SN/in_rand'].copy_(self.dis.state[s.scope + '/kernel/SN/in_rand#next'])
 
     def _step_body(self, z, real):
-        self._forward(z, real)
-        dz = self._backward_dis()
-        self._allreduce(self.dis)
-        self._backward_gen(dz, z)
-        self._allreduce(self.gen)
-        self._update()
+        lib = ops.require_device()
+        lib.mmdgan_set_outputs_prezeroed(1)
+        try:
+            for t in self._zero_each_step:
+                t.zero_()
+            self._forward(z, real)
+            dz = self._backward_dis()
+            self._allreduce(self.dis)
+            self._backward_gen(dz, z)
+            self._allreduce(self.gen)
+            self._update()
+        finally:
+            lib.mmdgan_set_outputs_prezeroed(0)
 
     def step(self, real_nhwc=None, z=None):
         """one training step; returns nothing on the host (losses stay in self.losses on the device:
