@@ -1,0 +1,84 @@
+"""N>1 data-parallel path on CPU: world_size-2 gloo processes exercise the same bucketed gradient
+averaging / state broadcast / shard helpers the GPU engine uses with RCCL (mmdgan_hip/dist.py is
+device-agnostic; only the kernels need a GPU)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as tdist
+import torch.multiprocessing as mp
+
+from mmdgan_hip import dist as mdist
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    tdist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(100 + rank)
+        flat = torch.randn(100003, generator=g)                      # a gradient arena, different per replica
+        mine = flat.clone()
+        # bucketed async SUM + scale == mean over replicas (what Adam's grad_scale applies)
+        works = mdist.allreduce_sum_async(flat, bucket_bytes=64 << 10)
+        assert len(works) == len(mdist.buckets(flat.numel(), 64 << 10)) == 7
+        mdist.wait_all(works)
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        tdist.all_gather(gathered, mine)
+        ref = torch.stack(gathered).sum(0)
+        ok_sum = torch.allclose(flat, ref, rtol=0, atol=1e-5)
+        avg = mdist.average_(mine.clone(), bucket_bytes=1 << 20)
+        ok_avg = torch.allclose(avg, ref / world, rtol=0, atol=1e-5)
+
+        # broadcast_state: every replica ends with rank 0's weights / moments / SN vectors
+        class Opt:
+            step_counter = torch.tensor([3 + rank], dtype=torch.int32)
+
+        class Net:
+            def __init__(self):
+                self.params = torch.full((17,), float(rank))
+                self.adam_m = torch.full((17,), 10.0 + rank)
+                self.adam_v = torch.full((17,), 20.0 + rank)
+                self.opt = Opt()
+                self.state = {'b': torch.full((3,), 5.0 + rank), 'a': torch.full((2,), 7.0 + rank)}
+
+        class Eng:
+            gen, dis = Net(), Net()
+        eng = Eng()
+        mdist.broadcast_state(eng)
+        ok_bc = all(float(n.params[0]) == 0.0 and float(n.adam_m[0]) == 10.0 and float(n.state['a'][0]) == 7.0
+                    and int(n.opt.step_counter[0]) == 3 for n in (eng.gen, eng.dis))
+        q.put((rank, ok_sum, ok_avg, ok_bc, mdist.shard_of(50000, rank, world)))
+    finally:
+        tdist.destroy_process_group()
+
+
+def test_gloo_world2_gradient_average_and_broadcast():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1:4] for r in results] == [(True, True, True)] * world
+    assert results[0][4] == (0, 25000) and results[1][4] == (25000, 50000)
+
+
+def test_buckets_cover_exactly():
+    for n in (1, 7, 4096, 100003):
+        b = mdist.buckets(n, 4096)
+        assert b[0][0] == 0 and b[-1][1] == n and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+        assert all(e - s <= 1024 for s, e in b)
+    assert mdist.shard_of(10, 0, 3) == (0, 4) and mdist.shard_of(10, 2, 3) == (7, 10)
