@@ -176,20 +176,82 @@ __device__ __forceinline__ void mainloop(P &p, int s_begin, int s_end, float *sm
 #undef MMDGAN_W_B
 }
 
-// C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-#define MMDGAN_FOR_EACH_ACC(T, BODY)                                                            \
-    {                                                                                           \
-        const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;                           \
-        const int wm_ = wave_ >> 1, wn_ = wave_ & 1, kh_ = lane_ >> 5, l31_ = lane_ & 31;       \
-        _Pragma("unroll") for (int mi = 0; mi < T::TM; ++mi)                                    \
-        _Pragma("unroll") for (int ni = 0; ni < T::TN; ++ni)                                    \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                        \
-            const int row = wm_ * T::WM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh_;           \
-            const int col = wn_ * T::WN + ni * 32 + l31_;                                       \
-            const float v = acc[mi][ni][r];                                                     \
-            BODY                                                                                \
-        }                                                                                       \
+// Epilogue.  C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) +
+// 4*(lane>>5) - a lane holds single floats of 16 different rows, so writing straight from the
+// accumulators means 64 scalar stores per lane and one address computation per element (measured:
+// 10 us of a 108 us launch).  Instead each wave transposes a 32-row slab of its tile through LDS
+// (the main loop's buffers are free after its last barrier) and every lane then owns 4 consecutive
+// channels of one pixel: one row-offset computation, float4 bias / dact loads, one float4 store,
+// 16 lanes x 16 B = 256 contiguous bytes per row.
+// ROWOFF(row) -> element offset of output row `row` (tile-local 0..BM-1) or -1 if out of range.
+template <int BM, int BN, bool ATOMIC, class RowOff>
+__device__ __forceinline__ void epilogue_store(float *smem, f32x16 (&acc)[TileCfg<BM, BN>::TM][TileCfg<BM, BN>::TN],
+                                               RowOff rowoff, int ch0, const ConvEpilogue &ep, float sc, float *out,
+                                               bool add_bias, bool raw) {
+    using T = TileCfg<BM, BN>;
+    constexpr int LDE = T::WN + 4;                       // slab row stride (16-byte aligned rows)
+    constexpr int LPR = T::WN / 4;                       // lanes per row
+    constexpr int RPP = 64 / LPR;                        // rows per pass
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+    const int kh = lane >> 5, l31 = lane & 31;
+    float *slab = smem + wave * (32 * LDE);
+    const int c4 = lane % LPR, rsub = lane / LPR;
+    const int ch = ch0 + wn * T::WN + c4 * 4;
+    if (ATOMIC) {
+        // split reductions (a compile-time variant: keeping both paths in one kernel cost scratch): accumulate straight from the MFMA layout - lanes 0..31 of a register are
+        // 32 consecutive channels of one row, so each atomic instruction covers two 128-byte runs
+        // (going through the float4 path made every lane issue 4 strided atomics: measured slower)
+#pragma unroll
+        for (int mi = 0; mi < T::TM; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long base = rowoff(wm * T::WM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh);
+#pragma unroll
+                for (int ni = 0; ni < T::TN; ++ni) {
+                    const int cl = wn * T::WN + ni * 32 + l31;
+                    float v = acc[mi][ni][r] * sc;
+                    if (ep.bias && add_bias) v += ep.bias[ch0 + cl];
+                    if (base >= 0) atomicAdd(out + base + cl, v);
+                }
+            }
+        return;
     }
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ep.bias && add_bias) bv = *reinterpret_cast<const float4 *>(ep.bias + ch);
+#pragma unroll
+    for (int mi = 0; mi < T::TM; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < T::TN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                slab[((r & 3) + 8 * (r >> 2) + 4 * kh) * LDE + ni * 32 + l31] = acc[mi][ni][r];
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < 32 / RPP; ++ps) {
+            const int rl = ps * RPP + rsub;
+            const long base = rowoff(wm * T::WM + mi * 32 + rl);
+            if (base >= 0) {
+                float4 v = *reinterpret_cast<const float4 *>(slab + rl * LDE + c4 * 4);
+                const long o = base + wn * T::WN + c4 * 4;
+                v.x = v.x * sc + bv.x; v.y = v.y * sc + bv.y; v.z = v.z * sc + bv.z; v.w = v.w * sc + bv.w;
+                {
+                    if (!raw) {
+                        if (ep.dact) {
+                            const float4 y = *reinterpret_cast<const float4 *>(ep.dact + o);
+                            v.x *= act_bwd_from_out(y.x, ep.act); v.y *= act_bwd_from_out(y.y, ep.act);
+                            v.z *= act_bwd_from_out(y.z, ep.act); v.w *= act_bwd_from_out(y.w, ep.act);
+                        } else {
+                            v.x = act_fwd(v.x, ep.act); v.y = act_fwd(v.y, ep.act);
+                            v.z = act_fwd(v.z, ep.act); v.w = act_fwd(v.w, ep.act);
+                        }
+                    }
+                    *reinterpret_cast<float4 *>(out + o) = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // forward: y[m = (n,p,q)][k] = sum_{tap,c} x[n, p*s-pad+r, q*s-pad+t, c] * w[tap][c][k]
@@ -238,7 +300,7 @@ struct FwdProblem {
     }
 };
 
-template <int BM, int BN>
+template <int BM, int BN, bool SPLIT>
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(ConvDims d, ConvEpilogue ep, const float *__restrict__ x,
                                                         const float *__restrict__ w, float *__restrict__ y,
                                                         int stages_per_split) {
@@ -260,16 +322,12 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(ConvDims d, ConvEpilogue
     p.init(d, x, w, m0, n0, M);
     mainloop<BM, BN>(p, s0, s1, smem, acc);
     const float sc = ep.scale ? ep.scale[0] : 1.f;
-    const bool split = gridDim.z > 1;
-    MMDGAN_FOR_EACH_ACC(T, {
+    const int Kc = d.K;
+    auto rowoff = [=](int row) -> long {
         const long m = (long)m0 + row;
-        if (m < M) {
-            const int ch = n0 + col;
-            const long o = m * d.K + ch;
-            if (split) atomicAdd(y + o, v * sc + ((ep.bias && blockIdx.z == 0) ? ep.bias[ch] : 0.f));
-            else y[o] = ep.apply(v * sc, ch, o);
-        }
-    })
+        return m < M ? m * Kc + n0 : -1;
+    };
+    epilogue_store<BM, BN, SPLIT>(smem, acc, rowoff, n0, ep, sc, y, !SPLIT || blockIdx.z == 0, false);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -332,7 +390,7 @@ struct DgradProblem {
     }
 };
 
-template <int BM, int BN>
+template <int BM, int BN, bool SPLIT>
 __global__ __launch_bounds__(256) void igemm_dgrad_kernel(ConvDims d, ConvEpilogue ep, const float *__restrict__ dy,
                                                           const float *__restrict__ w, float *__restrict__ dx,
                                                           int nsplit, int stages_per_split) {
@@ -359,19 +417,15 @@ __global__ __launch_bounds__(256) void igemm_dgrad_kernel(ConvDims d, ConvEpilog
     p.init(d, dy, w, m0, n0, ph, pw, Hh, Ww, M);
     mainloop<BM, BN>(p, s0, s1, smem, acc);
     const float sc = ep.scale ? ep.scale[0] : 1.f;
-    MMDGAN_FOR_EACH_ACC(T, {
-        const long m = (long)m0 + row;
-        if (m < M) {
-            const int ww = m % Ww;
-            const long t = m / Ww;
-            const int hh = t % Hh;
-            const long n = t / Hh;
-            const int ch = n0 + col;
-            const long o = ((n * d.H + (hh * d.stride + ph)) * d.W + (ww * d.stride + pw)) * d.C + ch;
-            if (nsplit > 1) atomicAdd(dx + o, v * sc + ((ep.bias && split == 0) ? ep.bias[ch] : 0.f));
-            else dx[o] = ep.apply(v * sc, ch, o);
-        }
-    })
+    const int Mi = (int)M;
+    auto rowoff = [=](int row) -> long {
+        const int m = m0 + row;
+        if (m >= Mi) return -1;
+        const int ww = m % Ww, t = m / Ww;
+        const int hh = t % Hh, n = t / Hh;
+        return (((long)n * d.H + (hh * d.stride + ph)) * d.W + (ww * d.stride + pw)) * d.C + n0;
+    };
+    epilogue_store<BM, BN, SPLIT>(smem, acc, rowoff, n0, ep, sc, dx, !SPLIT || split == 0, false);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -417,7 +471,7 @@ struct WgradProblem {
     }
 };
 
-template <int BM, int BN>
+template <int BM, int BN, bool SPLIT>
 __global__ __launch_bounds__(256) void igemm_wgrad_kernel(ConvDims d, const float *__restrict__ x,
                                                           const float *__restrict__ dy, float *__restrict__ dw,
                                                           int stages_per_split) {
@@ -438,12 +492,10 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(ConvDims d, const floa
     WgradProblem<BM, BN> p;
     p.init(d, x, dy, i0, n0, M);
     mainloop<BM, BN>(p, s0, s1, smem, acc);
-    const bool split = gridDim.z > 1;
-    MMDGAN_FOR_EACH_ACC(T, {
-        const long o = (long)(i0 + row) * d.K + n0 + col;
-        if (split) atomicAdd(dw + o, v);
-        else dw[o] = v;
-    })
+    const int Kc = d.K;
+    auto rowoff = [=](int row) -> long { return (long)(i0 + row) * Kc + n0; };
+    const ConvEpilogue none{nullptr, nullptr, nullptr, MMDGAN_ACT_LINEAR};
+    epilogue_store<BM, BN, SPLIT>(smem, acc, rowoff, n0, none, 1.f, dw, false, true);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -460,9 +512,12 @@ static void raise_lds_caps() {
     if (done) return;
     done = true;
     const int cap = (int)smem_bytes<128, 128>();
-    (void)hipFuncSetAttribute((const void *)igemm_fwd_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute((const void *)igemm_dgrad_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute((const void *)igemm_wgrad_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute((const void *)igemm_fwd_kernel<128, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute((const void *)igemm_fwd_kernel<128, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute((const void *)igemm_dgrad_kernel<128, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute((const void *)igemm_dgrad_kernel<128, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute((const void *)igemm_wgrad_kernel<128, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    (void)hipFuncSetAttribute((const void *)igemm_wgrad_kernel<128, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
 }
 
 bool igemm_fwd_ok(const ConvDims &d) { return d.C % BK == 0 && d.K % 64 == 0 && d.R * d.R * d.C >= 64; }
@@ -503,9 +558,9 @@ int igemm_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const f
     split = (nstages + sps - 1) / sps;
     if (split > 1 && zero_output(y, sizeof(float) * M * d.K, st) != hipSuccess) return check_launch("conv2d_fwd memset");
     const dim3 grid((unsigned)((M + bm - 1) / bm), d.K / bn, split);
-    if (bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_fwd_kernel<128, 128>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, ep, x, w, y, sps);
-    else if (bm == 128) hipLaunchKernelGGL((igemm_fwd_kernel<128, 64>), grid, dim3(256), (smem_bytes<128, 64>()), st, d, ep, x, w, y, sps);
-    else hipLaunchKernelGGL((igemm_fwd_kernel<64, 64>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, ep, x, w, y, sps);
+    if (bm == 128 && bn == 128) { if (split > 1) hipLaunchKernelGGL((igemm_fwd_kernel<128, 128, true>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, ep, x, w, y, sps); else hipLaunchKernelGGL((igemm_fwd_kernel<128, 128, false>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, ep, x, w, y, sps); }
+    else if (bm == 128) { if (split > 1) hipLaunchKernelGGL((igemm_fwd_kernel<128, 64, true>), grid, dim3(256), (smem_bytes<128, 64>()), st, d, ep, x, w, y, sps); else hipLaunchKernelGGL((igemm_fwd_kernel<128, 64, false>), grid, dim3(256), (smem_bytes<128, 64>()), st, d, ep, x, w, y, sps); }
+    else { if (split > 1) hipLaunchKernelGGL((igemm_fwd_kernel<64, 64, true>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, ep, x, w, y, sps); else hipLaunchKernelGGL((igemm_fwd_kernel<64, 64, false>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, ep, x, w, y, sps); }
     return check_launch("conv2d_fwd(igemm)");
 }
 
@@ -527,9 +582,9 @@ int igemm_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, cons
     if (split > 1 && zero_output(dx, sizeof(float) * (long)d.N * d.H * d.W * d.C, st) != hipSuccess)
         return check_launch("conv2d_dgrad memset");
     const dim3 grid((unsigned)((M + bm - 1) / bm), d.C / bn, s * s * split);
-    if (bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_dgrad_kernel<128, 128>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, ep, dy, w, dx, split, sps);
-    else if (bm == 128) hipLaunchKernelGGL((igemm_dgrad_kernel<128, 64>), grid, dim3(256), (smem_bytes<128, 64>()), st, d, ep, dy, w, dx, split, sps);
-    else hipLaunchKernelGGL((igemm_dgrad_kernel<64, 64>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, ep, dy, w, dx, split, sps);
+    if (bm == 128 && bn == 128) { if (split > 1) hipLaunchKernelGGL((igemm_dgrad_kernel<128, 128, true>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, ep, dy, w, dx, split, sps); else hipLaunchKernelGGL((igemm_dgrad_kernel<128, 128, false>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, ep, dy, w, dx, split, sps); }
+    else if (bm == 128) { if (split > 1) hipLaunchKernelGGL((igemm_dgrad_kernel<128, 64, true>), grid, dim3(256), (smem_bytes<128, 64>()), st, d, ep, dy, w, dx, split, sps); else hipLaunchKernelGGL((igemm_dgrad_kernel<128, 64, false>), grid, dim3(256), (smem_bytes<128, 64>()), st, d, ep, dy, w, dx, split, sps); }
+    else { if (split > 1) hipLaunchKernelGGL((igemm_dgrad_kernel<64, 64, true>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, ep, dy, w, dx, split, sps); else hipLaunchKernelGGL((igemm_dgrad_kernel<64, 64, false>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, ep, dy, w, dx, split, sps); }
     return check_launch("conv2d_dgrad(igemm)");
 }
 
@@ -552,8 +607,8 @@ int igemm_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, h
     if (split > 1 && zero_output(dw, sizeof(float) * (long)rows * d.K, st) != hipSuccess)
         return check_launch("conv2d_wgrad memset");
     const dim3 grid(rows / bm, d.K / bn, split);
-    if (bm == 128) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, x, dy, dw, sps);
-    else hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, x, dy, dw, sps);
+    if (bm == 128) { if (split > 1) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, true>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, x, dy, dw, sps); else hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, false>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, x, dy, dw, sps); }
+    else { if (split > 1) hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, true>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, x, dy, dw, sps); else hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, false>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, x, dy, dw, sps); }
     return check_launch("conv2d_wgrad(igemm)");
 }
 
