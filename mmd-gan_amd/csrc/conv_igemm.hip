@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(ConvDims d, const floa
 // ------------------------------------------------------------------------------------------------
 // host side: eligibility, tile and split selection
 // ------------------------------------------------------------------------------------------------
-constexpr int kTargetBlocks = 256;      // one workgroup per CU at least
+constexpr int kTargetBlocks = 512;      // two workgroups per CU: a second wave per SIMD hides LDS/barrier latency
 
 template <int BM, int BN>
 constexpr size_t smem_bytes() { return sizeof(float) * TileCfg<BM, BN>::SMEM_FLOATS; }
@@ -596,11 +596,22 @@ int igemm_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, h
     if (d.C % 128 == 0 && d.K % 128 == 0 && (long)(rows / 128) * (d.K / 128) >= kTargetBlocks) { bm = 128; bn = 128; }
     const long tiles = (long)(rows / bm) * (d.K / bn);
     const int nstages = (int)((M + BK - 1) / BK);
+    // Workgroups are equal-cost and spread round-robin over 256 CUs, so a launch runs as long as
+    // its most loaded CU: efficiency = (blocks/256) / ceil(blocks/256).  576 tiles (D l7) is 75 %;
+    // splitting the pixel reduction 4 ways makes it 2304 blocks = 100 % at the price of atomics.
+    // Pick the split with the best balance (ties -> fewer splits), >= 8 stages per block.
     int split = 1;
-    if (tiles < kTargetBlocks) {
-        split = (int)((2 * kTargetBlocks + tiles - 1) / tiles);
-        const int maxs = nstages / 4 > 0 ? nstages / 4 : 1;
-        if (split > maxs) split = maxs;
+    {
+        double best = 0;
+        const int maxs = nstages / 8 > 0 ? nstages / 8 : 1;
+        for (int sp = 1; sp <= maxs && sp <= 64; ++sp) {
+            const double blocks = (double)tiles * sp;
+            double eff = (blocks / 256.0) / (double)((long)((blocks + 255) / 256));
+            if (blocks < 256) eff = blocks / 256.0;
+            if (blocks < 512) eff *= 0.9;                  // one workgroup per CU = one wave per SIMD: nothing hides latency
+            if (sp > 1) eff *= 0.98 - 0.004 * sp;          // atomics + zeroing are not free
+            if (eff > best + 1e-9) { best = eff; split = sp; }
+        }
     }
     int sps = (nstages + split - 1) / split;
     split = (nstages + sps - 1) / sps;
