@@ -40,12 +40,18 @@ constexpr int KQ = BK / 4;         // float4 per k-contiguous row
 // on every store (SQ_LDS_BANK_CONFLICT 1.5e8 cycles per launch vs 0).
 constexpr int ld_of(int cols, bool kc) { return kc ? cols + 1 : cols + 4; }
 
-template <int BM, int BN, bool AKC = false, bool BKC = false>
+// KG = number of K-groups: with KG == 2 the workgroup has 8 waves and the two waves that share an
+// output sub-tile each take every other MFMA k-pair of a stage (their accumulators are summed
+// through LDS before the epilogue).  That puts 2 waves on every SIMD even when the grid is only one
+// 64x64 tile per CU (M = 2048 layers at batch 128), where a lone wave cannot hide LDS / barrier
+// latency behind its own MFMAs.
+template <int BM, int BN, bool AKC = false, bool BKC = false, int KG = 1>
 struct TileCfg {
+    static constexpr int NT = 256 * KG;
     static constexpr int LDA = ld_of(BM, AKC), LDB = ld_of(BN, BKC);
     static constexpr int WM = BM / 2, WN = BN / 2;
     static constexpr int TM = WM / 32, TN = WN / 32;
-    static constexpr int A_F4 = BM * BK / 4 / 256, B_F4 = BN * BK / 4 / 256;
+    static constexpr int A_F4 = BM * BK / 4 / NT, B_F4 = BN * BK / 4 / NT;
     static constexpr int SMEM_FLOATS = 2 * BK * (LDA + LDB);
 };
 
@@ -94,18 +100,19 @@ __device__ __forceinline__ void sts_mc(float *S, int LD, int f, const float4 &v)
 // `smem` must be the kernel's own __shared__ array: buffers are addressed by arithmetic on that
 // base (never through an array of pointers) so the LDS address space survives and ds_read/ds_write
 // are emitted - a pointer table degraded every access to flat_load/flat_store.
-template <int BM, int BN, class P>
+template <int BM, int BN, int KG, class P>
 __device__ __forceinline__ void mainloop(P &p, int s_begin, int s_end, float *smem,
                                          f32x16 (&acc)[TileCfg<BM, BN>::TM][TileCfg<BM, BN>::TN]) {
-    using T = TileCfg<BM, BN, P::A_KC, P::B_KC>;
+    using T = TileCfg<BM, BN, P::A_KC, P::B_KC, KG>;
     constexpr int A_BUF = BK * T::LDA, B_BUF = BK * T::LDB, B_OFF = 2 * A_BUF;
-    constexpr int NKP = BK / 2, PF = 4, NP = T::A_F4 + T::B_F4;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    constexpr int NKP = BK / 2 / KG, PF = 4, NP = T::A_F4 + T::B_F4, NT = T::NT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, kgroup = tid >> 8;
+    const int wm = wave >> 1, wn = wave & 1;
     const int kh = lane >> 5, l31 = lane & 31;
     float4 ra[T::A_F4], rb[T::B_F4];
     if (s_begin >= s_end) return;
-#define MMDGAN_W_A(DST, I) { if (P::A_KC) sts_kc(DST, T::LDA, tid + 256 * (I), ra[I]); else sts_mc<BM>(DST, T::LDA, tid + 256 * (I), ra[I]); }
-#define MMDGAN_W_B(DST, I) { if (P::B_KC) sts_kc(DST, T::LDB, tid + 256 * (I), rb[I]); else sts_mc<BN>(DST, T::LDB, tid + 256 * (I), rb[I]); }
+#define MMDGAN_W_A(DST, I) { if (P::A_KC) sts_kc(DST, T::LDA, tid + NT * (I), ra[I]); else sts_mc<BM>(DST, T::LDA, tid + NT * (I), ra[I]); }
+#define MMDGAN_W_B(DST, I) { if (P::B_KC) sts_kc(DST, T::LDB, tid + NT * (I), rb[I]); else sts_mc<BN>(DST, T::LDB, tid + NT * (I), rb[I]); }
 #pragma unroll
     for (int i = 0; i < T::A_F4; ++i) ra[i] = p.load_a1(s_begin, i);
 #pragma unroll
@@ -119,8 +126,9 @@ __device__ __forceinline__ void mainloop(P &p, int s_begin, int s_end, float *sm
 #pragma unroll
     for (int i = 0; i < T::B_F4; ++i) rb[i] = p.load_b1(s_begin + 1, i);
     __syncthreads();
-    const float *ap0 = smem + kh * T::LDA + wm * T::WM + l31;
-    const float *bp0 = smem + B_OFF + kh * T::LDB + wn * T::WN + l31;
+    // K-group g takes the k-pairs g, g+KG, g+2KG ... of every stage
+    const float *ap0 = smem + (kh + 2 * kgroup) * T::LDA + wm * T::WM + l31;
+    const float *bp0 = smem + B_OFF + (kh + 2 * kgroup) * T::LDB + wn * T::WN + l31;
     for (int s = s_begin; s < s_end; ++s) {
         const int buf = (s - s_begin) & 1;
         const float *ap = ap0 + buf * A_BUF, *bp = bp0 + buf * B_BUF;
@@ -128,8 +136,8 @@ __device__ __forceinline__ void mainloop(P &p, int s_begin, int s_end, float *sm
         float fa[NKP][T::TM], fb[NKP][T::TN];
 #define MMDGAN_FRAG(J)                                                                                  \
     {                                                                                                   \
-        _Pragma("unroll") for (int mi = 0; mi < T::TM; ++mi) fa[J][mi] = ap[2 * (J) * T::LDA + mi * 32]; \
-        _Pragma("unroll") for (int ni = 0; ni < T::TN; ++ni) fb[J][ni] = bp[2 * (J) * T::LDB + ni * 32]; \
+        _Pragma("unroll") for (int mi = 0; mi < T::TM; ++mi) fa[J][mi] = ap[2 * KG * (J) * T::LDA + mi * 32]; \
+        _Pragma("unroll") for (int ni = 0; ni < T::TN; ++ni) fb[J][ni] = bp[2 * KG * (J) * T::LDB + ni * 32]; \
     }
 #ifdef MMDGAN_ABLATE_FRAG
 #pragma unroll
@@ -184,20 +192,46 @@ __device__ __forceinline__ void mainloop(P &p, int s_begin, int s_end, float *sm
 // channels of one pixel: one row-offset computation, float4 bias / dact loads, one float4 store,
 // 16 lanes x 16 B = 256 contiguous bytes per row.
 // ROWOFF(row) -> element offset of output row `row` (tile-local 0..BM-1) or -1 if out of range.
-template <int BM, int BN, bool ATOMIC, class RowOff>
+template <int BM, int BN, bool ATOMIC, int KG, class RowOff>
 __device__ __forceinline__ void epilogue_store(float *smem, f32x16 (&acc)[TileCfg<BM, BN>::TM][TileCfg<BM, BN>::TN],
                                                RowOff rowoff, int ch0, const ConvEpilogue &ep, float sc, float *out,
                                                bool add_bias, bool raw) {
     using T = TileCfg<BM, BN>;
+    bool active = true;
+    if (KG > 1) {
+        // sum the K-groups: group 1 parks its accumulators in LDS (lane-major: conflict-free), group 0 adds
+        const int kgroup = threadIdx.x >> 8, w4 = (threadIdx.x >> 6) & 3, ln = threadIdx.x & 63;
+        float *park = smem + w4 * (T::TM * T::TN * 16 * 64);
+        if (kgroup == 1) {
+#pragma unroll
+            for (int mi = 0; mi < T::TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < T::TN; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) park[((mi * T::TN + ni) * 16 + r) * 64 + ln] = acc[mi][ni][r];
+        }
+        __syncthreads();
+        if (kgroup == 0) {
+#pragma unroll
+            for (int mi = 0; mi < T::TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < T::TN; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] += park[((mi * T::TN + ni) * 16 + r) * 64 + ln];
+        }
+        __syncthreads();
+        active = kgroup == 0;
+    }
     constexpr int LDE = T::WN + 4;                       // slab row stride (16-byte aligned rows)
     constexpr int LPR = T::WN / 4;                       // lanes per row
     constexpr int RPP = 64 / LPR;                        // rows per pass
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, wm = wave >> 1, wn = wave & 1;
     const int kh = lane >> 5, l31 = lane & 31;
     float *slab = smem + wave * (32 * LDE);
     const int c4 = lane % LPR, rsub = lane / LPR;
     const int ch = ch0 + wn * T::WN + c4 * 4;
     if (ATOMIC) {
+        if (!active) return;
         // split reductions (a compile-time variant: keeping both paths in one kernel cost scratch): accumulate straight from the MFMA layout - lanes 0..31 of a register are
         // 32 consecutive channels of one row, so each atomic instruction covers two 128-byte runs
         // (going through the float4 path made every lane issue 4 strided atomics: measured slower)
@@ -220,16 +254,18 @@ __device__ __forceinline__ void epilogue_store(float *smem, f32x16 (&acc)[TileCf
     if (ep.bias && add_bias) bv = *reinterpret_cast<const float4 *>(ep.bias + ch);
 #pragma unroll
     for (int mi = 0; mi < T::TM; ++mi) {
+        if (active) {
 #pragma unroll
-        for (int ni = 0; ni < T::TN; ++ni)
+            for (int ni = 0; ni < T::TN; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                slab[((r & 3) + 8 * (r >> 2) + 4 * kh) * LDE + ni * 32 + l31] = acc[mi][ni][r];
+                for (int r = 0; r < 16; ++r)
+                    slab[((r & 3) + 8 * (r >> 2) + 4 * kh) * LDE + ni * 32 + l31] = acc[mi][ni][r];
+        }
         __syncthreads();
 #pragma unroll
         for (int ps = 0; ps < 32 / RPP; ++ps) {
             const int rl = ps * RPP + rsub;
-            const long base = rowoff(wm * T::WM + mi * 32 + rl);
+            const long base = active ? rowoff(wm * T::WM + mi * 32 + rl) : -1;
             if (base >= 0) {
                 float4 v = *reinterpret_cast<const float4 *>(slab + rl * LDE + c4 * 4);
                 const long o = base + wn * T::WN + c4 * 4;
@@ -256,10 +292,10 @@ __device__ __forceinline__ void epilogue_store(float *smem, f32x16 (&acc)[TileCf
 // ------------------------------------------------------------------------------------------------
 // forward: y[m = (n,p,q)][k] = sum_{tap,c} x[n, p*s-pad+r, q*s-pad+t, c] * w[tap][c][k]
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN>
+template <int BM, int BN, int KG>
 struct FwdProblem {
     static constexpr bool A_KC = true, B_KC = false;
-    using T = TileCfg<BM, BN>;
+    using T = TileCfg<BM, BN, false, false, KG>;
     ConvDims d;
     __amdgpu_buffer_rsrc_t rx, rw;
     int n0;
@@ -271,7 +307,7 @@ struct FwdProblem {
         rw = make_rsrc(w_, (long)d.R * d.R * d.C * d.K * 4);
 #pragma unroll
         for (int i = 0; i < T::A_F4; ++i) {
-            const int f = threadIdx.x + 256 * i;
+            const int f = threadIdx.x + T::NT * i;
             const long m = (long)m0 + f / KQ;
             const bool ok = m < M;
             const long mm = ok ? m : 0;
@@ -294,14 +330,14 @@ struct FwdProblem {
         return bufld4(rx, ok ? off : kOOB);
     }
     __device__ __forceinline__ float4 load_b1(int s, int i) const {
-        const int f = threadIdx.x + 256 * i;
+        const int f = threadIdx.x + T::NT * i;
         const int k = f / (BN / 4), c4 = f % (BN / 4);
         return bufld4(rw, (unsigned)((((s * BK + k) * d.K) + n0 + c4 * 4) * 4));     // beyond the last stage: OOB -> 0
     }
 };
 
-template <int BM, int BN, bool SPLIT>
-__global__ __launch_bounds__(256) void igemm_fwd_kernel(ConvDims d, ConvEpilogue ep, const float *__restrict__ x,
+template <int BM, int BN, bool SPLIT, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(ConvDims d, ConvEpilogue ep, const float *__restrict__ x,
                                                         const float *__restrict__ w, float *__restrict__ y,
                                                         int stages_per_split) {
     using T = TileCfg<BM, BN>;
@@ -318,16 +354,16 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(ConvDims d, ConvEpilogue
         for (int ni = 0; ni < T::TN; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    FwdProblem<BM, BN> p;
+    FwdProblem<BM, BN, KG> p;
     p.init(d, x, w, m0, n0, M);
-    mainloop<BM, BN>(p, s0, s1, smem, acc);
+    mainloop<BM, BN, KG>(p, s0, s1, smem, acc);
     const float sc = ep.scale ? ep.scale[0] : 1.f;
     const int Kc = d.K;
     auto rowoff = [=](int row) -> long {
         const long m = (long)m0 + row;
         return m < M ? m * Kc + n0 : -1;
     };
-    epilogue_store<BM, BN, SPLIT>(smem, acc, rowoff, n0, ep, sc, y, !SPLIT || blockIdx.z == 0, false);
+    epilogue_store<BM, BN, SPLIT, KG>(smem, acc, rowoff, n0, ep, sc, y, !SPLIT || blockIdx.z == 0, false);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -335,10 +371,10 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(ConvDims d, ConvEpilogue
 // p*stride - pad + r = h.  For stride s the output pixels split into s*s parity phases, each a
 // dense GEMM over the (R/s)^2 taps that can reach it (blockIdx.z = phase).
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN>
+template <int BM, int BN, int KG>
 struct DgradProblem {
     static constexpr bool A_KC = true, B_KC = true;
-    using T = TileCfg<BM, BN>;
+    using T = TileCfg<BM, BN, false, false, KG>;
     ConvDims d;
     __amdgpu_buffer_rsrc_t rdy, rw;
     int TT, rbase, tbase, pbase, qbase;
@@ -355,7 +391,7 @@ struct DgradProblem {
         pbase = (ph + d.pad) / d.stride; qbase = (pw + d.pad) / d.stride;
 #pragma unroll
         for (int i = 0; i < T::A_F4; ++i) {
-            const int f = threadIdx.x + 256 * i;
+            const int f = threadIdx.x + T::NT * i;
             const long m = (long)m0 + f / KQ;
             const bool ok = m < M;
             const long mm = ok ? m : 0;
@@ -367,7 +403,7 @@ struct DgradProblem {
         }
 #pragma unroll
         for (int i = 0; i < T::B_F4; ++i) {
-            const int f = threadIdx.x + 256 * i;
+            const int f = threadIdx.x + T::NT * i;
             bbase[i] = (unsigned)(((long)(n0 + f / KQ) * d.K + (f % KQ) * 4) * 4);     // + tap*C*K + co0 per stage
         }
     }
@@ -390,8 +426,8 @@ struct DgradProblem {
     }
 };
 
-template <int BM, int BN, bool SPLIT>
-__global__ __launch_bounds__(256) void igemm_dgrad_kernel(ConvDims d, ConvEpilogue ep, const float *__restrict__ dy,
+template <int BM, int BN, bool SPLIT, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void igemm_dgrad_kernel(ConvDims d, ConvEpilogue ep, const float *__restrict__ dy,
                                                           const float *__restrict__ w, float *__restrict__ dx,
                                                           int nsplit, int stages_per_split) {
     using T = TileCfg<BM, BN>;
@@ -413,9 +449,9 @@ __global__ __launch_bounds__(256) void igemm_dgrad_kernel(ConvDims d, ConvEpilog
         for (int ni = 0; ni < T::TN; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    DgradProblem<BM, BN> p;
+    DgradProblem<BM, BN, KG> p;
     p.init(d, dy, w, m0, n0, ph, pw, Hh, Ww, M);
-    mainloop<BM, BN>(p, s0, s1, smem, acc);
+    mainloop<BM, BN, KG>(p, s0, s1, smem, acc);
     const float sc = ep.scale ? ep.scale[0] : 1.f;
     const int Mi = (int)M;
     auto rowoff = [=](int row) -> long {
@@ -425,17 +461,17 @@ __global__ __launch_bounds__(256) void igemm_dgrad_kernel(ConvDims d, ConvEpilog
         const int hh = t % Hh, n = t / Hh;
         return (((long)n * d.H + (hh * d.stride + ph)) * d.W + (ww * d.stride + pw)) * d.C + n0;
     };
-    epilogue_store<BM, BN, SPLIT>(smem, acc, rowoff, n0, ep, sc, dx, !SPLIT || split == 0, false);
+    epilogue_store<BM, BN, SPLIT, KG>(smem, acc, rowoff, n0, ep, sc, dx, !SPLIT || split == 0, false);
 }
 
 // ------------------------------------------------------------------------------------------------
 // weight gradient: dw[(tap,c)][k] = sum_{pixels m} x[m shifted by tap][c] * dy[m][k]
 // GEMM rows i = (tap, c) (a BM-row tile sits inside one tap: C % BM == 0), reduction over pixels.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN>
+template <int BM, int BN, int KG>
 struct WgradProblem {
     static constexpr bool A_KC = false, B_KC = false;
-    using T = TileCfg<BM, BN>;
+    using T = TileCfg<BM, BN, false, false, KG>;
     ConvDims d;
     __amdgpu_buffer_rsrc_t rx, rdy;
     int r, t, c0, n0;
@@ -449,7 +485,7 @@ struct WgradProblem {
         r = tap / d.R; t = tap - r * d.R;
     }
     __device__ __forceinline__ float4 load_a1(int s, int i) const {
-        const int f = threadIdx.x + 256 * i;
+        const int f = threadIdx.x + T::NT * i;
         const int k = f / (BM / 4), c4 = f % (BM / 4);
         const long m = (long)s * BK + k;
         bool ok = m < M;
@@ -464,15 +500,15 @@ struct WgradProblem {
         return bufld4(rx, ok ? off : kOOB);
     }
     __device__ __forceinline__ float4 load_b1(int s, int i) const {
-        const int f = threadIdx.x + 256 * i;
+        const int f = threadIdx.x + T::NT * i;
         const int k = f / (BN / 4), c4 = f % (BN / 4);
         const long m = (long)s * BK + k;
         return bufld4(rdy, m < M ? (unsigned)(((int)m * d.K + n0 + c4 * 4) * 4) : kOOB);
     }
 };
 
-template <int BM, int BN, bool SPLIT>
-__global__ __launch_bounds__(256) void igemm_wgrad_kernel(ConvDims d, const float *__restrict__ x,
+template <int BM, int BN, bool SPLIT, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void igemm_wgrad_kernel(ConvDims d, const float *__restrict__ x,
                                                           const float *__restrict__ dy, float *__restrict__ dw,
                                                           int stages_per_split) {
     using T = TileCfg<BM, BN>;
@@ -489,13 +525,13 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(ConvDims d, const floa
         for (int ni = 0; ni < T::TN; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    WgradProblem<BM, BN> p;
+    WgradProblem<BM, BN, KG> p;
     p.init(d, x, dy, i0, n0, M);
-    mainloop<BM, BN>(p, s0, s1, smem, acc);
+    mainloop<BM, BN, KG>(p, s0, s1, smem, acc);
     const int Kc = d.K;
     auto rowoff = [=](int row) -> long { return (long)(i0 + row) * Kc + n0; };
     const ConvEpilogue none{nullptr, nullptr, nullptr, MMDGAN_ACT_LINEAR};
-    epilogue_store<BM, BN, SPLIT>(smem, acc, rowoff, n0, none, 1.f, dw, false, true);
+    epilogue_store<BM, BN, SPLIT, KG>(smem, acc, rowoff, n0, none, 1.f, dw, false, true);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -560,6 +596,11 @@ int igemm_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const f
     const dim3 grid((unsigned)((M + bm - 1) / bm), d.K / bn, split);
     if (bm == 128 && bn == 128) { if (split > 1) hipLaunchKernelGGL((igemm_fwd_kernel<128, 128, true>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, ep, x, w, y, sps); else hipLaunchKernelGGL((igemm_fwd_kernel<128, 128, false>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, ep, x, w, y, sps); }
     else if (bm == 128) { if (split > 1) hipLaunchKernelGGL((igemm_fwd_kernel<128, 64, true>), grid, dim3(256), (smem_bytes<128, 64>()), st, d, ep, x, w, y, sps); else hipLaunchKernelGGL((igemm_fwd_kernel<128, 64, false>), grid, dim3(256), (smem_bytes<128, 64>()), st, d, ep, x, w, y, sps); }
+    else if ((long)grid.x * grid.y * grid.z < kTargetBlocks) {
+        // a single 64x64 workgroup per CU: use the 8-wave K-group variant (2 waves per SIMD)
+        if (split > 1) hipLaunchKernelGGL((igemm_fwd_kernel<64, 64, true, 2>), grid, dim3(512), (smem_bytes<64, 64>()), st, d, ep, x, w, y, sps);
+        else hipLaunchKernelGGL((igemm_fwd_kernel<64, 64, false, 2>), grid, dim3(512), (smem_bytes<64, 64>()), st, d, ep, x, w, y, sps);
+    }
     else { if (split > 1) hipLaunchKernelGGL((igemm_fwd_kernel<64, 64, true>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, ep, x, w, y, sps); else hipLaunchKernelGGL((igemm_fwd_kernel<64, 64, false>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, ep, x, w, y, sps); }
     return check_launch("conv2d_fwd(igemm)");
 }
@@ -584,6 +625,11 @@ int igemm_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, cons
     const dim3 grid((unsigned)((M + bm - 1) / bm), d.C / bn, s * s * split);
     if (bm == 128 && bn == 128) { if (split > 1) hipLaunchKernelGGL((igemm_dgrad_kernel<128, 128, true>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, ep, dy, w, dx, split, sps); else hipLaunchKernelGGL((igemm_dgrad_kernel<128, 128, false>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, ep, dy, w, dx, split, sps); }
     else if (bm == 128) { if (split > 1) hipLaunchKernelGGL((igemm_dgrad_kernel<128, 64, true>), grid, dim3(256), (smem_bytes<128, 64>()), st, d, ep, dy, w, dx, split, sps); else hipLaunchKernelGGL((igemm_dgrad_kernel<128, 64, false>), grid, dim3(256), (smem_bytes<128, 64>()), st, d, ep, dy, w, dx, split, sps); }
+    else if ((long)grid.x * grid.y * grid.z < kTargetBlocks) {
+        // a single 64x64 workgroup per CU: use the 8-wave K-group variant (2 waves per SIMD)
+        if (split > 1) hipLaunchKernelGGL((igemm_dgrad_kernel<64, 64, true, 2>), grid, dim3(512), (smem_bytes<64, 64>()), st, d, ep, dy, w, dx, split, sps);
+        else hipLaunchKernelGGL((igemm_dgrad_kernel<64, 64, false, 2>), grid, dim3(512), (smem_bytes<64, 64>()), st, d, ep, dy, w, dx, split, sps);
+    }
     else { if (split > 1) hipLaunchKernelGGL((igemm_dgrad_kernel<64, 64, true>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, ep, dy, w, dx, split, sps); else hipLaunchKernelGGL((igemm_dgrad_kernel<64, 64, false>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, ep, dy, w, dx, split, sps); }
     return check_launch("conv2d_dgrad(igemm)");
 }
@@ -619,6 +665,11 @@ int igemm_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, h
         return check_launch("conv2d_wgrad memset");
     const dim3 grid(rows / bm, d.K / bn, split);
     if (bm == 128) { if (split > 1) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, true>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, x, dy, dw, sps); else hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, false>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, x, dy, dw, sps); }
+    else if ((long)grid.x * grid.y * grid.z < kTargetBlocks) {
+        // a single 64x64 workgroup per CU: use the 8-wave K-group variant (2 waves per SIMD)
+        if (split > 1) hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, true, 2>), grid, dim3(512), (smem_bytes<64, 64>()), st, d, x, dy, dw, sps);
+        else hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, false, 2>), grid, dim3(512), (smem_bytes<64, 64>()), st, d, x, dy, dw, sps);
+    }
     else { if (split > 1) hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, true>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, x, dy, dw, sps); else hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, false>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, x, dy, dw, sps); }
     return check_launch("conv2d_wgrad(igemm)");
 }
