@@ -136,6 +136,8 @@ CONV_CASES = [
     (1, 4, 4, 512, 512, 3, 1),
     (2, 24, 24, 64, 128, 4, 2),          # STL-like
     (3, 6, 6, 256, 256, 3, 1),
+    # few tiles -> 8-wave K-group kernels, split reductions with a ragged last split
+    (32, 16, 16, 64, 128, 3, 1), (16, 8, 8, 128, 128, 4, 2), (8, 4, 4, 256, 256, 3, 1), (5, 10, 10, 64, 64, 3, 1),
 ]
 
 

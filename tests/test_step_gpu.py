@@ -136,7 +136,7 @@ def test_step_matches_oracle_mfma_path(loss_type):
                     r = ref_g[n].numpy()
                     l2 = np.linalg.norm(grads[n].astype(np.float64) - r) / (np.linalg.norm(r) + 1e-6 * gscale)
                     assert l2 <= 5e-3, (step, n, l2)
-                    assert close(grads[n], r, 2e-2, 1e-4 * gscale), (step, n)
+                    assert close(grads[n], r, 5e-2, 1e-4 * gscale), (step, n)
         final = eng.get_variables()
         for n, v in final.items():
             if n == last_bias:
