@@ -137,6 +137,9 @@ int mmdgan_bn_bwd(const float *x, const float *y, const float *dy, long rows, in
  *                 `dot` is a device scalar holding <G,W>.
  * ---------------------------------------------------------------------------------------------- */
 int mmdgan_sn_norm(const float *v, long n, float *out_norm, float *v_normalised, void *stream);
+/* sn_norm + sn_scale in one launch: also writes scale_out[0] = act_k / ||v|| (scale_out may be NULL) */
+int mmdgan_sn_norm_scale(const float *v, long n, float act_k, float *out_norm, float *scale_out, float *v_normalised,
+                         void *stream);
 int mmdgan_sn_scale(const float *sigma, float act_k, float *scale_out, void *stream);
 int mmdgan_sn_wgrad_fixup(float *g_inout, const float *dsigma_dw, const float *dot, const float *sigma,
                           const float *scale, long n, void *stream);

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void dot_kernel(const float *__restrict__ a, c
 // ||v||_2 and v/(||v||+1e-10) in ONE block (SN vectors are <= 64K elements): deterministic, no
 // inter-block traffic.  math_func.py:651,659.
 __global__ __launch_bounds__(1024) void sn_norm_kernel(const float *__restrict__ v, long n, float *out_norm,
-                                                       float *vn) {
+                                                       float *vn, float act_k, float *scale_out) {
     __shared__ double red[16];
     __shared__ float s_norm;
     double acc = 0;
@@ -55,6 +55,7 @@ __global__ __launch_bounds__(1024) void sn_norm_kernel(const float *__restrict__
         for (int w = 0; w < 16; ++w) t += red[w];
         s_norm = (float)sqrt(t);
         if (out_norm) out_norm[0] = s_norm;
+        if (scale_out) scale_out[0] = act_k / s_norm;          // layer_func.py:886-887
     }
     __syncthreads();
     if (vn) {
@@ -165,8 +166,17 @@ extern "C" int mmdgan_dot(const float *a, const float *b, long n, float *out, vo
 
 extern "C" int mmdgan_sn_norm(const float *v, long n, float *out_norm, float *v_normalised, void *stream) {
     MMDGAN_REQUIRE(v && n >= 1 && (out_norm || v_normalised), "sn_norm: bad arguments");
-    hipLaunchKernelGGL(sn_norm_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, v, n, out_norm, v_normalised);
+    hipLaunchKernelGGL(sn_norm_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, v, n, out_norm, v_normalised, 0.f,
+                       (float *)nullptr);
     return check_launch("sn_norm");
+}
+
+extern "C" int mmdgan_sn_norm_scale(const float *v, long n, float act_k, float *out_norm, float *scale_out,
+                                    float *v_normalised, void *stream) {
+    MMDGAN_REQUIRE(v && n >= 1 && (out_norm || v_normalised || scale_out), "sn_norm_scale: bad arguments");
+    hipLaunchKernelGGL(sn_norm_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, v, n, out_norm, v_normalised, act_k,
+                       scale_out);
+    return check_launch("sn_norm_scale");
 }
 
 extern "C" int mmdgan_sn_scale(const float *sigma, float act_k, float *scale_out, void *stream) {

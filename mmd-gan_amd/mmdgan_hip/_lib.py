@@ -33,6 +33,7 @@ SIGNATURES = {
     'mmdgan_bn_fwd_infer': (_I, [_P, _L, _I, _P, _P, _F, _I, _P, _P, _P, _P]),
     'mmdgan_bn_bwd': (_I, [_P, _P, _P, _L, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     'mmdgan_sn_norm': (_I, [_P, _L, _P, _P, _P]),
+    'mmdgan_sn_norm_scale': (_I, [_P, _L, _F, _P, _P, _P, _P]),
     'mmdgan_sn_scale': (_I, [_P, _F, _P, _P]),
     'mmdgan_sn_wgrad_fixup': (_I, [_P, _P, _P, _P, _P, _L, _P]),
     'mmdgan_mmd_workspace_bytes': (ctypes.c_size_t, [_I, _I]),

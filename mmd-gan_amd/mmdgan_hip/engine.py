@@ -180,7 +180,6 @@ class Network:
         for s in specs:
             if s.sn:
                 self.state[s.scope + '/kernel/SN/in_rand'] = torch.zeros(self._sn_native_shape(s), device=device)
-                self.state[s.scope + '/kernel/SN/in_rand#next'] = torch.zeros(self._sn_native_shape(s), device=device)
                 for k in ('sigma', 'scale'):
                     self.state[s.scope + '#' + k] = torch.zeros(1, device=device)
                 for k in ('dot', 'dsigma', 'u', 'xb'):
@@ -342,6 +341,7 @@ class GanEngine:
             import torch.distributed as tdist
             self.world = tdist.get_world_size(dist_group)
         self._pending = []
+        self._sn_stream = torch.cuda.Stream(device=self.device)
         if ops._workspace is None:
             ops.set_workspace(device=self.device)
         self._alloc(self.B)
@@ -393,44 +393,44 @@ class GanEngine:
     # spectral norm: one power-iteration step per D layer (math_func.py:661-672)
     # ---------------------------------------------------------------------------------------
     def _sn_step(self, s):
+        """sigma = ||F(x)|| from the pre-update x, dsigma/dW, then x <- normalised F^T(y) IN PLACE: every
+        reader of the old x (F(x) and the dsigma outer product / weight gradient) is issued before
+        the write on the same stream, which is the UPDATE_OPS ordering (reads precede writes)."""
         net, b = self.dis, self.buf
         w = net.p(s.scope + '/kernel/kernel')
         x = net.state[s.scope + '/kernel/SN/in_rand']
-        x_next = net.state[s.scope + '/kernel/SN/in_rand#next']
         sigma, scale = net.state[s.scope + '#sigma'], net.state[s.scope + '#scale']
         dsig = net.state[s.scope + '#dsigma']
-        u, un, xb = b[s.scope + '#u'], b[s.scope + '#un'], b[s.scope + '#xb']
+        u, un, xb, xbn = b[s.scope + '#u'], b[s.scope + '#un'], b[s.scope + '#xb'], b[s.scope + '#xbnorm']
         if s.op == 'd':
             if 1 in s.kernel_shape:                                          # math_func.py:702-704
-                ops.sn_norm(w.view(-1), True, out_norm=sigma, out_v=dsig.view(-1))
-                x_next.copy_(x)
+                ops.sn_norm_scale(w.view(-1), s.act_k, sigma, scale, dsig.view(-1))
             elif s.use_u:
                 ops.gemm(x, w, out=u)                                        # u = x W          [1,out]
-                ops.sn_norm(u.view(-1), True, out_norm=sigma, out_v=un.view(-1))
-                ops.gemm(un, w, trans_b=True, out=xb)                        # y W^T            [1,in]
-                ops.sn_norm(xb.view(-1), True, out_norm=b[s.scope + '#xbnorm'], out_v=x_next.view(-1))
+                ops.sn_norm_scale(u.view(-1), s.act_k, sigma, scale, un.view(-1))
                 ops.gemm(x, un, trans_a=True, out=dsig)                      # dsigma/dW = x^T y
+                ops.gemm(un, w, trans_b=True, out=xb)                        # y W^T            [1,in]
+                ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
             else:
                 ops.gemm(x, w, trans_b=True, out=u)                          # u = x W^T        [1,in]
-                ops.sn_norm(u.view(-1), True, out_norm=sigma, out_v=un.view(-1))
-                ops.gemm(un, w, out=xb)                                      # y W              [1,out]
-                ops.sn_norm(xb.view(-1), True, out_norm=b[s.scope + '#xbnorm'], out_v=x_next.view(-1))
+                ops.sn_norm_scale(u.view(-1), s.act_k, sigma, scale, un.view(-1))
                 ops.gemm(un, x, trans_a=True, out=dsig)                      # dsigma/dW = y^T x
+                ops.gemm(un, w, out=xb)                                      # y W              [1,out]
+                ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
         else:
             c, h, wd = s.in_shape_ref
             if s.use_u:
                 ops.conv2d_fwd(x, w, s.stride, out=u)
-                ops.sn_norm(u.view(-1), True, out_norm=sigma, out_v=un.view(-1))
-                ops.conv2d_dgrad(un, w, (h, wd), s.stride, out=xb)
-                ops.sn_norm(xb.view(-1), True, out_norm=b[s.scope + '#xbnorm'], out_v=x_next.view(-1))
+                ops.sn_norm_scale(u.view(-1), s.act_k, sigma, scale, un.view(-1))
                 ops.conv2d_wgrad(x, un, s.R, s.stride, out=dsig)             # SURVEY A.2
+                ops.conv2d_dgrad(un, w, (h, wd), s.stride, out=xb)
+                ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
             else:
                 ops.conv2d_dgrad(x, w, (h, wd), s.stride, out=u)
-                ops.sn_norm(u.view(-1), True, out_norm=sigma, out_v=un.view(-1))
-                ops.conv2d_fwd(un, w, s.stride, out=xb)
-                ops.sn_norm(xb.view(-1), True, out_norm=b[s.scope + '#xbnorm'], out_v=x_next.view(-1))
+                ops.sn_norm_scale(u.view(-1), s.act_k, sigma, scale, un.view(-1))
                 ops.conv2d_wgrad(un, x, s.R, s.stride, out=dsig)
-        ops.sn_scale(sigma, s.act_k, out=scale)                              # layer_func.py:886-887
+                ops.conv2d_fwd(un, w, s.stride, out=xb)
+                ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
         return scale
 
     # ---------------------------------------------------------------------------------------
@@ -479,13 +479,20 @@ class GanEngine:
     # ---------------------------------------------------------------------------------------
     def _forward(self, z, real):
         B, b = self.B, self.buf
+        # the spectral-norm power iteration depends on D's weights only, not on the batch: its ~50
+        # small launches run on a second HIP stream underneath G's forward pass
+        main = torch.cuda.current_stream()
+        self._sn_stream.wait_stream(main)
+        self._scales = {}
+        with torch.cuda.stream(self._sn_stream):
+            for s in self.dis.specs:
+                self._scales[s.scope] = self._sn_step(s) if s.sn else None
         b['dis_in'][:B].copy_(real)
         self.generate(z, is_training=True)                                   # writes dis_in[B:]
+        main.wait_stream(self._sn_stream)
         x = b['dis_in']
-        self._scales = {}
         for s in self.dis.specs:
-            scale = self._sn_step(s) if s.sn else None
-            self._scales[s.scope] = scale
+            scale = self._scales[s.scope]
             x = self._layer_forward(self.dis, s, x, True, scale)
             if s.out_reshape is not None:
                 x = x.view(_native_shape(s.out_shape_ref, x.shape[0]))
@@ -628,9 +635,6 @@ class GanEngine:
         gs = 1.0 / self.world
         self.dis.opt.step(self.lr_d, grad_scale=gs)
         self.gen.opt.step(self.lr_g, grad_scale=gs)
-        for s in self.dis.specs:                                             # UPDATE_OPS: x <- x' (reads preceded writes)
-            if s.sn:
-                self.dis.state[s.scope + '/kernel/SN/in_rand'].copy_(self.dis.state[s.scope + '/kernel/SN/in_rand#next'])
 
     def _step_body(self, z, real):
         lib = ops.require_device()

@@ -193,6 +193,13 @@ def sn_norm(v, normalise=True, out_norm=None, out_v=None):
     return norm, vn
 
 
+def sn_norm_scale(v, act_k, out_norm, out_scale, out_v=None):
+    """||v|| -> out_norm, act_k/||v|| -> out_scale, v/(||v||+1e-10) -> out_v, one launch"""
+    lib = require_device()
+    check(lib.mmdgan_sn_norm_scale(_p(v), v.numel(), float(act_k), _p(out_norm), _p(out_scale), _p(out_v), _stream()),
+          'sn_norm_scale')
+
+
 def sn_scale(sigma, act_k, out=None):
     lib = require_device()
     o = out if out is not None else torch.empty(1, device=sigma.device, dtype=torch.float32)
