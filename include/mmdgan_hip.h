@@ -77,16 +77,20 @@ typedef struct {
 /* y = act(scale * conv(x, w) + bias)                       tf.nn.conv2d      layer_func.py:913-916
  * also the input-gradient of a transposed conv (with dact_of != NULL, see below).
  * If dact_of != NULL the epilogue is the BACKWARD form  y = scale*conv(x,w) * act'(dact_of)  where
- * dact_of holds the forward OUTPUT of the activation `act` at the same coordinates as y. */
+ * dact_of holds the forward OUTPUT of the activation `act` at the same coordinates as y.
+ * dact_batch (conv entries) / dact_rows (gemm): how many images / rows dact_of holds; 0 = as many as
+ * the output.  If fewer, the trailing N - dact_batch output images reuse the LAST N - dact_batch
+ * images of dact_of: the discriminator back-propagates its loss_dis rows (2B) and its loss_gen
+ * rows (B, fake half only) in ONE 3B-row launch per layer. */
 int mmdgan_conv2d_fwd(const mmdgan_conv_geom *g, const float *x, const float *w, const float *bias,
-                      const float *scale, int act, const float *dact_of, float *y, void *stream);
+                      const float *scale, int act, const float *dact_of, int dact_batch, float *y, void *stream);
 
 /* dx = scale * conv_input_grad(dy, w) [* act'(dact_of)]      autodiff of conv2d, my_sngan.py:302-304
  * Forward form (dact_of == NULL): dx = act(scale*conv_transpose(dy,w) + bias)
  *                                                          tf.nn.conv2d_transpose layer_func.py:926
  * g describes the CONV whose input-gradient this is: dy is [N,P,Q,K], dx is [N,H,W,C]. */
 int mmdgan_conv2d_dgrad(const mmdgan_conv_geom *g, const float *dy, const float *w, const float *bias,
-                        const float *scale, int act, const float *dact_of, float *dx, void *stream);
+                        const float *scale, int act, const float *dact_of, int dact_batch, float *dx, void *stream);
 
 /* dw[R,R,C,K] = sum over pixels x (x) dy                   autodiff of conv2d / conv2d_transpose
  * dw is overwritten. */
@@ -97,7 +101,7 @@ int mmdgan_conv2d_wgrad(const mmdgan_conv_geom *g, const float *x, const float *
  *   C[M,N] = act(scale * op(A) op(B) + bias[N]),  op(A) is [M,K], op(B) is [K,N].
  * ---------------------------------------------------------------------------------------------- */
 int mmdgan_gemm(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
-                const float *bias, const float *scale, int act, const float *dact_of, float *C, int ldc,
+                const float *bias, const float *scale, int act, const float *dact_of, int dact_rows, float *C, int ldc,
                 void *stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -23,25 +23,45 @@ bool force_direct() {
 }
 }  // namespace
 
+namespace {
+// dact_batch: number of images dact_of holds (0 = as many as the output); the trailing
+// (N - dact_batch) output images reuse the LAST (N - dact_batch) images of dact_of
+int make_wrap(int N, int dact_batch, long per_image, const char *what, long *from, long *sub) {
+    *from = kNoWrap; *sub = 0;
+    if (dact_batch == 0 || dact_batch == N) return MMDGAN_OK;
+    MMDGAN_REQUIRE(dact_batch > 0 && dact_batch < N && N - dact_batch <= dact_batch, "%s: bad dact_batch %d for N %d", what,
+                   dact_batch, N);
+    *from = (long)dact_batch * per_image;
+    *sub = (long)(N - dact_batch) * per_image;
+    return MMDGAN_OK;
+}
+}  // namespace
+
 extern "C" int mmdgan_conv2d_fwd(const mmdgan_conv_geom *g, const float *x, const float *w, const float *bias,
-                                 const float *scale, int act, const float *dact_of, float *y, void *stream) {
+                                 const float *scale, int act, const float *dact_of, int dact_batch, float *y,
+                                 void *stream) {
     if (int rc = validate(g, "conv2d_fwd")) return rc;
     MMDGAN_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
     MMDGAN_REQUIRE(act >= MMDGAN_ACT_LINEAR && act <= MMDGAN_ACT_TANH, "conv2d_fwd: unknown activation %d", act);
     const ConvDims d = conv_dims(*g);
-    const ConvEpilogue ep{bias, scale, dact_of, act};
+    long wf, ws;
+    if (int rc = make_wrap(d.N, dact_of ? dact_batch : 0, (long)d.P * d.Q * d.K, "conv2d_fwd", &wf, &ws)) return rc;
+    const ConvEpilogue ep{bias, scale, dact_of, act, wf, ws};
     if (!force_direct() && igemm_fwd_ok(d)) return igemm_fwd(d, ep, x, w, y, (hipStream_t)stream);
     if (!force_direct() && (thin_fwd_in_ok(d) || thin_fwd_out_ok(d))) return thin_fwd(d, ep, x, w, y, (hipStream_t)stream);
     return direct_fwd(d, ep, x, w, y, (hipStream_t)stream);
 }
 
 extern "C" int mmdgan_conv2d_dgrad(const mmdgan_conv_geom *g, const float *dy, const float *w, const float *bias,
-                                   const float *scale, int act, const float *dact_of, float *dx, void *stream) {
+                                   const float *scale, int act, const float *dact_of, int dact_batch, float *dx,
+                                   void *stream) {
     if (int rc = validate(g, "conv2d_dgrad")) return rc;
     MMDGAN_REQUIRE(dy && w && dx, "conv2d_dgrad: null pointer");
     MMDGAN_REQUIRE(act >= MMDGAN_ACT_LINEAR && act <= MMDGAN_ACT_TANH, "conv2d_dgrad: unknown activation %d", act);
     const ConvDims d = conv_dims(*g);
-    const ConvEpilogue ep{bias, scale, dact_of, act};
+    long wf, ws;
+    if (int rc = make_wrap(d.N, dact_of ? dact_batch : 0, (long)d.H * d.W * d.C, "conv2d_dgrad", &wf, &ws)) return rc;
+    const ConvEpilogue ep{bias, scale, dact_of, act, wf, ws};
     if (!force_direct() && igemm_dgrad_ok(d)) return igemm_dgrad(d, ep, dy, w, dx, (hipStream_t)stream);
     if (!force_direct() && (thin_dgrad_in_ok(d) || thin_dgrad_out_ok(d)))
         return thin_dgrad(d, ep, dy, w, dx, (hipStream_t)stream);

@@ -273,7 +273,7 @@ __device__ __forceinline__ void epilogue_store(float *smem, f32x16 (&acc)[TileCf
                 {
                     if (!raw) {
                         if (ep.dact) {
-                            const float4 y = *reinterpret_cast<const float4 *>(ep.dact + o);
+                            const float4 y = *reinterpret_cast<const float4 *>(ep.dact + ep.dact_index(o));
                             v.x *= act_bwd_from_out(y.x, ep.act); v.y *= act_bwd_from_out(y.y, ep.act);
                             v.z *= act_bwd_from_out(y.z, ep.act); v.w *= act_bwd_from_out(y.w, ep.act);
                         } else {
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_wgrad_kernel(ConvDims d, const
     mainloop<BM, BN, KG>(p, s0, s1, smem, acc);
     const int Kc = d.K;
     auto rowoff = [=](int row) -> long { return (long)(i0 + row) * Kc + n0; };
-    const ConvEpilogue none{nullptr, nullptr, nullptr, MMDGAN_ACT_LINEAR};
+    const ConvEpilogue none{nullptr, nullptr, nullptr, MMDGAN_ACT_LINEAR, kNoWrap, 0};
     epilogue_store<BM, BN, SPLIT, KG>(smem, acc, rowoff, n0, none, 1.f, dw, false, true);
 }
 

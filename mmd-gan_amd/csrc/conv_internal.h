@@ -6,14 +6,20 @@ namespace mmdgan {
 
 // epilogue shared by every conv/dgrad kernel: forward form act(v + bias) or backward form
 // (v + bias) * act'(dact[o]);  v arrives already multiplied by the SN scale.
+// dact may cover fewer images than the output: output elements at offset >= wrap_from read
+// dact[o - wrap_sub] (the discriminator back-propagates [loss_dis rows (2B) ; loss_gen rows (B)] in one
+// 3B-row launch, and the last B rows reuse the activations of the fake half).
 struct ConvEpilogue {
     const float *bias, *scale, *dact;
     int act;
+    long wrap_from, wrap_sub;
+    __device__ __forceinline__ long dact_index(long o) const { return o >= wrap_from ? o - wrap_sub : o; }
     __device__ __forceinline__ float apply(float v, int ch, long o) const {
         if (bias) v += bias[ch];
-        return dact ? v * act_bwd_from_out(dact[o], act) : act_fwd(v, act);
+        return dact ? v * act_bwd_from_out(dact[dact_index(o)], act) : act_fwd(v, act);
     }
 };
+constexpr long kNoWrap = 0x7fffffffffffffffL;
 
 int direct_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, float *y, hipStream_t st);
 int direct_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, float *dx, hipStream_t st);

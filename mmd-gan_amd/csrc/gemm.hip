@@ -15,6 +15,7 @@ struct GemmArgs {
     const float *A, *B, *bias, *scale, *dact;
     float *C;
     int M, N, K, lda, ldb, ldc, transA, transB, act, ksplit, kchunk;
+    long wrap_from, wrap_sub;          // rows >= dact_rows read dact shifted back (see ConvEpilogue)
 };
 
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                 atomicAdd(g.C + o, v);
             } else {
                 if (g.bias) v += g.bias[gn];
-                g.C[o] = g.dact ? v * act_bwd_from_out(g.dact[o], g.act) : act_fwd(v, g.act);
+                g.C[o] = g.dact ? v * act_bwd_from_out(g.dact[o >= (size_t)g.wrap_from ? o - g.wrap_sub : o], g.act) : act_fwd(v, g.act);
             }
         }
     }
@@ -89,14 +90,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 using namespace mmdgan;
 
 extern "C" int mmdgan_gemm(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
-                           const float *bias, const float *scale, int act, const float *dact_of, float *C, int ldc,
-                           void *stream) {
+                           const float *bias, const float *scale, int act, const float *dact_of, int dact_rows, float *C,
+                           int ldc, void *stream) {
     MMDGAN_REQUIRE(A && B && C, "gemm: null pointer");
     MMDGAN_REQUIRE(M >= 1 && N >= 1 && K >= 1, "gemm: bad shape %dx%dx%d", M, N, K);
     MMDGAN_REQUIRE(act >= MMDGAN_ACT_LINEAR && act <= MMDGAN_ACT_TANH, "gemm: unknown activation %d", act);
     hipStream_t st = (hipStream_t)stream;
     GemmArgs g;
     g.A = A; g.B = B; g.bias = bias; g.scale = scale; g.dact = dact_of; g.C = C;
+    g.wrap_from = 0x7fffffffffffffffL; g.wrap_sub = 0;
+    if (dact_of && dact_rows != 0 && dact_rows != M) {
+        MMDGAN_REQUIRE(dact_rows > 0 && dact_rows < M && M - dact_rows <= dact_rows, "gemm: bad dact_rows %d for M %d", dact_rows, M);
+        g.wrap_from = (long)dact_rows * ldc; g.wrap_sub = (long)(M - dact_rows) * ldc;
+    }
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.transA = transA; g.transB = transB; g.act = act;
     const int tiles = ((M + GT - 1) / GT) * ((N + GT - 1) / GT);
     int ksplit = 1;

@@ -22,10 +22,10 @@ SIGNATURES = {
     'mmdgan_device_ok': (_I, []),
     'mmdgan_set_workspace': (_I, [_P, ctypes.c_size_t]),
     'mmdgan_set_outputs_prezeroed': (_I, [_I]),
-    'mmdgan_conv2d_fwd': (_I, [_G, _P, _P, _P, _P, _I, _P, _P, _P]),
-    'mmdgan_conv2d_dgrad': (_I, [_G, _P, _P, _P, _P, _I, _P, _P, _P]),
+    'mmdgan_conv2d_fwd': (_I, [_G, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
+    'mmdgan_conv2d_dgrad': (_I, [_G, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     'mmdgan_conv2d_wgrad': (_I, [_G, _P, _P, _P, _P]),
-    'mmdgan_gemm': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P]),
+    'mmdgan_gemm': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P]),
     'mmdgan_colsum': (_I, [_P, _L, _I, _P, _P]),
     'mmdgan_dot': (_I, [_P, _P, _L, _P, _P]),
     'mmdgan_bn_workspace_bytes': (ctypes.c_size_t, [_I]),

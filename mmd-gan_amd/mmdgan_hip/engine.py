@@ -368,12 +368,12 @@ class GanEngine:
                     self.buf[s.scope + '#invstd'] = torch.zeros(nfeat, device=dev)
                 is_gen_out = net is self.gen and s is self.gen.specs[-1]
                 self.buf[s.scope + '#y'] = self.buf['dis_in'][B:] if is_gen_out else torch.zeros(shp, device=dev)
-                # gradient w.r.t. the layer's pre-activation output (after act'), D also for the G pass
-                self.buf[s.scope + '#dz'] = torch.zeros(shp, device=dev)
-                if net is self.dis:
-                    self.buf[s.scope + '#dz_g'] = torch.zeros(_native_shape(s.op_out_ref, B), device=dev)
+                # gradient w.r.t. the layer's pre-activation output (after act').  D back-propagates
+                # [loss_dis rows (2B) ; loss_gen rows of the fake half (B)] together: 3B rows per layer
+                self.buf[s.scope + '#dz'] = torch.zeros(_native_shape(s.op_out_ref, 3 * B) if net is self.dis else shp,
+                                                        device=dev)
         self.buf['d_fake'] = torch.zeros(B, h, w, c, device=dev)
-        self.buf['ds_d'] = torch.zeros(2 * B, self.score_size, device=dev)
+        self.buf['ds_d'] = torch.zeros(3 * B, self.score_size, device=dev)
         # SN scratch per D layer (u / xb live in the network's zero-once-per-step arena)
         for s in self.dis.specs:
             if s.sn:
@@ -512,27 +512,31 @@ class GanEngine:
 
     # ---------------------------------------------------------------------------------------
     def _backward_dis(self):
-        """loss_dis -> D parameters (batch 2B), and loss_gen -> d(fake images) (fake half, dgrad only)."""
+        """loss_dis -> D parameters (rows 0..2B-1) and loss_gen -> d(fake images) (rows 2B..3B-1, the fake
+        half, input-gradients only), back-propagated through D together: one 3B-row dgrad launch per
+        layer (the last B rows take their activation derivative from the fake half's activations),
+        weight / bias gradients from the first 2B rows only."""
         B, b, net = self.B, self.buf, self.dis
         g = b['mmd_grads']                                                   # dLg/dsg, dLg/dsx, dLd/dsg, dLd/dsx
         specs = net.specs
-        # ---- D pass: upstream [dLd/ds_x ; dLd/ds_gen] (real rows first, my_sngan.py:278-279)
-        b['ds_d'][:B].copy_(g[3])
-        b['ds_d'][B:].copy_(g[2])
-        dz = b['ds_d']
+        ds = b['ds_d']
+        ds[:B].copy_(g[3])                                                   # real rows first (my_sngan.py:278-279)
+        ds[B:2 * B].copy_(g[2])
+        ds[2 * B:].copy_(g[0])                                               # dLgen/ds_gen
+        dz = ds
         for li in range(len(specs) - 1, -1, -1):
             s = specs[li]
             x_in = b['dis_in'] if li == 0 else b[specs[li - 1].scope + '#y']
             w = net.p(s.scope + '/kernel/kernel')
             gw = net.g(s.scope + '/kernel/kernel')
             scale = self._scales[s.scope]
-            dz2d = dz.reshape(-1, dz.shape[-1])
+            dz_main = dz[:2 * B]
             if s.has_bias:
-                ops.colsum(dz2d, out=net.g(s.scope + '/bias/bias'))
+                ops.colsum(dz_main.reshape(-1, dz.shape[-1]), out=net.g(s.scope + '/bias/bias'))
             if s.op == 'd':
-                ops.gemm(x_in.reshape(2 * B, -1), dz2d, trans_a=True, out=gw)
+                ops.gemm(x_in.reshape(2 * B, -1), dz_main.reshape(2 * B, -1), trans_a=True, out=gw)
             else:
-                ops.conv2d_wgrad(x_in, dz, s.R, s.stride, out=gw)
+                ops.conv2d_wgrad(x_in, dz_main, s.R, s.stride, out=gw)
             if s.sn:                                                         # SURVEY A.2 fix-up
                 dot = net.state[s.scope + '#dot']
                 ops.dot(gw.view(-1), w.view(-1), out=dot)
@@ -540,37 +544,27 @@ class GanEngine:
                                    net.state[s.scope + '#sigma'], scale)
             if li > 0:
                 prev = specs[li - 1]
-                dprev = b[prev.scope + '#dz']
-                yprev = b[prev.scope + '#y']
+                dprev, yprev = b[prev.scope + '#dz'], b[prev.scope + '#y']
                 if s.op == 'd':
-                    ops.gemm(dz2d, w, trans_b=True, scale=scale, act=prev.act, dact_of=yprev.view(2 * B, -1),
-                             out=dprev.view(2 * B, -1))
+                    ops.gemm(dz.reshape(3 * B, -1), w, trans_b=True, scale=scale, act=prev.act,
+                             dact_of=yprev.view(2 * B, -1), dact_rows=2 * B, out=dprev.view(3 * B, -1))
                 else:
                     ops.conv2d_dgrad(dz, w, (yprev.shape[1], yprev.shape[2]), s.stride, scale=scale, act=prev.act,
-                                     dact_of=yprev, out=dprev)
+                                     dact_of=yprev, dact_batch=2 * B, out=dprev)
                 dz = dprev
-        # ---- G pass through D: fake half only, dgrad only
-        dz = g[0]                                                            # dLgen/ds_gen [B, d]
-        gen_last = self.gen.specs[-1]
-        for li in range(len(specs) - 1, -1, -1):
-            s = specs[li]
-            w = net.p(s.scope + '/kernel/kernel')
-            scale = self._scales[s.scope]
-            if li > 0:
-                prev = specs[li - 1]
-                yprev, act_prev, out = b[prev.scope + '#y'][B:], prev.act, b[prev.scope + '#dz_g']
             else:
-                # below D l1 sits G's output: apply G's last activation derivative (tanh') unless G ends in BN
-                yprev, out = b['dis_in'][B:], b['d_fake']
+                # below D l1 sits G's output: only the loss_gen rows go further, with G's last
+                # activation derivative (tanh') unless G ends in BN (then bn_bwd applies it)
+                gen_last = self.gen.specs[-1]
                 act_prev = 'linear' if gen_last.bn else gen_last.act
-            if s.op == 'd':
-                ops.gemm(dz.reshape(B, -1), w, trans_b=True, scale=scale, act=act_prev, dact_of=yprev.reshape(B, -1),
-                         out=out.view(B, -1))
-            else:
-                ops.conv2d_dgrad(dz, w, (yprev.shape[1], yprev.shape[2]), s.stride, scale=scale, act=act_prev,
-                                 dact_of=yprev, out=out)
-            dz = out
-        return dz                                                            # gradient w.r.t. G's last pre-activation
+                yprev, out, dzg = b['dis_in'][B:], b['d_fake'], dz[2 * B:]
+                if s.op == 'd':
+                    ops.gemm(dzg.reshape(B, -1), w, trans_b=True, scale=scale, act=act_prev,
+                             dact_of=yprev.reshape(B, -1), out=out.view(B, -1))
+                else:
+                    ops.conv2d_dgrad(dzg, w, (yprev.shape[1], yprev.shape[2]), s.stride, scale=scale, act=act_prev,
+                                     dact_of=yprev, out=out)
+        return b['d_fake']                                                   # gradient w.r.t. G's last pre-activation
 
     def _backward_gen(self, dz, z):
         B, b, net = self.B, self.buf, self.gen

@@ -67,7 +67,7 @@ def out_hw(H, W, stride):
 
 
 # ------------------------------------------------------------------------------------------------
-def conv2d_fwd(x, w, stride, bias=None, scale=None, act='linear', dact_of=None, out=None):
+def conv2d_fwd(x, w, stride, bias=None, scale=None, act='linear', dact_of=None, out=None, dact_batch=0):
     """x [N,H,W,C], w [R,R,C,K] -> y [N,P,Q,K] = act(scale*conv(x,w)+bias) (layer_func.py:913-916)"""
     lib = require_device()
     N, H, W, C = x.shape
@@ -76,12 +76,12 @@ def conv2d_fwd(x, w, stride, bias=None, scale=None, act='linear', dact_of=None, 
     P, Q = out_hw(H, W, stride)
     y = out if out is not None else torch.empty((N, P, Q, K), device=x.device, dtype=torch.float32)
     g = geom(N, H, W, C, K, R, stride)
-    check(lib.mmdgan_conv2d_fwd(ctypes.byref(g), _p(x), _p(w), _p(bias), _p(scale), act_id(act), _p(dact_of), _p(y),
-                                _stream()), 'conv2d_fwd')
+    check(lib.mmdgan_conv2d_fwd(ctypes.byref(g), _p(x), _p(w), _p(bias), _p(scale), act_id(act), _p(dact_of), int(dact_batch),
+                                _p(y), _stream()), 'conv2d_fwd')
     return y
 
 
-def conv2d_dgrad(dy, w, in_hw, stride, bias=None, scale=None, act='linear', dact_of=None, out=None):
+def conv2d_dgrad(dy, w, in_hw, stride, bias=None, scale=None, act='linear', dact_of=None, out=None, dact_batch=0):
     """dy [N,P,Q,K], w [R,R,C,K] -> dx [N,H,W,C]; forward form = tf.nn.conv2d_transpose (layer_func.py:926)"""
     lib = require_device()
     N, P, Q, K = dy.shape
@@ -91,8 +91,8 @@ def conv2d_dgrad(dy, w, in_hw, stride, bias=None, scale=None, act='linear', dact
     assert out_hw(H, W, stride) == (P, Q)
     dx = out if out is not None else torch.empty((N, H, W, C), device=dy.device, dtype=torch.float32)
     g = geom(N, H, W, C, K, R, stride)
-    check(lib.mmdgan_conv2d_dgrad(ctypes.byref(g), _p(dy), _p(w), _p(bias), _p(scale), act_id(act), _p(dact_of), _p(dx),
-                                  _stream()), 'conv2d_dgrad')
+    check(lib.mmdgan_conv2d_dgrad(ctypes.byref(g), _p(dy), _p(w), _p(bias), _p(scale), act_id(act), _p(dact_of),
+                                  int(dact_batch), _p(dx), _stream()), 'conv2d_dgrad')
     return dx
 
 
@@ -107,7 +107,7 @@ def conv2d_wgrad(x, dy, R, stride, out=None):
     return dw
 
 
-def gemm(a, b, trans_a=False, trans_b=False, bias=None, scale=None, act='linear', dact_of=None, out=None):
+def gemm(a, b, trans_a=False, trans_b=False, bias=None, scale=None, act='linear', dact_of=None, out=None, dact_rows=0):
     """C = act(scale * op(a) op(b) + bias), row-major 2-D tensors (tf.matmul, layer_func.py:911)"""
     lib = require_device()
     M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
@@ -115,7 +115,7 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, scale=None, act='linear'
     assert K == K2, (a.shape, b.shape, trans_a, trans_b)
     c = out if out is not None else torch.empty((M, N), device=a.device, dtype=torch.float32)
     check(lib.mmdgan_gemm(int(trans_a), int(trans_b), M, N, K, _p(a), a.shape[1], _p(b), b.shape[1], _p(bias), _p(scale),
-                          act_id(act), _p(dact_of), _p(c), N, _stream()), 'gemm')
+                          act_id(act), _p(dact_of), int(dact_rows), _p(c), N, _stream()), 'gemm')
     return c
 
 

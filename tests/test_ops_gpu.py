@@ -200,6 +200,30 @@ def test_conv2d_transpose_forward_form(ops, case):
     assert rel_err(to_nchw(y), ref) <= RTOL
 
 
+def test_dact_batch_wrap(ops):
+    """3B-row backward: the last B output images take act' from the LAST B images of a 2B-image
+    activation tensor (conv dgrad on the MFMA path, on the direct path, and gemm)."""
+    rs = np.random.RandomState(4)
+    for (B, H, C, K, ksz, st) in ((4, 8, 64, 128, 3, 1), (2, 6, 5, 7, 3, 1), (4, 8, 64, 64, 4, 2)):
+        P = -(-H // st)
+        dy = rs.randn(3 * B, K, P, P).astype(np.float32)
+        w = (rs.randn(ksz, ksz, C, K) / np.sqrt(ksz * ksz * C)).astype(np.float32)
+        yprev = rs.randn(2 * B, C, H, H).astype(np.float32)
+        xt = torch.zeros(3 * B, C, H, H, dtype=torch.float64, requires_grad=True)
+        (R.conv2d_same(xt, torch.tensor(w, dtype=torch.float64), st) * torch.tensor(dy, dtype=torch.float64)).sum().backward()
+        mask = np.where(np.concatenate([yprev, yprev[B:]], 0) > 0, 1.0, 0.1)
+        ref = xt.grad.numpy() * mask
+        dx = ops.conv2d_dgrad(nhwc(dy), dev(w), (H, H), st, act='lrelu', dact_of=nhwc(yprev), dact_batch=2 * B)
+        assert rel_err(to_nchw(dx), ref) <= RTOL, (B, H, C, K)
+    a, bm = rs.randn(12, 16).astype(np.float32), rs.randn(40, 16).astype(np.float32)
+    y2 = rs.randn(8, 40).astype(np.float32)
+    ref = (a.astype(np.float64) @ bm.T.astype(np.float64)) * np.where(np.concatenate([y2, y2[4:]], 0) > 0, 1.0, 0.0)
+    c = ops.gemm(dev(a), dev(bm), trans_b=True, act='relu', dact_of=dev(y2), dact_rows=8)
+    assert rel_err(c.cpu().numpy(), ref) <= RTOL
+    with pytest.raises(ValueError, match='dact_rows'):
+        ops.gemm(dev(a), dev(bm), trans_b=True, act='relu', dact_of=dev(y2), dact_rows=3)
+
+
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('M,N,K,ta,tb', [(64, 8192, 128, False, False), (128, 16, 8192, False, False),
                                          (128, 8192, 16, False, True), (8192, 16, 128, True, False),
