@@ -39,6 +39,10 @@ extern "C" {
 #define MMDGAN_ACT_RELU 1
 #define MMDGAN_ACT_LRELU 2
 #define MMDGAN_ACT_TANH 3
+/* OR-ed into `act` of conv2d_fwd / conv2d_dgrad: the output buffer is zero on entry and the entry may
+ * ACCUMULATE into it (lets a launch with too few tiles for 256 CUs split its reduction even when
+ * mmdgan_set_outputs_prezeroed(1) is in force).  Only honoured with a linear epilogue (no dact_of). */
+#define MMDGAN_ACT_FLAG_OUT_ZEROED 0x100
 
 /* loss enum - math_func.py:2644-2647 */
 #define MMDGAN_LOSS_REP 0

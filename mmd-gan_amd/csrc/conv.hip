@@ -42,11 +42,13 @@ extern "C" int mmdgan_conv2d_fwd(const mmdgan_conv_geom *g, const float *x, cons
                                  void *stream) {
     if (int rc = validate(g, "conv2d_fwd")) return rc;
     MMDGAN_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
+    const bool out_zeroed = (act & MMDGAN_ACT_FLAG_OUT_ZEROED) != 0;
+    act &= ~MMDGAN_ACT_FLAG_OUT_ZEROED;
     MMDGAN_REQUIRE(act >= MMDGAN_ACT_LINEAR && act <= MMDGAN_ACT_TANH, "conv2d_fwd: unknown activation %d", act);
     const ConvDims d = conv_dims(*g);
     long wf, ws;
     if (int rc = make_wrap(d.N, dact_of ? dact_batch : 0, (long)d.P * d.Q * d.K, "conv2d_fwd", &wf, &ws)) return rc;
-    const ConvEpilogue ep{bias, scale, dact_of, act, wf, ws};
+    const ConvEpilogue ep{bias, scale, dact_of, act, wf, ws, out_zeroed};
     if (!force_direct() && igemm_fwd_ok(d)) return igemm_fwd(d, ep, x, w, y, (hipStream_t)stream);
     if (!force_direct() && (thin_fwd_in_ok(d) || thin_fwd_out_ok(d))) return thin_fwd(d, ep, x, w, y, (hipStream_t)stream);
     return direct_fwd(d, ep, x, w, y, (hipStream_t)stream);
@@ -57,11 +59,13 @@ extern "C" int mmdgan_conv2d_dgrad(const mmdgan_conv_geom *g, const float *dy, c
                                    void *stream) {
     if (int rc = validate(g, "conv2d_dgrad")) return rc;
     MMDGAN_REQUIRE(dy && w && dx, "conv2d_dgrad: null pointer");
+    const bool out_zeroed = (act & MMDGAN_ACT_FLAG_OUT_ZEROED) != 0;
+    act &= ~MMDGAN_ACT_FLAG_OUT_ZEROED;
     MMDGAN_REQUIRE(act >= MMDGAN_ACT_LINEAR && act <= MMDGAN_ACT_TANH, "conv2d_dgrad: unknown activation %d", act);
     const ConvDims d = conv_dims(*g);
     long wf, ws;
     if (int rc = make_wrap(d.N, dact_of ? dact_batch : 0, (long)d.H * d.W * d.C, "conv2d_dgrad", &wf, &ws)) return rc;
-    const ConvEpilogue ep{bias, scale, dact_of, act, wf, ws};
+    const ConvEpilogue ep{bias, scale, dact_of, act, wf, ws, out_zeroed};
     if (!force_direct() && igemm_dgrad_ok(d)) return igemm_dgrad(d, ep, dy, w, dx, (hipStream_t)stream);
     if (!force_direct() && (thin_dgrad_in_ok(d) || thin_dgrad_out_ok(d)))
         return thin_dgrad(d, ep, dy, w, dx, (hipStream_t)stream);

@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_wgrad_kernel(ConvDims d, const
     mainloop<BM, BN, KG>(p, s0, s1, smem, acc);
     const int Kc = d.K;
     auto rowoff = [=](int row) -> long { return (long)(i0 + row) * Kc + n0; };
-    const ConvEpilogue none{nullptr, nullptr, nullptr, MMDGAN_ACT_LINEAR, kNoWrap, 0};
+    const ConvEpilogue none{nullptr, nullptr, nullptr, MMDGAN_ACT_LINEAR, kNoWrap, 0, false};
     epilogue_store<BM, BN, SPLIT, KG>(smem, acc, rowoff, n0, none, 1.f, dw, false, true);
 }
 
@@ -588,11 +588,11 @@ int igemm_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const f
     const int nstages = d.R * d.R * d.C / BK;
     const long tiles = ((M + bm - 1) / bm) * (d.K / bn);
     // with caller-side zeroing only the batch-1 (spectral-norm power iteration) launches may split
-    const bool may_split = ep.act == MMDGAN_ACT_LINEAR && !ep.dact && (!outputs_prezeroed() || d.N == 1);
+    const bool may_split = ep.act == MMDGAN_ACT_LINEAR && !ep.dact && (!outputs_prezeroed() || d.N == 1 || ep.out_zeroed);
     int split = pick_split(tiles, nstages, may_split);
     int sps = (nstages + split - 1) / split;
     split = (nstages + sps - 1) / sps;
-    if (split > 1 && zero_output(y, sizeof(float) * M * d.K, st) != hipSuccess) return check_launch("conv2d_fwd memset");
+    if (split > 1 && !ep.out_zeroed && zero_output(y, sizeof(float) * M * d.K, st) != hipSuccess) return check_launch("conv2d_fwd memset");
     const dim3 grid((unsigned)((M + bm - 1) / bm), d.K / bn, split);
     if (bm == 128 && bn == 128) { if (split > 1) hipLaunchKernelGGL((igemm_fwd_kernel<128, 128, true>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, ep, x, w, y, sps); else hipLaunchKernelGGL((igemm_fwd_kernel<128, 128, false>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, ep, x, w, y, sps); }
     else if (bm == 128) { if (split > 1) hipLaunchKernelGGL((igemm_fwd_kernel<128, 64, true>), grid, dim3(256), (smem_bytes<128, 64>()), st, d, ep, x, w, y, sps); else hipLaunchKernelGGL((igemm_fwd_kernel<128, 64, false>), grid, dim3(256), (smem_bytes<128, 64>()), st, d, ep, x, w, y, sps); }
@@ -616,11 +616,11 @@ int igemm_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, cons
     const long tiles = ((M + bm - 1) / bm) * (d.C / bn) * s * s;
     const int TT = d.R / s;
     const int nstages = TT * TT * d.K / BK;
-    const bool may_split = ep.act == MMDGAN_ACT_LINEAR && !ep.dact && (!outputs_prezeroed() || d.N == 1);
+    const bool may_split = ep.act == MMDGAN_ACT_LINEAR && !ep.dact && (!outputs_prezeroed() || d.N == 1 || ep.out_zeroed);
     int split = pick_split(tiles, nstages, may_split);
     int sps = (nstages + split - 1) / split;
     split = (nstages + sps - 1) / sps;
-    if (split > 1 && zero_output(dx, sizeof(float) * (long)d.N * d.H * d.W * d.C, st) != hipSuccess)
+    if (split > 1 && !ep.out_zeroed && zero_output(dx, sizeof(float) * (long)d.N * d.H * d.W * d.C, st) != hipSuccess)
         return check_launch("conv2d_dgrad memset");
     const dim3 grid((unsigned)((M + bm - 1) / bm), d.C / bn, s * s * split);
     if (bm == 128 && bn == 128) { if (split > 1) hipLaunchKernelGGL((igemm_dgrad_kernel<128, 128, true>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, ep, dy, w, dx, split, sps); else hipLaunchKernelGGL((igemm_dgrad_kernel<128, 128, false>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, ep, dy, w, dx, split, sps); }

@@ -13,6 +13,7 @@ struct ConvEpilogue {
     const float *bias, *scale, *dact;
     int act;
     long wrap_from, wrap_sub;
+    bool out_zeroed;          // host-side hint only (MMDGAN_ACT_FLAG_OUT_ZEROED)
     __device__ __forceinline__ long dact_index(long o) const { return o >= wrap_from ? o - wrap_sub : o; }
     __device__ __forceinline__ float apply(float v, int ch, long o) const {
         if (bias) v += bias[ch];

@@ -388,6 +388,10 @@ class GanEngine:
             for s in net.specs:          # dense outputs whose K is long enough for the split-K gemm path
                 if s.op == 'd' and s.kernel_shape[0] >= 512:
                     self._zero_each_step.append(self.buf[s.scope + ('#raw' if s.bn else '#y')])
+        gs = self.gen.specs
+        for below, above in zip(gs, gs[1:]):     # input-gradient of a tc layer into a linear layer: split-K target
+            if above.op == 'tc' and (below.bn or below.act == 'linear'):
+                self._zero_each_step.append(self.buf[below.scope + ('#dy' if below.bn else '#dz')])
 
     # ---------------------------------------------------------------------------------------
     # spectral norm: one power-iteration step per D layer (math_func.py:661-672)
@@ -609,7 +613,11 @@ class GanEngine:
                 elif s.op == 'c':
                     ops.conv2d_dgrad(dz, w, (in_shape[1], in_shape[2]), s.stride, act=act_prev, dact_of=dact, out=dprev)
                 else:                                                        # d/dv of dgrad(v, W) = conv(dz, W)
-                    ops.conv2d_fwd(dz, w, s.stride, act=act_prev, dact_of=dact, out=dprev)
+                    # few tiles (M = B*h*w is small at the top of G): if the epilogue is linear let the
+                    # kernel split its K = R*R*Cout reduction into a buffer zeroed at step start
+                    zeroed = dact is None and act_prev == 'linear' and any(dprev.data_ptr() == t.data_ptr()
+                                                                            for t in self._zero_each_step)
+                    ops.conv2d_fwd(dz, w, s.stride, act=act_prev, dact_of=dact, out=dprev, out_zeroed=zeroed)
                 dz = dprev
 
     # ---------------------------------------------------------------------------------------

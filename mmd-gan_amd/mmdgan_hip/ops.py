@@ -67,7 +67,8 @@ def out_hw(H, W, stride):
 
 
 # ------------------------------------------------------------------------------------------------
-def conv2d_fwd(x, w, stride, bias=None, scale=None, act='linear', dact_of=None, out=None, dact_batch=0):
+def conv2d_fwd(x, w, stride, bias=None, scale=None, act='linear', dact_of=None, out=None, dact_batch=0,
+               out_zeroed=False):
     """x [N,H,W,C], w [R,R,C,K] -> y [N,P,Q,K] = act(scale*conv(x,w)+bias) (layer_func.py:913-916)"""
     lib = require_device()
     N, H, W, C = x.shape
@@ -76,7 +77,8 @@ def conv2d_fwd(x, w, stride, bias=None, scale=None, act='linear', dact_of=None, 
     P, Q = out_hw(H, W, stride)
     y = out if out is not None else torch.empty((N, P, Q, K), device=x.device, dtype=torch.float32)
     g = geom(N, H, W, C, K, R, stride)
-    check(lib.mmdgan_conv2d_fwd(ctypes.byref(g), _p(x), _p(w), _p(bias), _p(scale), act_id(act), _p(dact_of), int(dact_batch),
+    check(lib.mmdgan_conv2d_fwd(ctypes.byref(g), _p(x), _p(w), _p(bias), _p(scale),
+                                act_id(act) | (0x100 if out_zeroed else 0), _p(dact_of), int(dact_batch),
                                 _p(y), _stream()), 'conv2d_fwd')
     return y
 

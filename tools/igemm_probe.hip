@@ -10,7 +10,7 @@ int main(int argc, char **argv) {
     float *x, *w, *y;
     (void)hipMalloc(&x, nx * 4); (void)hipMalloc(&w, nw * 4); (void)hipMalloc(&y, ny * 4);
     (void)hipMemset(x, 0, nx * 4); (void)hipMemset(w, 0, nw * 4);
-    ConvEpilogue ep{nullptr, nullptr, nullptr, 0, kNoWrap, 0};
+    ConvEpilogue ep{nullptr, nullptr, nullptr, 0, kNoWrap, 0, false};
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int i = 0; i < 3; ++i) igemm_fwd(d, ep, x, w, y, 0);
     (void)hipEventRecord(e0);
