@@ -7,6 +7,7 @@
 // to the workspace, kernel B combines them per channel in fixed order (deterministic), kernel C
 // applies.  x is read twice, y written once.
 #include "common.h"
+#include <stdint.h>
 
 namespace mmdgan {
 
@@ -48,6 +49,73 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict
     }
 }
 
+// float4 variant for C % 4 == 0: a block covers 64 channels as 16 float4 lanes x 16 row lanes, four
+// independent rows in flight per thread (the scalar kernel above issues one 4-byte load per row and
+// runs at ~1 TB/s; this one streams)
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_partial_v4_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                            const float *__restrict__ dy, long rows, int C,
+                                                            long rows_per_split, const float *mean, const float *invstd,
+                                                            int act, double *partial) {
+    __shared__ double red[2][16][65];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cl * 4;
+    const long r0 = (long)blockIdx.y * rows_per_split;
+    long r1 = r0 + rows_per_split;
+    if (r1 > rows) r1 = rows;
+    double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+    if (c < C) {
+        float mu[4] = {0, 0, 0, 0}, is[4] = {0, 0, 0, 0};
+        if (MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { mu[j] = mean[c + j]; is[j] = invstd[c + j]; }
+        }
+        for (long r = r0 + rl; r < r1; r += 64) {
+            float4 vx[4], vy[4], vd[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long rr = r + u * 16;
+                const bool ok = rr < r1;
+                const long o = (ok ? rr : r) * C + c;
+                vx[u] = *reinterpret_cast<const float4 *>(x + o);
+                if (MODE == 1) {
+                    vy[u] = *reinterpret_cast<const float4 *>(y + o);
+                    vd[u] = *reinterpret_cast<const float4 *>(dy + o);
+                    if (!ok) vd[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else if (!ok) vx[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float xv[4] = {vx[u].x, vx[u].y, vx[u].z, vx[u].w};
+                if (MODE == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const double v = (double)xv[j]; sa[j] += v; sb[j] += v * v; }
+                } else {
+                    const float yv[4] = {vy[u].x, vy[u].y, vy[u].z, vy[u].w}, dv[4] = {vd[u].x, vd[u].y, vd[u].z, vd[u].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float dz = dv[j] * act_bwd_from_out(yv[j], act);
+                        const float xh = (xv[j] - mu[j]) * is[j];
+                        sa[j] += (double)dz; sb[j] += (double)dz * (double)xh;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[0][rl][cl * 4 + j] = sa[j]; red[1][rl][cl * 4 + j] = sb[j]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, ch = threadIdx.x & 63;
+        if (blockIdx.x * 64 + ch < C) {
+            double t = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[which][k][ch];
+            partial[((size_t)blockIdx.y * 2 + which) * C + blockIdx.x * 64 + ch] = t;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_stats_finish_kernel(const double *partial, int splits, long rows, int C,
                                                               float eps, float momentum, int unbiased, float *save_mean,
                                                               float *save_invstd, const float *mm, const float *mv,
@@ -84,6 +152,28 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__
     }
 }
 
+__global__ __launch_bounds__(256) void bn_apply_v4_kernel(const float *__restrict__ x, long total4, int C,
+                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                          const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                          float eps_for_var, int use_var, int act, float *__restrict__ y) {
+    const long stride = (long)gridDim.x * 256;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total4; q += stride) {
+        const int c = (int)((q * 4) % C);
+        const float4 v = reinterpret_cast<const float4 *>(x)[q];
+        const float4 g = *reinterpret_cast<const float4 *>(gamma + c), b = *reinterpret_cast<const float4 *>(beta + c);
+        const float4 m = *reinterpret_cast<const float4 *>(mean + c), iv = *reinterpret_cast<const float4 *>(invstd + c);
+        const float in[4] = {v.x, v.y, v.z, v.w}, gv[4] = {g.x, g.y, g.z, g.w}, bv[4] = {b.x, b.y, b.z, b.w};
+        const float mv[4] = {m.x, m.y, m.z, m.w}, sv[4] = {iv.x, iv.y, iv.z, iv.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float is = use_var ? rsqrtf(sv[j] + eps_for_var) : sv[j];
+            o[j] = act_fwd((in[j] - mv[j]) * is * gv[j] + bv[j], act);
+        }
+        reinterpret_cast<float4 *>(y)[q] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const double *partial, int splits, int C, float *dgamma,
                                                             float *dbeta) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -111,6 +201,36 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restri
         dx[o] = gamma[c] * invstd[c] * (dz - dbeta[c] * invn - xh * dgamma[c] * invn);
     }
 }
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                              const float *__restrict__ dy, long total4, long rows, int C,
+                                                              const float *__restrict__ gamma, const float *__restrict__ mean,
+                                                              const float *__restrict__ invstd, const float *__restrict__ dgamma,
+                                                              const float *__restrict__ dbeta, int act, float *__restrict__ dx) {
+    const float invn = 1.0f / (float)rows;
+    const long stride = (long)gridDim.x * 256;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total4; q += stride) {
+        const int c = (int)((q * 4) % C);
+        const float4 a = reinterpret_cast<const float4 *>(x)[q], b = reinterpret_cast<const float4 *>(y)[q];
+        const float4 d = reinterpret_cast<const float4 *>(dy)[q];
+        const float4 g = *reinterpret_cast<const float4 *>(gamma + c), m = *reinterpret_cast<const float4 *>(mean + c);
+        const float4 iv = *reinterpret_cast<const float4 *>(invstd + c);
+        const float4 dg = *reinterpret_cast<const float4 *>(dgamma + c), db = *reinterpret_cast<const float4 *>(dbeta + c);
+        const float xv[4] = {a.x, a.y, a.z, a.w}, yv[4] = {b.x, b.y, b.z, b.w}, dv[4] = {d.x, d.y, d.z, d.w};
+        const float gv[4] = {g.x, g.y, g.z, g.w}, mv[4] = {m.x, m.y, m.z, m.w}, sv[4] = {iv.x, iv.y, iv.z, iv.w};
+        const float dgv[4] = {dg.x, dg.y, dg.z, dg.w}, dbv[4] = {db.x, db.y, db.z, db.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float dz = dv[j] * act_bwd_from_out(yv[j], act);
+            const float xh = (xv[j] - mv[j]) * sv[j];
+            o[j] = gv[j] * sv[j] * (dz - dbv[j] * invn - xh * dgv[j] * invn);
+        }
+        reinterpret_cast<float4 *>(dx)[q] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+static inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 static int bn_splits(long rows, int C, long *rows_per_split) {
     const int cblocks = (C + 63) / 64;
@@ -141,16 +261,27 @@ extern "C" int mmdgan_bn_fwd_train(const float *x, long rows, int C, const float
     long rps;
     const int splits = bn_splits(rows, C, &rps);
     double *part = (double *)workspace;
-    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3((C + 63) / 64, splits), dim3(256), 0, st, x, nullptr, nullptr, rows, C,
-                       rps, nullptr, nullptr, 0, part);
+    const bool v4 = (C % 4) == 0 && al16(x) && al16(y) && al16(gamma) && al16(beta) && al16(save_mean) && al16(save_invstd);
+    if (v4)
+        hipLaunchKernelGGL(bn_partial_v4_kernel<0>, dim3((C + 63) / 64, splits), dim3(256), 0, st, x, nullptr, nullptr,
+                           rows, C, rps, nullptr, nullptr, 0, part);
+    else
+        hipLaunchKernelGGL(bn_partial_kernel<0>, dim3((C + 63) / 64, splits), dim3(256), 0, st, x, nullptr, nullptr, rows,
+                           C, rps, nullptr, nullptr, 0, part);
     hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, splits, rows, C, eps,
                        momentum, unbiased_moving_var, save_mean, save_invstd, moving_mean, moving_var, new_moving_mean,
                        new_moving_var);
     const long total = rows * C;
     long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, total, C, gamma, beta, save_mean,
-                       save_invstd, 0.f, 0, act, y);
+    if (v4) {
+        blocks = (total / 4 + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(bn_apply_v4_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, total / 4, C, gamma, beta,
+                           save_mean, save_invstd, 0.f, 0, act, y);
+    } else
+        hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, total, C, gamma, beta, save_mean,
+                           save_invstd, 0.f, 0, act, y);
     return check_launch("bn_fwd_train");
 }
 
@@ -160,8 +291,14 @@ extern "C" int mmdgan_bn_fwd_infer(const float *x, long rows, int C, const float
     const long total = rows * C;
     long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, total, C, gamma,
-                       beta, moving_mean, moving_var, eps, 1, act, y);
+    if (C % 4 == 0 && al16(x) && al16(y) && al16(gamma) && al16(beta) && al16(moving_mean) && al16(moving_var)) {
+        blocks = (total / 4 + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(bn_apply_v4_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, total / 4, C,
+                           gamma, beta, moving_mean, moving_var, eps, 1, act, y);
+    } else
+        hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, total, C, gamma,
+                           beta, moving_mean, moving_var, eps, 1, act, y);
     return check_launch("bn_fwd_infer");
 }
 
@@ -175,13 +312,25 @@ extern "C" int mmdgan_bn_bwd(const float *x, const float *y, const float *dy, lo
     long rps;
     const int splits = bn_splits(rows, C, &rps);
     double *part = (double *)workspace;
-    hipLaunchKernelGGL(bn_partial_kernel<1>, dim3((C + 63) / 64, splits), dim3(256), 0, st, x, y, dy, rows, C, rps,
-                       save_mean, save_invstd, act, part);
+    const bool v4 = (C % 4) == 0 && al16(x) && al16(y) && al16(dy) && al16(dx) && al16(gamma) && al16(save_mean) &&
+                    al16(save_invstd) && al16(dgamma) && al16(dbeta);
+    if (v4)
+        hipLaunchKernelGGL(bn_partial_v4_kernel<1>, dim3((C + 63) / 64, splits), dim3(256), 0, st, x, y, dy, rows, C, rps,
+                           save_mean, save_invstd, act, part);
+    else
+        hipLaunchKernelGGL(bn_partial_kernel<1>, dim3((C + 63) / 64, splits), dim3(256), 0, st, x, y, dy, rows, C, rps,
+                           save_mean, save_invstd, act, part);
     hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, splits, C, dgamma, dbeta);
     const long total = rows * C;
     long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, dy, total, rows, C, gamma,
-                       save_mean, save_invstd, dgamma, dbeta, act, dx);
+    if (v4) {
+        blocks = (total / 4 + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, dy, total / 4, rows, C,
+                           gamma, save_mean, save_invstd, dgamma, dbeta, act, dx);
+    } else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, dy, total, rows, C, gamma,
+                           save_mean, save_invstd, dgamma, dbeta, act, dx);
     return check_launch("bn_bwd");
 }
