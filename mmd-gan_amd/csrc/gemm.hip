@@ -19,8 +19,11 @@ struct GemmArgs {
 };
 
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    __shared__ float As[GK][GT + 4];
-    __shared__ float Bs[GK][GT + 4];
+    // double-buffered LDS tiles; the next k-tile's global loads are issued before the FMAs of the
+    // current one and parked in LDS after them, so one barrier per k-step and the HBM latency of
+    // these short-K launches hides behind the arithmetic
+    __shared__ float As[2][GK][GT + 4];
+    __shared__ float Bs[2][GK][GT + 4];
     const int tid = threadIdx.x;
     const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
     const int kbeg = blockIdx.z * g.kchunk;
@@ -28,8 +31,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     if (kend > g.K) kend = g.K;
     const int tm = (tid >> 4) * 4, tn = (tid & 15) * 4;
     float acc[4][4] = {};
-    for (int k0 = kbeg; k0 < kend; k0 += GK) {
-        // 64x16 elements per operand = 1024 -> 4 per thread
+    float ra[4], rb[4];
+    // 64x16 elements per operand = 1024 -> 4 per thread
+    auto gload = [&](int k0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int idx = tid + e * 256;
@@ -39,7 +43,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                 const int gm = m0 + m, gk = k0 + k;
                 float v = 0.f;
                 if (gm < g.M && gk < kend) v = g.transA ? g.A[(size_t)gk * g.lda + gm] : g.A[(size_t)gm * g.lda + gk];
-                As[k][m] = v;
+                ra[e] = v;
             }
             {   // B tile: element (k, n)
                 int n, k;
@@ -47,20 +51,36 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                 const int gn = n0 + n, gk = k0 + k;
                 float v = 0.f;
                 if (gn < g.N && gk < kend) v = g.transB ? g.B[(size_t)gn * g.ldb + gk] : g.B[(size_t)gk * g.ldb + gn];
-                Bs[k][n] = v;
+                rb[e] = v;
             }
         }
-        __syncthreads();
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + e * 256;
+            if (g.transA) As[buf][idx >> 6][idx & 63] = ra[e]; else As[buf][idx & 15][idx >> 4] = ra[e];
+            if (g.transB) Bs[buf][idx & 15][idx >> 4] = rb[e]; else Bs[buf][idx >> 6][idx & 63] = rb[e];
+        }
+    };
+    gload(kbeg);
+    sstore(0);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += GK, cur ^= 1) {
+        const bool more = k0 + GK < kend;
+        if (more) gload(k0 + GK);
 #pragma unroll
         for (int k = 0; k < GK; ++k) {
-            const float4 a = *reinterpret_cast<const float4 *>(&As[k][tm]);
-            const float4 b = *reinterpret_cast<const float4 *>(&Bs[k][tn]);
+            const float4 a = *reinterpret_cast<const float4 *>(&As[cur][k][tm]);
+            const float4 b = *reinterpret_cast<const float4 *>(&Bs[cur][k][tn]);
             const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
         }
+        if (more) sstore(cur ^ 1);
         __syncthreads();
     }
     const float sc = g.scale ? g.scale[0] : 1.f;
@@ -108,8 +128,8 @@ extern "C" int mmdgan_gemm(int transA, int transB, int M, int N, int K, const fl
     int ksplit = 1;
     if (act == MMDGAN_ACT_LINEAR && !dact_of && tiles < 128 && K >= 512 && ldc == N &&
         (!outputs_prezeroed() || (size_t)M * N * 4 <= (1u << 20))) {
-        ksplit = 256 / tiles;
-        const int maxs = K / 128;
+        ksplit = 512 / tiles;
+        const int maxs = K / 64;
         if (ksplit > maxs) ksplit = maxs;
         if (ksplit < 1) ksplit = 1;
     }
