@@ -25,6 +25,7 @@ MI355X-first choices
     get_variables()/set_variables() convert to and from the reference's names and layouts.
 """
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -342,6 +343,11 @@ class GanEngine:
             self.world = tdist.get_world_size(dist_group)
         self._pending = []
         self._sn_stream = torch.cuda.Stream(device=self.device)
+        # weight / bias gradients of a layer depend only on dz of that layer, not on the dgrad chain that
+        # continues below it: they go to a second stream so their blocks fill the tail of the dgrad
+        # launches (each launch alone leaves CUs idle while its last wave of tiles drains)
+        self._wg_stream = torch.cuda.Stream(device=self.device)
+        self._side_wgrad = os.environ.get('MMDGAN_SIDE_WGRAD', '1') != '0'
         if ops._workspace is None:
             ops.set_workspace(device=self.device)
         self._alloc(self.B)
@@ -535,17 +541,20 @@ class GanEngine:
             gw = net.g(s.scope + '/kernel/kernel')
             scale = self._scales[s.scope]
             dz_main = dz[:2 * B]
-            if s.has_bias:
-                ops.colsum(dz_main.reshape(-1, dz.shape[-1]), out=net.g(s.scope + '/bias/bias'))
-            if s.op == 'd':
-                ops.gemm(x_in.reshape(2 * B, -1), dz_main.reshape(2 * B, -1), trans_a=True, out=gw)
-            else:
-                ops.conv2d_wgrad(x_in, dz_main, s.R, s.stride, out=gw)
-            if s.sn:                                                         # SURVEY A.2 fix-up
-                dot = net.state[s.scope + '#dot']
-                ops.dot(gw.view(-1), w.view(-1), out=dot)
-                ops.sn_wgrad_fixup(gw.view(-1), net.state[s.scope + '#dsigma'].view(-1), dot,
-                                   net.state[s.scope + '#sigma'], scale)
+
+            def param_grads(s=s, x_in=x_in, w=w, gw=gw, scale=scale, dz_main=dz_main):
+                if s.has_bias:
+                    ops.colsum(dz_main.reshape(-1, dz_main.shape[-1]), out=net.g(s.scope + '/bias/bias'))
+                if s.op == 'd':
+                    ops.gemm(x_in.reshape(2 * B, -1), dz_main.reshape(2 * B, -1), trans_a=True, out=gw)
+                else:
+                    ops.conv2d_wgrad(x_in, dz_main, s.R, s.stride, out=gw)
+                if s.sn:                                                     # SURVEY A.2 fix-up
+                    dot = net.state[s.scope + '#dot']
+                    ops.dot(gw.view(-1), w.view(-1), out=dot)
+                    ops.sn_wgrad_fixup(gw.view(-1), net.state[s.scope + '#dsigma'].view(-1), dot,
+                                       net.state[s.scope + '#sigma'], scale)
+            self._on_wg_stream(param_grads, s)
             if li > 0:
                 prev = specs[li - 1]
                 dprev, yprev = b[prev.scope + '#dz'], b[prev.scope + '#y']
@@ -570,6 +579,22 @@ class GanEngine:
                                      dact_of=yprev, out=out)
         return b['d_fake']                                                   # gradient w.r.t. G's last pre-activation
 
+    def _on_wg_stream(self, fn, spec):
+        """run the parameter-gradient launches of one layer on the weight-gradient stream (ordered after
+        everything issued so far on the current stream).  Layers whose conv kernels use the shared
+        library workspace (the thin first/last layers) stay on the main stream."""
+        thin = spec.op != 'd' and (spec.kernel_shape[2] % 64 or spec.kernel_shape[3] % 64)
+        if not self._side_wgrad or thin:
+            fn()
+            return
+        self._wg_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._wg_stream):
+            fn()
+
+    def _join_wg_stream(self):
+        if self._side_wgrad:
+            torch.cuda.current_stream().wait_stream(self._wg_stream)
+
     def _backward_gen(self, dz, z):
         B, b, net = self.B, self.buf, self.gen
         specs = net.specs
@@ -593,14 +618,17 @@ class GanEngine:
                     ws.data_ptr(), ops._stream()), 'bn_bwd')
                 dz = draw
             dz = dz.view(_native_shape(s.op_out_ref, B))
-            if s.has_bias:
-                ops.colsum(dz.view(-1, dz.shape[-1]), out=net.g(s.scope + '/bias/bias'))
-            if s.op == 'd':
-                ops.gemm(x_in, dz, trans_a=True, out=gw)
-            elif s.op == 'c':
-                ops.conv2d_wgrad(x_in, dz, s.R, s.stride, out=gw)
-            else:                                                            # tc: W[R,R,Cout,Cin]; y = dgrad(v, W)
-                ops.conv2d_wgrad(dz, x_in, s.R, s.stride, out=gw)
+
+            def param_grads(s=s, x_in=x_in, gw=gw, dz=dz):
+                if s.has_bias:
+                    ops.colsum(dz.view(-1, dz.shape[-1]), out=net.g(s.scope + '/bias/bias'))
+                if s.op == 'd':
+                    ops.gemm(x_in, dz, trans_a=True, out=gw)
+                elif s.op == 'c':
+                    ops.conv2d_wgrad(x_in, dz, s.R, s.stride, out=gw)
+                else:                                                        # tc: W[R,R,Cout,Cin]; y = dgrad(v, W)
+                    ops.conv2d_wgrad(dz, x_in, s.R, s.stride, out=gw)
+            self._on_wg_stream(param_grads, s)
             if li > 0:
                 prev = specs[li - 1]
                 # a BN layer below gets d/d(its activated output) and applies act' itself in bn_bwd;
@@ -646,8 +674,11 @@ class GanEngine:
                 t.zero_()
             self._forward(z, real)
             dz = self._backward_dis()
+            if self.dist_group is not None:
+                self._join_wg_stream()
             self._allreduce(self.dis)
             self._backward_gen(dz, z)
+            self._join_wg_stream()
             self._allreduce(self.gen)
             self._update()
         finally:
