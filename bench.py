@@ -39,10 +39,14 @@ def parse():
     ap.add_argument('--no-graph', action='store_true', help='issue launches eagerly instead of one hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--probe-only', action='store_true',
+                    help='one step, then only the dominant-kernel probe (for rocprofv3: its kernel stats row is then '
+                         'exactly the launches that roofline.dominant_kernel times)')
+    ap.add_argument('--probe-reps', type=int, default=20)
     return ap.parse_args()
 
 
-def dominant_kernel_probe(eng, reps=20):
+def dominant_kernel_probe(eng, reps=20, warm=3):
     """HIP-event timing of the single heaviest launch of the step, issued on the stream it normally
     runs on: the weight gradient of the widest 3x3 D layer at batch 2B (D l5 for CIFAR)."""
     from mmdgan_hip import ops
@@ -60,7 +64,7 @@ def dominant_kernel_probe(eng, reps=20):
     x = eng.buf[eng.dis.specs[li - 1].scope + '#y']
     dz = eng.buf[s.scope + '#dz']
     gw = torch.empty(s.kernel_shape, device=x.device)
-    for _ in range(3):
+    for _ in range(warm):
         ops.conv2d_wgrad(x, dz, s.R, s.stride, out=gw)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -129,6 +133,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.probe_only:
+        eng.use_graph = False
+        eng.step(real)                                   # fills the activations / gradients the probe reads
+        torch.cuda.synchronize()
+        probe = dominant_kernel_probe(eng, reps=args.probe_reps, warm=0)
+        print(json.dumps({'dominant_kernel': probe, 'reps': args.probe_reps}))
+        return
     for _ in range(args.warmup):
         eng.step(real)
     barrier()
@@ -169,11 +180,17 @@ def main():
                          'scope': 'whole step: B*(3*F_G+7*F_D) = %.1f GFLOP over the HIP-event step time %.3f ms'
                                   % (flops_step / 1e9, ev_ms)},
         }
-        probe = dominant_kernel_probe(eng)
+        probe = dominant_kernel_probe(eng, reps=args.probe_reps)
         if probe:
             out['roofline']['dominant_kernel'] = {
                 'name': probe['kernel'], 'gflop_per_launch': probe['flops'] / 1e9, 'ms_per_launch': probe['ms'],
                 'achieved': probe['tflops'], 'frac': probe['tflops'] / PEAK_FP32_MFMA_TFLOPS}
+            pmc = os.path.join(ROOT, 'profiles', 'r01_dominant_kernel_pmc.json')
+            if os.path.exists(pmc):                      # HBM bytes per launch from the committed rocprofv3 --pmc passes
+                with open(pmc) as f:
+                    t = json.load(f)
+                out['roofline']['dominant_kernel']['traffic'] = t.get('hbm_bytes_per_launch')
+                out['roofline']['dominant_kernel']['traffic_source'] = 'profiles/r01_dominant_kernel_pmc.json'
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(arch, lr, args.loss, B, args.cpu_steps)
         print(json.dumps(out))

@@ -164,6 +164,8 @@ __device__ __forceinline__ void mainloop(P &p, int s_begin, int s_end, float *sm
 #pragma unroll
             for (int q = 0; q < 2 * NP; ++q) {
                 if ((q * NKP) / (2 * NP) != j) continue;
+#ifdef MMDGAN_PIECES_LOADS_LATE
+                // (old order: all LDS stores in the first half of the stage, all global loads in the second)
 #ifndef MMDGAN_ABLATE_STORE
                 if (q < T::A_F4) MMDGAN_W_A(An, q)
                 else if (q < NP) MMDGAN_W_B(Bn, q - T::A_F4)
@@ -171,6 +173,22 @@ __device__ __forceinline__ void mainloop(P &p, int s_begin, int s_end, float *sm
 #ifndef MMDGAN_ABLATE_GLOBAL
                 if (q >= NP && q < NP + T::A_F4) ra[q - NP] = p.load_a1(s + 2, q - NP);
                 else if (q >= NP + T::A_F4) rb[q - NP - T::A_F4] = p.load_b1(s + 2, q - NP - T::A_F4);
+#endif
+#else
+                // store register i to LDS (tile s+1), then immediately refill it from global (tile s+2):
+                // every load has a full stage of MFMAs between its issue and the ds_write that consumes it
+                const int i = q >> 1;
+                if ((q & 1) == 0) {
+#ifndef MMDGAN_ABLATE_STORE
+                    if (i < T::A_F4) MMDGAN_W_A(An, i)
+                    else MMDGAN_W_B(Bn, i - T::A_F4)
+#endif
+                } else {
+#ifndef MMDGAN_ABLATE_GLOBAL
+                    if (i < T::A_F4) ra[i] = p.load_a1(s + 2, i);
+                    else rb[i - T::A_F4] = p.load_b1(s + 2, i - T::A_F4);
+#endif
+                }
 #endif
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -292,17 +310,26 @@ __device__ __forceinline__ void epilogue_store(float *smem, f32x16 (&acc)[TileCf
 // ------------------------------------------------------------------------------------------------
 // forward: y[m = (n,p,q)][k] = sum_{tap,c} x[n, p*s-pad+r, q*s-pad+t, c] * w[tap][c][k]
 // ------------------------------------------------------------------------------------------------
+// Address generation is kept off the vector ALU as far as possible: VALU instructions issue through
+// the same port as the MFMAs, integer multiplies are quarter rate, and with four waves per SIMD the
+// gather arithmetic of the first version (two 64-bit mads, four compares per load; divisions in the
+// weight-gradient kernel) took a third to four fifths as many issue cycles as the MFMAs themselves
+// (rocprofv3: SQ_VALU_MFMA_BUSY 54 % on D l7 wgrad).  Now every row of the A tile is decomposed ONCE
+// into a byte offset plus a bit mask over the filter taps ("does this tap land inside the image"),
+// and a K-stage contributes only wave-uniform scalars: one v_add, one bit test, one select per load.
+__device__ __forceinline__ int mad24(int a, int b, int c) { return __mul24(a, b) + c; }
+
 template <int BM, int BN, int KG>
 struct FwdProblem {
     static constexpr bool A_KC = true, B_KC = false;
     using T = TileCfg<BM, BN, false, false, KG>;
-    ConvDims d;
     __amdgpu_buffer_rsrc_t rx, rw;
-    int n0;
-    unsigned abase[T::A_F4];          // byte offset of (n, 0, 0, kq*4)
-    int ah0[T::A_F4], aw0[T::A_F4];   // ah0 = INT_MIN/2 marks a row beyond M
-    __device__ void init(const ConvDims &dd, const float *x_, const float *w_, int m0, int n0_, long M) {
-        d = dd; n0 = n0_;
+    int C, R, RR, WC4, stageK4;
+    unsigned apix[T::A_F4];           // byte offset of (n, p*s-pad, q*s-pad, kq*4): tap (0,0), may wrap below 0
+    unsigned amask[T::A_F4];          // bit r*R+t: tap (r,t) of this output pixel reads inside the image
+    unsigned bbase[T::B_F4];
+    __device__ void init(const ConvDims &d, const float *x_, const float *w_, int m0, int n0, long M) {
+        C = d.C; R = d.R; RR = d.R * d.R; WC4 = d.W * d.C * 4; stageK4 = BK * d.K * 4;
         rx = make_rsrc(x_, (long)d.N * d.H * d.W * d.C * 4);
         rw = make_rsrc(w_, (long)d.R * d.R * d.C * d.K * 4);
 #pragma unroll
@@ -315,24 +342,29 @@ struct FwdProblem {
             const long t = mm / d.Q;
             const int p = t % d.P;
             const int n = t / d.P;
-            ah0[i] = ok ? p * d.stride - d.pad : -(1 << 28);
-            aw0[i] = q * d.stride - d.pad;
-            abase[i] = (unsigned)(((long)n * d.H * d.W * d.C + (f % KQ) * 4) * 4);
+            const int h0 = p * d.stride - d.pad, w0 = q * d.stride - d.pad;
+            apix[i] = (unsigned)((((n * d.H + h0) * d.W + w0) * d.C + (f % KQ) * 4) * 4);
+            unsigned cols = 0, mask = 0;
+            for (int tt = 0; tt < d.R; ++tt) cols |= (unsigned)(w0 + tt >= 0 && w0 + tt < d.W) << tt;
+            for (int r = 0; r < d.R; ++r) mask |= (h0 + r >= 0 && h0 + r < d.H) ? cols << (r * d.R) : 0u;
+            amask[i] = ok ? mask : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < T::B_F4; ++i) {
+            const int f = threadIdx.x + T::NT * i;
+            bbase[i] = (unsigned)((((f / (BN / 4)) * d.K) + n0 + (f % (BN / 4)) * 4) * 4);
         }
     }
     __device__ __forceinline__ float4 load_a1(int s, int i) const {
         const int k0 = s * BK;
-        const int tap = k0 / d.C, c0 = k0 - tap * d.C;
-        const int r = tap / d.R, t = tap - r * d.R;
-        const int h = ah0[i] + r, ww = aw0[i] + t;
-        const bool ok = h >= 0 && h < d.H && ww >= 0 && ww < d.W && r < d.R;
-        const unsigned off = abase[i] + (unsigned)(((h * d.W + ww) * d.C + c0) * 4);
-        return bufld4(rx, ok ? off : kOOB);
+        const int tap = k0 / C, c0 = k0 - tap * C;           // wave-uniform: scalar ALU
+        const int r = tap / R, t = tap - r * R;
+        const unsigned soff = (unsigned)(r * WC4 + (t * C + c0) * 4);
+        const bool ok = tap < RR && ((amask[i] >> tap) & 1u);
+        return bufld4(rx, ok ? apix[i] + soff : kOOB);
     }
     __device__ __forceinline__ float4 load_b1(int s, int i) const {
-        const int f = threadIdx.x + T::NT * i;
-        const int k = f / (BN / 4), c4 = f % (BN / 4);
-        return bufld4(rw, (unsigned)((((s * BK + k) * d.K) + n0 + c4 * 4) * 4));     // beyond the last stage: OOB -> 0
+        return bufld4(rw, bbase[i] + (unsigned)(s * stageK4));  // beyond the last stage: past the buffer -> 0
     }
 };
 
@@ -375,31 +407,34 @@ template <int BM, int BN, int KG>
 struct DgradProblem {
     static constexpr bool A_KC = true, B_KC = true;
     using T = TileCfg<BM, BN, false, false, KG>;
-    ConvDims d;
     __amdgpu_buffer_rsrc_t rdy, rw;
-    int TT, rbase, tbase, pbase, qbase;
-    unsigned abase[T::A_F4];
-    int ahh[T::A_F4], aww[T::A_F4];
+    int K, Q, R, C, stride, TT, rbase, tbase;
+    unsigned apix[T::A_F4];           // byte offset of dy(n, hh+pbase, ww+qbase, kq*4): tap (0,0)
+    unsigned amask[T::A_F4];          // bit jr*TT+jt: dy(n, hh+pbase-jr, ww+qbase-jt) exists
     unsigned bbase[T::B_F4];
-    __device__ void init(const ConvDims &dd, const float *dy_, const float *w_, int m0, int n0, int ph, int pw, int Hh,
+    __device__ void init(const ConvDims &d, const float *dy_, const float *w_, int m0, int n0, int ph, int pw, int Hh,
                          int Ww, long M) {
-        d = dd;
+        K = d.K; Q = d.Q; R = d.R; C = d.C; stride = d.stride;
         rdy = make_rsrc(dy_, (long)d.N * d.P * d.Q * d.K * 4);
         rw = make_rsrc(w_, (long)d.R * d.R * d.C * d.K * 4);
         TT = d.R / d.stride;
         rbase = (ph + d.pad) % d.stride; tbase = (pw + d.pad) % d.stride;
-        pbase = (ph + d.pad) / d.stride; qbase = (pw + d.pad) / d.stride;
+        const int pbase = (ph + d.pad) / d.stride, qbase = (pw + d.pad) / d.stride;
 #pragma unroll
         for (int i = 0; i < T::A_F4; ++i) {
             const int f = threadIdx.x + T::NT * i;
             const long m = (long)m0 + f / KQ;
             const bool ok = m < M;
             const long mm = ok ? m : 0;
-            aww[i] = mm % Ww;
+            const int qq = (int)(mm % Ww) + qbase;
             const long t = mm / Ww;
-            ahh[i] = ok ? (int)(t % Hh) : -(1 << 28);
+            const int pp = (int)(t % Hh) + pbase;
             const int n = t / Hh;
-            abase[i] = (unsigned)(((long)n * d.P * d.Q * d.K + (f % KQ) * 4) * 4);
+            apix[i] = (unsigned)((((n * d.P + pp) * d.Q + qq) * d.K + (f % KQ) * 4) * 4);
+            unsigned cols = 0, mask = 0;
+            for (int jt = 0; jt < TT; ++jt) cols |= (unsigned)(qq - jt >= 0 && qq - jt < d.Q) << jt;
+            for (int jr = 0; jr < TT; ++jr) mask |= (pp - jr >= 0 && pp - jr < d.P) ? cols << (jr * TT) : 0u;
+            amask[i] = ok ? mask : 0u;
         }
 #pragma unroll
         for (int i = 0; i < T::B_F4; ++i) {
@@ -409,19 +444,18 @@ struct DgradProblem {
     }
     __device__ __forceinline__ float4 load_a1(int s, int i) const {
         const int k0 = s * BK;
-        const int tap = k0 / d.K, co0 = k0 - tap * d.K;
+        const int tap = k0 / K, co0 = k0 - tap * K;          // wave-uniform: scalar ALU
         const int jr = tap / TT, jt = tap - jr * TT;
-        const int p = ahh[i] + pbase - jr, q = aww[i] + qbase - jt;
-        const bool ok = p >= 0 && p < d.P && q >= 0 && q < d.Q && jr < TT;
-        const unsigned off = abase[i] + (unsigned)(((p * d.Q + q) * d.K + co0) * 4);
-        return bufld4(rdy, ok ? off : kOOB);
+        const unsigned soff = (unsigned)((co0 - (jr * Q + jt) * K) * 4);
+        const bool ok = jr < TT && ((amask[i] >> tap) & 1u);
+        return bufld4(rdy, ok ? apix[i] + soff : kOOB);
     }
     __device__ __forceinline__ float4 load_b1(int s, int i) const {
         const int k0 = s * BK;
-        const int tap = k0 / d.K, co0 = k0 - tap * d.K;
+        const int tap = k0 / K, co0 = k0 - tap * K;
         const int jr = tap / TT, jt = tap - jr * TT;
-        const int r = rbase + jr * d.stride, t = tbase + jt * d.stride;
-        const unsigned off = (unsigned)((((r * d.R + t) * d.C) * d.K + co0) * 4);
+        const int r = rbase + jr * stride, t = tbase + jt * stride;
+        const unsigned off = (unsigned)((((r * R + t) * C) * K + co0) * 4);
         return bufld4(rw, jr < TT ? bbase[i] + off : kOOB);
     }
 };
@@ -468,42 +502,64 @@ __global__ __launch_bounds__(256 * KG) void igemm_dgrad_kernel(ConvDims d, ConvE
 // weight gradient: dw[(tap,c)][k] = sum_{pixels m} x[m shifted by tap][c] * dy[m][k]
 // GEMM rows i = (tap, c) (a BM-row tile sits inside one tap: C % BM == 0), reduction over pixels.
 // ------------------------------------------------------------------------------------------------
+// The reduction index of the weight gradient is the output pixel m = (n,p,q), 32 consecutive pixels
+// per stage, and every thread keeps the (q, p, image offset) of its rows as running state that is
+// advanced by 32 pixels per call with compare/select carries - no division or 32-bit multiply in the
+// loop (load_a1 / load_b1 must therefore be called exactly once per row and stage, in stage order,
+// which is how the main loop uses them; their `s` argument is ignored).  Pixels beyond the batch
+// walk off the end of the buffer and read 0.
 template <int BM, int BN, int KG>
 struct WgradProblem {
     static constexpr bool A_KC = false, B_KC = false;
     using T = TileCfg<BM, BN, false, false, KG>;
-    ConvDims d;
     __amdgpu_buffer_rsrc_t rx, rdy;
-    int r, t, c0, n0;
-    long M;
-    __device__ void init(const ConvDims &dd, const float *x_, const float *dy_, int i0, int n0_, long M_) {
-        d = dd; n0 = n0_; M = M_;
+    int H, W, Qd, Pd, stride, hoff, woff, C4, dq, dp;
+    unsigned HWC4, dnoff, stageK4;
+    int q[T::A_F4], p[T::A_F4];
+    unsigned noff[T::A_F4], boff[T::B_F4];
+    __device__ void init(const ConvDims &d, const float *x_, const float *dy_, int i0, int n0, int s0) {
         rx = make_rsrc(x_, (long)d.N * d.H * d.W * d.C * 4);
         rdy = make_rsrc(dy_, (long)d.N * d.P * d.Q * d.K * 4);
-        const int tap = i0 / d.C;
-        c0 = i0 - tap * d.C;
-        r = tap / d.R; t = tap - r * d.R;
+        const int tap = i0 / d.C, c0 = i0 - tap * d.C;
+        const int r = tap / d.R, t = tap - r * d.R;
+        H = d.H; W = d.W; Qd = d.Q; Pd = d.P; stride = d.stride; C4 = d.C * 4;
+        hoff = r - d.pad; woff = t - d.pad;
+        HWC4 = (unsigned)(d.H * d.W * d.C * 4);
+        dq = BK % d.Q; dp = (BK / d.Q) % d.P; dnoff = (unsigned)(BK / (d.P * d.Q)) * HWC4;
+        stageK4 = (unsigned)(BK * d.K * 4);
+#pragma unroll
+        for (int i = 0; i < T::A_F4; ++i) {
+            const int f = threadIdx.x + T::NT * i;
+            const int m = s0 * BK + f / (BM / 4);
+            q[i] = m % d.Q;
+            const int u = m / d.Q;
+            p[i] = u % d.P;
+            noff[i] = (unsigned)(u / d.P) * HWC4 + (unsigned)((c0 + (f % (BM / 4)) * 4) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < T::B_F4; ++i) {
+            const int f = threadIdx.x + T::NT * i;
+            boff[i] = (unsigned)((((s0 * BK + f / (BN / 4)) * d.K) + n0 + (f % (BN / 4)) * 4) * 4);
+        }
     }
-    __device__ __forceinline__ float4 load_a1(int s, int i) const {
-        const int f = threadIdx.x + T::NT * i;
-        const int k = f / (BM / 4), c4 = f % (BM / 4);
-        const long m = (long)s * BK + k;
-        bool ok = m < M;
-        const int mm = ok ? (int)m : 0;
-        const int q = mm % d.Q;
-        const int u = mm / d.Q;
-        const int p = u % d.P;
-        const int n = u / d.P;
-        const int h = p * d.stride - d.pad + r, ww = q * d.stride - d.pad + t;
-        ok = ok && h >= 0 && h < d.H && ww >= 0 && ww < d.W;
-        const unsigned off = (unsigned)((((n * d.H + h) * d.W + ww) * d.C + c0 + c4 * 4) * 4);
-        return bufld4(rx, ok ? off : kOOB);
+    __device__ __forceinline__ float4 load_a1(int, int i) {
+        const int h = mad24(p[i], stride, hoff), w = mad24(q[i], stride, woff);
+        const bool ok = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+        const unsigned off = noff[i] + (unsigned)__mul24(mad24(h, W, w), C4);
+        const float4 v = bufld4(rx, ok ? off : kOOB);
+        q[i] += dq;
+        const bool cq = q[i] >= Qd;
+        q[i] -= cq ? Qd : 0;
+        p[i] += dp + (cq ? 1 : 0);
+        const bool cp = p[i] >= Pd;
+        p[i] -= cp ? Pd : 0;
+        noff[i] += dnoff + (cp ? HWC4 : 0u);
+        return v;
     }
-    __device__ __forceinline__ float4 load_b1(int s, int i) const {
-        const int f = threadIdx.x + T::NT * i;
-        const int k = f / (BN / 4), c4 = f % (BN / 4);
-        const long m = (long)s * BK + k;
-        return bufld4(rdy, m < M ? (unsigned)(((int)m * d.K + n0 + c4 * 4) * 4) : kOOB);
+    __device__ __forceinline__ float4 load_b1(int, int i) {
+        const float4 v = bufld4(rdy, boff[i]);
+        boff[i] += stageK4;
+        return v;
     }
 };
 
@@ -526,7 +582,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_wgrad_kernel(ConvDims d, const
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
     WgradProblem<BM, BN, KG> p;
-    p.init(d, x, dy, i0, n0, M);
+    p.init(d, x, dy, i0, n0, s0);
     mainloop<BM, BN, KG>(p, s0, s1, smem, acc);
     const int Kc = d.K;
     auto rowoff = [=](int row) -> long { return (long)(i0 + row) * Kc + n0; };
@@ -556,8 +612,8 @@ static void raise_lds_caps() {
     (void)hipFuncSetAttribute((const void *)igemm_wgrad_kernel<128, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
 }
 
-bool igemm_fwd_ok(const ConvDims &d) { return d.C % BK == 0 && d.K % 64 == 0 && d.R * d.R * d.C >= 64; }
-bool igemm_dgrad_ok(const ConvDims &d) { return d.K % BK == 0 && d.C % 64 == 0 && d.R % d.stride == 0; }
+bool igemm_fwd_ok(const ConvDims &d) { return d.C % BK == 0 && d.K % 64 == 0 && d.R * d.R * d.C >= 64 && d.R <= 5; }   // 25 tap bits
+bool igemm_dgrad_ok(const ConvDims &d) { return d.K % BK == 0 && d.C % 64 == 0 && d.R % d.stride == 0 && d.R / d.stride <= 5; }
 bool igemm_wgrad_ok(const ConvDims &d) { return d.C % 64 == 0 && d.K % 64 == 0; }
 
 static void pick_tile(long M, int N, int &bm, int &bn) {
