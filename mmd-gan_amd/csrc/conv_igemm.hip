@@ -359,12 +359,15 @@ struct FwdProblem {
         const int k0 = s * BK;
         const int tap = k0 / C, c0 = k0 - tap * C;           // wave-uniform: scalar ALU
         const int r = tap / R, t = tap - r * R;
-        const unsigned soff = (unsigned)(r * WC4 + (t * C + c0) * 4);
-        const bool ok = tap < RR && ((amask[i] >> tap) & 1u);
+        // readfirstlane pins the wave-uniform part in an SGPR (left alone hipcc folds it back into a
+        // per-lane 64-bit mad)
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(r * WC4 + (t * C + c0) * 4);
+        const unsigned bit = (unsigned)__builtin_amdgcn_readfirstlane(tap < RR ? 1 << tap : 0);
+        const bool ok = (amask[i] & bit) != 0;
         return bufld4(rx, ok ? apix[i] + soff : kOOB);
     }
     __device__ __forceinline__ float4 load_b1(int s, int i) const {
-        return bufld4(rw, bbase[i] + (unsigned)(s * stageK4));  // beyond the last stage: past the buffer -> 0
+        return bufld4(rw, bbase[i] + (unsigned)__builtin_amdgcn_readfirstlane(s * stageK4));  // beyond the last stage: past the buffer -> 0
     }
 };
 
@@ -446,8 +449,9 @@ struct DgradProblem {
         const int k0 = s * BK;
         const int tap = k0 / K, co0 = k0 - tap * K;          // wave-uniform: scalar ALU
         const int jr = tap / TT, jt = tap - jr * TT;
-        const unsigned soff = (unsigned)((co0 - (jr * Q + jt) * K) * 4);
-        const bool ok = jr < TT && ((amask[i] >> tap) & 1u);
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((co0 - (jr * Q + jt) * K) * 4);
+        const unsigned bit = (unsigned)__builtin_amdgcn_readfirstlane(jr < TT ? 1 << tap : 0);
+        const bool ok = (amask[i] & bit) != 0;
         return bufld4(rdy, ok ? apix[i] + soff : kOOB);
     }
     __device__ __forceinline__ float4 load_b1(int s, int i) const {
@@ -455,8 +459,8 @@ struct DgradProblem {
         const int tap = k0 / K, co0 = k0 - tap * K;
         const int jr = tap / TT, jt = tap - jr * TT;
         const int r = rbase + jr * stride, t = tbase + jt * stride;
-        const unsigned off = (unsigned)((((r * R + t) * C) * K + co0) * 4);
-        return bufld4(rw, jr < TT ? bbase[i] + off : kOOB);
+        const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane(jr < TT ? (((r * R + t) * C) * K + co0) * 4 : (int)kOOB);
+        return bufld4(rw, bbase[i] + off);                   // bbase < 2^31: adding kOOB stays out of range
     }
 };
 
@@ -513,27 +517,40 @@ struct WgradProblem {
     static constexpr bool A_KC = false, B_KC = false;
     using T = TileCfg<BM, BN, false, false, KG>;
     __amdgpu_buffer_rsrc_t rx, rdy;
-    int H, W, Qd, Pd, stride, hoff, woff, C4, dq, dp;
-    unsigned HWC4, dnoff, stageK4;
-    int q[T::A_F4], p[T::A_F4];
+    // running state per A row, all in BYTES so that the loop has no multiply at all:
+    //   hq = w * C*4   (w = q*stride - pad + t, negative / >= W*C*4 when the tap leaves the row)
+    //   hp = h * W*C*4 (h = p*stride - pad + r)
+    //   noff = n * H*W*C*4 + channel offset;   address = noff + hp + hq
+    int hq[T::A_F4], hp[T::A_F4];
     unsigned noff[T::A_F4], boff[T::B_F4];
+    int dhq, qwrap, qlim, dhp, prow, pwrap, plim;
+    unsigned wlim, hlim, HWC4, dnoff, stageK4;
     __device__ void init(const ConvDims &d, const float *x_, const float *dy_, int i0, int n0, int s0) {
         rx = make_rsrc(x_, (long)d.N * d.H * d.W * d.C * 4);
         rdy = make_rsrc(dy_, (long)d.N * d.P * d.Q * d.K * 4);
         const int tap = i0 / d.C, c0 = i0 - tap * d.C;
         const int r = tap / d.R, t = tap - r * d.R;
-        H = d.H; W = d.W; Qd = d.Q; Pd = d.P; stride = d.stride; C4 = d.C * 4;
-        hoff = r - d.pad; woff = t - d.pad;
-        HWC4 = (unsigned)(d.H * d.W * d.C * 4);
-        dq = BK % d.Q; dp = (BK / d.Q) % d.P; dnoff = (unsigned)(BK / (d.P * d.Q)) * HWC4;
+        const int C4 = d.C * 4, WC4 = d.W * C4;
+        const int hoff = r - d.pad, woff = t - d.pad;
+        HWC4 = (unsigned)(d.H * WC4);
+        wlim = (unsigned)WC4; hlim = HWC4;
+        dhq = (BK % d.Q) * d.stride * C4;               // q += BK % Q
+        qwrap = d.Q * d.stride * C4;                    // q -= Q on carry
+        qlim = qwrap + woff * C4;                       // q >= Q  <=>  hq >= qlim
+        prow = d.stride * WC4;                          // p += 1
+        dhp = ((BK / d.Q) % d.P) * prow;
+        pwrap = d.P * prow;
+        plim = pwrap + hoff * WC4;
+        dnoff = (unsigned)(BK / (d.P * d.Q)) * HWC4;
         stageK4 = (unsigned)(BK * d.K * 4);
 #pragma unroll
         for (int i = 0; i < T::A_F4; ++i) {
             const int f = threadIdx.x + T::NT * i;
             const int m = s0 * BK + f / (BM / 4);
-            q[i] = m % d.Q;
-            const int u = m / d.Q;
-            p[i] = u % d.P;
+            const int q = m % d.Q, u = m / d.Q;
+            const int p = u % d.P;
+            hq[i] = (q * d.stride + woff) * C4;
+            hp[i] = (p * d.stride + hoff) * WC4;
             noff[i] = (unsigned)(u / d.P) * HWC4 + (unsigned)((c0 + (f % (BM / 4)) * 4) * 4);
         }
 #pragma unroll
@@ -543,16 +560,14 @@ struct WgradProblem {
         }
     }
     __device__ __forceinline__ float4 load_a1(int, int i) {
-        const int h = mad24(p[i], stride, hoff), w = mad24(q[i], stride, woff);
-        const bool ok = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
-        const unsigned off = noff[i] + (unsigned)__mul24(mad24(h, W, w), C4);
-        const float4 v = bufld4(rx, ok ? off : kOOB);
-        q[i] += dq;
-        const bool cq = q[i] >= Qd;
-        q[i] -= cq ? Qd : 0;
-        p[i] += dp + (cq ? 1 : 0);
-        const bool cp = p[i] >= Pd;
-        p[i] -= cp ? Pd : 0;
+        const bool ok = (unsigned)hp[i] < hlim && (unsigned)hq[i] < wlim;
+        const float4 v = bufld4(rx, ok ? noff[i] + (unsigned)hp[i] + (unsigned)hq[i] : kOOB);
+        hq[i] += dhq;
+        const bool cq = hq[i] >= qlim;
+        hq[i] -= cq ? qwrap : 0;
+        hp[i] += dhp + (cq ? prow : 0);
+        const bool cp = hp[i] >= plim;
+        hp[i] -= cp ? pwrap : 0;
         noff[i] += dnoff + (cp ? HWC4 : 0u);
         return v;
     }
