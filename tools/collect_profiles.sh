@@ -18,3 +18,5 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python $R/bench.py --probe-only --probe-reps 50 > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o q -- python $R/bench.py --probe-only --probe-reps 50 > /dev/null 2> $OUT/pmc_sq.err
 ls -R $OUT | head -50
+python $R/tools/bench_conv.py 64 > $OUT/conv_layers.txt 2>&1
+cd $R && python bench.py > $OUT/bench.json 2> $OUT/bench.err

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""gpurun_out/<tag>/ (written by tools/collect_profiles.sh on the GPU box) -> profiles/<tag>_*.
+usage: tools/make_profiles.py r01"""
+import csv, json, os, subprocess, sys, collections
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(ROOT, 'gpurun_out', tag), os.path.join(ROOT, 'profiles')
+os.makedirs(dst, exist_ok=True)
+
+def summary(sub, pre, steps, out, header):
+    txt = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'prof_summary.py'), os.path.join(src, sub), pre, str(steps)],
+                         capture_output=True, text=True).stdout
+    with open(os.path.join(dst, out), 'w') as f:
+        f.write(header + '\n' + txt)
+
+summary('graph', 'g', 25, tag + '_kernel_stats_graph.txt',
+        '# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline   (hipGraph, 3 streams;\n'
+        '# kernel durations under the profiler include overlap between streams: use the eager file for per-kernel cost)')
+summary('eager', 'e', 25, tag + '_kernel_stats_eager.txt',
+        '# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-graph --no-cpu-baseline')
+summary('probe', 'p', 1, tag + '_dominant_kernel_stats.txt',
+        '# rocprofv3 --kernel-trace --stats -- python bench.py --probe-only --probe-reps 50\n'
+        '# (one eager step, then 50 launches of the dominant kernel: D l7 weight gradient; its row is igemm_wgrad_kernel<64, 64, true, 1>)')
+
+def pmc(sub, pre):
+    rows = list(csv.DictReader(open(os.path.join(src, sub, pre + '_counter_collection.csv'))))
+    acc = collections.defaultdict(list)
+    for r in rows:
+        if 'igemm_wgrad_kernel' in r['Kernel_Name']:
+            acc[(r['Counter_Name'], r['Grid_Size'])].append(float(r['Counter_Value']))
+    # the probe launches are the most frequent grid size
+    best = {}
+    for (name, grid), v in acc.items():
+        if name not in best or len(v) > best[name][1]:
+            best[name] = (grid, len(v), sum(v) / len(v))
+    return best
+
+probe = json.load(open(os.path.join(src, 'probe.json')))['dominant_kernel']
+fetch, write, sq = pmc('pmc_fetch', 'f'), pmc('pmc_write', 'w'), pmc('pmc_sq', 'q')
+fetch_kb, write_kb = fetch['FETCH_SIZE'][2], write['WRITE_SIZE'][2]
+# MI355X_MICROARCH.md, HBM section: FETCH_SIZE on gfx950 reports half of the bytes of wide coalesced reads -> x2; KiB units
+hbm = (2 * fetch_kb + write_kb) * 1024
+mfma_busy, gui = sq['SQ_VALU_MFMA_BUSY_CYCLES'][2], sq['GRBM_GUI_ACTIVE'][2]
+out = {'kernel': probe['kernel'], 'launches_profiled': fetch['FETCH_SIZE'][1],
+       'FETCH_SIZE_KiB_raw': fetch_kb, 'WRITE_SIZE_KiB_raw': write_kb,
+       'hbm_bytes_per_launch': hbm,
+       'correction': 'FETCH_SIZE x2 (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section); '
+                     'WRITE_SIZE uncorrected (split-K fp32 atomics)',
+       'algorithmic_bytes_per_launch': None,
+       'SQ_VALU_MFMA_BUSY_CYCLES': mfma_busy, 'GRBM_GUI_ACTIVE_sum_over_8_XCD': gui,
+       'mfma_busy_frac_of_simd_cycles': mfma_busy / (gui / 8 * 1024),
+       'sq': {k: v[2] for k, v in sq.items()}}
+json.dump(out, open(os.path.join(dst, tag + '_dominant_kernel_pmc.json'), 'w'), indent=1)
+for name in ('conv_layers.txt', 'bench.json', 'bench_graph.json', 'bench_eager.json', 'probe.json'):
+    p = os.path.join(src, name)
+    if os.path.exists(p):
+        with open(p) as f, open(os.path.join(dst, tag + '_' + name if not name.startswith('bench.') else 'bench_' + tag + '.json'), 'w') as g:
+            g.write(f.read())
+print(json.dumps(out, indent=1)[:1500])
