@@ -4,6 +4,7 @@
 #include <stdlib.h>
 
 #include "conv_internal.h"
+#include <stdint.h>
 
 using namespace mmdgan;
 
@@ -21,6 +22,13 @@ bool force_direct() {
     if (v < 0) { const char *e = getenv("MMDGAN_FORCE_DIRECT"); v = (e && e[0] == '1') ? 1 : 0; }
     return v == 1;
 }
+// MMDGAN_THIN_VALU=1 keeps the thin first/last layers on the VALU kernels (A/B against the MFMA ones)
+bool force_valu_thin() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MMDGAN_THIN_VALU"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }    // also true for nullptr
 }  // namespace
 
 namespace {
@@ -50,6 +58,9 @@ extern "C" int mmdgan_conv2d_fwd(const mmdgan_conv_geom *g, const float *x, cons
     if (int rc = make_wrap(d.N, dact_of ? dact_batch : 0, (long)d.P * d.Q * d.K, "conv2d_fwd", &wf, &ws)) return rc;
     const ConvEpilogue ep{bias, scale, dact_of, act, wf, ws, out_zeroed};
     if (!force_direct() && igemm_fwd_ok(d)) return igemm_fwd(d, ep, x, w, y, (hipStream_t)stream);
+    if (!force_direct() && !force_valu_thin() && (thinm_fwd_n2w_ok(d) || thinm_fwd_w2n_ok(d)) && al16(x) && al16(y) &&
+        al16(bias) && al16(dact_of))
+        return thinm_fwd(d, ep, x, w, y, (hipStream_t)stream);
     if (!force_direct() && (thin_fwd_in_ok(d) || thin_fwd_out_ok(d))) return thin_fwd(d, ep, x, w, y, (hipStream_t)stream);
     return direct_fwd(d, ep, x, w, y, (hipStream_t)stream);
 }
@@ -67,6 +78,9 @@ extern "C" int mmdgan_conv2d_dgrad(const mmdgan_conv_geom *g, const float *dy, c
     if (int rc = make_wrap(d.N, dact_of ? dact_batch : 0, (long)d.H * d.W * d.C, "conv2d_dgrad", &wf, &ws)) return rc;
     const ConvEpilogue ep{bias, scale, dact_of, act, wf, ws, out_zeroed};
     if (!force_direct() && igemm_dgrad_ok(d)) return igemm_dgrad(d, ep, dy, w, dx, (hipStream_t)stream);
+    if (!force_direct() && !force_valu_thin() && (thinm_dgrad_n2w_ok(d) || thinm_dgrad_w2n_ok(d)) && al16(dy) && al16(dx) &&
+        al16(bias) && al16(dact_of))
+        return thinm_dgrad(d, ep, dy, w, dx, (hipStream_t)stream);
     if (!force_direct() && (thin_dgrad_in_ok(d) || thin_dgrad_out_ok(d)))
         return thin_dgrad(d, ep, dy, w, dx, (hipStream_t)stream);
     return direct_dgrad(d, ep, dy, w, dx, (hipStream_t)stream);
@@ -77,6 +91,10 @@ extern "C" int mmdgan_conv2d_wgrad(const mmdgan_conv_geom *g, const float *x, co
     MMDGAN_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
     const ConvDims d = conv_dims(*g);
     if (!force_direct() && igemm_wgrad_ok(d)) return igemm_wgrad(d, x, dy, dw, (hipStream_t)stream);
+    if (!force_direct() && !force_valu_thin() && thinm_wgrad_ok(d)) {
+        const int rc = thinm_wgrad(d, x, dy, dw, (hipStream_t)stream);
+        if (rc <= 0) return rc;                                    // 1: no workspace registered -> VALU kernel below
+    }
     if (!force_direct() && thin_wgrad_ok(d)) return thin_wgrad(d, x, dy, dw, (hipStream_t)stream);
     return direct_wgrad(d, x, dy, dw, (hipStream_t)stream);
 }

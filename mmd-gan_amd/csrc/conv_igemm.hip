@@ -26,6 +26,7 @@
 //     reductions that are long but narrow (batch-1 spectral-norm convs, weight gradients) are
 //     split over blockIdx.z and combined with fp32 atomics into a zeroed output.
 #include "conv_internal.h"
+#include "bufload.h"
 
 namespace mmdgan {
 
@@ -54,21 +55,6 @@ struct TileCfg {
     static constexpr int A_F4 = BM * BK / 4 / NT, B_F4 = BN * BK / 4 / NT;
     static constexpr int SMEM_FLOATS = 2 * BK * (LDA + LDB);
 };
-
-// Gathers go through buffer loads: the hardware range check returns 0 for an offset beyond
-// num_records, so zero padding ('SAME' borders, ragged last tile) is an offset select instead of a
-// divergent branch around the load.  The descriptor is built from kernel arguments only
-// (wave-uniform, so no waterfall loop is generated).
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr unsigned kOOB = 0x80000000u;          // every tensor here is < 2 GiB
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *base, long bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ float4 bufld4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
 
 // k-contiguous source element f of a ROWS x BK tile: row = f/KQ, kq = f%KQ; transposing store
 __device__ __forceinline__ void sts_kc(float *S, int LD, int f, const float4 &v) {

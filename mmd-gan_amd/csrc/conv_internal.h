@@ -36,6 +36,18 @@ int thin_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const fl
 int thin_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, float *dx, hipStream_t st);
 int thin_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st);
 
+int thin_wgrad_reduce(const float *partials, int nblocks, long nout, float *dw, hipStream_t st);
+
+// MFMA versions of the same thin layers for 3x3 / stride 1 (conv_thin_mfma.hip)
+bool thinm_fwd_n2w_ok(const ConvDims &d);
+bool thinm_fwd_w2n_ok(const ConvDims &d);
+bool thinm_dgrad_n2w_ok(const ConvDims &d);
+bool thinm_dgrad_w2n_ok(const ConvDims &d);
+bool thinm_wgrad_ok(const ConvDims &d);
+int thinm_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, float *y, hipStream_t st);
+int thinm_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, float *dx, hipStream_t st);
+int thinm_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st);   // 1 = no workspace
+
 // MFMA implicit-GEMM path (conv_igemm.hip); *_ok() say whether a geometry is eligible
 bool igemm_fwd_ok(const ConvDims &d);
 bool igemm_dgrad_ok(const ConvDims &d);

@@ -329,4 +329,9 @@ int thin_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hi
     return check_launch("conv2d_wgrad(thin)");
 }
 
+int thin_wgrad_reduce(const float *partials, int nblocks, long nout, float *dw, hipStream_t st) {
+    hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3((unsigned)((nout + 63) / 64)), dim3(256), 0, st, partials, nblocks, nout, dw);
+    return check_launch("conv2d_wgrad(thin reduce)");
+}
+
 }  // namespace mmdgan
