@@ -32,16 +32,41 @@ constexpr int kJP = 16;                  // MFMA k-pairs / rows for J <= 32
 template <bool FLIP>
 __device__ __forceinline__ int tap_off(int r, int pad) { return FLIP ? pad - r : r - pad; }
 
+// per patch column j = (tap, thin channel): byte offset of the gathered element relative to the
+// output pixel, the tap's bit in the validity mask and where its weights start - filled on the host
+// (32 x 2 runtime divisions per wave cost more than the wave's 32 MFMAs)
+struct PatchTab {
+    int delta[32];
+    unsigned tbit[32];
+    int woff[32];
+};
+
+template <bool FLIP>
+static PatchTab make_patch_tab(const ConvDims &d, int Cn) {
+    PatchTab t;
+    const int J = d.R * d.R * Cn;
+    for (int j = 0; j < 32; ++j) {
+        const bool used = j < J;
+        const int jj = used ? j : 0;
+        const int tap = jj / Cn, cn = jj - tap * Cn, r = tap / d.R, c = tap - r * d.R;
+        const int dh = FLIP ? d.pad - r : r - d.pad, dw = FLIP ? d.pad - c : c - d.pad;
+        t.delta[j] = ((dh * d.W + dw) * Cn + cn) * 4;
+        t.tbit[j] = used ? 1u << tap : 0u;
+        t.woff[j] = used ? (FLIP ? tap * d.C * d.K + cn : jj * d.K) : -1;
+    }
+    return t;
+}
+
 // ------------------------------------------------------------------------------------------------
 // n2w.  FLIP = false: forward (in = x [N,H,W,Cn=C], Wm[j][ch] = w[j*K + ch]);
 //       FLIP = true : input-gradient (in = dy [N,H,W,Cn=K], Wm[(tap,k)][c] = w[(tap*C + c)*K + k])
 template <bool FLIP, int WB>
 __global__ __launch_bounds__(256) void thinm_n2w_kernel(ConvDims d, ConvEpilogue ep, const float *__restrict__ in,
                                                         const float *__restrict__ w, float *__restrict__ out,
-                                                        int ntiles) {
+                                                        int ntiles, PatchTab tab) {
     constexpr int Wd = WB * 32;
     const int Cn = FLIP ? d.K : d.C;
-    const int R = d.R, J = R * R * Cn, IH = d.H, IW = d.W;
+    const int R = d.R, IH = d.H, IW = d.W;
     const long M = (long)d.N * IH * IW;
     const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5, wave = threadIdx.x >> 6;
     float a[WB][kJP];
@@ -49,17 +74,13 @@ __global__ __launch_bounds__(256) void thinm_n2w_kernel(ConvDims d, ConvEpilogue
     unsigned tbit[kJP];
 #pragma unroll
     for (int jp = 0; jp < kJP; ++jp) {
-        const int j = 2 * jp + kh;
-        const bool used = j < J;
-        const int jj = used ? j : 0;
-        const int tap = jj / Cn, cn = jj - tap * Cn, r = tap / R, t = tap - r * R;
-        delta[jp] = ((tap_off<FLIP>(r, d.pad) * IW + tap_off<FLIP>(t, d.pad)) * Cn + cn) * 4;
-        tbit[jp] = used ? 1u << tap : 0u;
+        delta[jp] = kh ? tab.delta[2 * jp + 1] : tab.delta[2 * jp];
+        tbit[jp] = kh ? tab.tbit[2 * jp + 1] : tab.tbit[2 * jp];
+        const int wo = kh ? tab.woff[2 * jp + 1] : tab.woff[2 * jp];
 #pragma unroll
         for (int wb = 0; wb < WB; ++wb) {
             const int ch = wb * 32 + l31;
-            const float v = FLIP ? w[((long)tap * d.C + ch) * d.K + cn] : w[(long)jj * d.K + ch];
-            a[wb][jp] = used ? v : 0.f;
+            a[wb][jp] = wo >= 0 ? w[wo + (FLIP ? ch * d.K : ch)] : 0.f;
         }
     }
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(in, M * Cn * 4);
@@ -283,9 +304,10 @@ static void launch_n2w(const ConvDims &d, const ConvEpilogue &ep, const float *i
     const int ntiles = (int)((M + 31) / 32);
     int blocks = (ntiles + 3) / 4;
     if (blocks > 1024) blocks = 1024;
-    if (wide == 32) hipLaunchKernelGGL((thinm_n2w_kernel<FLIP, 1>), dim3(blocks), dim3(256), 0, st, d, ep, in, w, out, ntiles);
-    else if (wide == 64) hipLaunchKernelGGL((thinm_n2w_kernel<FLIP, 2>), dim3(blocks), dim3(256), 0, st, d, ep, in, w, out, ntiles);
-    else hipLaunchKernelGGL((thinm_n2w_kernel<FLIP, 4>), dim3(blocks), dim3(256), 0, st, d, ep, in, w, out, ntiles);
+    const PatchTab tab = make_patch_tab<FLIP>(d, FLIP ? d.K : d.C);
+    if (wide == 32) hipLaunchKernelGGL((thinm_n2w_kernel<FLIP, 1>), dim3(blocks), dim3(256), 0, st, d, ep, in, w, out, ntiles, tab);
+    else if (wide == 64) hipLaunchKernelGGL((thinm_n2w_kernel<FLIP, 2>), dim3(blocks), dim3(256), 0, st, d, ep, in, w, out, ntiles, tab);
+    else hipLaunchKernelGGL((thinm_n2w_kernel<FLIP, 4>), dim3(blocks), dim3(256), 0, st, d, ep, in, w, out, ntiles, tab);
 }
 
 template <bool FLIP>

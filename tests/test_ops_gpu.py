@@ -138,6 +138,10 @@ CONV_CASES = [
     (3, 6, 6, 256, 256, 3, 1),
     # few tiles -> 8-wave K-group kernels, split reductions with a ragged last split
     (32, 16, 16, 64, 128, 3, 1), (16, 8, 8, 128, 128, 4, 2), (8, 4, 4, 256, 256, 3, 1), (5, 10, 10, 64, 64, 3, 1),
+    # thin layers on the MFMA patch-GEMM kernels: ragged pixel tiles, partial row bands, wide 32/64/128,
+    # 5x5 taps, 1..3 thin channels, STL / 64x64 image sizes
+    (3, 10, 12, 3, 32, 3, 1), (2, 7, 6, 64, 2, 3, 1), (2, 48, 48, 3, 64, 3, 1), (2, 48, 48, 64, 3, 3, 1),
+    (1, 64, 64, 128, 3, 3, 1), (1, 64, 64, 3, 128, 3, 1), (2, 9, 10, 1, 64, 5, 1), (2, 11, 8, 32, 1, 5, 1),
 ]
 
 
@@ -177,6 +181,13 @@ def test_conv2d_dgrad_and_wgrad(ops, case):
     assert rel_err(to_nchw(dx), gx.numpy()) <= RTOL
     dw = ops.conv2d_wgrad(nhwc(x), nhwc(dy), ksz, s)
     assert rel_err(dw.cpu().numpy(), gw.numpy()) <= RTOL
+    # with a registered library workspace the thin layers take the partial-sum (MFMA) kernels
+    ops.set_workspace()
+    try:
+        dw = ops.conv2d_wgrad(nhwc(x), nhwc(dy), ksz, s)
+        assert rel_err(dw.cpu().numpy(), gw.numpy()) <= RTOL
+    finally:
+        ops.require_device().mmdgan_set_workspace(None, 0)
     # backward epilogue form: scale * dgrad * lrelu'(y_prev)
     yprev = rs.randn(N, C, H, W).astype(np.float32)
     ref = 0.5 * gx.numpy() * np.where(yprev > 0, 1.0, 0.1)
@@ -204,7 +215,8 @@ def test_dact_batch_wrap(ops):
     """3B-row backward: the last B output images take act' from the LAST B images of a 2B-image
     activation tensor (conv dgrad on the MFMA path, on the direct path, and gemm)."""
     rs = np.random.RandomState(4)
-    for (B, H, C, K, ksz, st) in ((4, 8, 64, 128, 3, 1), (2, 6, 5, 7, 3, 1), (4, 8, 64, 64, 4, 2)):
+    for (B, H, C, K, ksz, st) in ((4, 8, 64, 128, 3, 1), (2, 6, 5, 7, 3, 1), (4, 8, 64, 64, 4, 2),
+                                  (4, 8, 3, 64, 3, 1), (4, 8, 64, 3, 3, 1)):       # + the thin MFMA kernels
         P = -(-H // st)
         dy = rs.randn(3 * B, K, P, P).astype(np.float32)
         w = (rs.randn(ksz, ksz, C, K) / np.sqrt(ksz * ksz * C)).astype(np.float32)
