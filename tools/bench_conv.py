@@ -33,6 +33,12 @@ for name, N, H, W, C, K, R, s in LAYERS:
     dy = torch.randn(N, P, Q, K, device='cuda'); y = torch.empty(N, P, Q, K, device='cuda')
     dx = torch.empty_like(x); dw = torch.empty_like(w); bias = torch.zeros(K, device='cuda')
     fl = 2.0 * N * P * Q * K * R * R * C
+    if os.environ.get('BENCH_DGRAD_3B') and name.startswith('D l') and 'thin' not in name and '(B)' not in name:
+        # the step's D backward: 3B rows (loss_dis rows 2B + loss_gen rows B), dact wraps to the last B images
+        n3 = N + N // 2
+        dy3 = torch.randn(n3, P, Q, K, device='cuda'); dx3 = torch.empty(n3, H, W, C, device='cuda')
+        t3 = timeit(lambda: ops.conv2d_dgrad(dy3, w, (H, W), s, act='lrelu', dact_of=x, dact_batch=N, out=dx3))
+        print('%-10s dgrad 3B rows: %7.1f us (%5.1f TF)' % (name, t3 * 1e3, 1.5 * fl / t3 / 1e9))
     t = [timeit(lambda: ops.conv2d_fwd(x, w, s, bias=bias, act='lrelu', out=y)),
          timeit(lambda: ops.conv2d_dgrad(dy, w, (H, W), s, act='lrelu', dact_of=x, out=dx)),
          timeit(lambda: ops.conv2d_wgrad(x, dy, R, s, out=dw))]
