@@ -342,7 +342,9 @@ class GanEngine:
             import torch.distributed as tdist
             self.world = tdist.get_world_size(dist_group)
         self._pending = []
-        self._sn_stream = torch.cuda.Stream(device=self.device)
+        # the power iterations of different layers are independent of each other too: two chains
+        self._sn_streams = [torch.cuda.Stream(device=self.device)
+                            for _ in range(int(os.environ.get('MMDGAN_SN_STREAMS', '2')))]
         # weight / bias gradients of a layer depend only on dz of that layer, not on the dgrad chain that
         # continues below it: they go to a second stream so their blocks fill the tail of the dgrad
         # launches (each launch alone leaves CUs idle while its last wave of tiles drains)
@@ -492,14 +494,16 @@ class GanEngine:
         # the spectral-norm power iteration depends on D's weights only, not on the batch: its ~50
         # small launches run on a second HIP stream underneath G's forward pass
         main = torch.cuda.current_stream()
-        self._sn_stream.wait_stream(main)
         self._scales = {}
-        with torch.cuda.stream(self._sn_stream):
-            for s in self.dis.specs:
+        for st in self._sn_streams:
+            st.wait_stream(main)
+        for i, s in enumerate(self.dis.specs):
+            with torch.cuda.stream(self._sn_streams[i % len(self._sn_streams)]):
                 self._scales[s.scope] = self._sn_step(s) if s.sn else None
         b['dis_in'][:B].copy_(real)
         self.generate(z, is_training=True)                                   # writes dis_in[B:]
-        main.wait_stream(self._sn_stream)
+        for st in self._sn_streams:
+            main.wait_stream(st)
         x = b['dis_in']
         for s in self.dis.specs:
             scale = self._scales[s.scope]
