@@ -674,9 +674,20 @@ class GanEngine:
         lib = ops.require_device()
         lib.mmdgan_set_outputs_prezeroed(1)
         try:
+            # the two gradient arenas (61 MB of memset) are first touched in the backward pass: zero them
+            # on the parameter-gradient stream, underneath the forward pass
+            arenas = (self.gen.grads, self.dis.grads) if self._side_wgrad else ()
+            if arenas:
+                self._wg_stream.wait_stream(torch.cuda.current_stream())      # after the previous step's Adam
+                with torch.cuda.stream(self._wg_stream):
+                    for t in arenas:
+                        t.zero_()
             for t in self._zero_each_step:
-                t.zero_()
+                if not any(t is a for a in arenas):
+                    t.zero_()
             self._forward(z, real)
+            if arenas:
+                torch.cuda.current_stream().wait_stream(self._wg_stream)
             dz = self._backward_dis()
             if self.dist_group is not None:
                 self._join_wg_stream()
