@@ -47,6 +47,11 @@ extern "C" {
 /* loss enum - math_func.py:2644-2647 */
 #define MMDGAN_LOSS_REP 0
 #define MMDGAN_LOSS_RMB 1
+/* OR-ed into loss_type: write the four gradient blocks of mmdgan_mmd_loss in the order
+ * [dL_dis/ds_x, dL_dis/ds_gen, dL_gen/ds_gen, dL_gen/ds_x] instead of [dL_gen/ds_gen, dL_gen/ds_x, dL_dis/ds_gen,
+ * dL_dis/ds_x]: the first 3B rows are then exactly the score gradient a discriminator fed [real ; fake] (and the
+ * fake half again for the generator loss) back-propagates - no gather copies. */
+#define MMDGAN_LOSS_FLAG_GRADS_DIS_FIRST 0x100
 
 const char *mmdgan_last_error(void);
 int mmdgan_version(void);

@@ -375,9 +375,25 @@ __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(ConvDims d, ConvEpi
         for (int ni = 0; ni < T::TN; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+#ifdef MMDGAN_TIMELINE          // tools/igemm_probe.hip: wall-clock (100 MHz) stamps per workgroup
+    extern __device__ unsigned long long g_timeline[];
+    const int tl = (blockIdx.y * gridDim.x + blockIdx.x) * 4;
+    if ((MMDGAN_TIMELINE & 1) && threadIdx.x == 0) g_timeline[tl + 0] = wall_clock64();
+    if ((MMDGAN_TIMELINE & 16) && threadIdx.x == 0)       // where did this workgroup run: XCC_ID (hwreg 20), HW_ID (hwreg 4)
+        g_timeline[tl + 1] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32) |
+                             (unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+#endif
     FwdProblem<BM, BN, KG> p;
     p.init(d, x, w, m0, n0, M);
+#ifdef MMDGAN_TIMELINE
+    if ((MMDGAN_TIMELINE & 2) && threadIdx.x == 0) g_timeline[tl + 1] = wall_clock64();
+    if ((MMDGAN_TIMELINE & 32) && threadIdx.x == 0) g_timeline[tl + 1] = clock64();      // shader clock at entry
+#endif
     mainloop<BM, BN, KG>(p, s0, s1, smem, acc);
+#ifdef MMDGAN_TIMELINE
+    if ((MMDGAN_TIMELINE & 4) && threadIdx.x == 0) g_timeline[tl + 2] = wall_clock64();
+    if ((MMDGAN_TIMELINE & 32) && threadIdx.x == 0) g_timeline[tl + 2] = clock64();      // ... and after the main loop
+#endif
     const float sc = ep.scale ? ep.scale[0] : 1.f;
     const int Kc = d.K;
     auto rowoff = [=](int row) -> long {
@@ -385,6 +401,9 @@ __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(ConvDims d, ConvEpi
         return m < M ? m * Kc + n0 : -1;
     };
     epilogue_store<BM, BN, SPLIT, KG>(smem, acc, rowoff, n0, ep, sc, y, !SPLIT || blockIdx.z == 0, false);
+#ifdef MMDGAN_TIMELINE
+    if ((MMDGAN_TIMELINE & 8) && threadIdx.x == 0) g_timeline[tl + 3] = wall_clock64();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

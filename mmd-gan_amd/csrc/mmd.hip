@@ -29,7 +29,7 @@ constexpr int kNumSums = 5;     // kxx kxy kyy kxx_b kyy_b
 
 struct MmdArgs {
     const float *x, *y;   // s_gen, s_x
-    int B, d, loss_type;
+    int B, d, loss_type, dis_first;
     float w0, w1, lb, ub;
     double *partials;     // [gridDim.x][kNumSums]
     unsigned *counter;
@@ -169,7 +169,9 @@ __global__ __launch_bounds__(256) void mmd_kernel(MmdArgs a) {
                 }
             }
             const int vec = lane >> 4, k = k0 + (lane & 15);
-            if (row_ok && k < d) a.grads[((size_t)vec * B + i) * d + k] = acc[0];
+            // MMDGAN_LOSS_FLAG_GRADS_DIS_FIRST: slots [dLdis/ds_x, dLdis/ds_gen, dLgen/ds_gen, dLgen/ds_x]
+            const int slot = a.dis_first ? (0x0132 >> (4 * vec)) & 15 : vec;
+            if (row_ok && k < d) a.grads[((size_t)slot * B + i) * d + k] = acc[0];
         }
     }
 
@@ -239,11 +241,13 @@ extern "C" int mmdgan_mmd_loss(const float *s_gen, const float *s_x, int B, int 
     MMDGAN_REQUIRE(s_gen && s_x && out_scalars && workspace, "mmd_loss: null pointer");
     MMDGAN_REQUIRE(B >= 2, "mmd_loss: batch_size must be >= 2 (got %d)", B);
     MMDGAN_REQUIRE(d >= 1 && d <= kMmdMaxD, "mmd_loss: d must be in [1,%d] (got %d)", kMmdMaxD, d);
+    const int dis_first = (loss_type & MMDGAN_LOSS_FLAG_GRADS_DIS_FIRST) != 0;
+    loss_type &= ~MMDGAN_LOSS_FLAG_GRADS_DIS_FIRST;
     MMDGAN_REQUIRE(loss_type == MMDGAN_LOSS_REP || loss_type == MMDGAN_LOSS_RMB, "mmd_loss: unknown loss %d", loss_type);
     MMDGAN_REQUIRE(w0 - w1 == 1.0f, "w[0]-w[1] must be 1");       // math_func.py:1340
     hipStream_t st = (hipStream_t)stream;
     MmdArgs a;
-    a.x = s_gen; a.y = s_x; a.B = B; a.d = d; a.loss_type = loss_type;
+    a.x = s_gen; a.y = s_x; a.B = B; a.d = d; a.loss_type = loss_type; a.dis_first = dis_first;
     a.w0 = w0; a.w1 = w1; a.lb = lower_bound; a.ub = upper_bound;
     a.counter = (unsigned *)workspace;
     a.partials = (double *)((char *)workspace + 64);

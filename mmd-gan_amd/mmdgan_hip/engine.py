@@ -381,7 +381,6 @@ class GanEngine:
                 self.buf[s.scope + '#dz'] = torch.zeros(_native_shape(s.op_out_ref, 3 * B) if net is self.dis else shp,
                                                         device=dev)
         self.buf['d_fake'] = torch.zeros(B, h, w, c, device=dev)
-        self.buf['ds_d'] = torch.zeros(3 * B, self.score_size, device=dev)
         # SN scratch per D layer (u / xb live in the network's zero-once-per-step arena)
         for s in self.dis.specs:
             if s.sn:
@@ -519,7 +518,7 @@ class GanEngine:
         if 'mmd_grads' not in b:
             b['mmd_grads'] = torch.zeros(4, B, self.score_size, device=self.device)
         ops.check(lib.mmdgan_mmd_loss(scores[B:].data_ptr(), scores[:B].data_ptr(), B, self.score_size,
-                                      ops.LOSS[self.loss_type], self.rep_weights[0], self.rep_weights[1], 0.25, 4.0,
+                                      ops.LOSS[self.loss_type] | 0x100, self.rep_weights[0], self.rep_weights[1], 0.25, 4.0,
                                       self.losses.data_ptr(), b['mmd_grads'].data_ptr(), None, None,
                                       ops._mmd_ws[key].data_ptr(), ops._stream()), 'mmd_loss')
         return scores
@@ -531,13 +530,10 @@ class GanEngine:
         layer (the last B rows take their activation derivative from the fake half's activations),
         weight / bias gradients from the first 2B rows only."""
         B, b, net = self.B, self.buf, self.dis
-        g = b['mmd_grads']                                                   # dLg/dsg, dLg/dsx, dLd/dsg, dLd/dsx
+        # the loss kernel wrote [dLd/ds_x (real rows, my_sngan.py:278-279) ; dLd/ds_gen ; dLg/ds_gen ; dLg/ds_x]:
+        # its first 3B rows are the score gradient of the 3B-row backward pass
         specs = net.specs
-        ds = b['ds_d']
-        ds[:B].copy_(g[3])                                                   # real rows first (my_sngan.py:278-279)
-        ds[B:2 * B].copy_(g[2])
-        ds[2 * B:].copy_(g[0])                                               # dLgen/ds_gen
-        dz = ds
+        dz = b['mmd_grads'].view(4 * B, -1)[:3 * B]
         for li in range(len(specs) - 1, -1, -1):
             s = specs[li]
             x_in = b['dis_in'] if li == 0 else b[specs[li - 1].scope + '#y']

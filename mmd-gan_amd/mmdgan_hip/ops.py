@@ -221,10 +221,11 @@ _mmd_ws = {}
 
 
 def mmd_loss(s_gen, s_x, loss_type='rep', rep_weights=(0.0, -1.0), lower_bound=0.25, upper_bound=4.0,
-             need_grads=True, need_masks=False, need_dist=False):
+             need_grads=True, need_masks=False, need_dist=False, grads_dis_first=False):
     """fused pairwise-distance / Gaussian-kernel / rep|rmb loss (math_func.py:2505-2550).
     Returns dict(scalars[8] = loss_gen, loss_dis, e_kxx, e_kxy, e_kyy, e_kxx_b, e_kyy_b, 0;
-                 grads[4,B,d], masks[3,B,B] (bool), dist[3,B,B])."""
+                 grads[4,B,d] = dLg/ds_gen, dLg/ds_x, dLd/ds_gen, dLd/ds_x (grads_dis_first: dLd/ds_x, dLd/ds_gen,
+                 dLg/ds_gen, dLg/ds_x), masks[3,B,B] (bool), dist[3,B,B])."""
     lib = require_device()
     if loss_type not in LOSS:
         raise NotImplementedError('Not implemented.')                            # math_func.py:2651
@@ -238,7 +239,7 @@ def mmd_loss(s_gen, s_x, loss_type='rep', rep_weights=(0.0, -1.0), lower_bound=0
     grads = torch.empty((4, B, d), device=dev, dtype=torch.float32) if need_grads else None
     masks = torch.empty((3, B, B), device=dev, dtype=torch.uint8) if need_masks else None
     dist = torch.empty((3, B, B), device=dev, dtype=torch.float32) if need_dist else None
-    check(lib.mmdgan_mmd_loss(_p(s_gen), _p(s_x), B, d, LOSS[loss_type], float(rep_weights[0]), float(rep_weights[1]),
+    check(lib.mmdgan_mmd_loss(_p(s_gen), _p(s_x), B, d, LOSS[loss_type] | (0x100 if grads_dis_first else 0), float(rep_weights[0]), float(rep_weights[1]),
                               float(lower_bound), float(upper_bound), _p(out), _p(grads),
                               masks.data_ptr() if masks is not None else None, _p(dist), _mmd_ws[key].data_ptr(),
                               _stream()), 'mmd_loss')

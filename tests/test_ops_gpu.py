@@ -110,6 +110,16 @@ def test_mmd_size_independent_properties(ops):
     assert abs(sh[0] - base[0]) <= 1e-4 * abs(base[0]) + 1e-6
 
 
+def test_mmd_grads_dis_first_order(ops):
+    rs = np.random.RandomState(3)
+    a, b = dev(rs.randn(64, 16).astype(np.float32)), dev(rs.randn(64, 16).astype(np.float32))
+    for lt in ('rep', 'rmb'):
+        g = ops.mmd_loss(a, b, lt)['grads']
+        h = ops.mmd_loss(a, b, lt, grads_dis_first=True)['grads']
+        for slot, src in enumerate((3, 2, 0, 1)):
+            assert torch.equal(h[slot], g[src]), (lt, slot)
+
+
 def test_mmd_errors(ops):
     z = torch.zeros(8, 16).cuda()
     with pytest.raises(NotImplementedError, match='Not implemented.'):          # math_func.py:2651
