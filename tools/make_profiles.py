@@ -51,7 +51,7 @@ out = {'kernel': probe['kernel'], 'launches_profiled': fetch['FETCH_SIZE'][1],
        'mfma_busy_frac_of_simd_cycles': mfma_busy / (gui / 8 * 1024),
        'sq': {k: v[2] for k, v in sq.items()}}
 json.dump(out, open(os.path.join(dst, tag + '_dominant_kernel_pmc.json'), 'w'), indent=1)
-for name in ('conv_layers.txt', 'bench.json', 'bench_graph.json', 'bench_eager.json', 'probe.json'):
+for name in ('conv_layers.txt', 'bench.json', 'bench_graph.json', 'bench_eager.json', 'probe.json', 'bench_stl.json', 'bench_celeba.json'):
     p = os.path.join(src, name)
     if os.path.exists(p):
         with open(p) as f, open(os.path.join(dst, tag + '_' + name if not name.startswith('bench.') else 'bench_' + tag + '.json'), 'w') as g:
