@@ -17,8 +17,18 @@ __device__ __forceinline__ float4 bufld4(__amdgpu_buffer_rsrc_t r, unsigned byte
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 bufld2(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
 __device__ __forceinline__ float bufld1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+
+// voffset (per lane, range-checked) + soffset (wave-uniform SGPR, not range-checked): no VALU add per load
+__device__ __forceinline__ float bufld1s(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned s_off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, s_off, 0));
 }
 
 }  // namespace mmdgan

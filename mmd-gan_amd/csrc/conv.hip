@@ -57,6 +57,7 @@ extern "C" int mmdgan_conv2d_fwd(const mmdgan_conv_geom *g, const float *x, cons
     long wf, ws;
     if (int rc = make_wrap(d.N, dact_of ? dact_batch : 0, (long)d.P * d.Q * d.K, "conv2d_fwd", &wf, &ws)) return rc;
     const ConvEpilogue ep{bias, scale, dact_of, act, wf, ws, out_zeroed};
+    if (!force_direct() && wino_fwd_ok(d)) return wino_fwd(d, ep, x, w, y, (hipStream_t)stream);
     if (!force_direct() && igemm_fwd_ok(d)) return igemm_fwd(d, ep, x, w, y, (hipStream_t)stream);
     if (!force_direct() && !force_valu_thin() && (thinm_fwd_n2w_ok(d) || thinm_fwd_w2n_ok(d)) && al16(x) && al16(y) &&
         al16(bias) && al16(dact_of))
@@ -77,6 +78,7 @@ extern "C" int mmdgan_conv2d_dgrad(const mmdgan_conv_geom *g, const float *dy, c
     long wf, ws;
     if (int rc = make_wrap(d.N, dact_of ? dact_batch : 0, (long)d.H * d.W * d.C, "conv2d_dgrad", &wf, &ws)) return rc;
     const ConvEpilogue ep{bias, scale, dact_of, act, wf, ws, out_zeroed};
+    if (!force_direct() && wino_dgrad_ok(d)) return wino_dgrad(d, ep, dy, w, dx, (hipStream_t)stream);
     if (!force_direct() && igemm_dgrad_ok(d)) return igemm_dgrad(d, ep, dy, w, dx, (hipStream_t)stream);
     if (!force_direct() && !force_valu_thin() && (thinm_dgrad_n2w_ok(d) || thinm_dgrad_w2n_ok(d)) && al16(dy) && al16(dx) &&
         al16(bias) && al16(dact_of))

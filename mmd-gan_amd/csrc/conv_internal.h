@@ -48,6 +48,12 @@ int thinm_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const f
 int thinm_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, float *dx, hipStream_t st);
 int thinm_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st);   // 1 = no workspace
 
+// Winograd F(2x2,3x3) for 3x3 / stride-1 layers (conv_wino.hip); needs the library workspace for G g G^T
+bool wino_fwd_ok(const ConvDims &d);
+bool wino_dgrad_ok(const ConvDims &d);
+int wino_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, float *y, hipStream_t st);
+int wino_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, float *dx, hipStream_t st);
+
 // MFMA implicit-GEMM path (conv_igemm.hip); *_ok() say whether a geometry is eligible
 bool igemm_fwd_ok(const ConvDims &d);
 bool igemm_dgrad_ok(const ConvDims &d);

@@ -1,0 +1,320 @@
+// Winograd F(2x2, 3x3) convolution for the 3x3 / stride-1 layers of the discriminator (D l3, l5, l7:
+// 43 % of the step's FLOPs), forward and input-gradient.  Why: the fp32 MFMA pipe is the bound and,
+// under it, the clock (1.8-1.9 GHz on real data: power) - the direct implicit GEMM already runs at
+// 83-89 % of what the pipe delivers at that clock, so the remaining lever is fewer MFMAs per output:
+// 16 multiplies per 2x2 output tile instead of 36 (2.25x).
+//
+//   y = A^T [ sum_c (G g G^T) (.) (B^T d B) ] A      g: 3x3 filter, d: 4x4 input patch, y: 2x2 outputs
+//
+// As GEMMs: for each of the 16 "frequencies" f, M_f[tile][k] = sum_c V_f[tile][c] * U_f[c][k].
+//   * U = G g G^T is computed once per launch by wino_weight_kernel into the library workspace
+//     ([16][C][K]; for the input-gradient the taps are flipped and the channel roles swapped).
+//   * one workgroup = 32 tiles (MFMA rows) x BN output channels, ALL 16 frequencies: wave w owns
+//     f = 4w..4w+3 (i = w, j = 0..3), i.e. 4 x BN/32 accumulators of v_mfma_f32_32x32x2_f32.
+//   * the input transform is fused into the load path: a thread owns row r of one tile for two
+//     channels (4 float2 loads per stage; padding = buffer-load range check baked into the offsets),
+//     does the row pass in registers, fetches the one other row it needs with a quad-permute DPP
+//     move and writes its 8 values of V to LDS.  A stage is 4 input channels: 16 MFMAs per wave.
+//   * the output transform is the epilogue: the j direction inside each wave's registers, the i
+//     direction across the 4 waves through LDS, then bias / SN scale / activation (or activation
+//     derivative with the 3B-row wrap) and coalesced stores - same ConvEpilogue as the direct kernels.
+// Numerics: all transform constants are 0, +-1, +-1/2 (exact); the result differs from the direct
+// kernel by fp32 rounding of a different summation order (measured <= 2e-6 relative on the parity cases).
+#include "conv_internal.h"
+#include "bufload.h"
+
+namespace mmdgan {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace wino {
+constexpr int BC = 4;                  // reduction channels per stage
+constexpr int LDT = 33;                // V: floats per channel row (32 tiles + 1)
+constexpr int FSV = BC * LDT + 6;      // V: floats per frequency; 4*FSV = 8 (mod 32) spreads the 4 tile rows over the banks
+constexpr int V_FLOATS = 16 * FSV;     // one stage of transformed activations
+template <int BN>
+struct Cfg {
+    static constexpr int NCB = BN / 32;
+    static constexpr int ZS_FLOATS = 4 * 2 * 32 * 32;        // epilogue exchange buffer
+    static constexpr int SMEM_FLOATS = 2 * V_FLOATS > ZS_FLOATS ? 2 * V_FLOATS : ZS_FLOATS;
+    static constexpr size_t LDS_BYTES = sizeof(float) * SMEM_FLOATS + sizeof(long) * 32;   // + output offset of each tile
+};
+}  // namespace wino
+
+// U[f][cr][ko] = (G g G^T)[f]  with g = w[.][.][c][k] (cr = c, ko = k)                      FLIP = false
+//                               or g = w[2-.][2-.][c][k] read as (cr = k, ko = c)            FLIP = true
+template <bool FLIP>
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float *__restrict__ w, float *__restrict__ U, int C, int K) {
+    __shared__ float tile[8][32][33];
+    const int c0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const int tk = threadIdx.x & 31, tq = threadIdx.x >> 5;
+    for (int half = 0; half < (FLIP ? 2 : 1); ++half) {
+        for (int cc = tq; cc < 32; cc += 8) {
+            const int c = c0 + cc, k = k0 + tk;
+            const bool ok = c < C && k < K;
+            float g[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    g[r][t] = ok ? w[((size_t)((FLIP ? 2 - r : r) * 3 + (FLIP ? 2 - t : t)) * C + c) * K + k] : 0.f;
+            float gg[4][3], u[4][4];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                gg[0][t] = g[0][t];
+                gg[1][t] = 0.5f * (g[0][t] + g[1][t] + g[2][t]);
+                gg[2][t] = 0.5f * (g[0][t] - g[1][t] + g[2][t]);
+                gg[3][t] = g[2][t];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u[i][0] = gg[i][0];
+                u[i][1] = 0.5f * (gg[i][0] + gg[i][1] + gg[i][2]);
+                u[i][2] = 0.5f * (gg[i][0] - gg[i][1] + gg[i][2]);
+                u[i][3] = gg[i][2];
+            }
+            if (!FLIP) {
+                if (ok) {
+#pragma unroll
+                    for (int f = 0; f < 16; ++f) U[((size_t)f * C + c) * K + k] = u[f >> 2][f & 3];
+                }
+            } else {
+#pragma unroll
+                for (int f = 0; f < 8; ++f) tile[f][cc][tk] = half ? u[2 + (f >> 2)][f & 3] : u[f >> 2][f & 3];
+            }
+        }
+        if (FLIP) {          // transposed write: U[f][k][c], threads along c
+            __syncthreads();
+            for (int kk = tq; kk < 32; kk += 8) {
+                const int k = k0 + kk, c = c0 + tk;
+                if (c < C && k < K) {
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) U[((size_t)(half * 8 + f) * K + k) * C + c] = tile[f][tk][kk];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// x [N,H,W,Cr] (*) U [16][Cr][Ko] -> out [N,H,W,Ko], 'SAME' padding, stride 1
+// Only V goes through LDS: wave w is the sole consumer of U[4w..4w+3], so its B fragments (one dword per
+// lane, 128 contiguous bytes per half-wave) are loaded from L2 straight into the MFMA operand registers,
+// each refilled for the next stage right after the MFMA that consumed it (measured on the D l3 shape:
+// staging U through LDS cost 10 of 60 us).
+template <int BN>
+__global__ __launch_bounds__(256, 2) void wino_kernel(int N, int H, int W, int Cr, int Ko, ConvEpilogue ep,
+                                                      const float *__restrict__ x, const float *__restrict__ U,
+                                                      float *__restrict__ out) {
+    using Cf = wino::Cfg<BN>;
+    constexpr int BC = wino::BC, LDT = wino::LDT, FSV = wino::FSV, NCB = Cf::NCB, VF = wino::V_FLOATS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5, wave = tid >> 6;
+    const int TH = H >> 1, TW = W >> 1;
+    const long T = (long)N * TH * TW;
+    const int t0 = blockIdx.x * 32, n0 = blockIdx.y * BN;
+    // ---- producer: thread = (tile pt, channel pair pp, patch row pr); pr in the low lane bits (DPP quad)
+    const int pt = tid >> 3, pp = (tid >> 2) & 1, pr = tid & 3;
+    unsigned xoff[4];
+    {
+        const long id = (long)t0 + pt;
+        const bool ok = id < T;
+        const long ii = ok ? id : 0;
+        const int tx = ii % TW, ty = (ii / TW) % TH, n = ii / ((long)TW * TH);
+        const int y = 2 * ty - 1 + pr;
+        const bool rowok = ok && y >= 0 && y < H;
+        if ((tid & 7) == 0)      // element offset of output pixel (2ty, 2tx), channel 0, for the epilogue (-1: no such tile)
+            reinterpret_cast<long *>(smem + Cf::SMEM_FLOATS)[pt] = ok ? (((long)n * H + 2 * ty) * W + 2 * tx) * Ko : -1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int xx = 2 * tx - 1 + j;
+            xoff[j] = (rowok && xx >= 0 && xx < W) ? (unsigned)(((((long)n * H + y) * W + xx) * Cr + 2 * pp) * 4) : kOOB;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (long)N * H * W * Cr * 4);
+    const __amdgpu_buffer_rsrc_t ru = make_rsrc(U, (long)16 * Cr * Ko * 4);
+    const float sa = pr == 3 ? -1.f : 1.f, sb = (pr & 1) ? 1.f : -1.f;      // V[i=pr] = sa * X[pr] + sb * X[other]
+    const int vdst = (pr * 4) * FSV + (2 * pp) * LDT + pt;
+    // B fragment of group g = (kp = g>>2, fl = g&3), column block cb: U[4*wave + fl][c0 + 2*kp + kh][n0 + cb*32 + l31]
+    const unsigned ubase = (unsigned)(((((long)4 * wave) * Cr + kh) * Ko + n0 + l31) * 4);
+    const unsigned ustage = (unsigned)(BC * Ko * 4), ufreq = (unsigned)((long)Cr * Ko * 4), ukp = (unsigned)(2 * Ko * 4);
+    const int nstages = Cr / BC;
+
+    f32x16 acc[4][NCB];
+#pragma unroll
+    for (int fl = 0; fl < 4; ++fl)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[fl][cb][r] = 0.f;
+
+    float2 rin[4];
+    float fb[8][NCB], X[4][2];
+#define WINO_VST(DST, VAL) DST = VAL
+#define WINO_ROWPASS                                                                                     \
+    X[0][0] = rin[0].x - rin[2].x; X[0][1] = rin[0].y - rin[2].y;                                        \
+    X[1][0] = rin[1].x + rin[2].x; X[1][1] = rin[1].y + rin[2].y;                                        \
+    X[2][0] = rin[2].x - rin[1].x; X[2][1] = rin[2].y - rin[1].y;                                        \
+    X[3][0] = rin[1].x - rin[3].x; X[3][1] = rin[1].y - rin[3].y;
+#define WINO_VSTORE(BUF, J)                                                                              \
+    _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                      \
+        const int other = __builtin_amdgcn_update_dpp(0, __float_as_int(X[J][e]), 0x5A, 0xF, 0xF, false); /* quad_perm [2,2,1,1] */ \
+        WINO_VST((BUF)[vdst + (J) * FSV + e * LDT], fmaf(sb, __int_as_float(other), sa * X[J][e]));       \
+    }
+#define WINO_XLOAD(S)                                                                                    \
+    {                                                                                                    \
+        const unsigned sx = (unsigned)((S) * BC * 4);          /* padded taps: kOOB + sx stays out of range */ \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) rin[j] = bufld2(rx, xoff[j] + sx);                 \
+    }
+#define WINO_BLOAD(G, S)                                                                                 \
+    _Pragma("unroll") for (int cb = 0; cb < NCB; ++cb)                                                   \
+        fb[G][cb] = bufld1s(ru, ubase, (unsigned)(S) * ustage + ((G) & 3) * ufreq + ((G) >> 2) * ukp + cb * 128);
+
+    // prologue: tile 0 -> LDS, tile 1 -> registers, B fragments of stage 0
+    WINO_XLOAD(0)
+#pragma unroll
+    for (int g = 0; g < 8; ++g) WINO_BLOAD(g, 0)
+    WINO_ROWPASS
+    WINO_VSTORE(smem, 0) WINO_VSTORE(smem, 1) WINO_VSTORE(smem, 2) WINO_VSTORE(smem, 3)
+    WINO_XLOAD(1)
+    __syncthreads();
+    // Same hand pipeline as the direct kernels (conv_igemm.hip mainloop): per stage a wave issues 8 groups
+    // of NCB MFMAs; A fragments are read from LDS 3 groups ahead; the transform + LDS stores of tile s+1
+    // and the global loads of tile s+2 sit behind individual MFMA groups (sched_barrier keeps hipcc from
+    // re-clumping them); one barrier per stage.
+    const int abase = (4 * wave) * FSV + kh * LDT + l31;
+    for (int s = 0; s < nstages; ++s) {
+        const float *cur = smem + (s & 1) * VF;
+        float *nxt = smem + ((s + 1) & 1) * VF;
+        const int sn = s + 1 < nstages ? s + 1 : s;           // the last refill re-reads the last stage (unused)
+        float fa[8];
+#define WINO_FRAG(G) fa[G] = cur[abase + ((G) & 3) * FSV + 2 * ((G) >> 2) * LDT];
+        WINO_FRAG(0) WINO_FRAG(1) WINO_FRAG(2)
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (g + 3 < 8) {
+                switch (g + 3) { case 3: WINO_FRAG(3) break; case 4: WINO_FRAG(4) break; case 5: WINO_FRAG(5) break;
+                                 case 6: WINO_FRAG(6) break; default: WINO_FRAG(7) break; }
+            }
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+                acc[g & 3][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g], fb[g][cb], acc[g & 3][cb], 0, 0, 0);
+            switch (g) {        // this group's B registers are free again: refill them for the next stage
+                case 0: WINO_BLOAD(0, sn) break; case 1: WINO_BLOAD(1, sn) break; case 2: WINO_BLOAD(2, sn) break;
+                case 3: WINO_BLOAD(3, sn) break; case 4: WINO_BLOAD(4, sn) break; case 5: WINO_BLOAD(5, sn) break;
+                case 6: WINO_BLOAD(6, sn) break; default: WINO_BLOAD(7, sn) break;
+            }
+            if (g == 0) {                              // tile s+1: row pass, then frequencies j = 0, 1
+                WINO_ROWPASS
+                WINO_VSTORE(nxt, 0) WINO_VSTORE(nxt, 1)
+            } else if (g == 1) {
+                WINO_VSTORE(nxt, 2) WINO_VSTORE(nxt, 3)
+            } else if (g == 2) {                       // tile s+2: activations
+                WINO_XLOAD(s + 2)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef WINO_FRAG
+        __syncthreads();
+    }
+#undef WINO_VST
+#undef WINO_ROWPASS
+#undef WINO_VSTORE
+#undef WINO_XLOAD
+#undef WINO_BLOAD
+
+    // ---- output transform + epilogue
+    const float sc = ep.scale ? ep.scale[0] : 1.f;
+    float *Zs = smem;                                   // [wave i][b][tile][k 32]
+    const long *obase = reinterpret_cast<const long *>(smem + Cf::SMEM_FLOATS);
+    const int kq = tid & 7, tb = tid >> 3;              // 4 channels kq*4.., item tb = (tile, b) and tb + 32
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int tile = (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const float m0 = acc[0][cb][r], m1 = acc[1][cb][r], m2 = acc[2][cb][r], m3 = acc[3][cb][r];
+            Zs[((wave * 2 + 0) * 32 + tile) * 32 + l31] = m0 + m1 + m2;
+            Zs[((wave * 2 + 1) * 32 + tile) * 32 + l31] = m1 - m2 - m3;
+        }
+        __syncthreads();
+        const int ch = n0 + cb * 32 + kq * 4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ep.bias) bv = *reinterpret_cast<const float4 *>(ep.bias + ch);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int item = tb + 32 * it, tile = item >> 1, b = item & 1;
+            const long ob = obase[tile];
+            if (ob >= 0) {
+                const float4 z0 = *reinterpret_cast<const float4 *>(Zs + ((0 * 2 + b) * 32 + tile) * 32 + kq * 4);
+                const float4 z1 = *reinterpret_cast<const float4 *>(Zs + ((1 * 2 + b) * 32 + tile) * 32 + kq * 4);
+                const float4 z2 = *reinterpret_cast<const float4 *>(Zs + ((2 * 2 + b) * 32 + tile) * 32 + kq * 4);
+                const float4 z3 = *reinterpret_cast<const float4 *>(Zs + ((3 * 2 + b) * 32 + tile) * 32 + kq * 4);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    float4 v;
+                    if (a == 0) v = make_float4(z0.x + z1.x + z2.x, z0.y + z1.y + z2.y, z0.z + z1.z + z2.z, z0.w + z1.w + z2.w);
+                    else v = make_float4(z1.x - z2.x - z3.x, z1.y - z2.y - z3.y, z1.z - z2.z - z3.z, z1.w - z2.w - z3.w);
+                    const long o = ob + ((long)a * W + b) * Ko + ch;
+                    v.x = v.x * sc + bv.x; v.y = v.y * sc + bv.y; v.z = v.z * sc + bv.z; v.w = v.w * sc + bv.w;
+                    if (ep.dact) {
+                        const float4 yv = *reinterpret_cast<const float4 *>(ep.dact + ep.dact_index(o));
+                        v.x *= act_bwd_from_out(yv.x, ep.act); v.y *= act_bwd_from_out(yv.y, ep.act);
+                        v.z *= act_bwd_from_out(yv.z, ep.act); v.w *= act_bwd_from_out(yv.w, ep.act);
+                    } else {
+                        v.x = act_fwd(v.x, ep.act); v.y = act_fwd(v.y, ep.act);
+                        v.z = act_fwd(v.z, ep.act); v.w = act_fwd(v.w, ep.act);
+                    }
+                    *reinterpret_cast<float4 *>(out + o) = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+static bool wino_enabled() {       // MMDGAN_WINO=0 keeps the 3x3 layers on the direct implicit-GEMM kernels
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MMDGAN_WINO"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
+
+// below ~768 tiles (24 x K/64 workgroups) the grid no longer fills the chip and the direct kernel wins
+// (measured: D l7 forward at batch 128 = 512 tiles: 92 us either way; 768 tiles: 116 vs 160 us).
+// MMDGAN_WINO_MIN_TILES overrides (the parity tests use small problems).
+static long wino_min_tiles() {
+    static long v = -1;
+    if (v < 0) { const char *e = getenv("MMDGAN_WINO_MIN_TILES"); v = e ? atol(e) : 768; }
+    return v;
+}
+
+static bool wino_geom_ok(const ConvDims &d, int cr, int ko) {
+    return wino_enabled() && d.R == 3 && d.stride == 1 && d.pad == 1 && d.H % 2 == 0 && d.W % 2 == 0 && cr % wino::BC == 0 &&
+           cr >= 32 && ko % 64 == 0 && (long)d.N * (d.H / 2) * (d.W / 2) >= wino_min_tiles() &&
+           workspace(sizeof(float) * 16 * (size_t)cr * ko) != nullptr;
+}
+bool wino_fwd_ok(const ConvDims &d) { return wino_geom_ok(d, d.C, d.K); }
+bool wino_dgrad_ok(const ConvDims &d) { return wino_geom_ok(d, d.K, d.C); }
+
+static int wino_launch(const ConvDims &d, const ConvEpilogue &ep, const float *in, const float *w, float *out, bool flip,
+                       hipStream_t st) {
+    const int cr = flip ? d.K : d.C, ko = flip ? d.C : d.K;
+    float *U = (float *)workspace(sizeof(float) * 16 * (size_t)cr * ko);
+    const dim3 wg((d.K + 31) / 32, (d.C + 31) / 32);
+    if (flip) hipLaunchKernelGGL(wino_weight_kernel<true>, wg, dim3(256), 0, st, w, U, d.C, d.K);
+    else hipLaunchKernelGGL(wino_weight_kernel<false>, wg, dim3(256), 0, st, w, U, d.C, d.K);
+    const long T = (long)d.N * (d.H / 2) * (d.W / 2);
+    const dim3 grid((unsigned)((T + 31) / 32), ko / 64);
+    hipLaunchKernelGGL((wino_kernel<64>), grid, dim3(256), (wino::Cfg<64>::LDS_BYTES), st, d.N, d.H, d.W, cr, ko, ep, in, U, out);
+    return check_launch(flip ? "conv2d_dgrad(winograd)" : "conv2d_fwd(winograd)");
+}
+
+int wino_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, float *y, hipStream_t st) {
+    return wino_launch(d, ep, x, w, y, false, st);
+}
+int wino_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, float *dx, hipStream_t st) {
+    return wino_launch(d, ep, dy, w, dx, true, st);
+}
+
+}  // namespace mmdgan

@@ -205,6 +205,42 @@ def test_conv2d_dgrad_and_wgrad(ops, case):
     assert rel_err(to_nchw(dx2), ref) <= RTOL
 
 
+WINO_CASES = [(16, 16, 16, 128, 128, 3, 1), (32, 8, 8, 64, 128, 3, 1), (9, 12, 12, 32, 64, 3, 1), (130, 4, 4, 64, 64, 3, 1),
+              (5, 14, 18, 36, 192, 3, 1)]
+
+
+@pytest.mark.parametrize('case', WINO_CASES, ids=[str(c) for c in WINO_CASES])
+def test_conv2d_winograd_path(ops, case):
+    """3x3 / stride-1 layers with the library workspace registered run Winograd F(2x2,3x3) (forward and
+    input-gradient, ragged last tile block, H != W, 3B-row dact wrap); same oracle, same tolerance."""
+    N, H, W, C, K, ksz, s = case
+    x, w, b = conv_data(case, 2)
+    rs = np.random.RandomState(9)
+    dy = rs.randn(N, K, H, W).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64)
+    yt = R.conv2d_same(xt, wt, s)
+    gx, = torch.autograd.grad((yt * torch.tensor(dy, dtype=torch.float64)).sum(), [xt])
+    ops.set_workspace()
+    try:
+        sc = np.float32(0.37)
+        for act in ('linear', 'lrelu'):
+            ref = R._act(yt.detach() * float(sc) + torch.tensor(b, dtype=torch.float64).reshape(1, -1, 1, 1), act).numpy()
+            y = ops.conv2d_fwd(nhwc(x), dev(w), s, bias=dev(b), scale=dev([sc]), act=act)
+            assert rel_err(to_nchw(y), ref) <= RTOL, act
+        dx = ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s)
+        assert rel_err(to_nchw(dx), gx.numpy()) <= RTOL
+        if N % 3 == 0:                                   # [2B ; B] rows against 2B activations
+            B = N // 3
+            yprev = rs.randn(2 * B, C, H, W).astype(np.float32)
+            mask = np.where(np.concatenate([yprev, yprev[B:]], 0) > 0, 1.0, 0.1)
+            dx2 = ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s, scale=dev([0.5]), act='lrelu', dact_of=nhwc(yprev),
+                                   dact_batch=2 * B)
+            assert rel_err(to_nchw(dx2), 0.5 * gx.numpy() * mask) <= RTOL
+    finally:
+        ops.require_device().mmdgan_set_workspace(None, 0)
+
+
 @pytest.mark.parametrize('case', [(4, 4, 4, 512, 256, 4, 2), (3, 8, 8, 256, 128, 4, 2), (2, 16, 16, 128, 64, 4, 2),
                                   (3, 4, 4, 32, 16, 4, 2), (2, 3, 3, 16, 8, 4, 2)],
                          ids=lambda c: str(c))
