@@ -11,10 +11,10 @@
 //     ([16][C][K]; for the input-gradient the taps are flipped and the channel roles swapped).
 //   * one workgroup = 32 tiles (MFMA rows) x BN output channels, ALL 16 frequencies: wave w owns
 //     f = 4w..4w+3 (i = w, j = 0..3), i.e. 4 x BN/32 accumulators of v_mfma_f32_32x32x2_f32.
-//   * the input transform is fused into the load path: a thread owns row r of one tile for two
-//     channels (4 float2 loads per stage; padding = buffer-load range check baked into the offsets),
+//   * the input transform is fused into the load path: a thread owns row r of one tile for four
+//     channels (4 float4 loads per stage; padding = buffer-load range check baked into the offsets),
 //     does the row pass in registers, fetches the one other row it needs with a quad-permute DPP
-//     move and writes its 8 values of V to LDS.  A stage is 4 input channels: 16 MFMAs per wave.
+//     move and writes its 16 values of V to LDS.  A stage is 8 input channels: 32 MFMAs per wave.
 //   * the output transform is the epilogue: the j direction inside each wave's registers, the i
 //     direction across the 4 waves through LDS, then bias / SN scale / activation (or activation
 //     derivative with the 3B-row wrap) and coalesced stores - same ConvEpilogue as the direct kernels.
@@ -28,9 +28,10 @@ namespace mmdgan {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace wino {
-constexpr int BC = 4;                  // reduction channels per stage
+constexpr int BC = 8;                  // reduction channels per stage: 32 MFMAs per wave between barriers
 constexpr int LDT = 33;                // V: floats per channel row (32 tiles + 1)
-constexpr int FSV = BC * LDT + 6;      // V: floats per frequency; 4*FSV = 8 (mod 32) spreads the 4 tile rows over the banks
+constexpr int FSV = BC * LDT + 2;      // V: floats per frequency; 4*FSV = 8 (mod 32) spreads the 4 tile rows over the banks
+static_assert((4 * FSV) % 32 == 8, "V frequency stride");
 constexpr int V_FLOATS = 16 * FSV;     // one stage of transformed activations
 template <int BN>
 struct Cfg {
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(int N, int H, int W, int C
     const int TH = H >> 1, TW = W >> 1;
     const long T = (long)N * TH * TW;
     const int t0 = blockIdx.x * 32, n0 = blockIdx.y * BN;
-    // ---- producer: thread = (tile pt, channel pair pp, patch row pr); pr in the low lane bits (DPP quad)
+    // ---- producer: thread = (tile pt, channel quad pp, patch row pr); pr in the low lane bits (DPP quad)
     const int pt = tid >> 3, pp = (tid >> 2) & 1, pr = tid & 3;
     unsigned xoff[4];
     {
@@ -128,17 +129,18 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(int N, int H, int W, int C
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int xx = 2 * tx - 1 + j;
-            xoff[j] = (rowok && xx >= 0 && xx < W) ? (unsigned)(((((long)n * H + y) * W + xx) * Cr + 2 * pp) * 4) : kOOB;
+            xoff[j] = (rowok && xx >= 0 && xx < W) ? (unsigned)(((((long)n * H + y) * W + xx) * Cr + 4 * pp) * 4) : kOOB;
         }
     }
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (long)N * H * W * Cr * 4);
     const __amdgpu_buffer_rsrc_t ru = make_rsrc(U, (long)16 * Cr * Ko * 4);
     const float sa = pr == 3 ? -1.f : 1.f, sb = (pr & 1) ? 1.f : -1.f;      // V[i=pr] = sa * X[pr] + sb * X[other]
-    const int vdst = (pr * 4) * FSV + (2 * pp) * LDT + pt;
+    const int vdst = (pr * 4) * FSV + (4 * pp) * LDT + pt;
     // B fragment of group g = (kp = g>>2, fl = g&3), column block cb: U[4*wave + fl][c0 + 2*kp + kh][n0 + cb*32 + l31]
     const unsigned ubase = (unsigned)(((((long)4 * wave) * Cr + kh) * Ko + n0 + l31) * 4);
     const unsigned ustage = (unsigned)(BC * Ko * 4), ufreq = (unsigned)((long)Cr * Ko * 4), ukp = (unsigned)(2 * Ko * 4);
     const int nstages = Cr / BC;
+    constexpr int NG = 2 * BC, PF = 3;                  // MFMA groups per stage, A-fragment prefetch distance
 
     f32x16 acc[4][NCB];
 #pragma unroll
@@ -148,23 +150,24 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(int N, int H, int W, int C
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[fl][cb][r] = 0.f;
 
-    float2 rin[4];
-    float fb[8][NCB], X[4][2];
-#define WINO_VST(DST, VAL) DST = VAL
+    float4 rin[4];
+    float fb[NG][NCB], X[4][4];
+    // row pass X = d B along the 4 columns of this thread's patch row, 4 channels
 #define WINO_ROWPASS                                                                                     \
-    X[0][0] = rin[0].x - rin[2].x; X[0][1] = rin[0].y - rin[2].y;                                        \
-    X[1][0] = rin[1].x + rin[2].x; X[1][1] = rin[1].y + rin[2].y;                                        \
-    X[2][0] = rin[2].x - rin[1].x; X[2][1] = rin[2].y - rin[1].y;                                        \
-    X[3][0] = rin[1].x - rin[3].x; X[3][1] = rin[1].y - rin[3].y;
+    X[0][0] = rin[0].x - rin[2].x; X[0][1] = rin[0].y - rin[2].y; X[0][2] = rin[0].z - rin[2].z; X[0][3] = rin[0].w - rin[2].w; \
+    X[1][0] = rin[1].x + rin[2].x; X[1][1] = rin[1].y + rin[2].y; X[1][2] = rin[1].z + rin[2].z; X[1][3] = rin[1].w + rin[2].w; \
+    X[2][0] = rin[2].x - rin[1].x; X[2][1] = rin[2].y - rin[1].y; X[2][2] = rin[2].z - rin[1].z; X[2][3] = rin[2].w - rin[1].w; \
+    X[3][0] = rin[1].x - rin[3].x; X[3][1] = rin[1].y - rin[3].y; X[3][2] = rin[1].z - rin[3].z; X[3][3] = rin[1].w - rin[3].w;
+    // column pass V = B^T X: row i = pr needs its own row and row {2,2,1,1}[pr] of the same quad
 #define WINO_VSTORE(BUF, J)                                                                              \
-    _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                      \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                      \
         const int other = __builtin_amdgcn_update_dpp(0, __float_as_int(X[J][e]), 0x5A, 0xF, 0xF, false); /* quad_perm [2,2,1,1] */ \
-        WINO_VST((BUF)[vdst + (J) * FSV + e * LDT], fmaf(sb, __int_as_float(other), sa * X[J][e]));       \
+        (BUF)[vdst + (J) * FSV + e * LDT] = fmaf(sb, __int_as_float(other), sa * X[J][e]);                \
     }
 #define WINO_XLOAD(S)                                                                                    \
     {                                                                                                    \
         const unsigned sx = (unsigned)((S) * BC * 4);          /* padded taps: kOOB + sx stays out of range */ \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) rin[j] = bufld2(rx, xoff[j] + sx);                 \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) rin[j] = bufld4(rx, xoff[j] + sx);                 \
     }
 #define WINO_BLOAD(G, S)                                                                                 \
     _Pragma("unroll") for (int cb = 0; cb < NCB; ++cb)                                                   \
@@ -173,51 +176,47 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(int N, int H, int W, int C
     // prologue: tile 0 -> LDS, tile 1 -> registers, B fragments of stage 0
     WINO_XLOAD(0)
 #pragma unroll
-    for (int g = 0; g < 8; ++g) WINO_BLOAD(g, 0)
+    for (int g = 0; g < NG; ++g) WINO_BLOAD(g, 0)
     WINO_ROWPASS
     WINO_VSTORE(smem, 0) WINO_VSTORE(smem, 1) WINO_VSTORE(smem, 2) WINO_VSTORE(smem, 3)
     WINO_XLOAD(1)
     __syncthreads();
-    // Same hand pipeline as the direct kernels (conv_igemm.hip mainloop): per stage a wave issues 8 groups
-    // of NCB MFMAs; A fragments are read from LDS 3 groups ahead; the transform + LDS stores of tile s+1
-    // and the global loads of tile s+2 sit behind individual MFMA groups (sched_barrier keeps hipcc from
-    // re-clumping them); one barrier per stage.
+    // Same hand pipeline as the direct kernels (conv_igemm.hip mainloop): per stage a wave issues NG groups
+    // of NCB MFMAs; A fragments are read from LDS PF groups ahead; each group's B registers are refilled
+    // for the next stage right after its MFMAs; the transform + LDS stores of tile s+1 and the global loads
+    // of tile s+2 sit behind individual groups (sched_barrier keeps hipcc from re-clumping them); one
+    // barrier per stage.
     const int abase = (4 * wave) * FSV + kh * LDT + l31;
     for (int s = 0; s < nstages; ++s) {
         const float *cur = smem + (s & 1) * VF;
         float *nxt = smem + ((s + 1) & 1) * VF;
         const int sn = s + 1 < nstages ? s + 1 : s;           // the last refill re-reads the last stage (unused)
-        float fa[8];
-#define WINO_FRAG(G) fa[G] = cur[abase + ((G) & 3) * FSV + 2 * ((G) >> 2) * LDT];
-        WINO_FRAG(0) WINO_FRAG(1) WINO_FRAG(2)
+        float fa[NG];
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            if (g + 3 < 8) {
-                switch (g + 3) { case 3: WINO_FRAG(3) break; case 4: WINO_FRAG(4) break; case 5: WINO_FRAG(5) break;
-                                 case 6: WINO_FRAG(6) break; default: WINO_FRAG(7) break; }
-            }
+        for (int g = 0; g < PF; ++g) fa[g] = cur[abase + (g & 3) * FSV + 2 * (g >> 2) * LDT];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + PF < NG) fa[g + PF] = cur[abase + ((g + PF) & 3) * FSV + 2 * ((g + PF) >> 2) * LDT];
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
                 acc[g & 3][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g], fb[g][cb], acc[g & 3][cb], 0, 0, 0);
-            switch (g) {        // this group's B registers are free again: refill them for the next stage
-                case 0: WINO_BLOAD(0, sn) break; case 1: WINO_BLOAD(1, sn) break; case 2: WINO_BLOAD(2, sn) break;
-                case 3: WINO_BLOAD(3, sn) break; case 4: WINO_BLOAD(4, sn) break; case 5: WINO_BLOAD(5, sn) break;
-                case 6: WINO_BLOAD(6, sn) break; default: WINO_BLOAD(7, sn) break;
-            }
-            if (g == 0) {                              // tile s+1: row pass, then frequencies j = 0, 1
+            WINO_BLOAD(g, sn)
+            if (g == 0) {                              // tile s+1: row pass, then one frequency column per group
                 WINO_ROWPASS
-                WINO_VSTORE(nxt, 0) WINO_VSTORE(nxt, 1)
+                WINO_VSTORE(nxt, 0)
             } else if (g == 1) {
-                WINO_VSTORE(nxt, 2) WINO_VSTORE(nxt, 3)
-            } else if (g == 2) {                       // tile s+2: activations
+                WINO_VSTORE(nxt, 1)
+            } else if (g == 2) {
+                WINO_VSTORE(nxt, 2)
+            } else if (g == 3) {
+                WINO_VSTORE(nxt, 3)
+            } else if (g == 4) {                       // tile s+2: activations
                 WINO_XLOAD(s + 2)
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-#undef WINO_FRAG
         __syncthreads();
     }
-#undef WINO_VST
 #undef WINO_ROWPASS
 #undef WINO_VSTORE
 #undef WINO_XLOAD

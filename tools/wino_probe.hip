@@ -32,6 +32,6 @@ int main(int argc, char **argv) {
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms2; (void)hipEventElapsedTime(&ms2, e0, e1);
     printf("%s N=%d H=%d C=%d K=%d: %d wgs, %d stages: kernel %.1f us (%.1f TF effective), weight transform %.1f us\n", VARIANT, N, H, C, K,
-           grid.x * grid.y, C / 4, ms / 20 * 1e3, 2.0 * N * H * H * K * 9.0 * C / (ms / 20) / 1e9, ms2 / 20 * 1e3);
+           grid.x * grid.y, C / mmdgan::wino::BC, ms / 20 * 1e3, 2.0 * N * H * H * K * 9.0 * C / (ms / 20) / 1e9, ms2 / 20 * 1e3);
     return 0;
 }
