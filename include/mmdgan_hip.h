@@ -43,6 +43,10 @@ extern "C" {
  * ACCUMULATE into it (lets a launch with too few tiles for 256 CUs split its reduction even when
  * mmdgan_set_outputs_prezeroed(1) is in force).  Only honoured with a linear epilogue (no dact_of). */
 #define MMDGAN_ACT_FLAG_OUT_ZEROED 0x100
+/* OR-ed into `act` of conv2d_fwd / conv2d_dgrad: `w` is not the HWIO kernel but the tensor mmdgan_wino_transform()
+ * produced from it (same dgrad flag as the call), for a geometry mmdgan_wino_eligible() accepts.  Lets a caller
+ * whose weights change once per step transform them once, off the critical path, instead of inside every call. */
+#define MMDGAN_ACT_FLAG_W_WINOGRAD 0x200
 
 /* loss enum - math_func.py:2644-2647 */
 #define MMDGAN_LOSS_REP 0
@@ -104,6 +108,18 @@ int mmdgan_conv2d_dgrad(const mmdgan_conv_geom *g, const float *dy, const float 
 /* dw[R,R,C,K] = sum over pixels x (x) dy                   autodiff of conv2d / conv2d_transpose
  * dw is overwritten. */
 int mmdgan_conv2d_wgrad(const mmdgan_conv_geom *g, const float *x, const float *dy, float *dw, void *stream);
+
+/* Winograd F(2x2,3x3) for 3x3 / stride-1 layers (same tf.nn.conv2d / autodiff call sites as above; csrc/conv_wino.hip).
+ * conv2d_fwd / conv2d_dgrad use it on their own when the geometry is eligible and a workspace is registered for
+ * the transformed weights; a caller can instead transform once per weight update:
+ *   mmdgan_wino_eligible(g, dgrad)        1 if conv2d_fwd (dgrad = 0) / conv2d_dgrad (1) of this geometry runs Winograd
+ *   mmdgan_wino_weight_bytes(g)           size of the transformed tensor (16 * C * K floats)
+ *   mmdgan_wino_transform(g, w, dgrad, u) u = G w G^T per (c,k), laid out for the forward (dgrad = 0) or the
+ *                                         input-gradient (1: taps flipped, channel roles swapped)
+ * and pass u as `w` with MMDGAN_ACT_FLAG_W_WINOGRAD. */
+int mmdgan_wino_eligible(const mmdgan_conv_geom *g, int dgrad);
+size_t mmdgan_wino_weight_bytes(const mmdgan_conv_geom *g);
+int mmdgan_wino_transform(const mmdgan_conv_geom *g, const float *w, int dgrad, float *u, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense (tf.matmul, layer_func.py:909-911).  Row-major.  trans flags as in BLAS:

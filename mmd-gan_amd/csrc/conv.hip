@@ -50,14 +50,18 @@ extern "C" int mmdgan_conv2d_fwd(const mmdgan_conv_geom *g, const float *x, cons
                                  void *stream) {
     if (int rc = validate(g, "conv2d_fwd")) return rc;
     MMDGAN_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
-    const bool out_zeroed = (act & MMDGAN_ACT_FLAG_OUT_ZEROED) != 0;
-    act &= ~MMDGAN_ACT_FLAG_OUT_ZEROED;
+    const bool out_zeroed = (act & MMDGAN_ACT_FLAG_OUT_ZEROED) != 0, w_wino = (act & MMDGAN_ACT_FLAG_W_WINOGRAD) != 0;
+    act &= ~(MMDGAN_ACT_FLAG_OUT_ZEROED | MMDGAN_ACT_FLAG_W_WINOGRAD);
     MMDGAN_REQUIRE(act >= MMDGAN_ACT_LINEAR && act <= MMDGAN_ACT_TANH, "conv2d_fwd: unknown activation %d", act);
     const ConvDims d = conv_dims(*g);
     long wf, ws;
     if (int rc = make_wrap(d.N, dact_of ? dact_batch : 0, (long)d.P * d.Q * d.K, "conv2d_fwd", &wf, &ws)) return rc;
     const ConvEpilogue ep{bias, scale, dact_of, act, wf, ws, out_zeroed};
-    if (!force_direct() && wino_fwd_ok(d)) return wino_fwd(d, ep, x, w, y, (hipStream_t)stream);
+    if (w_wino) {
+        MMDGAN_REQUIRE(wino_eligible(d, false), "conv2d_fwd: MMDGAN_ACT_FLAG_W_WINOGRAD on a geometry mmdgan_wino_eligible() rejects");
+        return wino_fwd(d, ep, x, nullptr, w, y, (hipStream_t)stream);
+    }
+    if (!force_direct() && wino_fwd_ok(d)) return wino_fwd(d, ep, x, w, nullptr, y, (hipStream_t)stream);
     if (!force_direct() && igemm_fwd_ok(d)) return igemm_fwd(d, ep, x, w, y, (hipStream_t)stream);
     if (!force_direct() && !force_valu_thin() && (thinm_fwd_n2w_ok(d) || thinm_fwd_w2n_ok(d)) && al16(x) && al16(y) &&
         al16(bias) && al16(dact_of))
@@ -71,14 +75,18 @@ extern "C" int mmdgan_conv2d_dgrad(const mmdgan_conv_geom *g, const float *dy, c
                                    void *stream) {
     if (int rc = validate(g, "conv2d_dgrad")) return rc;
     MMDGAN_REQUIRE(dy && w && dx, "conv2d_dgrad: null pointer");
-    const bool out_zeroed = (act & MMDGAN_ACT_FLAG_OUT_ZEROED) != 0;
-    act &= ~MMDGAN_ACT_FLAG_OUT_ZEROED;
+    const bool out_zeroed = (act & MMDGAN_ACT_FLAG_OUT_ZEROED) != 0, w_wino = (act & MMDGAN_ACT_FLAG_W_WINOGRAD) != 0;
+    act &= ~(MMDGAN_ACT_FLAG_OUT_ZEROED | MMDGAN_ACT_FLAG_W_WINOGRAD);
     MMDGAN_REQUIRE(act >= MMDGAN_ACT_LINEAR && act <= MMDGAN_ACT_TANH, "conv2d_dgrad: unknown activation %d", act);
     const ConvDims d = conv_dims(*g);
     long wf, ws;
     if (int rc = make_wrap(d.N, dact_of ? dact_batch : 0, (long)d.H * d.W * d.C, "conv2d_dgrad", &wf, &ws)) return rc;
     const ConvEpilogue ep{bias, scale, dact_of, act, wf, ws, out_zeroed};
-    if (!force_direct() && wino_dgrad_ok(d)) return wino_dgrad(d, ep, dy, w, dx, (hipStream_t)stream);
+    if (w_wino) {
+        MMDGAN_REQUIRE(wino_eligible(d, true), "conv2d_dgrad: MMDGAN_ACT_FLAG_W_WINOGRAD on a geometry mmdgan_wino_eligible() rejects");
+        return wino_dgrad(d, ep, dy, nullptr, w, dx, (hipStream_t)stream);
+    }
+    if (!force_direct() && wino_dgrad_ok(d)) return wino_dgrad(d, ep, dy, w, nullptr, dx, (hipStream_t)stream);
     if (!force_direct() && igemm_dgrad_ok(d)) return igemm_dgrad(d, ep, dy, w, dx, (hipStream_t)stream);
     if (!force_direct() && !force_valu_thin() && (thinm_dgrad_n2w_ok(d) || thinm_dgrad_w2n_ok(d)) && al16(dy) && al16(dx) &&
         al16(bias) && al16(dact_of))
@@ -86,6 +94,22 @@ extern "C" int mmdgan_conv2d_dgrad(const mmdgan_conv_geom *g, const float *dy, c
     if (!force_direct() && (thin_dgrad_in_ok(d) || thin_dgrad_out_ok(d)))
         return thin_dgrad(d, ep, dy, w, dx, (hipStream_t)stream);
     return direct_dgrad(d, ep, dy, w, dx, (hipStream_t)stream);
+}
+
+extern "C" int mmdgan_wino_eligible(const mmdgan_conv_geom *g, int dgrad) {
+    if (!g || g->N < 1 || g->H < 1 || g->W < 1 || g->C < 1 || g->K < 1 || g->R < 1 || g->stride < 1) return 0;
+    return !force_direct() && wino_eligible(conv_dims(*g), dgrad != 0) ? 1 : 0;
+}
+
+extern "C" size_t mmdgan_wino_weight_bytes(const mmdgan_conv_geom *g) {
+    return g ? sizeof(float) * 16 * (size_t)g->C * g->K : 0;
+}
+
+extern "C" int mmdgan_wino_transform(const mmdgan_conv_geom *g, const float *w, int dgrad, float *u, void *stream) {
+    if (int rc = validate(g, "wino_transform")) return rc;
+    MMDGAN_REQUIRE(w && u, "wino_transform: null pointer");
+    MMDGAN_REQUIRE(g->R == 3, "wino_transform: 3x3 kernels only (got %d)", g->R);
+    return wino_transform(conv_dims(*g), w, dgrad != 0, u, (hipStream_t)stream);
 }
 
 extern "C" int mmdgan_conv2d_wgrad(const mmdgan_conv_geom *g, const float *x, const float *dy, float *dw, void *stream) {

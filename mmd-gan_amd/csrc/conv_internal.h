@@ -51,8 +51,11 @@ int thinm_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, h
 // Winograd F(2x2,3x3) for 3x3 / stride-1 layers (conv_wino.hip); needs the library workspace for G g G^T
 bool wino_fwd_ok(const ConvDims &d);
 bool wino_dgrad_ok(const ConvDims &d);
-int wino_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, float *y, hipStream_t st);
-int wino_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, float *dx, hipStream_t st);
+bool wino_eligible(const ConvDims &d, bool dgrad);
+int wino_transform(const ConvDims &d, const float *w, bool flip, float *U, hipStream_t st);
+// U = weights already transformed by wino_transform, or nullptr (then w is transformed into the workspace)
+int wino_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, const float *U, float *y, hipStream_t st);
+int wino_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, const float *U, float *dx, hipStream_t st);
 
 // MFMA implicit-GEMM path (conv_igemm.hip); *_ok() say whether a geometry is eligible
 bool igemm_fwd_ok(const ConvDims &d);

@@ -288,32 +288,42 @@ static long wino_min_tiles() {
     return v;
 }
 
-static bool wino_geom_ok(const ConvDims &d, int cr, int ko) {
+static bool wino_shape_ok(const ConvDims &d, int cr, int ko) {
     return wino_enabled() && d.R == 3 && d.stride == 1 && d.pad == 1 && d.H % 2 == 0 && d.W % 2 == 0 && cr % wino::BC == 0 &&
-           cr >= 32 && ko % 64 == 0 && (long)d.N * (d.H / 2) * (d.W / 2) >= wino_min_tiles() &&
-           workspace(sizeof(float) * 16 * (size_t)cr * ko) != nullptr;
+           cr >= 32 && ko % 64 == 0 && (long)d.N * (d.H / 2) * (d.W / 2) >= wino_min_tiles();
 }
-bool wino_fwd_ok(const ConvDims &d) { return wino_geom_ok(d, d.C, d.K); }
-bool wino_dgrad_ok(const ConvDims &d) { return wino_geom_ok(d, d.K, d.C); }
+// would the library run this geometry through Winograd (given transformed weights or a workspace for them)?
+bool wino_eligible(const ConvDims &d, bool dgrad) { return dgrad ? wino_shape_ok(d, d.K, d.C) : wino_shape_ok(d, d.C, d.K); }
+bool wino_fwd_ok(const ConvDims &d) { return wino_shape_ok(d, d.C, d.K) && workspace(sizeof(float) * 16 * (size_t)d.C * d.K) != nullptr; }
+bool wino_dgrad_ok(const ConvDims &d) { return wino_shape_ok(d, d.K, d.C) && workspace(sizeof(float) * 16 * (size_t)d.C * d.K) != nullptr; }
 
-static int wino_launch(const ConvDims &d, const ConvEpilogue &ep, const float *in, const float *w, float *out, bool flip,
-                       hipStream_t st) {
-    const int cr = flip ? d.K : d.C, ko = flip ? d.C : d.K;
-    float *U = (float *)workspace(sizeof(float) * 16 * (size_t)cr * ko);
+int wino_transform(const ConvDims &d, const float *w, bool flip, float *U, hipStream_t st) {
     const dim3 wg((d.K + 31) / 32, (d.C + 31) / 32);
     if (flip) hipLaunchKernelGGL(wino_weight_kernel<true>, wg, dim3(256), 0, st, w, U, d.C, d.K);
     else hipLaunchKernelGGL(wino_weight_kernel<false>, wg, dim3(256), 0, st, w, U, d.C, d.K);
+    return check_launch("wino_transform");
+}
+
+// U == nullptr: transform w into the library workspace first
+static int wino_launch(const ConvDims &d, const ConvEpilogue &ep, const float *in, const float *w, const float *U, float *out,
+                       bool flip, hipStream_t st) {
+    const int cr = flip ? d.K : d.C, ko = flip ? d.C : d.K;
+    if (!U) {
+        float *ws = (float *)workspace(sizeof(float) * 16 * (size_t)cr * ko);
+        if (int rc = wino_transform(d, w, flip, ws, st)) return rc;
+        U = ws;
+    }
     const long T = (long)d.N * (d.H / 2) * (d.W / 2);
     const dim3 grid((unsigned)((T + 31) / 32), ko / 64);
     hipLaunchKernelGGL((wino_kernel<64>), grid, dim3(256), (wino::Cfg<64>::LDS_BYTES), st, d.N, d.H, d.W, cr, ko, ep, in, U, out);
     return check_launch(flip ? "conv2d_dgrad(winograd)" : "conv2d_fwd(winograd)");
 }
 
-int wino_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, float *y, hipStream_t st) {
-    return wino_launch(d, ep, x, w, y, false, st);
+int wino_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, const float *U, float *y, hipStream_t st) {
+    return wino_launch(d, ep, x, w, U, y, false, st);
 }
-int wino_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, float *dx, hipStream_t st) {
-    return wino_launch(d, ep, dy, w, dx, true, st);
+int wino_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, const float *U, float *dx, hipStream_t st) {
+    return wino_launch(d, ep, dy, w, U, dx, true, st);
 }
 
 }  // namespace mmdgan

@@ -395,6 +395,20 @@ class GanEngine:
             for s in net.specs:          # dense outputs whose K is long enough for the split-K gemm path
                 if s.op == 'd' and s.kernel_shape[0] >= 512:
                     self._zero_each_step.append(self.buf[s.scope + ('#raw' if s.bn else '#y')])
+        # 3x3 / stride-1 D layers that the library runs through Winograd: their weights change once per step, so
+        # G w G^T is computed once per step on the parameter-gradient stream (idle during the forward pass)
+        # instead of inside every conv call.  scope -> [forward tensor or None, input-gradient tensor or None]
+        self._wino = {}
+        if self._side_wgrad:
+            for s in self.dis.specs:
+                if s.op != 'c':
+                    continue
+                c, h, w = s.in_shape_ref
+                fw = ops.wino_eligible(2 * B, h, w, c, s.out, s.R, s.stride, False)
+                bw = ops.wino_eligible(3 * B, h, w, c, s.out, s.R, s.stride, True)
+                if fw or bw:
+                    self._wino[s.scope] = [torch.empty(16, c, s.out, device=dev) if fw else None,
+                                           torch.empty(16, s.out, c, device=dev) if bw else None]
         gs = self.gen.specs
         for below, above in zip(gs, gs[1:]):     # input-gradient of a tc layer into a linear layer: split-K target
             if above.op == 'tc' and (below.bn or below.act == 'linear'):
@@ -457,7 +471,8 @@ class GanEngine:
         if s.op == 'd':
             ops.gemm(x.reshape(n, -1), w, bias=bias, scale=scale, act=fused_act, out=tgt.view(n, -1))
         elif s.op == 'c':
-            ops.conv2d_fwd(x, w, s.stride, bias=bias, scale=scale, act=fused_act, out=tgt)
+            wino = self._wino.get(s.scope, (None, None))[0] if net is self.dis and n == 2 * self.B else None
+            ops.conv2d_fwd(x, w, s.stride, bias=bias, scale=scale, act=fused_act, out=tgt, wino=wino)
         else:
             ops.conv2d_dgrad(x, w, (tgt.shape[1], tgt.shape[2]), s.stride, bias=bias, scale=scale, act=fused_act, out=tgt)
         if s.bn:
@@ -503,6 +518,8 @@ class GanEngine:
         self.generate(z, is_training=True)                                   # writes dis_in[B:]
         for st in self._sn_streams:
             main.wait_stream(st)
+        if self._wino:
+            main.wait_stream(self._wg_stream)                                # transformed weights of this step
         x = b['dis_in']
         for s in self.dis.specs:
             scale = self._scales[s.scope]
@@ -563,7 +580,8 @@ class GanEngine:
                              dact_of=yprev.view(2 * B, -1), dact_rows=2 * B, out=dprev.view(3 * B, -1))
                 else:
                     ops.conv2d_dgrad(dz, w, (yprev.shape[1], yprev.shape[2]), s.stride, scale=scale, act=prev.act,
-                                     dact_of=yprev, dact_batch=2 * B, out=dprev)
+                                     dact_of=yprev, dact_batch=2 * B, out=dprev,
+                                     wino=self._wino.get(s.scope, (None, None))[1])
                 dz = dprev
             else:
                 # below D l1 sits G's output: only the loss_gen rows go further, with G's last
@@ -678,6 +696,12 @@ class GanEngine:
                 with torch.cuda.stream(self._wg_stream):
                     for t in arenas:
                         t.zero_()
+                    for scope, (uf, ub) in self._wino.items():
+                        w = self.dis.p(scope + '/kernel/kernel')
+                        if uf is not None:
+                            ops.wino_transform(w, False, out=uf)
+                        if ub is not None:
+                            ops.wino_transform(w, True, out=ub)
             for t in self._zero_each_step:
                 if not any(t is a for a in arenas):
                     t.zero_()

@@ -68,8 +68,9 @@ def out_hw(H, W, stride):
 
 # ------------------------------------------------------------------------------------------------
 def conv2d_fwd(x, w, stride, bias=None, scale=None, act='linear', dact_of=None, out=None, dact_batch=0,
-               out_zeroed=False):
-    """x [N,H,W,C], w [R,R,C,K] -> y [N,P,Q,K] = act(scale*conv(x,w)+bias) (layer_func.py:913-916)"""
+               out_zeroed=False, wino=None):
+    """x [N,H,W,C], w [R,R,C,K] -> y [N,P,Q,K] = act(scale*conv(x,w)+bias) (layer_func.py:913-916)
+    wino: the tensor wino_transform(w, ...) made from w (the library then skips its own transform)"""
     lib = require_device()
     N, H, W, C = x.shape
     R, K = w.shape[0], w.shape[3]
@@ -77,13 +78,15 @@ def conv2d_fwd(x, w, stride, bias=None, scale=None, act='linear', dact_of=None, 
     P, Q = out_hw(H, W, stride)
     y = out if out is not None else torch.empty((N, P, Q, K), device=x.device, dtype=torch.float32)
     g = geom(N, H, W, C, K, R, stride)
-    check(lib.mmdgan_conv2d_fwd(ctypes.byref(g), _p(x), _p(w), _p(bias), _p(scale),
-                                act_id(act) | (0x100 if out_zeroed else 0), _p(dact_of), int(dact_batch),
+    check(lib.mmdgan_conv2d_fwd(ctypes.byref(g), _p(x), _p(w if wino is None else wino), _p(bias), _p(scale),
+                                act_id(act) | (0x100 if out_zeroed else 0) | (0 if wino is None else 0x200),
+                                _p(dact_of), int(dact_batch),
                                 _p(y), _stream()), 'conv2d_fwd')
     return y
 
 
-def conv2d_dgrad(dy, w, in_hw, stride, bias=None, scale=None, act='linear', dact_of=None, out=None, dact_batch=0):
+def conv2d_dgrad(dy, w, in_hw, stride, bias=None, scale=None, act='linear', dact_of=None, out=None, dact_batch=0,
+                 wino=None):
     """dy [N,P,Q,K], w [R,R,C,K] -> dx [N,H,W,C]; forward form = tf.nn.conv2d_transpose (layer_func.py:926)"""
     lib = require_device()
     N, P, Q, K = dy.shape
@@ -93,9 +96,26 @@ def conv2d_dgrad(dy, w, in_hw, stride, bias=None, scale=None, act='linear', dact
     assert out_hw(H, W, stride) == (P, Q)
     dx = out if out is not None else torch.empty((N, H, W, C), device=dy.device, dtype=torch.float32)
     g = geom(N, H, W, C, K, R, stride)
-    check(lib.mmdgan_conv2d_dgrad(ctypes.byref(g), _p(dy), _p(w), _p(bias), _p(scale), act_id(act), _p(dact_of),
+    check(lib.mmdgan_conv2d_dgrad(ctypes.byref(g), _p(dy), _p(w if wino is None else wino), _p(bias), _p(scale),
+                                  act_id(act) | (0 if wino is None else 0x200), _p(dact_of),
                                   int(dact_batch), _p(dx), _stream()), 'conv2d_dgrad')
     return dx
+
+
+def wino_eligible(N, H, W, C, K, R, stride, dgrad):
+    """does conv2d_fwd (dgrad=False) / conv2d_dgrad (True) of this geometry run Winograd F(2x2,3x3)?"""
+    g = geom(N, H, W, C, K, R, stride)
+    return bool(require_device().mmdgan_wino_eligible(ctypes.byref(g), int(dgrad)))
+
+
+def wino_transform(w, dgrad, out=None):
+    """w [3,3,C,K] -> [16,C,K] (forward) or [16,K,C] (input-gradient) transformed weights"""
+    lib = require_device()
+    R, _, C, K = w.shape
+    u = out if out is not None else torch.empty((16, K, C) if dgrad else (16, C, K), device=w.device, dtype=torch.float32)
+    g = geom(1, 2, 2, C, K, R, 1)
+    check(lib.mmdgan_wino_transform(ctypes.byref(g), _p(w), int(dgrad), _p(u), _stream()), 'wino_transform')
+    return u
 
 
 def conv2d_wgrad(x, dy, R, stride, out=None):

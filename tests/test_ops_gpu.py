@@ -206,7 +206,7 @@ def test_conv2d_dgrad_and_wgrad(ops, case):
 
 
 WINO_CASES = [(16, 16, 16, 128, 128, 3, 1), (32, 8, 8, 64, 128, 3, 1), (9, 12, 12, 32, 64, 3, 1), (130, 4, 4, 64, 64, 3, 1),
-              (5, 14, 18, 36, 192, 3, 1)]
+              (5, 14, 18, 40, 192, 3, 1), (9, 10, 12, 64, 64, 3, 1)]
 
 
 @pytest.mark.parametrize('case', WINO_CASES, ids=[str(c) for c in WINO_CASES])
@@ -239,6 +239,21 @@ def test_conv2d_winograd_path(ops, case):
             assert rel_err(to_nchw(dx2), 0.5 * gx.numpy() * mask) <= RTOL
     finally:
         ops.require_device().mmdgan_set_workspace(None, 0)
+    # caller-side transform (no workspace): mmdgan_wino_transform + MMDGAN_ACT_FLAG_W_WINOGRAD
+    assert ops.wino_eligible(N, H, W, C, K, ksz, s, False)                  # every case here is, in the forward direction
+    uf, ub = ops.wino_transform(dev(w), False), ops.wino_transform(dev(w), True)
+    assert uf.shape == (16, C, K) and ub.shape == (16, K, C)
+    y = ops.conv2d_fwd(nhwc(x), dev(w), s, wino=uf)
+    assert rel_err(to_nchw(y), yt.detach().numpy()) <= RTOL
+    if ops.wino_eligible(N, H, W, C, K, ksz, s, True):                      # needs C % 64 == 0
+        dx = ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s, wino=ub)
+        assert rel_err(to_nchw(dx), gx.numpy()) <= RTOL
+    else:
+        with pytest.raises(ValueError, match='WINOGRAD'):
+            ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s, wino=ub)
+    assert not ops.wino_eligible(N, H, W, C, K, 4, 2, False)
+    with pytest.raises(ValueError, match='WINOGRAD'):
+        ops.conv2d_fwd(nhwc(x)[:, :, :, :], dev(np.zeros((4, 4, C, K), np.float32)), 2, wino=uf)
 
 
 @pytest.mark.parametrize('case', [(4, 4, 4, 512, 256, 4, 2), (3, 8, 8, 256, 128, 4, 2), (2, 16, 16, 128, 64, 4, 2),
