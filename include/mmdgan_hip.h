@@ -108,6 +108,10 @@ int mmdgan_conv2d_dgrad(const mmdgan_conv_geom *g, const float *dy, const float 
 /* dw[R,R,C,K] = sum over pixels x (x) dy                   autodiff of conv2d / conv2d_transpose
  * dw is overwritten. */
 int mmdgan_conv2d_wgrad(const mmdgan_conv_geom *g, const float *x, const float *dy, float *dw, void *stream);
+/* the same plus dbias[K] = column sums of dy (tf.nn.bias_add's gradient, layer_func.py:946): the MFMA kernel adds up
+ * the dy tiles it streams anyway instead of a second pass over dy.  dbias is overwritten. */
+int mmdgan_conv2d_wgrad_bias(const mmdgan_conv_geom *g, const float *x, const float *dy, float *dw, float *dbias,
+                             void *stream);
 
 /* Winograd F(2x2,3x3) for 3x3 / stride-1 layers (same tf.nn.conv2d / autodiff call sites as above; csrc/conv_wino.hip).
  * conv2d_fwd / conv2d_dgrad use it on their own when the geometry is eligible and a workspace is registered for

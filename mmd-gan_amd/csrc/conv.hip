@@ -112,15 +112,28 @@ extern "C" int mmdgan_wino_transform(const mmdgan_conv_geom *g, const float *w, 
     return wino_transform(conv_dims(*g), w, dgrad != 0, u, (hipStream_t)stream);
 }
 
-extern "C" int mmdgan_conv2d_wgrad(const mmdgan_conv_geom *g, const float *x, const float *dy, float *dw, void *stream) {
-    if (int rc = validate(g, "conv2d_wgrad")) return rc;
-    MMDGAN_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
+static int wgrad_impl(const mmdgan_conv_geom *g, const float *x, const float *dy, float *dw, float *dbias, void *stream,
+                      const char *what) {
+    if (int rc = validate(g, what)) return rc;
+    MMDGAN_REQUIRE(x && dy && dw, "%s: null pointer", what);
     const ConvDims d = conv_dims(*g);
-    if (!force_direct() && igemm_wgrad_ok(d)) return igemm_wgrad(d, x, dy, dw, (hipStream_t)stream);
-    if (!force_direct() && !force_valu_thin() && thinm_wgrad_ok(d)) {
-        const int rc = thinm_wgrad(d, x, dy, dw, (hipStream_t)stream);
-        if (rc <= 0) return rc;                                    // 1: no workspace registered -> VALU kernel below
+    if (!force_direct() && igemm_wgrad_ok(d)) return igemm_wgrad(d, x, dy, dw, dbias, (hipStream_t)stream);   // sums dy on the way
+    int rc = 1;
+    if (!force_direct() && !force_valu_thin() && thinm_wgrad_ok(d)) rc = thinm_wgrad(d, x, dy, dw, (hipStream_t)stream);
+    if (rc > 0) {                                                  // 1: no workspace registered -> VALU kernel
+        if (!force_direct() && thin_wgrad_ok(d)) rc = thin_wgrad(d, x, dy, dw, (hipStream_t)stream);
+        else rc = direct_wgrad(d, x, dy, dw, (hipStream_t)stream);
     }
-    if (!force_direct() && thin_wgrad_ok(d)) return thin_wgrad(d, x, dy, dw, (hipStream_t)stream);
-    return direct_wgrad(d, x, dy, dw, (hipStream_t)stream);
+    if (rc == 0 && dbias) rc = mmdgan_colsum(dy, (long)d.N * d.P * d.Q, d.K, dbias, stream);
+    return rc;
+}
+
+extern "C" int mmdgan_conv2d_wgrad(const mmdgan_conv_geom *g, const float *x, const float *dy, float *dw, void *stream) {
+    return wgrad_impl(g, x, dy, dw, nullptr, stream, "conv2d_wgrad");
+}
+
+extern "C" int mmdgan_conv2d_wgrad_bias(const mmdgan_conv_geom *g, const float *x, const float *dy, float *dw, float *dbias,
+                                        void *stream) {
+    MMDGAN_REQUIRE(dbias, "conv2d_wgrad_bias: null pointer");
+    return wgrad_impl(g, x, dy, dw, dbias, stream, "conv2d_wgrad_bias");
 }

@@ -530,7 +530,12 @@ struct WgradProblem {
     unsigned noff[T::A_F4], boff[T::B_F4];
     int dhq, qwrap, qlim, dhp, prow, pwrap, plim;
     unsigned wlim, hlim, HWC4, dnoff, stageK4;
-    __device__ void init(const ConvDims &d, const float *x_, const float *dy_, int i0, int n0, int s0) {
+    // bias gradient = column sums of dy: the row-tile-0 workgroups add up the dy tiles they stream anyway
+    bool want_bsum;
+    int bsum_stages;                  // stages still to count (the two prefetched past the split are not this block's)
+    float4 bsum;
+    __device__ void init(const ConvDims &d, const float *x_, const float *dy_, int i0, int n0, int s0, int s1, bool sum_dy) {
+        want_bsum = sum_dy; bsum_stages = (s1 - s0) * T::B_F4; bsum = make_float4(0.f, 0.f, 0.f, 0.f);
         rx = make_rsrc(x_, (long)d.N * d.H * d.W * d.C * 4);
         rdy = make_rsrc(dy_, (long)d.N * d.P * d.Q * d.K * 4);
         const int tap = i0 / d.C, c0 = i0 - tap * d.C;
@@ -579,6 +584,10 @@ struct WgradProblem {
     __device__ __forceinline__ float4 load_b1(int, int i) {
         const float4 v = bufld4(rdy, boff[i]);
         boff[i] += stageK4;
+        if (want_bsum) {                               // wave-uniform
+            if (bsum_stages > 0) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }
+            --bsum_stages;
+        }
         return v;
     }
 };
@@ -586,7 +595,7 @@ struct WgradProblem {
 template <int BM, int BN, bool SPLIT, int KG = 1>
 __global__ __launch_bounds__(256 * KG) void igemm_wgrad_kernel(ConvDims d, const float *__restrict__ x,
                                                           const float *__restrict__ dy, float *__restrict__ dw,
-                                                          int stages_per_split) {
+                                                          int stages_per_split, float *__restrict__ dbias) {
     using T = TileCfg<BM, BN>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const long M = (long)d.N * d.P * d.Q;
@@ -602,8 +611,21 @@ __global__ __launch_bounds__(256 * KG) void igemm_wgrad_kernel(ConvDims d, const
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
     WgradProblem<BM, BN, KG> p;
-    p.init(d, x, dy, i0, n0, s0);
+    const bool sum_dy = dbias != nullptr && blockIdx.x == 0;
+    p.init(d, x, dy, i0, n0, s0, s1, sum_dy);
     mainloop<BM, BN, KG>(p, s0, s1, smem, acc);
+    if (sum_dy) {                                      // threads tid % (BN/4) share a channel quad: combine through LDS
+        constexpr int NTH = 256 * KG, Q = BN / 4;
+        *reinterpret_cast<float4 *>(smem + threadIdx.x * 4) = p.bsum;
+        __syncthreads();
+        if (threadIdx.x < BN) {
+            const int c4 = threadIdx.x >> 2, e = threadIdx.x & 3;
+            float t = 0.f;
+            for (int g = 0; g < NTH / Q; ++g) t += smem[(g * Q + c4) * 4 + e];
+            atomicAdd(dbias + n0 + threadIdx.x, t);
+        }
+        __syncthreads();
+    }
     const int Kc = d.K;
     auto rowoff = [=](int row) -> long { return (long)(i0 + row) * Kc + n0; };
     const ConvEpilogue none{nullptr, nullptr, nullptr, MMDGAN_ACT_LINEAR, kNoWrap, 0, false};
@@ -718,7 +740,7 @@ int igemm_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, cons
     return check_launch("conv2d_dgrad(igemm)");
 }
 
-int igemm_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st) {
+int igemm_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, float *dbias, hipStream_t st) {
     raise_lds_caps();
     const long M = (long)d.N * d.P * d.Q;
     const int rows = d.R * d.R * d.C;
@@ -747,14 +769,15 @@ int igemm_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, h
     split = (nstages + sps - 1) / sps;
     if (split > 1 && zero_output(dw, sizeof(float) * (long)rows * d.K, st) != hipSuccess)
         return check_launch("conv2d_wgrad memset");
+    if (dbias && zero_output(dbias, sizeof(float) * d.K, st) != hipSuccess) return check_launch("conv2d_wgrad memset");
     const dim3 grid(rows / bm, d.K / bn, split);
-    if (bm == 128) { if (split > 1) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, true>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, x, dy, dw, sps); else hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, false>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, x, dy, dw, sps); }
+    if (bm == 128) { if (split > 1) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, true>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, x, dy, dw, sps, dbias); else hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, false>), grid, dim3(256), (smem_bytes<128, 128>()), st, d, x, dy, dw, sps, dbias); }
     else if ((long)grid.x * grid.y * grid.z < kTargetBlocks) {
         // a single 64x64 workgroup per CU: use the 8-wave K-group variant (2 waves per SIMD)
-        if (split > 1) hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, true, 2>), grid, dim3(512), (smem_bytes<64, 64>()), st, d, x, dy, dw, sps);
-        else hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, false, 2>), grid, dim3(512), (smem_bytes<64, 64>()), st, d, x, dy, dw, sps);
+        if (split > 1) hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, true, 2>), grid, dim3(512), (smem_bytes<64, 64>()), st, d, x, dy, dw, sps, dbias);
+        else hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, false, 2>), grid, dim3(512), (smem_bytes<64, 64>()), st, d, x, dy, dw, sps, dbias);
     }
-    else { if (split > 1) hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, true>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, x, dy, dw, sps); else hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, false>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, x, dy, dw, sps); }
+    else { if (split > 1) hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, true>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, x, dy, dw, sps, dbias); else hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, false>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, x, dy, dw, sps, dbias); }
     return check_launch("conv2d_wgrad(igemm)");
 }
 

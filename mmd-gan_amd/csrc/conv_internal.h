@@ -63,6 +63,6 @@ bool igemm_dgrad_ok(const ConvDims &d);
 bool igemm_wgrad_ok(const ConvDims &d);
 int igemm_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, float *y, hipStream_t st);
 int igemm_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, float *dx, hipStream_t st);
-int igemm_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st);
+int igemm_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, float *dbias, hipStream_t st);   // dbias: optional column sums of dy
 
 }  // namespace mmdgan

@@ -25,6 +25,7 @@ SIGNATURES = {
     'mmdgan_conv2d_fwd': (_I, [_G, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     'mmdgan_conv2d_dgrad': (_I, [_G, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     'mmdgan_conv2d_wgrad': (_I, [_G, _P, _P, _P, _P]),
+    'mmdgan_conv2d_wgrad_bias': (_I, [_G, _P, _P, _P, _P, _P]),
     'mmdgan_wino_eligible': (_I, [_G, _I]),
     'mmdgan_wino_weight_bytes': (ctypes.c_size_t, [_G]),
     'mmdgan_wino_transform': (_I, [_G, _P, _I, _P, _P]),

@@ -560,12 +560,13 @@ class GanEngine:
             dz_main = dz[:2 * B]
 
             def param_grads(s=s, x_in=x_in, w=w, gw=gw, scale=scale, dz_main=dz_main):
-                if s.has_bias:
-                    ops.colsum(dz_main.reshape(-1, dz_main.shape[-1]), out=net.g(s.scope + '/bias/bias'))
+                gb = net.g(s.scope + '/bias/bias') if s.has_bias else None
                 if s.op == 'd':
+                    if gb is not None:
+                        ops.colsum(dz_main.reshape(-1, dz_main.shape[-1]), out=gb)
                     ops.gemm(x_in.reshape(2 * B, -1), dz_main.reshape(2 * B, -1), trans_a=True, out=gw)
-                else:
-                    ops.conv2d_wgrad(x_in, dz_main, s.R, s.stride, out=gw)
+                else:                                                        # bias gradient rides on the wgrad launch
+                    ops.conv2d_wgrad(x_in, dz_main, s.R, s.stride, out=gw, dbias=gb)
                 if s.sn:                                                     # SURVEY A.2 fix-up
                     dot = net.state[s.scope + '#dot']
                     ops.dot(gw.view(-1), w.view(-1), out=dot)
@@ -638,12 +639,13 @@ class GanEngine:
             dz = dz.view(_native_shape(s.op_out_ref, B))
 
             def param_grads(s=s, x_in=x_in, gw=gw, dz=dz):
-                if s.has_bias:
-                    ops.colsum(dz.view(-1, dz.shape[-1]), out=net.g(s.scope + '/bias/bias'))
+                gb = net.g(s.scope + '/bias/bias') if s.has_bias else None
+                if gb is not None and s.op != 'c':
+                    ops.colsum(dz.view(-1, dz.shape[-1]), out=gb)
                 if s.op == 'd':
                     ops.gemm(x_in, dz, trans_a=True, out=gw)
                 elif s.op == 'c':
-                    ops.conv2d_wgrad(x_in, dz, s.R, s.stride, out=gw)
+                    ops.conv2d_wgrad(x_in, dz, s.R, s.stride, out=gw, dbias=gb)
                 else:                                                        # tc: W[R,R,Cout,Cin]; y = dgrad(v, W)
                     ops.conv2d_wgrad(dz, x_in, s.R, s.stride, out=gw)
             self._on_wg_stream(param_grads, s)

@@ -118,14 +118,18 @@ def wino_transform(w, dgrad, out=None):
     return u
 
 
-def conv2d_wgrad(x, dy, R, stride, out=None):
-    """x [N,H,W,C], dy [N,P,Q,K] -> dw [R,R,C,K]"""
+def conv2d_wgrad(x, dy, R, stride, out=None, dbias=None):
+    """x [N,H,W,C], dy [N,P,Q,K] -> dw [R,R,C,K]; dbias [K] (optional) receives the column sums of dy"""
     lib = require_device()
     N, H, W, C = x.shape
     K = dy.shape[3]
     dw = out if out is not None else torch.empty((R, R, C, K), device=x.device, dtype=torch.float32)
     g = geom(N, H, W, C, K, R, stride)
-    check(lib.mmdgan_conv2d_wgrad(ctypes.byref(g), _p(x), _p(dy), _p(dw), _stream()), 'conv2d_wgrad')
+    if dbias is None:
+        check(lib.mmdgan_conv2d_wgrad(ctypes.byref(g), _p(x), _p(dy), _p(dw), _stream()), 'conv2d_wgrad')
+    else:
+        check(lib.mmdgan_conv2d_wgrad_bias(ctypes.byref(g), _p(x), _p(dy), _p(dw), _p(dbias), _stream()),
+              'conv2d_wgrad_bias')
     return dw
 
 

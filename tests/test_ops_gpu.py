@@ -191,6 +191,10 @@ def test_conv2d_dgrad_and_wgrad(ops, case):
     assert rel_err(to_nchw(dx), gx.numpy()) <= RTOL
     dw = ops.conv2d_wgrad(nhwc(x), nhwc(dy), ksz, s)
     assert rel_err(dw.cpu().numpy(), gw.numpy()) <= RTOL
+    db = torch.full((K,), 7.0, device='cuda')                      # conv2d_wgrad_bias: + column sums of dy, overwritten
+    dw = ops.conv2d_wgrad(nhwc(x), nhwc(dy), ksz, s, dbias=db)
+    assert rel_err(dw.cpu().numpy(), gw.numpy()) <= RTOL
+    assert rel_err(db.cpu().numpy(), dy.astype(np.float64).sum((0, 2, 3))) <= RTOL
     # with a registered library workspace the thin layers take the partial-sum (MFMA) kernels
     ops.set_workspace()
     try:
