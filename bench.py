@@ -37,6 +37,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: 64; 128 for celeba)')
     ap.add_argument('--loss', default='rep', choices=['rep', 'rmb'])
     ap.add_argument('--no-graph', action='store_true', help='issue launches eagerly instead of one hipGraph')
+    ap.add_argument('--graph', action='store_true', help='always replay the captured hipGraph (default: try both during '
+                    'warm-up and keep the faster one - eager issue wins when the host keeps up, the graph when it does not)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--probe-only', action='store_true',
@@ -116,8 +118,9 @@ def main():
     from mmdgan_hip.engine import GanEngine
     arch, lr = configs.CONFIGS[args.config]()
     B = args.batch or (128 if args.config == 'celeba' else 64)
-    eng = GanEngine(arch, args.loss, lr, batch_size=B, seed=0, dist_group=group,
-                    use_graph=not args.no_graph)
+    # the engine starts in eager mode (its lazily-created buffers are then allocated on the stream that uses
+    # them); the hipGraph, if wanted, is captured after the warm-up steps
+    eng = GanEngine(arch, args.loss, lr, batch_size=B, seed=0, dist_group=group, use_graph=False)
     if world > 1:
         from mmdgan_hip import dist as mdist
         mdist.broadcast_state(eng, group)                # identical weights / SN vectors on every replica
@@ -143,6 +146,26 @@ def main():
     for _ in range(args.warmup):
         eng.step(real)
     barrier()
+    mode = 'eager' if (args.no_graph or world > 1) else 'graph'
+    eng.use_graph = mode == 'graph'
+    if world == 1 and not args.no_graph and not args.graph:
+        # untimed: a few steps each way, keep the faster launch mode
+        trial = {}
+        for m in ('eager', 'graph'):
+            eng.use_graph = m == 'graph'
+            for _ in range(5):
+                eng.step(real)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(25):
+                eng.step(real)
+            torch.cuda.synchronize()
+            trial[m] = (time.perf_counter() - t0) / 25
+        mode = min(trial, key=trial.get)
+        if os.environ.get('BENCH_VERBOSE'):
+            print('launch-mode trial (ms/step):', {k: round(v * 1e3, 3) for k, v in trial.items()}, file=sys.stderr)
+        eng.use_graph = mode == 'graph'
+        barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
@@ -173,7 +196,7 @@ def main():
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%s %dx%d DCGAN-SN, batch %d per GPU, %s loss, lr %g/%g, TF-Adam, one G+D step'
                                    % (args.config, h, w, B, args.loss, lr[0], lr[1]),
-                       'global_batch': B * world, 'parallelism': 'dp%d' % world, 'hip_graph': not args.no_graph},
+                       'global_batch': B * world, 'parallelism': 'dp%d' % world, 'launch_mode': mode},
             'loss_gen': float(losses[0]), 'loss_dis': float(losses[1]),
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,

@@ -6,7 +6,8 @@ step from one forward pass) and the error behaviour for bad argum
 TF graphs/sessions, summaries, the tfrecord reader and the Inception scorer (SURVEY.md section 8
 marks them out of scope); `mdl_score` says so instead of pretending.
 """
-from math import gcd
+from math import os
+import gcd
 
 import numpy as np
 import torch
@@ -53,7 +54,10 @@ class SNGan(object):
         if self.engine is None or self.engine.B != batch_size:
             self.engine = GanEngine(self.architecture, self.loss_type, lr_list, tuple(self.rep_weights),
                                     batch_size=batch_size, seed=seed, dist_group=self.dist_group,
-                                    use_graph=self.dist_group is None)
+                                    # eager issue measured faster than replaying the 3-branch hipGraph when the
+                                    # host keeps up (2.55 vs 2.72 ms/step, bench.py tries both); MMDGAN_HIP_GRAPH=1
+                                    # for hosts that do not
+                                    use_graph=self.dist_group is None and os.environ.get('MMDGAN_HIP_GRAPH') == '1')
         else:
             self.engine.lr_d, self.engine.lr_g = float(lr_list[0]), float(lr_list[1])
         return self.engine
