@@ -6,8 +6,8 @@ step from one forward pass) and the error behaviour for bad argum
 TF graphs/sessions, summaries, the tfrecord reader and the Inception scorer (SURVEY.md section 8
 marks them out of scope); `mdl_score` says so instead of pretending.
 """
-from math import os
-import gcd
+import os
+from math import gcd
 
 import numpy as np
 import torch
