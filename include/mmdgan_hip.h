@@ -113,11 +113,13 @@ int mmdgan_conv2d_wgrad(const mmdgan_conv_geom *g, const float *x, const float *
 int mmdgan_conv2d_wgrad_bias(const mmdgan_conv_geom *g, const float *x, const float *dy, float *dw, float *dbias,
                              void *stream);
 
-/* Winograd F(2x2,3x3) for 3x3 / stride-1 layers (same tf.nn.conv2d / autodiff call sites as above; csrc/conv_wino.hip).
+/* Winograd F(2x2,3x3) for 3x3 / stride-1 layers (csrc/conv_wino.hip) and F(2x2,2x2) on the parity decomposition of
+ * 4x4 / stride-2 layers and their transposes (csrc/conv_wino2.hip); same tf.nn.conv2d / conv2d_transpose / autodiff
+ * call sites as above.
  * conv2d_fwd / conv2d_dgrad use it on their own when the geometry is eligible and a workspace is registered for
  * the transformed weights; a caller can instead transform once per weight update:
  *   mmdgan_wino_eligible(g, dgrad)        1 if conv2d_fwd (dgrad = 0) / conv2d_dgrad (1) of this geometry runs Winograd
- *   mmdgan_wino_weight_bytes(g)           size of the transformed tensor (16 * C * K floats)
+ *   mmdgan_wino_weight_bytes(g)           size of the transformed tensor (16 * C * K floats for 3x3, 36 * C * K for 4x4)
  *   mmdgan_wino_transform(g, w, dgrad, u) u = G w G^T per (c,k), laid out for the forward (dgrad = 0) or the
  *                                         input-gradient (1: taps flipped, channel roles swapped)
  * and pass u as `w` with MMDGAN_ACT_FLAG_W_WINOGRAD. */

@@ -58,9 +58,11 @@ extern "C" int mmdgan_conv2d_fwd(const mmdgan_conv_geom *g, const float *x, cons
     if (int rc = make_wrap(d.N, dact_of ? dact_batch : 0, (long)d.P * d.Q * d.K, "conv2d_fwd", &wf, &ws)) return rc;
     const ConvEpilogue ep{bias, scale, dact_of, act, wf, ws, out_zeroed};
     if (w_wino) {
-        MMDGAN_REQUIRE(wino_eligible(d, false), "conv2d_fwd: MMDGAN_ACT_FLAG_W_WINOGRAD on a geometry mmdgan_wino_eligible() rejects");
-        return wino_fwd(d, ep, x, nullptr, w, y, (hipStream_t)stream);
+        MMDGAN_REQUIRE(wino_eligible(d, false) || wino2_eligible(d, false),
+                       "conv2d_fwd: MMDGAN_ACT_FLAG_W_WINOGRAD on a geometry mmdgan_wino_eligible() rejects");
+        return d.R == 3 ? wino_fwd(d, ep, x, nullptr, w, y, (hipStream_t)stream) : wino2_fwd(d, ep, x, nullptr, w, y, (hipStream_t)stream);
     }
+    if (!force_direct() && wino2_fwd_ok(d)) return wino2_fwd(d, ep, x, w, nullptr, y, (hipStream_t)stream);
     if (!force_direct() && wino_fwd_ok(d)) return wino_fwd(d, ep, x, w, nullptr, y, (hipStream_t)stream);
     if (!force_direct() && igemm_fwd_ok(d)) return igemm_fwd(d, ep, x, w, y, (hipStream_t)stream);
     if (!force_direct() && !force_valu_thin() && (thinm_fwd_n2w_ok(d) || thinm_fwd_w2n_ok(d)) && al16(x) && al16(y) &&
@@ -83,9 +85,11 @@ extern "C" int mmdgan_conv2d_dgrad(const mmdgan_conv_geom *g, const float *dy, c
     if (int rc = make_wrap(d.N, dact_of ? dact_batch : 0, (long)d.H * d.W * d.C, "conv2d_dgrad", &wf, &ws)) return rc;
     const ConvEpilogue ep{bias, scale, dact_of, act, wf, ws, out_zeroed};
     if (w_wino) {
-        MMDGAN_REQUIRE(wino_eligible(d, true), "conv2d_dgrad: MMDGAN_ACT_FLAG_W_WINOGRAD on a geometry mmdgan_wino_eligible() rejects");
-        return wino_dgrad(d, ep, dy, nullptr, w, dx, (hipStream_t)stream);
+        MMDGAN_REQUIRE(wino_eligible(d, true) || wino2_eligible(d, true),
+                       "conv2d_dgrad: MMDGAN_ACT_FLAG_W_WINOGRAD on a geometry mmdgan_wino_eligible() rejects");
+        return d.R == 3 ? wino_dgrad(d, ep, dy, nullptr, w, dx, (hipStream_t)stream) : wino2_dgrad(d, ep, dy, nullptr, w, dx, (hipStream_t)stream);
     }
+    if (!force_direct() && wino2_dgrad_ok(d)) return wino2_dgrad(d, ep, dy, w, nullptr, dx, (hipStream_t)stream);
     if (!force_direct() && wino_dgrad_ok(d)) return wino_dgrad(d, ep, dy, w, nullptr, dx, (hipStream_t)stream);
     if (!force_direct() && igemm_dgrad_ok(d)) return igemm_dgrad(d, ep, dy, w, dx, (hipStream_t)stream);
     if (!force_direct() && !force_valu_thin() && (thinm_dgrad_n2w_ok(d) || thinm_dgrad_w2n_ok(d)) && al16(dy) && al16(dx) &&
@@ -98,18 +102,21 @@ extern "C" int mmdgan_conv2d_dgrad(const mmdgan_conv_geom *g, const float *dy, c
 
 extern "C" int mmdgan_wino_eligible(const mmdgan_conv_geom *g, int dgrad) {
     if (!g || g->N < 1 || g->H < 1 || g->W < 1 || g->C < 1 || g->K < 1 || g->R < 1 || g->stride < 1) return 0;
-    return !force_direct() && wino_eligible(conv_dims(*g), dgrad != 0) ? 1 : 0;
+    const ConvDims d = conv_dims(*g);
+    return !force_direct() && (wino_eligible(d, dgrad != 0) || wino2_eligible(d, dgrad != 0)) ? 1 : 0;
 }
 
 extern "C" size_t mmdgan_wino_weight_bytes(const mmdgan_conv_geom *g) {
-    return g ? sizeof(float) * 16 * (size_t)g->C * g->K : 0;
+    return g ? sizeof(float) * (g->R == 3 ? 16 : 36) * (size_t)g->C * g->K : 0;
 }
 
 extern "C" int mmdgan_wino_transform(const mmdgan_conv_geom *g, const float *w, int dgrad, float *u, void *stream) {
     if (int rc = validate(g, "wino_transform")) return rc;
     MMDGAN_REQUIRE(w && u, "wino_transform: null pointer");
-    MMDGAN_REQUIRE(g->R == 3, "wino_transform: 3x3 kernels only (got %d)", g->R);
-    return wino_transform(conv_dims(*g), w, dgrad != 0, u, (hipStream_t)stream);
+    MMDGAN_REQUIRE((g->R == 3 && g->stride == 1) || (g->R == 4 && g->stride == 2),
+                   "wino_transform: 3x3 stride 1 or 4x4 stride 2 kernels only (got %dx%d stride %d)", g->R, g->R, g->stride);
+    const ConvDims d = conv_dims(*g);
+    return g->R == 3 ? wino_transform(d, w, dgrad != 0, u, (hipStream_t)stream) : wino2_transform(d, w, dgrad != 0, u, (hipStream_t)stream);
 }
 
 static int wgrad_impl(const mmdgan_conv_geom *g, const float *x, const float *dy, float *dw, float *dbias, void *stream,

@@ -57,6 +57,14 @@ int wino_transform(const ConvDims &d, const float *w, bool flip, float *U, hipSt
 int wino_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, const float *U, float *y, hipStream_t st);
 int wino_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, const float *U, float *dx, hipStream_t st);
 
+// Winograd F(2x2,2x2) for 4x4 / stride-2 layers and their input-gradient (conv_wino2.hip); U = 36*C*K floats
+bool wino2_eligible(const ConvDims &d, bool dgrad);
+bool wino2_fwd_ok(const ConvDims &d);
+bool wino2_dgrad_ok(const ConvDims &d);
+int wino2_transform(const ConvDims &d, const float *w, bool dgrad, float *U, hipStream_t st);
+int wino2_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, const float *U, float *y, hipStream_t st);
+int wino2_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, const float *U, float *dx, hipStream_t st);
+
 // MFMA implicit-GEMM path (conv_igemm.hip); *_ok() say whether a geometry is eligible
 bool igemm_fwd_ok(const ConvDims &d);
 bool igemm_dgrad_ok(const ConvDims &d);

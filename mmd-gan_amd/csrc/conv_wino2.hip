@@ -1,0 +1,340 @@
+// Winograd F(2x2, 2x2) for the 4x4 / stride-2 layers (D l2, l4, l6 and the transposed convolutions of
+// G): the other half of the conv FLOPs.  A 4x4 stride-2 convolution is a sum of four 2x2 stride-1
+// convolutions on the parity sub-images of its input, and its input-gradient (= the forward pass of a
+// 4x4 stride-2 transposed convolution) is four independent 2x2 stride-1 convolutions, one per output
+// parity phase.  F(2x2,2x2) computes a 2x2 output tile of such a convolution from a 3x3 patch with 9
+// multiplies instead of 16:
+//
+//   y = A^T [ sum (G g G^T) (.) (B^T d B) ] A,   B^T = [1 -1 0; 0 1 0; 0 -1 1], G = [1 0; 1 1; 0 1], A^T = [1 1 0; 0 1 1]
+//
+// (all constants 0 / +-1).  One kernel serves both forms through a table of "segments": a segment is
+// one (sub-image, 2x2 filter) pair, i.e. a patch origin, the steps between patch rows / tiles and a
+// slice of the transformed weights U[segment][9][Cr][Ko]:
+//   forward      1 phase  x 4 segments (input parities a,b): patch rows 2*(2ty) - 1 + a + 2u of x
+//   input-grad   4 phases x 1 segment  (output parities al,be): patch rows 2ty + al - 1 + u of dy
+// Structure as conv_wino.hip: 32 tiles x 64 output channels per workgroup, V through LDS, B fragments
+// straight from L2 into registers, output transform through LDS in the epilogue.  The 9 frequencies x 2
+// column blocks = 18 accumulators are dealt round-robin to the 4 waves (5,5,4,4).
+#include "conv_internal.h"
+#include "bufload.h"
+
+namespace mmdgan {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace wino2 {
+constexpr int BC = 8;                   // reduction channels per stage
+constexpr int LDT = 33;                 // V: floats per channel row (32 tiles + 1)
+constexpr int FSV = BC * LDT + 2;       // V: floats per frequency
+constexpr int V_FLOATS = 9 * FSV;
+constexpr int MS_FLOATS = 9 * 32 * 32;  // epilogue exchange buffer (one column block at a time)
+constexpr int SMEM_FLOATS = 2 * V_FLOATS > MS_FLOATS ? 2 * V_FLOATS : MS_FLOATS;
+constexpr size_t LDS_BYTES = sizeof(float) * SMEM_FLOATS + sizeof(long) * 32;
+constexpr int NM = 5;                   // frequencies per wave (waves 2, 3 use 4)
+
+struct Params {
+    int N, TH, TW;          // tiles per image (rows, cols)
+    int IH, IW, Cr;         // input image, reduction channels per segment
+    int nseg;               // segments per phase (1 or 4); phase = blockIdx.z
+    int r0[4], c0[4];       // patch origin (input row / col of patch element (0,0) for tile (0,0)) per global segment
+    int tstep, pstep;       // input rows (cols) between consecutive tiles / consecutive patch rows (cols)
+    int OH, OW, Ko;         // output image, channels
+    int otile, ostep;       // output row = ty * otile + a * ostep + o0r[phase]
+    int o0r[4], o0c[4];
+};
+}  // namespace wino2
+
+// U[seg][f][cr][ko] = (G g G^T)[f], f = 3i + j, g = the 2x2 filter of the segment
+//   FWD  : seg = (a,b);  g[u][v] = w[2u + a][2v + b][c][k];            cr = c, ko = k
+//   DGRAD: seg = (al,be); g[u][v] = w[rho(al,1-u)][rho(be,1-v)][c][k], rho(0,r') = 1 + 2r', rho(1,r') = 2r';  cr = k, ko = c
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void wino2_weight_kernel(const float *__restrict__ w, float *__restrict__ U, int C, int K) {
+    __shared__ float tile[9][32][33];
+    const int c0 = blockIdx.y * 32, k0 = blockIdx.x * 32, seg = blockIdx.z, sa = seg >> 1, sb = seg & 1;
+    const int tk = threadIdx.x & 31, tq = threadIdx.x >> 5;
+    for (int cc = tq; cc < 32; cc += 8) {
+        const int c = c0 + cc, k = k0 + tk;
+        const bool ok = c < C && k < K;
+        float g[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int r = DGRAD ? (sa == 0 ? 1 + 2 * (1 - u) : 2 * (1 - u)) : 2 * u + sa;
+                const int t = DGRAD ? (sb == 0 ? 1 + 2 * (1 - v) : 2 * (1 - v)) : 2 * v + sb;
+                g[u][v] = ok ? w[((size_t)(r * 4 + t) * C + c) * K + k] : 0.f;
+            }
+        float gg[3][2], uu[3][3];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) { gg[0][v] = g[0][v]; gg[1][v] = g[0][v] + g[1][v]; gg[2][v] = g[1][v]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { uu[i][0] = gg[i][0]; uu[i][1] = gg[i][0] + gg[i][1]; uu[i][2] = gg[i][1]; }
+        if (!DGRAD) {
+            if (ok) {
+#pragma unroll
+                for (int f = 0; f < 9; ++f) U[(((size_t)seg * 9 + f) * C + c) * K + k] = uu[f / 3][f % 3];
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < 9; ++f) tile[f][cc][tk] = uu[f / 3][f % 3];
+        }
+    }
+    if (DGRAD) {             // transposed write: U[seg][f][k][c], threads along c
+        __syncthreads();
+        for (int kk = tq; kk < 32; kk += 8) {
+            const int k = k0 + kk, c = c0 + tk;
+            if (c < C && k < K) {
+#pragma unroll
+                for (int f = 0; f < 9; ++f) U[(((size_t)seg * 9 + f) * K + k) * C + c] = tile[f][tk][kk];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpilogue ep, const float *__restrict__ x,
+                                                       const float *__restrict__ U, float *__restrict__ out) {
+    using namespace wino2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5, wave = tid >> 6;
+    const long T = (long)P.N * P.TH * P.TW;
+    const int t0 = blockIdx.x * 32, n0 = blockIdx.y * 64, phase = blockIdx.z;
+    const int spc = P.Cr / BC;                           // stages per segment
+    const int nstages = P.nseg * spc;
+    // ---- producer: lanes 0..47 of every wave: patch row pu = lane / 16, unit = (tile pt, channel quad pp)
+    const int pu = lane >> 4, unit = (lane & 15) + 16 * wave, pt = unit >> 1, pp = unit & 1;
+    const bool prod = pu < 3;
+    int tyx_ty = 0, tyx_tx = 0, tyx_n = 0;
+    bool tile_ok;
+    {
+        const long id = (long)t0 + pt;
+        tile_ok = id < T;
+        const long ii = tile_ok ? id : 0;
+        tyx_tx = ii % P.TW; tyx_ty = (ii / P.TW) % P.TH; tyx_n = ii / ((long)P.TW * P.TH);
+        if (prod && pu == 0 && pp == 0)      // element offset of this tile's output pixel (a=0, b=0), channel 0 (-1: no such tile)
+            reinterpret_cast<long *>(smem + SMEM_FLOATS)[pt] =
+                tile_ok ? (((long)tyx_n * P.OH + tyx_ty * P.otile + P.o0r[phase]) * P.OW + tyx_tx * P.otile + P.o0c[phase]) * P.Ko : -1;
+    }
+    unsigned xoff[3];
+    auto set_segment = [&](int sidx) {                  // byte offsets of this thread's 3 patch pixels, channel 4*pp
+        const int gs = phase * P.nseg + sidx;
+        const int row = tyx_ty * P.tstep + P.r0[gs] + pu * P.pstep;
+        const bool rowok = prod && tile_ok && row >= 0 && row < P.IH;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const int col = tyx_tx * P.tstep + P.c0[gs] + v * P.pstep;
+            xoff[v] = (rowok && col >= 0 && col < P.IW) ? (unsigned)(((((long)tyx_n * P.IH + row) * P.IW + col) * P.Cr + 4 * pp) * 4) : kOOB;
+        }
+    };
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (long)P.N * P.IH * P.IW * P.Cr * 4);
+    const __amdgpu_buffer_rsrc_t ru = make_rsrc(U, (long)4 * 9 * P.Cr * P.Ko * 4);
+    const int vdst = (pu * 3) * FSV + (4 * pp) * LDT + pt;
+    const int src1 = (lane & 15) + 16;                   // lane holding patch row 1 of the same unit
+    // ---- consumer: wave owns column block cb and frequencies fq + 2m
+    const int cb = wave & 1, fq = wave >> 1;
+    const unsigned ubase = (unsigned)(((long)kh * P.Ko + n0 + cb * 32 + l31) * 4);
+    const unsigned ufreq = (unsigned)((long)P.Cr * P.Ko * 4), ukp = (unsigned)(2 * P.Ko * 4), ustage = (unsigned)(BC * P.Ko * 4);
+    const unsigned useg = 9u * ufreq;
+    const int nm = fq == 0 ? 5 : 4;
+
+    f32x16 acc[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+    float4 rin[3];
+    float fb[4][NM], X[3][4];
+#define W2_XLOAD(S)                                                                                      \
+    {                                                                                                    \
+        const int sidx_ = (S) / spc, cs_ = (S) - sidx_ * spc;                                            \
+        if (cs_ == 0 && sidx_ < P.nseg) set_segment(sidx_);                                              \
+        const unsigned sx = (unsigned)(cs_ * BC * 4);          /* padded taps: kOOB + sx stays out of range */ \
+        _Pragma("unroll") for (int v = 0; v < 3; ++v) rin[v] = bufld4(rx, xoff[v] + sx);                 \
+    }
+    // row pass X = d B over the 3 pixels of this thread's patch row, 4 channels
+#define W2_ROWPASS                                                                                       \
+    X[0][0] = rin[0].x - rin[1].x; X[0][1] = rin[0].y - rin[1].y; X[0][2] = rin[0].z - rin[1].z; X[0][3] = rin[0].w - rin[1].w; \
+    X[1][0] = rin[1].x; X[1][1] = rin[1].y; X[1][2] = rin[1].z; X[1][3] = rin[1].w;                       \
+    X[2][0] = rin[2].x - rin[1].x; X[2][1] = rin[2].y - rin[1].y; X[2][2] = rin[2].z - rin[1].z; X[2][3] = rin[2].w - rin[1].w;
+    // column pass V = B^T X: rows 0 and 2 subtract row 1 (fetched from the lane 16 / 32 away), row 1 is itself
+#define W2_VSTORE(BUF, J)                                                                                \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                      \
+        const float mid = __shfl(X[J][e], src1, 64);                                                     \
+        if (prod) (BUF)[vdst + (J) * FSV + e * LDT] = pu == 1 ? X[J][e] : X[J][e] - mid;                  \
+    }
+#define W2_BLOAD(KP, M, S)                                                                               \
+    {                                                                                                    \
+        const int sidx_ = (S) / spc, cs_ = (S) - sidx_ * spc;                                            \
+        fb[KP][M] = bufld1s(ru, ubase, (unsigned)(phase * P.nseg + sidx_) * useg + (unsigned)(fq + 2 * (M)) * ufreq + \
+                                           (unsigned)cs_ * ustage + (KP) * ukp);                         \
+    }
+
+    W2_XLOAD(0)
+#pragma unroll
+    for (int kp = 0; kp < 4; ++kp)
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+            if (m < nm) W2_BLOAD(kp, m, 0)
+    W2_ROWPASS
+    W2_VSTORE(smem, 0) W2_VSTORE(smem, 1) W2_VSTORE(smem, 2)
+    W2_XLOAD(1)
+    __syncthreads();
+    const int abase = fq * FSV + kh * LDT + l31;
+    for (int s = 0; s < nstages; ++s) {
+        const float *cur = smem + (s & 1) * V_FLOATS;
+        float *nxt = smem + ((s + 1) & 1) * V_FLOATS;
+        const int sn = s + 1 < nstages ? s + 1 : s;           // the last refill re-reads the last stage (unused)
+        float fa[2][NM];                                   // A fragments of k-pair kp+1 are read while kp's MFMAs issue
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+            if (m < nm) fa[0][m] = cur[abase + 2 * m * FSV];
+#pragma unroll
+        for (int kp = 0; kp < 4; ++kp) {
+            if (kp + 1 < 4) {
+#pragma unroll
+                for (int m = 0; m < NM; ++m)
+                    if (m < nm) fa[(kp + 1) & 1][m] = cur[abase + 2 * m * FSV + 2 * (kp + 1) * LDT];
+            }
+#pragma unroll
+            for (int m = 0; m < NM; ++m)
+                if (m < nm) {
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kp & 1][m], fb[kp][m], acc[m], 0, 0, 0);
+                    W2_BLOAD(kp, m, sn)
+                }
+            if (kp == 0) {                             // tile s+1: transform + LDS stores
+                W2_ROWPASS
+                W2_VSTORE(nxt, 0)
+            } else if (kp == 1) {
+                W2_VSTORE(nxt, 1) W2_VSTORE(nxt, 2)
+            } else if (kp == 2) {                      // tile s+2: activations
+                W2_XLOAD(s + 2)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+#undef W2_XLOAD
+#undef W2_ROWPASS
+#undef W2_VSTORE
+#undef W2_BLOAD
+
+    // ---- output transform + epilogue: Ms[f][tile][k 32], one column block at a time
+    const float sc = ep.scale ? ep.scale[0] : 1.f;
+    float *Ms = smem;
+    const long *obase = reinterpret_cast<const long *>(smem + SMEM_FLOATS);
+    const int kq = tid & 7, tb = tid >> 3;
+    const long arow = (long)P.ostep * P.OW * P.Ko, bcol = (long)P.ostep * P.Ko;
+    for (int c = 0; c < 2; ++c) {
+        if (cb == c) {
+#pragma unroll
+            for (int m = 0; m < NM; ++m)
+                if (m < nm) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Ms[((fq + 2 * m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * 32 + l31] = acc[m][r];
+                }
+        }
+        __syncthreads();
+        const int ch = n0 + c * 32 + kq * 4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ep.bias) bv = *reinterpret_cast<const float4 *>(ep.bias + ch);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int item = tb + 32 * it, tile = item >> 1, b = item & 1;
+            const long ob = obase[tile];
+            if (ob >= 0) {
+                float4 z[3];                           // Z[i][b] = M[i][b] + M[i][b+1]
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const float4 p0 = *reinterpret_cast<const float4 *>(Ms + ((3 * i + b) * 32 + tile) * 32 + kq * 4);
+                    const float4 p1 = *reinterpret_cast<const float4 *>(Ms + ((3 * i + b + 1) * 32 + tile) * 32 + kq * 4);
+                    z[i] = make_float4(p0.x + p1.x, p0.y + p1.y, p0.z + p1.z, p0.w + p1.w);
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {          // Y[a][b] = Z[a][b] + Z[a+1][b]
+                    float4 v = make_float4(z[a].x + z[a + 1].x, z[a].y + z[a + 1].y, z[a].z + z[a + 1].z, z[a].w + z[a + 1].w);
+                    const long o = ob + a * arow + b * bcol + ch;
+                    v.x = v.x * sc + bv.x; v.y = v.y * sc + bv.y; v.z = v.z * sc + bv.z; v.w = v.w * sc + bv.w;
+                    if (ep.dact) {
+                        const float4 yv = *reinterpret_cast<const float4 *>(ep.dact + ep.dact_index(o));
+                        v.x *= act_bwd_from_out(yv.x, ep.act); v.y *= act_bwd_from_out(yv.y, ep.act);
+                        v.z *= act_bwd_from_out(yv.z, ep.act); v.w *= act_bwd_from_out(yv.w, ep.act);
+                    } else {
+                        v.x = act_fwd(v.x, ep.act); v.y = act_fwd(v.y, ep.act);
+                        v.z = act_fwd(v.z, ep.act); v.w = act_fwd(v.w, ep.act);
+                    }
+                    *reinterpret_cast<float4 *>(out + o) = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// First version: correct on every parity case, but at ~40 % of its MFMA floor it only beats the direct kernels on
+// the large input-gradient launches (measured, CIFAR batch 64: D l2 3B-row dgrad 128 vs 147 us, D l4 112 vs 122 us;
+// forward l2 98 vs 94, everything with fewer workgroups slower), and inside the training step even that is a
+// net loss (2.62 vs 2.55 ms/step).  So it is OFF by default: MMDGAN_WINO2=1 enables the input-gradient form for
+// launches with >= 768 workgroups, =2 every eligible shape in both directions (what the parity tests run).
+static int wino2_mode() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MMDGAN_WINO2"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
+// d describes the CONV (4x4, stride 2, pad 1): x [N,H,W,C] -> y [N,P,Q,K]
+static bool wino2_shape_ok(const ConvDims &d, bool dgrad) {
+    const int mode = wino2_mode();
+    if (mode == 0 || d.R != 4 || d.stride != 2 || d.pad != 1 || d.H % 4 || d.W % 4) return false;
+    const int cr = dgrad ? d.K : d.C, ko = dgrad ? d.C : d.K;
+    if (cr % wino2::BC || cr < 32 || ko % 64) return false;
+    if (mode >= 2) return true;
+    const long tiles = (long)d.N * (d.P / 2) * (d.Q / 2);          // per phase
+    return dgrad && ((tiles + 31) / 32) * (ko / 64) * 4 >= 768;
+}
+bool wino2_eligible(const ConvDims &d, bool dgrad) { return wino2_shape_ok(d, dgrad); }
+static size_t wino2_bytes(const ConvDims &d) { return sizeof(float) * 36 * (size_t)d.C * d.K; }
+bool wino2_fwd_ok(const ConvDims &d) { return wino2_shape_ok(d, false) && workspace(wino2_bytes(d)) != nullptr; }
+bool wino2_dgrad_ok(const ConvDims &d) { return wino2_shape_ok(d, true) && workspace(wino2_bytes(d)) != nullptr; }
+
+int wino2_transform(const ConvDims &d, const float *w, bool dgrad, float *U, hipStream_t st) {
+    const dim3 wg((d.K + 31) / 32, (d.C + 31) / 32, 4);
+    if (dgrad) hipLaunchKernelGGL(wino2_weight_kernel<true>, wg, dim3(256), 0, st, w, U, d.C, d.K);
+    else hipLaunchKernelGGL(wino2_weight_kernel<false>, wg, dim3(256), 0, st, w, U, d.C, d.K);
+    return check_launch("wino2_transform");
+}
+
+static int wino2_launch(const ConvDims &d, const ConvEpilogue &ep, const float *in, const float *w, const float *U, float *out,
+                        bool dgrad, hipStream_t st) {
+    if (!U) {
+        float *ws = (float *)workspace(wino2_bytes(d));
+        if (int rc = wino2_transform(d, w, dgrad, ws, st)) return rc;
+        U = ws;
+    }
+    wino2::Params P;
+    P.N = d.N; P.TH = d.P / 2; P.TW = d.Q / 2;
+    if (!dgrad) {            // y tile (2ty.., 2tx..) <- x rows 4ty - 1 + a + 2u
+        P.IH = d.H; P.IW = d.W; P.Cr = d.C; P.nseg = 4;
+        for (int s = 0; s < 4; ++s) { P.r0[s] = -1 + (s >> 1); P.c0[s] = -1 + (s & 1); P.o0r[s] = 0; P.o0c[s] = 0; }
+        P.tstep = 4; P.pstep = 2;
+        P.OH = d.P; P.OW = d.Q; P.Ko = d.K; P.otile = 2; P.ostep = 1;
+    } else {                 // dx phase (al,be), tile (h' = 2ty.., w' = 2tx..) <- dy rows 2ty + al - 1 + u
+        P.IH = d.P; P.IW = d.Q; P.Cr = d.K; P.nseg = 1;
+        for (int s = 0; s < 4; ++s) { P.r0[s] = (s >> 1) - 1; P.c0[s] = (s & 1) - 1; P.o0r[s] = s >> 1; P.o0c[s] = s & 1; }
+        P.tstep = 2; P.pstep = 1;
+        P.OH = d.H; P.OW = d.W; P.Ko = d.C; P.otile = 4; P.ostep = 2;
+    }
+    const long T = (long)d.N * P.TH * P.TW;
+    const dim3 grid((unsigned)((T + 31) / 32), P.Ko / 64, dgrad ? 4 : 1);
+    hipLaunchKernelGGL(wino2_kernel, grid, dim3(256), wino2::LDS_BYTES, st, P, ep, in, U, out);
+    return check_launch(dgrad ? "conv2d_dgrad(winograd 2x2)" : "conv2d_fwd(winograd 2x2)");
+}
+
+int wino2_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, const float *U, float *y, hipStream_t st) {
+    return wino2_launch(d, ep, x, w, U, y, false, st);
+}
+int wino2_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, const float *U, float *dx, hipStream_t st) {
+    return wino2_launch(d, ep, dy, w, U, dx, true, st);
+}
+
+}  // namespace mmdgan

@@ -407,8 +407,9 @@ class GanEngine:
                 fw = ops.wino_eligible(2 * B, h, w, c, s.out, s.R, s.stride, False)
                 bw = ops.wino_eligible(3 * B, h, w, c, s.out, s.R, s.stride, True)
                 if fw or bw:
-                    self._wino[s.scope] = [torch.empty(16, c, s.out, device=dev) if fw else None,
-                                           torch.empty(16, s.out, c, device=dev) if bw else None]
+                    lead = (16,) if s.R == 3 else (4, 9)         # F(2x2,3x3) / F(2x2,2x2) on 4 parity segments
+                    self._wino[s.scope] = [torch.empty(lead + (c, s.out), device=dev) if fw else None,
+                                           torch.empty(lead + (s.out, c), device=dev) if bw else None]
         gs = self.gen.specs
         for below, above in zip(gs, gs[1:]):     # input-gradient of a tc layer into a linear layer: split-K target
             if above.op == 'tc' and (below.bn or below.act == 'linear'):

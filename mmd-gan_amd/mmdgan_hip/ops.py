@@ -109,11 +109,13 @@ def wino_eligible(N, H, W, C, K, R, stride, dgrad):
 
 
 def wino_transform(w, dgrad, out=None):
-    """w [3,3,C,K] -> [16,C,K] (forward) or [16,K,C] (input-gradient) transformed weights"""
+    """w [3,3,C,K] -> [16,C,K] (forward) or [16,K,C] (input-gradient) transformed weights;
+    w [4,4,C,K] (stride-2 layers) -> [4,9,C,K] or [4,9,K,C]"""
     lib = require_device()
     R, _, C, K = w.shape
-    u = out if out is not None else torch.empty((16, K, C) if dgrad else (16, C, K), device=w.device, dtype=torch.float32)
-    g = geom(1, 2, 2, C, K, R, 1)
+    lead = (16,) if R == 3 else (4, 9)
+    u = out if out is not None else torch.empty(lead + ((K, C) if dgrad else (C, K)), device=w.device, dtype=torch.float32)
+    g = geom(1, 4, 4, C, K, R, 1 if R == 3 else 2)
     check(lib.mmdgan_wino_transform(ctypes.byref(g), _p(w), int(dgrad), _p(u), _stream()), 'wino_transform')
     return u
 

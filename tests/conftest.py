@@ -3,7 +3,8 @@ import sys
 
 import pytest
 
-os.environ.setdefault('MMDGAN_WINO_MIN_TILES', '256')     # let the small parity cases reach the Winograd kernels
+os.environ.setdefault('MMDGAN_WINO_MIN_TILES', '32')
+os.environ.setdefault('MMDGAN_WINO2', '2')               # ... and the F(2x2,2x2) stride-2 kernels in both directions     # let the small parity cases reach the Winograd kernels
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, 'mmd-gan_amd')

@@ -209,6 +209,57 @@ def test_conv2d_dgrad_and_wgrad(ops, case):
     assert rel_err(to_nchw(dx2), ref) <= RTOL
 
 
+WINO2_CASES = [(16, 16, 16, 64, 128, 4, 2), (30, 12, 12, 32, 64, 4, 2), (6, 8, 16, 64, 64, 4, 2), (9, 4, 4, 128, 64, 4, 2),
+               (33, 8, 8, 40, 192, 4, 2)]
+
+
+@pytest.mark.parametrize('case', WINO2_CASES, ids=[str(c) for c in WINO2_CASES])
+def test_conv2d_winograd_stride2_path(ops, case):
+    """4x4 / stride-2 layers: F(2x2,2x2) on the parity decomposition - forward (4 input-parity segments),
+    input-gradient / transposed-conv forward (4 output-parity phases), 3B-row dact wrap, ragged tile blocks."""
+    N, H, W, C, K, ksz, s = case
+    x, w, b = conv_data(case, 3)
+    P, Q = H // 2, W // 2
+    rs = np.random.RandomState(10)
+    dy = rs.randn(N, K, P, Q).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64)
+    yt = R.conv2d_same(xt, wt, s)
+    gx, = torch.autograd.grad((yt * torch.tensor(dy, dtype=torch.float64)).sum(), [xt])
+    fwd_ok, bwd_ok = ops.wino_eligible(N, H, W, C, K, ksz, s, False), ops.wino_eligible(N, H, W, C, K, ksz, s, True)
+    assert fwd_ok or bwd_ok
+    uf, ub = ops.wino_transform(dev(w), False), ops.wino_transform(dev(w), True)
+    assert uf.shape == (4, 9, C, K) and ub.shape == (4, 9, K, C)
+    sc = np.float32(0.61)
+    if fwd_ok:
+        for act in ('linear', 'lrelu'):
+            ref = R._act(yt.detach() * float(sc) + torch.tensor(b, dtype=torch.float64).reshape(1, -1, 1, 1), act).numpy()
+            y = ops.conv2d_fwd(nhwc(x), dev(w), s, bias=dev(b), scale=dev([sc]), act=act, wino=uf)
+            assert rel_err(to_nchw(y), ref) <= RTOL, act
+    if bwd_ok:
+        dx = ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s, wino=ub)
+        assert rel_err(to_nchw(dx), gx.numpy()) <= RTOL
+        bc = (rs.randn(C) * 0.1).astype(np.float32)                 # transposed-conv forward form: relu(dgrad + bias)
+        y2 = ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s, bias=dev(bc), act='relu', wino=ub)
+        assert rel_err(to_nchw(y2), np.maximum(gx.numpy() + bc.reshape(1, -1, 1, 1), 0)) <= RTOL
+        if N % 3 == 0:
+            B = N // 3
+            yprev = rs.randn(2 * B, C, H, W).astype(np.float32)
+            mask = np.where(np.concatenate([yprev, yprev[B:]], 0) > 0, 1.0, 0.1)
+            dx2 = ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s, scale=dev([0.5]), act='lrelu', dact_of=nhwc(yprev),
+                                   dact_batch=2 * B, wino=ub)
+            assert rel_err(to_nchw(dx2), 0.5 * gx.numpy() * mask) <= RTOL
+    # library-side transform (workspace) takes the same kernels
+    ops.set_workspace()
+    try:
+        y = ops.conv2d_fwd(nhwc(x), dev(w), s)
+        assert rel_err(to_nchw(y), yt.detach().numpy()) <= RTOL
+        dx = ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s)
+        assert rel_err(to_nchw(dx), gx.numpy()) <= RTOL
+    finally:
+        ops.require_device().mmdgan_set_workspace(None, 0)
+
+
 WINO_CASES = [(16, 16, 16, 128, 128, 3, 1), (32, 8, 8, 64, 128, 3, 1), (9, 12, 12, 32, 64, 3, 1), (130, 4, 4, 64, 64, 3, 1),
               (5, 14, 18, 40, 192, 3, 1), (9, 10, 12, 64, 64, 3, 1)]
 
@@ -255,9 +306,9 @@ def test_conv2d_winograd_path(ops, case):
     else:
         with pytest.raises(ValueError, match='WINOGRAD'):
             ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s, wino=ub)
-    assert not ops.wino_eligible(N, H, W, C, K, 4, 2, False)
+    assert not ops.wino_eligible(N, H, W, C, K, 5, 1, False)
     with pytest.raises(ValueError, match='WINOGRAD'):
-        ops.conv2d_fwd(nhwc(x)[:, :, :, :], dev(np.zeros((4, 4, C, K), np.float32)), 2, wino=uf)
+        ops.conv2d_fwd(nhwc(x), dev(np.zeros((5, 5, C, K), np.float32)), 1, wino=uf)
 
 
 @pytest.mark.parametrize('case', [(4, 4, 4, 512, 256, 4, 2), (3, 8, 8, 256, 128, 4, 2), (2, 16, 16, 128, 64, 4, 2),
