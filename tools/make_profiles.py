@@ -13,11 +13,12 @@ def summary(sub, pre, steps, out, header):
     with open(os.path.join(dst, out), 'w') as f:
         f.write(header + '\n' + txt)
 
-summary('graph', 'g', 25, tag + '_kernel_stats_graph.txt',
-        '# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline   (hipGraph, 3 streams;\n'
-        '# kernel durations under the profiler include overlap between streams: use the eager file for per-kernel cost)')
-summary('eager', 'e', 25, tag + '_kernel_stats_eager.txt',
-        '# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-graph --no-cpu-baseline')
+summary('graph', 'g', 85, tag + '_kernel_stats_default.txt',
+        '# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline   (the default command:\n'
+        '# 4 streams, launch-mode trial during warm-up = 85 steps in the trace; kernel durations include overlap between\n'
+        '# streams: use the single-stream file for per-kernel cost)')
+summary('eager', 'e', 25, tag + '_kernel_stats_single_stream.txt',
+        '# MMDGAN_SIDE_WGRAD=0 MMDGAN_SN_STREAMS=1 rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-graph --no-cpu-baseline')
 summary('probe', 'p', 1, tag + '_dominant_kernel_stats.txt',
         '# rocprofv3 --kernel-trace --stats -- python bench.py --probe-only --probe-reps 50\n'
         '# (one eager step, then 50 launches of the dominant kernel: D l7 weight gradient; its row is igemm_wgrad_kernel<64, 64, true, 1>)')
@@ -51,7 +52,7 @@ out = {'kernel': probe['kernel'], 'launches_profiled': fetch['FETCH_SIZE'][1],
        'mfma_busy_frac_of_simd_cycles': mfma_busy / (gui / 8 * 1024),
        'sq': {k: v[2] for k, v in sq.items()}}
 json.dump(out, open(os.path.join(dst, tag + '_dominant_kernel_pmc.json'), 'w'), indent=1)
-for name in ('conv_layers.txt', 'bench.json', 'bench_graph.json', 'bench_eager.json', 'probe.json', 'bench_stl.json', 'bench_celeba.json'):
+for name in ('conv_layers.txt', 'conv_layers_direct.txt', 'launch_modes.txt', 'bench.json', 'bench_graph.json', 'bench_eager.json', 'probe.json', 'bench_stl.json', 'bench_celeba.json'):
     p = os.path.join(src, name)
     if os.path.exists(p):
         with open(p) as f, open(os.path.join(dst, tag + '_' + name if not name.startswith('bench.') else 'bench_' + tag + '.json'), 'w') as g:
