@@ -95,7 +95,10 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
                                                        const float *__restrict__ U, float *__restrict__ out) {
     using namespace wino2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+    // wave-uniform by construction, but hipcc only knows once it sits in an SGPR: without this every B load with a
+    // wave-dependent scalar offset became a waterfall loop and every `m < nm` an exec-mask branch (2x slower)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long T = (long)P.N * P.TH * P.TW;
     const int t0 = blockIdx.x * 32, n0 = blockIdx.y * 64, phase = blockIdx.z;
     const int spc = P.Cr / BC;                           // stages per segment
@@ -142,6 +145,21 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
+#ifdef W2_ABLATE_XLOAD
+#define W2_XL(E) make_float4(1.f, 2.f, 3.f, 4.f)
+#else
+#define W2_XL(E) (E)
+#endif
+#ifdef W2_ABLATE_VSTORE
+#define W2_VS(S) asm volatile("" ::"v"(mid));
+#else
+#define W2_VS(S) S
+#endif
+#ifdef W2_ABLATE_BLOAD
+#define W2_BL 1.f + 0.f *
+#else
+#define W2_BL
+#endif
     float4 rin[3];
     float fb[4][NM], X[3][4];
 #define W2_XLOAD(S)                                                                                      \
@@ -149,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
         const int sidx_ = (S) / spc, cs_ = (S) - sidx_ * spc;                                            \
         if (cs_ == 0 && sidx_ < P.nseg) set_segment(sidx_);                                              \
         const unsigned sx = (unsigned)(cs_ * BC * 4);          /* padded taps: kOOB + sx stays out of range */ \
-        _Pragma("unroll") for (int v = 0; v < 3; ++v) rin[v] = bufld4(rx, xoff[v] + sx);                 \
+        _Pragma("unroll") for (int v = 0; v < 3; ++v) rin[v] = W2_XL(bufld4(rx, xoff[v] + sx));          \
     }
     // row pass X = d B over the 3 pixels of this thread's patch row, 4 channels
 #define W2_ROWPASS                                                                                       \
@@ -160,12 +178,12 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
 #define W2_VSTORE(BUF, J)                                                                                \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                      \
         const float mid = __shfl(X[J][e], src1, 64);                                                     \
-        if (prod) (BUF)[vdst + (J) * FSV + e * LDT] = pu == 1 ? X[J][e] : X[J][e] - mid;                  \
+        W2_VS(if (prod) (BUF)[vdst + (J) * FSV + e * LDT] = pu == 1 ? X[J][e] : X[J][e] - mid;)           \
     }
 #define W2_BLOAD(KP, M, S)                                                                               \
     {                                                                                                    \
         const int sidx_ = (S) / spc, cs_ = (S) - sidx_ * spc;                                            \
-        fb[KP][M] = bufld1s(ru, ubase, (unsigned)(phase * P.nseg + sidx_) * useg + (unsigned)(fq + 2 * (M)) * ufreq + \
+        fb[KP][M] = W2_BL bufld1s(ru, ubase, (unsigned)(phase * P.nseg + sidx_) * useg + (unsigned)(fq + 2 * (M)) * ufreq + \
                                            (unsigned)cs_ * ustage + (KP) * ukp);                         \
     }
 
@@ -218,6 +236,17 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
 #undef W2_VSTORE
 #undef W2_BLOAD
 
+#ifdef W2_ABLATE_EPILOGUE
+    {
+        float t = 0.f;
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += acc[m][r];
+        if (t == 123.456f) out[tid] = t;
+        return;
+    }
+#endif
     // ---- output transform + epilogue: Ms[f][tile][k 32], one column block at a time
     const float sc = ep.scale ? ep.scale[0] : 1.f;
     float *Ms = smem;
@@ -271,14 +300,15 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
 }
 
 // ------------------------------------------------------------------------------------------------
-// First version: correct on every parity case, but at ~40 % of its MFMA floor it only beats the direct kernels on
-// the large input-gradient launches (measured, CIFAR batch 64: D l2 3B-row dgrad 128 vs 147 us, D l4 112 vs 122 us;
-// forward l2 98 vs 94, everything with fewer workgroups slower), and inside the training step even that is a
-// net loss (2.62 vs 2.55 ms/step).  So it is OFF by default: MMDGAN_WINO2=1 enables the input-gradient form for
-// launches with >= 768 workgroups, =2 every eligible shape in both directions (what the parity tests run).
+// Measured against the direct kernels (CIFAR batch 64, tools/bench_conv.py with MMDGAN_WINO2=2): it wins where the
+// grid is large - D l2 3B-row dgrad 121 vs 146 us (1536 workgroups), D l4 3B dgrad 104 vs 120 (768), D l2 forward
+// 85 vs 94 (512) - and loses below (D l4 forward, 256 workgroups: 106 vs 81; the G layers at batch 64).  The forward
+// form is the weaker one: its stride-2 pixel gathers cost 25 of 79 us (16 bytes out of every 256-byte pixel per
+// stage).  Default (MMDGAN_WINO2=1): forward with >= 512 workgroups, input-gradient with >= 768; =0 never;
+// =2 every eligible shape (what the parity tests run).
 static int wino2_mode() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("MMDGAN_WINO2"); v = e ? atoi(e) : 0; }
+    if (v < 0) { const char *e = getenv("MMDGAN_WINO2"); v = e ? atoi(e) : 1; }
     return v;
 }
 
@@ -290,7 +320,8 @@ static bool wino2_shape_ok(const ConvDims &d, bool dgrad) {
     if (cr % wino2::BC || cr < 32 || ko % 64) return false;
     if (mode >= 2) return true;
     const long tiles = (long)d.N * (d.P / 2) * (d.Q / 2);          // per phase
-    return dgrad && ((tiles + 31) / 32) * (ko / 64) * 4 >= 768;
+    const long wgs = ((tiles + 31) / 32) * (ko / 64) * (dgrad ? 4 : 1);
+    return wgs >= (dgrad ? 768 : 512);
 }
 bool wino2_eligible(const ConvDims &d, bool dgrad) { return wino2_shape_ok(d, dgrad); }
 static size_t wino2_bytes(const ConvDims &d) { return sizeof(float) * 36 * (size_t)d.C * d.K; }
