@@ -23,7 +23,7 @@ namespace mmdgan {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace wino2 {
-constexpr int BC = 8;                   // reduction channels per stage
+constexpr int BC = 32;                  // reduction channels per stage: one 128-byte line of every patch pixel
 constexpr int LDT = 33;                 // V: floats per channel row (32 tiles + 1)
 constexpr int FSV = BC * LDT + 2;       // V: floats per frequency
 constexpr int V_FLOATS = 9 * FSV;
@@ -91,6 +91,12 @@ __global__ __launch_bounds__(256) void wino2_weight_kernel(const float *__restri
     }
 }
 
+// A stage is 32 reduction channels of one segment = 80 (64) MFMAs per wave between barriers:
+//   producer  thread = (tile, channel quad): the 9 pixels of its 3x3 patch as float4 (8 neighbouring lanes read one
+//             full 128-byte line of each pixel; the first version read 32 bytes per pixel and stage and paid a third of
+//             its time re-fetching lines from L2), the whole B^T d B in registers, 36 ds_write_b32;
+//   consumer  A fragments from LDS one k-pair ahead, B fragments straight from L2, every register refilled for 4
+//             k-pairs later right after the MFMA that consumed it.
 __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpilogue ep, const float *__restrict__ x,
                                                        const float *__restrict__ U, float *__restrict__ out) {
     using namespace wino2;
@@ -103,41 +109,43 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
     const int t0 = blockIdx.x * 32, n0 = blockIdx.y * 64, phase = blockIdx.z;
     const int spc = P.Cr / BC;                           // stages per segment
     const int nstages = P.nseg * spc;
-    // ---- producer: lanes 0..47 of every wave: patch row pu = lane / 16, unit = (tile pt, channel quad pp)
-    const int pu = lane >> 4, unit = (lane & 15) + 16 * wave, pt = unit >> 1, pp = unit & 1;
-    const bool prod = pu < 3;
-    int tyx_ty = 0, tyx_tx = 0, tyx_n = 0;
+    // ---- producer: thread = (tile pt, channel quad cq)
+    const int pt = tid >> 3, cq = tid & 7;
+    int ty, tx, tn;
     bool tile_ok;
     {
         const long id = (long)t0 + pt;
         tile_ok = id < T;
         const long ii = tile_ok ? id : 0;
-        tyx_tx = ii % P.TW; tyx_ty = (ii / P.TW) % P.TH; tyx_n = ii / ((long)P.TW * P.TH);
-        if (prod && pu == 0 && pp == 0)      // element offset of this tile's output pixel (a=0, b=0), channel 0 (-1: no such tile)
+        tx = ii % P.TW; ty = (ii / P.TW) % P.TH; tn = ii / ((long)P.TW * P.TH);
+        if (cq == 0)         // element offset of this tile's output pixel (a=0, b=0), channel 0 (-1: no such tile)
             reinterpret_cast<long *>(smem + SMEM_FLOATS)[pt] =
-                tile_ok ? (((long)tyx_n * P.OH + tyx_ty * P.otile + P.o0r[phase]) * P.OW + tyx_tx * P.otile + P.o0c[phase]) * P.Ko : -1;
+                tile_ok ? (((long)tn * P.OH + ty * P.otile + P.o0r[phase]) * P.OW + tx * P.otile + P.o0c[phase]) * P.Ko : -1;
     }
-    unsigned xoff[3];
-    auto set_segment = [&](int sidx) {                  // byte offsets of this thread's 3 patch pixels, channel 4*pp
+    unsigned xoff[3][3];
+    auto set_segment = [&](int sidx) {                  // byte offsets of the 9 patch pixels, channel 4*cq
         const int gs = phase * P.nseg + sidx;
-        const int row = tyx_ty * P.tstep + P.r0[gs] + pu * P.pstep;
-        const bool rowok = prod && tile_ok && row >= 0 && row < P.IH;
 #pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            const int col = tyx_tx * P.tstep + P.c0[gs] + v * P.pstep;
-            xoff[v] = (rowok && col >= 0 && col < P.IW) ? (unsigned)(((((long)tyx_n * P.IH + row) * P.IW + col) * P.Cr + 4 * pp) * 4) : kOOB;
+        for (int u = 0; u < 3; ++u) {
+            const int row = ty * P.tstep + P.r0[gs] + u * P.pstep;
+            const bool rowok = tile_ok && row >= 0 && row < P.IH;
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const int col = tx * P.tstep + P.c0[gs] + v * P.pstep;
+                xoff[u][v] = (rowok && col >= 0 && col < P.IW) ? (unsigned)(((((long)tn * P.IH + row) * P.IW + col) * P.Cr + 4 * cq) * 4) : kOOB;
+            }
         }
     };
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (long)P.N * P.IH * P.IW * P.Cr * 4);
     const __amdgpu_buffer_rsrc_t ru = make_rsrc(U, (long)4 * 9 * P.Cr * P.Ko * 4);
-    const int vdst = (pu * 3) * FSV + (4 * pp) * LDT + pt;
-    const int src1 = (lane & 15) + 16;                   // lane holding patch row 1 of the same unit
+    const int vdst = (4 * cq) * LDT + pt;
     // ---- consumer: wave owns column block cb and frequencies fq + 2m
     const int cb = wave & 1, fq = wave >> 1;
     const unsigned ubase = (unsigned)(((long)kh * P.Ko + n0 + cb * 32 + l31) * 4);
     const unsigned ufreq = (unsigned)((long)P.Cr * P.Ko * 4), ukp = (unsigned)(2 * P.Ko * 4), ustage = (unsigned)(BC * P.Ko * 4);
     const unsigned useg = 9u * ufreq;
     const int nm = fq == 0 ? 5 : 4;
+    constexpr int NKP = BC / 2, BD = 4;                  // k-pairs per stage, B prefetch distance in k-pairs
 
     f32x16 acc[NM];
 #pragma unroll
@@ -151,64 +159,67 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
 #define W2_XL(E) (E)
 #endif
 #ifdef W2_ABLATE_VSTORE
-#define W2_VS(S) asm volatile("" ::"v"(mid));
+#define W2_VS(DST, VAL) asm volatile("" ::"v"(VAL))
 #else
-#define W2_VS(S) S
+#define W2_VS(DST, VAL) DST = VAL
 #endif
 #ifdef W2_ABLATE_BLOAD
 #define W2_BL 1.f + 0.f *
 #else
 #define W2_BL
 #endif
-    float4 rin[3];
-    float fb[4][NM], X[3][4];
-#define W2_XLOAD(S)                                                                                      \
+    float4 rin[3][3];
+    float fb[BD][NM];
+    // global -> registers: patch row U_ of stage S
+#define W2_XLOAD_ROW(S, U_)                                                                              \
     {                                                                                                    \
         const int sidx_ = (S) / spc, cs_ = (S) - sidx_ * spc;                                            \
-        if (cs_ == 0 && sidx_ < P.nseg) set_segment(sidx_);                                              \
+        if ((U_) == 0 && cs_ == 0 && sidx_ < P.nseg) set_segment(sidx_);                                 \
         const unsigned sx = (unsigned)(cs_ * BC * 4);          /* padded taps: kOOB + sx stays out of range */ \
-        _Pragma("unroll") for (int v = 0; v < 3; ++v) rin[v] = W2_XL(bufld4(rx, xoff[v] + sx));          \
+        _Pragma("unroll") for (int v = 0; v < 3; ++v) rin[U_][v] = W2_XL(bufld4(rx, xoff[U_][v] + sx));  \
     }
-    // row pass X = d B over the 3 pixels of this thread's patch row, 4 channels
-#define W2_ROWPASS                                                                                       \
-    X[0][0] = rin[0].x - rin[1].x; X[0][1] = rin[0].y - rin[1].y; X[0][2] = rin[0].z - rin[1].z; X[0][3] = rin[0].w - rin[1].w; \
-    X[1][0] = rin[1].x; X[1][1] = rin[1].y; X[1][2] = rin[1].z; X[1][3] = rin[1].w;                       \
-    X[2][0] = rin[2].x - rin[1].x; X[2][1] = rin[2].y - rin[1].y; X[2][2] = rin[2].z - rin[1].z; X[2][3] = rin[2].w - rin[1].w;
-    // column pass V = B^T X: rows 0 and 2 subtract row 1 (fetched from the lane 16 / 32 away), row 1 is itself
-#define W2_VSTORE(BUF, J)                                                                                \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                      \
-        const float mid = __shfl(X[J][e], src1, 64);                                                     \
-        W2_VS(if (prod) (BUF)[vdst + (J) * FSV + e * LDT] = pu == 1 ? X[J][e] : X[J][e] - mid;)           \
+    // registers -> LDS: B^T d B for channel E_ of the quad (row pass over the 3 columns, column pass over the 3 rows)
+#define W2_VSTORE_CH(BUF, E_, C_)                                                                        \
+    {                                                                                                    \
+        float X[3][3];                                                                                   \
+        _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                                  \
+            X[u][0] = rin[u][0].C_ - rin[u][1].C_; X[u][1] = rin[u][1].C_; X[u][2] = rin[u][2].C_ - rin[u][1].C_; \
+        }                                                                                                \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                  \
+            W2_VS((BUF)[vdst + (0 * 3 + j) * FSV + (E_) * LDT], X[0][j] - X[1][j]);                       \
+            W2_VS((BUF)[vdst + (1 * 3 + j) * FSV + (E_) * LDT], X[1][j]);                                 \
+            W2_VS((BUF)[vdst + (2 * 3 + j) * FSV + (E_) * LDT], X[2][j] - X[1][j]);                       \
+        }                                                                                                \
     }
+    // B fragment (k-pair KP of stage S, frequency fq + 2*M) into register slot KP % BD
 #define W2_BLOAD(KP, M, S)                                                                               \
     {                                                                                                    \
         const int sidx_ = (S) / spc, cs_ = (S) - sidx_ * spc;                                            \
-        fb[KP][M] = W2_BL bufld1s(ru, ubase, (unsigned)(phase * P.nseg + sidx_) * useg + (unsigned)(fq + 2 * (M)) * ufreq + \
-                                           (unsigned)cs_ * ustage + (KP) * ukp);                         \
+        fb[(KP) % BD][M] = W2_BL bufld1s(ru, ubase, (unsigned)(phase * P.nseg + sidx_) * useg + (unsigned)(fq + 2 * (M)) * ufreq + \
+                                                    (unsigned)cs_ * ustage + (KP) * ukp);                \
     }
 
-    W2_XLOAD(0)
+    W2_XLOAD_ROW(0, 0) W2_XLOAD_ROW(0, 1) W2_XLOAD_ROW(0, 2)
 #pragma unroll
-    for (int kp = 0; kp < 4; ++kp)
+    for (int kp = 0; kp < BD; ++kp)
 #pragma unroll
         for (int m = 0; m < NM; ++m)
             if (m < nm) W2_BLOAD(kp, m, 0)
-    W2_ROWPASS
-    W2_VSTORE(smem, 0) W2_VSTORE(smem, 1) W2_VSTORE(smem, 2)
-    W2_XLOAD(1)
+    W2_VSTORE_CH(smem, 0, x) W2_VSTORE_CH(smem, 1, y) W2_VSTORE_CH(smem, 2, z) W2_VSTORE_CH(smem, 3, w)
+    W2_XLOAD_ROW(1, 0) W2_XLOAD_ROW(1, 1) W2_XLOAD_ROW(1, 2)
     __syncthreads();
     const int abase = fq * FSV + kh * LDT + l31;
     for (int s = 0; s < nstages; ++s) {
         const float *cur = smem + (s & 1) * V_FLOATS;
         float *nxt = smem + ((s + 1) & 1) * V_FLOATS;
-        const int sn = s + 1 < nstages ? s + 1 : s;           // the last refill re-reads the last stage (unused)
+        const int sn = s + 1 < nstages ? s + 1 : s;           // the last refills re-read the last stage (unused)
         float fa[2][NM];                                   // A fragments of k-pair kp+1 are read while kp's MFMAs issue
 #pragma unroll
         for (int m = 0; m < NM; ++m)
             if (m < nm) fa[0][m] = cur[abase + 2 * m * FSV];
 #pragma unroll
-        for (int kp = 0; kp < 4; ++kp) {
-            if (kp + 1 < 4) {
+        for (int kp = 0; kp < NKP; ++kp) {
+            if (kp + 1 < NKP) {
 #pragma unroll
                 for (int m = 0; m < NM; ++m)
                     if (m < nm) fa[(kp + 1) & 1][m] = cur[abase + 2 * m * FSV + 2 * (kp + 1) * LDT];
@@ -216,24 +227,23 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
 #pragma unroll
             for (int m = 0; m < NM; ++m)
                 if (m < nm) {
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kp & 1][m], fb[kp][m], acc[m], 0, 0, 0);
-                    W2_BLOAD(kp, m, sn)
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kp & 1][m], fb[kp % BD][m], acc[m], 0, 0, 0);
+                    if (kp + BD < NKP) W2_BLOAD(kp + BD, m, s) else W2_BLOAD(kp + BD - NKP, m, sn)
                 }
-            if (kp == 0) {                             // tile s+1: transform + LDS stores
-                W2_ROWPASS
-                W2_VSTORE(nxt, 0)
-            } else if (kp == 1) {
-                W2_VSTORE(nxt, 1) W2_VSTORE(nxt, 2)
-            } else if (kp == 2) {                      // tile s+2: activations
-                W2_XLOAD(s + 2)
-            }
+            // tile s+1 -> LDS (one channel of the quad per k-pair), then tile s+2 -> registers (one patch row per k-pair)
+            if (kp == 0) W2_VSTORE_CH(nxt, 0, x)
+            else if (kp == 1) W2_VSTORE_CH(nxt, 1, y)
+            else if (kp == 2) W2_VSTORE_CH(nxt, 2, z)
+            else if (kp == 3) W2_VSTORE_CH(nxt, 3, w)
+            else if (kp == 5) W2_XLOAD_ROW(s + 2, 0)
+            else if (kp == 6) W2_XLOAD_ROW(s + 2, 1)
+            else if (kp == 7) W2_XLOAD_ROW(s + 2, 2)
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
-#undef W2_XLOAD
-#undef W2_ROWPASS
-#undef W2_VSTORE
+#undef W2_XLOAD_ROW
+#undef W2_VSTORE_CH
 #undef W2_BLOAD
 
 #ifdef W2_ABLATE_EPILOGUE
@@ -300,12 +310,11 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
 }
 
 // ------------------------------------------------------------------------------------------------
-// Measured against the direct kernels (CIFAR batch 64, tools/bench_conv.py with MMDGAN_WINO2=2): it wins where the
-// grid is large - D l2 3B-row dgrad 121 vs 146 us (1536 workgroups), D l4 3B dgrad 104 vs 120 (768), D l2 forward
-// 85 vs 94 (512) - and loses below (D l4 forward, 256 workgroups: 106 vs 81; the G layers at batch 64).  The forward
-// form is the weaker one: its stride-2 pixel gathers cost 25 of 79 us (16 bytes out of every 256-byte pixel per
-// stage).  Default (MMDGAN_WINO2=1): forward with >= 512 workgroups, input-gradient with >= 768; =0 never;
-// =2 every eligible shape (what the parity tests run).
+// Measured against the direct kernels (CIFAR batch 64, tools/bench_conv.py with MMDGAN_WINO2=2, weight transform
+// included): D l2 forward 70 vs 94 us (512 workgroups), 3B-row dgrad 115 vs 146 (1536); D l4 73 vs 81 (256) and
+// 100 vs 120 (768); D l6 3B dgrad 109 vs 113 (384); it loses below that (D l6 forward, 128 workgroups: 128 vs 84;
+// G's top layers at batch 64).  Default (MMDGAN_WINO2=1): forward with >= 256 workgroups, input-gradient with
+// >= 384; =0 never; =2 every eligible shape (what the parity tests run).
 static int wino2_mode() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("MMDGAN_WINO2"); v = e ? atoi(e) : 1; }
@@ -321,7 +330,7 @@ static bool wino2_shape_ok(const ConvDims &d, bool dgrad) {
     if (mode >= 2) return true;
     const long tiles = (long)d.N * (d.P / 2) * (d.Q / 2);          // per phase
     const long wgs = ((tiles + 31) / 32) * (ko / 64) * (dgrad ? 4 : 1);
-    return wgs >= (dgrad ? 768 : 512);
+    return wgs >= (dgrad ? 384 : 256);
 }
 bool wino2_eligible(const ConvDims &d, bool dgrad) { return wino2_shape_ok(d, dgrad); }
 static size_t wino2_bytes(const ConvDims &d) { return sizeof(float) * 36 * (size_t)d.C * d.K; }
@@ -357,6 +366,11 @@ static int wino2_launch(const ConvDims &d, const ConvEpilogue &ep, const float *
     }
     const long T = (long)d.N * P.TH * P.TW;
     const dim3 grid((unsigned)((T + 31) / 32), P.Ko / 64, dgrad ? 4 : 1);
+    static bool cap_raised = false;                     // 76 KB of dynamic LDS: above the 64 KB default cap
+    if (!cap_raised) {
+        (void)hipFuncSetAttribute((const void *)wino2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino2::LDS_BYTES);
+        cap_raised = true;
+    }
     hipLaunchKernelGGL(wino2_kernel, grid, dim3(256), wino2::LDS_BYTES, st, P, ep, in, U, out);
     return check_launch(dgrad ? "conv2d_dgrad(winograd 2x2)" : "conv2d_fwd(winograd 2x2)");
 }

@@ -399,17 +399,24 @@ class GanEngine:
         # G w G^T is computed once per step on the parameter-gradient stream (idle during the forward pass)
         # instead of inside every conv call.  scope -> [forward tensor or None, input-gradient tensor or None]
         self._wino = {}
+        self._wino_gen_ready = torch.cuda.Event()
         if self._side_wgrad:
-            for s in self.dis.specs:
-                if s.op != 'c':
-                    continue
-                c, h, w = s.in_shape_ref
-                fw = ops.wino_eligible(2 * B, h, w, c, s.out, s.R, s.stride, False)
-                bw = ops.wino_eligible(3 * B, h, w, c, s.out, s.R, s.stride, True)
-                if fw or bw:
-                    lead = (16,) if s.R == 3 else (4, 9)         # F(2x2,3x3) / F(2x2,2x2) on 4 parity segments
-                    self._wino[s.scope] = [torch.empty(lead + (c, s.out), device=dev) if fw else None,
-                                           torch.empty(lead + (s.out, c), device=dev) if bw else None]
+            for net, nf, nb in ((self.dis, 2 * B, 3 * B), (self.gen, B, B)):
+                for s in net.specs:
+                    if s.op == 'c':                              # conv geometry: input = layer input
+                        c, h, w = s.in_shape_ref
+                        k = s.out
+                    elif s.op == 'tc':                           # the conv whose input-gradient the tc layer is
+                        k = s.in_shape_ref[0]
+                        c, h, w = s.out, s.in_shape_ref[1] * s.stride, s.in_shape_ref[2] * s.stride
+                    else:
+                        continue
+                    fw = ops.wino_eligible(nf, h, w, c, k, s.R, s.stride, False)
+                    bw = ops.wino_eligible(nb, h, w, c, k, s.R, s.stride, True)
+                    if fw or bw:
+                        lead = (16,) if s.R == 3 else (4, 9)     # F(2x2,3x3) / F(2x2,2x2) on 4 parity segments
+                        self._wino[s.scope] = [torch.empty(lead + (c, k), device=dev) if fw else None,
+                                               torch.empty(lead + (k, c), device=dev) if bw else None, net]
         gs = self.gen.specs
         for below, above in zip(gs, gs[1:]):     # input-gradient of a tc layer into a linear layer: split-K target
             if above.op == 'tc' and (below.bn or below.act == 'linear'):
@@ -472,10 +479,13 @@ class GanEngine:
         if s.op == 'd':
             ops.gemm(x.reshape(n, -1), w, bias=bias, scale=scale, act=fused_act, out=tgt.view(n, -1))
         elif s.op == 'c':
-            wino = self._wino.get(s.scope, (None, None))[0] if net is self.dis and n == 2 * self.B else None
+            full = n == (2 * self.B if net is self.dis else self.B)      # the batch the transforms were sized for
+            wino = self._wino.get(s.scope, (None, None, None))[0] if full and is_training else None
             ops.conv2d_fwd(x, w, s.stride, bias=bias, scale=scale, act=fused_act, out=tgt, wino=wino)
         else:
-            ops.conv2d_dgrad(x, w, (tgt.shape[1], tgt.shape[2]), s.stride, bias=bias, scale=scale, act=fused_act, out=tgt)
+            wino = self._wino.get(s.scope, (None, None, None))[1] if n == self.B and is_training else None
+            ops.conv2d_dgrad(x, w, (tgt.shape[1], tgt.shape[2]), s.stride, bias=bias, scale=scale, act=fused_act, out=tgt,
+                             wino=wino)
         if s.bn:
             gamma, beta = net.p(s.scope + '/BN/BN/gamma'), net.p(s.scope + '/BN/BN/beta')
             mm, mv = net.state[s.scope + '/BN/BN/moving_mean'], net.state[s.scope + '/BN/BN/moving_variance']
@@ -516,6 +526,8 @@ class GanEngine:
             with torch.cuda.stream(self._sn_streams[i % len(self._sn_streams)]):
                 self._scales[s.scope] = self._sn_step(s) if s.sn else None
         b['dis_in'][:B].copy_(real)
+        if any(net is self.gen for _, _, net in self._wino.values()):
+            main.wait_event(self._wino_gen_ready)
         self.generate(z, is_training=True)                                   # writes dis_in[B:]
         for st in self._sn_streams:
             main.wait_stream(st)
@@ -583,7 +595,7 @@ class GanEngine:
                 else:
                     ops.conv2d_dgrad(dz, w, (yprev.shape[1], yprev.shape[2]), s.stride, scale=scale, act=prev.act,
                                      dact_of=yprev, dact_batch=2 * B, out=dprev,
-                                     wino=self._wino.get(s.scope, (None, None))[1])
+                                     wino=self._wino.get(s.scope, (None, None, None))[1])
                 dz = dprev
             else:
                 # below D l1 sits G's output: only the loss_gen rows go further, with G's last
@@ -666,7 +678,8 @@ class GanEngine:
                     # kernel split its K = R*R*Cout reduction into a buffer zeroed at step start
                     zeroed = dact is None and act_prev == 'linear' and any(dprev.data_ptr() == t.data_ptr()
                                                                             for t in self._zero_each_step)
-                    ops.conv2d_fwd(dz, w, s.stride, act=act_prev, dact_of=dact, out=dprev, out_zeroed=zeroed)
+                    ops.conv2d_fwd(dz, w, s.stride, act=act_prev, dact_of=dact, out=dprev, out_zeroed=zeroed,
+                                   wino=self._wino.get(s.scope, (None, None, None))[0])
                 dz = dprev
 
     # ---------------------------------------------------------------------------------------
@@ -697,14 +710,21 @@ class GanEngine:
             if arenas:
                 self._wg_stream.wait_stream(torch.cuda.current_stream())      # after the previous step's Adam
                 with torch.cuda.stream(self._wg_stream):
-                    for t in arenas:
-                        t.zero_()
-                    for scope, (uf, ub) in self._wino.items():
-                        w = self.dis.p(scope + '/kernel/kernel')
-                        if uf is not None:
-                            ops.wino_transform(w, False, out=uf)
-                        if ub is not None:
-                            ops.wino_transform(w, True, out=ub)
+                    # G's transformed weights first (its forward pass starts right away and waits on this event),
+                    # then the memsets, then D's (needed after G's forward / in the backward pass)
+                    for first in (True, False):
+                        for scope, (uf, ub, net) in self._wino.items():
+                            if (net is self.gen) != first:
+                                continue
+                            w = net.p(scope + '/kernel/kernel')
+                            if uf is not None:
+                                ops.wino_transform(w, False, out=uf)
+                            if ub is not None:
+                                ops.wino_transform(w, True, out=ub)
+                        if first:
+                            self._wino_gen_ready.record(self._wg_stream)
+                            for t in arenas:
+                                t.zero_()
             for t in self._zero_each_step:
                 if not any(t is a for a in arenas):
                     t.zero_()

@@ -210,7 +210,7 @@ def test_conv2d_dgrad_and_wgrad(ops, case):
 
 
 WINO2_CASES = [(16, 16, 16, 64, 128, 4, 2), (30, 12, 12, 32, 64, 4, 2), (6, 8, 16, 64, 64, 4, 2), (9, 4, 4, 128, 64, 4, 2),
-               (33, 8, 8, 40, 192, 4, 2)]
+               (33, 8, 8, 96, 192, 4, 2)]
 
 
 @pytest.mark.parametrize('case', WINO2_CASES, ids=[str(c) for c in WINO2_CASES])
