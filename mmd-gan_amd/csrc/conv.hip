@@ -124,6 +124,11 @@ static int wgrad_impl(const mmdgan_conv_geom *g, const float *x, const float *dy
     if (int rc = validate(g, what)) return rc;
     MMDGAN_REQUIRE(x && dy && dw, "%s: null pointer", what);
     const ConvDims d = conv_dims(*g);
+    if (!force_direct() && wino_wgrad_ok(d)) {
+        int rcw = wino_wgrad(d, x, dy, dw, (hipStream_t)stream);
+        if (rcw == 0 && dbias) rcw = mmdgan_colsum(dy, (long)d.N * d.P * d.Q, d.K, dbias, stream);
+        return rcw;
+    }
     if (!force_direct() && igemm_wgrad_ok(d)) return igemm_wgrad(d, x, dy, dw, dbias, (hipStream_t)stream);   // sums dy on the way
     int rc = 1;
     if (!force_direct() && !force_valu_thin() && thinm_wgrad_ok(d)) rc = thinm_wgrad(d, x, dy, dw, (hipStream_t)stream);

@@ -57,6 +57,9 @@ int wino_transform(const ConvDims &d, const float *w, bool flip, float *U, hipSt
 int wino_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, const float *U, float *y, hipStream_t st);
 int wino_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, const float *U, float *dx, hipStream_t st);
 
+bool wino_wgrad_ok(const ConvDims &d);
+int wino_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st);
+
 // Winograd F(2x2,2x2) for 4x4 / stride-2 layers and their input-gradient (conv_wino2.hip); U = 36*C*K floats
 bool wino2_eligible(const ConvDims &d, bool dgrad);
 bool wino2_fwd_ok(const ConvDims &d);

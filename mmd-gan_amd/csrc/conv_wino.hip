@@ -326,4 +326,227 @@ int wino_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const
     return wino_launch(d, ep, dy, w, U, dx, true, st);
 }
 
+
+
+// ================================================================================================
+// Weight gradient of the same 3x3 / stride-1 layers in the Winograd domain:
+//   dW = G^T [ sum_tiles (B^T d B) (.) (A dY A^T) ] G
+// i.e. per frequency f a GEMM dU_f[c][k] = sum_tiles V_f[tile][c] * dM_f[tile][k] whose reduction runs over the
+// 2x2 output tiles - 16 multiplies per tile and (c,k) instead of 36.
+//   * workgroup = 32 input channels x 64 output channels x all 16 frequencies (wave w: i = w, j = 0..3), a slice
+//     of the tile range (blockIdx.z); a stage is 8 tiles = 4 MFMA k-pairs = 32 MFMAs per wave.
+//   * V = B^T d B goes through LDS exactly as in the forward kernel (thread = tile, channel quad, patch row).
+//   * dM = A dY A^T never touches LDS: wave w needs row i = w only, and a lane (tile 2kp+kh, channel k) gets its
+//     four j-values from the four dY pixels of its tile with 6 adds - B fragments are built in registers from
+//     coalesced dword loads.
+//   * epilogue: G^T dU G (linear, so it is applied to the partial sums): j direction in registers, i direction
+//     across the waves through LDS, then 9 fp32 atomics per (c,k) into the zeroed dW - the same atomic traffic as
+//     the split direct kernel.
+struct TileWalk {             // running (tx, ty, image) of a tile index advanced by a fixed step
+    int tx, ty, n;
+};
+struct TileStep {
+    int dtx, dty, dn;
+};
+__device__ __forceinline__ TileStep make_step(int d, int TW, int TH) { return {d % TW, (d / TW) % TH, d / (TW * TH)}; }
+__device__ __forceinline__ TileWalk make_walk(long id, int TW, int TH) {
+    return {(int)(id % TW), (int)((id / TW) % TH), (int)(id / ((long)TW * TH))};
+}
+__device__ __forceinline__ void advance(TileWalk &t, const TileStep &s, int TW, int TH) {
+    t.tx += s.dtx;
+    const bool c1 = t.tx >= TW;
+    t.tx -= c1 ? TW : 0;
+    t.ty += s.dty + (c1 ? 1 : 0);
+    const bool c2 = t.ty >= TH;
+    t.ty -= c2 ? TH : 0;
+    t.n += s.dn + (c2 ? 1 : 0);
+}
+
+namespace winow {
+constexpr int BT = 8;                         // tiles per stage
+constexpr int LDC = 33;                       // V: floats per tile row (32 channels + 1)
+constexpr int FS = BT * LDC + 2;              // V: floats per frequency
+static_assert((4 * FS) % 32 == 8, "V frequency stride");
+constexpr int V_FLOATS = 16 * FS;
+constexpr int TS_FLOATS = 4 * 3 * 32 * 32;    // epilogue exchange buffer, one column block at a time
+constexpr int SMEM_FLOATS = 2 * V_FLOATS > TS_FLOATS ? 2 * V_FLOATS : TS_FLOATS;
+constexpr size_t LDS_BYTES = sizeof(float) * SMEM_FLOATS + sizeof(unsigned) * 4 * BT;   // + ring of dY tile offsets
+}  // namespace winow
+
+__global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(int N, int H, int W, int C, int K, const float *__restrict__ x,
+                                                            const float *__restrict__ dy, float *__restrict__ dw,
+                                                            int stages_per_split) {
+    using namespace winow;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int TH = H >> 1, TW = W >> 1;
+    const long T = (long)N * TH * TW;
+    const int nst_all = (int)((T + BT - 1) / BT);
+    const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 64;
+    const int s0 = blockIdx.z * stages_per_split, s1 = min(nst_all, s0 + stages_per_split);
+    if (s0 >= s1) return;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (long)N * H * W * C * 4);
+    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, (long)N * H * W * K * 4);
+    // ---- producer of V: thread = (tile of the stage pt, channel quad pp, patch row pr)
+    const int pt = tid >> 5, pp = (tid >> 2) & 7, pr = tid & 3;
+    TileWalk pw = make_walk((long)s0 * BT + pt, TW, TH);
+    const TileStep step8 = make_step(BT, TW, TH);
+    const float sa = pr == 3 ? -1.f : 1.f, sb = (pr & 1) ? 1.f : -1.f;
+    const int vdst = (pr * 4) * FS + pt * LDC + 4 * pp;
+    float4 rin[4];
+    unsigned *dyoff = reinterpret_cast<unsigned *>(smem + SMEM_FLOATS);      // [stage & 3][tile of the stage]
+    int pstage = s0;                          // stage the producer is loading
+    auto xload = [&]() {                      // the 4 pixels of patch row pr of the producer's current tile, then advance
+        if ((tid & 31) == 0)                  // byte offset of dY pixel (2ty, 2tx), channel 0, of this tile (consumers add the rest)
+            dyoff[(pstage & 3) * BT + pt] = pw.n < N ? (unsigned)((((pw.n * H + 2 * pw.ty) * W + 2 * pw.tx) * K) * 4) : kOOB;
+        ++pstage;
+        const int y = 2 * pw.ty - 1 + pr;
+        const bool rowok = pw.n < N && y >= 0 && y < H;
+        const unsigned base = (unsigned)((((pw.n * H + y) * W + 2 * pw.tx - 1) * C + c0 + 4 * pp) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int xx = 2 * pw.tx - 1 + j;
+#ifdef WW_ABLATE_XLOAD
+            rin[j] = make_float4(1.f, 2.f, 3.f, (float)j);
+#else
+            rin[j] = bufld4(rx, (rowok && xx >= 0 && xx < W) ? base + (unsigned)(j * C * 4) : kOOB);
+#endif
+        }
+        advance(pw, step8, TW, TH);
+    };
+    auto vstore = [&](float *buf) {
+        float X[4][4];
+        X[0][0] = rin[0].x - rin[2].x; X[0][1] = rin[0].y - rin[2].y; X[0][2] = rin[0].z - rin[2].z; X[0][3] = rin[0].w - rin[2].w;
+        X[1][0] = rin[1].x + rin[2].x; X[1][1] = rin[1].y + rin[2].y; X[1][2] = rin[1].z + rin[2].z; X[1][3] = rin[1].w + rin[2].w;
+        X[2][0] = rin[2].x - rin[1].x; X[2][1] = rin[2].y - rin[1].y; X[2][2] = rin[2].z - rin[1].z; X[2][3] = rin[2].w - rin[1].w;
+        X[3][0] = rin[1].x - rin[3].x; X[3][1] = rin[1].y - rin[3].y; X[3][2] = rin[1].z - rin[3].z; X[3][3] = rin[1].w - rin[3].w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int other = __builtin_amdgcn_update_dpp(0, __float_as_int(X[j][e]), 0x5A, 0xF, 0xF, false);   // quad_perm [2,2,1,1]
+                buf[vdst + j * FS + e] = fmaf(sb, __int_as_float(other), sa * X[j][e]);
+            }
+    };
+    // ---- consumer: this lane's tile for k-pair kp of a stage is s*8 + 2*kp + kh, its channel n0 + cb*32 + l31
+    const unsigned kcol = (unsigned)((n0 + l31) * 4);
+    const unsigned dyrow = (unsigned)(W * K * 4), dypix = (unsigned)(K * 4);
+    // A dY A^T, row i = wave: with e[b] = wa*dY[0][b] + wb*dY[1][b]  ->  dM[i][.] = (e0, e0 + e1, e0 - e1, -e1)
+    const float wa = wave == 3 ? 0.f : 1.f, wb = wave == 0 ? 0.f : (wave == 1 ? 1.f : -1.f);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int fl = 0; fl < 4; ++fl)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[fl][cb][r] = 0.f;
+
+    float dyv[2][2][4];                        // [slot][cb][pixel a*2+b] of the k-pair being prefetched
+    auto dyload = [&](int slot, int stage, int kp) {
+        const unsigned off = dyoff[(stage & 3) * BT + 2 * kp + kh] + kcol;     // kOOB + kcol stays out of range
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+#ifdef WW_ABLATE_DYLOAD
+                dyv[slot][cb][p] = (float)(p + cb);
+#else
+                dyv[slot][cb][p] = bufld1s(rdy, off, (unsigned)(cb * 128) + (p >> 1) * dyrow + (p & 1) * dypix);
+#endif
+            }
+    };
+
+    xload();
+    vstore(smem);
+    xload();
+    __syncthreads();
+    dyload(0, s0, 0);
+    const int abase = (4 * wave) * FS + kh * LDC + l31;
+    for (int s = s0; s < s1; ++s) {
+        const float *cur = smem + ((s - s0) & 1) * V_FLOATS;
+        float *nxt = smem + ((s - s0 + 1) & 1) * V_FLOATS;
+#pragma unroll
+        for (int kp = 0; kp < 4; ++kp) {
+            float fa[4];
+#pragma unroll
+            for (int fl = 0; fl < 4; ++fl) fa[fl] = cur[abase + fl * FS + 2 * kp * LDC];
+            if (kp < 3) dyload((kp + 1) & 1, s, kp + 1);      // next k-pair; the last one prefetches the next stage's first
+            else dyload(0, s + 1, 0);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const float *d = dyv[kp & 1][cb];
+                const float e0 = fmaf(wb, d[2], wa * d[0]), e1 = fmaf(wb, d[3], wa * d[1]);
+                const float bq[4] = {e0, e0 + e1, e0 - e1, -e1};
+#pragma unroll
+                for (int fl = 0; fl < 4; ++fl)
+                    acc[fl][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fl], bq[fl], acc[fl][cb], 0, 0, 0);
+            }
+            if (kp == 0) vstore(nxt);          // tile s+1 -> LDS
+            else if (kp == 2) xload();         // tile s+2 -> registers
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+
+    // ---- G^T dU G on the partial sums, then atomics.  Ts[i][t][c][k 32], one column block at a time
+    float *Ts = smem;
+    const int kk = tid & 31, cr = tid >> 5;              // lanes along k: one atomic instruction = two 128-byte runs
+    const long CK = (long)C * K;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cl = (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const float a0 = acc[0][cb][r], a1 = acc[1][cb][r], a2 = acc[2][cb][r], a3 = acc[3][cb][r];
+            const float h = 0.5f * (a1 + a2);
+            Ts[((wave * 3 + 0) * 32 + cl) * 32 + l31] = a0 + h;
+            Ts[((wave * 3 + 1) * 32 + cl) * 32 + l31] = 0.5f * (a1 - a2);
+            Ts[((wave * 3 + 2) * 32 + cl) * 32 + l31] = h + a3;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cc = cr + 8 * q;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const float z0 = Ts[((0 * 3 + t) * 32 + cc) * 32 + kk], z1 = Ts[((1 * 3 + t) * 32 + cc) * 32 + kk];
+                const float z2 = Ts[((2 * 3 + t) * 32 + cc) * 32 + kk], z3 = Ts[((3 * 3 + t) * 32 + cc) * 32 + kk];
+                float *dst = dw + ((long)t * CK) + (long)(c0 + cc) * K + n0 + cb * 32 + kk;      // dw[r][t][c][k], r = 0
+                const float h = 0.5f * (z1 + z2);
+#ifdef WW_ABLATE_ATOMICS
+                if (h == 123.456f) dst[0] = z0 + z3;
+#else
+                atomicAdd(dst, z0 + h);
+                atomicAdd(dst + 3 * CK, 0.5f * (z1 - z2));
+                atomicAdd(dst + 6 * CK, h + z3);
+#endif
+            }
+        }
+        __syncthreads();
+    }
+}
+
+bool wino_wgrad_ok(const ConvDims &d) {
+    static int en = -1;
+    if (en < 0) { const char *e = getenv("MMDGAN_WINO_WGRAD"); en = (e && e[0] == '0') ? 0 : 1; }
+    return en && wino_enabled() && d.R == 3 && d.stride == 1 && d.pad == 1 && d.H % 2 == 0 && d.W % 2 == 0 && d.C % 32 == 0 &&
+           d.K % 64 == 0 && (long)d.N * (d.H / 2) * (d.W / 2) >= (wino_min_tiles() < 256 ? wino_min_tiles() : 256);   // 79 vs 89 us at 512 tiles (D l7)
+}
+
+int wino_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st) {
+    const long T = (long)d.N * (d.H / 2) * (d.W / 2);
+    const int nst = (int)((T + winow::BT - 1) / winow::BT);
+    const long base = (long)(d.C / 32) * (d.K / 64);
+    int split = (int)((512 + base - 1) / base);                    // ~512 workgroups
+    if (split > nst / 8) split = nst / 8 > 0 ? nst / 8 : 1;         // >= 8 stages (256 MFMAs per wave) per workgroup
+    int sps = (nst + split - 1) / split;
+    split = (nst + sps - 1) / sps;
+    if (zero_output(dw, sizeof(float) * 9 * (size_t)d.C * d.K, st) != hipSuccess) return check_launch("conv2d_wgrad memset");
+    hipLaunchKernelGGL(wino_wgrad_kernel, dim3(d.C / 32, d.K / 64, split), dim3(256), winow::LDS_BYTES, st, d.N, d.H, d.W, d.C,
+                       d.K, x, dy, dw, sps);
+    return check_launch("conv2d_wgrad(winograd)");
+}
+
 }  // namespace mmdgan

@@ -275,7 +275,14 @@ def test_conv2d_winograd_path(ops, case):
     xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
     wt = torch.tensor(w, dtype=torch.float64)
     yt = R.conv2d_same(xt, wt, s)
-    gx, = torch.autograd.grad((yt * torch.tensor(dy, dtype=torch.float64)).sum(), [xt])
+    wt.requires_grad_(True)
+    gx, gw = torch.autograd.grad((R.conv2d_same(xt, wt, s) * torch.tensor(dy, dtype=torch.float64)).sum(), [xt, wt])
+    wt = wt.detach()
+    if C % 32 == 0:                                      # Winograd-domain weight gradient (+ fused-API bias gradient)
+        db = torch.empty(K, device='cuda')
+        dw = ops.conv2d_wgrad(nhwc(x), nhwc(dy), ksz, s, dbias=db)
+        assert rel_err(dw.cpu().numpy(), gw.numpy()) <= RTOL
+        assert rel_err(db.cpu().numpy(), dy.astype(np.float64).sum((0, 2, 3))) <= RTOL
     ops.set_workspace()
     try:
         sc = np.float32(0.37)
