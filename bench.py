@@ -49,33 +49,38 @@ def parse():
 
 
 def dominant_kernel_probe(eng, reps=20, warm=3):
-    """HIP-event timing of the single heaviest launch of the step, issued on the stream it normally
-    runs on: the weight gradient of the widest 3x3 D layer at batch 2B (D l5 for CIFAR)."""
+    """HIP-event timing of one launch of the kernel with the largest share of the step
+    (profiles/*_kernel_stats_single_stream.txt): the input-gradient of D's first 4x4 stride-2 layer over the 3B
+    rows of the batched backward pass (CIFAR: D l2, wino2_kernel, 1536 workgroups), issued exactly as the
+    engine issues it.  `flops` are the algorithmic FLOPs of that input-gradient (the F(2x2,2x2) kernel issues
+    9/16 of them as MFMAs)."""
     from mmdgan_hip import ops
-    best = None
-    for s in eng.dis.specs:
-        if s.op == 'c' and s.R == 3 and s.stride == 1 and s.in_shape_ref[0] >= 64:
-            c, h, w = s.in_shape_ref
-            flops = 2.0 * 2 * eng.B * h * w * s.R * s.R * c * s.out
-            if best is None or flops >= best[1]:
-                best = (s, flops)
-    if best is None:
+    specs = eng.dis.specs
+    li = next((i for i, s in enumerate(specs) if i > 0 and s.op == 'c' and s.R == 4 and s.stride == 2), None)
+    if li is None:
         return None
-    s, flops = best
-    li = eng.dis.specs.index(s)
-    x = eng.buf[eng.dis.specs[li - 1].scope + '#y']
-    dz = eng.buf[s.scope + '#dz']
-    gw = torch.empty(s.kernel_shape, device=x.device)
+    s, prev = specs[li], specs[li - 1]
+    c, h, w = s.in_shape_ref
+    B = eng.B
+    dz, yprev, dprev = eng.buf[s.scope + '#dz'], eng.buf[prev.scope + '#y'], eng.buf[prev.scope + '#dz']
+    wgt, scale = eng.dis.p(s.scope + '/kernel/kernel'), eng._scales[s.scope]
+    wino = eng._wino.get(s.scope, (None, None, None))[1]
+    flops = 2.0 * 3 * B * (h // 2) * (w // 2) * s.R * s.R * c * s.out
+
+    def launch():
+        ops.conv2d_dgrad(dz, wgt, (h, w), s.stride, scale=scale, act=prev.act, dact_of=yprev, dact_batch=2 * B, out=dprev,
+                         wino=wino)
     for _ in range(warm):
-        ops.conv2d_wgrad(x, dz, s.R, s.stride, out=gw)
+        launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        ops.conv2d_wgrad(x, dz, s.R, s.stride, out=gw)
+        launch()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    return {'kernel': 'igemm_wgrad(%s: %dx%dx%d->%d, batch %d)' % (s.scope, h, w, c, s.out, 2 * eng.B),
+    return {'kernel': 'conv2d_dgrad(%s: %dx%dx%d <- %d 4x4/2, %d rows; %s)' % (
+                s.scope, h, w, c, s.out, 3 * B, 'wino2_kernel F(2x2,2x2)' if wino is not None else 'library choice'),
             'flops': flops, 'ms': ms, 'tflops': flops / ms / 1e9}
 
 

@@ -21,13 +21,15 @@ summary('eager', 'e', 25, tag + '_kernel_stats_single_stream.txt',
         '# MMDGAN_SIDE_WGRAD=0 MMDGAN_SN_STREAMS=1 rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-graph --no-cpu-baseline')
 summary('probe', 'p', 1, tag + '_dominant_kernel_stats.txt',
         '# rocprofv3 --kernel-trace --stats -- python bench.py --probe-only --probe-reps 50\n'
-        '# (one eager step, then 50 launches of the dominant kernel: D l7 weight gradient; its row is igemm_wgrad_kernel<64, 64, true, 1>)')
+        '# (one eager step, then 50 launches of the dominant kernel: D l2 3B-row input-gradient; its row is wino2_kernel)')
 
 def pmc(sub, pre):
     rows = list(csv.DictReader(open(os.path.join(src, sub, pre + '_counter_collection.csv'))))
     acc = collections.defaultdict(list)
+    calls = collections.Counter(r['Kernel_Name'] for r in rows)
+    top = calls.most_common(1)[0][0]                      # the probe's 50 launches dominate the run
     for r in rows:
-        if 'igemm_wgrad_kernel' in r['Kernel_Name']:
+        if r['Kernel_Name'] == top:
             acc[(r['Counter_Name'], r['Grid_Size'])].append(float(r['Counter_Value']))
     # the probe launches are the most frequent grid size
     best = {}
@@ -46,7 +48,7 @@ out = {'kernel': probe['kernel'], 'launches_profiled': fetch['FETCH_SIZE'][1],
        'FETCH_SIZE_KiB_raw': fetch_kb, 'WRITE_SIZE_KiB_raw': write_kb,
        'hbm_bytes_per_launch': hbm,
        'correction': 'FETCH_SIZE x2 (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section); '
-                     'WRITE_SIZE uncorrected (split-K fp32 atomics)',
+                     'WRITE_SIZE uncorrected',
        'algorithmic_bytes_per_launch': None,
        'SQ_VALU_MFMA_BUSY_CYCLES': mfma_busy, 'GRBM_GUI_ACTIVE_sum_over_8_XCD': gui,
        'mfma_busy_frac_of_simd_cycles': mfma_busy / (gui / 8 * 1024),
