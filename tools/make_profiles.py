@@ -26,8 +26,7 @@ summary('probe', 'p', 1, tag + '_dominant_kernel_stats.txt',
 def pmc(sub, pre):
     rows = list(csv.DictReader(open(os.path.join(src, sub, pre + '_counter_collection.csv'))))
     acc = collections.defaultdict(list)
-    calls = collections.Counter(r['Kernel_Name'] for r in rows)
-    top = calls.most_common(1)[0][0]                      # the probe's 50 launches dominate the run
+    top = TOP_KERNEL                                      # the kernel with the largest total time in the probe run
     for r in rows:
         if r['Kernel_Name'] == top:
             acc[(r['Counter_Name'], r['Grid_Size'])].append(float(r['Counter_Value']))
@@ -39,6 +38,7 @@ def pmc(sub, pre):
     return best
 
 probe = json.load(open(os.path.join(src, 'probe.json')))['dominant_kernel']
+TOP_KERNEL = next(csv.DictReader(open(os.path.join(src, 'probe', 'p_kernel_stats.csv'))))['Name']
 fetch, write, sq = pmc('pmc_fetch', 'f'), pmc('pmc_write', 'w'), pmc('pmc_sq', 'q')
 fetch_kb, write_kb = fetch['FETCH_SIZE'][2], write['WRITE_SIZE'][2]
 # MI355X_MICROARCH.md, HBM section: FETCH_SIZE on gfx950 reports half of the bytes of wide coalesced reads -> x2; KiB units
