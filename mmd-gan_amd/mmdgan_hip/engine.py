@@ -417,6 +417,15 @@ class GanEngine:
                         lead = (16,) if s.R == 3 else (4, 9)     # F(2x2,3x3) / F(2x2,2x2) on 4 parity segments
                         self._wino[s.scope] = [torch.empty(lead + (c, k), device=dev) if fw else None,
                                                torch.empty(lead + (k, c), device=dev) if bw else None, net]
+        # The batch-1 convolutions of the power iteration take the library's own route; should one of them be
+        # Winograd-eligible (tiny thresholds, as in the parity tests) the library transforms its weights into the
+        # shared workspace inside the call - one user at a time, so then all SN chains share one stream.
+        for s in self.dis.specs:
+            if s.sn and s.op == 'c':
+                c, h, w = s.in_shape_ref
+                if ops.wino_eligible(1, h, w, c, s.out, s.R, s.stride, False) or ops.wino_eligible(1, h, w, c, s.out, s.R, s.stride, True):
+                    self._sn_streams = self._sn_streams[:1]
+                    break
         gs = self.gen.specs
         for below, above in zip(gs, gs[1:]):     # input-gradient of a tc layer into a linear layer: split-K target
             if above.op == 'tc' and (below.bn or below.act == 'linear'):

@@ -48,7 +48,16 @@ def _p(t):
     return t.data_ptr()
 
 
+import os as _os
+_raw_stream = None if _os.environ.get('MMDGAN_SLOW_STREAM') else getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream.  torch.cuda.current_stream() builds a Stream object and resolves the
+    device index through several Python layers - measured at a third of the host time of an eagerly issued
+    step (150 calls) - the raw accessor is one C call."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
