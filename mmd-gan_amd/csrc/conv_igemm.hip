@@ -765,6 +765,11 @@ int igemm_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, f
             if (eff > best + 1e-9) { best = eff; split = sp; }
         }
     }
+    {
+        static int forced = -2;              // MMDGAN_WGRAD_SPLIT=n forces the pixel-reduction split (tuning aid)
+        if (forced == -2) { const char *e = getenv("MMDGAN_WGRAD_SPLIT"); forced = e ? atoi(e) : -1; }
+        if (forced > 0) split = forced;
+    }
     int sps = (nstages + split - 1) / split;
     split = (nstages + sps - 1) / sps;
     if (split > 1 && zero_output(dw, sizeof(float) * (long)rows * d.K, st) != hipSuccess)

@@ -140,7 +140,10 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
     const __amdgpu_buffer_rsrc_t ru = make_rsrc(U, (long)4 * 9 * P.Cr * P.Ko * 4);
     const int vdst = (4 * cq) * LDT + pt;
     // ---- consumer: wave owns column block cb and frequencies fq + 2m
-    const int cb = wave & 1, fq = wave >> 1;
+    // 18 accumulators over 4 waves = 5,5,4,4: odd workgroups rotate the roles so that, with two workgroups per CU,
+    // every SIMD carries 9 of them
+    const int wrole = (wave + ((blockIdx.x & 1) << 1)) & 3;
+    const int cb = wrole & 1, fq = wrole >> 1;
     const unsigned ubase = (unsigned)(((long)kh * P.Ko + n0 + cb * 32 + l31) * 4);
     const unsigned ufreq = (unsigned)((long)P.Cr * P.Ko * 4), ukp = (unsigned)(2 * P.Ko * 4), ustage = (unsigned)(BC * P.Ko * 4);
     const unsigned useg = 9u * ufreq;
