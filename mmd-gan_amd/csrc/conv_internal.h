@@ -57,6 +57,8 @@ int wino_transform(const ConvDims &d, const float *w, bool flip, float *U, hipSt
 int wino_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, const float *U, float *y, hipStream_t st);
 int wino_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, const float *U, float *dx, hipStream_t st);
 
+// in-place bias / activation / activation-derivative pass after a split-reduction launch (conv_wino.hip)
+int epilogue_pass(float *y, long total, int Ko, const ConvEpilogue &ep, hipStream_t st);
 bool wino_wgrad_ok(const ConvDims &d);
 int wino_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st);
 

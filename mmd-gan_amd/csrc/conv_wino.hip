@@ -103,10 +103,13 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float *__restric
 // lane, 128 contiguous bytes per half-wave) are loaded from L2 straight into the MFMA operand registers,
 // each refilled for the next stage right after the MFMA that consumed it (measured on the D l3 shape:
 // staging U through LDS cost 10 of 60 us).
-template <int BN>
+// SPLIT: blockIdx.z takes a slice of the channel reduction and ADDS scale * (A^T M A) into a zeroed output with
+// atomics (the transform is linear); bias / activation follow in epilogue_pass_kernel.  For launches whose tile
+// count alone cannot fill the chip (D l7 forward at batch 128: 16 x 8 workgroups on 256 CUs).
+template <int BN, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void wino_kernel(int N, int H, int W, int Cr, int Ko, ConvEpilogue ep,
                                                       const float *__restrict__ x, const float *__restrict__ U,
-                                                      float *__restrict__ out) {
+                                                      float *__restrict__ out, int stages_per_split) {
     using Cf = wino::Cfg<BN>;
     constexpr int BC = wino::BC, LDT = wino::LDT, FSV = wino::FSV, NCB = Cf::NCB, VF = wino::V_FLOATS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -139,7 +142,8 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(int N, int H, int W, int C
     // B fragment of group g = (kp = g>>2, fl = g&3), column block cb: U[4*wave + fl][c0 + 2*kp + kh][n0 + cb*32 + l31]
     const unsigned ubase = (unsigned)(((((long)4 * wave) * Cr + kh) * Ko + n0 + l31) * 4);
     const unsigned ustage = (unsigned)(BC * Ko * 4), ufreq = (unsigned)((long)Cr * Ko * 4), ukp = (unsigned)(2 * Ko * 4);
-    const int nstages = Cr / BC;
+    const int s_begin = SPLIT ? blockIdx.z * stages_per_split : 0;
+    const int nstages = SPLIT ? min(Cr / BC, s_begin + stages_per_split) : Cr / BC;      // = end of this block's stage range
     constexpr int NG = 2 * BC, PF = 3;                  // MFMA groups per stage, A-fragment prefetch distance
 
     f32x16 acc[4][NCB];
@@ -174,12 +178,12 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(int N, int H, int W, int C
         fb[G][cb] = bufld1s(ru, ubase, (unsigned)(S) * ustage + ((G) & 3) * ufreq + ((G) >> 2) * ukp + cb * 128);
 
     // prologue: tile 0 -> LDS, tile 1 -> registers, B fragments of stage 0
-    WINO_XLOAD(0)
+    WINO_XLOAD(s_begin)
 #pragma unroll
-    for (int g = 0; g < NG; ++g) WINO_BLOAD(g, 0)
+    for (int g = 0; g < NG; ++g) WINO_BLOAD(g, s_begin)
     WINO_ROWPASS
     WINO_VSTORE(smem, 0) WINO_VSTORE(smem, 1) WINO_VSTORE(smem, 2) WINO_VSTORE(smem, 3)
-    WINO_XLOAD(1)
+    WINO_XLOAD(s_begin + 1)
     __syncthreads();
     // Same hand pipeline as the direct kernels (conv_igemm.hip mainloop): per stage a wave issues NG groups
     // of NCB MFMAs; A fragments are read from LDS PF groups ahead; each group's B registers are refilled
@@ -187,9 +191,9 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(int N, int H, int W, int C
     // of tile s+2 sit behind individual groups (sched_barrier keeps hipcc from re-clumping them); one
     // barrier per stage.
     const int abase = (4 * wave) * FSV + kh * LDT + l31;
-    for (int s = 0; s < nstages; ++s) {
-        const float *cur = smem + (s & 1) * VF;
-        float *nxt = smem + ((s + 1) & 1) * VF;
+    for (int s = s_begin; s < nstages; ++s) {
+        const float *cur = smem + ((s - s_begin) & 1) * VF;
+        float *nxt = smem + ((s - s_begin + 1) & 1) * VF;
         const int sn = s + 1 < nstages ? s + 1 : s;           // the last refill re-reads the last stage (unused)
         float fa[NG];
 #pragma unroll
@@ -255,6 +259,11 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(int N, int H, int W, int C
                     if (a == 0) v = make_float4(z0.x + z1.x + z2.x, z0.y + z1.y + z2.y, z0.z + z1.z + z2.z, z0.w + z1.w + z2.w);
                     else v = make_float4(z1.x - z2.x - z3.x, z1.y - z2.y - z3.y, z1.z - z2.z - z3.z, z1.w - z2.w - z3.w);
                     const long o = ob + ((long)a * W + b) * Ko + ch;
+                    if (SPLIT) {
+                        atomicAdd(out + o, v.x * sc); atomicAdd(out + o + 1, v.y * sc);
+                        atomicAdd(out + o + 2, v.z * sc); atomicAdd(out + o + 3, v.w * sc);
+                        continue;
+                    }
                     v.x = v.x * sc + bv.x; v.y = v.y * sc + bv.y; v.z = v.z * sc + bv.z; v.w = v.w * sc + bv.w;
                     if (ep.dact) {
                         const float4 yv = *reinterpret_cast<const float4 *>(ep.dact + ep.dact_index(o));
@@ -272,6 +281,37 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(int N, int H, int W, int C
     }
 }
 
+// y = act(y + bias[ch])  or  y *= act'(dact[...])  in place: the non-linear part of the epilogue after a split launch
+__global__ __launch_bounds__(256) void epilogue_pass_kernel(float *__restrict__ y, long total4, int Ko, ConvEpilogue ep) {
+    const long stride = (long)gridDim.x * 256;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total4; q += stride) {
+        const long o = q * 4;
+        const int ch = (int)(o % Ko);
+        float4 v = reinterpret_cast<float4 *>(y)[q];
+        if (ep.bias) {
+            const float4 bv = *reinterpret_cast<const float4 *>(ep.bias + ch);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        }
+        if (ep.dact) {
+            const float4 yv = *reinterpret_cast<const float4 *>(ep.dact + ep.dact_index(o));
+            v.x *= act_bwd_from_out(yv.x, ep.act); v.y *= act_bwd_from_out(yv.y, ep.act);
+            v.z *= act_bwd_from_out(yv.z, ep.act); v.w *= act_bwd_from_out(yv.w, ep.act);
+        } else {
+            v.x = act_fwd(v.x, ep.act); v.y = act_fwd(v.y, ep.act);
+            v.z = act_fwd(v.z, ep.act); v.w = act_fwd(v.w, ep.act);
+        }
+        reinterpret_cast<float4 *>(y)[q] = v;
+    }
+}
+
+int epilogue_pass(float *y, long total, int Ko, const ConvEpilogue &ep, hipStream_t st) {
+    if (!ep.bias && !ep.dact && ep.act == MMDGAN_ACT_LINEAR) return MMDGAN_OK;
+    long blocks = (total / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(epilogue_pass_kernel, dim3((unsigned)blocks), dim3(256), 0, st, y, total / 4, Ko, ep);
+    return check_launch("conv epilogue pass");
+}
+
 // ------------------------------------------------------------------------------------------------
 static bool wino_enabled() {       // MMDGAN_WINO=0 keeps the 3x3 layers on the direct implicit-GEMM kernels
     static int v = -1;
@@ -280,8 +320,11 @@ static bool wino_enabled() {       // MMDGAN_WINO=0 keeps the 3x3 layers on the 
 }
 
 // below ~768 tiles (24 x K/64 workgroups) the grid no longer fills the chip and the direct kernel wins
-// (measured: D l7 forward at batch 128 = 512 tiles: 92 us either way; 768 tiles: 116 vs 160 us).
-// MMDGAN_WINO_MIN_TILES overrides (the parity tests use small problems).
+// (measured: D l7 forward at batch 128 = 512 tiles: 92 us either way; 768 tiles: 101 vs 160 us).  Splitting the
+// channel reduction (wino_kernel<.., true>) does not rescue the small launches either - memset + atomics + the
+// activation pass cost what the extra workgroups gain (D l7 forward 98 vs 92 direct, 3B dgrad 139 vs 101
+// unsplit) - so it is only used below 96 workgroups.  MMDGAN_WINO_MIN_TILES overrides (the parity tests use small
+// problems, which is also what exercises the split path).
 static long wino_min_tiles() {
     static long v = -1;
     if (v < 0) { const char *e = getenv("MMDGAN_WINO_MIN_TILES"); v = e ? atol(e) : 768; }
@@ -314,8 +357,28 @@ static int wino_launch(const ConvDims &d, const ConvEpilogue &ep, const float *i
         U = ws;
     }
     const long T = (long)d.N * (d.H / 2) * (d.W / 2);
+    const long wgs = ((T + 31) / 32) * (ko / 64);
+    const int nstages = cr / wino::BC;
+    int split = 1;
+    if (wgs < 96) {                                      // far too few tiles for 256 CUs: split the channel reduction
+        split = (int)((512 + wgs - 1) / wgs);
+        if (split > nstages / 8) split = nstages / 8;    // >= 8 stages (256 MFMAs per wave) per workgroup
+        if (split < 1) split = 1;
+    }
+    if (split > 1) {
+        const int sps = (nstages + split - 1) / split;
+        split = (nstages + sps - 1) / sps;
+        const long total = (long)d.N * d.H * d.W * ko;
+        if (hipMemsetAsync(out, 0, sizeof(float) * total, st) != hipSuccess) return check_launch("conv2d(winograd) memset");
+        const dim3 grid((unsigned)((T + 31) / 32), ko / 64, split);
+        hipLaunchKernelGGL((wino_kernel<64, true>), grid, dim3(256), (wino::Cfg<64>::LDS_BYTES), st, d.N, d.H, d.W, cr, ko, ep, in,
+                           U, out, sps);
+        if (int rc = check_launch(flip ? "conv2d_dgrad(winograd split)" : "conv2d_fwd(winograd split)")) return rc;
+        return epilogue_pass(out, total, ko, ep, st);
+    }
     const dim3 grid((unsigned)((T + 31) / 32), ko / 64);
-    hipLaunchKernelGGL((wino_kernel<64>), grid, dim3(256), (wino::Cfg<64>::LDS_BYTES), st, d.N, d.H, d.W, cr, ko, ep, in, U, out);
+    hipLaunchKernelGGL((wino_kernel<64, false>), grid, dim3(256), (wino::Cfg<64>::LDS_BYTES), st, d.N, d.H, d.W, cr, ko, ep, in, U,
+                       out, nstages);
     return check_launch(flip ? "conv2d_dgrad(winograd)" : "conv2d_fwd(winograd)");
 }
 

@@ -21,9 +21,9 @@ int main(int argc, char **argv) {
 #endif
     const dim3 grid((unsigned)((T + 31) / 32), K / PBN);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((wino_kernel<PBN>), grid, dim3(256), (wino::Cfg<PBN>::LDS_BYTES), 0, N, H, H, C, K, ep, x, U, y);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((wino_kernel<PBN, false>), grid, dim3(256), (wino::Cfg<PBN>::LDS_BYTES), 0, N, H, H, C, K, ep, x, U, y, C / mmdgan::wino::BC);
     (void)hipEventRecord(e0);
-    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((wino_kernel<PBN>), grid, dim3(256), (wino::Cfg<PBN>::LDS_BYTES), 0, N, H, H, C, K, ep, x, U, y);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((wino_kernel<PBN, false>), grid, dim3(256), (wino::Cfg<PBN>::LDS_BYTES), 0, N, H, H, C, K, ep, x, U, y, C / mmdgan::wino::BC);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     const dim3 wg((K + 31) / 32, (C + 31) / 32);
