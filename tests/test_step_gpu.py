@@ -152,3 +152,49 @@ def test_step_matches_oracle_mfma_path(loss_type):
                 du, dr = v.astype(np.float64) - before, ref - before
                 assert np.linalg.norm(du - dr) <= 0.1 * np.linalg.norm(dr) + 1e-12, (step, n)
                 assert np.abs(v - ref).max() <= 2.5 * 5e-4, (step, n)
+
+
+@pytest.mark.parametrize('config', ['cifar', 'stl', 'celeba'])
+def test_step_on_the_shipped_architectures(config):
+    """the full-width architectures of configs.py (the bench workloads) at batch 8: with the test thresholds every
+    3x3 layer runs the Winograd kernels (forward, input-gradient, weight-gradient) and every 4x4 stride-2 layer the
+    F(2x2,2x2) ones, in their real channel counts and image sizes.  Two teacher-forced steps against the fp64
+    oracle: generated images, D scores and losses each step, all gradients (L2) at the second."""
+    import configs
+    from mmdgan_hip.engine import GanEngine
+    arch, lr = configs.CONFIGS[config]()
+    B = 8
+    c, h, w = arch['input'][0]
+    eng = GanEngine(arch, 'rep', tuple(lr), batch_size=B, seed=5)
+    ora = R.OracleGan(arch, 'rep', tuple(lr), dtype=torch.float64, params=eng.get_variables())
+    rs = np.random.RandomState(7)
+    last = eng.dis.specs[-1].scope
+    for step in range(2):
+        z = rs.randn(B, arch['code'][0][0]).astype(np.float32)
+        real = rs.uniform(-1, 1, (B, c, h, w)).astype(np.float32)
+        eng.set_variables({k: v.numpy().copy() for k, v in ora.params.items()})
+        zt, rt = torch.tensor(z, dtype=torch.float64), torch.tensor(real, dtype=torch.float64)
+        lg, ld, stats, upd, gd, gg, (gen, s_x, s_gen) = ora.grads(zt, rt)
+        ora.step(zt, rt)
+        eng.step(nhwc(real), torch.as_tensor(z).cuda())
+        fake = np.transpose(eng.buf['dis_in'][B:].cpu().numpy(), (0, 3, 1, 2))
+        assert close(fake, gen.detach().numpy(), RTOL, 0.0), step
+        scores = eng.buf[last + '#y'].cpu().numpy()
+        assert close(scores[:B], s_x.detach().numpy(), RTOL, 0.0), step
+        assert close(scores[B:], s_gen.detach().numpy(), RTOL, 0.0), step
+        losses = eng.losses.cpu().numpy().astype(np.float64)
+        escale = float(max(losses[2:5]))
+        assert abs(losses[0] - float(lg)) <= RTOL * abs(float(lg)) + 1e-5 * escale, (step, losses[0], float(lg))
+        assert abs(losses[1] - float(ld)) <= RTOL * abs(float(ld)) + 1e-5 * escale, (step, losses[1], float(ld))
+        if step == 0:
+            continue
+        grads = eng.get_variables(grad=True)
+        ref_g = dict(gd)
+        ref_g.update(gg)
+        for net in ('gen', 'dis'):
+            gscale = max(float(ref_g[n].abs().max()) for n in grads if n.startswith(net))
+            for n in grads:
+                if n.startswith(net) and n != last + '/bias/bias':
+                    r = ref_g[n].numpy()
+                    l2 = np.linalg.norm(grads[n].astype(np.float64) - r) / (np.linalg.norm(r) + 1e-6 * gscale)
+                    assert l2 <= 5e-3, (config, n, l2)
