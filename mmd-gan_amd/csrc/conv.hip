@@ -124,8 +124,8 @@ static int wgrad_impl(const mmdgan_conv_geom *g, const float *x, const float *dy
     if (int rc = validate(g, what)) return rc;
     MMDGAN_REQUIRE(x && dy && dw, "%s: null pointer", what);
     const ConvDims d = conv_dims(*g);
-    if (!force_direct() && wino_wgrad_ok(d)) {
-        int rcw = wino_wgrad(d, x, dy, dw, (hipStream_t)stream);
+    if (!force_direct() && (wino_wgrad_ok(d) || wino2_wgrad_ok(d))) {
+        int rcw = d.R == 3 ? wino_wgrad(d, x, dy, dw, (hipStream_t)stream) : wino2_wgrad(d, x, dy, dw, (hipStream_t)stream);
         if (rcw == 0 && dbias) rcw = mmdgan_colsum(dy, (long)d.N * d.P * d.Q, d.K, dbias, stream);
         return rcw;
     }

@@ -69,6 +69,8 @@ bool wino2_dgrad_ok(const ConvDims &d);
 int wino2_transform(const ConvDims &d, const float *w, bool dgrad, float *U, hipStream_t st);
 int wino2_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, const float *U, float *y, hipStream_t st);
 int wino2_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, const float *U, float *dx, hipStream_t st);
+bool wino2_wgrad_ok(const ConvDims &d);
+int wino2_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st);
 
 // MFMA implicit-GEMM path (conv_igemm.hip); *_ok() say whether a geometry is eligible
 bool igemm_fwd_ok(const ConvDims &d);

@@ -385,4 +385,192 @@ int wino2_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, cons
     return wino2_launch(d, ep, dy, w, U, dx, true, st);
 }
 
+
+
+// ================================================================================================
+// Weight gradient of the 4x4 / stride-2 layers in the F(2x2,2x2) domain.  The 16 taps split into four 2x2 filters
+// (tap parities a,b), each the gradient of a 2x2 stride-1 correlation on a parity sub-image of x:
+//   dW^{ab} = G^T [ sum_tiles (B^T d^{ab} B) (.) (A dY A^T) ] G        - 9 multiplies per tile and (c,k) instead of 16
+// blockIdx.z = (split of the tile range) * 4 + parity.  Three waves, wave i owns row i of the 3x3 frequency grid:
+//   * V = B^T d B: a stage is 24 tiles, thread = (tile of the stage, channel quad): the 9 patch pixels as float4,
+//     the whole transform in registers, 9 ds_write_b128 into V[f][tile][c];
+//   * dM = A dY A^T row i is built in registers from the 2x2 dY pixels of the lane's tile (tile offsets published by
+//     the producer lanes through an LDS ring, as in wino_wgrad_kernel);
+//   * epilogue: G^T dU G on the partial sums (j in registers, i across the waves through LDS), 4 coalesced fp32
+//     atomics per (c,k) into the zeroed dW.
+namespace wino2w {
+constexpr int BT = 24;                        // tiles per stage = 12 MFMA k-pairs: 24 tiles x 8 channel quads = one producer item per thread
+constexpr int LDC = 36;                       // V: floats per tile row (32 channels + 4: 16-byte aligned, conflict-free)
+constexpr int FS = BT * LDC + 4;              // V: floats per frequency
+constexpr int V_FLOATS = 9 * FS;
+constexpr int TS_FLOATS = 3 * 2 * 32 * 32;    // epilogue exchange buffer, one column block at a time
+constexpr int SMEM_FLOATS = 2 * V_FLOATS > TS_FLOATS ? 2 * V_FLOATS : TS_FLOATS;
+constexpr size_t LDS_BYTES = sizeof(float) * SMEM_FLOATS + sizeof(unsigned) * 4 * BT;
+}  // namespace wino2w
+
+__global__ __launch_bounds__(192) void wino2_wgrad_kernel(int N, int H, int W, int C, int K, const float *__restrict__ x,
+                                                          const float *__restrict__ dy, float *__restrict__ dw,
+                                                          int stages_per_split) {
+    using namespace wino2w;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // = frequency row i
+    const int P = H >> 1, Q = W >> 1, TH = P >> 1, TW = Q >> 1;
+    const long T = (long)N * TH * TW;
+    const int nst_all = (int)((T + BT - 1) / BT);
+    const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 64;
+    const int par = blockIdx.z & 3, pa = par >> 1, pb = par & 1;
+    const int s0 = (blockIdx.z >> 2) * stages_per_split, s1 = min(nst_all, s0 + stages_per_split);
+    if (s0 >= s1) return;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (long)N * H * W * C * 4);
+    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, (long)N * P * Q * K * 4);
+    unsigned *dyoff = reinterpret_cast<unsigned *>(smem + SMEM_FLOATS);      // [stage & 3][tile of the stage]
+    // ---- producer: thread = (tile of the stage pt, channel quad cq)
+    const int pt = tid >> 3, cq = tid & 7;
+    long ptile = (long)s0 * BT + pt;
+    int pstage = s0;
+    float4 rin[3][3];
+    auto xload = [&]() {
+        const bool ok = ptile < T;
+        const long ii = ok ? ptile : 0;
+        const int tx = ii % TW, ty = (ii / TW) % TH, n = ii / ((long)TW * TH);
+        if (cq == 0)          // byte offset of dY pixel (2ty, 2tx), channel 0, of this tile (consumers add the rest)
+            dyoff[(pstage & 3) * BT + pt] = ok ? (unsigned)((((n * P + 2 * ty) * Q + 2 * tx) * K) * 4) : kOOB;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int row = 4 * ty - 1 + pa + 2 * u;
+            const bool rowok = ok && row >= 0 && row < H;
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const int col = 4 * tx - 1 + pb + 2 * v;
+                rin[u][v] = bufld4(rx, (rowok && col >= 0 && col < W) ? (unsigned)(((((long)n * H + row) * W + col) * C + c0 + 4 * cq) * 4) : kOOB);
+            }
+        }
+        ptile += BT;
+        ++pstage;
+    };
+    auto vstore = [&](float *buf) {           // V[f = 3i + j][tile][4 channels of the quad]
+        float4 X[3][3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const float4 d0 = rin[u][0], d1 = rin[u][1], d2 = rin[u][2];
+            X[u][0] = make_float4(d0.x - d1.x, d0.y - d1.y, d0.z - d1.z, d0.w - d1.w);
+            X[u][1] = d1;
+            X[u][2] = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
+        }
+        float *dst = buf + pt * LDC + 4 * cq;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float4 m = X[1][j];
+            *reinterpret_cast<float4 *>(dst + (0 * 3 + j) * FS) = make_float4(X[0][j].x - m.x, X[0][j].y - m.y, X[0][j].z - m.z, X[0][j].w - m.w);
+            *reinterpret_cast<float4 *>(dst + (1 * 3 + j) * FS) = m;
+            *reinterpret_cast<float4 *>(dst + (2 * 3 + j) * FS) = make_float4(X[2][j].x - m.x, X[2][j].y - m.y, X[2][j].z - m.z, X[2][j].w - m.w);
+        }
+    };
+    // ---- consumer: this lane's tile for k-pair kp of a stage is s*8 + 2*kp + kh, its channel n0 + cb*32 + l31
+    const unsigned kcol = (unsigned)((n0 + l31) * 4);
+    const unsigned dyrow = (unsigned)(Q * K * 4), dypix = (unsigned)(K * 4);
+    // A dY A^T, row i = wave, A = [1 0; 1 1; 0 1]: e[b] = wa*dY[0][b] + wb*dY[1][b];  dM[i][.] = (e0, e0 + e1, e1)
+    const float wa = wave == 2 ? 0.f : 1.f, wb = wave == 0 ? 0.f : 1.f;
+
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][cb][r] = 0.f;
+    float dyv[2][2][4];
+    auto dyload = [&](int slot, int stage, int kp) {
+        const unsigned off = dyoff[(stage & 3) * BT + 2 * kp + kh] + kcol;     // kOOB + kcol stays out of range
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                dyv[slot][cb][p] = bufld1s(rdy, off, (unsigned)(cb * 128) + (p >> 1) * dyrow + (p & 1) * dypix);
+    };
+
+    xload();
+    vstore(smem);
+    xload();
+    __syncthreads();
+    dyload(0, s0, 0);
+    const int abase = (3 * wave) * FS + kh * LDC + l31;
+    for (int s = s0; s < s1; ++s) {
+        const float *cur = smem + ((s - s0) & 1) * V_FLOATS;
+        float *nxt = smem + ((s - s0 + 1) & 1) * V_FLOATS;
+#pragma unroll
+        for (int kp = 0; kp < BT / 2; ++kp) {
+            float fa[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) fa[j] = cur[abase + j * FS + 2 * kp * LDC];
+            if (kp + 1 < BT / 2) dyload((kp + 1) & 1, s, kp + 1);
+            else dyload(0, s + 1, 0);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const float *d = dyv[kp & 1][cb];
+                const float e0 = fmaf(wb, d[2], wa * d[0]), e1 = fmaf(wb, d[3], wa * d[1]);
+                const float bq[3] = {e0, e0 + e1, e1};
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    acc[j][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], bq[j], acc[j][cb], 0, 0, 0);
+            }
+            if (kp == 0) vstore(nxt);              // tile s+1 -> LDS
+            else if (kp == 4) xload();             // tile s+2 -> registers
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+
+    // ---- G^T dU G on the partial sums (G = [1 0; 1 1; 0 1]), then atomics.  Ts[i][v][c][k 32], one column block at a time
+    float *Ts = smem;
+    const long CK = (long)C * K;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cl = (r & 3) + 8 * (r >> 2) + 4 * kh;
+            Ts[((wave * 2 + 0) * 32 + cl) * 32 + l31] = acc[0][cb][r] + acc[1][cb][r];
+            Ts[((wave * 2 + 1) * 32 + cl) * 32 + l31] = acc[1][cb][r] + acc[2][cb][r];
+        }
+        __syncthreads();
+        for (int e = tid; e < 32 * 32; e += 192) {
+            const int cc = e >> 5, kk = e & 31;
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const float t0 = Ts[((0 * 2 + v) * 32 + cc) * 32 + kk], t1 = Ts[((1 * 2 + v) * 32 + cc) * 32 + kk];
+                const float t2 = Ts[((2 * 2 + v) * 32 + cc) * 32 + kk];
+                float *dst = dw + (long)(pa * 4 + 2 * v + pb) * CK + (long)(c0 + cc) * K + n0 + cb * 32 + kk;   // tap (r = pa, t = 2v + pb)
+                atomicAdd(dst, t0 + t1);                        // u = 0: tap row 2*0 + pa
+                atomicAdd(dst + 8 * CK, t1 + t2);               // u = 1: tap row 2*1 + pa
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Measured (CIFAR batch 128): 114 / 110 / 99 us on D l2 / l4 / l6 vs 90 / 84 / 78 for the direct split kernel - with
+// only 16/9 fewer multiplies, one VMEM load per MFMA for dY and the atomics it does not pay off yet.  Parity-tested
+// and kept behind MMDGAN_WINO2_WGRAD=1 (or MMDGAN_WINO2=2, which the tests set).
+bool wino2_wgrad_ok(const ConvDims &d) {
+    static int en = -1;
+    if (en < 0) { const char *e = getenv("MMDGAN_WINO2_WGRAD"); en = e ? atoi(e) : 0; }
+    if ((!en && wino2_mode() < 2) || wino2_mode() == 0) return false;
+    return d.R == 4 && d.stride == 2 && d.pad == 1 && d.H % 4 == 0 && d.W % 4 == 0 && d.C % 32 == 0 && d.K % 64 == 0;
+}
+
+int wino2_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st) {
+    const long T = (long)d.N * (d.P / 2) * (d.Q / 2);
+    const int nst = (int)((T + wino2w::BT - 1) / wino2w::BT);
+    const long base = (long)(d.C / 32) * (d.K / 64) * 4;
+    int split = (int)((768 + base - 1) / base);                    // ~768 workgroups of 3 waves
+    if (split > nst / 4) split = nst / 4 > 0 ? nst / 4 : 1;         // >= 4 stages (288 MFMAs per wave) per workgroup
+    int sps = (nst + split - 1) / split;
+    split = (nst + sps - 1) / sps;
+    if (zero_output(dw, sizeof(float) * 16 * (size_t)d.C * d.K, st) != hipSuccess) return check_launch("conv2d_wgrad memset");
+    hipLaunchKernelGGL(wino2_wgrad_kernel, dim3(d.C / 32, d.K / 64, 4 * split), dim3(192), wino2w::LDS_BYTES, st, d.N, d.H, d.W, d.C,
+                       d.K, x, dy, dw, sps);
+    return check_launch("conv2d_wgrad(winograd 2x2)");
+}
+
 }  // namespace mmdgan

@@ -225,7 +225,12 @@ def test_conv2d_winograd_stride2_path(ops, case):
     xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
     wt = torch.tensor(w, dtype=torch.float64)
     yt = R.conv2d_same(xt, wt, s)
-    gx, = torch.autograd.grad((yt * torch.tensor(dy, dtype=torch.float64)).sum(), [xt])
+    wt.requires_grad_(True)
+    gx, gw = torch.autograd.grad((R.conv2d_same(xt, wt, s) * torch.tensor(dy, dtype=torch.float64)).sum(), [xt, wt])
+    wt = wt.detach()
+    if C % 32 == 0 and K % 64 == 0:                      # F(2x2,2x2)-domain weight gradient, four tap-parity problems
+        dw = ops.conv2d_wgrad(nhwc(x), nhwc(dy), ksz, s)
+        assert rel_err(dw.cpu().numpy(), gw.numpy()) <= RTOL
     fwd_ok, bwd_ok = ops.wino_eligible(N, H, W, C, K, ksz, s, False), ops.wino_eligible(N, H, W, C, K, ksz, s, True)
     assert fwd_ok or bwd_ok
     uf, ub = ops.wino_transform(dev(w), False), ops.wino_transform(dev(w), True)
