@@ -150,7 +150,9 @@ int mmdgan_dot(const float *a, const float *b, long n, float *out, void *stream)
  * fwd: y = act((x - mean)/sqrt(var+eps) * gamma + beta); writes save_mean/save_invstd [C] and
  *      new_moving_mean/var (may alias the inputs' storage: all reads precede all writes).
  * bwd: dx, dgamma, dbeta from dy (gradient w.r.t. y, i.e. AFTER the activation), y.
- * workspace: mmdgan_bn_workspace_bytes(C) bytes of device scratch (double partial sums).
+ * workspace: mmdgan_bn_workspace_bytes(C) bytes of device scratch (2*C fp64 totals, accumulated with atomics).  The
+ * entries zero it themselves, unless mmdgan_set_outputs_prezeroed(1) is in force: then it must be zero on entry and
+ * distinct per call within a step (the forward and the backward call of a layer need separate totals).
  * ---------------------------------------------------------------------------------------------- */
 size_t mmdgan_bn_workspace_bytes(int C);
 int mmdgan_bn_fwd_train(const float *x, long rows, int C, const float *gamma, const float *beta, float eps,

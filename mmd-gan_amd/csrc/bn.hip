@@ -3,9 +3,14 @@
 // layer_func.py:960-966 (TF defaults momentum .99, eps 1e-3) and its autodiff.
 //
 // HBM-bound.  Statistics are column sums accumulated in double (products of floats are exact in
-// double, so E[x^2]-mean^2 carries no fp32 cancellation): kernel A writes per-chunk partial sums
-// to the workspace, kernel B combines them per channel in fixed order (deterministic), kernel C
-// applies.  x is read twice, y written once.
+// double, so E[x^2]-mean^2 carries no fp32 cancellation).  Two launches per direction: kernel A
+// reduces a chunk of rows per workgroup and adds its 2*C sums to the totals in the workspace with
+// fp64 atomics (256 workgroups x 2C adds: nothing); kernel B derives mean / 1/std (or dgamma / dbeta)
+// for all channels from the totals into LDS at the top of every workgroup, applies, and workgroup 0
+// writes the saved / moving statistics.  (A separate "finish" launch between the two cost 5 us + a
+// launch gap per BN layer and direction on the generator's critical path.)  x is read twice, y
+// written once.  The workspace (2*C doubles) must be zero on entry; the entries zero it themselves
+// unless mmdgan_set_outputs_prezeroed(1) says the caller did.
 #include "common.h"
 #include <stdint.h>
 
@@ -13,7 +18,7 @@ namespace mmdgan {
 
 constexpr int kBnMaxSplits = 256;
 
-// partial[(split*2 + which)*C + c], which 0: sum a, 1: sum b
+// partial[which*C + c] += this workgroup's sum; which 0: sum a, 1: sum b
 template <int MODE>   // 0: a = x, b = x*x      1: a = dz, b = dz*xhat  (dz = dy*act'(y))
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                          const float *__restrict__ dy, long rows, int C,
@@ -44,8 +49,8 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict
     red[0][rl][cl] = sa; red[1][rl][cl] = sb;
     __syncthreads();
     if (rl == 0 && c < C) {
-        partial[((size_t)blockIdx.y * 2 + 0) * C + c] = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-        partial[((size_t)blockIdx.y * 2 + 1) * C + c] = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+        atomicAdd(partial + c, red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]);
+        atomicAdd(partial + C + c, red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]);
     }
 }
 
@@ -111,32 +116,57 @@ __global__ __launch_bounds__(256) void bn_partial_v4_kernel(const float *__restr
             double t = 0;
 #pragma unroll
             for (int k = 0; k < 16; ++k) t += red[which][k][ch];
-            partial[((size_t)blockIdx.y * 2 + which) * C + blockIdx.x * 64 + ch] = t;
+            atomicAdd(partial + (size_t)which * C + blockIdx.x * 64 + ch, t);
         }
     }
 }
 
-__global__ __launch_bounds__(256) void bn_stats_finish_kernel(const double *partial, int splits, long rows, int C,
-                                                              float eps, float momentum, int unbiased, float *save_mean,
-                                                              float *save_invstd, const float *mm, const float *mv,
-                                                              float *new_mm, float *new_mv) {
-    // one wave per channel: lanes stride over the splits, then a wave reduction (fixed order)
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (c >= C) return;
-    double s = 0, s2 = 0;
-    for (int k = lane; k < splits; k += 64) { s += partial[((size_t)k * 2) * C + c]; s2 += partial[((size_t)k * 2 + 1) * C + c]; }
-    s = wave_sum(s); s2 = wave_sum(s2);
-    if (lane != 0) return;
-    const double n = (double)rows, mean = s / n;
-    double var = s2 / n - mean * mean;            // biased batch variance
-    if (var < 0) var = 0;
-    save_mean[c] = (float)mean;
-    save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (new_mm) {
-        const double var_u = unbiased ? var * (n / (n > 1 ? n - 1.0 : 1.0)) : var;
-        const float om = mm[c], ov = mv[c];       // reads precede writes (buffers may alias)
-        new_mm[c] = om * momentum + (float)mean * (1.f - momentum);
-        new_mv[c] = ov * momentum + (float)var_u * (1.f - momentum);
+// mean / 1/std of every channel from the totals into LDS (every workgroup; workgroup 0 also publishes the
+// saved and moving statistics), then y = act((x - mean) * invstd * gamma + beta)
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_train_apply_kernel(const float *__restrict__ x, long total, int C,
+                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                             const double *__restrict__ totals, long rows, float eps,
+                                                             float momentum, int unbiased, int act, float *__restrict__ y,
+                                                             float *save_mean, float *save_invstd, const float *mm,
+                                                             const float *mv, float *new_mm, float *new_mv) {
+    extern __shared__ float stat[];                     // [mean C][invstd C]
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const double n = (double)rows, mean = totals[c] / n;
+        double var = totals[C + c] / n - mean * mean;   // biased batch variance
+        if (var < 0) var = 0;
+        const float is = (float)(1.0 / sqrt(var + (double)eps));
+        stat[c] = (float)mean;
+        stat[C + c] = is;
+        if (blockIdx.x == 0) {
+            save_mean[c] = (float)mean;
+            save_invstd[c] = is;
+            if (new_mm) {
+                const double var_u = unbiased ? var * (n / (n > 1 ? n - 1.0 : 1.0)) : var;
+                const float om = mm[c], ov = mv[c];     // reads precede writes (buffers may alias)
+                new_mm[c] = om * momentum + (float)mean * (1.f - momentum);
+                new_mv[c] = ov * momentum + (float)var_u * (1.f - momentum);
+            }
+        }
+    }
+    __syncthreads();
+    const long stride = (long)gridDim.x * 256;
+    if (VEC == 4) {
+        for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total / 4; q += stride) {
+            const int c = (int)((q * 4) % C);
+            const float4 v = reinterpret_cast<const float4 *>(x)[q];
+            const float4 g = *reinterpret_cast<const float4 *>(gamma + c), b = *reinterpret_cast<const float4 *>(beta + c);
+            const float in[4] = {v.x, v.y, v.z, v.w}, gv[4] = {g.x, g.y, g.z, g.w}, bv[4] = {b.x, b.y, b.z, b.w};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = act_fwd((in[j] - stat[c + j]) * stat[C + c + j] * gv[j] + bv[j], act);
+            reinterpret_cast<float4 *>(y)[q] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    } else {
+        for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {
+            const int c = o % C;
+            y[o] = act_fwd((x[o] - stat[c]) * stat[C + c] * gamma[c] + beta[c], act);
+        }
     }
 }
 
@@ -172,18 +202,6 @@ __global__ __launch_bounds__(256) void bn_apply_v4_kernel(const float *__restric
         }
         reinterpret_cast<float4 *>(y)[q] = make_float4(o[0], o[1], o[2], o[3]);
     }
-}
-
-__global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const double *partial, int splits, int C, float *dgamma,
-                                                            float *dbeta) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (c >= C) return;
-    double s = 0, s2 = 0;
-    for (int k = lane; k < splits; k += 64) { s += partial[((size_t)k * 2) * C + c]; s2 += partial[((size_t)k * 2 + 1) * C + c]; }
-    s = wave_sum(s); s2 = wave_sum(s2);
-    if (lane != 0) return;
-    dbeta[c] = (float)s;
-    dgamma[c] = (float)s2;
 }
 
 // dx = gamma*invstd*(dz - dbeta/n - xhat*dgamma/n)
@@ -230,6 +248,52 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float *__res
     }
 }
 
+// dbeta / dgamma of every channel from the totals into LDS (workgroup 0 publishes them), then
+// dx = gamma*invstd*(dz - dbeta/n - xhat*dgamma/n)
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_fused_apply_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                                 const float *__restrict__ dy, long total, long rows, int C,
+                                                                 const float *__restrict__ gamma, const float *__restrict__ mean,
+                                                                 const float *__restrict__ invstd, const double *__restrict__ totals,
+                                                                 float *dgamma, float *dbeta, int act, float *__restrict__ dx) {
+    extern __shared__ float stat[];                     // [dbeta C][dgamma C]
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float db = (float)totals[c], dg = (float)totals[C + c];
+        stat[c] = db;
+        stat[C + c] = dg;
+        if (blockIdx.x == 0) { dbeta[c] = db; dgamma[c] = dg; }
+    }
+    __syncthreads();
+    const float invn = 1.0f / (float)rows;
+    const long stride = (long)gridDim.x * 256;
+    if (VEC == 4) {
+        for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total / 4; q += stride) {
+            const int c = (int)((q * 4) % C);
+            const float4 a = reinterpret_cast<const float4 *>(x)[q], b = reinterpret_cast<const float4 *>(y)[q];
+            const float4 d = reinterpret_cast<const float4 *>(dy)[q];
+            const float4 g = *reinterpret_cast<const float4 *>(gamma + c), m = *reinterpret_cast<const float4 *>(mean + c);
+            const float4 iv = *reinterpret_cast<const float4 *>(invstd + c);
+            const float xv[4] = {a.x, a.y, a.z, a.w}, yv[4] = {b.x, b.y, b.z, b.w}, dv[4] = {d.x, d.y, d.z, d.w};
+            const float gv[4] = {g.x, g.y, g.z, g.w}, mv[4] = {m.x, m.y, m.z, m.w}, sv[4] = {iv.x, iv.y, iv.z, iv.w};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dz = dv[j] * act_bwd_from_out(yv[j], act);
+                const float xh = (xv[j] - mv[j]) * sv[j];
+                o[j] = gv[j] * sv[j] * (dz - stat[c + j] * invn - xh * stat[C + c + j] * invn);
+            }
+            reinterpret_cast<float4 *>(dx)[q] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    } else {
+        for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {
+            const int c = o % C;
+            const float dz = dy[o] * act_bwd_from_out(y[o], act);
+            const float xh = (x[o] - mean[c]) * invstd[c];
+            dx[o] = gamma[c] * invstd[c] * (dz - stat[c] * invn - xh * stat[C + c] * invn);
+        }
+    }
+}
+
 static inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 static int bn_splits(long rows, int C, long *rows_per_split) {
@@ -248,7 +312,7 @@ static int bn_splits(long rows, int C, long *rows_per_split) {
 
 using namespace mmdgan;
 
-extern "C" size_t mmdgan_bn_workspace_bytes(int C) { return C < 1 ? 0 : (size_t)kBnMaxSplits * 2 * C * sizeof(double); }
+extern "C" size_t mmdgan_bn_workspace_bytes(int C) { return C < 1 ? 0 : (size_t)2 * C * sizeof(double); }
 
 extern "C" int mmdgan_bn_fwd_train(const float *x, long rows, int C, const float *gamma, const float *beta, float eps,
                                    float momentum, int unbiased_moving_var, int act, float *y, float *save_mean,
@@ -261,6 +325,7 @@ extern "C" int mmdgan_bn_fwd_train(const float *x, long rows, int C, const float
     long rps;
     const int splits = bn_splits(rows, C, &rps);
     double *part = (double *)workspace;
+    if (zero_output(part, sizeof(double) * 2 * C, st) != hipSuccess) return check_launch("bn_fwd_train memset");
     const bool v4 = (C % 4) == 0 && al16(x) && al16(y) && al16(gamma) && al16(beta) && al16(save_mean) && al16(save_invstd);
     if (v4)
         hipLaunchKernelGGL(bn_partial_v4_kernel<0>, dim3((C + 63) / 64, splits), dim3(256), 0, st, x, nullptr, nullptr,
@@ -268,20 +333,18 @@ extern "C" int mmdgan_bn_fwd_train(const float *x, long rows, int C, const float
     else
         hipLaunchKernelGGL(bn_partial_kernel<0>, dim3((C + 63) / 64, splits), dim3(256), 0, st, x, nullptr, nullptr, rows,
                            C, rps, nullptr, nullptr, 0, part);
-    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, splits, rows, C, eps,
-                       momentum, unbiased_moving_var, save_mean, save_invstd, moving_mean, moving_var, new_moving_mean,
-                       new_moving_var);
     const long total = rows * C;
-    long blocks = (total + 255) / 256;
+    long blocks = ((v4 ? total / 4 : total) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    if (v4) {
-        blocks = (total / 4 + 255) / 256;
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(bn_apply_v4_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, total / 4, C, gamma, beta,
-                           save_mean, save_invstd, 0.f, 0, act, y);
-    } else
-        hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, total, C, gamma, beta, save_mean,
-                           save_invstd, 0.f, 0, act, y);
+    const size_t lds = sizeof(float) * 2 * C;
+    if (v4)
+        hipLaunchKernelGGL(bn_train_apply_kernel<4>, dim3((unsigned)blocks), dim3(256), lds, st, x, total, C, gamma, beta, part, rows,
+                           eps, momentum, unbiased_moving_var, act, y, save_mean, save_invstd, moving_mean, moving_var,
+                           new_moving_mean, new_moving_var);
+    else
+        hipLaunchKernelGGL(bn_train_apply_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, st, x, total, C, gamma, beta, part, rows,
+                           eps, momentum, unbiased_moving_var, act, y, save_mean, save_invstd, moving_mean, moving_var,
+                           new_moving_mean, new_moving_var);
     return check_launch("bn_fwd_train");
 }
 
@@ -312,6 +375,7 @@ extern "C" int mmdgan_bn_bwd(const float *x, const float *y, const float *dy, lo
     long rps;
     const int splits = bn_splits(rows, C, &rps);
     double *part = (double *)workspace;
+    if (zero_output(part, sizeof(double) * 2 * C, st) != hipSuccess) return check_launch("bn_bwd memset");
     const bool v4 = (C % 4) == 0 && al16(x) && al16(y) && al16(dy) && al16(dx) && al16(gamma) && al16(save_mean) &&
                     al16(save_invstd) && al16(dgamma) && al16(dbeta);
     if (v4)
@@ -320,17 +384,15 @@ extern "C" int mmdgan_bn_bwd(const float *x, const float *y, const float *dy, lo
     else
         hipLaunchKernelGGL(bn_partial_kernel<1>, dim3((C + 63) / 64, splits), dim3(256), 0, st, x, y, dy, rows, C, rps,
                            save_mean, save_invstd, act, part);
-    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, splits, C, dgamma, dbeta);
     const long total = rows * C;
-    long blocks = (total + 255) / 256;
+    long blocks = ((v4 ? total / 4 : total) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    if (v4) {
-        blocks = (total / 4 + 255) / 256;
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, dy, total / 4, rows, C,
-                           gamma, save_mean, save_invstd, dgamma, dbeta, act, dx);
-    } else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, y, dy, total, rows, C, gamma,
-                           save_mean, save_invstd, dgamma, dbeta, act, dx);
+    const size_t lds = sizeof(float) * 2 * C;
+    if (v4)
+        hipLaunchKernelGGL(bn_bwd_fused_apply_kernel<4>, dim3((unsigned)blocks), dim3(256), lds, st, x, y, dy, total, rows, C, gamma,
+                           save_mean, save_invstd, part, dgamma, dbeta, act, dx);
+    else
+        hipLaunchKernelGGL(bn_bwd_fused_apply_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, st, x, y, dy, total, rows, C, gamma,
+                           save_mean, save_invstd, part, dgamma, dbeta, act, dx);
     return check_launch("bn_bwd");
 }

@@ -391,6 +391,16 @@ class GanEngine:
         # buffers some kernel accumulates into with atomics: zeroed once at the start of every step
         # (4 memset nodes instead of one per kernel, see mmdgan_set_outputs_prezeroed)
         self._zero_each_step = [self.gen.grads, self.dis.grads, self.dis.sn_scratch.flat]
+        # batch-norm statistics are accumulated with fp64 atomics into per-layer totals ([forward | backward] x 2C),
+        # which must be zero when the layer runs: one flat buffer, one memset per step
+        bn = [(s.scope, s.out if s.op == 'd' else s.channels) for net in (self.gen, self.dis) for s in net.specs if s.bn]
+        self._bn_flat = torch.zeros(max(1, sum(4 * c for _, c in bn)), dtype=torch.float64, device=dev)
+        self._bn_totals, off = {}, 0
+        for scope, c in bn:
+            self._bn_totals[scope] = (self._bn_flat[off:off + 2 * c], self._bn_flat[off + 2 * c:off + 4 * c])
+            off += 4 * c
+        if bn:
+            self._zero_each_step.append(self._bn_flat)
         for net in (self.gen, self.dis):
             for s in net.specs:          # dense outputs whose K is long enough for the split-K gemm path
                 if s.op == 'd' and s.kernel_shape[0] >= 512:
@@ -500,7 +510,7 @@ class GanEngine:
             mm, mv = net.state[s.scope + '/BN/BN/moving_mean'], net.state[s.scope + '/BN/BN/moving_variance']
             raw2d = tgt.view(-1, tgt.shape[-1])
             lib = ops.require_device()
-            ws = ops._bn_workspace(raw2d.shape[1], raw2d.device)
+            ws = self._bn_totals[s.scope][0]
             if is_training:
                 ops.check(lib.mmdgan_bn_fwd_train(
                     raw2d.data_ptr(), raw2d.shape[0], raw2d.shape[1], gamma.data_ptr(), beta.data_ptr(), 1e-3, 0.99,
@@ -649,7 +659,7 @@ class GanEngine:
                 raw, y = b[s.scope + '#raw'], b[s.scope + '#y']
                 lib = ops.require_device()
                 C = raw.shape[-1]
-                ws = ops._bn_workspace(C, raw.device)
+                ws = self._bn_totals[s.scope][1]
                 draw = b[s.scope + '#dz']
                 ops.check(lib.mmdgan_bn_bwd(
                     raw.data_ptr(), y.data_ptr(), dz.data_ptr(), raw.numel() // C, C,
