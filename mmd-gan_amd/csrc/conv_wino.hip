@@ -319,15 +319,15 @@ static bool wino_enabled() {       // MMDGAN_WINO=0 keeps the 3x3 layers on the 
     return v == 1;
 }
 
-// below ~768 tiles (24 x K/64 workgroups) the grid no longer fills the chip and the direct kernel wins
-// (measured: D l7 forward at batch 128 = 512 tiles: 92 us either way; 768 tiles: 101 vs 160 us).  Splitting the
+// below ~512 tiles the grid no longer fills the chip and the direct kernel wins (measured: D l7 forward at batch
+// 128 = 512 tiles: 68 us with 32-channel column blocks vs 92 direct; 768 tiles: 98 vs 160 us).  Splitting the
 // channel reduction (wino_kernel<.., true>) does not rescue the small launches either - memset + atomics + the
 // activation pass cost what the extra workgroups gain (D l7 forward 98 vs 92 direct, 3B dgrad 139 vs 101
 // unsplit) - so it is only used below 96 workgroups.  MMDGAN_WINO_MIN_TILES overrides (the parity tests use small
 // problems, which is also what exercises the split path).
 static long wino_min_tiles() {
     static long v = -1;
-    if (v < 0) { const char *e = getenv("MMDGAN_WINO_MIN_TILES"); v = e ? atol(e) : 768; }
+    if (v < 0) { const char *e = getenv("MMDGAN_WINO_MIN_TILES"); v = e ? atol(e) : 512; }
     return v;
 }
 
@@ -376,9 +376,18 @@ static int wino_launch(const ConvDims &d, const ConvEpilogue &ep, const float *i
         if (int rc = check_launch(flip ? "conv2d_dgrad(winograd split)" : "conv2d_fwd(winograd split)")) return rc;
         return epilogue_pass(out, total, ko, ep, st);
     }
-    const dim3 grid((unsigned)((T + 31) / 32), ko / 64);
-    hipLaunchKernelGGL((wino_kernel<64, false>), grid, dim3(256), (wino::Cfg<64>::LDS_BYTES), st, d.N, d.H, d.W, cr, ko, ep, in, U,
-                       out, nstages);
+    // 32-channel column blocks (half the accumulators: 4 waves per SIMD instead of 2, twice the workgroups, but the
+    // input transform is redone per column block) pay off at the grid sizes where 64 leaves CUs idle - measured:
+    // 128 workgroups (D l7 forward) 68 vs 94 us, 384 (D l5 3B dgrad) 83 vs 91; 192 / 256 / 512+ are better at 64
+    if (wgs <= 128 || (wgs > 256 && wgs < 512)) {
+        const dim3 grid((unsigned)((T + 31) / 32), ko / 32);
+        hipLaunchKernelGGL((wino_kernel<32, false>), grid, dim3(256), (wino::Cfg<32>::LDS_BYTES), st, d.N, d.H, d.W, cr, ko, ep, in,
+                           U, out, nstages);
+    } else {
+        const dim3 grid((unsigned)((T + 31) / 32), ko / 64);
+        hipLaunchKernelGGL((wino_kernel<64, false>), grid, dim3(256), (wino::Cfg<64>::LDS_BYTES), st, d.N, d.H, d.W, cr, ko, ep, in,
+                           U, out, nstages);
+    }
     return check_launch(flip ? "conv2d_dgrad(winograd)" : "conv2d_fwd(winograd)");
 }
 
