@@ -106,8 +106,14 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float *__restric
 // SPLIT: blockIdx.z takes a slice of the channel reduction and ADDS scale * (A^T M A) into a zeroed output with
 // atomics (the transform is linear); bias / activation follow in epilogue_pass_kernel.  For launches whose tile
 // count alone cannot fill the chip (D l7 forward at batch 128: 16 x 8 workgroups on 256 CUs).
+#ifndef WINO_WAVES
+#define WINO_WAVES 2
+#endif
+#ifndef WINO_BD
+#define WINO_BD 16          // B-fragment prefetch distance in MFMA groups (16 = one full stage)
+#endif
 template <int BN, bool SPLIT>
-__global__ __launch_bounds__(256, 2) void wino_kernel(int N, int H, int W, int Cr, int Ko, ConvEpilogue ep,
+__global__ __launch_bounds__(256, WINO_WAVES) void wino_kernel(int N, int H, int W, int Cr, int Ko, ConvEpilogue ep,
                                                       const float *__restrict__ x, const float *__restrict__ U,
                                                       float *__restrict__ out, int stages_per_split) {
     using Cf = wino::Cfg<BN>;
@@ -155,7 +161,8 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(int N, int H, int W, int C
             for (int r = 0; r < 16; ++r) acc[fl][cb][r] = 0.f;
 
     float4 rin[4];
-    float fb[NG][NCB], X[4][4];
+    constexpr int BD = WINO_BD;
+    float fb[BD][NCB], X[4][4];
     // row pass X = d B along the 4 columns of this thread's patch row, 4 channels
 #define WINO_ROWPASS                                                                                     \
     X[0][0] = rin[0].x - rin[2].x; X[0][1] = rin[0].y - rin[2].y; X[0][2] = rin[0].z - rin[2].z; X[0][3] = rin[0].w - rin[2].w; \
@@ -175,12 +182,12 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(int N, int H, int W, int C
     }
 #define WINO_BLOAD(G, S)                                                                                 \
     _Pragma("unroll") for (int cb = 0; cb < NCB; ++cb)                                                   \
-        fb[G][cb] = bufld1s(ru, ubase, (unsigned)(S) * ustage + ((G) & 3) * ufreq + ((G) >> 2) * ukp + cb * 128);
+        fb[(G) % BD][cb] = bufld1s(ru, ubase, (unsigned)(S) * ustage + ((G) & 3) * ufreq + ((G) >> 2) * ukp + cb * 128);
 
     // prologue: tile 0 -> LDS, tile 1 -> registers, B fragments of stage 0
     WINO_XLOAD(s_begin)
 #pragma unroll
-    for (int g = 0; g < NG; ++g) WINO_BLOAD(g, s_begin)
+    for (int g = 0; g < BD; ++g) WINO_BLOAD(g, s_begin)
     WINO_ROWPASS
     WINO_VSTORE(smem, 0) WINO_VSTORE(smem, 1) WINO_VSTORE(smem, 2) WINO_VSTORE(smem, 3)
     WINO_XLOAD(s_begin + 1)
@@ -203,8 +210,8 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(int N, int H, int W, int C
             if (g + PF < NG) fa[g + PF] = cur[abase + ((g + PF) & 3) * FSV + 2 * ((g + PF) >> 2) * LDT];
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
-                acc[g & 3][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g], fb[g][cb], acc[g & 3][cb], 0, 0, 0);
-            WINO_BLOAD(g, sn)
+                acc[g & 3][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g], fb[g % BD][cb], acc[g & 3][cb], 0, 0, 0);
+            if (g + BD < NG) WINO_BLOAD(g + BD, s) else WINO_BLOAD(g + BD - NG, sn)
             if (g == 0) {                              // tile s+1: row pass, then one frequency column per group
                 WINO_ROWPASS
                 WINO_VSTORE(nxt, 0)
