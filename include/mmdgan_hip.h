@@ -51,6 +51,10 @@ extern "C" {
 /* loss enum - math_func.py:2644-2647 */
 #define MMDGAN_LOSS_REP 0
 #define MMDGAN_LOSS_RMB 1
+#define MMDGAN_LOSS_MMD_G 2    /* 'mmd_g' / 'fixed_g': five-scale Gaussian mixture, math_func.py:2160-2173 */
+#define MMDGAN_LOSS_MGB 3      /* 'mgb': sigma-1 Gaussian with bounds (0.25, 4) on the D side, math_func.py:2175-2193 */
+#define MMDGAN_LOSS_HINGE 4    /* math_func.py:2137-2143 (w, bounds, masks, dist, workspace unused) */
+#define MMDGAN_LOSS_LOGISTIC 5 /* 'logistic' / '': non-saturating, math_func.py:2128-2135 */
 /* OR-ed into loss_type: write the four gradient blocks of mmdgan_mmd_loss in the order
  * [dL_dis/ds_x, dL_dis/ds_gen, dL_gen/ds_gen, dL_gen/ds_x] instead of [dL_gen/ds_gen, dL_gen/ds_x, dL_dis/ds_gen,
  * dL_dis/ds_x]: the first 3B rows are then exactly the score gradient a discriminator fed [real ; fake] (and the
@@ -187,7 +191,11 @@ int mmdgan_sn_wgrad_fixup(float *g_inout, const float *dsigma_dw, const float *d
  *   math_func.py: get_squared_dist :799-840, matrix_mean_wo_diagonal :1064, mmd_g :1312-1343,
  *   mmd_g_bounded :1380-1422, GANLoss._repulsive_mmd_g_(bounded_) :2505-2550.
  *   s_gen, s_x   [B,d]  discriminator scores of generated / real samples (x = gen, y = real)
- *   out_scalars  [8]    loss_gen, loss_dis, e_kxx, e_kxy, e_kyy, e_kxx_b, e_kyy_b, reserved
+ *   MMDGAN_LOSS_MMD_G / MGB (GANLoss._mmd_g_ :2160-2173 with mixture_mmd_g :1435-1462, _mmd_g_bound_ :2175-2193)
+ *   run the same launch with their own kernel terms (w0, w1 ignored; e_k* of the mixture are summed over its five
+ *   scales); MMDGAN_LOSS_HINGE / LOGISTIC (:2137-2143, :2128-2135) have no pairwise term: one small launch over
+ *   the B*d scores, out_scalars = loss_gen, loss_dis, the two means of loss_dis, zeros; masks / dist must be NULL.
+ *   out_scalars  [8]    loss_gen, loss_dis, e_kxx, e_kxy, e_kyy, e_kxx_b, e_kyy_b, e_kxy_b
  *   grads        [4,B,d] dLgen/ds_gen, dLgen/ds_x, dLdis/ds_gen, dLdis/ds_x   (NULL = forward only)
  *   masks        [3,B,B] bytes: dist_gg < lb, dist_gd > ub, dist_dd > ub       (NULL = skip)
  *   dist         [3,B,B] dist_gg, dist_gd, dist_dd                             (NULL = skip)

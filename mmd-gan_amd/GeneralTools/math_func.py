@@ -4,13 +4,13 @@ Kept names and signatures: get_squared_dist (math_func.py:767) and GANLoss (:208
 .apply(score_gen, score_data, loss_type, **kwargs) -> (loss_gen, loss_dis); matrix_mean_wo_diagonal
 (:1048), mmd_g (:1288) and mmd_g_bounded (:1356) are fused inside the kernel and have no separate
 entry (the B x B matrices they take are never materialised).  Inputs are [B, d] fp32 CUDA tensors; results are
-device tensors (no host synchronisation).  Only the hot-path loss names are implemented ('rep',
-'rmb' and their aliases, math_func.py:2644-2647); every other name raises exactly as the
-reference does for an unknown one.
+device tensors (no host synchronisation).  Implemented loss names: the hot path's 'rep', 'rmb' and their
+aliases (math_func.py:2644-2647) and, from SURVEY 8(f) row 1, 'mmd_g' / 'fixed_g', 'mgb', 'hinge' and
+'logistic' / '' (:2602-2611); every other name raises exactly as the reference does for an unknown one.
 """
 from mmdgan_hip import ops
 
-_NOT_ON_HOT_PATH = {'logistic', '', 'hinge', 'wasserstein', 'fixed_g', 'mmd_g', 'mgb', 'fixed_t', 'mmd_t',
+_NOT_ON_HOT_PATH = {'wasserstein', 'fixed_t', 'mmd_t',
                     'mmd_g_mix', 'fixed_g_mix', 'sgm', 'rand_g', 'rgb', 'rand_g_mix', 'sym_rg_mix', 'sym_rg',
                     'sym_rand_g', 'instance_noise', 'ins_noise', 'rep_gp', 'rep_ds', 'rmb_gp', 'rmb_ds', 'test'}
 
@@ -48,18 +48,19 @@ class GANLoss(object):
                           ('dis_scale', 'dis_scale'), ('rep_weights', 'repulsive_weights')):
             if key in kwargs:
                 setattr(self, attr, kwargs[key])
-        if loss_type in {'rep', 'rmb'} | ops.LOSS.keys():
+        if loss_type in {'fixed_g', 'mmd_g', 'rep', 'rmb'}:                               # math_func.py:2589-2592
             assert self.batch_size is not None, 'GANLoss: batch_size must be provided'   # math_func.py:2592
         if loss_type not in ops.LOSS:
             if loss_type in _NOT_ON_HOT_PATH:
                 raise NotImplementedError('Not implemented.')     # outside SURVEY section 8 scope
             raise NotImplementedError('Not implemented.')         # math_func.py:2651
         w = self.repulsive_weights
-        assert w[0] - w[1] == 1.0, 'w[0]-w[1] must be 1'          # math_func.py:1340
+        if ops.LOSS[loss_type] <= 1:
+            assert w[0] - w[1] == 1.0, 'w[0]-w[1] must be 1'      # math_func.py:1340
         out = ops.mmd_loss(score_gen.contiguous(), score_data.contiguous(), loss_type, tuple(w), need_grads=True)
         self.loss_gen, self.loss_dis = out['scalars'][0], out['scalars'][1]
         self.stats, self.grads = out['scalars'][2:7], out['grads']
-        if self.dis_penalty is not None:
+        if self.dis_penalty is not None and loss_type not in ('logistic', '', 'hinge'):   # :2128-2143 take none
             self.loss_dis = self.loss_dis + self.dis_penalty
         return self.loss_gen, self.loss_dis
 

@@ -6,7 +6,12 @@
 //                                matrix, clamped at 0 - reproduced literally so that the rmb clamp
 //                                masks are bit-identical)
 //   matrix_mean_wo_diagonal :1064, mmd_g :1312-1343, mmd_g_bounded :1380-1422,
-//   GANLoss._repulsive_mmd_g_ / _bounded_ :2505-2550, and TF autodiff of all of it.
+//   GANLoss._repulsive_mmd_g_ / _bounded_ :2505-2550, and TF autodiff of all of it;
+//   the same tile walk also serves the two non-repulsive Gaussian losses:
+//   mixture_mmd_g :1435-1462 over sigma = [1, sqrt2, 2, sqrt8, 4] (GANLoss._mmd_g_ :2160-2173) and
+//   mmd_g with bounds (GANLoss._mmd_g_bound_ :2175-2193).  The kernel is instantiated per loss so
+//   the rep / rmb code on the training path is unchanged by them.
+//   score_loss_kernel (bottom) is GANLoss._logistic_ :2128-2135 and _hinge_ :2137-2143.
 //
 // Mapping (wave = 64 lanes): one wave owns one row i; lane l owns column j = tile*64 + l.  A block
 // (4 waves = 4 rows) stages a 64-row tile of s_gen and s_x in LDS (row stride d+1: conflict-free
@@ -25,7 +30,7 @@ constexpr int kMmdRows = 4;     // rows (waves) per block
 constexpr int kMmdTile = 64;    // columns per tile = one per lane
 constexpr int kMmdMaxD = 256;   // LDS: 2 * 64 * (d+1) * 4 B <= 131 KB
 constexpr int kMmdKC = 16;      // gradient k-chunk (64 accumulators = 4 vectors x 16)
-constexpr int kNumSums = 5;     // kxx kxy kyy kxx_b kyy_b
+constexpr int kNumSums = 6;     // kxx kxy kyy kxx_b kyy_b kxy_b
 
 struct MmdArgs {
     const float *x, *y;   // s_gen, s_x
@@ -43,6 +48,26 @@ __device__ __forceinline__ float dotk(const float *a, const float *b, int d) {
     return acc;
 }
 
+// kernel value and -2 dK/dD of one squared distance: a single Gaussian (sigma 1), or the five-scale
+// mixture whose 2 sigma^2 are the exact powers of two 2..32
+template <bool MIX>
+__device__ __forceinline__ void gauss(float D, float &K, float &G) {
+    if (!MIX) {
+        K = expf(-D / 2.0f);
+        G = K;
+    } else {
+        K = 0.f; G = 0.f;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const float two_s2 = (float)(2 << q);
+            const float e = expf(-D / two_s2);
+            K += e;
+            G += e * (2.0f / two_s2);
+        }
+    }
+}
+
+template <int LT>
 __global__ __launch_bounds__(256) void mmd_kernel(MmdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int d = a.d, ld = d + 1;
@@ -71,13 +96,14 @@ __global__ __launch_bounds__(256) void mmd_kernel(MmdArgs a) {
 
     const float m = (float)B;
     const float inv = 1.0f / (m * (m - 1.0f));
-    const bool rmb = a.loss_type == MMDGAN_LOSS_RMB;
+    constexpr bool rmb = LT == MMDGAN_LOSS_RMB, mgb = LT == MMDGAN_LOSS_MGB, mix = LT == MMDGAN_LOSS_MMD_G;
     const bool yy_lower = a.w1 > 0.f;                             // math_func.py:1391-1394
     // coefficients of e(K_xx), e(K_xy), e(K_yy): loss_gen = (1,-2,1); loss_dis = (-1, w0, -w1)
+    // (the host passes w = (2, 1) for mmd_g / mgb, whose loss_dis is -mmd)
     const float cg_xx = 1.f, cg_xy = -2.f, cg_yy = 1.f;
     const float cd_xx = -1.f, cd_xy = a.w0, cd_yy = -a.w1;
 
-    double s_xx = 0, s_xy = 0, s_yy = 0, s_xxb = 0, s_yyb = 0;
+    double s_xx = 0, s_xy = 0, s_yy = 0, s_xxb = 0, s_yyb = 0, s_xyb = 0;
     const int ntiles = (B + kMmdTile - 1) / kMmdTile;
     const int nchunks = a.grads ? (d + kMmdKC - 1) / kMmdKC : 1;
 
@@ -108,8 +134,9 @@ __global__ __launch_bounds__(256) void mmd_kernel(MmdArgs a) {
             const float r_yx = (nxj - 2.0f * g_yx) + nyi, r_yy = (nyi - 2.0f * g_yy) + nyj;
             const float D_xx = fmaxf(r_xx, 0.f), D_xy = fmaxf(r_xy, 0.f);
             const float D_yx = fmaxf(r_yx, 0.f), D_yy = fmaxf(r_yy, 0.f);
-            const float K_xx = expf(-D_xx / 2.0f), K_xy = expf(-D_xy / 2.0f);
-            const float K_yx = expf(-D_yx / 2.0f), K_yy = expf(-D_yy / 2.0f);
+            float K_xx, K_xy, K_yx, K_yy, G_xx, G_xy, G_yx, G_yy;
+            gauss<mix>(D_xx, K_xx, G_xx); gauss<mix>(D_xy, K_xy, G_xy);
+            gauss<mix>(D_yx, K_yx, G_yx); gauss<mix>(D_yy, K_yy, G_yy);
 
             if (kc == 0) {
                 if (off) {
@@ -118,6 +145,11 @@ __global__ __launch_bounds__(256) void mmd_kernel(MmdArgs a) {
                         s_xxb += (double)expf(-fmaxf(D_xx, a.lb) / 2.0f);                        // :1386
                         s_yyb += (double)(yy_lower ? expf(-fmaxf(D_yy, a.lb) / 2.0f)
                                                    : expf(-fminf(D_yy, a.ub) / 2.0f));          // :1391-1394
+                    }
+                    if (mgb) {                                                                   // :1316-1322
+                        s_xxb += (double)expf(-fmaxf(D_xx, a.lb) / 2.0f);
+                        s_yyb += (double)expf(-fmaxf(D_yy, a.lb) / 2.0f);
+                        s_xyb += (double)expf(-fminf(D_xy, a.ub) / 2.0f);
                     }
                 }
                 if (valid) {
@@ -133,15 +165,19 @@ __global__ __launch_bounds__(256) void mmd_kernel(MmdArgs a) {
                 // clamp-active entries of the bounded loss pass none
                 const float p_xx = (off && r_xx > 0.f) ? 1.f : 0.f, p_xy = (off && r_xy > 0.f) ? 1.f : 0.f;
                 const float p_yx = (off && r_yx > 0.f) ? 1.f : 0.f, p_yy = (off && r_yy > 0.f) ? 1.f : 0.f;
-                float b_xx = p_xx, b_yy = p_yy;
+                float b_xx = p_xx, b_yy = p_yy, b_xy = p_xy, b_yx = p_yx;
                 if (rmb) {
                     b_xx = (D_xx > a.lb) ? p_xx : 0.f;
                     b_yy = (yy_lower ? (D_yy > a.lb) : (D_yy < a.ub)) ? p_yy : 0.f;
                 }
-                const float Ag = -2.f * cg_xx * inv * K_xx * p_xx, Bg = -cg_xy * inv * K_xy * p_xy;
-                const float Cg = -2.f * cg_yy * inv * K_yy * p_yy, Eg = -cg_xy * inv * K_yx * p_yx;
-                const float Ad = -2.f * cd_xx * inv * K_xx * b_xx, Bd = -cd_xy * inv * K_xy * p_xy;
-                const float Cd = -2.f * cd_yy * inv * K_yy * b_yy, Ed = -cd_xy * inv * K_yx * p_yx;
+                if (mgb) {                       // tf.maximum / tf.minimum pass the gradient to the distance on a tie
+                    b_xx = (D_xx >= a.lb) ? p_xx : 0.f; b_yy = (D_yy >= a.lb) ? p_yy : 0.f;
+                    b_xy = (D_xy <= a.ub) ? p_xy : 0.f; b_yx = (D_yx <= a.ub) ? p_yx : 0.f;
+                }
+                const float Ag = -2.f * cg_xx * inv * G_xx * p_xx, Bg = -cg_xy * inv * G_xy * p_xy;
+                const float Cg = -2.f * cg_yy * inv * G_yy * p_yy, Eg = -cg_xy * inv * G_yx * p_yx;
+                const float Ad = -2.f * cd_xx * inv * G_xx * b_xx, Bd = -cd_xy * inv * G_xy * b_xy;
+                const float Cd = -2.f * cd_yy * inv * G_yy * b_yy, Ed = -cd_xy * inv * G_yx * b_yx;
 #pragma unroll
                 for (int k = 0; k < kMmdKC; ++k) {
                     if (k0 + k < d) {
@@ -176,7 +212,7 @@ __global__ __launch_bounds__(256) void mmd_kernel(MmdArgs a) {
     }
 
     // ---- kernel-sum reduction: wave -> block -> grid (last block finalises) -------------------
-    double sums[kNumSums] = {s_xx, s_xy, s_yy, s_xxb, s_yyb};
+    double sums[kNumSums] = {s_xx, s_xy, s_yy, s_xxb, s_yyb, s_xyb};
 #pragma unroll
     for (int q = 0; q < kNumSums; ++q) sums[q] = wave_sum(sums[q]);
     __syncthreads();
@@ -208,14 +244,62 @@ __global__ __launch_bounds__(256) void mmd_kernel(MmdArgs a) {
         if (lane == 0) {
             const double denom = (double)B * ((double)B - 1.0);
             const double e_xx = tot[0] / denom, e_xy = tot[1] / denom, e_yy = tot[2] / denom;
-            const double e_xxb = rmb ? tot[3] / denom : e_xx, e_yyb = rmb ? tot[4] / denom : e_yy;
-            // math_func.py:1341-1342,1421; e_kxy_b == e_kxy for every admissible weight pair (:1402)
+            const double e_xxb = (rmb || mgb) ? tot[3] / denom : e_xx, e_yyb = (rmb || mgb) ? tot[4] / denom : e_yy;
+            // math_func.py:1341-1342,1421; in rmb e_kxy_b == e_kxy for every admissible weight pair (:1402)
+            const double e_xyb = mgb ? tot[5] / denom : e_xy;
             a.out[0] = (float)(e_xx + e_yy - 2.0 * e_xy);
-            a.out[1] = (float)((double)a.w0 * e_xy - e_xxb - (double)a.w1 * e_yyb);
+            a.out[1] = (float)((double)a.w0 * e_xyb - e_xxb - (double)a.w1 * e_yyb);
             a.out[2] = (float)e_xx; a.out[3] = (float)e_xy; a.out[4] = (float)e_yy;
-            a.out[5] = (float)e_xxb; a.out[6] = (float)e_yyb; a.out[7] = 0.f;
+            a.out[5] = (float)e_xxb; a.out[6] = (float)e_yyb; a.out[7] = (float)e_xyb;
             __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+}
+
+// ---- score-based losses: no pairwise term, one block --------------------------------------------
+// hinge (math_func.py:2137-2143):    loss_dis = mean relu(1 + s_gen) + mean relu(1 - s_x); loss_gen = mean(-s_gen)
+// logistic (math_func.py:2128-2135): loss_dis = mean(softplus(s_gen) + softplus(-s_x)); loss_gen = mean softplus(-s_gen)
+__device__ __forceinline__ float softplus_f(float z) { return fmaxf(z, 0.f) + log1pf(expf(-fabsf(z))); }
+__device__ __forceinline__ float sigmoid_f(float z) {
+    const float e = expf(-fabsf(z));
+    return z >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+}
+
+template <bool HINGE>
+__global__ __launch_bounds__(256) void score_loss_kernel(const float *sg, const float *sx, int n, int dis_first,
+                                                         float *out, float *grads) {
+    __shared__ double red[4][3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float invn = 1.0f / (float)n;
+    // natural order [dLg/ds_gen, dLg/ds_x, dLd/ds_gen, dLd/ds_x]; dis_first as in mmd_kernel
+    const int s0 = dis_first ? 2 : 0, s1 = dis_first ? 3 : 1, s2 = dis_first ? 1 : 2, s3 = dis_first ? 0 : 3;
+    double a_dg = 0, a_dx = 0, a_g = 0;
+    for (int t = tid; t < n; t += 256) {
+        const float g = sg[t], x = sx[t];
+        float gg, dg, dx;
+        if (HINGE) {
+            a_dg += (double)fmaxf(1.0f + g, 0.f); a_dx += (double)fmaxf(1.0f - x, 0.f); a_g += (double)(-g);
+            gg = -invn; dg = (1.0f + g > 0.f) ? invn : 0.f; dx = (1.0f - x > 0.f) ? -invn : 0.f;
+        } else {
+            a_dg += (double)softplus_f(g); a_dx += (double)softplus_f(-x); a_g += (double)softplus_f(-g);
+            gg = -sigmoid_f(-g) * invn; dg = sigmoid_f(g) * invn; dx = -sigmoid_f(-x) * invn;
+        }
+        if (grads) {
+            grads[(size_t)s0 * n + t] = gg; grads[(size_t)s1 * n + t] = 0.f;
+            grads[(size_t)s2 * n + t] = dg; grads[(size_t)s3 * n + t] = dx;
+        }
+    }
+    a_dg = wave_sum(a_dg); a_dx = wave_sum(a_dx); a_g = wave_sum(a_g);
+    if (lane == 0) { red[wave][0] = a_dg; red[wave][1] = a_dx; red[wave][2] = a_g; }
+    __syncthreads();
+    if (tid == 0) {
+        double t0 = 0, t1 = 0, t2 = 0;
+        for (int w = 0; w < 4; ++w) { t0 += red[w][0]; t1 += red[w][1]; t2 += red[w][2]; }
+        const double dn = (double)n;
+        out[0] = (float)(t2 / dn);
+        out[1] = (float)(t0 / dn + t1 / dn);
+        out[2] = (float)(t0 / dn); out[3] = (float)(t1 / dn);
+        out[4] = out[5] = out[6] = out[7] = 0.f;
     }
 }
 
@@ -238,14 +322,25 @@ extern "C" size_t mmdgan_mmd_workspace_bytes(int B, int d) {
 extern "C" int mmdgan_mmd_loss(const float *s_gen, const float *s_x, int B, int d, int loss_type, float w0, float w1,
                                float lower_bound, float upper_bound, float *out_scalars, float *grads,
                                unsigned char *masks, float *dist, void *workspace, void *stream) {
-    MMDGAN_REQUIRE(s_gen && s_x && out_scalars && workspace, "mmd_loss: null pointer");
-    MMDGAN_REQUIRE(B >= 2, "mmd_loss: batch_size must be >= 2 (got %d)", B);
-    MMDGAN_REQUIRE(d >= 1 && d <= kMmdMaxD, "mmd_loss: d must be in [1,%d] (got %d)", kMmdMaxD, d);
+    MMDGAN_REQUIRE(s_gen && s_x && out_scalars, "mmd_loss: null pointer");
     const int dis_first = (loss_type & MMDGAN_LOSS_FLAG_GRADS_DIS_FIRST) != 0;
     loss_type &= ~MMDGAN_LOSS_FLAG_GRADS_DIS_FIRST;
-    MMDGAN_REQUIRE(loss_type == MMDGAN_LOSS_REP || loss_type == MMDGAN_LOSS_RMB, "mmd_loss: unknown loss %d", loss_type);
-    MMDGAN_REQUIRE(w0 - w1 == 1.0f, "w[0]-w[1] must be 1");       // math_func.py:1340
+    MMDGAN_REQUIRE(loss_type >= MMDGAN_LOSS_REP && loss_type <= MMDGAN_LOSS_LOGISTIC, "mmd_loss: unknown loss %d", loss_type);
     hipStream_t st = (hipStream_t)stream;
+    if (loss_type == MMDGAN_LOSS_HINGE || loss_type == MMDGAN_LOSS_LOGISTIC) {
+        MMDGAN_REQUIRE(!masks && !dist, "mmd_loss: hinge / logistic have no pairwise distances");
+        MMDGAN_REQUIRE(B >= 1 && d >= 1, "mmd_loss: empty scores");
+        if (loss_type == MMDGAN_LOSS_HINGE)
+            hipLaunchKernelGGL(score_loss_kernel<true>, dim3(1), dim3(256), 0, st, s_gen, s_x, B * d, dis_first, out_scalars, grads);
+        else
+            hipLaunchKernelGGL(score_loss_kernel<false>, dim3(1), dim3(256), 0, st, s_gen, s_x, B * d, dis_first, out_scalars, grads);
+        return check_launch("score_loss");
+    }
+    MMDGAN_REQUIRE(workspace, "mmd_loss: null workspace");
+    MMDGAN_REQUIRE(B >= 2, "mmd_loss: batch_size must be >= 2 (got %d)", B);
+    MMDGAN_REQUIRE(d >= 1 && d <= kMmdMaxD, "mmd_loss: d must be in [1,%d] (got %d)", kMmdMaxD, d);
+    if (loss_type == MMDGAN_LOSS_MMD_G || loss_type == MMDGAN_LOSS_MGB) { w0 = 2.0f; w1 = 1.0f; }   // loss_dis = -mmd
+    MMDGAN_REQUIRE(w0 - w1 == 1.0f, "w[0]-w[1] must be 1");       // math_func.py:1340
     MmdArgs a;
     a.x = s_gen; a.y = s_x; a.B = B; a.d = d; a.loss_type = loss_type; a.dis_first = dis_first;
     a.w0 = w0; a.w1 = w1; a.lb = lower_bound; a.ub = upper_bound;
@@ -255,11 +350,14 @@ extern "C" int mmdgan_mmd_loss(const float *s_gen, const float *s_x, int B, int 
     if (zero_output(a.counter, 64, st) != hipSuccess) return check_launch("mmd_loss memset");
     const int blocks = (B + kMmdRows - 1) / kMmdRows;
     const size_t lds = mmd_lds_bytes(d);
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void *)mmd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    void (*kern)(MmdArgs) = loss_type == MMDGAN_LOSS_REP ? mmd_kernel<MMDGAN_LOSS_REP>
+                          : loss_type == MMDGAN_LOSS_RMB ? mmd_kernel<MMDGAN_LOSS_RMB>
+                          : loss_type == MMDGAN_LOSS_MMD_G ? mmd_kernel<MMDGAN_LOSS_MMD_G> : mmd_kernel<MMDGAN_LOSS_MGB>;
+    static bool attr_set[4] = {false, false, false, false};
+    if (!attr_set[loss_type] && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set[loss_type] = true;
     }
-    hipLaunchKernelGGL(mmd_kernel, dim3(blocks), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, a);
     return check_launch("mmd_loss");
 }

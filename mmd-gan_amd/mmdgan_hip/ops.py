@@ -12,7 +12,8 @@ from . import _lib
 from ._lib import ConvGeom, check
 
 ACT = {'linear': 0, 'relu': 1, 'lrelu': 2, 'tanh': 3}
-LOSS = {'rep': 0, 'rep_mmd_g': 0, 'rmb': 1, 'rep_b': 1, 'rep_mmd_b': 1}
+LOSS = {'rep': 0, 'rep_mmd_g': 0, 'rmb': 1, 'rep_b': 1, 'rep_mmd_b': 1,                  # math_func.py:2644-2647
+        'mmd_g': 2, 'fixed_g': 2, 'mgb': 3, 'hinge': 4, 'logistic': 5, '': 5}                  # :2602-2611
 
 _device_checked = False
 
@@ -257,8 +258,10 @@ _mmd_ws = {}
 
 def mmd_loss(s_gen, s_x, loss_type='rep', rep_weights=(0.0, -1.0), lower_bound=0.25, upper_bound=4.0,
              need_grads=True, need_masks=False, need_dist=False, grads_dis_first=False):
-    """fused pairwise-distance / Gaussian-kernel / rep|rmb loss (math_func.py:2505-2550).
-    Returns dict(scalars[8] = loss_gen, loss_dis, e_kxx, e_kxy, e_kyy, e_kxx_b, e_kyy_b, 0;
+    """fused pairwise-distance / Gaussian-kernel / rep|rmb loss (math_func.py:2505-2550); also 'mmd_g', 'mgb'
+    (:2160-2193) and the score losses 'hinge', 'logistic' (:2128-2143), for which scalars[2:4] are the two means of
+    loss_dis and masks / dist do not exist.
+    Returns dict(scalars[8] = loss_gen, loss_dis, e_kxx, e_kxy, e_kyy, e_kxx_b, e_kyy_b, e_kxy_b;
                  grads[4,B,d] = dLg/ds_gen, dLg/ds_x, dLd/ds_gen, dLd/ds_x (grads_dis_first: dLd/ds_x, dLd/ds_gen,
                  dLg/ds_gen, dLg/ds_x), masks[3,B,B] (bool), dist[3,B,B])."""
     lib = require_device()

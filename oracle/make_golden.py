@@ -112,6 +112,51 @@ def make_mmd():
 
 
 # ---------------------------------------------------------------------------
+# 1b. SURVEY 8(f) row 1: the other in-kernel losses - mixture-Gaussian mmd_g (math_func.py:1435-1473, 2160-2173),
+#     mgb (:2175-2193), hinge (:2137-2143), logistic (:2128-2135) - through the reference's own GANLoss
+# ---------------------------------------------------------------------------
+def run_loss_next(loss_type, s_gen_np, s_x_np):
+    out = {}
+    B = s_gen_np.shape[0]
+    for key, dt in DT.items():
+        tf.set_dtype(dt)
+        tf.STATE.reset()
+        sg = torch.tensor(s_gen_np, dtype=dt, requires_grad=True)
+        sx = torch.tensor(s_x_np, dtype=dt, requires_grad=True)
+        lg, ld = ref_math.GANLoss(False).apply(sg, sx, loss_type, batch_size=B, d=s_gen_np.shape[1])
+        glg = torch.autograd.grad(lg, [sg, sx], retain_graph=True, allow_unused=True)
+        gld = torch.autograd.grad(ld, [sg, sx], allow_unused=True)
+        z = lambda g, like: npy(g) if g is not None else np.zeros_like(npy(like))
+        out.update({'loss_gen_' + key: npy(lg), 'loss_dis_' + key: npy(ld),
+                    'dLg_dsgen_' + key: z(glg[0], sg), 'dLg_dsx_' + key: z(glg[1], sx),
+                    'dLd_dsgen_' + key: z(gld[0], sg), 'dLd_dsx_' + key: z(gld[1], sx)})
+        if key == 'f32' and loss_type == 'mgb':
+            dgg, dgd, ddd = ref_math.get_squared_dist(sg, sx)
+            off = ~np.eye(B, dtype=bool)
+            out['threshold_margin'] = np.float64(min(np.abs(npy(dgg)[off] - 0.25).min(), np.abs(npy(ddd)[off] - 0.25).min(),
+                                                     np.abs(npy(dgd) - 4.0).min()))
+    out.update({'s_gen': s_gen_np, 's_x': s_x_np, 'loss_type': np.asarray(loss_type)})
+    return out
+
+
+def make_loss_next():
+    n = 0
+    for loss_type in ('mmd_g', 'mgb', 'hinge', 'logistic'):
+        for B in (8, 64):
+            for (sg, sx, off) in ((0.25, 0.3, 0.1), (1.0, 1.0, 0.2)):
+                seed = 0
+                while True:                                       # reject near-threshold seeds (mgb clamps)
+                    s_gen, s_x = mmd_inputs(B, 16, sg, sx, off, 5000 + 1000 * n + seed)
+                    fx = run_loss_next(loss_type, s_gen, s_x)
+                    if fx.get('threshold_margin', 1.0) > 1e-4:
+                        break
+                    seed += 1
+                np.savez_compressed(os.path.join(OUT, 'lossx_{}_B{}_c{:02d}.npz'.format(loss_type, B, n)), **fx)
+                n += 1
+    print('next-row loss fixtures:', n)
+
+
+# ---------------------------------------------------------------------------
 # 2. layers through the reference's Net / Routine (layer_func.py)
 # ---------------------------------------------------------------------------
 def build_routine(designs, net_name, input_shape):
@@ -296,6 +341,10 @@ if __name__ == '__main__':
     torch.manual_seed(0)
     torch.set_num_threads(4)
     make_mmd()
+    if '--only-next' in sys.argv:
+        make_loss_next()
+        sys.exit(0)
+    make_loss_next()
     make_layers()
     make_step('rep')
     make_step('rmb', store_grads=False)

@@ -352,7 +352,43 @@ def gan_loss(score_gen, score_data, loss_type, batch_size, rep_weights=(0.0, -1.
         d = get_squared_dist(score_gen, score_data)
         return mmd_g_bounded(*d, batch_size, sigma=1.0, lower_bound=0.25, upper_bound=4.0,
                              custom_weights=list(rep_weights))
+    # ---- the other in-kernel losses
+    if loss_type in ('mmd_g', 'fixed_g'):                 # math_func.py:2160-2173 + mixture_mmd_g :1435-1462
+        d = get_squared_dist(score_gen, score_data)
+        total, stats = 0.0, {'kxx': 0.0, 'kxy': 0.0, 'kyy': 0.0}
+        for sigma in MIXTURE_SIGMA:
+            mmd_i, _, st = mmd_g(*d, batch_size, sigma=sigma)
+            total = total + mmd_i
+            stats = {k: stats[k] + st[k] for k in stats}
+        return total, -total, stats
+    if loss_type == 'mgb':                                # math_func.py:2175-2193
+        d = get_squared_dist(score_gen, score_data)
+        loss_gen, _, stats = mmd_g(*d, batch_size, sigma=1.0)
+        mmd_b, st_b = mmd_g_clamped(*d, batch_size, sigma=1.0, upper_bound=4.0, lower_bound=0.25)
+        stats.update(st_b)
+        return loss_gen, -mmd_b, stats
+    if loss_type == 'hinge':                              # math_func.py:2137-2143
+        loss_dis = torch.relu(1.0 + score_gen).mean() + torch.relu(1.0 - score_data).mean()
+        return (-score_gen).mean(), loss_dis, {}
+    if loss_type in ('logistic', ''):                     # math_func.py:2128-2135 (non-saturating)
+        sp = torch.nn.functional.softplus
+        return sp(-score_gen).mean(), (sp(score_gen) + sp(-score_data)).mean(), {}
     raise NotImplementedError('Not implemented.')
+
+
+MIXTURE_SIGMA = [1.0, math.sqrt(2.0), 2.0, math.sqrt(8.0), 4.0]      # math_func.py:2108
+
+
+def mmd_g_clamped(dist_xx, dist_xy, dist_yy, batch_size, sigma=1.0, upper_bound=None, lower_bound=None):
+    """mmd_g with its bounds arguments (math_func.py:1312-1322, 1324-1335): k_xx, k_yy from max(dist, lower_bound),
+    k_xy from min(dist, upper_bound)."""
+    s2 = 2.0 * sigma ** 2
+    dxx = dist_xx if lower_bound is None else torch.clamp(dist_xx, min=lower_bound)
+    dyy = dist_yy if lower_bound is None else torch.clamp(dist_yy, min=lower_bound)
+    dxy = dist_xy if upper_bound is None else torch.clamp(dist_xy, max=upper_bound)
+    m = float(batch_size)
+    e_kxx, e_kxy, e_kyy = (matrix_mean_wo_diagonal(torch.exp(-t / s2), m) for t in (dxx, dxy, dyy))
+    return e_kxx + e_kyy - 2.0 * e_kxy, {'kxx_b': e_kxx, 'kxy_b': e_kxy, 'kyy_b': e_kyy}
 
 
 def mmd_masks(score_gen, score_data, lower_bound=0.25, upper_bound=4.0):

@@ -40,13 +40,13 @@ def test_ganloss_and_squared_dist_api():
     rs = np.random.RandomState(0)
     sg = torch.as_tensor((rs.randn(64, 16) * 0.25).astype(np.float32)).cuda()
     sx = torch.as_tensor((rs.randn(64, 16) * 0.3 + 0.1).astype(np.float32)).cuda()
-    for loss in ('rep', 'rmb'):
+    for loss in ('rep', 'rmb', 'mmd_g', 'fixed_g', 'mgb', 'hinge', 'logistic', ''):
         lg, ld = GANLoss(False).apply(sg, sx, loss, batch_size=64, d=16, rep_weights=[0.0, -1.0])
         rg, rd, _ = R.gan_loss(sg.cpu().double(), sx.cpu().double(), loss, 64)
         assert abs(float(lg) - float(rg)) <= RTOL * abs(float(rg)) + 4e-7
         assert abs(float(ld) - float(rd)) <= RTOL * abs(float(rd)) + 4e-7
     with pytest.raises(NotImplementedError, match='Not implemented.'):
-        GANLoss().apply(sg, sx, 'hinge', batch_size=64)
+        GANLoss().apply(sg, sx, 'wasserstein', batch_size=64)
     dxx, dxy, dyy = get_squared_dist(sg, sx)
     ref = R.get_squared_dist(sg.cpu().double(), sx.cpu().double())
     for got, r in zip((dxx, dxy, dyy), ref):

@@ -88,6 +88,51 @@ def test_mmd_loss_matches_c_oracle(ops, B, d, loss_type):
         assert rel_err(g[i], ref['grads'][i]) <= RTOL, i
 
 
+LOSSX = golden('lossx_*.npz')
+NEXT_LOSSES = ('mmd_g', 'mgb', 'hinge', 'logistic')
+
+
+def _check_loss_against(out, lg, ld, grads_ref, pairwise):
+    sc = out['scalars'].cpu().numpy().astype(np.float64)
+    # MMD losses are differences of O(1) kernel means; the score losses are plain means
+    escale = float(np.max(sc[2:5])) if pairwise else 0.0
+    assert abs(sc[0] - lg) <= loss_tol(lg, escale), (sc[0], lg)
+    assert abs(sc[1] - ld) <= loss_tol(ld, escale), (sc[1], ld)
+    g = out['grads'].cpu().numpy()
+    for i in range(4):
+        assert rel_err(g[i], grads_ref[i]) <= RTOL, i
+
+
+@pytest.mark.parametrize('path', LOSSX, ids=[p.split('/')[-1] for p in LOSSX])
+def test_next_row_losses_match_reference_golden(ops, path):
+    """SURVEY 8(f) row 1 ('mmd_g', 'mgb', 'hinge', 'logistic') against the reference's own GANLoss outputs."""
+    fx = load(path)
+    lt = str(fx['loss_type'])
+    out = ops.mmd_loss(dev(fx['s_gen']), dev(fx['s_x']), lt, need_grads=True)
+    _check_loss_against(out, float(fx['loss_gen_f64']), float(fx['loss_dis_f64']),
+                        [fx[k] for k in ('dLg_dsgen_f64', 'dLg_dsx_f64', 'dLd_dsgen_f64', 'dLd_dsx_f64')],
+                        lt in ('mmd_g', 'mgb'))
+
+
+@pytest.mark.parametrize('B,d', [(64, 16), (100, 1), (257, 7), (1024, 16), (2, 3)])
+@pytest.mark.parametrize('loss_type', NEXT_LOSSES)
+def test_next_row_losses_match_oracle(ops, B, d, loss_type):
+    rs = np.random.RandomState(B * 31 + d)
+    s_gen = (rs.randn(B, d) * 0.6).astype(np.float32)          # distances straddle both mgb bounds
+    s_x = (rs.randn(B, d) * 0.5 + 0.2).astype(np.float32)
+    sg = torch.tensor(s_gen, dtype=torch.float64, requires_grad=True)
+    sx = torch.tensor(s_x, dtype=torch.float64, requires_grad=True)
+    lg, ld, _ = R.gan_loss(sg, sx, loss_type, B)
+    g = list(torch.autograd.grad(lg, [sg, sx], retain_graph=True, allow_unused=True))
+    g += list(torch.autograd.grad(ld, [sg, sx], allow_unused=True))
+    g = [np.zeros((B, d)) if t is None else t.numpy() for t in g]
+    out = ops.mmd_loss(dev(s_gen), dev(s_x), loss_type, need_grads=True)
+    _check_loss_against(out, float(lg), float(ld), g, loss_type in ('mmd_g', 'mgb'))
+    h = ops.mmd_loss(dev(s_gen), dev(s_x), loss_type, grads_dis_first=True)['grads']
+    for slot, src in enumerate((3, 2, 0, 1)):
+        assert torch.equal(h[slot], out['grads'][src]), (loss_type, slot)
+
+
 def test_mmd_size_independent_properties(ops):
     """at the benchmark's full sweep sizes: permutation invariance, x<->y symmetry of loss_gen,
     zero loss_gen for identical sets, translation invariance."""
@@ -123,7 +168,9 @@ def test_mmd_grads_dis_first_order(ops):
 def test_mmd_errors(ops):
     z = torch.zeros(8, 16).cuda()
     with pytest.raises(NotImplementedError, match='Not implemented.'):          # math_func.py:2651
-        ops.mmd_loss(z, z, 'hinge')
+        ops.mmd_loss(z, z, 'wasserstein')
+    with pytest.raises(ValueError):                                               # no pairwise matrices to return
+        ops.mmd_loss(z, z, 'hinge', need_dist=True)
     with pytest.raises(ValueError, match=r'w\[0\]-w\[1\] must be 1'):            # math_func.py:1340
         ops.mmd_loss(z, z, 'rep', rep_weights=(0.5, 0.0))
     with pytest.raises(ValueError):

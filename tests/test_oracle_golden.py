@@ -35,6 +35,29 @@ def test_mmd_restatement_matches_reference(path, prec):
         assert np.array_equal(m['xy_gt_ub'].numpy(), fx['mask_gd_gt_ub'])
 
 
+LOSSX = golden('lossx_*.npz')
+
+
+@pytest.mark.parametrize('path', LOSSX, ids=[p.split('/')[-1] for p in LOSSX])
+@pytest.mark.parametrize('prec', ['f32', 'f64'])
+def test_next_row_losses_restatement_matches_reference(path, prec):
+    """'mmd_g', 'mgb', 'hinge', 'logistic' of the reference's GANLoss (fixtures from
+    oracle/make_golden.py:make_loss_next)."""
+    fx = load(path)
+    dt = torch.float32 if prec == 'f32' else torch.float64
+    sg = torch.tensor(fx['s_gen'], dtype=dt, requires_grad=True)
+    sx = torch.tensor(fx['s_x'], dtype=dt, requires_grad=True)
+    lg, ld, _ = R.gan_loss(sg, sx, str(fx['loss_type']), sg.shape[0])
+    tol = 2e-5 if prec == 'f32' else 1e-12
+    assert abs(float(lg) - float(fx['loss_gen_' + prec])) <= tol * max(abs(float(fx['loss_gen_' + prec])), 1e-3)
+    assert abs(float(ld) - float(fx['loss_dis_' + prec])) <= tol * max(abs(float(fx['loss_dis_' + prec])), 1e-3)
+    glg = torch.autograd.grad(lg, [sg, sx], retain_graph=True, allow_unused=True)
+    gld = torch.autograd.grad(ld, [sg, sx], allow_unused=True)
+    for got, key in ((glg[0], 'dLg_dsgen_'), (glg[1], 'dLg_dsx_'), (gld[0], 'dLd_dsgen_'), (gld[1], 'dLd_dsx_')):
+        got = np.zeros_like(fx[key + prec]) if got is None else got.numpy()
+        assert rel_err(got, fx[key + prec]) <= (1e-4 if prec == 'f32' else 1e-10)
+
+
 @pytest.mark.parametrize('path', MMD, ids=[p.split('/')[-1] for p in MMD])
 def test_mmd_c_oracle_matches_reference(path):
     fx = load(path)
