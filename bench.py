@@ -113,7 +113,9 @@ def main():
             sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % args.gpus)
     torch.cuda.set_device(local_rank)
     group = None
-    if world > 1:
+    # MMDGAN_DP_FORCE=1 under torch.distributed.run with one rank: time the exchange plumbing on a 1-GPU box
+    force_dp = os.environ.get('MMDGAN_DP_FORCE') == '1' and 'RANK' in os.environ
+    if world > 1 or force_dp:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))     # RCCL over xGMI
@@ -126,7 +128,7 @@ def main():
     # the engine starts in eager mode (its lazily-created buffers are then allocated on the stream that uses
     # them); the hipGraph, if wanted, is captured after the warm-up steps
     eng = GanEngine(arch, args.loss, lr, batch_size=B, seed=0, dist_group=group, use_graph=False)
-    if world > 1:
+    if group is not None:
         from mmdgan_hip import dist as mdist
         mdist.broadcast_state(eng, group)                # identical weights / SN vectors on every replica
     gen = torch.Generator(device='cuda')
@@ -136,7 +138,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if group is not None:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -151,9 +153,9 @@ def main():
     for _ in range(args.warmup):
         eng.step(real)
     barrier()
-    mode = 'eager' if (args.no_graph or world > 1) else 'graph'
+    mode = 'eager' if (args.no_graph or group is not None) else 'graph'
     eng.use_graph = mode == 'graph'
-    if world == 1 and not args.no_graph and not args.graph:
+    if group is None and not args.no_graph and not args.graph:
         # untimed: a few steps each way, keep the faster launch mode
         trial = {}
         for m in ('eager', 'graph'):
@@ -180,7 +182,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1) / args.steps
-    if world > 1:
+    if group is not None:
         import torch.distributed as dist
         t = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -225,7 +227,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(arch, lr, args.loss, B, args.cpu_steps)
         print(json.dumps(out))
-    if world > 1:
+    if group is not None:
         import torch.distributed as dist
         dist.destroy_process_group()
 

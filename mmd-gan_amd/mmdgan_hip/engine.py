@@ -337,6 +337,7 @@ class GanEngine:
         self.score_size = self.dis.specs[-1].out
         self.global_step = 0
         self.dist_group = dist_group
+        self._dp_force = os.environ.get('MMDGAN_DP_FORCE') == '1'
         self.world = 1
         if dist_group is not None:
             import torch.distributed as tdist
@@ -705,8 +706,8 @@ class GanEngine:
     def _allreduce(self, net):
         """start the bucketed SUM all-reduce of one network's gradient arena (RCCL, its own stream);
         it overlaps with whatever backward work is issued next and is awaited before Adam."""
-        if self.dist_group is None or self.world == 1:
-            return
+        if self.dist_group is None or (self.world == 1 and not self._dp_force):
+            return                                       # MMDGAN_DP_FORCE=1: exchange even with one rank (plumbing test)
         from . import dist as mdist
         self._pending += mdist.allreduce_sum_async(net.grads, self.dist_group)
 
