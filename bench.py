@@ -116,10 +116,8 @@ def main():
     # MMDGAN_DP_FORCE=1 under torch.distributed.run with one rank: time the exchange plumbing on a 1-GPU box
     force_dp = os.environ.get('MMDGAN_DP_FORCE') == '1' and 'RANK' in os.environ
     if world > 1 or force_dp:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))     # RCCL over xGMI
-        group = dist.group.WORLD
+        from mmdgan_hip import dist as mdist
+        group = mdist.init_process_group(local_rank)     # RCCL over xGMI, its stream on a hardware queue of its own
 
     import configs
     from mmdgan_hip.engine import GanEngine

@@ -342,14 +342,17 @@ class GanEngine:
         if dist_group is not None:
             import torch.distributed as tdist
             self.world = tdist.get_world_size(dist_group)
-        self._pending = []
-        # the power iterations of different layers are independent of each other too: two chains
-        self._sn_streams = [torch.cuda.Stream(device=self.device)
-                            for _ in range(int(os.environ.get('MMDGAN_SN_STREAMS', '2')))]
+        self._exchange_pending = False
+        # the power iterations of different layers are independent of each other too: two chains.
         # weight / bias gradients of a layer depend only on dz of that layer, not on the dgrad chain that
-        # continues below it: they go to a second stream so their blocks fill the tail of the dgrad
-        # launches (each launch alone leaves CUs idle while its last wave of tiles drains)
-        self._wg_stream = torch.cuda.Stream(device=self.device)
+        # continues below it: they go to another stream so their blocks fill the tail of the dgrad
+        # launches (each launch alone leaves CUs idle while its last wave of tiles drains).
+        # All of them must sit on hardware queues of their own (streams.py: 2.43 vs 2.55 / 2.89 ms per step)
+        from .streams import distinct_queue_streams
+        n_sn = int(os.environ.get('MMDGAN_SN_STREAMS', '2'))
+        side = distinct_queue_streams(n_sn + 1, self.device)
+        self._wg_stream, self._sn_streams = side[0], side[1:]
+        self._comm_stream = side[1] if len(side) > 1 else side[0]      # gradient exchange, see _allreduce
         self._side_wgrad = os.environ.get('MMDGAN_SIDE_WGRAD', '1') != '0'
         if ops._workspace is None:
             ops.set_workspace(device=self.device)
@@ -704,18 +707,29 @@ class GanEngine:
 
     # ---------------------------------------------------------------------------------------
     def _allreduce(self, net):
-        """start the bucketed SUM all-reduce of one network's gradient arena (RCCL, its own stream);
-        it overlaps with whatever backward work is issued next and is awaited before Adam."""
+        """start the bucketed SUM all-reduce of one network's gradient arena; it overlaps with whatever backward
+        work is issued next and is awaited before Adam.  The collectives are issued as blocking ones on a stream
+        of our own choosing - ProcessGroupNCCL then runs them there, not on its internal stream, whose hardware
+        queue it shares with whichever of our streams happens to map to it (streams.py).  The stream used is the
+        first power-iteration stream: idle from the start of D's forward pass to the next step, on a queue of
+        its own, and the spectral-norm chain of the next step has to wait for this step's Adam anyway."""
         if self.dist_group is None or (self.world == 1 and not self._dp_force):
             return                                       # MMDGAN_DP_FORCE=1: exchange even with one rank (plumbing test)
         from . import dist as mdist
-        self._pending += mdist.allreduce_sum_async(net.grads, self.dist_group)
+        comm = self._comm_stream
+        # the arena is complete once the parameter-gradient stream has drained AND the main stream has reached
+        # this point (thin layers' gradients stay there); the main stream itself goes straight on
+        comm.wait_stream(torch.cuda.current_stream())
+        if self._side_wgrad:
+            comm.wait_stream(self._wg_stream)
+        with torch.cuda.stream(comm):
+            mdist.allreduce_sum_(net.grads, self.dist_group)
+        self._exchange_pending = True
 
     def _update(self):
-        if self._pending:
-            from . import dist as mdist
-            mdist.wait_all(self._pending)
-            self._pending = []
+        if self._exchange_pending:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+            self._exchange_pending = False
         gs = 1.0 / self.world
         self.dis.opt.step(self.lr_d, grad_scale=gs)
         self.gen.opt.step(self.lr_g, grad_scale=gs)
@@ -752,12 +766,10 @@ class GanEngine:
             if arenas:
                 torch.cuda.current_stream().wait_stream(self._wg_stream)
             dz = self._backward_dis()
-            if self.dist_group is not None:
-                self._join_wg_stream()
             self._allreduce(self.dis)
             self._backward_gen(dz, z)
-            self._join_wg_stream()
             self._allreduce(self.gen)
+            self._join_wg_stream()
             self._update()
         finally:
             lib.mmdgan_set_outputs_prezeroed(0)

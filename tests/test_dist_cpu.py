@@ -35,6 +35,8 @@ def _worker(rank, world, port, q):
         tdist.all_gather(gathered, mine)
         ref = torch.stack(gathered).sum(0)
         ok_sum = torch.allclose(flat, ref, rtol=0, atol=1e-5)
+        # the blocking variant the engine issues on its own stream: same buckets, same sums
+        ok_sum = ok_sum and torch.allclose(mdist.allreduce_sum_(mine.clone(), bucket_bytes=64 << 10), ref, rtol=0, atol=1e-5)
         avg = mdist.average_(mine.clone(), bucket_bytes=1 << 20)
         ok_avg = torch.allclose(avg, ref / world, rtol=0, atol=1e-5)
 
