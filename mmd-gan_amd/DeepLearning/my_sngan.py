@@ -54,6 +54,7 @@ class SNGan(object):
         if self.engine is None or self.engine.B != batch_size:
             self.engine = GanEngine(self.architecture, self.loss_type, lr_list, tuple(self.rep_weights),
                                     batch_size=batch_size, seed=seed, dist_group=self.dist_group,
+                                    sn_mode=FLAGS.SPECTRAL_NORM_MODE,                # layer_func.py:802-814
                                     # eager issue measured faster than replaying the 3-branch hipGraph when the
                                     # host keeps up (2.55 vs 2.72 ms/step, bench.py tries both); MMDGAN_HIP_GRAPH=1
                                     # for hosts that do not

@@ -40,7 +40,8 @@ class Routine(object):
         """input_shape = [batch, features] or [batch, C, H, W]; only dims [1:] matter (layer_func.py:694)."""
         if out_layer_indices != [0]:
             raise NotImplementedError('only sequential routines are on the hot path')
-        self.net.specs = build_specs(self.net.net_def, list(input_shape[1:]), self.net.net_name)
+        self.net.specs = build_specs(self.net.net_def, list(input_shape[1:]), self.net.net_name,
+                                    FLAGS.SPECTRAL_NORM_MODE)
         self.layer_indices.append(0)
 
     def seq_links(self, in_layer_indices):

@@ -14,7 +14,7 @@ _DEFAULTS = dict(
     INCEPTION_V1=None, INCEPTION_V3=None, PLT_ACC=None, PLT_KEY=None,
     IMAGE_FORMAT='channels_first', IMAGE_FORMAT_ALIAS='NCHW',
     WEIGHT_INITIALIZER='default',          # 'default' | 'sn_paper' | 'pg_paper'
-    SPECTRAL_NORM_MODE='default',          # 'default' (= PICO) | 'sn_paper' (PIM, not on the hot path)
+    SPECTRAL_NORM_MODE='default',          # 'default' (= PICO) | 'sn_paper' (PIM: flattened-kernel power iteration)
     SYNTHETIC_DATA=False,
 )
 

@@ -57,7 +57,7 @@ def _chw_perm(c, h, w):
 class LayerSpec:
     """one layer of a Net after update_layer_design defaults and shape inference."""
 
-    def __init__(self, design, net_name, in_shape_ref):
+    def __init__(self, design, net_name, in_shape_ref, sn_mode='default'):
         d = dict(_TEMPLATE)
         d.update(design)
         if d['act_nm'] in ('bn', 'BN') and d['bias'] in ('b', 'bias'):     # layer_func.py:1241-1242
@@ -99,10 +99,18 @@ class LayerSpec:
             out = [self.out, h * self.stride, w * self.stride]
         self.op_out_ref = out
         self.channels = out[0]
+        self.pim = False
         if self.sn:                                                        # math_func.py:481-486, 512-528
             if self.op == 'd':
                 self.use_u = in_shape_ref[0] <= self.out
                 self.sn_x_ref = [1, in_shape_ref[0]] if self.use_u else [1, self.out]
+            elif self.op == 'c' and sn_mode in ('sn_paper', 'PIM', 'pim'):
+                # layer_func.py:811-814: power iteration on the kernel flattened to [k*k*c_in, c_out]
+                # (HWIO is already that matrix, row-major) through the dense routine
+                num_in = int(np.prod(self.kernel_shape[:3]))
+                self.pim = True
+                self.use_u = num_in <= self.out
+                self.sn_x_ref = [1, num_in] if self.use_u else [1, self.out]
             else:
                 self.use_u = int(np.prod(in_shape_ref)) <= int(np.prod(out))
                 if self.op == 'c':
@@ -120,10 +128,10 @@ class LayerSpec:
             self.col_perm = _chw_perm(*self.out_reshape)
 
 
-def build_specs(designs, input_shape_ref, net_name):
+def build_specs(designs, input_shape_ref, net_name, sn_mode='default'):
     specs, shape, prev = [], list(input_shape_ref), None
     for design in designs:
-        s = LayerSpec(design, net_name, shape)
+        s = LayerSpec(design, net_name, shape, sn_mode)
         if s.op == 'd' and prev is not None and len(prev.op_out_ref) == 3:
             s.row_perm = _chw_perm(*prev.op_out_ref)                       # e.g. D l7 -> l8 (my_test_cifar.py:36)
         specs.append(s)
@@ -199,8 +207,8 @@ class Network:
 
     @staticmethod
     def _sn_u_shape(s):
-        if s.op == 'd':
-            return [1, s.out] if s.use_u else [1, s.kernel_shape[0]]
+        if s.op == 'd' or s.pim:
+            return [1, s.out] if s.use_u else [1, int(np.prod(s.kernel_shape[:-1]))]
         c, h, w = s.in_shape_ref
         k, p, q = s.op_out_ref
         return [1, p, q, k] if s.use_u else [1, h, w, c]
@@ -317,7 +325,7 @@ class GanEngine:
     """G + D + loss + two TF-Adam optimisers; `step()` = one sess.run of graph_func.py:853."""
 
     def __init__(self, architecture, loss_type='rep', lr_list=(5e-4, 2e-4), rep_weights=(0.0, -1.0),
-                 batch_size=64, seed=0, device=None, dist_group=None, use_graph=False):
+                 batch_size=64, seed=0, device=None, dist_group=None, use_graph=False, sn_mode='default'):
         ops.require_device()
         if loss_type not in ops.LOSS:
             raise NotImplementedError('Not implemented.')                   # math_func.py:2651
@@ -329,8 +337,11 @@ class GanEngine:
         self.code_size = architecture['code'][0][0]
         self.in_shape_ref = list(architecture['input'][0])
         rng = np.random.RandomState(seed)
-        self.gen = Network(build_specs(architecture['generator'], [self.code_size], 'gen'), self.device, rng)
-        self.dis = Network(build_specs(architecture['discriminator'], self.in_shape_ref, 'dis'), self.device, rng)
+        if sn_mode not in ('default', 'PICO', 'pico', 'sn_paper', 'PIM', 'pim'):                      # layer_func.py:802-814
+            raise NotImplementedError('spectral norm mode {} is not implemented.'.format(sn_mode))
+        self.sn_mode = sn_mode
+        self.gen = Network(build_specs(architecture['generator'], [self.code_size], 'gen', sn_mode), self.device, rng)
+        self.dis = Network(build_specs(architecture['discriminator'], self.in_shape_ref, 'dis', sn_mode), self.device, rng)
         if self.gen.specs[-1].out_shape_ref != self.in_shape_ref:
             raise AssertionError('gen: the output shape {} does not match existed shape {}.'.format(
                 self.gen.specs[-1].out_shape_ref, self.in_shape_ref))
@@ -458,8 +469,10 @@ class GanEngine:
         sigma, scale = net.state[s.scope + '#sigma'], net.state[s.scope + '#scale']
         dsig = net.state[s.scope + '#dsigma']
         u, un, xb, xbn = b[s.scope + '#u'], b[s.scope + '#un'], b[s.scope + '#xb'], b[s.scope + '#xbnorm']
-        if s.op == 'd':
-            if 1 in s.kernel_shape:                                          # math_func.py:702-704
+        if s.op == 'd' or s.pim:
+            if s.pim:                                                        # layer_func.py:811-814
+                w, dsig = w.view(-1, s.out), dsig.view(-1, s.out)
+            if 1 in w.shape:                                                 # math_func.py:702-704
                 ops.sn_norm_scale(w.view(-1), s.act_k, sigma, scale, dsig.view(-1))
             elif s.use_u:
                 ops.gemm(x, w, out=u)                                        # u = x W          [1,out]

@@ -274,7 +274,9 @@ def tf_adam_inplace(var, g, m, v, t, lr, b1=0.5, b2=0.999, eps=1e-8):
         var.sub_(lr_t * m / (torch.sqrt(v) + eps))
 
 
-def make_step(loss_type, B=8, n_steps=3, lr=(5e-4, 2e-4), store_grads=True):
+def make_step(loss_type, B=8, n_steps=3, lr=(5e-4, 2e-4), store_grads=True, sn_mode='default'):
+    """sn_mode='sn_paper': the flattened-matrix power iteration of layer_func.py:811-814."""
+    FLAGS.SPECTRAL_NORM_MODE = sn_mode
     arch = tiny_architecture()
     out = {'lr': np.asarray(lr), 'loss_type': np.asarray(loss_type), 'B': np.asarray(B)}
     rs = np.random.RandomState(77)
@@ -332,8 +334,11 @@ def make_step(loss_type, B=8, n_steps=3, lr=(5e-4, 2e-4), store_grads=True):
         if key == 'f64':
             for k, v in tf.STATE.variables.items():
                 out['final/' + k + '_f64'] = npy(v).astype(np.float32)
-    np.savez_compressed(os.path.join(OUT, 'step_tiny_{}.npz'.format(loss_type)), **out)
-    print('step fixture:', loss_type)
+    tag = loss_type if sn_mode == 'default' else loss_type + '_pim'
+    out['sn_mode'] = np.asarray(sn_mode)
+    FLAGS.SPECTRAL_NORM_MODE = 'default'
+    np.savez_compressed(os.path.join(OUT, 'step_tiny_{}.npz'.format(tag)), **out)
+    print('step fixture:', tag)
 
 
 if __name__ == '__main__':
@@ -343,10 +348,12 @@ if __name__ == '__main__':
     make_mmd()
     if '--only-next' in sys.argv:
         make_loss_next()
+        make_step('rep', store_grads=False, sn_mode='sn_paper')
         sys.exit(0)
     make_loss_next()
     make_layers()
     make_step('rep')
     make_step('rmb', store_grads=False)
+    make_step('rep', store_grads=False, sn_mode='sn_paper')
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print('tests/golden total bytes:', total)

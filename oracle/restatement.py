@@ -60,7 +60,7 @@ def _same_out(size, stride):
     return -(-size // stride)          # math_func.py:172-193 ('SAME')
 
 
-def build_net(designs, input_shape, net_name):
+def build_net(designs, input_shape, net_name, sn_mode='default'):
     """Net + Routine.add_input_layers/seq_links shape inference (layer_func.py:2118,2221,2349).
 
     input_shape excludes the batch dimension: [z] or [C,H,W].  Returns a list of spec dicts."""
@@ -87,6 +87,12 @@ def build_net(designs, input_shape, net_name):
             if d['op'] == 'd':
                 use_u = shape[0] <= d['out']
                 s['sn_x_shape'] = [1, shape[0]] if use_u else [1, d['out']]
+            elif d['op'] == 'c' and sn_mode in ('sn_paper', 'PIM', 'pim'):
+                # layer_func.py:811-814: the kernel flattened to [k*k*c_in, c_out] goes through the dense routine
+                num_in, num_out = int(np.prod(s['kernel_shape'][:3])), d['out']
+                use_u = num_in <= num_out
+                s['sn_x_shape'] = [1, num_in] if use_u else [1, num_out]
+                s['pim'] = True
             else:
                 use_u = int(np.prod(shape)) <= int(np.prod(out))
                 if d['op'] == 'c':
@@ -195,7 +201,8 @@ def sn_power_iteration(w, x, spec):
     """one power-iteration step.  Returns (sigma, x_update).  sigma = ||F(x)|| from the
     PRE-update x (math_func.py:668-670); x is a constant (non-trainable variable)."""
     d = spec['design']
-    if d['op'] == 'd':
+    if d['op'] == 'd' or spec.get('pim'):
+        w = w.reshape(-1, w.shape[-1])                       # no-op for a dense kernel
         if 1 in w.shape:                                     # math_func.py:702-704
             return _l2(w), x
         if spec['use_u']:
@@ -423,11 +430,11 @@ class OracleGan:
     """G + D + losses + two TF-Adam optimisers; one `step` = one sess.run of graph_func.py:853."""
 
     def __init__(self, architecture, loss_type='rep', lr_list=(5e-4, 2e-4), rep_weights=(0.0, -1.0),
-                 seed=0, dtype=torch.float32, params=None):
+                 seed=0, dtype=torch.float32, params=None, sn_mode='default'):
         self.arch, self.loss_type, self.rep_weights, self.dtype = architecture, loss_type, rep_weights, dtype
         self.code_size = architecture['code'][0][0]
-        self.gen_specs = build_net(architecture['generator'], [self.code_size], 'gen')
-        self.dis_specs = build_net(architecture['discriminator'], list(architecture['input'][0]), 'dis')
+        self.gen_specs = build_net(architecture['generator'], [self.code_size], 'gen', sn_mode)
+        self.dis_specs = build_net(architecture['discriminator'], list(architecture['input'][0]), 'dis', sn_mode)
         assert self.gen_specs[-1]['out_shape'] == list(architecture['input'][0])
         rng = np.random.RandomState(seed)
         self.params = OrderedDict()

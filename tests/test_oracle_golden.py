@@ -118,16 +118,19 @@ def test_net_restatement_matches_reference(path):
                 params[n] = v
 
 
-@pytest.mark.parametrize('loss_type', ['rep', 'rmb'])
+@pytest.mark.parametrize('loss_type', ['rep', 'rmb', 'rep_pim'])
 def test_full_step_restatement_matches_reference(loss_type):
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
     fx = load(golden('step_tiny_%s.npz' % loss_type)[0])
     from tiny_arch import tiny_architecture
     arch = tiny_architecture()
+    # '_pim': FLAGS.SPECTRAL_NORM_MODE = 'sn_paper' in the reference run (layer_func.py:811-814)
+    sn_mode = str(fx['sn_mode']) if 'sn_mode' in fx else 'default'
+    loss_type = str(fx['loss_type'])
     init = {k[len('init/'):]: v for k, v in fx.items() if k.startswith('init/')}
     for prec, dt in (('f32', torch.float32), ('f64', torch.float64)):
-        gan = R.OracleGan(arch, loss_type, tuple(fx['lr']), dtype=dt, params=init)
+        gan = R.OracleGan(arch, loss_type, tuple(fx['lr']), dtype=dt, params=init, sn_mode=sn_mode)
         for step in range(3):
             z, real = torch.tensor(fx['z'][step], dtype=dt), torch.tensor(fx['real'][step], dtype=dt)
             pre = 'step%d/' % step
