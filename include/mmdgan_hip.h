@@ -223,6 +223,12 @@ int mmdgan_adam_multi(const void *const *ptrs, const long *sizes, int n_tensors,
 /* layout seam helpers: NCHW <-> NHWC (the reference API speaks NCHW, misc_fun.py:50-51) */
 int mmdgan_nchw_to_nhwc(const float *src, float *dst, int N, int C, int H, int W, void *stream);
 int mmdgan_nhwc_to_nchw(const float *src, float *dst, int N, int C, int H, int W, void *stream);
+/* a batch of uint8 image records -> fp32 NHWC in [-1,1], the reference's input preprocessing
+ * (input_func.py:797-801 decode_raw + cast, :839-842 image / 127.5 - 1, reshape (channels, height, width)).
+ * src: N records of C*H*W bytes on the DEVICE, stored [C,H,W] (src_is_chw = 1, how the reference's converters
+ * write them) or [H,W,C] (0).  Bit-exact: IEEE fp32 divide and subtract. */
+int mmdgan_u8_records_to_nhwc(const unsigned char *src, int src_is_chw, float *dst, int N, int C, int H, int W,
+                              void *stream);
 
 #ifdef __cplusplus
 }

@@ -63,28 +63,25 @@ class SNGan(object):
             self.engine.lr_d, self.engine.lr_g = float(lr_list[0]), float(lr_list[1])
         return self.engine
 
-    def get_data_batch(self, filename, batch_size, num_instance):
-        """returns fn() -> NHWC fp32 batch on the device, values in [-1, 1] (input_func.py:839)."""
-        dev = torch.device('cuda')
-        shape = (batch_size, self.height, self.width, self.channels)
+    def get_data_batch(self, filename, batch_size, num_instance, file_repeat=1, num_threads=7, shuffle_file=False):
+        """returns fn() -> NHWC fp32 batch on the device, values in [-1, 1] (my_sngan.py:348-354: ReadTFRecords ->
+        shape2image -> next_batch; the uint8 records are decoded on the device, GeneralTools/input_func.py)."""
         if FLAGS.SYNTHETIC_DATA:
+            dev = torch.device('cuda')
             gen = torch.Generator(device=dev)
             gen.manual_seed(1234)
-            buf = torch.empty(shape, device=dev)
+            buf = torch.empty((batch_size, self.height, self.width, self.channels), device=dev)
             return lambda: buf.uniform_(-1, 1, generator=gen)
-        path = FLAGS.DEFAULT_IN + (filename if isinstance(filename, str) else filename[0]) + '.npy'
+        from GeneralTools.input_func import ReadTFRecords
         try:
-            data = np.load(path, mmap_mode='r')           # uint8 [N, C, H, W], the converters' pixel layout
-        except OSError:
-            raise FileNotFoundError('{} not found: the tfrecord reader is outside the hot path; provide a uint8 '
-                                    '[N,C,H,W] .npy or set FLAGS.SYNTHETIC_DATA = True'.format(path))
-        rs = np.random.RandomState(0)
-
-        def next_batch():
-            idx = np.sort(rs.randint(0, min(num_instance, data.shape[0]), batch_size))
-            x = torch.as_tensor(np.ascontiguousarray(data[idx])).to(dev).float().div_(127.5).sub_(1.0)
-            return ops.nchw_to_nhwc(x.contiguous())
-        return next_batch
+            self.training_data = ReadTFRecords(
+                filename, self.channels * self.height * self.width, num_labels=0, x_dtype='string',
+                batch_size=batch_size, file_repeat=file_repeat, num_threads=num_threads, shuffle_file=shuffle_file)
+        except AssertionError as err:
+            raise FileNotFoundError('{} (a uint8 [N, C*H*W] .npy of the same name is accepted too; '
+                                    'FLAGS.SYNTHETIC_DATA = True needs no data)'.format(err))
+        self.training_data.shape2image(self.channels, self.height, self.width)
+        return lambda: self.training_data.next_batch()['x']
 
     # --------------------------------------------------------------------------------------
     def training(self, filename, agent, num_instance, lr_list, end_lr=1e-7, max_step=None, batch_size=64,
@@ -100,7 +97,7 @@ class SNGan(object):
         FLAGS.print('Num Instance: {}; Num Class: {}; Batch: {}; File_repeat: {}'.format(
             num_instance, self.num_class, batch_size, file_repeat))
         eng = self.init_net(lr_list, batch_size)
-        next_batch = self.get_data_batch(filename, batch_size, num_instance)
+        next_batch = self.get_data_batch(filename, batch_size, num_instance, file_repeat, num_threads)
         FLAGS.print('Shape of input batch: {}'.format([batch_size, self.channels, self.height, self.width]))
         FLAGS.print('loss_list name: {}.'.format(self.loss_names))
 

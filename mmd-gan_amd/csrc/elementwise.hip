@@ -167,6 +167,48 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float *__restri
     }
 }
 
+// uint8 records -> fp32 NHWC in [-1, 1]: input_func.py:797-801 (decode_raw uint8, cast float32) and
+// :839-842 (image / 127.5 - 1, reshape to (channels, height, width)).  One thread per pixel: byte reads are
+// coalesced along each channel plane, the C floats a thread writes are contiguous with its neighbours'.
+// IEEE division and subtraction, nothing to contract: bit-identical to the reference's arithmetic.
+template <bool CHW>
+__global__ __launch_bounds__(256) void u8_records_kernel(const unsigned char *__restrict__ src,
+                                                         float *__restrict__ dst, long NP, int C, int HW) {
+    const long stride = (long)gridDim.x * 256;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < NP; t += stride) {        // t = n * HW + pixel
+        const long n = t / HW;
+        const int px = (int)(t - n * HW);
+        for (int c = 0; c < C; ++c) {
+            const unsigned char b = CHW ? src[(n * C + c) * HW + px] : src[t * C + c];
+            dst[t * C + c] = __fsub_rn(__fdiv_rn((float)b, 127.5f), 1.0f);
+        }
+    }
+}
+
+// [C,H,W] records with H*W % 4 == 0: a thread takes four neighbouring pixels - one 4-byte load per channel plane,
+// 4*C floats stored as C 16-byte vectors (the 12-byte-per-thread stores of the scalar kernel top out at ~50 % of HBM)
+template <int C>
+__global__ __launch_bounds__(256) void u8_records_chw4_kernel(const unsigned char *__restrict__ src,
+                                                              float *__restrict__ dst, long NQ, int HW4) {
+    const long stride = (long)gridDim.x * 256;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < NQ; t += stride) {        // t = n * HW/4 + pixel quad
+        const long n = t / HW4;
+        const int q = (int)(t - n * HW4);
+        float v[4 * C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const uchar4 b = *reinterpret_cast<const uchar4 *>(src + ((n * C + c) * HW4 + q) * 4);
+            v[0 * C + c] = __fsub_rn(__fdiv_rn((float)b.x, 127.5f), 1.0f);
+            v[1 * C + c] = __fsub_rn(__fdiv_rn((float)b.y, 127.5f), 1.0f);
+            v[2 * C + c] = __fsub_rn(__fdiv_rn((float)b.z, 127.5f), 1.0f);
+            v[3 * C + c] = __fsub_rn(__fdiv_rn((float)b.w, 127.5f), 1.0f);
+        }
+        float4 *o = reinterpret_cast<float4 *>(dst + t * 4 * C);
+#pragma unroll
+        for (int k = 0; k < C; ++k) o[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    }
+}
+
 static inline int grid_for(long n, int per_block = 256, int cap = 2048) {
     long b = (n + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -249,6 +291,25 @@ extern "C" int mmdgan_nchw_to_nhwc(const float *src, float *dst, int N, int C, i
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long)N * C * H * W)), dim3(256), 0, (hipStream_t)stream, src,
                        dst, N, C, H * W);
     return check_launch("nchw_to_nhwc");
+}
+extern "C" int mmdgan_u8_records_to_nhwc(const unsigned char *src, int src_is_chw, float *dst, int N, int C, int H,
+                                         int W, void *stream) {
+    MMDGAN_REQUIRE(src && dst && N >= 1 && C >= 1 && H >= 1 && W >= 1, "u8_records_to_nhwc: bad arguments");
+    const long np = (long)N * H * W;
+    const bool vec = src_is_chw && (H * W) % 4 == 0 && ((uintptr_t)src % 4 == 0) && ((uintptr_t)dst % 16 == 0);
+    if (vec && (C == 1 || C == 3 || C == 4)) {
+        const long nq = np / 4;
+        const dim3 g(grid_for(nq, 256, 8192));
+        if (C == 1) hipLaunchKernelGGL(u8_records_chw4_kernel<1>, g, dim3(256), 0, (hipStream_t)stream, src, dst, nq, H * W / 4);
+        if (C == 3) hipLaunchKernelGGL(u8_records_chw4_kernel<3>, g, dim3(256), 0, (hipStream_t)stream, src, dst, nq, H * W / 4);
+        if (C == 4) hipLaunchKernelGGL(u8_records_chw4_kernel<4>, g, dim3(256), 0, (hipStream_t)stream, src, dst, nq, H * W / 4);
+        return check_launch("u8_records_to_nhwc");
+    }
+    if (src_is_chw)
+        hipLaunchKernelGGL(u8_records_kernel<true>, dim3(grid_for(np)), dim3(256), 0, (hipStream_t)stream, src, dst, np, C, H * W);
+    else
+        hipLaunchKernelGGL(u8_records_kernel<false>, dim3(grid_for(np)), dim3(256), 0, (hipStream_t)stream, src, dst, np, C, H * W);
+    return check_launch("u8_records_to_nhwc");
 }
 extern "C" int mmdgan_nhwc_to_nchw(const float *src, float *dst, int N, int C, int H, int W, void *stream) {
     MMDGAN_REQUIRE(src && dst && N >= 1 && C >= 1 && H >= 1 && W >= 1, "nhwc_to_nchw: bad arguments");

@@ -45,6 +45,7 @@ SIGNATURES = {
     'mmdgan_adam_multi': (_I, [_P, _P, _I, _L, _F, _F, _F, _F, _I, _P, _P, _F, _P]),
     'mmdgan_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'mmdgan_nhwc_to_nchw': (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    'mmdgan_u8_records_to_nhwc': (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
 }
 
 _lib = None

@@ -318,6 +318,20 @@ def nchw_to_nhwc(x):
     return y
 
 
+def u8_records_to_nhwc(records, channels, height, width, chw=True, out=None):
+    """uint8 device tensor of N records (any shape with N*C*H*W bytes) -> fp32 NHWC in [-1,1]
+    (input_func.py:797-801, 839-842)."""
+    lib = require_device()
+    assert records.dtype == torch.uint8 and records.is_cuda and records.is_contiguous()
+    n = records.numel() // (channels * height * width)
+    assert n * channels * height * width == records.numel(), 'u8_records_to_nhwc: size is not a multiple of C*H*W'
+    if out is None:
+        out = torch.empty((n, height, width, channels), device=records.device, dtype=torch.float32)
+    check(lib.mmdgan_u8_records_to_nhwc(records.data_ptr(), int(chw), _p(out), n, channels, height, width, _stream()),
+          'u8_records_to_nhwc')
+    return out
+
+
 def nhwc_to_nchw(x):
     lib = require_device()
     N, H, W, C = x.shape
