@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from GeneralTools.misc_fun import FLAGS
-from GeneralTools.graph_func import prepare_folder
+from GeneralTools.graph_func import prepare_folder, write_sprite_wrapper
 from mmdgan_hip import ops
 from mmdgan_hip.engine import GanEngine
 
@@ -116,11 +116,20 @@ class SNGan(object):
     def eval_sampling(self, filename, sub_folder, mesh_num=None, mesh_mode=0, if_invert=False, code_x=None,
                       code_y=None, real_sample=False, sample_same_class=False, get_dis_score=False, do_embedding=False,
                       do_sprite=True, ckpt_file=None, num_threads=7):
-        """G(code_x) with BN moving statistics, clipped to [-1,1]; returns NCHW numpy (my_sngan.py:499-581).
-        The sprite/embedding writers are cosmetic and outside the hot path: the array is saved as .npy."""
+        """G(code_x) with BN moving statistics, clipped to [-1,1], written as the reference's sprite
+        <summary_folder>/<filename>_g_<sub_folder>_<step>_<mesh_mode>.png (my_sngan.py:499-581); returns the NCHW
+        array.  code_x defaults to N(0,1) draws (MeshCode's mesh modes, real-sample sprites, discriminator scores and
+        the TensorBoard embedding are not built)."""
         if self.engine is None:
             raise RuntimeError('eval_sampling: train (or load) a model first')
-        n = int(np.prod(mesh_num)) if mesh_num is not None else self.engine.B
+        if real_sample or get_dis_score or do_embedding:
+            raise NotImplementedError('eval_sampling: real_sample / get_dis_score / do_embedding are not built')
+        _, summary_folder, _ = prepare_folder(filename, sub_folder=sub_folder)
+        if mesh_num is None:
+            mesh_num = (10, 10)                                              # my_sngan.py:524-525
+        elif code_x is not None:
+            assert code_x.shape[0] == mesh_num[0] * mesh_num[1]               # my_sngan.py:526-527
+        n = mesh_num[0] * mesh_num[1]
         if code_x is None:
             code_x = np.random.randn(n, self.code_size).astype(np.float32)
         code_x = torch.as_tensor(np.asarray(code_x, np.float32)).cuda()
@@ -131,8 +140,10 @@ class SNGan(object):
             outs.append(ops.nhwc_to_nchw(img.contiguous()).clamp_(-1, 1).cpu().numpy())
         x_gen = np.concatenate(outs, 0)
         if do_sprite:
-            _, summary_folder, _ = prepare_folder(filename, sub_folder=sub_folder)
-            np.save('{}/{}_step_{}.npy'.format(summary_folder, filename, self.engine.global_step), x_gen)
+            write_sprite_wrapper(
+                x_gen, mesh_num, filename, file_folder=summary_folder,
+                file_index='_g_' + sub_folder + '_' + str(self.engine.global_step) + '_' + str(mesh_mode),
+                if_invert=if_invert, image_format=FLAGS.IMAGE_FORMAT)
         return x_gen
 
     def mdl_score(self, filename, sub_folder, batch_size, num_batch=10, model='v1', ckpt_file=None, num_threads=7):

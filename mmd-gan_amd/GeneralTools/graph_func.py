@@ -8,8 +8,12 @@ import math
 import os
 import time
 
+import warnings
+
+import numpy as np
 import torch
 
+from GeneralTools.math_func import mean_cov_np, trace_sqrt_product_np
 from GeneralTools.misc_fun import FLAGS
 
 
@@ -24,6 +28,86 @@ def prepare_folder(filename, sub_folder='', set_folder=True):
         os.makedirs(ckpt_folder, exist_ok=True)
         os.makedirs(summary_folder, exist_ok=True)
     return ckpt_folder, summary_folder, save_path
+
+
+def sprite_array(images, mesh_num=None, if_invert=False):
+    """the uint8 [rows*H, cols*W, 3] mosaic write_sprite saves (graph_func.py:222-263): each image scaled by its own
+    min and max to [0,1], optionally inverted, laid out row-major on the mesh (a square one, zero-padded, when no
+    mesh is given), x*255 truncated to uint8."""
+    img = np.asarray(images)
+    if img.ndim == 3:
+        img = img[..., np.newaxis]
+    if img.shape[3] == 1:
+        img = np.repeat(img, 3, axis=3)
+    img = img.astype(np.float32)
+    flat = img.reshape(img.shape[0], -1)
+    img = img - flat.min(axis=1).reshape(-1, 1, 1, 1)
+    img = img / img.reshape(img.shape[0], -1).max(axis=1).reshape(-1, 1, 1, 1)
+    if if_invert:
+        img = 1 - img
+    if mesh_num is None:
+        FLAGS.print('Mesh_num will be calculated as sqrt of batch_size')
+        side = int(np.ceil(np.sqrt(img.shape[0])))
+        mesh_num = (side, side)
+        blank = np.zeros((side * side - img.shape[0],) + img.shape[1:], dtype=img.dtype)
+        img = np.concatenate([img, blank], axis=0)
+    rows, cols = tuple(mesh_num)
+    n, h, w, c = img.shape
+    assert rows * cols == n, 'mesh {}x{} does not hold {} images'.format(rows, cols, n)
+    mosaic = np.empty((rows * h, cols * w, c), dtype=np.float32)
+    for r in range(rows):
+        for q in range(cols):
+            mosaic[r * h:(r + 1) * h, q * w:(q + 1) * w] = img[r * cols + q]
+    return (mosaic * 255).astype(np.uint8)
+
+
+def write_sprite(sprite_path, images, mesh_num=None, if_invert=False):
+    """channels_last images -> one PNG mosaic (graph_func.py:222-266; scipy.misc.imsave no longer exists, PIL writes
+    the same uint8 array)."""
+    from PIL import Image
+    Image.fromarray(sprite_array(images, mesh_num, if_invert)).save(sprite_path)
+
+
+def write_sprite_wrapper(images, mesh_num, filename, file_folder=None, file_index='', if_invert=False,
+                         image_format='channels_last'):
+    """graph_func.py:269-297: <file_folder>/<filename><file_index>.png, never overwriting an existing file."""
+    if not isinstance(filename, str):
+        filename = filename[0]
+    if isinstance(mesh_num, list):
+        mesh_num = tuple(mesh_num)
+    if file_folder is None:
+        file_folder = FLAGS.DEFAULT_OUT
+    if image_format in {'channels_first', 'NCHW'}:
+        images = np.transpose(images, axes=(0, 2, 3, 1))
+    sprite_path = os.path.join(file_folder, filename + file_index + '.png')
+    if os.path.isfile(sprite_path):
+        warnings.warn('This file already exists: ' + sprite_path)
+    else:
+        write_sprite(sprite_path, images, mesh_num=mesh_num, if_invert=if_invert)
+    return sprite_path
+
+
+class GenerativeModelMetric(object):
+    """Only the part of the reference class (graph_func.py:1595-2094) that needs no pretrained network: the Frechet
+    distance between two sets of EXTERNALLY SUPPLIED pool3 features.  Everything that runs the frozen Inception-v1
+    graph raises (the file is not part of the reference repository, Addon/inception_v1/ReadMe.md)."""
+
+    def __init__(self, image_format=None, model='v1', model_path=None):
+        self.image_format = FLAGS.IMAGE_FORMAT if image_format is None else image_format
+        self.model, self.model_path = model, model_path
+
+    @staticmethod
+    def my_fid_from_pool3(x_pool3_np, y_pool3_np):
+        """graph_func.py:1733-1745; either argument may be features [N, D] or a [mean, cov] pair."""
+        x_mean, x_cov = x_pool3_np if isinstance(x_pool3_np, (list, tuple)) else mean_cov_np(x_pool3_np)
+        y_mean, y_cov = y_pool3_np if isinstance(y_pool3_np, (list, tuple)) else mean_cov_np(y_pool3_np)
+        return np.sum((x_mean - y_mean) ** 2) + np.trace(x_cov) + np.trace(y_cov) \
+            - 2.0 * trace_sqrt_product_np(x_cov, y_cov)
+
+    def inception_score_and_fid_v1(self, *args, **kwargs):
+        raise NotImplementedError('needs the frozen Inception-v1 graph (graph_func.py:1748-1799), not in the repository')
+
+    inception_v1 = inception_v1_one_batch = inception_score_and_fid_v1
 
 
 class Agent(object):

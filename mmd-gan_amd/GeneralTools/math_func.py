@@ -8,6 +8,9 @@ device tensors (no host synchronisation).  Implemented loss names: the hot path'
 aliases (math_func.py:2644-2647) and, from SURVEY 8(f) row 1, 'mmd_g' / 'fixed_g', 'mgb', 'hinge' and
 'logistic' / '' (:2602-2611); every other name raises exactly as the reference does for an unknown one.
 """
+import numpy as np
+
+from GeneralTools.misc_fun import FLAGS
 from mmdgan_hip import ops
 
 _NOT_ON_HOT_PATH = {'wasserstein', 'fixed_t', 'mmd_t',
@@ -70,3 +73,31 @@ class GANLoss(object):
     def get_register(self):
         registered_info, self.debug_register = self.debug_register, None
         return registered_info
+
+
+# ------------------------------------------------------------------------------------------------
+# evaluation helpers (host NumPy in the reference too)
+# ------------------------------------------------------------------------------------------------
+def mean_cov_np(x):
+    """column means and unbiased covariance of a 2-D array (math_func.py:56-67)."""
+    x = np.asarray(x)
+    mu = np.mean(x, axis=0)
+    centred = x - mu
+    return mu, centred.T.dot(centred) / (x.shape[0] - 1.0)
+
+
+def sqrt_sym_mat_np(mat, eps=None):
+    """square root of a symmetric matrix as the reference defines it (math_func.py:2671-2683): U sqrt(S) V^T of
+    the SVD with singular values below eps dropped.  For a symmetric matrix that is sum_i sign(l_i) sqrt|l_i| v_i v_i^T
+    over its eigenpairs, which one symmetric eigendecomposition gives at a third of the SVD's cost."""
+    if eps is None:
+        eps = FLAGS.EPSI
+    lam, vec = np.linalg.eigh((mat + mat.T) * 0.5)
+    root = np.where(np.abs(lam) < eps, 0.0, np.sign(lam) * np.sqrt(np.abs(lam)))
+    return (vec * root).dot(vec.T)
+
+
+def trace_sqrt_product_np(cov1, cov2):
+    """trace(sqrt(cov1 cov2)) through sqrt(cov1) cov2 sqrt(cov1) (math_func.py:2686-2699)."""
+    root1 = sqrt_sym_mat_np(cov1)
+    return np.trace(sqrt_sym_mat_np(root1.dot(cov2).dot(root1)))

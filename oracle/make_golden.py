@@ -341,6 +341,74 @@ def make_step(loss_type, B=8, n_steps=3, lr=(5e-4, 2e-4), store_grads=True, sn_m
     print('step fixture:', tag)
 
 
+# ---------------------------------------------------------------------------
+# 5. eval helpers: NumPy FID on supplied pool3 features (graph_func.py:1733-1745,
+#    math_func.py:56-67, 2671-2699) and the sprite grid (graph_func.py:222-266)
+# ---------------------------------------------------------------------------
+def import_reference_graph_func():
+    """graph_func.py imports tf.contrib.gan, the timeline client and pyplot at module level; none of them is touched
+    by the NumPy functions recorded here, so empty modules stand in for them at import time."""
+    import types
+    for name in ('tensorflow.contrib', 'tensorflow.contrib.gan', 'tensorflow.python', 'tensorflow.python.client',
+                 'tensorflow.python.client.timeline'):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules['tensorflow.contrib'].gan = sys.modules['tensorflow.contrib.gan']
+    sys.modules['tensorflow.python.client'].timeline = sys.modules['tensorflow.python.client.timeline']
+    # its input_func import (default arguments use tf.uint8 / tf.string dtypes the shim does not carry) likewise
+    stub = types.ModuleType('GeneralTools.input_func')
+    stub.ReadTFRecords = None
+    sys.modules.setdefault('GeneralTools.input_func', stub)
+    import matplotlib
+    matplotlib.use('Agg')
+    from GeneralTools import graph_func as ref_graph
+    return ref_graph
+
+
+def make_eval():
+    ref_graph = import_reference_graph_func()
+    out = {}
+    rs = np.random.RandomState(2024)
+    mix = rs.randn(48, 48) * 0.3
+    x = (rs.randn(300, 48) @ mix + rs.randn(48) * 0.2).astype(np.float64)
+    y = (rs.randn(260, 48) @ (mix + rs.randn(48, 48) * 0.05) + 0.1).astype(np.float64)
+    mu_x, cov_x = ref_math.mean_cov_np(x)
+    mu_y, cov_y = ref_math.mean_cov_np(y)
+    out.update({'x': x, 'y': y, 'mu_x': mu_x, 'cov_x': cov_x, 'mu_y': mu_y, 'cov_y': cov_y,
+                'sqrt_cov_x': ref_math.sqrt_sym_mat_np(cov_x),
+                'trace_sqrt_product': np.float64(ref_math.trace_sqrt_product_np(cov_x, cov_y)),
+                'fid': np.float64(ref_graph.GenerativeModelMetric.my_fid_from_pool3(x, y)),
+                'fid_from_stats': np.float64(ref_graph.GenerativeModelMetric.my_fid_from_pool3([mu_x, cov_x], y)),
+                'fid_self': np.float64(ref_graph.GenerativeModelMetric.my_fid_from_pool3(x, x))})
+    # rank-deficient covariance (fewer samples than features): the eps cut of sqrt_sym_mat_np matters
+    z = rs.randn(20, 48)
+    out['z'] = z
+    out['fid_rank_deficient'] = np.float64(ref_graph.GenerativeModelMetric.my_fid_from_pool3(z, y))
+    np.savez_compressed(os.path.join(OUT, 'eval_fid.npz'), **out)
+
+    # sprite: capture what write_sprite hands to scipy.misc.imsave (removed from SciPy long ago)
+    import types
+    import scipy
+    captured = {}
+    misc = types.ModuleType('scipy.misc')
+    misc.imsave = lambda path, arr: captured.__setitem__('arr', np.array(arr))
+    sys.modules['scipy.misc'] = misc
+    scipy.misc = misc
+    sp = {}
+    cases = {'rgb_auto': (rs.uniform(-1, 1, (10, 6, 5, 3)), None, False),
+             'rgb_mesh': (rs.uniform(-1, 1, (10, 6, 5, 3)), (2, 5), False),
+             'rgb_invert': (rs.uniform(0, 1, (6, 4, 4, 3)), [3, 2], True),
+             'gray3d': (rs.uniform(-1, 1, (9, 5, 7)), None, False),
+             'gray4d': (rs.uniform(-1, 1, (4, 5, 7, 1)), (2, 2), False)}
+    for name, (img, mesh, inv) in cases.items():
+        ref_graph.write_sprite('unused.png', img.astype(np.float32), mesh_num=mesh, if_invert=inv)
+        sp[name + '/images'] = img.astype(np.float32)
+        sp[name + '/mesh'] = np.asarray(mesh if mesh is not None else [-1, -1])
+        sp[name + '/invert'] = np.asarray(inv)
+        sp[name + '/sprite'] = captured['arr']
+    np.savez_compressed(os.path.join(OUT, 'eval_sprite.npz'), **sp)
+    print('eval fixtures: fid %.6f, sprites %s' % (out['fid'], [sp[k + '/sprite'].shape for k in cases]))
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -349,11 +417,13 @@ if __name__ == '__main__':
     if '--only-next' in sys.argv:
         make_loss_next()
         make_step('rep', store_grads=False, sn_mode='sn_paper')
+        make_eval()
         sys.exit(0)
     make_loss_next()
     make_layers()
     make_step('rep')
     make_step('rmb', store_grads=False)
     make_step('rep', store_grads=False, sn_mode='sn_paper')
+    make_eval()
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print('tests/golden total bytes:', total)

@@ -486,3 +486,57 @@ class OracleGan:
             self.params[n] = v
         self.global_step += 1                                  # my_sngan.py:424
         return float(loss_gen), float(loss_dis)
+
+
+# ---------------------------------------------------------------------------
+# eval helpers - NumPy in the reference too
+# ---------------------------------------------------------------------------
+def mean_cov(x):
+    """math_func.py:56-67: column means and the unbiased covariance of a 2-D array"""
+    x = np.asarray(x)
+    mu = x.mean(axis=0)
+    xc = x - mu
+    return mu, xc.T @ xc / (x.shape[0] - 1.0)
+
+
+def sqrt_sym_mat(mat, eps=EPSI):
+    """math_func.py:2671-2683: U diag(sqrt(s)) V^T from an SVD, singular values below eps cut to 0"""
+    u, s, vh = np.linalg.svd(mat)
+    return (u * np.where(s < eps, 0.0, np.sqrt(s))) @ vh
+
+
+def trace_sqrt_product(cov1, cov2):
+    """math_func.py:2686-2699: trace sqrt(cov1 cov2) = trace sqrt(sqrt(cov1) cov2 sqrt(cov1))"""
+    r = sqrt_sym_mat(cov1)
+    return np.trace(sqrt_sym_mat(r @ cov2 @ r))
+
+
+def fid_from_pool3(x, y):
+    """graph_func.py:1733-1745 (my_fid_from_pool3): either argument may be features [N,D] or a [mean, cov] pair"""
+    mx, cx = x if isinstance(x, (list, tuple)) else mean_cov(x)
+    my, cy = y if isinstance(y, (list, tuple)) else mean_cov(y)
+    return np.sum((mx - my) ** 2) + np.trace(cx) + np.trace(cy) - 2.0 * trace_sqrt_product(cx, cy)
+
+
+def sprite_grid(images, mesh_num=None, if_invert=False):
+    """graph_func.py:222-263 (write_sprite up to the file write): per-image min/max scaling to [0,1], optional
+    inversion, zero padding to a square mesh when none is given, row-major tiling, uint8 truncation of x*255."""
+    images = np.asarray(images)
+    if images.ndim == 3:
+        images = np.tile(images[..., None], (1, 1, 1, 3))
+    if images.shape[3] == 1:
+        images = np.tile(images, (1, 1, 1, 3))
+    images = images.astype(np.float32)
+    n = images.shape[0]
+    images = images - images.reshape(n, -1).min(axis=1)[:, None, None, None]
+    images = images / images.reshape(n, -1).max(axis=1)[:, None, None, None]
+    if if_invert:
+        images = 1 - images
+    if mesh_num is None:
+        side = int(np.ceil(np.sqrt(n)))
+        mesh_num = (side, side)
+        images = np.pad(images, ((0, side * side - n), (0, 0), (0, 0), (0, 0)), mode='constant', constant_values=0)
+    rows, cols = tuple(mesh_num)
+    h, w, c = images.shape[1:]
+    grid = images.reshape(rows, cols, h, w, c).transpose(0, 2, 1, 3, 4).reshape(rows * h, cols * w, c)
+    return (grid * 255).astype(np.uint8)

@@ -74,3 +74,36 @@ def test_routine_inference_matches_oracle():
     params['gen/l2_up/BN/BN/moving_variance'] = torch.ones(16, dtype=torch.float64)
     ref, _ = R.net_forward(specs, params, z.cpu().double(), True)
     assert rel_err(y.cpu().numpy(), ref.numpy()) <= RTOL
+
+
+def test_eval_sampling_writes_the_reference_sprite_from_inference_mode_images(tmp_path):
+    """my_sngan.py:499-581 after a few training steps (BN moving statistics away from their initial values): the
+    images are G(code) with the MOVING statistics, checked against the oracle run with the engine's
+    variables; the PNG on disk is the reference's mosaic of exactly those images, at the reference's path."""
+    from PIL import Image
+    from GeneralTools.misc_fun import FLAGS
+    from GeneralTools.graph_func import Agent, sprite_array
+    from DeepLearning.my_sngan import SNGan
+    FLAGS.DEFAULT_OUT = str(tmp_path) + '/'
+    FLAGS.SYNTHETIC_DATA, FLAGS.SILENT_MODE = True, True
+    try:
+        arch, lr = configs.cifar()
+        mdl = SNGan(arch, num_class=0, loss_type='rep', optimizer='adam')
+        agent = Agent('cifar', 'ev', load_ckpt=False, do_save=False, query_step=None)
+        mdl.training('cifar', agent, 64 * 4, lr, max_step=7, batch_size=64)
+        code = np.random.RandomState(3).randn(12, 128).astype(np.float32)
+        x = mdl.eval_sampling('cifar', 'ev', mesh_num=(3, 4), code_x=code)
+        assert x.shape == (12, 3, 32, 32) and np.abs(x).max() <= 1.0
+        var = mdl.engine.get_variables()
+        specs = R.build_net(arch['generator'], [128], 'gen')
+        params = {k: torch.tensor(v, dtype=torch.float64) for k, v in var.items() if k.startswith('gen/')}
+        assert float(params['gen/l2_up/BN/BN/moving_mean'].abs().max()) > 0           # training moved them
+        ref, upd = R.net_forward(specs, params, torch.tensor(code, dtype=torch.float64), False)
+        assert not upd                                                                # inference updates nothing
+        assert rel_err(x, ref.clamp(-1, 1).numpy()) <= RTOL
+        path = '{}cifar_log/ev/cifar_g_ev_7_0.png'.format(FLAGS.DEFAULT_OUT)
+        assert np.array_equal(np.asarray(Image.open(path)), sprite_array(x.transpose(0, 2, 3, 1), (3, 4)))
+        with pytest.raises(NotImplementedError):
+            mdl.eval_sampling('cifar', 'ev', mesh_num=(3, 4), code_x=code, real_sample=True)
+    finally:
+        FLAGS.SYNTHETIC_DATA, FLAGS.SILENT_MODE = False, False
