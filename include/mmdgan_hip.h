@@ -220,6 +220,26 @@ int mmdgan_adam_multi(const void *const *ptrs, const long *sizes, int n_tensors,
                       float beta1, float beta2, float eps, int step, int *step_counter, float *lr_t_scratch,
                       float grad_scale, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Elementwise pieces of the residual blocks (layer_func.py:1687-1842), NHWC fp32.
+ *   resample_down: y[n,p,q,:] (+)= scale * sum of the factor x factor window of x [N, P*factor, Q*factor, C].
+ *                  scale = 1/factor^2 is ImageScaling 'avg' (:1155-1159); scale = 1 is the gradient of 'unpool'.
+ *   resample_up:   y[n,h,w,:] (+)= scale * x[n, h/factor, w/factor, :], x [N,P,Q,C], y [N, P*factor, Q*factor, C].
+ *                  scale = 1 is ImageScaling 'unpool' (:1160-1163, nearest-neighbour); scale = 1/factor^2 is the
+ *                  gradient of 'avg'.
+ *   act_fwd / act_bwd: a block's pre-activation on its input (:1785) and its gradient, taken from the
+ *                  activation's output; dx (+)= dy * act'(y).
+ *   axpby:         out = alpha*a + beta*b (the branch sum :1842 and gradient fan-in); out may alias a or b.
+ * `accumulate` != 0 adds to what the output holds.
+ * ---------------------------------------------------------------------------------------------- */
+int mmdgan_resample_down(const float *x, float *y, int N, int P, int Q, int C, int factor, float scale, int accumulate,
+                         void *stream);
+int mmdgan_resample_up(const float *x, float *y, int N, int P, int Q, int C, int factor, float scale, int accumulate,
+                       void *stream);
+int mmdgan_act_fwd(const float *x, float *y, long n, int act, void *stream);
+int mmdgan_act_bwd(const float *dy, const float *y, float *dx, long n, int act, int accumulate, void *stream);
+int mmdgan_axpby(const float *a, float alpha, const float *b, float beta, float *out, long n, void *stream);
+
 /* layout seam helpers: NCHW <-> NHWC (the reference API speaks NCHW, misc_fun.py:50-51) */
 int mmdgan_nchw_to_nhwc(const float *src, float *dst, int N, int C, int H, int W, void *stream);
 int mmdgan_nhwc_to_nchw(const float *src, float *dst, int N, int C, int H, int W, void *stream);

@@ -1,0 +1,153 @@
+// Elementwise pieces of the reference's residual blocks (layer_func.py:1687-1842), NHWC fp32, gfx950.
+//   ImageScaling 'avg'    :1155-1159  tf.nn.avg_pool, window = stride = f          -> resample_down (scale 1/f^2)
+//   ImageScaling 'unpool' :1160-1163  four channel copies + depth_to_space = every pixel repeated f x f
+//                                                                                   -> resample_up   (scale 1)
+//   their gradients are each other with the other scale (sum over the window / spread over it),
+//   the pre-activation of a block (:1785 _apply_activation_ on the block input, whose raw value also feeds the
+//   shortcut, so it cannot ride on the producer's epilogue), and the branch sum (:1842).
+// All of it is HBM-bound streaming: one thread per 16-byte channel quad, rows of C contiguous floats, so every
+// load and store is a full coalesced line; nothing is staged through LDS because nothing is reused.
+#include "common.h"
+
+namespace mmdgan {
+
+template <int VEC>
+struct Pack;
+template <>
+struct Pack<4> {
+    using T = float4;
+    static __device__ __forceinline__ T zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    static __device__ __forceinline__ void acc(T &a, const T &b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    static __device__ __forceinline__ T scaled(const T &a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+};
+template <>
+struct Pack<1> {
+    using T = float;
+    static __device__ __forceinline__ T zero() { return 0.f; }
+    static __device__ __forceinline__ void acc(T &a, const T &b) { a += b; }
+    static __device__ __forceinline__ T scaled(const T &a, float s) { return a * s; }
+};
+
+// y[n, p, q, :] = scale * sum_{i,j < f} x[n, p*f + i, q*f + j, :]      (x is [N, P*f, Q*f, C])
+template <int VEC>
+__global__ __launch_bounds__(256) void resample_down_kernel(const float *__restrict__ x, float *__restrict__ y, long total,
+                                                            int P, int Q, int CV, int f, float scale, int accumulate) {
+    using V = typename Pack<VEC>::T;
+    const V *xv = reinterpret_cast<const V *>(x);
+    V *yv = reinterpret_cast<V *>(y);
+    const long stride = (long)gridDim.x * 256;
+    const int W = Q * f;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {     // o = ((n*P + p)*Q + q)*CV + c
+        const int c = (int)(o % CV);
+        long t = o / CV;
+        const int q = (int)(t % Q);
+        t /= Q;
+        const int p = (int)(t % P);
+        const long n = t / P;
+        V a = Pack<VEC>::zero();
+        // the window is summed row by row, left to right: the order tf.nn.avg_pool's reference kernel uses
+        for (int i = 0; i < f; ++i)
+            for (int j = 0; j < f; ++j)
+                Pack<VEC>::acc(a, xv[((n * (P * f) + p * f + i) * W + q * f + j) * CV + c]);
+        a = Pack<VEC>::scaled(a, scale);
+        if (accumulate) Pack<VEC>::acc(a, yv[o]);
+        yv[o] = a;
+    }
+}
+
+// y[n, h, w, :] = scale * x[n, h / f, w / f, :]                        (y is [N, P*f, Q*f, C])
+template <int VEC>
+__global__ __launch_bounds__(256) void resample_up_kernel(const float *__restrict__ x, float *__restrict__ y, long total,
+                                                          int P, int Q, int CV, int f, float scale, int accumulate) {
+    using V = typename Pack<VEC>::T;
+    const V *xv = reinterpret_cast<const V *>(x);
+    V *yv = reinterpret_cast<V *>(y);
+    const long stride = (long)gridDim.x * 256;
+    const int H = P * f, W = Q * f;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {     // o indexes y
+        const int c = (int)(o % CV);
+        long t = o / CV;
+        const int w = (int)(t % W);
+        t /= W;
+        const int h = (int)(t % H);
+        const long n = t / H;
+        V a = Pack<VEC>::scaled(xv[((n * P + h / f) * Q + w / f) * CV + c], scale);
+        if (accumulate) Pack<VEC>::acc(a, yv[o]);
+        yv[o] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, long n, int act) {
+    const long stride = (long)gridDim.x * 256;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < n; o += stride) y[o] = act_fwd(x[o], act);
+}
+// dx (+)= dy * act'(.), the derivative taken from the activation's OUTPUT y
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+                                                      float *__restrict__ dx, long n, int act, int accumulate) {
+    const long stride = (long)gridDim.x * 256;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < n; o += stride) {
+        const float g = dy[o] * act_bwd_from_out(y[o], act);
+        dx[o] = accumulate ? dx[o] + g : g;
+    }
+}
+__global__ __launch_bounds__(256) void axpby_kernel(const float *__restrict__ a, float alpha, const float *__restrict__ b,
+                                                    float beta, float *__restrict__ out, long n) {
+    const long stride = (long)gridDim.x * 256;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < n; o += stride) out[o] = alpha * a[o] + beta * b[o];
+}
+
+static inline int grid_of(long n) {
+    long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+static inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace mmdgan
+
+using namespace mmdgan;
+
+extern "C" int mmdgan_resample_down(const float *x, float *y, int N, int P, int Q, int C, int factor, float scale,
+                                    int accumulate, void *stream) {
+    MMDGAN_REQUIRE(x && y && N >= 1 && P >= 1 && Q >= 1 && C >= 1 && factor >= 1, "resample_down: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (C % 4 == 0 && al16(x) && al16(y)) {
+        const long total = (long)N * P * Q * (C / 4);
+        hipLaunchKernelGGL(resample_down_kernel<4>, dim3(grid_of(total)), dim3(256), 0, st, x, y, total, P, Q, C / 4, factor, scale, accumulate);
+    } else {
+        const long total = (long)N * P * Q * C;
+        hipLaunchKernelGGL(resample_down_kernel<1>, dim3(grid_of(total)), dim3(256), 0, st, x, y, total, P, Q, C, factor, scale, accumulate);
+    }
+    return check_launch("resample_down");
+}
+
+extern "C" int mmdgan_resample_up(const float *x, float *y, int N, int P, int Q, int C, int factor, float scale,
+                                  int accumulate, void *stream) {
+    MMDGAN_REQUIRE(x && y && N >= 1 && P >= 1 && Q >= 1 && C >= 1 && factor >= 1, "resample_up: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (C % 4 == 0 && al16(x) && al16(y)) {
+        const long total = (long)N * P * factor * Q * factor * (C / 4);
+        hipLaunchKernelGGL(resample_up_kernel<4>, dim3(grid_of(total)), dim3(256), 0, st, x, y, total, P, Q, C / 4, factor, scale, accumulate);
+    } else {
+        const long total = (long)N * P * factor * Q * factor * C;
+        hipLaunchKernelGGL(resample_up_kernel<1>, dim3(grid_of(total)), dim3(256), 0, st, x, y, total, P, Q, C, factor, scale, accumulate);
+    }
+    return check_launch("resample_up");
+}
+
+extern "C" int mmdgan_act_fwd(const float *x, float *y, long n, int act, void *stream) {
+    MMDGAN_REQUIRE(x && y && n >= 1 && act >= MMDGAN_ACT_LINEAR && act <= MMDGAN_ACT_TANH, "act_fwd: bad arguments");
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_of(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, act);
+    return check_launch("act_fwd");
+}
+
+extern "C" int mmdgan_act_bwd(const float *dy, const float *y, float *dx, long n, int act, int accumulate, void *stream) {
+    MMDGAN_REQUIRE(dy && y && dx && n >= 1 && act >= MMDGAN_ACT_LINEAR && act <= MMDGAN_ACT_TANH, "act_bwd: bad arguments");
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_of(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n, act, accumulate);
+    return check_launch("act_bwd");
+}
+
+extern "C" int mmdgan_axpby(const float *a, float alpha, const float *b, float beta, float *out, long n, void *stream) {
+    MMDGAN_REQUIRE(a && b && out && n >= 1, "axpby: bad arguments");
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_of(n)), dim3(256), 0, (hipStream_t)stream, a, alpha, b, beta, out, n);
+    return check_launch("axpby");
+}

@@ -318,6 +318,61 @@ def nchw_to_nhwc(x):
     return y
 
 
+def resample_down(x, factor=2, scale=None, out=None, accumulate=False):
+    """window sums of an NHWC tensor: scale = 1/factor^2 (default) is ImageScaling 'avg' (layer_func.py:1155-1159),
+    scale = 1 the gradient of 'unpool'."""
+    lib = require_device()
+    n, h, w, c = x.shape
+    assert h % factor == 0 and w % factor == 0, 'resample_down: {}x{} is not a multiple of {}'.format(h, w, factor)
+    if out is None:
+        assert not accumulate
+        out = torch.empty((n, h // factor, w // factor, c), device=x.device, dtype=torch.float32)
+    check(lib.mmdgan_resample_down(_p(x), _p(out), n, h // factor, w // factor, c, factor,
+                                   1.0 / (factor * factor) if scale is None else float(scale), int(accumulate),
+                                   _stream()), 'resample_down')
+    return out
+
+
+def resample_up(x, factor=2, scale=1.0, out=None, accumulate=False):
+    """every pixel of an NHWC tensor repeated factor x factor: scale = 1 is ImageScaling 'unpool'
+    (layer_func.py:1160-1163), scale = 1/factor^2 the gradient of 'avg'."""
+    lib = require_device()
+    n, h, w, c = x.shape
+    if out is None:
+        assert not accumulate
+        out = torch.empty((n, h * factor, w * factor, c), device=x.device, dtype=torch.float32)
+    check(lib.mmdgan_resample_up(_p(x), _p(out), n, h, w, c, factor, float(scale), int(accumulate), _stream()),
+          'resample_up')
+    return out
+
+
+def act_fwd(x, act, out=None):
+    lib = require_device()
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.mmdgan_act_fwd(_p(x), _p(out), x.numel(), act_id(act), _stream()), 'act_fwd')
+    return out
+
+
+def act_bwd(dy, y, act, out=None, accumulate=False):
+    """dx (+)= dy * act'(.), the derivative taken from the activation's output y"""
+    lib = require_device()
+    if out is None:
+        assert not accumulate
+        out = torch.empty_like(dy)
+    check(lib.mmdgan_act_bwd(_p(dy), _p(y), _p(out), dy.numel(), act_id(act), int(accumulate), _stream()), 'act_bwd')
+    return out
+
+
+def axpby(a, b, alpha=1.0, beta=1.0, out=None):
+    lib = require_device()
+    assert a.numel() == b.numel()
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib.mmdgan_axpby(_p(a), float(alpha), _p(b), float(beta), _p(out), a.numel(), _stream()), 'axpby')
+    return out
+
+
 def u8_records_to_nhwc(records, channels, height, width, chw=True, out=None):
     """uint8 device tensor of N records (any shape with N*C*H*W bytes) -> fp32 NHWC in [-1,1]
     (input_func.py:797-801, 839-842)."""

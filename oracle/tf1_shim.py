@@ -378,7 +378,25 @@ def _bias_add(x, bias, data_format=None, name=None):
     return x + bias
 
 
+def _avg_pool(value, ksize, strides, padding, data_format='NHWC', name=None):
+    """tf.nn.avg_pool, NCHW, window == stride, 'SAME' on sizes the window divides (what ImageScaling 'avg' issues,
+    layer_func.py:1155-1159)"""
+    kh, kw = _stride_hw(ksize, data_format)
+    assert (kh, kw) == _stride_hw(strides, data_format) and value.shape[2] % kh == 0 and value.shape[3] % kw == 0
+    return F.avg_pool2d(value, (kh, kw))
+
+
+def depth_to_space(x, block_size, data_format='NHWC', name=None):
+    """tf.depth_to_space, NCHW: out[n, c, h*r + i, w*r + j] = in[n, (i*r + j)*C + c, h, w]"""
+    assert data_format == 'NCHW'
+    r = int(block_size)
+    n, cr2, h, w = x.shape
+    c = cr2 // (r * r)
+    return x.reshape(n, r, r, c, h, w).permute(0, 3, 4, 1, 5, 2).reshape(n, c, h * r, w * r)
+
+
 nn = types.SimpleNamespace(
+    avg_pool=_avg_pool,
     conv2d=_conv2d,
     conv2d_transpose=_conv2d_transpose,
     bias_add=_bias_add,

@@ -504,3 +504,56 @@ def test_sn_helpers_and_adam(ops):
         opt.apply(params, {'a': torch.tensor(gs[0]), 'b': torch.tensor(gs[1])})
     assert rel_err(dp[0].cpu().numpy(), params['a'].numpy()) <= 1e-6
     assert rel_err(dp[1].cpu().numpy(), params['b'].numpy()) <= 1e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# elementwise pieces of the residual blocks
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('n,h,w,c,f', [(4, 8, 8, 16, 2), (3, 6, 10, 3, 2), (2, 9, 6, 5, 3), (128, 64, 64, 64, 2), (1, 2, 2, 1, 2),
+                                       (5, 4, 4, 8, 4)])
+def test_resample_matches_the_reference_ops_and_their_gradients(ops, n, h, w, c, f):
+    """'avg' = tf.nn.avg_pool(window = stride = f) and 'unpool' = nearest repeat (layer_func.py:1155-1163), and each
+    one's gradient, against torch autograd on NCHW tensors"""
+    rs = np.random.RandomState(n + h + c)
+    x = rs.randn(n, c, h, w).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    pooled = torch.nn.functional.avg_pool2d(xt, f)
+    got = to_nchw(ops.resample_down(nhwc(x), f))
+    assert rel_err(got, pooled.detach().numpy()) <= 2e-6
+    dy = rs.randn(*pooled.shape).astype(np.float32)
+    gx, = torch.autograd.grad(pooled, xt, torch.tensor(dy, dtype=torch.float64))
+    assert rel_err(to_nchw(ops.resample_up(nhwc(dy), f, scale=1.0 / (f * f))), gx.numpy()) <= 2e-6      # d avg
+    up = xt.repeat_interleave(f, dim=2).repeat_interleave(f, dim=3)
+    got_up = to_nchw(ops.resample_up(nhwc(x), f))
+    assert np.array_equal(got_up, up.detach().numpy().astype(np.float32))                               # pure copies
+    du = rs.randn(*up.shape).astype(np.float32)
+    gx, = torch.autograd.grad(up, xt, torch.tensor(du, dtype=torch.float64))
+    assert rel_err(to_nchw(ops.resample_down(nhwc(du), f, scale=1.0)), gx.numpy()) <= 2e-6              # d unpool
+    # accumulate: out += ...
+    base = nhwc(rs.randn(*pooled.shape).astype(np.float32))
+    want = base + ops.resample_down(nhwc(x), f)
+    ops.resample_down(nhwc(x), f, out=base, accumulate=True)
+    assert torch.equal(base, want)
+
+
+@pytest.mark.parametrize('act', ['linear', 'relu', 'lrelu', 'tanh'])
+def test_act_and_axpby(ops, act):
+    rs = np.random.RandomState(5)
+    x = rs.randn(3, 7, 5, 11).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    yt = R._act(xt, act)
+    y = ops.act_fwd(dev(x), act)
+    assert rel_err(y.cpu().numpy(), yt.detach().numpy()) <= 2e-6
+    dy = rs.randn(*x.shape).astype(np.float32)
+    gx, = torch.autograd.grad(yt, xt, torch.tensor(dy, dtype=torch.float64), allow_unused=True)
+    got = ops.act_bwd(dev(dy), y, act)
+    assert rel_err(got.cpu().numpy(), gx.numpy()) <= 2e-6
+    acc = dev(dy).clone()
+    ops.act_bwd(dev(dy), y, act, out=acc, accumulate=True)
+    assert rel_err(acc.cpu().numpy(), gx.numpy() + dy) <= 2e-6
+    a, b = dev(x), dev(dy)
+    assert torch.equal(ops.axpby(a, b), a + b)
+    out = ops.axpby(a, b, 0.5, -2.0)
+    assert rel_err(out.cpu().numpy(), 0.5 * x - 2.0 * dy) <= 1e-6
+    ops.axpby(a, b, out=a)                                                                              # in place
+    assert rel_err(a.cpu().numpy(), x + dy) <= 1e-6
