@@ -261,7 +261,7 @@ def make_layers():
 # ---------------------------------------------------------------------------
 # 3. full G+D step on a width/8 CIFAR-shaped net, 3 consecutive steps
 # ---------------------------------------------------------------------------
-from tiny_arch import tiny_architecture  # noqa: E402
+from tiny_arch import tiny_architecture, tiny_res_architecture  # noqa: E402
 
 
 def tf_adam_inplace(var, g, m, v, t, lr, b1=0.5, b2=0.999, eps=1e-8):
@@ -274,14 +274,15 @@ def tf_adam_inplace(var, g, m, v, t, lr, b1=0.5, b2=0.999, eps=1e-8):
         var.sub_(lr_t * m / (torch.sqrt(v) + eps))
 
 
-def make_step(loss_type, B=8, n_steps=3, lr=(5e-4, 2e-4), store_grads=True, sn_mode='default'):
+def make_step(loss_type, B=8, n_steps=3, lr=(5e-4, 2e-4), store_grads=True, sn_mode='default', arch_fn=None,
+              tag=None):
     """sn_mode='sn_paper': the flattened-matrix power iteration of layer_func.py:811-814."""
     FLAGS.SPECTRAL_NORM_MODE = sn_mode
-    arch = tiny_architecture()
+    arch = (arch_fn or tiny_architecture)()
     out = {'lr': np.asarray(lr), 'loss_type': np.asarray(loss_type), 'B': np.asarray(B)}
     rs = np.random.RandomState(77)
     zs = rs.randn(n_steps, B, arch['code'][0][0]).astype(np.float32)
-    reals = rs.uniform(-1, 1, size=(n_steps, B, 3, 32, 32)).astype(np.float32)
+    reals = rs.uniform(-1, 1, size=(n_steps, B) + tuple(arch['input'][0])).astype(np.float32)
     out['z'], out['real'] = zs, reals
     init = None
     for key, dt in DT.items():
@@ -324,7 +325,10 @@ def make_step(loss_type, B=8, n_steps=3, lr=(5e-4, 2e-4), store_grads=True, sn_m
                 for v, g in list(zip(vd, gd)) + list(zip(vg, gg)):
                     out[pre + 'grad/' + v.tf_name + '_f64'] = npy(g).astype(np.float32)
             for layer in D.net.layers:
-                out[pre + 'sigma/' + layer.layer_scope + '_' + key] = npy(layer.ops['kernel'].kernel_norm)
+                for op_name, op in layer.ops.items():
+                    if getattr(op, 'kernel_norm', None) is not None:
+                        scope = layer.layer_scope if op_name == 'kernel' else layer.layer_scope + '/' + op_name
+                        out[pre + 'sigma/' + scope + '_' + key] = npy(op.kernel_norm)
             # apply both Adam updates, then the UPDATE_OPS (values were computed before any write)
             for lr_i, vs, gs in ((lr[0], vd, gd), (lr[1], vg, gg)):
                 for v, g in zip(vs, gs):
@@ -334,7 +338,7 @@ def make_step(loss_type, B=8, n_steps=3, lr=(5e-4, 2e-4), store_grads=True, sn_m
         if key == 'f64':
             for k, v in tf.STATE.variables.items():
                 out['final/' + k + '_f64'] = npy(v).astype(np.float32)
-    tag = loss_type if sn_mode == 'default' else loss_type + '_pim'
+    tag = tag or (loss_type if sn_mode == 'default' else loss_type + '_pim')
     out['sn_mode'] = np.asarray(sn_mode)
     FLAGS.SPECTRAL_NORM_MODE = 'default'
     np.savez_compressed(os.path.join(OUT, 'step_tiny_{}.npz'.format(tag)), **out)
@@ -417,6 +421,7 @@ if __name__ == '__main__':
     if '--only-next' in sys.argv:
         make_loss_next()
         make_step('rep', store_grads=False, sn_mode='sn_paper')
+        make_step('rep', arch_fn=tiny_res_architecture, tag='res_rep')
         make_eval()
         sys.exit(0)
     make_loss_next()
@@ -424,6 +429,7 @@ if __name__ == '__main__':
     make_step('rep')
     make_step('rmb', store_grads=False)
     make_step('rep', store_grads=False, sn_mode='sn_paper')
+    make_step('rep', arch_fn=tiny_res_architecture, tag='res_rep')
     make_eval()
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print('tests/golden total bytes:', total)

@@ -49,11 +49,110 @@ def layer_defaults(design):
         d['bias'] = None
     if d['op'] == 'tc':
         d['scale'] = None
-    if d['op'] not in ('d', 'c', 'tc'):
+    if d['op'] not in ('d', 'c', 'tc', 'i'):
         raise AttributeError('layer op {} not supported.'.format(d['op']))
-    if d['type'] != 'default':
+    if d['type'] not in ('default',) + RES_TYPES:
         raise NotImplementedError('{} is not implemented.'.format(d['type']))
+    if d['type'] in RES_TYPES and d['op'] != 'c':
+        raise NotImplementedError('residual blocks are restated for op "c" only')
+    if d['scale'] is not None:
+        assert isinstance(d['scale'], (list, tuple)), 'Value for key "scale" must be list or tuple.'   # :1250-1252
     return d
+
+
+RES_TYPES = ('res', 'res_i', 'res_v1')                       # layer_func.py:2062
+
+
+def _pick(value, index):
+    """Layer._update_design_ (layer_func.py:1380-1395): list-valued design entries are per kernel"""
+    return value[index] if isinstance(value, (list, tuple)) else value
+
+
+def _scaled_shape(shape, scale):
+    """ImageScaling._get_shape_ (layer_func.py:1076-1109) for the methods restated here"""
+    method, factor = scale
+    c, h, w = shape
+    if method == 'avg':
+        if factor > 0:
+            raise AttributeError('avg can only be used for downsampling')
+    elif method == 'unpool':
+        if factor < 0:
+            raise AttributeError('unpool can only be used for upsampling')
+        if factor != 2:
+            raise AttributeError('unpool can only deal with factor = 2')
+    else:
+        raise NotImplementedError('Method {} not implemented.'.format(method))
+    return [c, int(h * factor), int(w * factor)] if factor > 0 else [c, int(-h / factor), int(-w / factor)]
+
+
+def _rescale(x, scale):
+    """ImageScaling.__call__ (layer_func.py:1155-1163): 'avg' = avg_pool with window = stride = -factor;
+    'unpool' = four channel copies through depth_to_space = every pixel repeated 2 x 2"""
+    method, factor = scale
+    if method == 'avg':
+        return F.avg_pool2d(x, -factor)
+    return x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+
+
+def _kernel_spec(layer_scope, op_name, d, index, in_shape, sn_mode):
+    """one ParametricOperation of a block (Layer._add_kernel_, layer_func.py:1415-1452): a conv kernel with its own
+    spectral norm; variables live under <layer>/<op_name>/"""
+    sub = {'op': 'c', 'type': 'default', 'in_reshape': None, 'out_reshape': None}
+    for key in ('out', 'act', 'act_k', 'w_nm', 'kernel', 'strides', 'dilation', 'padding'):
+        sub[key] = _pick(d[key], index)
+    c, h, w = in_shape
+    ks = {'design': sub, 'scope': '{}/{}'.format(layer_scope, op_name), 'in_shape': list(in_shape),
+          'kernel_shape': [sub['kernel'], sub['kernel'], c, sub['out']],
+          'op_out_shape': [sub['out'], _same_out(h, sub['strides']), _same_out(w, sub['strides'])]}
+    if sub['w_nm'] == 's':
+        if sn_mode in ('sn_paper', 'PIM', 'pim'):
+            num_in = int(np.prod(ks['kernel_shape'][:3]))
+            ks['use_u'] = num_in <= sub['out']
+            ks['sn_x_shape'] = [1, num_in] if ks['use_u'] else [1, sub['out']]
+            ks['pim'] = True
+        else:
+            ks['use_u'] = int(np.prod(in_shape)) <= int(np.prod(ks['op_out_shape']))
+            ks['sn_x_shape'] = [1] + (list(in_shape) if ks['use_u'] else list(ks['op_out_shape']))
+        if not isinstance(sub['act_k'], (float, int)) or sub['act_k'] is False:
+            raise ValueError('{}: w_nm="s" needs a numeric act_k'.format(ks['scope']))
+    return ks
+
+
+def _build_res(s, d, shape, sn_mode):
+    """Layer._add_layer_res_ (layer_func.py:1687-1771)"""
+    sc, bn = s['scope'], d['act_nm'] in ('bn', 'BN')
+    up = d['scale'] is not None and d['scale'][1] > 0
+    down = d['scale'] is not None and d['scale'][1] < 0
+    res = {'bn0': bn and d['type'] != 'res_v1', 'bn1': bn, 'up': up, 'down': down,
+           'bias': d['bias'] is not None, 'bias_sc': True}        # :1745 "'bias' in self.design" holds for every design
+    cur = list(shape)
+    if up:
+        cur = _scaled_shape(cur, d['scale'])
+    res['k0'] = _kernel_spec(sc, 'kernel_0', d, 0, cur, sn_mode)
+    cur = res['k0']['op_out_shape']
+    res['k1'] = _kernel_spec(sc, 'kernel_1', d, 1, cur, sn_mode)
+    cur = res['k1']['op_out_shape']
+    if down:
+        cur = _scaled_shape(cur, d['scale'])
+    sc_shape = list(shape)
+    if d['type'] == 'res':
+        if up:
+            sc_shape = _scaled_shape(sc_shape, d['scale'])
+        res['ksc'] = _kernel_spec(sc, 'kernel_sc', d, 2, sc_shape, sn_mode)
+        sc_shape = res['ksc']['op_out_shape']
+        if down:
+            sc_shape = _scaled_shape(sc_shape, d['scale'])
+    elif d['type'] == 'res_v1':
+        if d['scale'] is not None:
+            if not down:
+                raise AttributeError('{}: res_v1 is only used with downsampling.'.format(sc))
+            sc_shape = _scaled_shape(sc_shape, d['scale'])
+        res['ksc'] = _kernel_spec(sc, 'kernel_sc', d, 2, sc_shape, sn_mode)
+        sc_shape = res['ksc']['op_out_shape']
+    assert sc_shape == cur, '{}: Resnet shape {} and shortcut shape {} do not match.'.format(sc, cur, sc_shape)
+    s['res'] = res
+    return list(cur)
+
 
 
 def _same_out(size, stride):
@@ -70,6 +169,22 @@ def build_net(designs, input_shape, net_name, sn_mode='default'):
         if d['in_reshape'] is not None:
             shape = list(d['in_reshape'])
         s = {'design': d, 'scope': '{}/{}'.format(net_name, d['name']), 'in_shape': list(shape)}
+        if d['type'] in RES_TYPES or d['op'] == 'i':
+            if d['type'] in RES_TYPES:
+                out = _build_res(s, d, shape, sn_mode)
+            else:                                            # identity kernel: BN / activation only (:1275, 1646-1685)
+                if d['scale'] is not None:
+                    raise NotImplementedError('scaling on an identity layer is not restated')
+                out = list(shape)
+            s['op_out_shape'] = list(out)
+            if d['out_reshape'] is not None:
+                out = list(d['out_reshape'])
+            s['out_shape'] = list(out)
+            specs.append(s)
+            shape = list(out)
+            continue
+        if d['scale'] is not None:
+            raise NotImplementedError('{}: scaling outside residual blocks is not restated'.format(s['scope']))
         if d['op'] == 'd':                                   # layer_func.py:576-578
             assert len(shape) == 1, '{}: dense layer needs a flat input'.format(s['scope'])
             s['kernel_shape'] = [shape[0], d['out']]
@@ -140,8 +255,37 @@ def init_kernel(rng, shape, act):
 def init_params(specs, rng, dtype=torch.float32):
     """all variables of one net, in TF creation order, reference names and layouts."""
     p = OrderedDict()
+    def bn_vars(prefix, c):
+        p[prefix + '/BN/gamma'] = torch.ones(c, dtype=dtype)
+        p[prefix + '/BN/beta'] = torch.zeros(c, dtype=dtype)
+        p[prefix + '/BN/moving_mean'] = torch.zeros(c, dtype=dtype)
+        p[prefix + '/BN/moving_variance'] = torch.ones(c, dtype=dtype)
+
+    def kernel_vars(ks, bias_name):
+        kd = ks['design']
+        p[ks['scope'] + '/kernel'] = torch.as_tensor(init_kernel(rng, ks['kernel_shape'], kd['act']), dtype=dtype)
+        if kd['w_nm'] == 's':
+            p[ks['scope'] + '/SN/in_rand'] = torch.as_tensor(_trunc_normal(rng, ks['sn_x_shape'], 1.0), dtype=dtype)
+        if bias_name is not None:
+            p[bias_name] = torch.as_tensor(_trunc_normal(rng, [kd['out']], 1e-5), dtype=dtype)
+
     for s in specs:
         d, sc = s['design'], s['scope']
+        if 'res' in s:                                                # creation order of layer_func.py:1687-1771
+            r = s['res']
+            if r['bn0']:
+                bn_vars(sc + '/BN_0', s['in_shape'][0])
+            kernel_vars(r['k0'], sc + '/bias_0/bias' if r['bias'] else None)
+            if r['bn1']:
+                bn_vars(sc + '/BN_1', r['k0']['design']['out'])
+            kernel_vars(r['k1'], sc + '/bias_1/bias' if r['bias'] else None)
+            if 'ksc' in r:
+                kernel_vars(r['ksc'], sc + '/bias_sc/bias')
+            continue
+        if d['op'] == 'i':
+            if d['act_nm'] in ('bn', 'BN'):
+                bn_vars(sc + '/BN', s['in_shape'][0])
+            continue
         p[sc + '/kernel/kernel'] = torch.as_tensor(init_kernel(rng, s['kernel_shape'], d['act']), dtype=dtype)
         if d['w_nm'] == 's':                                          # math_func.py:565-567
             p[sc + '/kernel/SN/in_rand'] = torch.as_tensor(_trunc_normal(rng, s['sn_x_shape'], 1.0), dtype=dtype)
@@ -242,6 +386,36 @@ def net_forward(specs, params, x, is_training=True, collect=None):
     """returns (output, updates) - updates maps variable name -> new value (the UPDATE_OPS of
     graph_func.py:848: SN in_rand assignments and BN moving statistics)."""
     updates = OrderedDict()
+
+    def batch_norm(t, prefix):                                # layer_func.py:953-966, SURVEY A.4
+        axis_shape, dims = [1, -1, 1, 1], [0, 2, 3]
+        if is_training:
+            mean = t.mean(dim=dims)
+            var = ((t - mean.reshape(axis_shape)) ** 2).mean(dim=dims)
+            cnt = t.numel() // t.shape[1]
+            var_u = var * (cnt / max(cnt - 1.0, 1.0))
+            mm, mv = params[prefix + '/BN/moving_mean'], params[prefix + '/BN/moving_variance']
+            updates[prefix + '/BN/moving_mean'] = mm * BN_MOMENTUM + mean.detach() * (1 - BN_MOMENTUM)
+            updates[prefix + '/BN/moving_variance'] = mv * BN_MOMENTUM + var_u.detach() * (1 - BN_MOMENTUM)
+        else:
+            mean, var = params[prefix + '/BN/moving_mean'], params[prefix + '/BN/moving_variance']
+        t = (t - mean.reshape(axis_shape)) / torch.sqrt(var.reshape(axis_shape) + BN_EPS)
+        return t * params[prefix + '/BN/gamma'].reshape(axis_shape) + params[prefix + '/BN/beta'].reshape(axis_shape)
+
+    def conv_op(t, ks, bias_name):                            # ParametricOperation.apply, layer_func.py:870-950
+        kd = ks['design']
+        w = params[ks['scope'] + '/kernel']
+        if kd['w_nm'] == 's':
+            sigma, x_new = sn_power_iteration(w, params[ks['scope'] + '/SN/in_rand'], ks)
+            updates[ks['scope'] + '/SN/in_rand'] = x_new
+            w = w * (kd['act_k'] / sigma)
+            if collect is not None:
+                collect[ks['scope'] + '/sigma'] = sigma.detach()
+        t = conv2d_same(t, w, kd['strides'])
+        if bias_name is not None:
+            t = t + params[bias_name].reshape(1, -1, 1, 1)
+        return t
+
     for s in specs:
         d, sc = s['design'], s['scope']
         n = x.shape[0]
@@ -249,6 +423,45 @@ def net_forward(specs, params, x, is_training=True, collect=None):
             x = x.reshape([n] + list(d['in_reshape']))
         assert list(x.shape[1:]) == s['in_shape'], \
             '{}: the input shape {} does not match existed shape {}.'.format(sc, list(x.shape[1:]), s['in_shape'])
+        if 'res' in s or d['op'] == 'i':
+            if d['op'] == 'i':                                # identity kernel, then BN and activation (:1646-1685)
+                if d['act_nm'] in ('bn', 'BN'):
+                    x = batch_norm(x, sc + '/BN')
+                x = _act(x, d['act'])
+            else:                                             # Layer._apply_layer_res_, layer_func.py:1773-1842
+                r = s['res']
+                res = x
+                if d['type'] != 'res_v1':
+                    if r['bn0']:
+                        res = batch_norm(res, sc + '/BN_0')
+                    res = _act(res, d['act'])
+                if r['up']:
+                    res = _rescale(res, d['scale'])
+                res = conv_op(res, r['k0'], sc + '/bias_0/bias' if r['bias'] else None)
+                if r['bn1']:
+                    res = batch_norm(res, sc + '/BN_1')
+                res = _act(res, d['act'])
+                res = conv_op(res, r['k1'], sc + '/bias_1/bias' if r['bias'] else None)
+                if r['down']:
+                    res = _rescale(res, d['scale'])
+                short = x
+                if d['type'] == 'res':
+                    if r['up']:
+                        short = _rescale(short, d['scale'])
+                    short = conv_op(short, r['ksc'], sc + '/bias_sc/bias')
+                    if r['down']:
+                        short = _rescale(short, d['scale'])
+                elif d['type'] == 'res_v1':
+                    if r['down']:
+                        short = _rescale(short, d['scale'])
+                    short = conv_op(short, r['ksc'], sc + '/bias_sc/bias')
+                x = res + short
+            if collect is not None:
+                collect[sc + '/out'] = x.detach()
+                collect[sc + '/out_live'] = x
+            if d['out_reshape'] is not None:
+                x = x.reshape([n] + list(d['out_reshape']))
+            continue
         w = params[sc + '/kernel/kernel']
         if d['w_nm'] == 's':                                  # layer_func.py:884-887, 913
             sigma, x_new = sn_power_iteration(w, params[sc + '/kernel/SN/in_rand'], s)

@@ -21,3 +21,26 @@ def tiny_architecture(loss_base=4):
                               {'name': 'l7', 'out': 64, 'op': 'c', 'act': 'lrelu', 'act_k': ak, 'w_nm': s,
                                'out_reshape': [4 * 4 * 64]},
                               {'name': 'l8_s', 'out': 16, 'op': 'd', 'act_k': ak, 'bias': 'b', 'w_nm': s}]}
+
+
+def tiny_res_architecture():
+    """width/16 ResNet-SN shaped pair: G = dense -> two up-sampling residual blocks with BN ->
+    BN/relu -> conv/tanh at 16x16; D = the 'optimised' first block (res_v1), a down-sampling block, an identity-
+    shortcut block, dense - every kind of block the reference defines (layer_func.py:1687-1842)."""
+    ak = float(np.power(64.0, 0.125))
+    k = [3, 3, 1]
+    return {'input': [(3, 16, 16)], 'code': [(24, 'linear')],
+            'generator': [{'name': 'l1', 'out': 32 * 4 * 4, 'op': 'd', 'out_reshape': [32, 4, 4]},
+                          {'name': 'l2_res', 'type': 'res', 'out': 16, 'act': 'relu', 'act_nm': 'bn', 'kernel': k,
+                           'scale': ['unpool', 2]},
+                          {'name': 'l3_res', 'type': 'res', 'out': 16, 'act': 'relu', 'act_nm': 'bn', 'kernel': k,
+                           'scale': ['unpool', 2]},
+                          {'name': 'l4_bn', 'op': 'i', 'act': 'relu', 'act_nm': 'bn'},
+                          {'name': 'l5_t16', 'out': 3, 'act': 'tanh'}],
+            'discriminator': [{'name': 'l1_res', 'type': 'res_v1', 'out': 16, 'act': 'relu', 'act_k': ak, 'w_nm': 's',
+                               'kernel': k, 'scale': ['avg', -2]},
+                              {'name': 'l2_res', 'type': 'res', 'out': 32, 'act': 'relu', 'act_k': ak, 'w_nm': 's',
+                               'kernel': k, 'scale': ['avg', -2]},
+                              {'name': 'l3_res', 'type': 'res_i', 'out': 32, 'act': 'relu', 'act_k': ak, 'w_nm': 's',
+                               'out_reshape': [4 * 4 * 32]},
+                              {'name': 'l4_s', 'out': 16, 'op': 'd', 'act_k': ak, 'w_nm': 's'}]}
