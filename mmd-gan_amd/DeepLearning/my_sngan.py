@@ -16,6 +16,7 @@ from GeneralTools.misc_fun import FLAGS
 from GeneralTools.graph_func import prepare_folder, write_sprite_wrapper
 from mmdgan_hip import ops
 from mmdgan_hip.engine import GanEngine
+from mmdgan_hip.tape import TapeEngine, has_residual_blocks
 
 
 class SNGan(object):
@@ -52,7 +53,9 @@ class SNGan(object):
     def init_net(self, lr_list, batch_size, seed=0):
         """G and D with their optimisers (my_sngan.py:85-108, 412-415)."""
         if self.engine is None or self.engine.B != batch_size:
-            self.engine = GanEngine(self.architecture, self.loss_type, lr_list, tuple(self.rep_weights),
+            # residual blocks / scaling ops / identity layers: the primitive-op engine (mmdgan_hip/tape.py)
+            engine_cls = TapeEngine if has_residual_blocks(self.architecture) else GanEngine
+            self.engine = engine_cls(self.architecture, self.loss_type, lr_list, tuple(self.rep_weights),
                                     batch_size=batch_size, seed=seed, dist_group=self.dist_group,
                                     sn_mode=FLAGS.SPECTRAL_NORM_MODE,                # layer_func.py:802-814
                                     # eager issue measured faster than replaying the 3-branch hipGraph when the

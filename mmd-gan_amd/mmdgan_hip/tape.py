@@ -1,0 +1,715 @@
+"""Engine for architectures with residual blocks (reference layer_func.py:1687-1842).
+
+The DCGAN path (engine.py) is a hand-scheduled chain of fused launches; residual nets are not a chain - a block's
+input feeds two branches, its pre-activation cannot ride on the producer's epilogue, scaling ops sit between the
+convolutions.  Here every net is lowered to a short list of primitive ops over named values (dense, conv, bn+act,
+act, resample up / down, add, reshape), run forward and then backward in reverse order, each primitive calling the
+same C-ABI kernels as the DCGAN path (MFMA / Winograd convs, GEMM, BN, spectral-norm helpers, fused MMD loss,
+multi-tensor Adam) plus the block-specific elementwise kernels of csrc/resample.hip.  Same semantics as
+GanEngine.step: one spectral-norm power iteration per SN kernel per step (every kernel of a block has its own,
+layer_func.py:1415-1452), D sees [real ; fake], both gradients are taken before either update.
+
+Layout: NHWC on the device; variables are exchanged in the reference's layouts (get_variables / set_variables).
+"""
+import math
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ops
+from .engine import _Arena, _chw_perm, _trunc_normal
+
+_TEMPLATE = {'name': None, 'type': 'default', 'op': 'c', 'out': None, 'bias': 'b', 'act': 'linear', 'act_nm': None,
+             'act_k': False, 'w_nm': None, 'w_p': None, 'kernel': 3, 'strides': 1, 'dilation': 1, 'padding': 'SAME',
+             'scale': None, 'in_reshape': None, 'out_reshape': None, 'aux': None}
+RES_TYPES = ('res', 'res_i', 'res_v1')                                   # layer_func.py:2062
+_PIM = ('sn_paper', 'PIM', 'pim')
+
+
+def has_residual_blocks(architecture):
+    return any(d.get('type', 'default') in RES_TYPES or d.get('op') == 'i' or d.get('scale') is not None
+               for net in ('generator', 'discriminator') for d in architecture[net])
+
+
+def _pick(value, index):                                                 # Layer._update_design_, layer_func.py:1380-1395
+    return value[index] if isinstance(value, (list, tuple)) else value
+
+
+class _Kernel:
+    """one ParametricOperation (layer_func.py:480-1038): a dense or conv kernel, optional bias, optional SN"""
+
+    def __init__(self, scope, op, kernel_shape, in_ref, out_ref, act, w_nm, act_k, bias_name, stride, sn_mode):
+        self.scope, self.op, self.kernel_shape = scope, op, list(kernel_shape)
+        self.in_ref, self.out_ref = list(in_ref), list(out_ref)          # reference shapes without batch
+        self.act_init, self.bias_name, self.stride = act, bias_name, stride
+        self.R = kernel_shape[0] if op == 'c' else 1
+        self.out = kernel_shape[-1]
+        self.sn, self.act_k, self.pim = w_nm == 's', act_k, False
+        self.row_perm = self.col_perm = None                             # dense kernels at an NCHW <-> NHWC seam
+        if w_nm not in (None, 's'):
+            raise NotImplementedError('{}: {} method not implemented'.format(scope, w_nm))       # layer_func.py:824
+        if self.sn:
+            if act_k is False or not isinstance(act_k, (float, int)):
+                raise ValueError('{}: w_nm="s" needs a numeric act_k'.format(scope))
+            if op == 'd' or sn_mode in _PIM:                             # math_func.py:481-486, layer_func.py:811-814
+                num_in = int(np.prod(kernel_shape[:-1]))
+                self.pim = op == 'c'
+                self.use_u = num_in <= self.out
+                self.sn_x_ref = [1, num_in] if self.use_u else [1, self.out]
+            else:                                                        # math_func.py:512-528
+                self.use_u = int(np.prod(in_ref)) <= int(np.prod(out_ref))
+                self.sn_x_ref = [1] + (list(in_ref) if self.use_u else list(out_ref))
+
+    @property
+    def w_name(self):
+        return self.scope + '/kernel'
+
+    def sn_native(self):
+        r = self.sn_x_ref
+        return [1, r[2], r[3], r[1]] if len(r) == 4 else list(r)
+
+    def sn_u_shape(self):
+        if self.op == 'd' or self.pim:
+            return [1, self.out] if self.use_u else [1, int(np.prod(self.kernel_shape[:-1]))]
+        src = self.out_ref if self.use_u else self.in_ref
+        return [1, src[1], src[2], src[0]]
+
+
+class _Net:
+    """one net lowered to primitives; owns its variables (flat arenas) and state"""
+
+    def __init__(self, designs, in_ref, name, device, rng, sn_mode):
+        self.name, self.device, self.sn_mode = name, device, sn_mode
+        self.prims, self.kernels, self.bns = [], [], []
+        self._nval = 1                                                   # value 0 is the net input
+        self.shapes = {0: list(in_ref)}                                  # value id -> reference shape (no batch)
+        cur = 0
+        for design in designs:
+            cur = self._lower(design, cur)
+        self.out_val = cur
+        self._allocate(rng)
+
+    # ---- lowering ---------------------------------------------------------------------------------------------
+    def _new(self, ref_shape):
+        v = self._nval
+        self._nval += 1
+        self.shapes[v] = list(ref_shape)
+        return v
+
+    def _emit(self, kind, ins, out_shape, **attrs):
+        out = self._new(out_shape)
+        self.prims.append(dict(kind=kind, ins=list(ins), out=out, **attrs))
+        return out
+
+    def _conv(self, scope, opname, d, index, x, bias_name):
+        c, h, w = self.shapes[x]
+        R, stride, out = _pick(d['kernel'], index), _pick(d['strides'], index), _pick(d['out'], index)
+        if _pick(d['dilation'], index) != 1 or _pick(d['padding'], index) != 'SAME':
+            raise NotImplementedError('{}: dilation / VALID are not built'.format(scope))
+        out_ref = [out, -(-h // stride), -(-w // stride)]
+        k = _Kernel('{}/{}'.format(scope, opname), 'c', [R, R, c, out], [c, h, w], out_ref, _pick(d['act'], index),
+                    _pick(d['w_nm'], index), _pick(d['act_k'], index), bias_name, stride, self.sn_mode)
+        self.kernels.append(k)
+        return self._emit('conv', [x], out_ref, k=k)
+
+    def _bn_act(self, prefix, x, act):
+        self.bns.append((prefix, self.shapes[x][0]))
+        return self._emit('bn', [x], self.shapes[x], prefix=prefix, act=act)
+
+    def _scale(self, x, scale):                                          # ImageScaling, layer_func.py:1041-1176
+        method, factor = scale
+        c, h, w = self.shapes[x]
+        if method == 'avg':
+            if factor > 0:
+                raise AttributeError('avg can only be used for downsampling')             # :1098-1099
+            f = -factor
+            if h % f or w % f:
+                raise NotImplementedError('avg pooling of a size its window does not divide is not built')
+            return self._emit('down', [x], [c, h // f, w // f], f=f)
+        if method == 'unpool':
+            if factor < 0:
+                raise AttributeError('unpool can only be used for upsampling')            # :1100-1101
+            if factor != 2:
+                raise AttributeError('unpool can only deal with factor = 2')              # :1102-1103
+            return self._emit('up', [x], [c, h * 2, w * 2], f=2)
+        raise NotImplementedError('Method {} not implemented.'.format(method))            # :1165-1167
+
+    def _lower(self, design, x):
+        d = dict(_TEMPLATE)
+        d.update(design)
+        if d['act_nm'] in ('bn', 'BN') and d['bias'] in ('b', 'bias'):                    # layer_func.py:1241-1242
+            d['bias'] = None
+        if d['op'] == 'tc':
+            d['scale'] = None                                                             # :1245-1247
+        scope = '{}/{}'.format(self.name, d['name'])
+        if d['act_nm'] not in (None, 'bn', 'BN'):
+            raise NotImplementedError('{}: {} not implemented'.format(scope, d['act_nm']))
+        if d['act'] not in ('linear', 'relu', 'lrelu', 'tanh'):
+            raise NotImplementedError('Function {} is not implemented.'.format(d['act']))  # :149
+        bn = d['act_nm'] in ('bn', 'BN')
+        if d['in_reshape'] is not None:
+            x = self._reshape(x, d['in_reshape'])
+        if d['type'] in RES_TYPES:
+            if d['op'] != 'c':
+                raise NotImplementedError('{}: residual blocks are built for op "c"'.format(scope))
+            y = self._lower_res(d, scope, x, bn)
+        elif d['type'] != 'default':
+            raise NotImplementedError('{}: {} is not implemented.'.format(scope, d['type']))   # :2067
+        elif d['op'] == 'i':                                             # identity kernel, then BN / activation
+            y = self._bn_act(scope + '/BN', x, d['act']) if bn else self._emit('act', [x], self.shapes[x], act=d['act'])
+        elif d['op'] in ('d', 'c'):
+            if d['scale'] is not None and d['scale'][1] > 0:             # :1627-1629
+                x = self._scale(x, d['scale'])
+            bias_name = scope + '/bias/bias' if d['bias'] is not None else None
+            if d['op'] == 'd':
+                assert len(self.shapes[x]) == 1, '{}: the input shape {} does not match a dense layer'.format(scope, self.shapes[x])
+                k = _Kernel(scope + '/kernel', 'd', [self.shapes[x][0], d['out']], self.shapes[x], [d['out']], d['act'],
+                            d['w_nm'], d['act_k'], bias_name, 1, self.sn_mode)
+                self.kernels.append(k)
+                y = self._emit('dense', [x], [d['out']], k=k)
+            else:
+                y = self._conv(scope, 'kernel', d, None, x, bias_name)
+            if bn:
+                y = self._bn_act(scope + '/BN', y, d['act'])
+            elif d['act'] != 'linear':
+                y = self._emit('act', [y], self.shapes[y], act=d['act'])
+            if d['scale'] is not None and d['scale'][1] < 0:             # :1640-1642
+                y = self._scale(y, d['scale'])
+        else:
+            raise NotImplementedError('{}: op {} is served by the DCGAN engine only'.format(scope, d['op']))
+        if d['out_reshape'] is not None:
+            y = self._reshape(y, d['out_reshape'])
+        return y
+
+    def _reshape(self, x, ref_shape):
+        ref_shape = list(ref_shape)
+        assert int(np.prod(ref_shape)) == int(np.prod(self.shapes[x])), \
+            'the output shape {} does not match existed shape {}.'.format(self.shapes[x], ref_shape)
+        return self._emit('reshape', [x], ref_shape, src_shape=list(self.shapes[x]))
+
+    def _lower_res(self, d, scope, x, bn):                               # layer_func.py:1687-1842
+        act, typ = d['act'], d['type']
+        up = d['scale'] is not None and d['scale'][1] > 0
+        down = d['scale'] is not None and d['scale'][1] < 0
+        bias = d['bias'] is not None
+        r = x
+        if typ != 'res_v1':
+            if bn:
+                r = self._bn_act(scope + '/BN_0', r, act)
+            elif act != 'linear':
+                r = self._emit('act', [r], self.shapes[r], act=act)
+        if up:
+            r = self._scale(r, d['scale'])
+        r = self._conv(scope, 'kernel_0', d, 0, r, scope + '/bias_0/bias' if bias else None)
+        if bn:
+            r = self._bn_act(scope + '/BN_1', r, act)
+        elif act != 'linear':
+            r = self._emit('act', [r], self.shapes[r], act=act)
+        r = self._conv(scope, 'kernel_1', d, 1, r, scope + '/bias_1/bias' if bias else None)
+        if down:
+            r = self._scale(r, d['scale'])
+        s = x
+        if typ == 'res':
+            if up:
+                s = self._scale(s, d['scale'])
+            s = self._conv(scope, 'kernel_sc', d, 2, s, scope + '/bias_sc/bias')          # :1745 keeps the bias
+            if down:
+                s = self._scale(s, d['scale'])
+        elif typ == 'res_v1':
+            if d['scale'] is not None:
+                if not down:
+                    raise AttributeError('{}: res_v1 is only used with downsampling.'.format(scope))
+                s = self._scale(s, d['scale'])
+            s = self._conv(scope, 'kernel_sc', d, 2, s, scope + '/bias_sc/bias')
+        assert self.shapes[s] == self.shapes[r], \
+            '{}: Resnet shape {} and shortcut shape {} do not match.'.format(scope, self.shapes[r], self.shapes[s])
+        return self._emit('add', [r, s], self.shapes[r])
+
+    # ---- variables --------------------------------------------------------------------------------------------
+    def _allocate(self, rng):
+        # dense kernels next to a [C,H,W] <-> flat reshape carry the NCHW <-> NHWC permutation (as engine.py does)
+        produced_by = {p['out']: p for p in self.prims}
+        for p in self.prims:
+            if p['kind'] == 'dense':
+                src = produced_by.get(p['ins'][0])
+                if src is not None and src['kind'] == 'reshape' and len(src['src_shape']) == 3:
+                    p['k'].row_perm = _chw_perm(*src['src_shape'])
+            if p['kind'] == 'reshape' and len(self.shapes[p['out']]) == 3:
+                src = produced_by.get(p['ins'][0])
+                if src is not None and src['kind'] == 'dense':
+                    src['k'].col_perm = _chw_perm(*self.shapes[p['out']])
+                else:
+                    raise NotImplementedError('a reshape to an image must follow a dense layer')
+        for p in self.prims:
+            if p['kind'] == 'bn':
+                src = produced_by.get(p['ins'][0])
+                if src is not None and src['kind'] == 'dense' and src['k'].col_perm is not None:
+                    raise NotImplementedError('batch norm between a dense layer and its image reshape is served by the '
+                                              'DCGAN engine only')
+        entries = []
+        for item in self._creation_order():
+            if isinstance(item, _Kernel):
+                entries.append((item.w_name, item.kernel_shape))
+                if item.bias_name is not None:
+                    entries.append((item.bias_name, [item.out]))
+            else:
+                prefix, c = item
+                entries += [(prefix + '/BN/gamma', [c]), (prefix + '/BN/beta', [c])]
+        self.arena = _Arena(entries, self.device)
+        self.params = self.arena.flat
+        self.grads, self.adam_m, self.adam_v = self.arena.like(), self.arena.like(), self.arena.like()
+        self.opt = ops.AdamGroup([self.params], [self.grads], [self.adam_m], [self.adam_v])
+        self.state, self.sn = OrderedDict(), {}
+        for item in self._creation_order():
+            if isinstance(item, _Kernel):
+                if item.sn:
+                    self.state[item.scope + '/SN/in_rand'] = torch.zeros(item.sn_native(), device=self.device)
+                    z = lambda *shape: torch.zeros(*shape, device=self.device)
+                    self.sn[item.scope] = dict(sigma=z(1), scale=z(1), dot=z(1), xbn=z(1), dsigma=z(item.kernel_shape),
+                                               u=z(item.sn_u_shape()), un=z(item.sn_u_shape()), xb=z(item.sn_native()))
+            else:
+                prefix, c = item
+                self.state[prefix + '/BN/moving_mean'] = torch.zeros(c, device=self.device)
+                self.state[prefix + '/BN/moving_variance'] = torch.ones(c, device=self.device)
+        self._kernel_by_name = {}
+        for k in self.kernels:
+            self._kernel_by_name[k.w_name] = k
+            if k.bias_name is not None:
+                self._kernel_by_name[k.bias_name] = k
+            if k.sn:
+                self._kernel_by_name[k.scope + '/SN/in_rand'] = k
+        self.init_variables(rng)
+
+    def _creation_order(self):
+        """kernels and BN ops in the order the primitives use them (= the reference's variable creation order)"""
+        for p in self.prims:
+            if p['kind'] in ('dense', 'conv'):
+                yield p['k']
+            elif p['kind'] == 'bn':
+                yield (p['prefix'], self.shapes[p['out']][0])
+
+    def p(self, name):
+        return self.arena.view(name)
+
+    def g(self, name):
+        return self.arena.view(name, self.grads)
+
+    def variable_names(self, trainable_only=False):
+        names = list(self.arena.offsets)
+        return names if trainable_only else names + list(self.state)
+
+    def _dense_vec_perm(self, name):
+        """a bias / BN vector that lives on the output of a dense layer feeding an image reshape"""
+        k = self._kernel_by_name.get(name)
+        if k is not None and k.op == 'd' and name == k.bias_name:
+            return k.col_perm
+        return None
+
+    def to_native(self, name, ref):
+        ref = np.asarray(ref, dtype=np.float32)
+        k = self._kernel_by_name.get(name)
+        if name.endswith('/SN/in_rand'):
+            if ref.ndim == 4:
+                return np.ascontiguousarray(ref.transpose(0, 2, 3, 1))
+            perm = k.row_perm if (k.op == 'd' and k.use_u) else (k.col_perm if k.op == 'd' else None)
+            return ref[:, perm] if perm is not None else ref
+        if k is not None and k.op == 'd' and name == k.w_name:
+            if k.row_perm is not None:
+                ref = ref[k.row_perm, :]
+            if k.col_perm is not None:
+                ref = ref[:, k.col_perm]
+            return np.ascontiguousarray(ref)
+        perm = self._dense_vec_perm(name)
+        return np.ascontiguousarray(ref[perm]) if perm is not None else ref
+
+    def to_ref(self, name, nat):
+        nat = np.asarray(nat, dtype=np.float32)
+        k = self._kernel_by_name.get(name)
+
+        def unperm(a, perm, axis):
+            out = np.empty_like(a)
+            if axis == 0:
+                out[perm] = a
+            else:
+                out[:, perm] = a
+            return out
+        if name.endswith('/SN/in_rand'):
+            if nat.ndim == 4:
+                return np.ascontiguousarray(nat.transpose(0, 3, 1, 2))
+            perm = k.row_perm if (k.op == 'd' and k.use_u) else (k.col_perm if k.op == 'd' else None)
+            return unperm(nat, perm, 1) if perm is not None else nat
+        if k is not None and k.op == 'd' and name == k.w_name:
+            if k.col_perm is not None:
+                nat = unperm(nat, k.col_perm, 1)
+            if k.row_perm is not None:
+                nat = unperm(nat, k.row_perm, 0)
+            return nat
+        perm = self._dense_vec_perm(name)
+        return unperm(nat, perm, 0) if perm is not None else nat
+
+    def tensor(self, name, grad=False):
+        if name in self.arena.offsets:
+            return self.g(name) if grad else self.p(name)
+        return self.state[name]
+
+    def set_variable(self, name, value):
+        t = self.tensor(name)
+        t.copy_(torch.as_tensor(self.to_native(name, value)).reshape(t.shape))
+
+    def get_variable(self, name, grad=False):
+        return self.to_ref(name, self.tensor(name, grad).detach().cpu().numpy())
+
+    def init_variables(self, rng):
+        """the reference's initialisers (layer_func.py:27-52, 745-747; TF fan rule), reference layouts"""
+        for item in self._creation_order():
+            if not isinstance(item, _Kernel):
+                self.set_variable(item[0] + '/BN/gamma', np.ones(item[1], np.float32))
+                continue
+            shape = item.kernel_shape
+            receptive = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+            fan_in, fan_out = shape[-2] * receptive, shape[-1] * receptive
+            if item.act_init == 'relu':
+                w = _trunc_normal(rng, shape, math.sqrt(2.0 / fan_in))
+            elif item.act_init == 'lrelu':
+                w = _trunc_normal(rng, shape, math.sqrt(2.0 / 1.01 / fan_in))
+            else:
+                lim = math.sqrt(3.0 / ((fan_in + fan_out) / 2.0))
+                w = rng.uniform(-lim, lim, size=shape).astype(np.float32)
+            self.set_variable(item.w_name, w)
+            if item.sn:
+                self.set_variable(item.scope + '/SN/in_rand', _trunc_normal(rng, item.sn_x_ref, 1.0))
+            if item.bias_name is not None:
+                self.set_variable(item.bias_name, _trunc_normal(rng, [item.out], 1e-5))
+
+
+def _native(ref_shape, n):
+    return [n, ref_shape[1], ref_shape[2], ref_shape[0]] if len(ref_shape) == 3 else [n, ref_shape[0]]
+
+
+class TapeEngine:
+    """G + D + loss + two TF-Adam optimisers for nets with residual blocks; same interface as GanEngine."""
+
+    def __init__(self, architecture, loss_type='rep', lr_list=(5e-4, 2e-4), rep_weights=(0.0, -1.0), batch_size=64,
+                 seed=0, device=None, dist_group=None, use_graph=False, sn_mode='default'):
+        ops.require_device()
+        if loss_type not in ops.LOSS:
+            raise NotImplementedError('Not implemented.')                                # math_func.py:2651
+        assert rep_weights[0] - rep_weights[1] == 1.0, 'w[0]-w[1] must be 1'              # math_func.py:1340
+        if sn_mode not in ('default', 'PICO', 'pico') + _PIM:
+            raise NotImplementedError('spectral norm mode {} is not implemented.'.format(sn_mode))
+        self.device = torch.device(device if device is not None else 'cuda')
+        self.arch, self.loss_type, self.rep_weights = architecture, loss_type, tuple(rep_weights)
+        self.lr_d, self.lr_g = float(lr_list[0]), float(lr_list[1])
+        self.B, self.sn_mode = int(batch_size), sn_mode
+        self.code_size = architecture['code'][0][0]
+        self.in_shape_ref = list(architecture['input'][0])
+        rng = np.random.RandomState(seed)
+        self.gen = _Net(architecture['generator'], [self.code_size], 'gen', self.device, rng, sn_mode)
+        self.dis = _Net(architecture['discriminator'], self.in_shape_ref, 'dis', self.device, rng, sn_mode)
+        assert self.gen.shapes[self.gen.out_val] == self.in_shape_ref, \
+            'generator output {} does not match the input shape {}'.format(self.gen.shapes[self.gen.out_val], self.in_shape_ref)
+        assert len(self.dis.shapes[self.dis.out_val]) == 1, 'the discriminator must end in a score vector'
+        if any(k.sn for k in self.gen.kernels):
+            raise NotImplementedError('spectral norm in the generator is not built')
+        self.score_size = self.dis.shapes[self.dis.out_val][0]
+        self.global_step = 0
+        self.dist_group, self.world = dist_group, 1
+        if dist_group is not None:
+            import torch.distributed as tdist
+            self.world = tdist.get_world_size(dist_group)
+        self._dp_force = os.environ.get('MMDGAN_DP_FORCE') == '1'
+        self.use_graph = False                                           # eager issue only
+        if ops._workspace is None:
+            ops.set_workspace(device=self.device)
+        self.losses = torch.zeros(8, device=self.device)
+        self._static_z = torch.zeros(self.B, self.code_size, device=self.device)
+        self._static_real = torch.zeros(_native(self.in_shape_ref, self.B), device=self.device)
+        self._dis_in = torch.zeros(_native(self.in_shape_ref, 2 * self.B), device=self.device)
+        self._mmd_grads = torch.zeros(4, self.B, self.score_size, device=self.device)
+        self._bufs = {}
+        self._d_has_bn = bool(self.dis.bns)
+        lib = ops.require_device()
+        self._mmd_ws = torch.zeros(max(lib.mmdgan_mmd_workspace_bytes(self.B, self.score_size), 64), device=self.device,
+                                   dtype=torch.uint8)
+
+    # ---- buffers ----------------------------------------------------------------------------------------------
+    def _buf(self, key, shape, zero=False):
+        t = self._bufs.get(key)
+        if t is None or list(t.shape) != list(shape):
+            t = torch.zeros(list(shape), device=self.device)
+            self._bufs[key] = t
+        elif zero:
+            t.zero_()
+        return t
+
+    # ---- spectral norm (math_func.py:661-672), as engine.py:_sn_step -------------------------------------------
+    def _sn_step(self, net, k):
+        st = net.sn[k.scope]
+        w, x = net.p(k.w_name), net.state[k.scope + '/SN/in_rand']
+        sigma, scale, dsig, u, un, xb, xbn = st['sigma'], st['scale'], st['dsigma'], st['u'], st['un'], st['xb'], st['xbn']
+        if k.op == 'd' or k.pim:
+            if k.pim:
+                w, dsig = w.view(-1, k.out), dsig.view(-1, k.out)
+            if 1 in w.shape:                                             # math_func.py:702-704
+                ops.sn_norm_scale(w.reshape(-1), k.act_k, sigma, scale, dsig.view(-1))
+            elif k.use_u:
+                ops.gemm(x, w, out=u)
+                ops.sn_norm_scale(u.view(-1), k.act_k, sigma, scale, un.view(-1))
+                ops.gemm(x, un, trans_a=True, out=dsig)
+                ops.gemm(un, w, trans_b=True, out=xb)
+                ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
+            else:
+                ops.gemm(x, w, trans_b=True, out=u)
+                ops.sn_norm_scale(u.view(-1), k.act_k, sigma, scale, un.view(-1))
+                ops.gemm(un, x, trans_a=True, out=dsig)
+                ops.gemm(un, w, out=xb)
+                ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
+        else:
+            h, wd = k.in_ref[1], k.in_ref[2]
+            if k.use_u:
+                ops.conv2d_fwd(x, w, k.stride, out=u)
+                ops.sn_norm_scale(u.view(-1), k.act_k, sigma, scale, un.view(-1))
+                ops.conv2d_wgrad(x, un, k.R, k.stride, out=dsig)
+                ops.conv2d_dgrad(un, w, (h, wd), k.stride, out=xb)
+                ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
+            else:
+                ops.conv2d_dgrad(x, w, (h, wd), k.stride, out=u)
+                ops.sn_norm_scale(u.view(-1), k.act_k, sigma, scale, un.view(-1))
+                ops.conv2d_wgrad(un, x, k.R, k.stride, out=dsig)
+                ops.conv2d_fwd(un, w, k.stride, out=xb)
+                ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
+        return scale
+
+    # ---- forward ----------------------------------------------------------------------------------------------
+    def _forward(self, net, x, training, tag):
+        """runs the net's primitives; returns the value table (kept for the backward pass when training)"""
+        n = x.shape[0]
+        vals = {0: x}
+        lib = ops.require_device()
+        for i, p in enumerate(net.prims):
+            kind, a = p['kind'], vals[p['ins'][0]]
+            key = (tag, net.name, i)
+            out_shape = _native(net.shapes[p['out']], n)
+            if kind == 'reshape':
+                y = a.reshape(out_shape)
+            elif kind in ('dense', 'conv'):
+                k = p['k']
+                scale = net.sn[k.scope]['scale'] if k.sn else None
+                bias = net.p(k.bias_name) if k.bias_name is not None else None
+                y = self._buf(key, out_shape)
+                if kind == 'dense':
+                    ops.gemm(a.reshape(n, -1), net.p(k.w_name), bias=bias, scale=scale, out=y)
+                else:
+                    ops.conv2d_fwd(a, net.p(k.w_name), k.stride, bias=bias, scale=scale, out=y)
+            elif kind == 'bn':
+                y = self._buf(key, out_shape)
+                c = out_shape[-1]
+                pre = p['prefix']
+                gamma, beta = net.p(pre + '/BN/gamma'), net.p(pre + '/BN/beta')
+                mm, mv = net.state[pre + '/BN/moving_mean'], net.state[pre + '/BN/moving_variance']
+                x2, y2 = a.reshape(-1, c), y.view(-1, c)
+                if training:
+                    mean, invstd = self._buf(key + ('mean',), [c]), self._buf(key + ('invstd',), [c])
+                    ws = self._buf(key + ('ws',), [max(lib.mmdgan_bn_workspace_bytes(c) // 4, 4)])
+                    p['_saved'] = (mean, invstd)
+                    ops.check(lib.mmdgan_bn_fwd_train(
+                        x2.data_ptr(), x2.shape[0], c, gamma.data_ptr(), beta.data_ptr(), 1e-3, 0.99, int(a.dim() == 4),
+                        ops.act_id(p['act']), y2.data_ptr(), mean.data_ptr(), invstd.data_ptr(), mm.data_ptr(),
+                        mv.data_ptr(), mm.data_ptr(), mv.data_ptr(), ws.data_ptr(), ops._stream()), 'bn_fwd_train')
+                else:
+                    ops.check(lib.mmdgan_bn_fwd_infer(
+                        x2.data_ptr(), x2.shape[0], c, gamma.data_ptr(), beta.data_ptr(), 1e-3, ops.act_id(p['act']),
+                        mm.data_ptr(), mv.data_ptr(), y2.data_ptr(), ops._stream()), 'bn_fwd_infer')
+            elif kind == 'act':
+                y = ops.act_fwd(a, p['act'], out=self._buf(key, out_shape))
+            elif kind == 'down':
+                y = ops.resample_down(a, p['f'], out=self._buf(key, out_shape))
+            elif kind == 'up':
+                y = ops.resample_up(a, p['f'], out=self._buf(key, out_shape))
+            elif kind == 'add':
+                y = ops.axpby(a, vals[p['ins'][1]], out=self._buf(key, out_shape))
+            else:
+                raise AssertionError(kind)
+            vals[p['out']] = y
+        return vals
+
+    # ---- backward ---------------------------------------------------------------------------------------------
+    def _backward(self, net, vals, dout, tag, rows=None, param_grads=True, need_input_grad=False):
+        """gradients of one scalar through the net.  rows = (lo, hi): only those batch rows carry gradient (the
+        loss_gen pass through D touches the fake half only); parameter gradients are then not formed."""
+        lib = ops.require_device()
+        lo, hi = rows if rows is not None else (0, vals[0].shape[0])
+        n = hi - lo
+        sl = (lambda t: t[lo:hi]) if rows is not None else (lambda t: t)
+        grads = {net.out_val: dout}
+
+        def give(v, g):
+            # fan-in: a value with two consumers sums their gradients.  The sum goes to a buffer of its own - the
+            # first gradient may be shared with another value (both inputs of an add receive the same tensor)
+            if v in grads:
+                acc = self._buf((tag, net.name, 'acc', v), list(g.shape))
+                ops.axpby(grads[v], g, out=acc)
+                grads[v] = acc
+            else:
+                grads[v] = g
+        for i in range(len(net.prims) - 1, -1, -1):
+            p = net.prims[i]
+            if p['out'] not in grads:
+                continue
+            kind, dy = p['kind'], grads.pop(p['out'])
+            vin = p['ins'][0]
+            if vin == 0 and not need_input_grad and kind not in ('dense', 'conv', 'bn'):
+                continue
+            key = (tag, net.name, i, 'd')
+            a = sl(vals[vin])
+            in_shape = list(a.shape)
+            want_dx = vin != 0 or need_input_grad
+            if kind == 'reshape':
+                give(vin, dy.reshape(in_shape))
+            elif kind in ('dense', 'conv'):
+                k = p['k']
+                w = net.p(k.w_name)
+                scale = net.sn[k.scope]['scale'] if k.sn else None
+                if param_grads:
+                    gw = net.g(k.w_name)
+                    gb = net.g(k.bias_name) if k.bias_name is not None else None
+                    if kind == 'dense':
+                        if gb is not None:
+                            ops.colsum(dy.reshape(n, -1), out=gb)
+                        ops.gemm(a.reshape(n, -1), dy.reshape(n, -1), trans_a=True, out=gw)
+                    else:
+                        ops.conv2d_wgrad(a, dy, k.R, k.stride, out=gw, dbias=gb)
+                    if k.sn:                                             # SURVEY A.2 fix-up
+                        st = net.sn[k.scope]
+                        ops.dot(gw.view(-1), w.view(-1), out=st['dot'])
+                        ops.sn_wgrad_fixup(gw.view(-1), st['dsigma'].view(-1), st['dot'], st['sigma'], scale)
+                if want_dx:
+                    dx = self._buf(key, in_shape)
+                    if kind == 'dense':
+                        ops.gemm(dy.reshape(n, -1), w, trans_b=True, scale=scale, out=dx.view(n, -1))
+                    else:
+                        ops.conv2d_dgrad(dy, w, (in_shape[1], in_shape[2]), k.stride, scale=scale, out=dx)
+                    give(vin, dx)
+            elif kind == 'bn':
+                if rows is not None:
+                    raise NotImplementedError('a row-restricted backward pass cannot cross batch norm')
+                c = in_shape[-1]
+                pre = p['prefix']
+                mean, invstd = p['_saved']
+                dx = self._buf(key, in_shape)
+                ws = self._buf(key + ('ws',), [max(lib.mmdgan_bn_workspace_bytes(c) // 4, 4)])
+                y = vals[p['out']]
+                gg = net.g(pre + '/BN/gamma') if param_grads else self._buf(key + ('gg',), [c])
+                gb = net.g(pre + '/BN/beta') if param_grads else self._buf(key + ('gb',), [c])
+                ops.check(lib.mmdgan_bn_bwd(
+                    a.data_ptr(), y.data_ptr(), dy.data_ptr(), a.numel() // c, c, net.p(pre + '/BN/gamma').data_ptr(),
+                    mean.data_ptr(), invstd.data_ptr(), ops.act_id(p['act']), dx.data_ptr(), gg.data_ptr(), gb.data_ptr(),
+                    ws.data_ptr(), ops._stream()), 'bn_bwd')
+                if want_dx:
+                    give(vin, dx)
+            elif kind == 'act':
+                give(vin, ops.act_bwd(dy, sl(vals[p['out']]), p['act'], out=self._buf(key, in_shape)))
+            elif kind == 'down':                                         # d avg-pool: spread over the window
+                f = p['f']
+                give(vin, ops.resample_up(dy, f, scale=1.0 / (f * f), out=self._buf(key, in_shape)))
+            elif kind == 'up':                                           # d unpool: sum over the window
+                give(vin, ops.resample_down(dy, p['f'], scale=1.0, out=self._buf(key, in_shape)))
+            elif kind == 'add':
+                give(vin, dy)
+                give(p['ins'][1], dy)
+            else:
+                raise AssertionError(kind)
+        return grads.get(0)
+
+    # ---- one training step -----------------------------------------------------------------------------------
+    def generate(self, z, is_training=False):
+        vals = self._forward(self.gen, z, is_training, 'gen%d' % z.shape[0])
+        return vals[self.gen.out_val]
+
+    def _allreduce(self, net):
+        if self.dist_group is None or (self.world == 1 and not self._dp_force):
+            return
+        from . import dist as mdist
+        mdist.allreduce_sum_(net.grads, self.dist_group)                 # blocking collectives, current stream
+
+    def step(self, real_nhwc=None, z=None):
+        B = self.B
+        if z is None:
+            self._static_z.normal_()                                     # my_sngan.py:123-124
+        else:
+            self._static_z.copy_(z)
+        if real_nhwc is not None:
+            self._static_real.copy_(real_nhwc)
+        gvals = self._forward(self.gen, self._static_z, True, 'g')
+        self._dis_in[:B].copy_(self._static_real)                        # my_sngan.py:278: D sees [real ; fake]
+        self._dis_in[B:].copy_(gvals[self.gen.out_val])
+        for k in self.dis.kernels:
+            if k.sn:
+                self._sn_step(self.dis, k)
+        dvals = self._forward(self.dis, self._dis_in, True, 'd')
+        scores = dvals[self.dis.out_val]                                 # [2B, d]: s_x = [:B], s_gen = [B:]
+        lib = ops.require_device()
+        ops.check(lib.mmdgan_mmd_loss(scores[B:].data_ptr(), scores[:B].data_ptr(), B, self.score_size,
+                                      ops.LOSS[self.loss_type] | 0x100, self.rep_weights[0], self.rep_weights[1], 0.25,
+                                      4.0, self.losses.data_ptr(), self._mmd_grads.data_ptr(), None, None,
+                                      self._mmd_ws.data_ptr(), ops._stream()), 'mmd_loss')
+        self.gen.grads.zero_()
+        self.dis.grads.zero_()
+        ds = self._mmd_grads.view(4 * B, -1)        # [dLd/ds_x ; dLd/ds_gen ; dLg/ds_gen ; dLg/ds_x]
+        self._backward(self.dis, dvals, ds[:2 * B], 'bd', param_grads=True)
+        self._allreduce(self.dis)
+        if self._d_has_bn:                          # batch statistics couple the rows: full pass, zero on the real half
+            dg = self._buf('dg_full', [2 * B, self.score_size], zero=True)
+            dg[B:].copy_(ds[2 * B:3 * B])
+            d_in = self._backward(self.dis, dvals, dg, 'bg', param_grads=False, need_input_grad=True)[B:]
+        else:
+            d_in = self._backward(self.dis, dvals, ds[2 * B:3 * B], 'bg', rows=(B, 2 * B), param_grads=False,
+                                  need_input_grad=True)
+        self._backward(self.gen, gvals, d_in.contiguous(), 'gb', param_grads=True)
+        self._allreduce(self.gen)
+        gs = 1.0 / self.world
+        self.dis.opt.step(self.lr_d, grad_scale=gs)
+        self.gen.opt.step(self.lr_g, grad_scale=gs)
+        self.global_step += 1
+
+    # ---- variables / checkpoints (reference names and layouts) -------------------------------------------------
+    def _net_of(self, name):
+        return self.gen if name.startswith('gen/') else self.dis
+
+    def variable_names(self, trainable_only=False):
+        return self.gen.variable_names(trainable_only) + self.dis.variable_names(trainable_only)
+
+    def set_variables(self, values):
+        for k, v in values.items():
+            self._net_of(k).set_variable(k, v)
+
+    def get_variables(self, names=None, grad=False):
+        names = names if names is not None else self.variable_names(trainable_only=grad)
+        return OrderedDict((k, self._net_of(k).get_variable(k, grad=grad)) for k in names)
+
+    def sigmas(self):
+        """spectral norms of the last step, keyed like the reference's op scopes (<layer> for a plain layer's
+        kernel, <layer>/kernel_0 ... inside a block)"""
+        out = OrderedDict()
+        for k in self.dis.kernels:
+            if k.sn:
+                scope = k.scope[:-len('/kernel')] if k.scope.endswith('/kernel') else k.scope
+                out[scope] = float(self.dis.sn[k.scope]['sigma'].item())
+        return out
+
+    def state_dict(self):
+        sd = {'global_step': self.global_step, 'variables': self.get_variables()}
+        for tag, net in (('gen', self.gen), ('dis', self.dis)):
+            sd[tag + '/adam_m'], sd[tag + '/adam_v'] = net.adam_m.cpu(), net.adam_v.cpu()
+            sd[tag + '/adam_t'] = int(net.opt.step_counter.item())
+        return sd
+
+    def load_state_dict(self, sd):
+        self.set_variables(sd['variables'])
+        self.global_step = int(sd['global_step'])
+        for tag, net in (('gen', self.gen), ('dis', self.dis)):
+            net.adam_m.copy_(sd[tag + '/adam_m'])
+            net.adam_v.copy_(sd[tag + '/adam_v'])
+            net.opt.step_counter.fill_(int(sd[tag + '/adam_t']))

@@ -1,0 +1,188 @@
+"""Residual-block architectures on the GPU: the primitive-op engine against (a) the 3-step fixture
+the reference's own code produced for a tiny ResNet-SN pair and (b) the fp64 oracle on a wider one whose channel
+counts reach the MFMA / Winograd conv kernels."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import RTOL, golden, load
+from oracle import restatement as R
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
+from tiny_arch import tiny_res_architecture  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def nhwc(a):
+    return torch.as_tensor(np.ascontiguousarray(np.transpose(a, (0, 2, 3, 1)))).cuda()
+
+
+def close(got, ref, rtol, floor):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    return np.max(np.abs(got - ref)) <= rtol * np.max(np.abs(ref)) + floor
+
+
+@pytest.mark.parametrize('sn_mode', ['default'])
+def test_res_step_matches_reference_golden(sn_mode):
+    from mmdgan_hip.tape import TapeEngine
+    fx = load(golden('step_tiny_res_rep.npz')[0])
+    B = int(fx['B'])
+    eng = TapeEngine(tiny_res_architecture(), 'rep', tuple(fx['lr']), batch_size=B, sn_mode=sn_mode)
+    init = {k[len('init/'):]: v for k, v in fx.items() if k.startswith('init/')}
+    assert sorted(init) == sorted(eng.variable_names())              # the reference's variable names, all of them
+    eng.set_variables(init)
+    back = eng.get_variables()
+    for k, v in init.items():                                        # layout round trip (NCHW <-> NHWC seams)
+        assert np.array_equal(back[k], v), k
+    n_steps = fx['z'].shape[0]
+    for step in range(n_steps):
+        eng.step(nhwc(fx['real'][step]), torch.as_tensor(fx['z'][step]).cuda())
+        pre = 'step%d/' % step
+        losses = eng.losses.cpu().numpy().astype(np.float64)
+        escale = float(max(losses[2:5]))
+        for idx, name in ((0, 'loss_gen'), (1, 'loss_dis')):
+            ref = float(fx[pre + name + '_f64'])
+            assert abs(losses[idx] - ref) <= RTOL * abs(ref) + 4e-7 * escale, (step, name, losses[idx], ref)
+        sig = eng.sigmas()
+        for k, v in fx.items():                                      # spectral norm of every kernel of every block
+            if k.startswith(pre + 'sigma/') and k.endswith('_f64'):
+                scope = k[len(pre + 'sigma/'):-len('_f64')]
+                assert abs(sig[scope] - float(v)) <= RTOL * float(v), (step, scope)
+        if step in (0, n_steps - 1):                                 # gradients of the first and the last step
+            grads = eng.get_variables(grad=True)
+            gscale = {net: max(np.abs(fx[pre + 'grad/' + n + '_f64']).max() for n in grads if n.startswith(net))
+                      for net in ('gen', 'dis')}
+            for n, g in grads.items():
+                ref = fx[pre + 'grad/' + n + '_f64']
+                # floor: biases behind which only score DIFFERENCES matter (the last block's bias_1, the dense bias)
+                # have an analytically zero gradient; what is left is rounding, ~3e-6 of the net's gradient scale
+                assert close(g, ref, RTOL, 1e-5 * gscale[n[:3]]), (step, n, np.abs(g - ref).max(), np.abs(ref).max())
+    final = eng.get_variables()
+    # variables whose gradient is analytically zero - a bias in front of a batch norm (the G blocks' bias_sc feeds the
+    # next block's BN_0), biases behind which only score differences matter: what every implementation, the reference
+    # included, feeds Adam there is rounding noise, which Adam normalises into +-lr-sized steps.  Bounded, not compared.
+    pre = 'step%d/' % (n_steps - 1)
+    gsc = {net: max(np.abs(fx[pre + 'grad/' + n + '_f64']).max() for n in final if (pre + 'grad/' + n + '_f64') in fx
+                    and n.startswith(net)) for net in ('gen', 'dis')}
+    noise = {n for n in final if (pre + 'grad/' + n + '_f64') in fx
+             and np.abs(fx[pre + 'grad/' + n + '_f64']).max() <= 1e-5 * gsc[n[:3]]}
+    assert {'dis/l4_s/bias/bias', 'dis/l3_res/bias_1/bias', 'gen/l2_res/bias_sc/bias'} <= noise and len(noise) <= 8, noise
+    for n, v in final.items():
+        if n in noise:
+            assert np.abs(v - fx['init/' + n]).max() <= 3.5 * float(fx['lr'].max()), n
+            continue
+        ref = fx['final/' + n + '_f64']
+        # the step-0 gradients of this net are ~1e-9: single entries sit at Adam's eps, where rounding moves the update
+        # by a few % of lr - elementwise at 6% of one lr step, and the whole 3-step update at 1% in L2
+        assert close(v, ref, RTOL, 0.06 * float(fx['lr'].max())), (n, np.abs(v - ref).max(), np.abs(ref).max())
+        if not (n.endswith('in_rand') or '/moving_' in n):
+            du, dr = v.astype(np.float64) - fx['init/' + n], ref.astype(np.float64) - fx['init/' + n]
+            assert np.linalg.norm(du - dr) <= 0.01 * np.linalg.norm(dr) + 1e-12, n
+
+
+def mid_res_architecture():
+    """channel counts that are tile multiples: the MFMA implicit-GEMM and Winograd kernels carry the 3x3 convs"""
+    ak = float(np.power(64.0, 0.125))
+    k = [3, 3, 1]
+    return {'input': [(3, 32, 32)], 'code': [(64, 'linear')],
+            'generator': [{'name': 'l1', 'out': 128 * 4 * 4, 'op': 'd', 'out_reshape': [128, 4, 4]},
+                          {'name': 'l2', 'type': 'res', 'out': 128, 'act': 'relu', 'act_nm': 'bn', 'kernel': k, 'scale': ['unpool', 2]},
+                          {'name': 'l3', 'type': 'res', 'out': 64, 'act': 'relu', 'act_nm': 'bn', 'kernel': k, 'scale': ['unpool', 2]},
+                          {'name': 'l4', 'type': 'res', 'out': 64, 'act': 'relu', 'act_nm': 'bn', 'kernel': k, 'scale': ['unpool', 2]},
+                          {'name': 'l5', 'op': 'i', 'act': 'relu', 'act_nm': 'bn'},
+                          {'name': 'l6', 'out': 3, 'act': 'tanh'}],
+            'discriminator': [{'name': 'l1', 'type': 'res_v1', 'out': 64, 'act': 'relu', 'act_k': ak, 'w_nm': 's', 'kernel': k, 'scale': ['avg', -2]},
+                              {'name': 'l2', 'type': 'res', 'out': 128, 'act': 'relu', 'act_k': ak, 'w_nm': 's', 'kernel': k, 'scale': ['avg', -2]},
+                              {'name': 'l3', 'type': 'res', 'out': 128, 'act': 'lrelu', 'act_k': ak, 'w_nm': 's', 'kernel': k, 'scale': ['avg', -2]},
+                              {'name': 'l4', 'type': 'res_i', 'out': 128, 'act': 'relu', 'act_k': ak, 'w_nm': 's', 'out_reshape': [4 * 4 * 128]},
+                              {'name': 'l5', 'out': 16, 'op': 'd', 'act_k': ak, 'w_nm': 's'}]}
+
+
+@pytest.mark.parametrize('loss_type,sn_mode', [('rep', 'default'), ('rmb', 'sn_paper')])
+def test_res_step_matches_oracle_on_mfma_sized_blocks(loss_type, sn_mode):
+    from mmdgan_hip.tape import TapeEngine
+    arch, B = mid_res_architecture(), 16
+    eng = TapeEngine(arch, loss_type, (5e-4, 2e-4), batch_size=B, seed=3, sn_mode=sn_mode)
+    ora = R.OracleGan(arch, loss_type, (5e-4, 2e-4), dtype=torch.float64, params=eng.get_variables(), sn_mode=sn_mode)
+    rs = np.random.RandomState(42)
+    last_bias = 'dis/l5/bias/bias'
+    for step in range(3):
+        z = rs.randn(B, 64).astype(np.float32)
+        real = rs.uniform(-1, 1, (B, 3, 32, 32)).astype(np.float32)
+        prev_vars = {k: v.numpy().copy() for k, v in ora.params.items()}
+        eng.set_variables(prev_vars)                                 # see test_step_gpu.py: re-synchronise each step
+        zt, rt = torch.tensor(z, dtype=torch.float64), torch.tensor(real, dtype=torch.float64)
+        lg, ld, stats, upd, gd, gg, (gen, s_x, s_gen) = ora.grads(zt, rt)
+        ora.step(zt, rt)
+        eng.step(nhwc(real), torch.as_tensor(z).cuda())
+        losses = eng.losses.cpu().numpy().astype(np.float64)
+        escale = float(max(losses[2:5]))
+        assert abs(losses[0] - float(lg)) <= RTOL * abs(float(lg)) + 1e-5 * escale, (step, losses[0], float(lg))
+        assert abs(losses[1] - float(ld)) <= RTOL * abs(float(ld)) + 1e-5 * escale, (step, losses[1], float(ld))
+        if step == 0:
+            continue                                     # un-normalised SN start vectors: step-0 gradients of the
+        #                                                  residual branches are below fp32 rounding
+        grads = eng.get_variables(grad=True)
+        ref_g = dict(gd)
+        ref_g.update(gg)
+        # analytically zero gradients: a bias whose only consumer is a batch norm (G's bias_sc feed the next block's
+        # BN_0 / the identity layer's BN), and biases behind which only score differences matter (D's last two)
+        noise = {last_bias, 'dis/l4/bias_1/bias', 'gen/l2/bias_sc/bias', 'gen/l3/bias_sc/bias', 'gen/l4/bias_sc/bias'}
+        for net in ('gen', 'dis'):
+            gscale = max(float(ref_g[n].abs().max()) for n in grads if n.startswith(net))
+            for n in grads:
+                if not n.startswith(net):
+                    continue
+                r = ref_g[n].numpy()
+                if n in noise:
+                    assert np.abs(r).max() <= 1e-9 * gscale and np.abs(grads[n]).max() <= 1e-4 * gscale, (step, n)
+                    continue
+                l2 = np.linalg.norm(grads[n].astype(np.float64) - r) / (np.linalg.norm(r) + 1e-6 * gscale)
+                assert l2 <= 5e-3, (step, n, l2)
+        final = eng.get_variables()
+        for n, v in final.items():
+            if n in noise:
+                continue
+            ref = ora.params[n].numpy()
+            if n.endswith('in_rand') or '/moving_' in n:
+                assert close(v, ref, RTOL, 0.0), (step, n)
+            else:
+                before = prev_vars[n]
+                du, dr = v.astype(np.float64) - before, ref - before
+                assert np.linalg.norm(du - dr) <= 0.1 * np.linalg.norm(dr) + 1e-12, (step, n)
+
+
+def test_res_inference_and_api_selection(tmp_path):
+    """SNGan picks the primitive-op engine for an architecture with blocks; eval_sampling runs it in inference mode"""
+    from DeepLearning.my_sngan import SNGan
+    from GeneralTools.graph_func import Agent
+    from GeneralTools.misc_fun import FLAGS
+    from mmdgan_hip.tape import TapeEngine
+    FLAGS.DEFAULT_OUT = str(tmp_path) + '/'
+    FLAGS.SYNTHETIC_DATA, FLAGS.SILENT_MODE = True, True
+    try:
+        arch = tiny_res_architecture()
+        mdl = SNGan(arch, num_class=0, loss_type='rep', optimizer='adam')
+        agent = Agent('toy', 'res', load_ckpt=False, do_save=True, query_step=2)
+        mdl.training('toy', agent, 8 * 3, (5e-4, 2e-4), max_step=5, batch_size=8)
+        assert isinstance(mdl.engine, TapeEngine) and mdl.global_step == 5
+        code = np.random.RandomState(0).randn(6, 24).astype(np.float32)
+        x = mdl.eval_sampling('toy', 'res', mesh_num=(2, 3), code_x=code)
+        var = mdl.engine.get_variables()
+        specs = R.build_net(arch['generator'], [24], 'gen')
+        params = {k: torch.tensor(v, dtype=torch.float64) for k, v in var.items() if k.startswith('gen/')}
+        ref, _ = R.net_forward(specs, params, torch.tensor(code, dtype=torch.float64), False)
+        assert close(x, ref.clamp(-1, 1).numpy(), RTOL, 0.0)
+        # checkpoint round trip through the Agent
+        agent2 = Agent('toy', 'res', load_ckpt=True, do_save=False, query_step=None)
+        mdl2 = SNGan(arch, num_class=0, loss_type='rep', optimizer='adam')
+        mdl2.init_net((5e-4, 2e-4), 8)
+        assert agent2.load(mdl2.engine) and mdl2.engine.global_step == 5
+        for k, v in mdl2.engine.get_variables().items():
+            assert np.array_equal(v, var[k]), k
+    finally:
+        FLAGS.SYNTHETIC_DATA, FLAGS.SILENT_MODE = False, False
