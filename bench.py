@@ -33,8 +33,8 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--config', default='cifar', choices=['cifar', 'stl', 'celeba'])
-    ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: 64; 128 for celeba)')
+    ap.add_argument('--config', default='cifar', choices=['cifar', 'stl', 'celeba', 'lsun_resnet'])
+    ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: 64; 128 for celeba; 32 for lsun_resnet = 256 on 8 GPUs)')
     ap.add_argument('--loss', default='rep', choices=['rep', 'rmb'])
     ap.add_argument('--no-graph', action='store_true', help='issue launches eagerly instead of one hipGraph')
     ap.add_argument('--graph', action='store_true', help='always replay the captured hipGraph (default: try both during '
@@ -122,7 +122,12 @@ def main():
     import configs
     from mmdgan_hip.engine import GanEngine
     arch, lr = configs.CONFIGS[args.config]()
-    B = args.batch or (128 if args.config == 'celeba' else 64)
+    B = args.batch or {'celeba': 128, 'lsun_resnet': 32}.get(args.config, 64)
+    from mmdgan_hip.tape import TapeEngine, has_residual_blocks
+    tape = has_residual_blocks(arch)                     # residual blocks: the primitive-op engine, eager issue only
+    if tape:
+        GanEngine = TapeEngine                           # noqa: F811
+        args.no_graph = True
     # the engine starts in eager mode (its lazily-created buffers are then allocated on the stream that uses
     # them); the hipGraph, if wanted, is captured after the warm-up steps
     eng = GanEngine(arch, args.loss, lr, batch_size=B, seed=0, dist_group=group, use_graph=False)
@@ -199,15 +204,15 @@ def main():
             'value': B * world * args.steps / dt, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': '%s %dx%d DCGAN-SN, batch %d per GPU, %s loss, lr %g/%g, TF-Adam, one G+D step'
-                                   % (args.config, h, w, B, args.loss, lr[0], lr[1]),
+            'config': {'workload': '%s %dx%d %s, batch %d per GPU, %s loss, lr %g/%g, TF-Adam, one G+D step'
+                                   % (args.config, h, w, 'ResNet-SN' if tape else 'DCGAN-SN', B, args.loss, lr[0], lr[1]),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world, 'launch_mode': mode},
             'loss_gen': float(losses[0]), 'loss_dis': float(losses[1]),
         }
         whole = {'achieved': achieved, 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
                  'scope': 'whole step: B*(3*F_G+7*F_D) = %.1f GFLOP algorithmic over the HIP-event step time %.3f ms'
                           % (flops_step / 1e9, ev_ms)}
-        probe = dominant_kernel_probe(eng, reps=args.probe_reps)
+        probe = None if tape else dominant_kernel_probe(eng, reps=args.probe_reps)
         if probe:
             # the roofline object is about the dominant kernel (HIP-event time of its launches, algorithmic FLOPs);
             # the whole-step figure - the more conservative one - rides along
@@ -223,7 +228,7 @@ def main():
         else:
             out['roofline'] = dict(whole, bound='mfma', peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s', traffic=None)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(arch, lr, args.loss, B, args.cpu_steps)
+            out['cpu_baseline'] = cpu_baseline(arch, lr, args.loss, B, 1 if tape else args.cpu_steps)
         print(json.dumps(out))
     if group is not None:
         import torch.distributed as dist
