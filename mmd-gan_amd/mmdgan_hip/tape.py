@@ -429,8 +429,55 @@ class TapeEngine:
         self._dis_in = torch.zeros(_native(self.in_shape_ref, 2 * self.B), device=self.device)
         self._mmd_grads = torch.zeros(4, self.B, self.score_size, device=self.device)
         self._bufs = {}
+        self._in_step = False                                            # transformed weights are valid inside step() only
         self._d_has_bn = bool(self.dis.bns)
         lib = ops.require_device()
+        # side streams on hardware queues of their own (streams.py): the power iterations run under G's forward pass,
+        # weight / bias gradients beside the input-gradient chain; MMDGAN_TAPE_STREAMS=0 keeps everything on one stream
+        self._side = os.environ.get('MMDGAN_TAPE_STREAMS', '1') != '0'
+        if self._side:
+            from .streams import distinct_queue_streams
+            self._wg_stream, self._sn_stream = distinct_queue_streams(2, self.device)
+            self._gen_ready, self._dis_ready = torch.cuda.Event(), torch.cuda.Event()
+        # Winograd-eligible convolutions get their weights transformed once per step, off the critical path, instead
+        # of inside every call (forward, and up to two input-gradient passes) - which also keeps the library's
+        # shared workspace out of every launch of the main stream.  kernel scope -> {(dgrad, batch): tensor}
+        self._wino = {}
+        rows_d = (2 * self.B,) if self._d_has_bn else (2 * self.B, self.B)
+        for net, batches in ((self.gen, (self.B,)), (self.dis, rows_d)):
+            for k in net.kernels:
+                if k.op != 'c' or not self._side:
+                    continue
+                c, h, w = k.in_ref
+                table = {}
+                for dgrad in (False, True):
+                    u = None
+                    for n in batches:
+                        if (not dgrad and n != batches[0]) or not ops.wino_eligible(n, h, w, c, k.out, k.R, k.stride, dgrad):
+                            continue
+                        if u is None:
+                            lead = (16,) if k.R == 3 else (4, 9)
+                            u = torch.empty(lead + ((k.out, c) if dgrad else (c, k.out)), device=self.device)
+                        table[(dgrad, n)] = u
+                if table:
+                    self._wino[k.scope] = (net, k, table)
+        # everything the backward pass accumulates into with atomics and that is not a gradient arena: one flat
+        # scratch, zeroed once per step (the backward pass runs with mmdgan_set_outputs_prezeroed(1))
+        sizes = []
+        for net in (self.gen, self.dis):
+            for k in net.kernels:
+                if k.sn:
+                    sizes.append((net.sn[k.scope], 'dot', 4))
+            for i, p in enumerate(net.prims):
+                if p['kind'] == 'bn':
+                    c = net.shapes[p['out']][0]
+                    sizes.append((p, '_ws_bwd', max(lib.mmdgan_bn_workspace_bytes(c) // 4, 4)))
+        total = sum((n + 3) // 4 * 4 for _, _, n in sizes)
+        self._zero_scratch = torch.zeros(max(total, 4), device=self.device)
+        off = 0
+        for holder, key, n in sizes:
+            holder[key] = self._zero_scratch[off:off + n]
+            off += (n + 3) // 4 * 4
         self._mmd_ws = torch.zeros(max(lib.mmdgan_mmd_workspace_bytes(self.B, self.score_size), 64), device=self.device,
                                    dtype=torch.uint8)
 
@@ -502,7 +549,8 @@ class TapeEngine:
                 if kind == 'dense':
                     ops.gemm(a.reshape(n, -1), net.p(k.w_name), bias=bias, scale=scale, out=y)
                 else:
-                    ops.conv2d_fwd(a, net.p(k.w_name), k.stride, bias=bias, scale=scale, out=y)
+                    ops.conv2d_fwd(a, net.p(k.w_name), k.stride, bias=bias, scale=scale, out=y,
+                                   wino=self._wino_of(k, False, n) if (training and self._in_step) else None)
             elif kind == 'bn':
                 y = self._buf(key, out_shape)
                 c = out_shape[-1]
@@ -573,24 +621,34 @@ class TapeEngine:
                 w = net.p(k.w_name)
                 scale = net.sn[k.scope]['scale'] if k.sn else None
                 if param_grads:
-                    gw = net.g(k.w_name)
-                    gb = net.g(k.bias_name) if k.bias_name is not None else None
-                    if kind == 'dense':
-                        if gb is not None:
-                            ops.colsum(dy.reshape(n, -1), out=gb)
-                        ops.gemm(a.reshape(n, -1), dy.reshape(n, -1), trans_a=True, out=gw)
+                    def param_grads_of(k=k, kind=kind, a=a, dy=dy, w=w, scale=scale):
+                        gw = net.g(k.w_name)
+                        gb = net.g(k.bias_name) if k.bias_name is not None else None
+                        if kind == 'dense':
+                            if gb is not None:
+                                ops.colsum(dy.reshape(n, -1), out=gb)
+                            ops.gemm(a.reshape(n, -1), dy.reshape(n, -1), trans_a=True, out=gw)
+                        else:
+                            ops.conv2d_wgrad(a, dy, k.R, k.stride, out=gw, dbias=gb)
+                        if k.sn:                                         # SURVEY A.2 fix-up
+                            st = net.sn[k.scope]
+                            ops.dot(gw.view(-1), w.view(-1), out=st['dot'])
+                            ops.sn_wgrad_fixup(gw.view(-1), st['dsigma'].view(-1), st['dot'], st['sigma'], scale)
+                    # kernels that use the library's shared workspace (thin first / last layers) stay on this stream
+                    thin = kind == 'conv' and (k.kernel_shape[2] % 64 or k.kernel_shape[3] % 64)
+                    if self._side and not thin:
+                        self._wg_stream.wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(self._wg_stream):
+                            param_grads_of()
                     else:
-                        ops.conv2d_wgrad(a, dy, k.R, k.stride, out=gw, dbias=gb)
-                    if k.sn:                                             # SURVEY A.2 fix-up
-                        st = net.sn[k.scope]
-                        ops.dot(gw.view(-1), w.view(-1), out=st['dot'])
-                        ops.sn_wgrad_fixup(gw.view(-1), st['dsigma'].view(-1), st['dot'], st['sigma'], scale)
+                        param_grads_of()
                 if want_dx:
                     dx = self._buf(key, in_shape)
                     if kind == 'dense':
                         ops.gemm(dy.reshape(n, -1), w, trans_b=True, scale=scale, out=dx.view(n, -1))
                     else:
-                        ops.conv2d_dgrad(dy, w, (in_shape[1], in_shape[2]), k.stride, scale=scale, out=dx)
+                        ops.conv2d_dgrad(dy, w, (in_shape[1], in_shape[2]), k.stride, scale=scale, out=dx,
+                                         wino=self._wino_of(k, True, n))
                     give(vin, dx)
             elif kind == 'bn':
                 if rows is not None:
@@ -599,10 +657,12 @@ class TapeEngine:
                 pre = p['prefix']
                 mean, invstd = p['_saved']
                 dx = self._buf(key, in_shape)
-                ws = self._buf(key + ('ws',), [max(lib.mmdgan_bn_workspace_bytes(c) // 4, 4)])
                 y = vals[p['out']]
-                gg = net.g(pre + '/BN/gamma') if param_grads else self._buf(key + ('gg',), [c])
-                gb = net.g(pre + '/BN/beta') if param_grads else self._buf(key + ('gb',), [c])
+                if param_grads:                                          # zeroed with the step's arenas / scratch
+                    ws, gg, gb = p['_ws_bwd'], net.g(pre + '/BN/gamma'), net.g(pre + '/BN/beta')
+                else:                                                    # a second pass through the same op
+                    ws = self._buf(key + ('ws',), [max(lib.mmdgan_bn_workspace_bytes(c) // 4, 4)], zero=True)
+                    gg, gb = self._buf(key + ('gg',), [c], zero=True), self._buf(key + ('gb',), [c], zero=True)
                 ops.check(lib.mmdgan_bn_bwd(
                     a.data_ptr(), y.data_ptr(), dy.data_ptr(), a.numel() // c, c, net.p(pre + '/BN/gamma').data_ptr(),
                     mean.data_ptr(), invstd.data_ptr(), ops.act_id(p['act']), dx.data_ptr(), gg.data_ptr(), gb.data_ptr(),
@@ -623,6 +683,20 @@ class TapeEngine:
                 raise AssertionError(kind)
         return grads.get(0)
 
+    def _wino_of(self, k, dgrad, n):
+        entry = self._wino.get(k.scope)
+        return entry[2].get((dgrad, n)) if entry is not None else None
+
+    def _transform_weights(self, net):
+        for scope, (owner, k, table) in self._wino.items():
+            if owner is not net:
+                continue
+            done = set()
+            for (dgrad, _), u in table.items():
+                if dgrad not in done:
+                    ops.wino_transform(net.p(k.w_name), dgrad, out=u)
+                    done.add(dgrad)
+
     # ---- one training step -----------------------------------------------------------------------------------
     def generate(self, z, is_training=False):
         vals = self._forward(self.gen, z, is_training, 'gen%d' % z.shape[0])
@@ -636,38 +710,71 @@ class TapeEngine:
 
     def step(self, real_nhwc=None, z=None):
         B = self.B
+        lib = ops.require_device()
+        main = torch.cuda.current_stream()
         if z is None:
             self._static_z.normal_()                                     # my_sngan.py:123-124
         else:
             self._static_z.copy_(z)
         if real_nhwc is not None:
             self._static_real.copy_(real_nhwc)
+        if self._side:
+            # after the previous step's Adam: G's transformed weights first (its forward pass waits for them), then
+            # the zeroing of everything the backward pass accumulates into, then D's
+            self._wg_stream.wait_stream(main)
+            with torch.cuda.stream(self._wg_stream):
+                self._transform_weights(self.gen)
+                self._gen_ready.record(self._wg_stream)
+                self.gen.grads.zero_()
+                self.dis.grads.zero_()
+                self._zero_scratch.zero_()
+                self._transform_weights(self.dis)
+                self._dis_ready.record(self._wg_stream)
+            self._sn_stream.wait_stream(main)
+            with torch.cuda.stream(self._sn_stream):                     # depends on D's weights only
+                for k in self.dis.kernels:
+                    if k.sn:
+                        self._sn_step(self.dis, k)
+            main.wait_event(self._gen_ready)
+        else:
+            self.gen.grads.zero_()
+            self.dis.grads.zero_()
+            self._zero_scratch.zero_()
+            for k in self.dis.kernels:
+                if k.sn:
+                    self._sn_step(self.dis, k)
+        self._in_step = True
         gvals = self._forward(self.gen, self._static_z, True, 'g')
         self._dis_in[:B].copy_(self._static_real)                        # my_sngan.py:278: D sees [real ; fake]
         self._dis_in[B:].copy_(gvals[self.gen.out_val])
-        for k in self.dis.kernels:
-            if k.sn:
-                self._sn_step(self.dis, k)
+        if self._side:
+            main.wait_stream(self._sn_stream)
+            main.wait_event(self._dis_ready)
         dvals = self._forward(self.dis, self._dis_in, True, 'd')
         scores = dvals[self.dis.out_val]                                 # [2B, d]: s_x = [:B], s_gen = [B:]
-        lib = ops.require_device()
         ops.check(lib.mmdgan_mmd_loss(scores[B:].data_ptr(), scores[:B].data_ptr(), B, self.score_size,
                                       ops.LOSS[self.loss_type] | 0x100, self.rep_weights[0], self.rep_weights[1], 0.25,
                                       4.0, self.losses.data_ptr(), self._mmd_grads.data_ptr(), None, None,
                                       self._mmd_ws.data_ptr(), ops._stream()), 'mmd_loss')
-        self.gen.grads.zero_()
-        self.dis.grads.zero_()
         ds = self._mmd_grads.view(4 * B, -1)        # [dLd/ds_x ; dLd/ds_gen ; dLg/ds_gen ; dLg/ds_x]
-        self._backward(self.dis, dvals, ds[:2 * B], 'bd', param_grads=True)
+        lib.mmdgan_set_outputs_prezeroed(1)         # gradient arenas and the scratch were zeroed at step start
+        try:
+            self._backward(self.dis, dvals, ds[:2 * B], 'bd', param_grads=True)
+            if self._d_has_bn:                      # batch statistics couple the rows: full pass, zero on the real half
+                dg = self._buf('dg_full', [2 * B, self.score_size])
+                dg[:B].zero_()
+                dg[B:].copy_(ds[2 * B:3 * B])
+                d_in = self._backward(self.dis, dvals, dg, 'bg', param_grads=False, need_input_grad=True)[B:]
+            else:
+                d_in = self._backward(self.dis, dvals, ds[2 * B:3 * B], 'bg', rows=(B, 2 * B), param_grads=False,
+                                      need_input_grad=True)
+            self._backward(self.gen, gvals, d_in.contiguous(), 'gb', param_grads=True)
+            if self._side:
+                main.wait_stream(self._wg_stream)
+        finally:
+            lib.mmdgan_set_outputs_prezeroed(0)
+            self._in_step = False
         self._allreduce(self.dis)
-        if self._d_has_bn:                          # batch statistics couple the rows: full pass, zero on the real half
-            dg = self._buf('dg_full', [2 * B, self.score_size], zero=True)
-            dg[B:].copy_(ds[2 * B:3 * B])
-            d_in = self._backward(self.dis, dvals, dg, 'bg', param_grads=False, need_input_grad=True)[B:]
-        else:
-            d_in = self._backward(self.dis, dvals, ds[2 * B:3 * B], 'bg', rows=(B, 2 * B), param_grads=False,
-                                  need_input_grad=True)
-        self._backward(self.gen, gvals, d_in.contiguous(), 'gb', param_grads=True)
         self._allreduce(self.gen)
         gs = 1.0 / self.world
         self.dis.opt.step(self.lr_d, grad_scale=gs)

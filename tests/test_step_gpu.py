@@ -232,9 +232,14 @@ from test_step_gpu import mid_architecture
 torch.cuda.set_device(0)
 mdist.init_process_group(0)
 arch, B = mid_architecture(), 16
+if os.environ.get('RCCL_CHILD_ENGINE') == 'tape':                   # the residual-block engine (mmdgan_hip/tape.py)
+    from mmdgan_hip.tape import TapeEngine as GanEngine
+    from tiny_arch import tiny_res_architecture
+    arch, B = tiny_res_architecture(), 8
 rs = np.random.RandomState(5)
-z = [torch.as_tensor(rs.randn(B, 64).astype(np.float32)).cuda() for _ in range(3)]
-real = [torch.as_tensor(rs.uniform(-1, 1, (B, 32, 32, 3)).astype(np.float32)).cuda() for _ in range(3)]
+code, (c, h, w) = arch['code'][0][0], arch['input'][0]
+z = [torch.as_tensor(rs.randn(B, code).astype(np.float32)).cuda() for _ in range(3)]
+real = [torch.as_tensor(rs.uniform(-1, 1, (B, h, w, c)).astype(np.float32)).cuda() for _ in range(3)]
 out = {}
 for name, group in (('dp', dist.group.WORLD), ('single', None)):
     eng = GanEngine(arch, 'rep', (5e-4, 2e-4), batch_size=B, seed=3, dist_group=group)
@@ -251,14 +256,16 @@ dist.destroy_process_group()
 # noise (the last bias: analytically zero under an MMD loss) goes either way: compare the UPDATES in L2
 worst = 0.0
 for n, v in out['single'][0].items():
-    if n == 'dis/l5_s/bias/bias' or n.endswith('in_rand') or '/moving_' in n:
-        continue
+    if n in ('dis/l5_s/bias/bias', 'dis/l4_s/bias/bias', 'dis/l3_res/bias_1/bias') or 'bias_sc' in n \
+            or n.endswith('in_rand') or '/moving_' in n:
+        continue                                                        # analytically zero gradients, state
     worst = max(worst, float(np.linalg.norm(out['dp'][0][n] - v) / (np.linalg.norm(v - init[n]) + 1e-12)))
 print('RESULT ' + json.dumps({'worst': worst, 'loss_dp': out['dp'][1][:2].tolist(), 'loss_single': out['single'][1][:2].tolist()}), flush=True)
 """
 
 
-def test_data_parallel_exchange_runs_over_rccl():
+@pytest.mark.parametrize('engine', ['dcgan', 'tape'])
+def test_data_parallel_exchange_runs_over_rccl(engine):
     """the gradient exchange of the multi-GPU path (bucketed all-reduce on the engine's exchange stream between the D and G
     backward passes, awaited before Adam) with a one-rank RCCL group on this GPU: the same three steps with and
     without it must give the same variables.  The >1-rank arithmetic is covered on CPU (tests/test_dist_cpu.py)."""
@@ -270,7 +277,7 @@ def test_data_parallel_exchange_runs_over_rccl():
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     env = dict(os.environ, MMDGAN_DP_FORCE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0',
-               WORLD_SIZE='1', LOCAL_RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+               WORLD_SIZE='1', LOCAL_RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0', RCCL_CHILD_ENGINE=engine)
     r = subprocess.run([sys.executable, '-c', 'ROOT = %r\n' % root + _RCCL_CHILD], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
