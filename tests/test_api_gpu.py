@@ -107,3 +107,24 @@ def test_eval_sampling_writes_the_reference_sprite_from_inference_mode_images(tm
             mdl.eval_sampling('cifar', 'ev', mesh_num=(3, 4), code_x=code, real_sample=True)
     finally:
         FLAGS.SYNTHETIC_DATA, FLAGS.SILENT_MODE = False, False
+
+
+def test_driver_script_runs(tmp_path):
+    """python my_test_cifar.py --synthetic: one round of the experiment loop (train past one epoch, checkpoint, sprite)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    pkg = os.path.join(root, 'mmd-gan_amd')
+    env = dict(os.environ, PYTHONPATH=pkg)
+    code = ("import sys; sys.argv = ['my_test_cifar.py', '--synthetic', '--steps', '790', '--rounds', '1']\n"
+            "from GeneralTools.misc_fun import FLAGS\n"
+            "FLAGS.DEFAULT_OUT = %r\n"
+            "import runpy; runpy.run_path(%r, run_name='__main__')\n" % (str(tmp_path) + '/', os.path.join(pkg, 'my_test_cifar.py')))
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert 'Chunk of code finished.' in r.stdout
+    sub = [d for d in os.listdir(str(tmp_path / 'cifar_ckpt'))][0]
+    assert sub.startswith('sngan_rep_5e-04_2e-04_k1.68_0.0_-1.0')
+    assert any(f.startswith('cifar.ckpt-790') for f in os.listdir(str(tmp_path / 'cifar_ckpt' / sub)))
+    assert any(f.endswith('.png') for f in os.listdir(str(tmp_path / 'cifar_log' / sub)))
