@@ -153,7 +153,10 @@ class Agent(object):
         for step in range(max_step):
             step_fn()
             last = step == max_step - 1
-            if self.query_step is not None and (step % self.query_step == self.query_step - 1 or last):
+            # the reference keys its periodic print on the GLOBAL step (graph_func.py:860), so a resumed run keeps the
+            # cadence of the run it continues; the value it fetches next to the update is the pre-increment one
+            gstep = engine.global_step - 1
+            if self.query_step is not None and (gstep % self.query_step == self.query_step - 1 or last):
                 # losses stay on the device between query points: one host sync per query_step
                 # (the reference syncs every step for its NaN assert, graph_func.py:856)
                 lg, ld = read_losses()
