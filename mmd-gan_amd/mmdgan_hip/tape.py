@@ -430,6 +430,7 @@ class TapeEngine:
         self._mmd_grads = torch.zeros(4, self.B, self.score_size, device=self.device)
         self._bufs = {}
         self._in_step = False                                            # transformed weights are valid inside step() only
+        self._exchange_pending = False
         self._d_has_bn = bool(self.dis.bns)
         lib = ops.require_device()
         # side streams on hardware queues of their own (streams.py): the power iterations run under G's forward pass,
@@ -703,10 +704,21 @@ class TapeEngine:
         return vals[self.gen.out_val]
 
     def _allreduce(self, net):
+        """SUM all-reduce of one network's gradient arena as blocking collectives on the power-iteration stream (idle
+        from D's forward pass to the next step, on a hardware queue of its own - see engine.py:_allreduce): D's
+        exchange overlaps with the second pass through D and the whole of G's backward pass."""
         if self.dist_group is None or (self.world == 1 and not self._dp_force):
             return
         from . import dist as mdist
-        mdist.allreduce_sum_(net.grads, self.dist_group)                 # blocking collectives, current stream
+        if not self._side:
+            mdist.allreduce_sum_(net.grads, self.dist_group)
+            return
+        comm = self._sn_stream
+        comm.wait_stream(torch.cuda.current_stream())
+        comm.wait_stream(self._wg_stream)
+        with torch.cuda.stream(comm):
+            mdist.allreduce_sum_(net.grads, self.dist_group)
+        self._exchange_pending = True
 
     def step(self, real_nhwc=None, z=None):
         B = self.B
@@ -760,6 +772,7 @@ class TapeEngine:
         lib.mmdgan_set_outputs_prezeroed(1)         # gradient arenas and the scratch were zeroed at step start
         try:
             self._backward(self.dis, dvals, ds[:2 * B], 'bd', param_grads=True)
+            self._allreduce(self.dis)
             if self._d_has_bn:                      # batch statistics couple the rows: full pass, zero on the real half
                 dg = self._buf('dg_full', [2 * B, self.score_size])
                 dg[:B].zero_()
@@ -774,8 +787,10 @@ class TapeEngine:
         finally:
             lib.mmdgan_set_outputs_prezeroed(0)
             self._in_step = False
-        self._allreduce(self.dis)
         self._allreduce(self.gen)
+        if self._exchange_pending:
+            main.wait_stream(self._sn_stream)
+            self._exchange_pending = False
         gs = 1.0 / self.world
         self.dis.opt.step(self.lr_d, grad_scale=gs)
         self.gen.opt.step(self.lr_g, grad_scale=gs)
