@@ -256,6 +256,50 @@ def test_conv2d_dgrad_and_wgrad(ops, case):
     assert rel_err(to_nchw(dx2), ref) <= RTOL
 
 
+# the benchmark's own launches, at full size (too large for the CPU oracle): size-independent properties of a
+# linear operator and its two gradients
+FULL_SIZE = [
+    # N, H, W, C, K, R, stride                                    (rows 3B = 192 are the batched backward pass)
+    (128, 32, 32, 64, 128, 4, 2), (192, 32, 32, 64, 128, 4, 2),   # CIFAR D l2: F(2x2,2x2) kernels
+    (128, 16, 16, 128, 128, 3, 1), (192, 16, 16, 128, 128, 3, 1),  # CIFAR D l3: F(2x2,3x3) kernels
+    (128, 8, 8, 256, 512, 4, 2), (128, 4, 4, 512, 512, 3, 1),     # CIFAR D l6, l7
+    (128, 32, 32, 3, 64, 3, 1),                                   # CIFAR D l1 (thin)
+    (64, 32, 32, 64, 128, 4, 2),                                  # G l4_up as the conv it is the input-gradient of
+    (256, 64, 64, 64, 128, 4, 2),                                 # CelebA D l2 at batch 2B = 256: 268 MB of activations
+    (64, 64, 64, 128, 128, 3, 1),                                 # the ResNet-SN config's largest 3x3
+]
+
+
+@pytest.mark.parametrize('case', FULL_SIZE, ids=[str(c) for c in FULL_SIZE])
+def test_conv_full_size_adjointness_and_linearity(ops, case):
+    """<conv(x, w), dy> = <x, dgrad(dy, w)> = <w, wgrad(x, dy)> (one bilinear form, three kernels), conv linear in x;
+    every launch goes through the library's own dispatch (Winograd / implicit GEMM / thin) for that size"""
+    N, H, W, C, K, ksz, s = case
+    g = torch.Generator(device='cuda').manual_seed(N + C)
+    P, Q = -(-H // s), -(-W // s)
+    x = torch.empty(N, H, W, C, device='cuda').uniform_(-1, 1, generator=g)
+    x2 = torch.empty(N, H, W, C, device='cuda').uniform_(-1, 1, generator=g)
+    w = torch.randn(ksz, ksz, C, K, device='cuda', generator=g) / float(np.sqrt(ksz * ksz * C))
+    dy = torch.randn(N, P, Q, K, device='cuda', generator=g)
+    y = ops.conv2d_fwd(x, w, s)
+    dx = ops.conv2d_dgrad(dy, w, (H, W), s)
+    dw = ops.conv2d_wgrad(x, dy, ksz, s)
+
+    def dot(a, b):
+        return float((a.double() * b.double()).sum())
+    form = dot(y, dy)
+    scale = float(y.double().norm() * dy.double().norm())                # |<y, dy>| <= scale; the form itself is ~scale/sqrt(n)
+    assert abs(dot(x, dx) - form) <= 1e-6 * scale, (form, dot(x, dx), scale)
+    assert abs(dot(w, dw) - form) <= 1e-6 * scale, (form, dot(w, dw), scale)
+    lin = ops.conv2d_fwd(x + 2.0 * x2, w, s)
+    ref = y + 2.0 * ops.conv2d_fwd(x2, w, s)
+    assert float((lin - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    # the batch is a batch: every image's result is independent of its neighbours (first / last image alone)
+    for i in (0, N - 1):
+        alone = ops.conv2d_fwd(x[i:i + 1].contiguous(), w, s)
+        assert float((alone[0] - y[i]).abs().max()) <= 1e-4 * float(y[i].abs().max())
+
+
 WINO2_CASES = [(16, 16, 16, 64, 128, 4, 2), (30, 12, 12, 32, 64, 4, 2), (6, 8, 16, 64, 64, 4, 2), (9, 4, 4, 128, 64, 4, 2),
                (33, 8, 8, 96, 192, 4, 2)]
 
