@@ -364,6 +364,7 @@ class GanEngine:
         side = distinct_queue_streams(n_sn + 1, self.device)
         self._wg_stream, self._sn_streams = side[0], side[1:]
         self._comm_stream = side[1] if len(side) > 1 else side[0]      # gradient exchange, see _allreduce
+        self._dis_exchanged = torch.cuda.Event()
         self._side_wgrad = os.environ.get('MMDGAN_SIDE_WGRAD', '1') != '0'
         if ops._workspace is None:
             ops.set_workspace(device=self.device)
@@ -737,13 +738,21 @@ class GanEngine:
             comm.wait_stream(self._wg_stream)
         with torch.cuda.stream(comm):
             mdist.allreduce_sum_(net.grads, self.dist_group)
+            if net is self.dis:
+                self._dis_exchanged.record(comm)
         self._exchange_pending = True
 
     def _update(self):
+        gs = 1.0 / self.world
         if self._exchange_pending:
+            # D's exchange finished long ago (it ran under G's backward pass): its Adam goes first and hides part
+            # of G's exchange, the only one that is exposed
+            torch.cuda.current_stream().wait_event(self._dis_exchanged)
+            self.dis.opt.step(self.lr_d, grad_scale=gs)
             torch.cuda.current_stream().wait_stream(self._comm_stream)
             self._exchange_pending = False
-        gs = 1.0 / self.world
+            self.gen.opt.step(self.lr_g, grad_scale=gs)
+            return
         self.dis.opt.step(self.lr_d, grad_scale=gs)
         self.gen.opt.step(self.lr_g, grad_scale=gs)
 
