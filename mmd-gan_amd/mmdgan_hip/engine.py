@@ -365,6 +365,7 @@ class GanEngine:
         self._wg_stream, self._sn_streams = side[0], side[1:]
         self._comm_stream = side[1] if len(side) > 1 else side[0]      # gradient exchange, see _allreduce
         self._dis_exchanged = torch.cuda.Event()
+        self._early_d_adam = os.environ.get('MMDGAN_EARLY_D_ADAM', '1') != '0'
         self._side_wgrad = os.environ.get('MMDGAN_SIDE_WGRAD', '1') != '0'
         if ops._workspace is None:
             ops.set_workspace(device=self.device)
@@ -753,7 +754,8 @@ class GanEngine:
             self._exchange_pending = False
             self.gen.opt.step(self.lr_g, grad_scale=gs)
             return
-        self.dis.opt.step(self.lr_d, grad_scale=gs)
+        if not getattr(self, '_d_updated_early', False):
+            self.dis.opt.step(self.lr_d, grad_scale=gs)
         self.gen.opt.step(self.lr_g, grad_scale=gs)
 
     def _step_body(self, z, real):
@@ -789,6 +791,15 @@ class GanEngine:
                 torch.cuda.current_stream().wait_stream(self._wg_stream)
             dz = self._backward_dis()
             self._allreduce(self.dis)
+            self._d_updated_early = False
+            if self._early_d_adam and self.dist_group is None and self._side_wgrad:
+                # D's gradients are complete once the parameter-gradient stream has drained what it holds now and
+                # the main stream has reached this point (thin layers); nothing in G's backward pass reads D's
+                # weights, so D's Adam runs there, beside G's backward pass, instead of at the tail of the step
+                self._wg_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._wg_stream):
+                    self.dis.opt.step(self.lr_d, grad_scale=1.0)
+                self._d_updated_early = True
             self._backward_gen(dz, z)
             self._allreduce(self.gen)
             self._join_wg_stream()
