@@ -366,6 +366,7 @@ class GanEngine:
         self._comm_stream = side[1] if len(side) > 1 else side[0]      # gradient exchange, see _allreduce
         self._dis_exchanged = torch.cuda.Event()
         self._early_d_adam = os.environ.get('MMDGAN_EARLY_D_ADAM', '1') != '0'
+        self._thin_on_main = os.environ.get('MMDGAN_THIN_ON_MAIN') == '1'
         self._side_wgrad = os.environ.get('MMDGAN_SIDE_WGRAD', '1') != '0'
         if ops._workspace is None:
             ops.set_workspace(device=self.device)
@@ -651,10 +652,12 @@ class GanEngine:
 
     def _on_wg_stream(self, fn, spec):
         """run the parameter-gradient launches of one layer on the weight-gradient stream (ordered after
-        everything issued so far on the current stream).  Layers whose conv kernels use the shared
-        library workspace (the thin first/last layers) stay on the main stream."""
+        everything issued so far on the current stream).  That includes the thin first / last layers, whose weight
+        gradients put their partial sums in the library's shared workspace: in the backward pass this stream is the
+        workspace's only user - every Winograd launch of the main stream gets weights transformed at step start,
+        never an in-call transform (MMDGAN_THIN_ON_MAIN=1 keeps them on the main stream)."""
         thin = spec.op != 'd' and (spec.kernel_shape[2] % 64 or spec.kernel_shape[3] % 64)
-        if not self._side_wgrad or thin:
+        if not self._side_wgrad or (thin and self._thin_on_main):
             fn()
             return
         self._wg_stream.wait_stream(torch.cuda.current_stream())
@@ -710,7 +713,8 @@ class GanEngine:
                 if s.op == 'd':
                     ops.gemm(dz, w, trans_b=True, act=act_prev, dact_of=dact, out=dprev)
                 elif s.op == 'c':
-                    ops.conv2d_dgrad(dz, w, (in_shape[1], in_shape[2]), s.stride, act=act_prev, dact_of=dact, out=dprev)
+                    ops.conv2d_dgrad(dz, w, (in_shape[1], in_shape[2]), s.stride, act=act_prev, dact_of=dact, out=dprev,
+                                     wino=self._wino.get(s.scope, (None, None, None))[1])
                 else:                                                        # d/dv of dgrad(v, W) = conv(dz, W)
                     # few tiles (M = B*h*w is small at the top of G): if the epilogue is linear let the
                     # kernel split its K = R*R*Cout reduction into a buffer zeroed at step start

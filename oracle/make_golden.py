@@ -420,7 +420,7 @@ if __name__ == '__main__':
     make_mmd()
     if '--only-next' in sys.argv:
         make_loss_next()
-        make_step('rep', store_grads=False, sn_mode='sn_paper')
+        make_step('rep', sn_mode='sn_paper')
         make_step('rep', arch_fn=tiny_res_architecture, tag='res_rep')
         make_eval()
         sys.exit(0)
@@ -428,7 +428,7 @@ if __name__ == '__main__':
     make_layers()
     make_step('rep')
     make_step('rmb', store_grads=False)
-    make_step('rep', store_grads=False, sn_mode='sn_paper')
+    make_step('rep', sn_mode='sn_paper')
     make_step('rep', arch_fn=tiny_res_architecture, tag='res_rep')
     make_eval()
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))

@@ -144,10 +144,11 @@ def test_full_step_restatement_matches_reference(loss_type):
                         # un-normalised SN start vectors make D's step-0 outputs
                         # ~1e-14, the kernel values 1 - O(1e-28) and every gradient <1e-12, gated by the sign of
                         # rounding-noise distances (max(.,0) of +-1e-28), in the reference too: only magnitude is checkable
-                        if not is_res:
+                        if not is_res and sn_mode == 'default':
                             assert np.abs(ref).max() < 1e-12 and np.abs(g.numpy()).max() < 1e-12, n
                             continue
-                        # (the residual net's shortcuts keep the step-0 scores at ~1e-4: its gradients are ordinary)
+                        # (the residual net's shortcuts keep the step-0 scores at ~1e-4, the flattened-kernel norms of
+                        # 'sn_paper' are ~30x smaller than PICO's: their step-0 gradients are small but ordinary)
                     # dL/d(last bias) is exactly 0 analytically (the loss sees only score
                     # differences): allow an absolute floor tied to the net's gradient scale
                     gscale = max(np.abs(fx[pre + 'grad/' + m + '_f64']).max() for m in (gd if n in gd else gg))
