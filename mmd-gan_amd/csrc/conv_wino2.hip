@@ -132,7 +132,11 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
 #pragma unroll
             for (int v = 0; v < 3; ++v) {
                 const int col = tx * P.tstep + P.c0[gs] + v * P.pstep;
+#ifdef W2_ABLATE_XSAME        /* every tile reads image 0: the loads stay, their HBM / L2-miss part goes */
+                xoff[u][v] = (rowok && col >= 0 && col < P.IW) ? (unsigned)(((((long)0 * P.IH + row) * P.IW + col) * P.Cr + 4 * cq) * 4) : kOOB;
+#else
                 xoff[u][v] = (rowok && col >= 0 && col < P.IW) ? (unsigned)(((((long)tn * P.IH + row) * P.IW + col) * P.Cr + 4 * cq) * 4) : kOOB;
+#endif
             }
         }
     };
@@ -148,7 +152,10 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
     const unsigned ufreq = (unsigned)((long)P.Cr * P.Ko * 4), ukp = (unsigned)(2 * P.Ko * 4), ustage = (unsigned)(BC * P.Ko * 4);
     const unsigned useg = 9u * ufreq;
     const int nm = fq == 0 ? 5 : 4;
-    constexpr int NKP = BC / 2, BD = 4;                  // k-pairs per stage, B prefetch distance in k-pairs
+#ifndef W2_BD
+#define W2_BD 4
+#endif
+    constexpr int NKP = BC / 2, BD = W2_BD;              // k-pairs per stage, B prefetch distance in k-pairs
 
     f32x16 acc[NM];
 #pragma unroll
