@@ -236,6 +236,11 @@ int mmdgan_resample_down(const float *x, float *y, int N, int P, int Q, int C, i
                          void *stream);
 int mmdgan_resample_up(const float *x, float *y, int N, int P, int Q, int C, int factor, float scale, int accumulate,
                        void *stream);
+/* ImageScaling 'ps' (layer_func.py:197-244, 1125-1127): tf.depth_to_space (to_big = 1) / tf.space_to_depth (0) with
+ * the reference's NCHW block-major channel order, on NHWC tensors:
+ *   big[n, h*f + i, w*f + j, c] <-> small[n, h, w, (i*f + j)*C + c];  small is [N,H,W,f*f*C], big [N,H*f,W*f,C].
+ * Each direction is the other's gradient. */
+int mmdgan_periodic_shuffle(const float *src, float *dst, int N, int H, int W, int C, int factor, int to_big, void *stream);
 int mmdgan_act_fwd(const float *x, float *y, long n, int act, void *stream);
 int mmdgan_act_bwd(const float *dy, const float *y, float *dx, long n, int act, int accumulate, void *stream);
 int mmdgan_axpby(const float *a, float alpha, const float *b, float beta, float *out, long n, void *stream);

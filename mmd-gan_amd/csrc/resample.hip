@@ -77,6 +77,36 @@ __global__ __launch_bounds__(256) void resample_up_kernel(const float *__restric
     }
 }
 
+// periodic shuffling (layer_func.py:197-244: tf.depth_to_space / tf.space_to_depth, block-major channel order):
+//   big[n, h*r + i, w*r + j, c] <-> small[n, h, w, (i*r + j)*C + c],  big [N, H*r, W*r, C], small [N, H, W, r*r*C].
+// TO_BIG = depth_to_space (the up-sampling direction), else space_to_depth; each is the other's gradient.
+// Runs of C contiguous floats move as they are: thread = one 16-byte (or 4-byte) element of the destination.
+template <int VEC, bool TO_BIG>
+__global__ __launch_bounds__(256) void shuffle_kernel(const float *__restrict__ src, float *__restrict__ dst, long total, int H,
+                                                      int W, int CV, int r) {
+    using V = typename Pack<VEC>::T;
+    const V *sv = reinterpret_cast<const V *>(src);
+    V *dv = reinterpret_cast<V *>(dst);
+    const long stride = (long)gridDim.x * 256;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {     // o indexes the destination
+        long t = o;
+        if (TO_BIG) {                       // dst = big: ((n*H*r + y)*W*r + x)*CV + c
+            const int c = (int)(t % CV); t /= CV;
+            const int x = (int)(t % (W * r)); t /= (W * r);
+            const int y = (int)(t % (H * r));
+            const long n = t / (H * r);
+            dv[o] = sv[((n * H + y / r) * W + x / r) * ((long)r * r * CV) + ((y % r) * r + x % r) * CV + c];
+        } else {                            // dst = small: ((n*H + h)*W + w)*(r*r*CV) + (i*r + j)*CV + c
+            const int c = (int)(t % CV); t /= CV;
+            const int ij = (int)(t % (r * r)); t /= (r * r);
+            const int w = (int)(t % W); t /= W;
+            const int h = (int)(t % H);
+            const long n = t / H;
+            dv[o] = sv[((n * (H * r) + h * r + ij / r) * (W * r) + w * r + ij % r) * CV + c];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void act_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, long n, int act) {
     const long stride = (long)gridDim.x * 256;
     for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < n; o += stride) y[o] = act_fwd(x[o], act);
@@ -150,4 +180,22 @@ extern "C" int mmdgan_axpby(const float *a, float alpha, const float *b, float b
     MMDGAN_REQUIRE(a && b && out && n >= 1, "axpby: bad arguments");
     hipLaunchKernelGGL(axpby_kernel, dim3(grid_of(n)), dim3(256), 0, (hipStream_t)stream, a, alpha, b, beta, out, n);
     return check_launch("axpby");
+}
+
+extern "C" int mmdgan_periodic_shuffle(const float *src, float *dst, int N, int H, int W, int C, int factor, int to_big,
+                                       void *stream) {
+    MMDGAN_REQUIRE(src && dst && N >= 1 && H >= 1 && W >= 1 && C >= 1 && factor >= 1, "periodic_shuffle: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const bool v4 = C % 4 == 0 && al16(src) && al16(dst);
+    const int cv = v4 ? C / 4 : C;
+    const long total = (long)N * H * W * factor * factor * cv;
+    const dim3 g(grid_of(total));
+    if (v4) {
+        if (to_big) hipLaunchKernelGGL((shuffle_kernel<4, true>), g, dim3(256), 0, st, src, dst, total, H, W, cv, factor);
+        else hipLaunchKernelGGL((shuffle_kernel<4, false>), g, dim3(256), 0, st, src, dst, total, H, W, cv, factor);
+    } else {
+        if (to_big) hipLaunchKernelGGL((shuffle_kernel<1, true>), g, dim3(256), 0, st, src, dst, total, H, W, cv, factor);
+        else hipLaunchKernelGGL((shuffle_kernel<1, false>), g, dim3(256), 0, st, src, dst, total, H, W, cv, factor);
+    }
+    return check_launch("periodic_shuffle");
 }

@@ -346,6 +346,26 @@ def resample_up(x, factor=2, scale=1.0, out=None, accumulate=False):
     return out
 
 
+def periodic_shuffle(x, factor, to_big, out=None):
+    """ImageScaling 'ps' (layer_func.py:197-244): to_big: [N,H,W,f*f*C] -> [N,H*f,W*f,C] (tf.depth_to_space), else the
+    inverse (tf.space_to_depth); channel order as the reference's NCHW ops define it"""
+    lib = require_device()
+    n, h, w, c = x.shape
+    f = int(factor)
+    if to_big:
+        assert c % (f * f) == 0, 'periodic_shuffle: {} channels are not a multiple of {}'.format(c, f * f)
+        H, W, C = h, w, c // (f * f)
+        shape = (n, h * f, w * f, C)
+    else:
+        assert h % f == 0 and w % f == 0
+        H, W, C = h // f, w // f, c
+        shape = (n, H, W, c * f * f)
+    if out is None:
+        out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    check(lib.mmdgan_periodic_shuffle(_p(x), _p(out), n, H, W, C, f, int(bool(to_big)), _stream()), 'periodic_shuffle')
+    return out
+
+
 def act_fwd(x, act, out=None):
     lib = require_device()
     if out is None:

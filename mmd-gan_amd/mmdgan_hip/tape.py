@@ -3,7 +3,7 @@
 The DCGAN path (engine.py) is a hand-scheduled chain of fused launches; residual nets are not a chain - a block's
 input feeds two branches, its pre-activation cannot ride on the producer's epilogue, scaling ops sit between the
 convolutions.  Here every net is lowered to a short list of primitive ops over named values (dense, conv, bn+act,
-act, resample up / down, add, reshape), run forward and then backward in reverse order, each primitive calling the
+act, resample up / down, periodic shuffle, add, reshape), run forward and then backward in reverse order, each primitive calling the
 same C-ABI kernels as the DCGAN path (MFMA / Winograd convs, GEMM, BN, spectral-norm helpers, fused MMD loss,
 multi-tensor Adam) plus the block-specific elementwise kernels of csrc/resample.hip.  Same semantics as
 GanEngine.step: one spectral-norm power iteration per SN kernel per step (every kernel of a block has its own,
@@ -134,6 +134,15 @@ class _Net:
             if factor != 2:
                 raise AttributeError('unpool can only deal with factor = 2')              # :1102-1103
             return self._emit('up', [x], [c, h * 2, w * 2], f=2)
+        if method == 'ps':                                               # periodic shuffling, :1125-1127 / :197-244
+            f = abs(int(factor))
+            if factor > 0:
+                if c % (f * f):
+                    raise AssertionError('periodic shuffling needs a channel count divisible by {}'.format(f * f))
+                return self._emit('shuffle', [x], [c // (f * f), h * f, w * f], f=f, to_big=True)
+            if h % f or w % f:
+                raise AssertionError('periodic shuffling needs a size divisible by {}'.format(f))
+            return self._emit('shuffle', [x], [c * f * f, h // f, w // f], f=f, to_big=False)
         raise NotImplementedError('Method {} not implemented.'.format(method))            # :1165-1167
 
     def _lower(self, design, x):
@@ -577,6 +586,8 @@ class TapeEngine:
                 y = ops.resample_down(a, p['f'], out=self._buf(key, out_shape))
             elif kind == 'up':
                 y = ops.resample_up(a, p['f'], out=self._buf(key, out_shape))
+            elif kind == 'shuffle':
+                y = ops.periodic_shuffle(a, p['f'], p['to_big'], out=self._buf(key, out_shape))
             elif kind == 'add':
                 y = ops.axpby(a, vals[p['ins'][1]], out=self._buf(key, out_shape))
             else:
@@ -677,6 +688,8 @@ class TapeEngine:
                 give(vin, ops.resample_up(dy, f, scale=1.0 / (f * f), out=self._buf(key, in_shape)))
             elif kind == 'up':                                           # d unpool: sum over the window
                 give(vin, ops.resample_down(dy, p['f'], scale=1.0, out=self._buf(key, in_shape)))
+            elif kind == 'shuffle':                                      # a permutation: its gradient is the inverse one
+                give(vin, ops.periodic_shuffle(dy.contiguous(), p['f'], not p['to_big'], out=self._buf(key, in_shape)))
             elif kind == 'add':
                 give(vin, dy)
                 give(p['ins'][1], dy)

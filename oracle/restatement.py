@@ -80,17 +80,27 @@ def _scaled_shape(shape, scale):
             raise AttributeError('unpool can only be used for upsampling')
         if factor != 2:
             raise AttributeError('unpool can only deal with factor = 2')
+    elif method == 'ps':                                      # periodic shuffling moves pixels into / out of channels
+        nh, nw = (int(h * factor), int(w * factor)) if factor > 0 else (int(-h / factor), int(-w / factor))
+        return [int(c * h * w / nh / nw), nh, nw]                # layer_func.py:1105-1107
     else:
         raise NotImplementedError('Method {} not implemented.'.format(method))
     return [c, int(h * factor), int(w * factor)] if factor > 0 else [c, int(-h / factor), int(-w / factor)]
 
 
 def _rescale(x, scale):
-    """ImageScaling.__call__ (layer_func.py:1155-1163): 'avg' = avg_pool with window = stride = -factor;
-    'unpool' = four channel copies through depth_to_space = every pixel repeated 2 x 2"""
+    """ImageScaling.__call__ (layer_func.py:1125-1163): 'avg' = avg_pool with window = stride = -factor;
+    'unpool' = four channel copies through depth_to_space = every pixel repeated 2 x 2; 'ps' = periodic shuffling"""
     method, factor = scale
     if method == 'avg':
         return F.avg_pool2d(x, -factor)
+    if method == 'ps':                                        # layer_func.py:197-244, 1125-1127: tf.depth_to_space /
+        r = abs(int(factor))                                  # tf.space_to_depth on NCHW, block-major channel order
+        n, c, h, w = x.shape
+        if factor > 0:
+            co = c // (r * r)
+            return x.reshape(n, r, r, co, h, w).permute(0, 3, 4, 1, 5, 2).reshape(n, co, h * r, w * r)
+        return x.reshape(n, c, h // r, r, w // r, r).permute(0, 3, 5, 1, 2, 4).reshape(n, r * r * c, h // r, w // r)
     return x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
 
 

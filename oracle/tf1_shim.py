@@ -395,6 +395,15 @@ def depth_to_space(x, block_size, data_format='NHWC', name=None):
     return x.reshape(n, r, r, c, h, w).permute(0, 3, 4, 1, 5, 2).reshape(n, c, h * r, w * r)
 
 
+def space_to_depth(x, block_size, data_format='NHWC', name=None):
+    """tf.space_to_depth, NCHW: out[n, (i*r + j)*C + c, h, w] = in[n, c, h*r + i, w*r + j]"""
+    assert data_format == 'NCHW'
+    r = int(block_size)
+    n, c, hr, wr = x.shape
+    h, w = hr // r, wr // r
+    return x.reshape(n, c, h, r, w, r).permute(0, 3, 5, 1, 2, 4).reshape(n, r * r * c, h, w)
+
+
 nn = types.SimpleNamespace(
     avg_pool=_avg_pool,
     conv2d=_conv2d,

@@ -44,3 +44,24 @@ def tiny_res_architecture():
                               {'name': 'l3_res', 'type': 'res_i', 'out': 32, 'act': 'relu', 'act_k': ak, 'w_nm': 's',
                                'out_reshape': [4 * 4 * 32]},
                               {'name': 'l4_s', 'out': 16, 'op': 'd', 'act_k': ak, 'w_nm': 's'}]}
+
+
+def tiny_res_ps_architecture():
+    """the residual pair again with periodic shuffling ('ps', layer_func.py:197-244) as the scaling method: up-sampling
+    moves 4 channels into a 2x2 block (32 -> 8 channels in front of kernel_0 and kernel_sc), down-sampling the reverse"""
+    ak = float(np.power(64.0, 0.125))
+    k = [3, 3, 1]
+    return {'input': [(3, 16, 16)], 'code': [(24, 'linear')],
+            'generator': [{'name': 'l1', 'out': 32 * 4 * 4, 'op': 'd', 'out_reshape': [32, 4, 4]},
+                          {'name': 'l2_res', 'type': 'res', 'out': 32, 'act': 'relu', 'act_nm': 'bn', 'kernel': k,
+                           'scale': ['ps', 2]},
+                          {'name': 'l3_res', 'type': 'res', 'out': 16, 'act': 'relu', 'act_nm': 'bn', 'kernel': k,
+                           'scale': ['ps', 2]},
+                          {'name': 'l4_t16', 'out': 3, 'act': 'tanh'}],
+            # (a res_v1 block cannot shuffle down: its shortcut shuffles BEFORE the 1x1 kernel, the branch after - the
+            # reference's own shape check rejects it, layer_func.py:1767)
+            'discriminator': [{'name': 'l1_res', 'type': 'res', 'out': 8, 'act': 'lrelu', 'act_k': ak, 'w_nm': 's',
+                               'kernel': k, 'scale': ['ps', -2]},
+                              {'name': 'l2_res', 'type': 'res', 'out': 8, 'act': 'lrelu', 'act_k': ak, 'w_nm': 's',
+                               'kernel': k, 'scale': ['ps', -2], 'out_reshape': [4 * 4 * 32]},
+                              {'name': 'l3_s', 'out': 16, 'op': 'd', 'act_k': ak, 'w_nm': 's'}]}

@@ -580,6 +580,24 @@ def test_resample_matches_the_reference_ops_and_their_gradients(ops, n, h, w, c,
     assert torch.equal(base, want)
 
 
+@pytest.mark.parametrize('n,h,w,c,f', [(2, 4, 4, 8, 2), (3, 5, 3, 3, 2), (2, 4, 6, 2, 3), (64, 16, 16, 64, 2), (1, 1, 1, 1, 2)])
+def test_periodic_shuffle_is_the_reference_permutation(ops, n, h, w, c, f):
+    """'ps' = tf.depth_to_space / tf.space_to_depth on NCHW tensors (layer_func.py:197-244): block-major channels.
+    Pure permutations: exact, inverse of each other, each the other's gradient."""
+    rs = np.random.RandomState(n + c)
+    small = rs.randn(n, f * f * c, h, w).astype(np.float32)                     # NCHW, channel = (i*f + j)*c + ch
+    big_ref = small.reshape(n, f, f, c, h, w).transpose(0, 3, 4, 1, 5, 2).reshape(n, c, h * f, w * f)
+    big = ops.periodic_shuffle(nhwc(small), f, True)
+    assert np.array_equal(to_nchw(big), big_ref)
+    back = ops.periodic_shuffle(big, f, False)
+    assert np.array_equal(to_nchw(back), small)
+    # <shuffle(x), y> == <x, unshuffle(y)>: the inverse permutation is the adjoint
+    y = rs.randn(*big_ref.shape).astype(np.float32)
+    lhs = float((big_ref.astype(np.float64) * y).sum())
+    rhs = float((small.astype(np.float64) * to_nchw(ops.periodic_shuffle(nhwc(y), f, False))).sum())
+    assert abs(lhs - rhs) <= 1e-9 * max(abs(lhs), 1.0)
+
+
 @pytest.mark.parametrize('act', ['linear', 'relu', 'lrelu', 'tanh'])
 def test_act_and_axpby(ops, act):
     rs = np.random.RandomState(5)
