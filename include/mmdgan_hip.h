@@ -241,6 +241,10 @@ int mmdgan_resample_up(const float *x, float *y, int N, int P, int Q, int C, int
  *   big[n, h*f + i, w*f + j, c] <-> small[n, h, w, (i*f + j)*C + c];  small is [N,H,W,f*f*C], big [N,H*f,W*f,C].
  * Each direction is the other's gradient. */
 int mmdgan_periodic_shuffle(const float *src, float *dst, int N, int H, int W, int C, int factor, int to_big, void *stream);
+/* ImageScaling 'bil' (layer_func.py:1128-1137): tf.image.resize_bilinear(align_corners=True), [N,H,W,C] -> [N,OH,OW,C]
+ * (grad = 0), or its adjoint (grad = 1: src = dy [N,OH,OW,C], dst = dx [N,H,W,C], accumulated with atomics into a dx
+ * the entry zeroes itself unless mmdgan_set_outputs_prezeroed(1) is in force). */
+int mmdgan_bilinear_resize(const float *src, float *dst, int N, int H, int W, int C, int OH, int OW, int grad, void *stream);
 int mmdgan_act_fwd(const float *x, float *y, long n, int act, void *stream);
 int mmdgan_act_bwd(const float *dy, const float *y, float *dx, long n, int act, int accumulate, void *stream);
 int mmdgan_axpby(const float *a, float alpha, const float *b, float beta, float *out, long n, void *stream);

@@ -107,6 +107,42 @@ __global__ __launch_bounds__(256) void shuffle_kernel(const float *__restrict__ 
     }
 }
 
+// ImageScaling 'bil' (layer_func.py:1128-1137): tf.image.resize_bilinear(align_corners=True).  Source coordinate of
+// output row y: y * (H - 1) / (OH - 1) in fp32 as TF computes it; rows floor(.) and min(floor(.) + 1, H - 1) blended
+// with the fractional part, columns likewise.  GRAD: the adjoint - every output gradient is scattered to its four
+// sources with the same weights (fp32 atomics into a zeroed dx; not a hot path).
+template <bool GRAD>
+__global__ __launch_bounds__(256) void bilinear_kernel(const float *__restrict__ src, float *__restrict__ dst, long total, int H,
+                                                       int W, int C, int OH, int OW, float sy, float sx) {
+    const long stride = (long)gridDim.x * 256;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {     // o indexes the OH x OW side
+        const int c = (int)(o % C);
+        long t = o / C;
+        const int x = (int)(t % OW);
+        t /= OW;
+        const int y = (int)(t % OH);
+        const long n = t / OH;
+        const float fy = (float)y * sy, fx = (float)x * sx;
+        const int y0 = min((int)floorf(fy), H - 1), x0 = min((int)floorf(fx), W - 1);
+        const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+        const float wy = fy - (float)y0, wx = fx - (float)x0;
+        const long b = n * H;
+        const long i00 = ((b + y0) * W + x0) * C + c, i01 = ((b + y0) * W + x1) * C + c;
+        const long i10 = ((b + y1) * W + x0) * C + c, i11 = ((b + y1) * W + x1) * C + c;
+        if (!GRAD) {
+            const float top = src[i00] + (src[i01] - src[i00]) * wx;          // TF: top_left + (top_right - top_left) * x_lerp
+            const float bot = src[i10] + (src[i11] - src[i10]) * wx;
+            dst[o] = top + (bot - top) * wy;
+        } else {
+            const float g = src[o];
+            atomicAdd(dst + i00, g * (1.f - wy) * (1.f - wx));
+            atomicAdd(dst + i01, g * (1.f - wy) * wx);
+            atomicAdd(dst + i10, g * wy * (1.f - wx));
+            atomicAdd(dst + i11, g * wy * wx);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void act_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, long n, int act) {
     const long stride = (long)gridDim.x * 256;
     for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < n; o += stride) y[o] = act_fwd(x[o], act);
@@ -198,4 +234,19 @@ extern "C" int mmdgan_periodic_shuffle(const float *src, float *dst, int N, int 
         else hipLaunchKernelGGL((shuffle_kernel<1, false>), g, dim3(256), 0, st, src, dst, total, H, W, cv, factor);
     }
     return check_launch("periodic_shuffle");
+}
+
+extern "C" int mmdgan_bilinear_resize(const float *src, float *dst, int N, int H, int W, int C, int OH, int OW, int grad,
+                                      void *stream) {
+    MMDGAN_REQUIRE(src && dst && N >= 1 && H >= 1 && W >= 1 && C >= 1 && OH >= 1 && OW >= 1, "bilinear_resize: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const float sy = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f, sx = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+    const long total = (long)N * OH * OW * C;
+    if (grad) {                              // src = dy [N,OH,OW,C], dst = dx [N,H,W,C]
+        if (zero_output(dst, sizeof(float) * (size_t)N * H * W * C, st) != hipSuccess) return check_launch("bilinear_resize memset");
+        hipLaunchKernelGGL(bilinear_kernel<true>, dim3(grid_of(total)), dim3(256), 0, st, src, dst, total, H, W, C, OH, OW, sy, sx);
+    } else {
+        hipLaunchKernelGGL(bilinear_kernel<false>, dim3(grid_of(total)), dim3(256), 0, st, src, dst, total, H, W, C, OH, OW, sy, sx);
+    }
+    return check_launch("bilinear_resize");
 }

@@ -366,6 +366,29 @@ def periodic_shuffle(x, factor, to_big, out=None):
     return out
 
 
+def bilinear_resize(x, size, out=None):
+    """ImageScaling 'bil' (layer_func.py:1128-1137): tf.image.resize_bilinear(align_corners=True) of an NHWC tensor"""
+    lib = require_device()
+    n, h, w, c = x.shape
+    oh, ow = int(size[0]), int(size[1])
+    if out is None:
+        out = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.float32)
+    check(lib.mmdgan_bilinear_resize(_p(x), _p(out), n, h, w, c, oh, ow, 0, _stream()), 'bilinear_resize')
+    return out
+
+
+def bilinear_resize_grad(dy, in_hw, out=None):
+    """gradient of bilinear_resize w.r.t. its input: dy [N,OH,OW,C] -> dx [N,H,W,C]; `out` must be zero when
+    mmdgan_set_outputs_prezeroed(1) is in force"""
+    lib = require_device()
+    n, oh, ow, c = dy.shape
+    h, w = int(in_hw[0]), int(in_hw[1])
+    if out is None:
+        out = torch.zeros((n, h, w, c), device=dy.device, dtype=torch.float32)
+    check(lib.mmdgan_bilinear_resize(_p(dy), _p(out), n, h, w, c, oh, ow, 1, _stream()), 'bilinear_resize_grad')
+    return out
+
+
 def act_fwd(x, act, out=None):
     lib = require_device()
     if out is None:

@@ -3,7 +3,7 @@
 The DCGAN path (engine.py) is a hand-scheduled chain of fused launches; residual nets are not a chain - a block's
 input feeds two branches, its pre-activation cannot ride on the producer's epilogue, scaling ops sit between the
 convolutions.  Here every net is lowered to a short list of primitive ops over named values (dense, conv, bn+act,
-act, resample up / down, periodic shuffle, add, reshape), run forward and then backward in reverse order, each primitive calling the
+act, resample up / down, periodic shuffle, bilinear resize, add, reshape), run forward and then backward in reverse order, each primitive calling the
 same C-ABI kernels as the DCGAN path (MFMA / Winograd convs, GEMM, BN, spectral-norm helpers, fused MMD loss,
 multi-tensor Adam) plus the block-specific elementwise kernels of csrc/resample.hip.  Same semantics as
 GanEngine.step: one spectral-norm power iteration per SN kernel per step (every kernel of a block has its own,
@@ -134,6 +134,9 @@ class _Net:
             if factor != 2:
                 raise AttributeError('unpool can only deal with factor = 2')              # :1102-1103
             return self._emit('up', [x], [c, h * 2, w * 2], f=2)
+        if method == 'bil':                                              # tf.image.resize_bilinear, :1128-1137
+            nh, nw = (int(h * factor), int(w * factor)) if factor > 0 else (int(-h / factor), int(-w / factor))
+            return self._emit('bilinear', [x], [c, nh, nw])
         if method == 'ps':                                               # periodic shuffling, :1125-1127 / :197-244
             f = abs(int(factor))
             if factor > 0:
@@ -588,6 +591,8 @@ class TapeEngine:
                 y = ops.resample_up(a, p['f'], out=self._buf(key, out_shape))
             elif kind == 'shuffle':
                 y = ops.periodic_shuffle(a, p['f'], p['to_big'], out=self._buf(key, out_shape))
+            elif kind == 'bilinear':
+                y = ops.bilinear_resize(a, out_shape[1:3], out=self._buf(key, out_shape))
             elif kind == 'add':
                 y = ops.axpby(a, vals[p['ins'][1]], out=self._buf(key, out_shape))
             else:
@@ -688,6 +693,8 @@ class TapeEngine:
                 give(vin, ops.resample_up(dy, f, scale=1.0 / (f * f), out=self._buf(key, in_shape)))
             elif kind == 'up':                                           # d unpool: sum over the window
                 give(vin, ops.resample_down(dy, p['f'], scale=1.0, out=self._buf(key, in_shape)))
+            elif kind == 'bilinear':                                     # scatter with the forward weights (atomics)
+                give(vin, ops.bilinear_resize_grad(dy.contiguous(), in_shape[1:3], out=self._buf(key, in_shape, zero=True)))
             elif kind == 'shuffle':                                      # a permutation: its gradient is the inverse one
                 give(vin, ops.periodic_shuffle(dy.contiguous(), p['f'], not p['to_big'], out=self._buf(key, in_shape)))
             elif kind == 'add':

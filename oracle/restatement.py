@@ -80,6 +80,8 @@ def _scaled_shape(shape, scale):
             raise AttributeError('unpool can only be used for upsampling')
         if factor != 2:
             raise AttributeError('unpool can only deal with factor = 2')
+    elif method == 'bil':                                     # any integer factor, either direction
+        pass
     elif method == 'ps':                                      # periodic shuffling moves pixels into / out of channels
         nh, nw = (int(h * factor), int(w * factor)) if factor > 0 else (int(-h / factor), int(-w / factor))
         return [int(c * h * w / nh / nw), nh, nw]                # layer_func.py:1105-1107
@@ -94,6 +96,10 @@ def _rescale(x, scale):
     method, factor = scale
     if method == 'avg':
         return F.avg_pool2d(x, -factor)
+    if method == 'bil':                                       # layer_func.py:1128-1137: tf.image.resize_bilinear,
+        n, c, h, w = x.shape                                  # align_corners=True
+        size = (int(h * factor), int(w * factor)) if factor > 0 else (int(-h / factor), int(-w / factor))
+        return bilinear_resize(x, size)
     if method == 'ps':                                        # layer_func.py:197-244, 1125-1127: tf.depth_to_space /
         r = abs(int(factor))                                  # tf.space_to_depth on NCHW, block-major channel order
         n, c, h, w = x.shape
@@ -102,6 +108,26 @@ def _rescale(x, scale):
             return x.reshape(n, r, r, co, h, w).permute(0, 3, 4, 1, 5, 2).reshape(n, co, h * r, w * r)
         return x.reshape(n, c, h // r, r, w // r, r).permute(0, 3, 5, 1, 2, 4).reshape(n, r * r * c, h // r, w // r)
     return x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+
+
+def bilinear_resize(x, size):
+    """tf.image.resize_bilinear(align_corners=True) written out (resize_bilinear_op.cc semantics): for an output row y
+    the source coordinate is y * (in_h - 1) / (out_h - 1); rows floor(.) and min(floor(.) + 1, in_h - 1) are blended
+    with the fractional part, columns likewise.  NCHW in, NCHW out."""
+    n, c, h, w = x.shape
+    oh, ow = size
+
+    def axis(out_n, in_n):
+        scale = (in_n - 1) / (out_n - 1) if out_n > 1 else 0.0
+        src = torch.arange(out_n, dtype=x.dtype) * scale
+        lo = torch.floor(src).long().clamp(max=in_n - 1)
+        hi = torch.clamp(lo + 1, max=in_n - 1)
+        return lo, hi, (src - lo.to(x.dtype))
+    y0, y1, wy = axis(oh, h)
+    x0, x1, wx = axis(ow, w)
+    top = x[:, :, y0][:, :, :, x0] * (1 - wx) + x[:, :, y0][:, :, :, x1] * wx
+    bot = x[:, :, y1][:, :, :, x0] * (1 - wx) + x[:, :, y1][:, :, :, x1] * wx
+    return top * (1 - wy)[:, None] + bot * wy[:, None]
 
 
 def _kernel_spec(layer_scope, op_name, d, index, in_shape, sn_mode):

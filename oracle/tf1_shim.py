@@ -299,6 +299,10 @@ def reduce_mean(x, axis=None, keepdims=False, name=None):
     return torch.mean(x, dim=axis, keepdim=keepdims)
 
 
+def transpose(x, perm=None, name=None):
+    return x.permute(*perm) if perm is not None else x.t()
+
+
 def concat(values, axis, name=None):
     return torch.cat(list(values), dim=axis)
 
@@ -447,6 +451,16 @@ def _batch_normalization(x, axis=-1, momentum=0.99, epsilon=1e-3, center=True, s
     return y * gamma.reshape(bshape) + beta.reshape(bshape)
 
 
+def _resize_bilinear(images, size, align_corners=False, name=None):
+    """tf.image.resize_bilinear on NHWC with align_corners=True (what ImageScaling 'bil' issues, layer_func.py:1128-1137):
+    source coordinate = y * (in - 1) / (out - 1), linear interpolation between the two neighbours"""
+    assert align_corners
+    x = images.permute(0, 3, 1, 2)
+    y = F.interpolate(x, size=(int(size[0]), int(size[1])), mode='bilinear', align_corners=True)
+    return y.permute(0, 2, 3, 1)
+
+
+image = types.SimpleNamespace(resize_bilinear=_resize_bilinear)
 layers = types.SimpleNamespace(batch_normalization=_batch_normalization)
 summary = types.SimpleNamespace(scalar=lambda *a, **k: None, histogram=lambda *a, **k: None,
                                 image=lambda *a, **k: None)

@@ -65,3 +65,23 @@ def tiny_res_ps_architecture():
                               {'name': 'l2_res', 'type': 'res', 'out': 8, 'act': 'lrelu', 'act_k': ak, 'w_nm': 's',
                                'kernel': k, 'scale': ['ps', -2], 'out_reshape': [4 * 4 * 32]},
                               {'name': 'l3_s', 'out': 16, 'op': 'd', 'act_k': ak, 'w_nm': 's'}]}
+
+
+def tiny_res_bil_architecture():
+    """the residual pair with bilinear resizing ('bil', tf.image.resize_bilinear align_corners=True, layer_func.py:
+    1128-1137) as the scaling method, both directions; 12x12 images so that the interpolation weights are not all
+    dyadic (4 -> 6 -> 12 up with factors 1.5 is not expressible: factors are integers, so 3 -> 6 -> 12)"""
+    ak = float(np.power(64.0, 0.125))
+    k = [3, 3, 1]
+    return {'input': [(3, 12, 12)], 'code': [(24, 'linear')],
+            'generator': [{'name': 'l1', 'out': 16 * 3 * 3, 'op': 'd', 'out_reshape': [16, 3, 3]},
+                          {'name': 'l2_res', 'type': 'res', 'out': 16, 'act': 'relu', 'act_nm': 'bn', 'kernel': k,
+                           'scale': ['bil', 2]},
+                          {'name': 'l3_res', 'type': 'res', 'out': 8, 'act': 'relu', 'act_nm': 'bn', 'kernel': k,
+                           'scale': ['bil', 2]},
+                          {'name': 'l4_t12', 'out': 3, 'act': 'tanh'}],
+            'discriminator': [{'name': 'l1_res', 'type': 'res_v1', 'out': 8, 'act': 'relu', 'act_k': ak, 'w_nm': 's',
+                               'kernel': k, 'scale': ['bil', -2]},
+                              {'name': 'l2_res', 'type': 'res', 'out': 16, 'act': 'relu', 'act_k': ak, 'w_nm': 's',
+                               'kernel': k, 'scale': ['bil', -3], 'out_reshape': [2 * 2 * 16]},
+                              {'name': 'l3_s', 'out': 16, 'op': 'd', 'act_k': ak, 'w_nm': 's'}]}

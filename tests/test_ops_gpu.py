@@ -598,6 +598,27 @@ def test_periodic_shuffle_is_the_reference_permutation(ops, n, h, w, c, f):
     assert abs(lhs - rhs) <= 1e-9 * max(abs(lhs), 1.0)
 
 
+@pytest.mark.parametrize('n,c,h,w,oh,ow', [(2, 3, 4, 4, 8, 8), (3, 5, 6, 6, 3, 3), (2, 4, 6, 9, 2, 3), (2, 8, 3, 3, 12, 12),
+                                           (1, 1, 1, 1, 2, 2), (2, 2, 5, 7, 5, 7), (4, 16, 16, 16, 32, 32), (2, 3, 4, 4, 1, 1)])
+def test_bilinear_resize_and_its_gradient(ops, n, c, h, w, oh, ow):
+    """'bil' = tf.image.resize_bilinear(align_corners=True) (layer_func.py:1128-1137) against the oracle's written-out
+    interpolation in fp64, and the adjoint against autograd"""
+    rs = np.random.RandomState(n + c + oh)
+    x = rs.randn(n, c, h, w).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    ref = R.bilinear_resize(xt, (oh, ow))
+    got = ops.bilinear_resize(nhwc(x), (oh, ow))
+    assert rel_err(to_nchw(got), ref.detach().numpy()) <= 2e-6
+    dy = rs.randn(n, c, oh, ow).astype(np.float32)
+    gx, = torch.autograd.grad(ref, xt, torch.tensor(dy, dtype=torch.float64))
+    dx = ops.bilinear_resize_grad(nhwc(dy), (h, w))
+    assert rel_err(to_nchw(dx), gx.numpy()) <= 5e-6
+    # align_corners: the corner pixels are copied
+    assert np.array_equal(to_nchw(got)[:, :, 0, 0], x[:, :, 0, 0])
+    if oh > 1 and ow > 1:
+        assert np.allclose(to_nchw(got)[:, :, -1, -1], x[:, :, -1, -1], rtol=1e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize('act', ['linear', 'relu', 'lrelu', 'tanh'])
 def test_act_and_axpby(ops, act):
     rs = np.random.RandomState(5)
