@@ -245,6 +245,10 @@ int mmdgan_periodic_shuffle(const float *src, float *dst, int N, int H, int W, i
  * (grad = 0), or its adjoint (grad = 1: src = dy [N,OH,OW,C], dst = dx [N,H,W,C], accumulated with atomics into a dx
  * the entry zeroes itself unless mmdgan_set_outputs_prezeroed(1) is in force). */
 int mmdgan_bilinear_resize(const float *src, float *dst, int N, int H, int W, int C, int OH, int OW, int grad, void *stream);
+/* ImageScaling 'max' (layer_func.py:1149-1153): tf.nn.max_pool with window = stride = factor on x [N, P*factor, Q*factor, C].
+ * dy == NULL: out [N,P,Q,C] = window maxima.  dy != NULL ([N,P,Q,C]): out [N, P*factor, Q*factor, C] = the gradient
+ * w.r.t. x - dy at the first maximum of each window (row-major), zero elsewhere; every element of out is written. */
+int mmdgan_max_pool(const float *x, const float *dy, float *out, int N, int P, int Q, int C, int factor, void *stream);
 int mmdgan_act_fwd(const float *x, float *y, long n, int act, void *stream);
 int mmdgan_act_bwd(const float *dy, const float *y, float *dx, long n, int act, int accumulate, void *stream);
 int mmdgan_axpby(const float *a, float alpha, const float *b, float beta, float *out, long n, void *stream);

@@ -143,6 +143,39 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const float *__restrict__
     }
 }
 
+// ImageScaling 'max' (layer_func.py:1149-1153): tf.nn.max_pool, window = stride = f.  Windows do not overlap, so the
+// gradient needs no atomics: the thread of a window writes dy to its first maximum (row-major order, the element a
+// strict '>' scan keeps - what TF's and the oracle's max-pool gradients pick) and zero to the rest.
+template <bool GRAD>
+__global__ __launch_bounds__(256) void maxpool_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                      float *__restrict__ out, long total, int P, int Q, int C, int f) {
+    const long stride = (long)gridDim.x * 256;
+    const int W = Q * f;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {     // o = ((n*P + p)*Q + q)*C + c
+        const int c = (int)(o % C);
+        long t = o / C;
+        const int q = (int)(t % Q);
+        t /= Q;
+        const int p = (int)(t % P);
+        const long n = t / P;
+        float best = -INFINITY;
+        int arg = 0;
+        for (int i = 0; i < f; ++i)
+            for (int j = 0; j < f; ++j) {
+                const float v = x[((n * (P * f) + p * f + i) * W + q * f + j) * C + c];
+                if (v > best || (i == 0 && j == 0)) { best = v; arg = i * f + j; }
+            }
+        if (!GRAD) {
+            out[o] = best;
+        } else {
+            const float g = dy[o];
+            for (int i = 0; i < f; ++i)
+                for (int j = 0; j < f; ++j)
+                    out[((n * (P * f) + p * f + i) * W + q * f + j) * C + c] = (i * f + j == arg) ? g : 0.f;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void act_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, long n, int act) {
     const long stride = (long)gridDim.x * 256;
     for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < n; o += stride) y[o] = act_fwd(x[o], act);
@@ -249,4 +282,13 @@ extern "C" int mmdgan_bilinear_resize(const float *src, float *dst, int N, int H
         hipLaunchKernelGGL(bilinear_kernel<false>, dim3(grid_of(total)), dim3(256), 0, st, src, dst, total, H, W, C, OH, OW, sy, sx);
     }
     return check_launch("bilinear_resize");
+}
+
+extern "C" int mmdgan_max_pool(const float *x, const float *dy, float *out, int N, int P, int Q, int C, int factor,
+                               void *stream) {
+    MMDGAN_REQUIRE(x && out && N >= 1 && P >= 1 && Q >= 1 && C >= 1 && factor >= 1, "max_pool: bad arguments");
+    const long total = (long)N * P * Q * C;
+    if (dy) hipLaunchKernelGGL(maxpool_kernel<true>, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, x, dy, out, total, P, Q, C, factor);
+    else hipLaunchKernelGGL(maxpool_kernel<false>, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, x, dy, out, total, P, Q, C, factor);
+    return check_launch("max_pool");
 }

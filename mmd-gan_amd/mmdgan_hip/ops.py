@@ -389,6 +389,19 @@ def bilinear_resize_grad(dy, in_hw, out=None):
     return out
 
 
+def max_pool(x, factor=2, dy=None, out=None):
+    """ImageScaling 'max' (layer_func.py:1149-1153).  dy=None: window maxima of x [N,H,W,C]; with dy [N,H/f,W/f,C]: the
+    gradient w.r.t. x (dy at each window's first maximum, zero elsewhere)"""
+    lib = require_device()
+    n, h, w, c = x.shape
+    f = int(factor)
+    assert h % f == 0 and w % f == 0, 'max_pool: {}x{} is not a multiple of {}'.format(h, w, f)
+    if out is None:
+        out = torch.empty((n, h // f, w // f, c) if dy is None else (n, h, w, c), device=x.device, dtype=torch.float32)
+    check(lib.mmdgan_max_pool(_p(x), _p(dy), _p(out), n, h // f, w // f, c, f, _stream()), 'max_pool')
+    return out
+
+
 def act_fwd(x, act, out=None):
     lib = require_device()
     if out is None:

@@ -134,6 +134,13 @@ class _Net:
             if factor != 2:
                 raise AttributeError('unpool can only deal with factor = 2')              # :1102-1103
             return self._emit('up', [x], [c, h * 2, w * 2], f=2)
+        if method == 'max':                                              # tf.nn.max_pool, :1149-1153
+            if factor > 0:
+                raise AttributeError('max can only be used for downsampling')             # :1098-1099
+            f = -factor
+            if h % f or w % f:
+                raise NotImplementedError('max pooling of a size its window does not divide is not built')
+            return self._emit('maxpool', [x], [c, h // f, w // f], f=f)
         if method == 'bil':                                              # tf.image.resize_bilinear, :1128-1137
             nh, nw = (int(h * factor), int(w * factor)) if factor > 0 else (int(-h / factor), int(-w / factor))
             return self._emit('bilinear', [x], [c, nh, nw])
@@ -593,6 +600,8 @@ class TapeEngine:
                 y = ops.periodic_shuffle(a, p['f'], p['to_big'], out=self._buf(key, out_shape))
             elif kind == 'bilinear':
                 y = ops.bilinear_resize(a, out_shape[1:3], out=self._buf(key, out_shape))
+            elif kind == 'maxpool':
+                y = ops.max_pool(a, p['f'], out=self._buf(key, out_shape))
             elif kind == 'add':
                 y = ops.axpby(a, vals[p['ins'][1]], out=self._buf(key, out_shape))
             else:
@@ -693,6 +702,8 @@ class TapeEngine:
                 give(vin, ops.resample_up(dy, f, scale=1.0 / (f * f), out=self._buf(key, in_shape)))
             elif kind == 'up':                                           # d unpool: sum over the window
                 give(vin, ops.resample_down(dy, p['f'], scale=1.0, out=self._buf(key, in_shape)))
+            elif kind == 'maxpool':                                      # dy to each window's first maximum
+                give(vin, ops.max_pool(a.contiguous(), p['f'], dy=dy.contiguous(), out=self._buf(key, in_shape)))
             elif kind == 'bilinear':                                     # scatter with the forward weights (atomics)
                 give(vin, ops.bilinear_resize_grad(dy.contiguous(), in_shape[1:3], out=self._buf(key, in_shape, zero=True)))
             elif kind == 'shuffle':                                      # a permutation: its gradient is the inverse one

@@ -262,7 +262,7 @@ def make_layers():
 # 3. full G+D step on a width/8 CIFAR-shaped net, 3 consecutive steps
 # ---------------------------------------------------------------------------
 from tiny_arch import (tiny_architecture, tiny_res_architecture, tiny_res_ps_architecture,  # noqa: E402
-                       tiny_res_bil_architecture)  # noqa: E402
+                       tiny_res_bil_architecture, tiny_res_max_architecture)  # noqa: E402
 
 
 def tf_adam_inplace(var, g, m, v, t, lr, b1=0.5, b2=0.999, eps=1e-8):
@@ -425,6 +425,7 @@ if __name__ == '__main__':
         make_step('rep', arch_fn=tiny_res_architecture, tag='res_rep')
         make_step('rmb', arch_fn=tiny_res_ps_architecture, tag='res_ps_rmb')
         make_step('rep', arch_fn=tiny_res_bil_architecture, tag='res_bil_rep', store_grads=True)
+        make_step('rep', arch_fn=tiny_res_max_architecture, tag='res_max_rep')
         make_eval()
         sys.exit(0)
     make_loss_next()
@@ -435,6 +436,7 @@ if __name__ == '__main__':
     make_step('rep', arch_fn=tiny_res_architecture, tag='res_rep')
     make_step('rmb', arch_fn=tiny_res_ps_architecture, tag='res_ps_rmb')
     make_step('rep', arch_fn=tiny_res_bil_architecture, tag='res_bil_rep')
+    make_step('rep', arch_fn=tiny_res_max_architecture, tag='res_max_rep')
     make_eval()
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print('tests/golden total bytes:', total)

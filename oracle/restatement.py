@@ -72,9 +72,9 @@ def _scaled_shape(shape, scale):
     """ImageScaling._get_shape_ (layer_func.py:1076-1109) for the methods restated here"""
     method, factor = scale
     c, h, w = shape
-    if method == 'avg':
+    if method in ('avg', 'max'):
         if factor > 0:
-            raise AttributeError('avg can only be used for downsampling')
+            raise AttributeError('{} can only be used for downsampling'.format(method))
     elif method == 'unpool':
         if factor < 0:
             raise AttributeError('unpool can only be used for upsampling')
@@ -96,6 +96,8 @@ def _rescale(x, scale):
     method, factor = scale
     if method == 'avg':
         return F.avg_pool2d(x, -factor)
+    if method == 'max':                                       # layer_func.py:1149-1153
+        return F.max_pool2d(x, -factor)
     if method == 'bil':                                       # layer_func.py:1128-1137: tf.image.resize_bilinear,
         n, c, h, w = x.shape                                  # align_corners=True
         size = (int(h * factor), int(w * factor)) if factor > 0 else (int(-h / factor), int(-w / factor))

@@ -408,8 +408,17 @@ def space_to_depth(x, block_size, data_format='NHWC', name=None):
     return x.reshape(n, c, h, r, w, r).permute(0, 3, 5, 1, 2, 4).reshape(n, r * r * c, h, w)
 
 
+def _max_pool(value, ksize, strides, padding, data_format='NHWC', name=None):
+    """tf.nn.max_pool, NCHW, window == stride on sizes the window divides (ImageScaling 'max', layer_func.py:1149-1153);
+    the gradient goes to the first maximum of a window in row-major order, as TF's kernels route it"""
+    kh, kw = _stride_hw(ksize, data_format)
+    assert (kh, kw) == _stride_hw(strides, data_format) and value.shape[2] % kh == 0 and value.shape[3] % kw == 0
+    return F.max_pool2d(value, (kh, kw))
+
+
 nn = types.SimpleNamespace(
     avg_pool=_avg_pool,
+    max_pool=_max_pool,
     conv2d=_conv2d,
     conv2d_transpose=_conv2d_transpose,
     bias_add=_bias_add,

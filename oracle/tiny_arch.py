@@ -85,3 +85,12 @@ def tiny_res_bil_architecture():
                               {'name': 'l2_res', 'type': 'res', 'out': 16, 'act': 'relu', 'act_k': ak, 'w_nm': 's',
                                'kernel': k, 'scale': ['bil', -3], 'out_reshape': [2 * 2 * 16]},
                               {'name': 'l3_s', 'out': 16, 'op': 'd', 'act_k': ak, 'w_nm': 's'}]}
+
+
+def tiny_res_max_architecture():
+    """the residual pair with max pooling ('max', layer_func.py:1149-1153) as D's down-sampling method"""
+    arch = tiny_res_architecture()
+    for d in arch['discriminator']:
+        if d.get('scale') is not None:
+            d['scale'] = ['max', -2]
+    return arch

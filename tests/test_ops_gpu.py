@@ -619,6 +619,22 @@ def test_bilinear_resize_and_its_gradient(ops, n, c, h, w, oh, ow):
         assert np.allclose(to_nchw(got)[:, :, -1, -1], x[:, :, -1, -1], rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize('n,c,h,w,f', [(2, 3, 4, 4, 2), (3, 5, 6, 9, 3), (8, 64, 16, 16, 2), (1, 1, 2, 2, 2)])
+def test_max_pool_and_its_gradient(ops, n, c, h, w, f):
+    """'max' = tf.nn.max_pool(window = stride = f) (layer_func.py:1149-1153); ties (plenty after a relu) send the
+    gradient to the first maximum of the window"""
+    rs = np.random.RandomState(n + c)
+    x = np.maximum(rs.randn(n, c, h, w), 0.0).astype(np.float32)                # relu output: windows of zeros tie
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    ref = torch.nn.functional.max_pool2d(xt, f)
+    got = ops.max_pool(nhwc(x), f)
+    assert np.array_equal(to_nchw(got), ref.detach().numpy().astype(np.float32))
+    dy = rs.randn(*ref.shape).astype(np.float32)
+    gx, = torch.autograd.grad(ref, xt, torch.tensor(dy, dtype=torch.float64))
+    dx = ops.max_pool(nhwc(x), f, dy=nhwc(dy))
+    assert np.array_equal(to_nchw(dx), gx.numpy().astype(np.float32))
+
+
 @pytest.mark.parametrize('act', ['linear', 'relu', 'lrelu', 'tanh'])
 def test_act_and_axpby(ops, act):
     rs = np.random.RandomState(5)
