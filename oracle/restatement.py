@@ -221,8 +221,12 @@ def build_net(designs, input_shape, net_name, sn_mode='default'):
             specs.append(s)
             shape = list(out)
             continue
-        if d['scale'] is not None:
-            raise NotImplementedError('{}: scaling outside residual blocks is not restated'.format(s['scope']))
+        if d['scale'] is not None:                           # layer_func.py:1627-1629: up-sampling precedes the kernel
+            if d['op'] != 'c':
+                raise NotImplementedError('{}: scaling is restated for conv layers'.format(s['scope']))
+            if d['scale'][1] > 0:
+                shape = _scaled_shape(shape, d['scale'])
+                s['in_shape_scaled'] = list(shape)
         if d['op'] == 'd':                                   # layer_func.py:576-578
             assert len(shape) == 1, '{}: dense layer needs a flat input'.format(s['scope'])
             s['kernel_shape'] = [shape[0], d['out']]
@@ -257,6 +261,8 @@ def build_net(designs, input_shape, net_name, sn_mode='default'):
                 # layer_func.py:835: act_k=False passes isinstance(int) and zeroes the kernel;
                 # every shipped config sets act_k, and the build rejects the quirk
                 raise ValueError('{}: w_nm="s" needs a numeric act_k'.format(s['scope']))
+        if d['scale'] is not None and d['scale'][1] < 0:     # layer_func.py:1640-1642: down-sampling is the last op
+            out = _scaled_shape(out, d['scale'])
         if d['out_reshape'] is not None:
             out = list(d['out_reshape'])
         s['out_shape'] = list(out)
@@ -393,7 +399,7 @@ def sn_power_iteration(w, x, spec):
             fwd, bwd = (lambda t: t @ w.t()), (lambda t: t @ w)
     else:
         stride = d['strides']
-        in_hw = spec['in_shape'][1:] if d['op'] == 'c' else spec['op_out_shape'][1:]
+        in_hw = spec.get('in_shape_scaled', spec['in_shape'])[1:] if d['op'] == 'c' else spec['op_out_shape'][1:]
         conv = lambda t: conv2d_same(t, w, stride)                       # math_func.py:604-619
         conv_t = lambda t: conv2d_transpose_same(t, w, in_hw, stride)    # math_func.py:621-637
         fwd, bwd = (conv, conv_t) if spec['use_u'] else (conv_t, conv)   # math_func.py:527-528
@@ -500,6 +506,8 @@ def net_forward(specs, params, x, is_training=True, collect=None):
             if d['out_reshape'] is not None:
                 x = x.reshape([n] + list(d['out_reshape']))
             continue
+        if d['scale'] is not None and d['scale'][1] > 0:     # layer_func.py:1654-1656
+            x = _rescale(x, d['scale'])
         w = params[sc + '/kernel/kernel']
         if d['w_nm'] == 's':                                  # layer_func.py:884-887, 913
             sigma, x_new = sn_power_iteration(w, params[sc + '/kernel/SN/in_rand'], s)
@@ -532,6 +540,8 @@ def net_forward(specs, params, x, is_training=True, collect=None):
             x = (x - mean.reshape(axis_shape)) / torch.sqrt(var.reshape(axis_shape) + BN_EPS)
             x = x * params[sc + '/BN/BN/gamma'].reshape(axis_shape) + params[sc + '/BN/BN/beta'].reshape(axis_shape)
         x = _act(x, d['act'])
+        if d['scale'] is not None and d['scale'][1] < 0:     # layer_func.py:1682-1684
+            x = _rescale(x, d['scale'])
         if collect is not None:
             collect[sc + '/out'] = x.detach()
             collect[sc + '/out_live'] = x              # graph-attached (tests differentiate w.r.t. it)

@@ -88,9 +88,20 @@ def tiny_res_bil_architecture():
 
 
 def tiny_res_max_architecture():
-    """the residual pair with max pooling ('max', layer_func.py:1149-1153) as D's down-sampling method"""
-    arch = tiny_res_architecture()
-    for d in arch['discriminator']:
-        if d.get('scale') is not None:
-            d['scale'] = ['max', -2]
-    return arch
+    """max pooling ('max', layer_func.py:1149-1153) as the down-sampling method, and scaling on PLAIN layers as well
+    (layer_func.py:1627-1642: up-sampling in front of the kernel, down-sampling behind the activation): G's second
+    stage is a plain conv layer with 'unpool', D's first a plain SN conv layer with 'max'"""
+    ak = float(np.power(64.0, 0.125))
+    k = [3, 3, 1]
+    return {'input': [(3, 16, 16)], 'code': [(24, 'linear')],
+            'generator': [{'name': 'l1', 'out': 32 * 4 * 4, 'op': 'd', 'out_reshape': [32, 4, 4]},
+                          {'name': 'l2_res', 'type': 'res', 'out': 16, 'act': 'relu', 'act_nm': 'bn', 'kernel': k,
+                           'scale': ['unpool', 2]},
+                          {'name': 'l3_up', 'out': 16, 'act': 'relu', 'act_nm': 'bn', 'scale': ['unpool', 2]},
+                          {'name': 'l4_t16', 'out': 3, 'act': 'tanh'}],
+            'discriminator': [{'name': 'l1_ds', 'out': 16, 'act': 'lrelu', 'act_k': ak, 'w_nm': 's', 'scale': ['max', -2]},
+                              {'name': 'l2_res', 'type': 'res', 'out': 32, 'act': 'relu', 'act_k': ak, 'w_nm': 's',
+                               'kernel': k, 'scale': ['max', -2]},
+                              {'name': 'l3_res', 'type': 'res_i', 'out': 32, 'act': 'relu', 'act_k': ak, 'w_nm': 's',
+                               'out_reshape': [4 * 4 * 32]},
+                              {'name': 'l4_s', 'out': 16, 'op': 'd', 'act_k': ak, 'w_nm': 's'}]}
