@@ -45,6 +45,8 @@ def parse():
                     help='one step, then only the dominant-kernel probe (for rocprofv3: its kernel stats row is then '
                          'exactly the launches that roofline.dominant_kernel times)')
     ap.add_argument('--probe-reps', type=int, default=20)
+    ap.add_argument('--engine', default='auto', choices=['auto', 'tape'],
+                    help="'tape': run a DCGAN config on the primitive-op engine too (it is what residual-block configs use)")
     return ap.parse_args()
 
 
@@ -124,7 +126,7 @@ def main():
     arch, lr = configs.CONFIGS[args.config]()
     B = args.batch or {'celeba': 128, 'lsun_resnet': 32}.get(args.config, 64)
     from mmdgan_hip.tape import TapeEngine, has_residual_blocks
-    tape = has_residual_blocks(arch)                     # residual blocks: the primitive-op engine, eager issue only
+    tape = has_residual_blocks(arch) or args.engine == 'tape'   # residual blocks: the primitive-op engine, eager issue only
     if tape:
         GanEngine = TapeEngine                           # noqa: F811
         args.no_graph = True
@@ -209,7 +211,8 @@ def main():
             'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%s %dx%d %s, batch %d per GPU, %s loss, lr %g/%g, TF-Adam, one G+D step'
-                                   % (args.config, h, w, 'ResNet-SN' if tape else 'DCGAN-SN', B, args.loss, lr[0], lr[1]),
+                                   % (args.config, h, w, ('ResNet-SN' if has_residual_blocks(arch) else 'DCGAN-SN (primitive-op engine)') if tape else 'DCGAN-SN',
+                                      B, args.loss, lr[0], lr[1]),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world, 'launch_mode': mode},
             'loss_gen': float(losses[0]), 'loss_dis': float(losses[1]),
         }

@@ -40,12 +40,14 @@ def _pick(value, index):                                                 # Layer
 class _Kernel:
     """one ParametricOperation (layer_func.py:480-1038): a dense or conv kernel, optional bias, optional SN"""
 
-    def __init__(self, scope, op, kernel_shape, in_ref, out_ref, act, w_nm, act_k, bias_name, stride, sn_mode):
+    def __init__(self, scope, op, kernel_shape, in_ref, out_ref, act, w_nm, act_k, bias_name, stride, sn_mode, out=None):
         self.scope, self.op, self.kernel_shape = scope, op, list(kernel_shape)
         self.in_ref, self.out_ref = list(in_ref), list(out_ref)          # reference shapes without batch
         self.act_init, self.bias_name, self.stride = act, bias_name, stride
-        self.R = kernel_shape[0] if op == 'c' else 1
-        self.out = kernel_shape[-1]
+        self.R = kernel_shape[0] if op in ('c', 'tc') else 1
+        self.out = kernel_shape[-1] if out is None else out           # a tc kernel is [R, R, out, in]
+        if op == 'tc' and w_nm is not None:
+            raise NotImplementedError('{}: spectral norm on tc layers is outside the hot path'.format(scope))
         self.sn, self.act_k, self.pim = w_nm == 's', act_k, False
         self.row_perm = self.col_perm = None                             # dense kernels at an NCHW <-> NHWC seam
         if w_nm not in (None, 's'):
@@ -178,6 +180,20 @@ class _Net:
             raise NotImplementedError('{}: {} is not implemented.'.format(scope, d['type']))   # :2067
         elif d['op'] == 'i':                                             # identity kernel, then BN / activation
             y = self._bn_act(scope + '/BN', x, d['act']) if bn else self._emit('act', [x], self.shapes[x], act=d['act'])
+        elif d['op'] == 'tc':                                            # transposed conv (layer_func.py:590-600, 918-928)
+            c, h, w = self.shapes[x]
+            R, stride, out = d['kernel'], d['strides'], d['out']
+            if d['dilation'] != 1 or d['padding'] != 'SAME':
+                raise NotImplementedError('{}: dilation / VALID are not built'.format(scope))
+            out_ref = [out, h * stride, w * stride]
+            k = _Kernel(scope + '/kernel', 'tc', [R, R, out, c], [c, h, w], out_ref, d['act'], d['w_nm'], d['act_k'],
+                        scope + '/bias/bias' if d['bias'] is not None else None, stride, self.sn_mode, out=out)
+            self.kernels.append(k)
+            y = self._emit('tconv', [x], out_ref, k=k)
+            if bn:
+                y = self._bn_act(scope + '/BN', y, d['act'])
+            elif d['act'] != 'linear':
+                y = self._emit('act', [y], self.shapes[y], act=d['act'])
         elif d['op'] in ('d', 'c'):
             if d['scale'] is not None and d['scale'][1] > 0:             # :1627-1629
                 x = self._scale(x, d['scale'])
@@ -197,7 +213,7 @@ class _Net:
             if d['scale'] is not None and d['scale'][1] < 0:             # :1640-1642
                 y = self._scale(y, d['scale'])
         else:
-            raise NotImplementedError('{}: op {} is served by the DCGAN engine only'.format(scope, d['op']))
+            raise AttributeError('layer op {} not supported.'.format(d['op']))                # layer_func.py:1275
         if d['out_reshape'] is not None:
             y = self._reshape(y, d['out_reshape'])
         return y
@@ -304,7 +320,7 @@ class _Net:
     def _creation_order(self):
         """kernels and BN ops in the order the primitives use them (= the reference's variable creation order)"""
         for p in self.prims:
-            if p['kind'] in ('dense', 'conv'):
+            if p['kind'] in ('dense', 'conv', 'tconv'):
                 yield p['k']
             elif p['kind'] == 'bn':
                 yield (p['prefix'], self.shapes[p['out']][0])
@@ -466,18 +482,23 @@ class TapeEngine:
         rows_d = (2 * self.B,) if self._d_has_bn else (2 * self.B, self.B)
         for net, batches in ((self.gen, (self.B,)), (self.dis, rows_d)):
             for k in net.kernels:
-                if k.op != 'c' or not self._side:
+                if k.op not in ('c', 'tc') or not self._side:
                     continue
-                c, h, w = k.in_ref
+                if k.op == 'c':
+                    c, h, w, kout = k.in_ref[0], k.in_ref[1], k.in_ref[2], k.out
+                else:                                  # the conv whose input-gradient the tc layer is: its input is
+                    c, h, w, kout = k.out, k.out_ref[1], k.out_ref[2], k.in_ref[0]     # the layer's OUTPUT
                 table = {}
                 for dgrad in (False, True):
                     u = None
                     for n in batches:
-                        if (not dgrad and n != batches[0]) or not ops.wino_eligible(n, h, w, c, k.out, k.R, k.stride, dgrad):
+                        # the forward pass of a conv (= the backward pass of a tc layer) runs at one batch size only
+                        single = (not dgrad) if k.op == 'c' else dgrad
+                        if (single and n != batches[0]) or not ops.wino_eligible(n, h, w, c, kout, k.R, k.stride, dgrad):
                             continue
                         if u is None:
                             lead = (16,) if k.R == 3 else (4, 9)
-                            u = torch.empty(lead + ((k.out, c) if dgrad else (c, k.out)), device=self.device)
+                            u = torch.empty(lead + ((kout, c) if dgrad else (c, kout)), device=self.device)
                         table[(dgrad, n)] = u
                 if table:
                     self._wino[k.scope] = (net, k, table)
@@ -571,6 +592,12 @@ class TapeEngine:
                 else:
                     ops.conv2d_fwd(a, net.p(k.w_name), k.stride, bias=bias, scale=scale, out=y,
                                    wino=self._wino_of(k, False, n) if (training and self._in_step) else None)
+            elif kind == 'tconv':                                        # y = the input-gradient of a conv with kernel w
+                k = p['k']
+                bias = net.p(k.bias_name) if k.bias_name is not None else None
+                y = self._buf(key, out_shape)
+                ops.conv2d_dgrad(a, net.p(k.w_name), (out_shape[1], out_shape[2]), k.stride, bias=bias, out=y,
+                                 wino=self._wino_of(k, True, n) if (training and self._in_step) else None)
             elif kind == 'bn':
                 y = self._buf(key, out_shape)
                 c = out_shape[-1]
@@ -634,7 +661,7 @@ class TapeEngine:
                 continue
             kind, dy = p['kind'], grads.pop(p['out'])
             vin = p['ins'][0]
-            if vin == 0 and not need_input_grad and kind not in ('dense', 'conv', 'bn'):
+            if vin == 0 and not need_input_grad and kind not in ('dense', 'conv', 'tconv', 'bn'):
                 continue
             key = (tag, net.name, i, 'd')
             a = sl(vals[vin])
@@ -675,6 +702,25 @@ class TapeEngine:
                     else:
                         ops.conv2d_dgrad(dy, w, (in_shape[1], in_shape[2]), k.stride, scale=scale, out=dx,
                                          wino=self._wino_of(k, True, n))
+                    give(vin, dx)
+            elif kind == 'tconv':
+                k = p['k']
+                w = net.p(k.w_name)
+                if param_grads:
+                    def tconv_grads(k=k, a=a, dy=dy):
+                        if k.bias_name is not None:
+                            ops.colsum(dy.reshape(-1, dy.shape[-1]), out=net.g(k.bias_name))
+                        ops.conv2d_wgrad(dy, a, k.R, k.stride, out=net.g(k.w_name))    # W[R,R,out,in]: roles swapped
+                    thin = k.kernel_shape[2] % 64 or k.kernel_shape[3] % 64
+                    if self._side and not thin:
+                        self._wg_stream.wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(self._wg_stream):
+                            tconv_grads()
+                    else:
+                        tconv_grads()
+                if want_dx:                                              # d/dx of dgrad(x, W) = conv(dy, W)
+                    dx = self._buf(key, in_shape)
+                    ops.conv2d_fwd(dy, w, k.stride, out=dx, wino=self._wino_of(k, False, n))
                     give(vin, dx)
             elif kind == 'bn':
                 if rows is not None:

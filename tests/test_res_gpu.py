@@ -213,3 +213,45 @@ def test_res_inference_and_api_selection(tmp_path):
             assert np.array_equal(v, var[k]), k
     finally:
         FLAGS.SYNTHETIC_DATA, FLAGS.SILENT_MODE = False, False
+
+
+@pytest.mark.parametrize('loss_type', ['rep', 'rmb'])
+def test_primitive_op_engine_reproduces_the_dcgan_fixture(loss_type):
+    """the other engine on the hot path's own fixture: dense / conv / transposed-conv / BN layers lowered to primitives
+    give the reference's losses, spectral norms, gradients and variables of the width/8 CIFAR net too - two
+    independently scheduled implementations over the same kernels agreeing with the same reference run"""
+    from mmdgan_hip.tape import TapeEngine
+    from tiny_arch import tiny_architecture
+    fx = load(golden('step_tiny_%s.npz' % loss_type)[0])
+    B = int(fx['B'])
+    eng = TapeEngine(tiny_architecture(), loss_type, tuple(fx['lr']), batch_size=B)
+    init = {k[len('init/'):]: v for k, v in fx.items() if k.startswith('init/')}
+    assert sorted(init) == sorted(eng.variable_names())
+    eng.set_variables(init)
+    n_steps = fx['z'].shape[0]
+    for step in range(n_steps):
+        eng.step(nhwc(fx['real'][step]), torch.as_tensor(fx['z'][step]).cuda())
+        pre = 'step%d/' % step
+        losses = eng.losses.cpu().numpy().astype(np.float64)
+        escale = float(max(losses[2:5]))
+        for idx, name in ((0, 'loss_gen'), (1, 'loss_dis')):
+            ref = float(fx[pre + name + '_f64'])
+            assert abs(losses[idx] - ref) <= RTOL * abs(ref) + 4e-7 * escale, (step, name, losses[idx], ref)
+        sig = eng.sigmas()
+        for k, v in fx.items():
+            if k.startswith(pre + 'sigma/') and k.endswith('_f64'):
+                scope = k[len(pre + 'sigma/'):-len('_f64')]
+                assert abs(sig[scope] - float(v)) <= RTOL * float(v), (step, scope)
+    pre = 'step%d/' % (n_steps - 1)
+    if any(k.startswith(pre + 'grad/') for k in fx):
+        grads = eng.get_variables(grad=True)
+        gscale = {net: max(np.abs(fx[pre + 'grad/' + n + '_f64']).max() for n in grads if n.startswith(net))
+                  for net in ('gen', 'dis')}
+        for n, g in grads.items():
+            ref = fx[pre + 'grad/' + n + '_f64']
+            assert close(g, ref, RTOL, 1e-6 * gscale[n[:3]]), (n, np.abs(g - ref).max(), np.abs(ref).max())
+    for n, v in eng.get_variables().items():
+        if n == 'dis/l8_s/bias/bias':
+            continue                                               # analytically zero gradient (test_step_gpu.py)
+        ref = fx['final/' + n + '_f64']
+        assert close(v, ref, RTOL, 0.02 * float(fx['lr'].max())), (n, np.abs(v - ref).max(), np.abs(ref).max())
