@@ -6,7 +6,9 @@ TEST INFRASTRUCTURE.  Only `tests/`, `__graft_entry__.smoke()` and
 
 This is a from-scratch restatement (torch-CPU tensors as the array library,
 fp32 or fp64 selectable) of exactly the slice of richardwth/MMD-GAN that
-SURVEY.md section 8 puts on the hot path.  Every function cites the reference
+SURVEY.md section 8 puts on the hot path, and of the section 8(f) rows built after
+it (the other in-kernel losses, flattened-kernel spectral norm, residual blocks
+and scaling ops, FID / sprite helpers).  Every function cites the reference
 file:line it follows (paths relative to /root/reference).  It is pinned against
 the reference's own code, executed through `oracle/tf1_shim.py`, by the golden
 vectors in `tests/golden/` (`oracle/make_golden.py` writes them,
