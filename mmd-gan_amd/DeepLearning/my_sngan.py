@@ -121,8 +121,8 @@ class SNGan(object):
                       do_sprite=True, ckpt_file=None, num_threads=7):
         """G(code_x) with BN moving statistics, clipped to [-1,1], written as the reference's sprite
         <summary_folder>/<filename>_g_<sub_folder>_<step>_<mesh_mode>.png (my_sngan.py:499-581); returns the NCHW
-        array.  code_x defaults to N(0,1) draws (MeshCode's mesh modes, real-sample sprites, discriminator scores and
-        the TensorBoard embedding are not built)."""
+        array.  code_x defaults to MeshCode(...).get_batch(mesh_mode) (real-sample sprites, discriminator scores and the
+        TensorBoard embedding are not built)."""
         if self.engine is None:
             raise RuntimeError('eval_sampling: train (or load) a model first')
         if real_sample or get_dis_score or do_embedding:
@@ -133,8 +133,9 @@ class SNGan(object):
         elif code_x is not None:
             assert code_x.shape[0] == mesh_num[0] * mesh_num[1]               # my_sngan.py:526-527
         n = mesh_num[0] * mesh_num[1]
-        if code_x is None:
-            code_x = np.random.randn(n, self.code_size).astype(np.float32)
+        if code_x is None:                                                    # my_sngan.py:545-547
+            from GeneralTools.math_func import MeshCode
+            code_x = MeshCode(self.code_size, mesh_num=mesh_num).get_batch(mesh_mode, name='code_x')
         code_x = torch.as_tensor(np.asarray(code_x, np.float32)).cuda()
         outs = []
         for i in range(0, code_x.shape[0], self.engine.B):

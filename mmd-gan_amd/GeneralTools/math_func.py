@@ -101,3 +101,57 @@ def trace_sqrt_product_np(cov1, cov2):
     """trace(sqrt(cov1 cov2)) through sqrt(cov1) cov2 sqrt(cov1) (math_func.py:2686-2699)."""
     root1 = sqrt_sym_mat_np(cov1)
     return np.trace(sqrt_sym_mat_np(root1.dot(cov2).dot(root1)))
+
+
+class MeshCode(object):
+    """codes for a grid of samples (math_func.py:220-340), as NumPy float32 arrays: 'random' N(0,1) draws, 'sine' a
+    two-angle interpolation between four support codes, 'feature' one latent feature varied per row, and the plain
+    2-D grid.  Row j * mesh_num[0] + i of the 'sine' batch is
+        cos(phi_i) (cos(psi_j) z0 + sin(psi_j) z1) + sin(phi_i) (cos(psi_j) z2 + sin(psi_j) z3),
+    phi_i over mesh_num[0] and psi_j over mesh_num[1] points of [0, pi/4]."""
+
+    def __init__(self, code_length, mesh_num=None):
+        self.D = code_length
+        self.mesh_num = (10, 10) if mesh_num is None else tuple(mesh_num)
+
+    def get_batch(self, mesh_mode, name=None):
+        if mesh_mode in (0, 'random'):
+            return self.by_random(name)
+        if mesh_mode in (1, 'sine'):
+            return self.by_sine(name=name)
+        if mesh_mode in (2, 'feature'):
+            return self.by_feature(name=name)
+        raise AttributeError('mesh_mode is not supported.')                    # math_func.py:244
+
+    def by_random(self, name=None):
+        return np.random.randn(self.mesh_num[0] * self.mesh_num[1], self.D).astype(np.float32)
+
+    def by_sine(self, z_support=None, name=None):
+        z = np.random.randn(4, self.D) if z_support is None else np.asarray(z_support)
+        z = z.astype(np.float32)
+        phi = np.float32(np.pi / 4.0 * np.linspace(0.0, 1.0, self.mesh_num[0]))
+        psi = np.float32(np.pi / 4.0 * np.linspace(0.0, 1.0, self.mesh_num[1]))
+        low = np.cos(psi)[:, None] * z[0] + np.sin(psi)[:, None] * z[1]        # [mesh_num[1], D]
+        high = np.cos(psi)[:, None] * z[2] + np.sin(psi)[:, None] * z[3]
+        batch = np.cos(phi)[None, :, None] * low[:, None, :] + np.sin(phi)[None, :, None] * high[:, None, :]
+        return batch.reshape(self.mesh_num[0] * self.mesh_num[1], self.D).astype(np.float32)
+
+    def by_feature(self, grid=2.0, name=None):
+        """feature f (a random one of the D, distinct per row group) takes mesh_num[1] values in [-grid, grid], all
+        other features 0; the reference shuffles the columns with tf.random_shuffle"""
+        values = np.float32(np.linspace(-grid, grid, self.mesh_num[1]))
+        batch = np.zeros((self.mesh_num[0], self.mesh_num[1], self.D), np.float32)
+        for f in range(min(self.mesh_num[0], self.D)):
+            batch[f, :, f] = values
+        batch = batch.reshape(-1, self.D)
+        return batch[:, np.random.permutation(self.D)]
+
+    def simple_grid(self, grid=None):
+        if self.D != 2:
+            raise AttributeError('Code length has to be two')                  # math_func.py:323
+        if grid is None:
+            grid = np.array([[-1.0, 1.0], [-1.0, 1.0]], dtype=np.float32)
+        x = np.linspace(grid[0][0], grid[0][1], self.mesh_num[0])
+        y = np.linspace(grid[1][0], grid[1][1], self.mesh_num[1])
+        z = np.stack([np.repeat(x, self.mesh_num[1]), np.tile(y, self.mesh_num[0])], axis=1)
+        return z, x, y

@@ -390,6 +390,19 @@ def make_eval():
     out['fid_rank_deficient'] = np.float64(ref_graph.GenerativeModelMetric.my_fid_from_pool3(z, y))
     np.savez_compressed(os.path.join(OUT, 'eval_fid.npz'), **out)
 
+    # MeshCode (math_func.py:220-340): the deterministic code layouts eval_sampling can ask for
+    mc = {}
+    support = rs.randn(4, 5).astype(np.float32)
+    for key, dt in DT.items():
+        tf.set_dtype(dt)
+        code = ref_math.MeshCode(5, mesh_num=(3, 4))
+        mc['sine_' + key] = npy(code.by_sine(z_support=torch.tensor(support, dtype=dt)))
+    tf.set_dtype(torch.float32)
+    z, gx, gy = ref_math.MeshCode(2, mesh_num=(3, 4)).simple_grid()
+    z2, _, _ = ref_math.MeshCode(2, mesh_num=(2, 5)).simple_grid(np.array([[-2.0, 0.5], [1.0, 3.0]], dtype=np.float32))
+    mc.update({'support': support, 'grid_z': z, 'grid_x': gx, 'grid_y': gy, 'grid2_z': z2})
+    np.savez_compressed(os.path.join(OUT, 'eval_meshcode.npz'), **mc)
+
     # sprite: capture what write_sprite hands to scipy.misc.imsave (removed from SciPy long ago)
     import types
     import scipy

@@ -275,6 +275,18 @@ def add(a, b, name=None):
     return a + b
 
 
+def cos(x, name=None):
+    return torch.cos(_t(x))
+
+
+def sin(x, name=None):
+    return torch.sin(_t(x))
+
+
+def eye(num_rows, num_columns=None, dtype=None, name=None):
+    return torch.eye(int(num_rows), int(num_columns if num_columns is not None else num_rows), dtype=DTYPE)
+
+
 def exp(x, name=None):
     return torch.exp(x)
 

@@ -76,3 +76,23 @@ def test_sprite_wrapper_names_and_never_overwrites(tmp_path):
         G.write_sprite_wrapper(imgs * 0, [2, 5], 'cifar', file_folder=str(tmp_path), file_index='_g_t_7_0',
                                image_format='channels_first')
     assert np.array_equal(np.asarray(Image.open(path)), SPRITE['rgb_mesh/sprite'])
+
+
+def test_meshcode_matches_reference():
+    """MeshCode.by_sine / simple_grid (math_func.py:220-340) against the reference's outputs; the random modes by shape"""
+    mc = load(golden('eval_meshcode.npz')[0])
+    code = M.MeshCode(5, mesh_num=(3, 4))
+    got = code.by_sine(z_support=mc['support'])
+    assert got.dtype == np.float32 and np.allclose(got, mc['sine_f64'], rtol=0, atol=3e-7)
+    assert np.abs(got - mc['sine_f32']).max() <= 3e-7
+    z, x, y = M.MeshCode(2, mesh_num=(3, 4)).simple_grid()
+    assert np.array_equal(z, mc['grid_z']) and np.array_equal(x, mc['grid_x']) and np.array_equal(y, mc['grid_y'])
+    z2, _, _ = M.MeshCode(2, mesh_num=(2, 5)).simple_grid(np.array([[-2.0, 0.5], [1.0, 3.0]], dtype=np.float32))
+    assert np.array_equal(z2, mc['grid2_z'])
+    assert code.get_batch(0).shape == (12, 5) and code.get_batch('sine').shape == (12, 5)
+    f = M.MeshCode(6, mesh_num=(3, 4)).get_batch(2)
+    assert f.shape == (12, 6) and np.all((f != 0).sum(axis=1) <= 1) and np.isclose(np.abs(f).max(), 2.0)
+    with pytest.raises(AttributeError, match='mesh_mode is not supported'):
+        code.get_batch(7)
+    with pytest.raises(AttributeError, match='Code length has to be two'):
+        code.simple_grid()
