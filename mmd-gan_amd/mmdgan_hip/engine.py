@@ -818,15 +818,17 @@ class GanEngine:
             self._static_z.normal_()                                         # my_sngan.py:123-124
         else:
             self._static_z.copy_(z)
-        if real_nhwc is not None:
-            self._static_real.copy_(real_nhwc)
-        if self.use_graph and self.dist_group is None:
+        graph = self.use_graph and self.dist_group is None
+        if real_nhwc is not None and graph:
+            self._static_real.copy_(real_nhwc)                               # the captured graph reads this buffer
+        if graph:
             if self._graph is None:
                 self._capture()
             else:
                 self._graph.replay()
         else:
-            self._step_body(self._static_z, self._static_real)
+            # eager issue: the batch goes straight into the first half of D's input buffer (one copy, not two)
+            self._step_body(self._static_z, real_nhwc if real_nhwc is not None else self._static_real)
         self.global_step += 1                                                # tied to the D update, my_sngan.py:424
 
     def _capture(self):
