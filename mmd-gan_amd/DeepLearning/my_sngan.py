@@ -59,7 +59,7 @@ class SNGan(object):
                                     batch_size=batch_size, seed=seed, dist_group=self.dist_group,
                                     sn_mode=FLAGS.SPECTRAL_NORM_MODE,                # layer_func.py:802-814
                                     # eager issue measured faster than replaying the 3-branch hipGraph when the
-                                    # host keeps up (2.55 vs 2.72 ms/step, bench.py tries both); MMDGAN_HIP_GRAPH=1
+                                    # host keeps up (2.35 vs 2.69 ms/step, bench.py tries both); MMDGAN_HIP_GRAPH=1
                                     # for hosts that do not
                                     use_graph=self.dist_group is None and os.environ.get('MMDGAN_HIP_GRAPH') == '1')
         else:
