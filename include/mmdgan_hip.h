@@ -249,6 +249,13 @@ int mmdgan_bilinear_resize(const float *src, float *dst, int N, int H, int W, in
  * dy == NULL: out [N,P,Q,C] = window maxima.  dy != NULL ([N,P,Q,C]): out [N, P*factor, Q*factor, C] = the gradient
  * w.r.t. x - dy at the first maximum of each window (row-major), zero elsewhere; every element of out is written. */
 int mmdgan_max_pool(const float *x, const float *dy, float *out, int N, int P, int Q, int C, int factor, void *stream);
+/* The scaling op of a residual block folded into the 3x3 stride-1 conv next to it (layer_func.py:1687-1842 order of ops):
+ *   mode 0: avg-pool /2 AFTER the conv  = one 4x4 stride-2 conv;  dst [4,4,C,K] = 1/4 * (1_2 (*) w), for mmdgan_conv2d_fwd
+ *   mode 1: 'unpool' x2 BEFORE the conv = one 4x4 stride-2 transposed conv; dst [4,4,K,C] (flipped, transposed), for the
+ *           forward form of mmdgan_conv2d_dgrad
+ * with w [3,3,C,K] the block's HWIO kernel.  grad = 1 is the adjoint: src = the gradient w.r.t. the 4x4 kernel (same
+ * layout as dst above), dst [3,3,C,K] = the gradient w.r.t. w (overwritten). */
+int mmdgan_compose_scaled_conv(const float *src, float *dst, int C, int K, int mode, int grad, void *stream);
 int mmdgan_act_fwd(const float *x, float *y, long n, int act, void *stream);
 int mmdgan_act_bwd(const float *dy, const float *y, float *dx, long n, int act, int accumulate, void *stream);
 int mmdgan_axpby(const float *a, float alpha, const float *b, float beta, float *out, long n, void *stream);

@@ -176,6 +176,74 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float *__restrict__ 
     }
 }
 
+// A residual block's scaling op and the 3x3 conv next to it are ONE linear map with a 4x4 stride-2 kernel:
+//   MODE 0  avgpool/2 o conv3x3(W):  y[p] = 1/4 sum_{i<2} sum_a W[a] x[2p + i + a - 1]  = conv4x4/2 with  1/4 * (1_2 (*) W)
+//   MODE 1  conv3x3(W) o unpool x2:  y[2p] = W[0] x[p-1] + (W[1]+W[2]) x[p],  y[2p+1] = (W[0]+W[1]) x[p] + W[2] x[p+1]
+//           = the input-gradient form (transposed conv 4x4/2) with the flipped 1_2 (*) W, kernel stored [4,4,K,C]
+// (1_2 (*) W = full convolution with [1,1], per dimension [W0, W0+W1, W1+W2, W2]).  4 taps per pixel instead of 9 and no
+// up-sampled / un-pooled tensor in HBM.  GRAD: the adjoint map (gradient w.r.t. the 4x4 kernel -> gradient w.r.t. W).
+template <int MODE, bool GRAD>
+__global__ __launch_bounds__(256) void compose_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int K) {
+    const long total = (long)C * K;
+    const long stride = (long)gridDim.x * 256;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {     // o = c*K + k
+        const int c = (int)(o / K), k = (int)(o - (long)c * K);
+        const float s = MODE == 0 ? 0.25f : 1.f;
+        // F[r][a] = 1 where tap a of W contributes to tap r of the 4-wide kernel
+        //   MODE 0: r = a + i (i = 0,1);  MODE 1: flipped: r = 3 - (a + i)
+        auto idx4 = [&](int r, int t) -> long {
+            return MODE == 0 ? ((long)(r * 4 + t) * C + c) * K + k : ((long)(r * 4 + t) * K + k) * C + c;
+        };
+        if (!GRAD) {
+            float w[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) w[a][b] = src[((long)(a * 3 + b) * C + c) * K + k];
+            float out[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) out[r][t] = 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int r = MODE == 0 ? a + i : 3 - (a + i), t = MODE == 0 ? b + j : 3 - (b + j);
+                            out[r][t] += w[a][b];
+                        }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dst[idx4(r, t)] = out[r][t] * s;
+        } else {
+            float g[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) g[r][t] = src[idx4(r, t)];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int r = MODE == 0 ? a + i : 3 - (a + i), t = MODE == 0 ? b + j : 3 - (b + j);
+                            acc += g[r][t];
+                        }
+                    dst[((long)(a * 3 + b) * C + c) * K + k] = acc * s;
+                }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void act_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, long n, int act) {
     const long stride = (long)gridDim.x * 256;
     for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < n; o += stride) y[o] = act_fwd(x[o], act);
@@ -291,4 +359,18 @@ extern "C" int mmdgan_max_pool(const float *x, const float *dy, float *out, int 
     if (dy) hipLaunchKernelGGL(maxpool_kernel<true>, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, x, dy, out, total, P, Q, C, factor);
     else hipLaunchKernelGGL(maxpool_kernel<false>, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, x, dy, out, total, P, Q, C, factor);
     return check_launch("max_pool");
+}
+
+extern "C" int mmdgan_compose_scaled_conv(const float *src, float *dst, int C, int K, int mode, int grad, void *stream) {
+    MMDGAN_REQUIRE(src && dst && C >= 1 && K >= 1 && (mode == 0 || mode == 1), "compose_scaled_conv: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 g(grid_of((long)C * K));
+    if (mode == 0) {
+        if (grad) hipLaunchKernelGGL((compose_kernel<0, true>), g, dim3(256), 0, st, src, dst, C, K);
+        else hipLaunchKernelGGL((compose_kernel<0, false>), g, dim3(256), 0, st, src, dst, C, K);
+    } else {
+        if (grad) hipLaunchKernelGGL((compose_kernel<1, true>), g, dim3(256), 0, st, src, dst, C, K);
+        else hipLaunchKernelGGL((compose_kernel<1, false>), g, dim3(256), 0, st, src, dst, C, K);
+    }
+    return check_launch("compose_scaled_conv");
 }

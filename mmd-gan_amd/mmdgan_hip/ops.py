@@ -402,6 +402,29 @@ def max_pool(x, factor=2, dy=None, out=None):
     return out
 
 
+def compose_scaled_conv(w3, mode, out=None):
+    """w3 [3,3,C,K] -> the 4x4 stride-2 kernel of avgpool/2 o conv (mode 'avg': [4,4,C,K], use with conv2d_fwd) or of
+    conv o unpool x2 (mode 'unpool': [4,4,K,C], use with the forward form of conv2d_dgrad)"""
+    lib = require_device()
+    _, _, C, K = w3.shape
+    m = {'avg': 0, 'unpool': 1}[mode]
+    if out is None:
+        out = torch.empty((4, 4, C, K) if m == 0 else (4, 4, K, C), device=w3.device, dtype=torch.float32)
+    check(lib.mmdgan_compose_scaled_conv(_p(w3), _p(out), C, K, m, 0, _stream()), 'compose_scaled_conv')
+    return out
+
+
+def compose_scaled_conv_grad(d4, mode, out=None):
+    """the adjoint: gradient w.r.t. the composed 4x4 kernel -> gradient w.r.t. the 3x3 kernel [3,3,C,K]"""
+    lib = require_device()
+    m = {'avg': 0, 'unpool': 1}[mode]
+    C, K = (d4.shape[2], d4.shape[3]) if m == 0 else (d4.shape[3], d4.shape[2])
+    if out is None:
+        out = torch.empty((3, 3, C, K), device=d4.device, dtype=torch.float32)
+    check(lib.mmdgan_compose_scaled_conv(_p(d4), _p(out), C, K, m, 1, _stream()), 'compose_scaled_conv_grad')
+    return out
+
+
 def act_fwd(x, act, out=None):
     lib = require_device()
     if out is None:

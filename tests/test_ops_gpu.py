@@ -635,6 +635,28 @@ def test_max_pool_and_its_gradient(ops, n, c, h, w, f):
     assert np.array_equal(to_nchw(dx), gx.numpy().astype(np.float32))
 
 
+@pytest.mark.parametrize('n,h,c,k', [(2, 8, 8, 64), (3, 6, 5, 3), (4, 16, 64, 128), (2, 4, 128, 64), (1, 2, 3, 5)])
+def test_scaling_folded_into_the_conv(ops, n, h, c, k):
+    """avgpool/2 o conv3x3 and conv3x3 o unpool x2 as single 4x4 stride-2 (transposed) convs with composed kernels:
+    same results as the two-op form, and the kernel-gradient adjoint"""
+    rs = np.random.RandomState(n + c + k)
+    w = dev((rs.randn(3, 3, c, k) / np.sqrt(9 * c)).astype(np.float32))
+    x = dev(rs.uniform(-1, 1, (n, h, h, c)).astype(np.float32))
+    b = dev((rs.randn(k) * 0.1).astype(np.float32))
+    two = ops.resample_down(ops.conv2d_fwd(x, w, 1, bias=b), 2)
+    one = ops.conv2d_fwd(x, ops.compose_scaled_conv(w, 'avg'), 2, bias=b)
+    assert rel_err(one.cpu().numpy(), two.cpu().numpy()) <= 5e-6
+    two = ops.conv2d_fwd(ops.resample_up(x, 2), w, 1, bias=b)
+    one = ops.conv2d_dgrad(x, ops.compose_scaled_conv(w, 'unpool'), (2 * h, 2 * h), 2, bias=b)
+    assert rel_err(one.cpu().numpy(), two.cpu().numpy()) <= 5e-6
+    for mode in ('avg', 'unpool'):
+        w4 = ops.compose_scaled_conv(w, mode)
+        d4 = dev(rs.randn(*w4.shape).astype(np.float32))
+        lhs = float((w4.double() * d4.double()).sum())
+        rhs = float((w.double() * ops.compose_scaled_conv_grad(d4, mode).double()).sum())
+        assert abs(lhs - rhs) <= 1e-6 * max(abs(lhs), 1.0), mode
+
+
 @pytest.mark.parametrize('act', ['linear', 'relu', 'lrelu', 'tanh'])
 def test_act_and_axpby(ops, act):
     rs = np.random.RandomState(5)
