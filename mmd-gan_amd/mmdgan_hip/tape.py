@@ -49,6 +49,7 @@ class _Kernel:
         if op == 'tc' and w_nm is not None:
             raise NotImplementedError('{}: spectral norm on tc layers is outside the hot path'.format(scope))
         self.sn, self.act_k, self.pim = w_nm == 's', act_k, False
+        self.fold = None                                                 # 'unpool' / 'avg': scaling folded into this conv
         self.row_perm = self.col_perm = None                             # dense kernels at an NCHW <-> NHWC seam
         if w_nm not in (None, 's'):
             raise NotImplementedError('{}: {} method not implemented'.format(scope, w_nm))       # layer_func.py:824
@@ -84,6 +85,9 @@ class _Net:
 
     def __init__(self, designs, in_ref, name, device, rng, sn_mode):
         self.name, self.device, self.sn_mode = name, device, sn_mode
+        # fold a block's 'unpool' x2 / 'avg' /2 into the 3x3 conv next to it (one 4x4 stride-2 launch: 4 taps per pixel
+        # instead of 9, no up-sampled tensor in HBM; ResNet-SN config 7.32 -> 6.57 ms per step); MMDGAN_TAPE_COMPOSE=0: two ops
+        self.compose = os.environ.get('MMDGAN_TAPE_COMPOSE', '1') != '0'
         self.prims, self.kernels, self.bns = [], [], []
         self._nval = 1                                                   # value 0 is the net input
         self.shapes = {0: list(in_ref)}                                  # value id -> reference shape (no batch)
@@ -105,8 +109,13 @@ class _Net:
         self.prims.append(dict(kind=kind, ins=list(ins), out=out, **attrs))
         return out
 
-    def _conv(self, scope, opname, d, index, x, bias_name):
+    def _conv(self, scope, opname, d, index, x, bias_name, fold=None):
+        """fold = 'unpool': x is the block's value BEFORE its x2 up-sampling, fold = 'avg': the result is wanted AFTER
+        its /2 pooling - the kernel keeps the reference's geometry (spectral norm, names) and the scaling op is folded
+        into it (one 4x4 stride-2 launch, csrc/resample.hip:compose_kernel)"""
         c, h, w = self.shapes[x]
+        if fold == 'unpool':
+            h, w = 2 * h, 2 * w
         R, stride, out = _pick(d['kernel'], index), _pick(d['strides'], index), _pick(d['out'], index)
         if _pick(d['dilation'], index) != 1 or _pick(d['padding'], index) != 'SAME':
             raise NotImplementedError('{}: dilation / VALID are not built'.format(scope))
@@ -114,7 +123,19 @@ class _Net:
         k = _Kernel('{}/{}'.format(scope, opname), 'c', [R, R, c, out], [c, h, w], out_ref, _pick(d['act'], index),
                     _pick(d['w_nm'], index), _pick(d['act_k'], index), bias_name, stride, self.sn_mode)
         self.kernels.append(k)
-        return self._emit('conv', [x], out_ref, k=k)
+        if fold is None:
+            return self._emit('conv', [x], out_ref, k=k)
+        assert R == 3 and stride == 1
+        k.fold = fold
+        if fold == 'unpool':
+            return self._emit('upconv', [x], out_ref, k=k)
+        return self._emit('convdown', [x], [out, out_ref[1] // 2, out_ref[2] // 2], k=k)
+
+    def _can_fold(self, d, index, x, method):
+        c, h, w = self.shapes[x]
+        return (self.compose and d['scale'] is not None and d['scale'][0] == method and abs(d['scale'][1]) == 2
+                and _pick(d['kernel'], index) == 3 and _pick(d['strides'], index) == 1
+                and (method == 'unpool' or (h % 2 == 0 and w % 2 == 0)))
 
     def _bn_act(self, prefix, x, act):
         self.bns.append((prefix, self.shapes[x][0]))
@@ -235,16 +256,22 @@ class _Net:
                 r = self._bn_act(scope + '/BN_0', r, act)
             elif act != 'linear':
                 r = self._emit('act', [r], self.shapes[r], act=act)
-        if up:
-            r = self._scale(r, d['scale'])
-        r = self._conv(scope, 'kernel_0', d, 0, r, scope + '/bias_0/bias' if bias else None)
+        if up and self._can_fold(d, 0, r, 'unpool'):
+            r = self._conv(scope, 'kernel_0', d, 0, r, scope + '/bias_0/bias' if bias else None, fold='unpool')
+        else:
+            if up:
+                r = self._scale(r, d['scale'])
+            r = self._conv(scope, 'kernel_0', d, 0, r, scope + '/bias_0/bias' if bias else None)
         if bn:
             r = self._bn_act(scope + '/BN_1', r, act)
         elif act != 'linear':
             r = self._emit('act', [r], self.shapes[r], act=act)
-        r = self._conv(scope, 'kernel_1', d, 1, r, scope + '/bias_1/bias' if bias else None)
-        if down:
-            r = self._scale(r, d['scale'])
+        if down and self._can_fold(d, 1, r, 'avg'):
+            r = self._conv(scope, 'kernel_1', d, 1, r, scope + '/bias_1/bias' if bias else None, fold='avg')
+        else:
+            r = self._conv(scope, 'kernel_1', d, 1, r, scope + '/bias_1/bias' if bias else None)
+            if down:
+                r = self._scale(r, d['scale'])
         s = x
         if typ == 'res':
             if up:
@@ -320,7 +347,7 @@ class _Net:
     def _creation_order(self):
         """kernels and BN ops in the order the primitives use them (= the reference's variable creation order)"""
         for p in self.prims:
-            if p['kind'] in ('dense', 'conv', 'tconv'):
+            if p['kind'] in ('dense', 'conv', 'tconv', 'upconv', 'convdown'):
                 yield p['k']
             elif p['kind'] == 'bn':
                 yield (p['prefix'], self.shapes[p['out']][0])
@@ -479,12 +506,19 @@ class TapeEngine:
         # of inside every call (forward, and up to two input-gradient passes) - which also keeps the library's
         # shared workspace out of every launch of the main stream.  kernel scope -> {(dgrad, batch): tensor}
         self._wino = {}
+        self._folded = {}                              # kernel scope -> (4x4 kernel, its gradient buffer)
         rows_d = (2 * self.B,) if self._d_has_bn else (2 * self.B, self.B)
         for net, batches in ((self.gen, (self.B,)), (self.dis, rows_d)):
             for k in net.kernels:
+                if k.fold is not None:
+                    cin, cout = k.kernel_shape[2], k.out
+                    shape = (4, 4, cin, cout) if k.fold == 'avg' else (4, 4, cout, cin)
+                    self._folded[k.scope] = [torch.zeros(shape, device=self.device), None]
                 if k.op not in ('c', 'tc') or not self._side:
                     continue
-                if k.op == 'c':
+                R, stride = (4, 2) if k.fold is not None else (k.R, k.stride)
+                as_conv = k.op == 'c' and k.fold != 'unpool'
+                if as_conv:                            # (a folded 'avg' conv: same input, 4x4 stride 2)
                     c, h, w, kout = k.in_ref[0], k.in_ref[1], k.in_ref[2], k.out
                 else:                                  # the conv whose input-gradient the tc layer is: its input is
                     c, h, w, kout = k.out, k.out_ref[1], k.out_ref[2], k.in_ref[0]     # the layer's OUTPUT
@@ -493,11 +527,11 @@ class TapeEngine:
                     u = None
                     for n in batches:
                         # the forward pass of a conv (= the backward pass of a tc layer) runs at one batch size only
-                        single = (not dgrad) if k.op == 'c' else dgrad
-                        if (single and n != batches[0]) or not ops.wino_eligible(n, h, w, c, kout, k.R, k.stride, dgrad):
+                        single = (not dgrad) if as_conv else dgrad
+                        if (single and n != batches[0]) or not ops.wino_eligible(n, h, w, c, kout, R, stride, dgrad):
                             continue
                         if u is None:
-                            lead = (16,) if k.R == 3 else (4, 9)
+                            lead = (16,) if R == 3 else (4, 9)
                             u = torch.empty(lead + ((kout, c) if dgrad else (c, kout)), device=self.device)
                         table[(dgrad, n)] = u
                 if table:
@@ -513,12 +547,17 @@ class TapeEngine:
                 if p['kind'] == 'bn':
                     c = net.shapes[p['out']][0]
                     sizes.append((p, '_ws_bwd', max(lib.mmdgan_bn_workspace_bytes(c) // 4, 4)))
+            for k in net.kernels:                          # weight gradients of the folded 4x4 kernels (atomics)
+                if k.fold is not None:
+                    sizes.append((self._folded[k.scope], 1, self._folded[k.scope][0].numel()))
         total = sum((n + 3) // 4 * 4 for _, _, n in sizes)
         self._zero_scratch = torch.zeros(max(total, 4), device=self.device)
         off = 0
         for holder, key, n in sizes:
             holder[key] = self._zero_scratch[off:off + n]
             off += (n + 3) // 4 * 4
+        for entry in self._folded.values():
+            entry[1] = entry[1].view(entry[0].shape)
         self._mmd_ws = torch.zeros(max(lib.mmdgan_mmd_workspace_bytes(self.B, self.score_size), 64), device=self.device,
                                    dtype=torch.uint8)
 
@@ -592,6 +631,20 @@ class TapeEngine:
                 else:
                     ops.conv2d_fwd(a, net.p(k.w_name), k.stride, bias=bias, scale=scale, out=y,
                                    wino=self._wino_of(k, False, n) if (training and self._in_step) else None)
+            elif kind in ('upconv', 'convdown'):                         # a conv with its block's scaling op folded in
+                k = p['k']
+                scale = net.sn[k.scope]['scale'] if k.sn else None
+                bias = net.p(k.bias_name) if k.bias_name is not None else None
+                w4 = self._folded[k.scope][0]
+                if not (training and self._in_step):                     # outside step(): compose on the spot
+                    w4 = ops.compose_scaled_conv(net.p(k.w_name), k.fold)
+                y = self._buf(key, out_shape)
+                if kind == 'convdown':
+                    ops.conv2d_fwd(a, w4, 2, bias=bias, scale=scale, out=y,
+                                   wino=self._wino_of(k, False, n) if (training and self._in_step) else None)
+                else:
+                    ops.conv2d_dgrad(a, w4, (out_shape[1], out_shape[2]), 2, bias=bias, scale=scale, out=y,
+                                     wino=self._wino_of(k, True, n) if (training and self._in_step) else None)
             elif kind == 'tconv':                                        # y = the input-gradient of a conv with kernel w
                 k = p['k']
                 bias = net.p(k.bias_name) if k.bias_name is not None else None
@@ -661,7 +714,7 @@ class TapeEngine:
                 continue
             kind, dy = p['kind'], grads.pop(p['out'])
             vin = p['ins'][0]
-            if vin == 0 and not need_input_grad and kind not in ('dense', 'conv', 'tconv', 'bn'):
+            if vin == 0 and not need_input_grad and kind not in ('dense', 'conv', 'tconv', 'upconv', 'convdown', 'bn'):
                 continue
             key = (tag, net.name, i, 'd')
             a = sl(vals[vin])
@@ -702,6 +755,41 @@ class TapeEngine:
                     else:
                         ops.conv2d_dgrad(dy, w, (in_shape[1], in_shape[2]), k.stride, scale=scale, out=dx,
                                          wino=self._wino_of(k, True, n))
+                    give(vin, dx)
+            elif kind in ('upconv', 'convdown'):
+                k = p['k']
+                w = net.p(k.w_name)
+                w4, g4 = self._folded[k.scope]
+                scale = net.sn[k.scope]['scale'] if k.sn else None
+                if param_grads:
+                    def folded_grads(k=k, kind=kind, a=a, dy=dy, w=w, g4=g4, scale=scale):
+                        gb = net.g(k.bias_name) if k.bias_name is not None else None
+                        if kind == 'convdown':
+                            ops.conv2d_wgrad(a, dy, 4, 2, out=g4, dbias=gb)
+                        else:                                            # transposed form: roles swapped
+                            if gb is not None:
+                                ops.colsum(dy.reshape(-1, dy.shape[-1]), out=gb)
+                            ops.conv2d_wgrad(dy, a, 4, 2, out=g4)
+                        gw = net.g(k.w_name)
+                        ops.compose_scaled_conv_grad(g4, k.fold, out=gw)
+                        if k.sn:
+                            st = net.sn[k.scope]
+                            ops.dot(gw.view(-1), w.view(-1), out=st['dot'])
+                            ops.sn_wgrad_fixup(gw.view(-1), st['dsigma'].view(-1), st['dot'], st['sigma'], scale)
+                    thin = k.kernel_shape[2] % 64 or k.kernel_shape[3] % 64
+                    if self._side and not thin:
+                        self._wg_stream.wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(self._wg_stream):
+                            folded_grads()
+                    else:
+                        folded_grads()
+                if want_dx:
+                    dx = self._buf(key, in_shape)
+                    if kind == 'convdown':
+                        ops.conv2d_dgrad(dy, w4, (in_shape[1], in_shape[2]), 2, scale=scale, out=dx,
+                                         wino=self._wino_of(k, True, n))
+                    else:
+                        ops.conv2d_fwd(dy, w4, 2, scale=scale, out=dx, wino=self._wino_of(k, False, n))
                     give(vin, dx)
             elif kind == 'tconv':
                 k = p['k']
@@ -765,14 +853,21 @@ class TapeEngine:
         entry = self._wino.get(k.scope)
         return entry[2].get((dgrad, n)) if entry is not None else None
 
+    def _compose_weights(self, net):
+        for k in net.kernels:                              # 4x4 kernels of the folded scaling ops
+            if k.fold is not None:
+                ops.compose_scaled_conv(net.p(k.w_name), k.fold, out=self._folded[k.scope][0])
+
     def _transform_weights(self, net):
+        self._compose_weights(net)
         for scope, (owner, k, table) in self._wino.items():
             if owner is not net:
                 continue
             done = set()
+            src = self._folded[k.scope][0] if k.fold is not None else net.p(k.w_name)
             for (dgrad, _), u in table.items():
                 if dgrad not in done:
-                    ops.wino_transform(net.p(k.w_name), dgrad, out=u)
+                    ops.wino_transform(src, dgrad, out=u)
                     done.add(dgrad)
 
     # ---- one training step -----------------------------------------------------------------------------------
@@ -829,6 +924,8 @@ class TapeEngine:
             self.gen.grads.zero_()
             self.dis.grads.zero_()
             self._zero_scratch.zero_()
+            self._compose_weights(self.gen)
+            self._compose_weights(self.dis)
             for k in self.dis.kernels:
                 if k.sn:
                     self._sn_step(self.dis, k)

@@ -159,6 +159,7 @@ def test_res_step_matches_oracle_on_mfma_sized_blocks(loss_type, sn_mode):
         # analytically zero gradients: a bias whose only consumer is a batch norm (G's bias_sc feed the next block's
         # BN_0 / the identity layer's BN), and biases behind which only score differences matter (D's last two)
         noise = {last_bias, 'dis/l4/bias_1/bias', 'gen/l2/bias_sc/bias', 'gen/l3/bias_sc/bias', 'gen/l4/bias_sc/bias'}
+        floor32 = None
         for net in ('gen', 'dis'):
             gscale = max(float(ref_g[n].abs().max()) for n in grads if n.startswith(net))
             for n in grads:
@@ -169,7 +170,19 @@ def test_res_step_matches_oracle_on_mfma_sized_blocks(loss_type, sn_mode):
                     assert np.abs(r).max() <= 1e-9 * gscale and np.abs(grads[n]).max() <= 1e-4 * gscale, (step, n)
                     continue
                 l2 = np.linalg.norm(grads[n].astype(np.float64) - r) / (np.linalg.norm(r) + 1e-6 * gscale)
-                assert l2 <= 5e-3, (step, n, l2)
+                # G: one relu behind a batch norm whose input is ~1e-7 flips between the fp32 and the fp64 evaluation
+                # (which one depends on the last bit: the folded and the two-op form of a block flip different ones,
+                # tools/fold_debug.py) and moves every gradient upstream of it by up to ~8e-3 in L2; D has no BN
+                if l2 > (2e-2 if net == 'gen' else 5e-3):
+                    # relu / BN masks that flip between an fp32 and an fp64 evaluation move a few gradient entries by
+                    # much more than rounding (test_step_gpu.py): the bar is then what the oracle ITSELF loses in fp32
+                    if floor32 is None:
+                        o32 = R.OracleGan(arch, loss_type, (5e-4, 2e-4), dtype=torch.float32, params=prev_vars, sn_mode=sn_mode)
+                        r32 = o32.grads(torch.tensor(z), torch.tensor(real))
+                        floor32 = dict(r32[4])
+                        floor32.update(r32[5])
+                    fl = np.linalg.norm(floor32[n].double().numpy() - r) / (np.linalg.norm(r) + 1e-6 * gscale)
+                    assert l2 <= 2.0 * fl + 1e-3, (step, n, l2, fl)
         final = eng.get_variables()
         for n, v in final.items():
             if n in noise:
