@@ -109,13 +109,16 @@ class _Net:
         self.prims.append(dict(kind=kind, ins=list(ins), out=out, **attrs))
         return out
 
-    def _conv(self, scope, opname, d, index, x, bias_name, fold=None):
+    def _conv(self, scope, opname, d, index, x, bias_name, fold=None, ref_hw=None):
         """fold = 'unpool': x is the block's value BEFORE its x2 up-sampling, fold = 'avg': the result is wanted AFTER
         its /2 pooling - the kernel keeps the reference's geometry (spectral norm, names) and the scaling op is folded
         into it (one 4x4 stride-2 launch, csrc/resample.hip:compose_kernel)"""
         c, h, w = self.shapes[x]
+        run_hw = (h, w)
         if fold == 'unpool':
             h, w = 2 * h, 2 * w
+        if ref_hw is not None:                           # a 1x1 conv moved across its block's scaling op: the kernel keeps
+            h, w = ref_hw                                # the reference's geometry (spectral norm), the launch runs on x
         R, stride, out = _pick(d['kernel'], index), _pick(d['strides'], index), _pick(d['out'], index)
         if _pick(d['dilation'], index) != 1 or _pick(d['padding'], index) != 'SAME':
             raise NotImplementedError('{}: dilation / VALID are not built'.format(scope))
@@ -123,6 +126,9 @@ class _Net:
         k = _Kernel('{}/{}'.format(scope, opname), 'c', [R, R, c, out], [c, h, w], out_ref, _pick(d['act'], index),
                     _pick(d['w_nm'], index), _pick(d['act_k'], index), bias_name, stride, self.sn_mode)
         self.kernels.append(k)
+        if ref_hw is not None:
+            assert R == 1 and stride == 1 and fold is None
+            return self._emit('conv', [x], [out, run_hw[0], run_hw[1]], k=k)
         if fold is None:
             return self._emit('conv', [x], out_ref, k=k)
         assert R == 3 and stride == 1
@@ -274,11 +280,23 @@ class _Net:
                 r = self._scale(r, d['scale'])
         s = x
         if typ == 'res':
-            if up:
+            # a 1x1 conv commutes with nearest-neighbour up-sampling (exactly) and with average pooling (to rounding):
+            # it runs on the small side of the scaling op, a quarter of the work
+            commute = (self.compose and _pick(d['kernel'], 2) == 1 and _pick(d['strides'], 2) == 1
+                       and d['scale'] is not None and abs(d['scale'][1]) == 2)
+            c0, h0, w0 = self.shapes[s]
+            if up and commute and d['scale'][0] == 'unpool':
+                s = self._conv(scope, 'kernel_sc', d, 2, s, scope + '/bias_sc/bias', ref_hw=(2 * h0, 2 * w0))
                 s = self._scale(s, d['scale'])
-            s = self._conv(scope, 'kernel_sc', d, 2, s, scope + '/bias_sc/bias')          # :1745 keeps the bias
-            if down:
+            elif down and commute and d['scale'][0] == 'avg' and h0 % 2 == 0 and w0 % 2 == 0:
                 s = self._scale(s, d['scale'])
+                s = self._conv(scope, 'kernel_sc', d, 2, s, scope + '/bias_sc/bias', ref_hw=(h0, w0))
+            else:
+                if up:
+                    s = self._scale(s, d['scale'])
+                s = self._conv(scope, 'kernel_sc', d, 2, s, scope + '/bias_sc/bias')      # :1745 keeps the bias
+                if down:
+                    s = self._scale(s, d['scale'])
         elif typ == 'res_v1':
             if d['scale'] is not None:
                 if not down:
