@@ -117,3 +117,25 @@ def test_agent_checkpoint_rotation(tmp_path):
     with pytest.raises(AssertionError, match='Model diverged'):                                    # graph_func.py:856
         agent.train([step], lambda: (float('nan'), 0.0), eng, 2)
     FLAGS.SILENT_MODE = False
+
+
+def test_driver_table_and_residual_config():
+    """drivers.py (the four experiment scripts as a table), the authored ResNet-SN dict and its FLOP accounting"""
+    import configs
+    import drivers
+    from mmdgan_hip.tape import has_residual_blocks
+    assert drivers.sub_folder_name('rep', [5e-4, 2e-4], 1.6817928, [0.0, -1.0]) == 'sngan_rep_5e-04_2e-04_k1.68_0.0_-1.0'
+    assert drivers.sub_folder_name('hinge', [1e-4, 2e-4], 1.5157166, [0.0, -1.0]) == 'sngan_hinge_1e-04_2e-04_k1.52'
+    assert drivers.EXPERIMENTS['celebA'].num_file * drivers.EXPERIMENTS['celebA'].per_file == 202599      # my_test_celebA.py:42
+    assert drivers.EXPERIMENTS['lsun'].num_file * drivers.EXPERIMENTS['lsun'].per_file == 3033042         # my_test_lsun.py:42
+    arch, lr = configs.lsun_resnet()
+    assert has_residual_blocks(arch) and not has_residual_blocks(configs.cifar()[0])
+    assert [d.get('type', 'default') for d in arch['discriminator']] == ['res_v1', 'res', 'res', 'res', 'res_i', 'default']
+    fg, fd = configs.flops_per_image(arch)
+    # by hand for the first D block (res_v1, 3 -> 64 at 64x64): 3x3 3->64 and 3x3 64->64 at 64x64, 1x1 3->64 at 32x32
+    first = 2 * 9 * 3 * 64 * 64 * 64 + 2 * 9 * 64 * 64 * 64 * 64 + 2 * 3 * 64 * 32 * 32
+    rest = configs.flops_per_image({'generator': arch['generator'], 'code': arch['code'], 'input': [(64, 32, 32)],
+                                    'discriminator': arch['discriminator'][1:]})[1]
+    assert fd == first + rest
+    assert abs(fg / 1e9 - 3.91) < 0.01 and abs(fd / 1e9 - 1.88) < 0.01
+    assert configs.flops_per_image(configs.cifar()[0]) == (206962688, 431620096)                          # SURVEY 8(d)
