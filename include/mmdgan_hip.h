@@ -39,7 +39,7 @@ extern "C" {
 #define MMDGAN_ACT_RELU 1
 #define MMDGAN_ACT_LRELU 2
 #define MMDGAN_ACT_TANH 3
-/* OR-ed into `act` of conv2d_fwd / conv2d_dgrad: the output buffer is zero on entry and the entry may
+/* OR-ed into `act` of conv2d_fwd / conv2d_dgrad / gemm: the output buffer is zero on entry and the entry may
  * ACCUMULATE into it (lets a launch with too few tiles for 256 CUs split its reduction even when
  * mmdgan_set_outputs_prezeroed(1) is in force).  Only honoured with a linear epilogue (no dact_of). */
 #define MMDGAN_ACT_FLAG_OUT_ZEROED 0x100
@@ -76,7 +76,7 @@ int mmdgan_set_workspace(void *ptr, size_t bytes);
  * one memset over a whole gradient arena per step instead of ~40 small ones - sets this to 1 and the
  * internal memsets are skipped; the outputs MUST then be zero on entry.  In this mode conv2d_fwd /
  * conv2d_dgrad split their reduction (and so accumulate) only for batch-1 geometries (N == 1, the
- * spectral-norm power iteration) and gemm only for outputs <= 1 MiB with K >= 512.  Default 0. */
+ * spectral-norm power iteration) and gemm splits only when the call carries MMDGAN_ACT_FLAG_OUT_ZEROED.  Default 0. */
 int mmdgan_set_outputs_prezeroed(int on);
 
 /* ------------------------------------------------------------------------------------------------

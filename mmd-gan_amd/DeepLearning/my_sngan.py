@@ -16,7 +16,7 @@ from GeneralTools.misc_fun import FLAGS
 from GeneralTools.graph_func import prepare_folder, write_sprite_wrapper
 from mmdgan_hip import ops
 from mmdgan_hip.engine import GanEngine
-from mmdgan_hip.tape import TapeEngine, has_residual_blocks
+from mmdgan_hip.tape import TapeEngine, needs_tape_engine
 
 
 class SNGan(object):
@@ -53,15 +53,20 @@ class SNGan(object):
     def init_net(self, lr_list, batch_size, seed=0):
         """G and D with their optimisers (my_sngan.py:85-108, 412-415)."""
         if self.engine is None or self.engine.B != batch_size:
-            # residual blocks / scaling ops / identity layers: the primitive-op engine (mmdgan_hip/tape.py)
-            engine_cls = TapeEngine if has_residual_blocks(self.architecture) else GanEngine
+            # residual blocks / scaling ops / identity layers / batch norm in D: the primitive-op engine (mmdgan_hip/tape.py)
+            engine_cls = TapeEngine if needs_tape_engine(self.architecture) else GanEngine
             self.engine = engine_cls(self.architecture, self.loss_type, lr_list, tuple(self.rep_weights),
                                     batch_size=batch_size, seed=seed, dist_group=self.dist_group,
                                     sn_mode=FLAGS.SPECTRAL_NORM_MODE,                # layer_func.py:802-814
+                                    weight_init=FLAGS.WEIGHT_INITIALIZER,           # layer_func.py:27-64
                                     # eager issue measured faster than replaying the 3-branch hipGraph when the
                                     # host keeps up (2.35 vs 2.69 ms/step, bench.py tries both); MMDGAN_HIP_GRAPH=1
                                     # for hosts that do not
                                     use_graph=self.dist_group is None and os.environ.get('MMDGAN_HIP_GRAPH') == '1')
+            if self.dist_group is not None:
+                # data-parallel replicas must start from the same variables, Adam moments, SN vectors and BN statistics
+                from mmdgan_hip import dist as mdist
+                mdist.broadcast_state(self.engine, self.dist_group)
         else:
             self.engine.lr_d, self.engine.lr_g = float(lr_list[0]), float(lr_list[1])
         return self.engine
@@ -72,7 +77,7 @@ class SNGan(object):
         if FLAGS.SYNTHETIC_DATA:
             dev = torch.device('cuda')
             gen = torch.Generator(device=dev)
-            gen.manual_seed(1234)
+            gen.manual_seed(1234 + (self.engine.rank if self.engine is not None else 0))   # a replica's own batches
             buf = torch.empty((batch_size, self.height, self.width, self.channels), device=dev)
             return lambda: buf.uniform_(-1, 1, generator=gen)
         from GeneralTools.input_func import ReadTFRecords

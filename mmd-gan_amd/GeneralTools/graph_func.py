@@ -130,14 +130,25 @@ class Agent(object):
     def load(self, engine):
         path = self.latest_ckpt()
         if self.load_ckpt and path is not None:
-            engine.load_state_dict(torch.load(path, map_location='cpu', weights_only=False))
+            # tensors and plain containers only: a checkpoint file is data, never code (weights_only=True refuses
+            # anything that would need unpickling arbitrary objects)
+            sd = torch.load(path, map_location='cpu', weights_only=True)
+            if 'variables' in sd:
+                sd['variables'] = {k: v.numpy() for k, v in sd['variables'].items()}
+            engine.load_state_dict(sd)
             FLAGS.print('Model reloaded from {}'.format(path))
             return True
         return False
 
     def save(self, engine):
+        """in a data-parallel run the replicas hold identical variables: rank 0 writes, the others return"""
+        if getattr(engine, 'rank', 0) != 0:
+            return None
         path = '{}-{}'.format(self.save_path, engine.global_step)
-        torch.save(engine.state_dict(), path)
+        sd = engine.state_dict()
+        if 'variables' in sd:                                    # numpy arrays -> tensors: loadable with weights_only=True
+            sd['variables'] = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd['variables'].items()}
+        torch.save(sd, path)
         files = sorted(glob.glob(self.save_path + '-*'), key=lambda f: int(f.rsplit('-', 1)[1]))
         for old in files[:-2]:                                   # Saver(max_to_keep=2), graph_func.py:708-717
             os.remove(old)
@@ -167,6 +178,10 @@ class Agent(object):
                         epoch, engine.global_step, ['{}'.format(['<{:.2f}>'.format(v) for v in (lg, ld)])]),
                         force_print=force_print)
             if last and self.do_save:
+                # never write a diverged model: the next run would reload it (the reference asserts on every step,
+                # graph_func.py:856; here the losses stay on the device between query points, so check now)
+                lg, ld = read_losses()
+                assert not (math.isnan(lg) or math.isnan(ld)), 'Model diverged with loss = NaN'
                 self.save(engine)
         duration = time.time() - start
         FLAGS.print('Training for {} steps took {:.3f} sec.'.format(max_step, duration))

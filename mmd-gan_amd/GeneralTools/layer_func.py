@@ -2,7 +2,8 @@
 an API so that `Net(design, net_name, data_format, num_class)` + `Routine(net).add_input_layers /
 seq_links / add_output_layers / __call__` read as they do in my_sngan.py:85-108.
 
-Only sequential default-type layers with ops d / c / tc are on the hot path (SURVEY.md section 2);
+Only sequential default-type layers with ops d / c / tc (spectral norm and batch norm included) are on the hot path
+(SURVEY.md section 2);
 anything else raises the reference's error for an unsupported op or type.  Tensors crossing this
 API are NCHW like the reference's (misc_fun.py:50-51); inside they are NHWC and every op is a HIP
 kernel (mmdgan_hip.ops).  Training uses mmdgan_hip.engine.GanEngine (preallocated buffers, one
@@ -13,7 +14,7 @@ import torch
 
 from GeneralTools.misc_fun import FLAGS
 from mmdgan_hip import ops
-from mmdgan_hip.engine import Network, build_specs, _native_shape
+from mmdgan_hip.engine import Network, build_specs, _native_shape, sn_power_iteration, sn_scratch_buffers
 
 
 class Net(object):
@@ -35,6 +36,7 @@ class Routine(object):
     def __init__(self, net_object):
         self.net = net_object
         self.layer_indices, self.output_layer_indices, self.output_added = [], [], False
+        self._sn_bufs = {}
 
     def add_input_layers(self, input_shape, out_layer_indices):
         """input_shape = [batch, features] or [batch, C, H, W]; only dims [1:] matter (layer_func.py:694)."""
@@ -60,7 +62,7 @@ class Routine(object):
 
     def _ensure_network(self, device):
         if self.net.network is None:
-            self.net.network = Network(self.net.specs, device, np.random.RandomState(0))
+            self.net.network = Network(self.net.specs, device, np.random.RandomState(0), FLAGS.WEIGHT_INITIALIZER)
         return self.net.network
 
     def __call__(self, routine_inputs, is_training=True):
@@ -81,7 +83,12 @@ class Routine(object):
             bias = net.p(s.scope + '/bias/bias') if s.has_bias else None
             scale = None
             if s.sn:
-                raise NotImplementedError('{}: spectral-norm layers run inside GanEngine'.format(s.scope))
+                # _get_weight_norm_ (layer_func.py:785-825): sigma from one power-iteration step on the stored vector,
+                # W_eff = W * act_k / sigma (:886-887).  The vector's update is an UPDATE_OP (math_func.py:744), which
+                # the reference's sessions run in training only - as this eager path does with BN's moving statistics
+                if s.scope not in self._sn_bufs:
+                    self._sn_bufs[s.scope] = sn_scratch_buffers(net, s, x.device)
+                scale = sn_power_iteration(net, s, self._sn_bufs[s.scope], update=bool(is_training), out_zeroed=False)
             act = 'linear' if s.bn else s.act
             if s.op == 'd':
                 y = ops.gemm(x, w, bias=bias, scale=scale, act=act)

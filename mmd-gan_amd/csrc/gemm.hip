@@ -114,6 +114,11 @@ extern "C" int mmdgan_gemm(int transA, int transB, int M, int N, int K, const fl
                            int ldc, void *stream) {
     MMDGAN_REQUIRE(A && B && C, "gemm: null pointer");
     MMDGAN_REQUIRE(M >= 1 && N >= 1 && K >= 1, "gemm: bad shape %dx%dx%d", M, N, K);
+    // MMDGAN_ACT_FLAG_OUT_ZEROED: C is zero on entry and the launch may accumulate into it (split-K).  Under
+    // mmdgan_set_outputs_prezeroed(1) that flag is the ONLY licence to split: the caller names the outputs it zeroed,
+    // the library never guesses from the shape
+    const bool out_zeroed = (act & MMDGAN_ACT_FLAG_OUT_ZEROED) != 0;
+    act &= 0xff;
     MMDGAN_REQUIRE(act >= MMDGAN_ACT_LINEAR && act <= MMDGAN_ACT_TANH, "gemm: unknown activation %d", act);
     hipStream_t st = (hipStream_t)stream;
     GemmArgs g;
@@ -127,7 +132,7 @@ extern "C" int mmdgan_gemm(int transA, int transB, int M, int N, int K, const fl
     const int tiles = ((M + GT - 1) / GT) * ((N + GT - 1) / GT);
     int ksplit = 1;
     if (act == MMDGAN_ACT_LINEAR && !dact_of && tiles < 128 && K >= 512 && ldc == N &&
-        (!outputs_prezeroed() || (size_t)M * N * 4 <= (1u << 20))) {
+        (!outputs_prezeroed() || out_zeroed)) {
         ksplit = 512 / tiles;
         const int maxs = K / 64;
         if (ksplit > maxs) ksplit = maxs;
@@ -137,7 +142,7 @@ extern "C" int mmdgan_gemm(int transA, int transB, int M, int N, int K, const fl
     kchunk = (kchunk + GK - 1) / GK * GK;
     ksplit = (K + kchunk - 1) / kchunk;
     g.ksplit = ksplit; g.kchunk = kchunk;
-    if (ksplit > 1 && zero_output(C, sizeof(float) * (size_t)M * N, st) != hipSuccess)
+    if (ksplit > 1 && !out_zeroed && zero_output(C, sizeof(float) * (size_t)M * N, st) != hipSuccess)
         return check_launch("gemm memset");
     hipLaunchKernelGGL(gemm_kernel, dim3((N + GT - 1) / GT, (M + GT - 1) / GT, ksplit), dim3(256), 0, st, g);
     return check_launch("gemm");

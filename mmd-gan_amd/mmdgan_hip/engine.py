@@ -31,7 +31,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from . import ops
+from . import initializers, ops
 
 _TEMPLATE = {'name': None, 'type': 'default', 'op': 'c', 'out': None, 'bias': 'b',
              'act': 'linear', 'act_nm': None, 'act_k': False, 'w_nm': None, 'w_p': None,
@@ -40,13 +40,7 @@ _TEMPLATE = {'name': None, 'type': 'default', 'op': 'c', 'out': None, 'bias': 'b
 _ACTS = ('linear', 'relu', 'lrelu', 'tanh')
 
 
-def _trunc_normal(rng, shape, stddev):
-    out = rng.randn(*shape)
-    bad = np.abs(out) > 2.0
-    while bad.any():
-        out[bad] = rng.randn(int(bad.sum()))
-        bad = np.abs(out) > 2.0
-    return (out * stddev).astype(np.float32)
+_trunc_normal = initializers.trunc_normal
 
 
 def _chw_perm(c, h, w):
@@ -80,6 +74,7 @@ class LayerSpec:
         self.has_bias = d['bias'] is not None
         self.sn = d['w_nm'] == 's'
         self.act_k = d['act_k']
+        self.init_w_scale = d.get('init_w_scale')                          # layer_func.py:517, 719-720
         if self.sn and (self.act_k is False or not isinstance(self.act_k, (float, int))):
             # layer_func.py:835 would silently multiply the kernel by False (= 0); documented deviation
             raise ValueError('{}: w_nm="s" needs a numeric act_k'.format(self.scope))
@@ -162,8 +157,9 @@ class _Arena:
 class Network:
     """parameters, state and per-layer buffers of one net (G or D)."""
 
-    def __init__(self, specs, device, rng):
+    def __init__(self, specs, device, rng, weight_init='default'):
         self.specs, self.device = specs, device
+        self.weight_init = initializers.check_mode(weight_init)            # FLAGS.WEIGHT_INITIALIZER, layer_func.py:27-64
         entries = []
         for s in specs:
             entries.append((s.scope + '/kernel/kernel', s.kernel_shape))
@@ -292,19 +288,12 @@ class Network:
             t = self.state[name]
         return self._to_ref(name, t.detach().cpu().numpy())
 
-    # ---- initialisers: weight_initializer 'default' (layer_func.py:27-52), bias 1e-5 (:747) --
+    # ---- initialisers: weight_initializer in the mode FLAGS.WEIGHT_INITIALIZER names (layer_func.py:14-66,
+    #      mmdgan_hip/initializers.py), bias 1e-5 (:747) --
     def init_variables(self, rng):
         for s in self.specs:
-            shape = s.kernel_shape
-            receptive = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
-            fan_in, fan_out = shape[-2] * receptive, shape[-1] * receptive   # TF fan rule (tc quirk)
-            if s.act == 'relu':
-                w = _trunc_normal(rng, shape, math.sqrt(2.0 / fan_in))
-            elif s.act == 'lrelu':
-                w = _trunc_normal(rng, shape, math.sqrt(2.0 / 1.01 / fan_in))
-            else:
-                lim = math.sqrt(3.0 / ((fan_in + fan_out) / 2.0))
-                w = rng.uniform(-lim, lim, size=shape).astype(np.float32)
+            w = initializers.weight_initializer(rng, s.kernel_shape, s.act, self.weight_init,
+                                                1.0 if s.init_w_scale is None else s.init_w_scale)
             self.set_variable(s.scope + '/kernel/kernel', w)
             if s.sn:                                                        # math_func.py:565-567: NOT normalised
                 self.set_variable(s.scope + '/kernel/SN/in_rand', _trunc_normal(rng, s.sn_x_ref, 1.0))
@@ -321,12 +310,74 @@ def _native_shape(shape_ref, batch):
     return [batch, shape_ref[1], shape_ref[2], shape_ref[0]] if len(shape_ref) == 3 else [batch, shape_ref[0]]
 
 
+def sn_scratch_buffers(net, s, device):
+    """the scratch sn_power_iteration needs for layer `s` when no engine owns it (Routine's eager path)"""
+    u = net.state[s.scope + '#u']                         # the network's own scratch arena holds u and xb
+    return {s.scope + '#u': u, s.scope + '#un': torch.zeros_like(u), s.scope + '#xb': net.state[s.scope + '#xb'],
+            s.scope + '#xbnorm': torch.zeros(1, device=device)}
+
+
+def sn_power_iteration(net, s, b, update=True, out_zeroed=True):
+    """one power-iteration step of layer `s` of `net` (math_func.py:661-672, 739-744):
+    sigma = ||F(x)|| from the pre-update x, dsigma/dW, then (update=True, the UPDATE_OPS of a training step)
+    x <- normalised F^T(y) IN PLACE: every reader of the old x (F(x) and the dsigma outer product / weight gradient)
+    is issued before the write on the same stream, which is the UPDATE_OPS ordering (reads precede writes).
+    update=False evaluates sigma / scale only (inference: the reference's sessions do not run UPDATE_OPS there).
+    `b` holds the scratch (`#u`, `#un`, `#xb`, `#xbnorm`); out_zeroed: `#u` / `#xb` / the state's `#dsigma` are zero on
+    entry (the engine's once-per-step memset), so the split reductions may accumulate into them.
+    Returns the device scalar act_k / sigma."""
+    w = net.p(s.scope + '/kernel/kernel')
+    x = net.state[s.scope + '/kernel/SN/in_rand']
+    sigma, scale = net.state[s.scope + '#sigma'], net.state[s.scope + '#scale']
+    dsig = net.state[s.scope + '#dsigma']
+    u, un, xb, xbn = b[s.scope + '#u'], b[s.scope + '#un'], b[s.scope + '#xb'], b[s.scope + '#xbnorm']
+    oz = bool(out_zeroed)
+    if s.op == 'd' or s.pim:
+        if s.pim:                                                        # layer_func.py:811-814
+            w, dsig = w.view(-1, s.out), dsig.view(-1, s.out)
+        if 1 in w.shape:                                                 # math_func.py:702-704
+            ops.sn_norm_scale(w.view(-1), s.act_k, sigma, scale, dsig.view(-1))
+        elif s.use_u:
+            ops.gemm(x, w, out=u, out_zeroed=oz)                         # u = x W          [1,out]
+            ops.sn_norm_scale(u.view(-1), s.act_k, sigma, scale, un.view(-1))
+            if update:
+                ops.gemm(x, un, trans_a=True, out=dsig, out_zeroed=oz)   # dsigma/dW = x^T y
+                ops.gemm(un, w, trans_b=True, out=xb, out_zeroed=oz)     # y W^T            [1,in]
+                ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
+        else:
+            ops.gemm(x, w, trans_b=True, out=u, out_zeroed=oz)           # u = x W^T        [1,in]
+            ops.sn_norm_scale(u.view(-1), s.act_k, sigma, scale, un.view(-1))
+            if update:
+                ops.gemm(un, x, trans_a=True, out=dsig, out_zeroed=oz)   # dsigma/dW = y^T x
+                ops.gemm(un, w, out=xb, out_zeroed=oz)                   # y W              [1,out]
+                ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
+    else:
+        c, h, wd = s.in_shape_ref
+        if s.use_u:
+            ops.conv2d_fwd(x, w, s.stride, out=u)
+            ops.sn_norm_scale(u.view(-1), s.act_k, sigma, scale, un.view(-1))
+            if update:
+                ops.conv2d_wgrad(x, un, s.R, s.stride, out=dsig)         # SURVEY A.2
+                ops.conv2d_dgrad(un, w, (h, wd), s.stride, out=xb)
+                ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
+        else:
+            ops.conv2d_dgrad(x, w, (h, wd), s.stride, out=u)
+            ops.sn_norm_scale(u.view(-1), s.act_k, sigma, scale, un.view(-1))
+            if update:
+                ops.conv2d_wgrad(un, x, s.R, s.stride, out=dsig)
+                ops.conv2d_fwd(un, w, s.stride, out=xb)
+                ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
+    return scale
+
+
 class GanEngine:
     """G + D + loss + two TF-Adam optimisers; `step()` = one sess.run of graph_func.py:853."""
 
     def __init__(self, architecture, loss_type='rep', lr_list=(5e-4, 2e-4), rep_weights=(0.0, -1.0),
-                 batch_size=64, seed=0, device=None, dist_group=None, use_graph=False, sn_mode='default'):
+                 batch_size=64, seed=0, device=None, dist_group=None, use_graph=False, sn_mode='default',
+                 weight_init='default'):
         ops.require_device()
+        initializers.check_mode(weight_init)
         if loss_type not in ops.LOSS:
             raise NotImplementedError('Not implemented.')                   # math_func.py:2651
         assert rep_weights[0] - rep_weights[1] == 1.0, 'w[0]-w[1] must be 1'   # math_func.py:1340
@@ -340,8 +391,20 @@ class GanEngine:
         if sn_mode not in ('default', 'PICO', 'pico', 'sn_paper', 'PIM', 'pim'):                      # layer_func.py:802-814
             raise NotImplementedError('spectral norm mode {} is not implemented.'.format(sn_mode))
         self.sn_mode = sn_mode
-        self.gen = Network(build_specs(architecture['generator'], [self.code_size], 'gen', sn_mode), self.device, rng)
-        self.dis = Network(build_specs(architecture['discriminator'], self.in_shape_ref, 'dis', sn_mode), self.device, rng)
+        self.gen = Network(build_specs(architecture['generator'], [self.code_size], 'gen', sn_mode), self.device, rng,
+                           weight_init)
+        self.dis = Network(build_specs(architecture['discriminator'], self.in_shape_ref, 'dis', sn_mode), self.device, rng,
+                           weight_init)
+        # this engine's hand-written schedule covers the shipped DCGAN-SN shape of the reference's drivers: batch norm
+        # in G only (my_test_*.py), spectral norm in D only.  Anything else must not train silently wrong:
+        # mmdgan_hip.tape.TapeEngine takes batch norm in D (SNGan.init_net routes there), nothing here takes SN in G
+        for s in self.dis.specs:
+            if s.bn:
+                raise NotImplementedError('{}: batch norm in the discriminator is not on this engine\'s schedule; use '
+                                          'mmdgan_hip.tape.TapeEngine (SNGan.init_net does)'.format(s.scope))
+        for s in self.gen.specs:
+            if s.sn:
+                raise NotImplementedError('{}: spectral norm in the generator is not implemented.'.format(s.scope))
         if self.gen.specs[-1].out_shape_ref != self.in_shape_ref:
             raise AssertionError('gen: the output shape {} does not match existed shape {}.'.format(
                 self.gen.specs[-1].out_shape_ref, self.in_shape_ref))
@@ -349,10 +412,15 @@ class GanEngine:
         self.global_step = 0
         self.dist_group = dist_group
         self._dp_force = os.environ.get('MMDGAN_DP_FORCE') == '1'
-        self.world = 1
+        self.world, self.rank = 1, 0
         if dist_group is not None:
             import torch.distributed as tdist
-            self.world = tdist.get_world_size(dist_group)
+            self.world, self.rank = tdist.get_world_size(dist_group), tdist.get_rank(dist_group)
+        # the code sampler of this replica (my_sngan.py:123-124): a generator of its own, seeded per rank - torch's
+        # default CUDA generator starts from the same constant in every process, which would hand all replicas the
+        # same fake half of the batch
+        self._z_gen = torch.Generator(device=self.device)
+        self._z_gen.manual_seed((int(seed) * 1000003 + 7919 * self.rank + 12345) % (2 ** 63 - 1))
         self._exchange_pending = False
         # the power iterations of different layers are independent of each other too: two chains.
         # weight / bias gradients of a layer depend only on dz of that layer, not on the dgrad chain that
@@ -373,6 +441,7 @@ class GanEngine:
         self._alloc(self.B)
         self.losses = torch.zeros(8, device=self.device)       # filled by the loss kernel each step
         self.use_graph, self._graph = use_graph, None
+        self._in_step = False                                  # True while step() runs (buffers on the zero list ARE zero)
         self._static_z = torch.zeros(self.B, self.code_size, device=self.device)
         self._static_real = torch.zeros(_native_shape(self.in_shape_ref, self.B), device=self.device)
 
@@ -458,52 +527,13 @@ class GanEngine:
         for below, above in zip(gs, gs[1:]):     # input-gradient of a tc layer into a linear layer: split-K target
             if above.op == 'tc' and (below.bn or below.act == 'linear'):
                 self._zero_each_step.append(self.buf[below.scope + ('#dy' if below.bn else '#dz')])
+        self._zeroed_ptrs = {t.data_ptr() for t in self._zero_each_step}
 
     # ---------------------------------------------------------------------------------------
     # spectral norm: one power-iteration step per D layer (math_func.py:661-672)
     # ---------------------------------------------------------------------------------------
     def _sn_step(self, s):
-        """sigma = ||F(x)|| from the pre-update x, dsigma/dW, then x <- normalised F^T(y) IN PLACE: every
-        reader of the old x (F(x) and the dsigma outer product / weight gradient) is issued before
-        the write on the same stream, which is the UPDATE_OPS ordering (reads precede writes)."""
-        net, b = self.dis, self.buf
-        w = net.p(s.scope + '/kernel/kernel')
-        x = net.state[s.scope + '/kernel/SN/in_rand']
-        sigma, scale = net.state[s.scope + '#sigma'], net.state[s.scope + '#scale']
-        dsig = net.state[s.scope + '#dsigma']
-        u, un, xb, xbn = b[s.scope + '#u'], b[s.scope + '#un'], b[s.scope + '#xb'], b[s.scope + '#xbnorm']
-        if s.op == 'd' or s.pim:
-            if s.pim:                                                        # layer_func.py:811-814
-                w, dsig = w.view(-1, s.out), dsig.view(-1, s.out)
-            if 1 in w.shape:                                                 # math_func.py:702-704
-                ops.sn_norm_scale(w.view(-1), s.act_k, sigma, scale, dsig.view(-1))
-            elif s.use_u:
-                ops.gemm(x, w, out=u)                                        # u = x W          [1,out]
-                ops.sn_norm_scale(u.view(-1), s.act_k, sigma, scale, un.view(-1))
-                ops.gemm(x, un, trans_a=True, out=dsig)                      # dsigma/dW = x^T y
-                ops.gemm(un, w, trans_b=True, out=xb)                        # y W^T            [1,in]
-                ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
-            else:
-                ops.gemm(x, w, trans_b=True, out=u)                          # u = x W^T        [1,in]
-                ops.sn_norm_scale(u.view(-1), s.act_k, sigma, scale, un.view(-1))
-                ops.gemm(un, x, trans_a=True, out=dsig)                      # dsigma/dW = y^T x
-                ops.gemm(un, w, out=xb)                                      # y W              [1,out]
-                ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
-        else:
-            c, h, wd = s.in_shape_ref
-            if s.use_u:
-                ops.conv2d_fwd(x, w, s.stride, out=u)
-                ops.sn_norm_scale(u.view(-1), s.act_k, sigma, scale, un.view(-1))
-                ops.conv2d_wgrad(x, un, s.R, s.stride, out=dsig)             # SURVEY A.2
-                ops.conv2d_dgrad(un, w, (h, wd), s.stride, out=xb)
-                ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
-            else:
-                ops.conv2d_dgrad(x, w, (h, wd), s.stride, out=u)
-                ops.sn_norm_scale(u.view(-1), s.act_k, sigma, scale, un.view(-1))
-                ops.conv2d_wgrad(un, x, s.R, s.stride, out=dsig)
-                ops.conv2d_fwd(un, w, s.stride, out=xb)
-                ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
-        return scale
+        return sn_power_iteration(self.dis, s, self.buf)
 
     # ---------------------------------------------------------------------------------------
     def _layer_forward(self, net, s, x, is_training, scale):
@@ -516,7 +546,9 @@ class GanEngine:
         fused_act = 'linear' if s.bn else s.act
         tgt = (b[s.scope + '#raw'][:n] if s.bn else y)
         if s.op == 'd':
-            ops.gemm(x.reshape(n, -1), w, bias=bias, scale=scale, act=fused_act, out=tgt.view(n, -1))
+            # a long-K dense output is on the step's zero list (_alloc): only then may the launch split K
+            zeroed = self._in_step and tgt.data_ptr() in self._zeroed_ptrs
+            ops.gemm(x.reshape(n, -1), w, bias=bias, scale=scale, act=fused_act, out=tgt.view(n, -1), out_zeroed=zeroed)
         elif s.op == 'c':
             full = n == (2 * self.B if net is self.dis else self.B)      # the batch the transforms were sized for
             wino = self._wino.get(s.scope, (None, None, None))[0] if full and is_training else None
@@ -616,7 +648,7 @@ class GanEngine:
                 if s.op == 'd':
                     if gb is not None:
                         ops.colsum(dz_main.reshape(-1, dz_main.shape[-1]), out=gb)
-                    ops.gemm(x_in.reshape(2 * B, -1), dz_main.reshape(2 * B, -1), trans_a=True, out=gw)
+                    ops.gemm(x_in.reshape(2 * B, -1), dz_main.reshape(2 * B, -1), trans_a=True, out=gw, out_zeroed=True)
                 else:                                                        # bias gradient rides on the wgrad launch
                     ops.conv2d_wgrad(x_in, dz_main, s.R, s.stride, out=gw, dbias=gb)
                 if s.sn:                                                     # SURVEY A.2 fix-up
@@ -697,7 +729,7 @@ class GanEngine:
                 if gb is not None and s.op != 'c':
                     ops.colsum(dz.view(-1, dz.shape[-1]), out=gb)
                 if s.op == 'd':
-                    ops.gemm(x_in, dz, trans_a=True, out=gw)
+                    ops.gemm(x_in, dz, trans_a=True, out=gw, out_zeroed=True)   # the gradient arena was zeroed
                 elif s.op == 'c':
                     ops.conv2d_wgrad(x_in, dz, s.R, s.stride, out=gw, dbias=gb)
                 else:                                                        # tc: W[R,R,Cout,Cin]; y = dgrad(v, W)
@@ -711,6 +743,8 @@ class GanEngine:
                 act_prev, dact = ('linear', None) if prev.bn else (prev.act, yprev)
                 dprev = b[prev.scope + ('#dy' if prev.bn else '#dz')].view(in_shape)
                 if s.op == 'd':
+                    # dprev is NOT on the step's zero list: no out_zeroed, so no split-K accumulation into last
+                    # step's values (a dense layer above a BN dense layer meets every other split condition)
                     ops.gemm(dz, w, trans_b=True, act=act_prev, dact_of=dact, out=dprev)
                 elif s.op == 'c':
                     ops.conv2d_dgrad(dz, w, (in_shape[1], in_shape[2]), s.stride, act=act_prev, dact_of=dact, out=dprev,
@@ -718,8 +752,7 @@ class GanEngine:
                 else:                                                        # d/dv of dgrad(v, W) = conv(dz, W)
                     # few tiles (M = B*h*w is small at the top of G): if the epilogue is linear let the
                     # kernel split its K = R*R*Cout reduction into a buffer zeroed at step start
-                    zeroed = dact is None and act_prev == 'linear' and any(dprev.data_ptr() == t.data_ptr()
-                                                                            for t in self._zero_each_step)
+                    zeroed = dact is None and act_prev == 'linear' and dprev.data_ptr() in self._zeroed_ptrs
                     ops.conv2d_fwd(dz, w, s.stride, act=act_prev, dact_of=dact, out=dprev, out_zeroed=zeroed,
                                    wino=self._wino.get(s.scope, (None, None, None))[0])
                 dz = dprev
@@ -790,6 +823,7 @@ class GanEngine:
             for t in self._zero_each_step:
                 if not any(t is a for a in arenas):
                     t.zero_()
+            self._in_step = True
             self._forward(z, real)
             if arenas:
                 torch.cuda.current_stream().wait_stream(self._wg_stream)
@@ -809,13 +843,14 @@ class GanEngine:
             self._join_wg_stream()
             self._update()
         finally:
+            self._in_step = False
             lib.mmdgan_set_outputs_prezeroed(0)
 
     def step(self, real_nhwc=None, z=None):
         """one training step; returns nothing on the host (losses stay in self.losses on the device:
         [0] loss_gen, [1] loss_dis, [2..6] e_kxx e_kxy e_kyy e_kxx_b e_kyy_b, pre-update values)."""
         if z is None:
-            self._static_z.normal_()                                         # my_sngan.py:123-124
+            self._static_z.normal_(generator=self._z_gen)                    # my_sngan.py:123-124
         else:
             self._static_z.copy_(z)
         graph = self.use_graph and self.dist_group is None
@@ -875,6 +910,17 @@ class GanEngine:
     def get_variables(self, names=None, grad=False):
         names = names if names is not None else self.variable_names(trainable_only=grad)
         return OrderedDict((k, self._net_of(k).get_variable(k, grad=grad)) for k in names)
+
+    def set_adam_state(self, m, v, t):
+        """Adam moments (reference names and layouts, as set_variables takes them) and the step count both
+        optimisers have taken: resume mid-run from state recorded elsewhere"""
+        for k in m:
+            net = self._net_of(k)
+            net.arena.view(k, net.adam_m).copy_(torch.as_tensor(net._to_native(k, m[k]), device=self.device))
+            net.arena.view(k, net.adam_v).copy_(torch.as_tensor(net._to_native(k, v[k]), device=self.device))
+        for net in (self.gen, self.dis):
+            net.opt.step_counter.fill_(int(t))
+        self._graph = None
 
     def sigmas(self):
         return OrderedDict((s.scope, float(self.dis.state[s.scope + '#sigma'].item())) for s in self.dis.specs if s.sn)

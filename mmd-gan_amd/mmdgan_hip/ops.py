@@ -145,15 +145,19 @@ def conv2d_wgrad(x, dy, R, stride, out=None, dbias=None):
     return dw
 
 
-def gemm(a, b, trans_a=False, trans_b=False, bias=None, scale=None, act='linear', dact_of=None, out=None, dact_rows=0):
-    """C = act(scale * op(a) op(b) + bias), row-major 2-D tensors (tf.matmul, layer_func.py:911)"""
+def gemm(a, b, trans_a=False, trans_b=False, bias=None, scale=None, act='linear', dact_of=None, out=None, dact_rows=0,
+         out_zeroed=False):
+    """C = act(scale * op(a) op(b) + bias), row-major 2-D tensors (tf.matmul, layer_func.py:911)
+    out_zeroed: `out` is zero on entry (the caller zeroed it this step): the launch may split its K reduction and
+    accumulate - the only way it splits while mmdgan_set_outputs_prezeroed(1) is in force"""
     lib = require_device()
     M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
     K2, N = (b.shape[1], b.shape[0]) if trans_b else b.shape
     assert K == K2, (a.shape, b.shape, trans_a, trans_b)
     c = out if out is not None else torch.empty((M, N), device=a.device, dtype=torch.float32)
     check(lib.mmdgan_gemm(int(trans_a), int(trans_b), M, N, K, _p(a), a.shape[1], _p(b), b.shape[1], _p(bias), _p(scale),
-                          act_id(act), _p(dact_of), int(dact_rows), _p(c), N, _stream()), 'gemm')
+                          act_id(act) | (0x100 if out_zeroed else 0), _p(dact_of), int(dact_rows), _p(c), N, _stream()),
+          'gemm')
     return c
 
 

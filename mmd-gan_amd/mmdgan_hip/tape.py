@@ -18,7 +18,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from . import ops
+from . import initializers, ops
 from .engine import _Arena, _chw_perm, _trunc_normal
 
 _TEMPLATE = {'name': None, 'type': 'default', 'op': 'c', 'out': None, 'bias': 'b', 'act': 'linear', 'act_nm': None,
@@ -31,6 +31,12 @@ _PIM = ('sn_paper', 'PIM', 'pim')
 def has_residual_blocks(architecture):
     return any(d.get('type', 'default') in RES_TYPES or d.get('op') == 'i' or d.get('scale') is not None
                for net in ('generator', 'discriminator') for d in architecture[net])
+
+
+def needs_tape_engine(architecture):
+    """architectures the hand-scheduled GanEngine does not cover: residual blocks / scaling / identity layers, and
+    batch norm anywhere in the discriminator (GanEngine's D backward pass has no BN path and refuses those)"""
+    return has_residual_blocks(architecture) or any(d.get('act_nm') in ('bn', 'BN') for d in architecture['discriminator'])
 
 
 def _pick(value, index):                                                 # Layer._update_design_, layer_func.py:1380-1395
@@ -83,8 +89,9 @@ class _Kernel:
 class _Net:
     """one net lowered to primitives; owns its variables (flat arenas) and state"""
 
-    def __init__(self, designs, in_ref, name, device, rng, sn_mode):
+    def __init__(self, designs, in_ref, name, device, rng, sn_mode, weight_init='default'):
         self.name, self.device, self.sn_mode = name, device, sn_mode
+        self.weight_init = initializers.check_mode(weight_init)          # FLAGS.WEIGHT_INITIALIZER
         # fold a block's 'unpool' x2 / 'avg' /2 into the 3x3 conv next to it (one 4x4 stride-2 launch: 4 taps per pixel
         # instead of 9, no up-sampled tensor in HBM; ResNet-SN config 7.32 -> 6.57 ms per step); MMDGAN_TAPE_COMPOSE=0: two ops
         self.compose = os.environ.get('MMDGAN_TAPE_COMPOSE', '1') != '0'
@@ -447,16 +454,7 @@ class _Net:
             if not isinstance(item, _Kernel):
                 self.set_variable(item[0] + '/BN/gamma', np.ones(item[1], np.float32))
                 continue
-            shape = item.kernel_shape
-            receptive = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
-            fan_in, fan_out = shape[-2] * receptive, shape[-1] * receptive
-            if item.act_init == 'relu':
-                w = _trunc_normal(rng, shape, math.sqrt(2.0 / fan_in))
-            elif item.act_init == 'lrelu':
-                w = _trunc_normal(rng, shape, math.sqrt(2.0 / 1.01 / fan_in))
-            else:
-                lim = math.sqrt(3.0 / ((fan_in + fan_out) / 2.0))
-                w = rng.uniform(-lim, lim, size=shape).astype(np.float32)
+            w = initializers.weight_initializer(rng, item.kernel_shape, item.act_init, self.weight_init)
             self.set_variable(item.w_name, w)
             if item.sn:
                 self.set_variable(item.scope + '/SN/in_rand', _trunc_normal(rng, item.sn_x_ref, 1.0))
@@ -472,8 +470,9 @@ class TapeEngine:
     """G + D + loss + two TF-Adam optimisers for nets with residual blocks; same interface as GanEngine."""
 
     def __init__(self, architecture, loss_type='rep', lr_list=(5e-4, 2e-4), rep_weights=(0.0, -1.0), batch_size=64,
-                 seed=0, device=None, dist_group=None, use_graph=False, sn_mode='default'):
+                 seed=0, device=None, dist_group=None, use_graph=False, sn_mode='default', weight_init='default'):
         ops.require_device()
+        initializers.check_mode(weight_init)
         if loss_type not in ops.LOSS:
             raise NotImplementedError('Not implemented.')                                # math_func.py:2651
         assert rep_weights[0] - rep_weights[1] == 1.0, 'w[0]-w[1] must be 1'              # math_func.py:1340
@@ -486,8 +485,8 @@ class TapeEngine:
         self.code_size = architecture['code'][0][0]
         self.in_shape_ref = list(architecture['input'][0])
         rng = np.random.RandomState(seed)
-        self.gen = _Net(architecture['generator'], [self.code_size], 'gen', self.device, rng, sn_mode)
-        self.dis = _Net(architecture['discriminator'], self.in_shape_ref, 'dis', self.device, rng, sn_mode)
+        self.gen = _Net(architecture['generator'], [self.code_size], 'gen', self.device, rng, sn_mode, weight_init)
+        self.dis = _Net(architecture['discriminator'], self.in_shape_ref, 'dis', self.device, rng, sn_mode, weight_init)
         assert self.gen.shapes[self.gen.out_val] == self.in_shape_ref, \
             'generator output {} does not match the input shape {}'.format(self.gen.shapes[self.gen.out_val], self.in_shape_ref)
         assert len(self.dis.shapes[self.dis.out_val]) == 1, 'the discriminator must end in a score vector'
@@ -495,16 +494,19 @@ class TapeEngine:
             raise NotImplementedError('spectral norm in the generator is not built')
         self.score_size = self.dis.shapes[self.dis.out_val][0]
         self.global_step = 0
-        self.dist_group, self.world = dist_group, 1
+        self.dist_group, self.world, self.rank = dist_group, 1, 0
         if dist_group is not None:
             import torch.distributed as tdist
             self.world = tdist.get_world_size(dist_group)
+            self.rank = tdist.get_rank(dist_group)
         self._dp_force = os.environ.get('MMDGAN_DP_FORCE') == '1'
         self.use_graph = False                                           # eager issue only
         if ops._workspace is None:
             ops.set_workspace(device=self.device)
         self.losses = torch.zeros(8, device=self.device)
         self._static_z = torch.zeros(self.B, self.code_size, device=self.device)
+        self._z_gen = torch.Generator(device=self.device)                # per-replica code sampler, see GanEngine
+        self._z_gen.manual_seed((int(seed) * 1000003 + 7919 * self.rank + 12345) % (2 ** 63 - 1))
         self._static_real = torch.zeros(_native(self.in_shape_ref, self.B), device=self.device)
         self._dis_in = torch.zeros(_native(self.in_shape_ref, 2 * self.B), device=self.device)
         self._mmd_grads = torch.zeros(4, self.B, self.score_size, device=self.device)
@@ -915,7 +917,7 @@ class TapeEngine:
         lib = ops.require_device()
         main = torch.cuda.current_stream()
         if z is None:
-            self._static_z.normal_()                                     # my_sngan.py:123-124
+            self._static_z.normal_(generator=self._z_gen)                # my_sngan.py:123-124
         else:
             self._static_z.copy_(z)
         if real_nhwc is not None:
@@ -1002,6 +1004,16 @@ class TapeEngine:
     def get_variables(self, names=None, grad=False):
         names = names if names is not None else self.variable_names(trainable_only=grad)
         return OrderedDict((k, self._net_of(k).get_variable(k, grad=grad)) for k in names)
+
+    def set_adam_state(self, m, v, t):
+        """Adam moments (reference names and layouts) and the step count of both optimisers, see GanEngine"""
+        for k in m:
+            net = self._net_of(k)
+            for flat, src in ((net.adam_m, m[k]), (net.adam_v, v[k])):
+                t = net.arena.view(k, flat)
+                t.copy_(torch.as_tensor(net.to_native(k, src), device=self.device).reshape(t.shape))
+        for net in (self.gen, self.dis):
+            net.opt.step_counter.fill_(int(t))
 
     def sigmas(self):
         """spectral norms of the last step, keyed like the reference's op scopes (<layer> for a plain layer's

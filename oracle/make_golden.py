@@ -347,6 +347,101 @@ def make_step(loss_type, B=8, n_steps=3, lr=(5e-4, 2e-4), store_grads=True, sn_m
 
 
 # ---------------------------------------------------------------------------
+# 3b. the same step, recorded AFTER a warm-up: the reference starts its spectral-norm vectors un-normalised
+#     (math_func.py:565-567), so the first step's gradients are ~1e-9 - at Adam's eps, where rounding noise decides
+#     the update - and any two fp32 implementations part ways there.  Here the reference code first runs `warm` steps
+#     (in fp64), the state it reached (variables, Adam moments, step count; rounded to fp32) is the fixture's starting
+#     point, and the next `n_steps` steps are recorded from it in fp32 and fp64: gradients are O(1e-3) and a free-running
+#     implementation can be held to 1e-4 on every step.
+# ---------------------------------------------------------------------------
+def make_step_warm(loss_type, warm=20, B=8, n_steps=3, lr=(5e-4, 2e-4), arch_fn=None, tag=None, sn_mode='default'):
+    FLAGS.SPECTRAL_NORM_MODE = sn_mode
+    arch = (arch_fn or tiny_architecture)()
+    out = {'lr': np.asarray(lr), 'loss_type': np.asarray(loss_type), 'B': np.asarray(B), 'warm': np.asarray(warm),
+           'sn_mode': np.asarray(sn_mode)}
+    rs = np.random.RandomState(99)
+    zs = rs.randn(warm + n_steps, B, arch['code'][0][0]).astype(np.float32)
+    reals = rs.uniform(-1, 1, size=(warm + n_steps, B) + tuple(arch['input'][0])).astype(np.float32)
+    out['z'], out['real'] = zs[warm:], reals[warm:]
+
+    def build():
+        g = build_routine(arch['generator'], 'gen', [arch['code'][0][0]])
+        d = build_routine(arch['discriminator'], 'dis', list(arch['input'][0]))
+        return g, d
+
+    def one_step(step, dt, adam, record=None, key=None):
+        G, D = build()                                               # "re-trace the graph"
+        z, real = torch.tensor(zs[step], dtype=dt), torch.tensor(reals[step], dtype=dt)
+        gen = G({'x': z}, is_training=True)['x']                     # my_sngan.py:277
+        dis_out = D({'x': torch.cat([real, gen], 0)}, is_training=True)['x']     # my_sngan.py:278
+        s_x, s_gen = tf.split(dis_out, 2, 0)                         # my_sngan.py:279
+        lg, ld = ref_math.GANLoss(False).apply(s_gen, s_x, loss_type, batch_size=B, d=16,
+                                               rep_weights=[0.0, -1.0])          # my_sngan.py:284-286
+        vd = tf.get_collection(tf.GraphKeys.TRAINABLE_VARIABLES, 'dis')
+        vg = tf.get_collection(tf.GraphKeys.TRAINABLE_VARIABLES, 'gen')
+        gd = torch.autograd.grad(ld, vd, retain_graph=True)          # my_sngan.py:302
+        gg = torch.autograd.grad(lg, vg)                             # my_sngan.py:304
+        if record is not None:
+            pre = 'step{}/'.format(step - warm)
+            record[pre + 'loss_gen_' + key], record[pre + 'loss_dis_' + key] = npy(lg), npy(ld)
+            record[pre + 's_x_' + key], record[pre + 's_gen_' + key] = npy(s_x), npy(s_gen)
+            if key == 'f64' and step in (warm, warm + n_steps - 1):   # gradients of the first and the last recorded step
+                for v, g in list(zip(vd, gd)) + list(zip(vg, gg)):
+                    record[pre + 'grad/' + v.tf_name + '_f64'] = npy(g).astype(np.float32)
+            for layer in D.net.layers:
+                for op_name, op in layer.ops.items():
+                    if getattr(op, 'kernel_norm', None) is not None:
+                        scope = layer.layer_scope if op_name == 'kernel' else layer.layer_scope + '/' + op_name
+                        record[pre + 'sigma/' + scope + '_' + key] = npy(op.kernel_norm)
+        for lr_i, vs, gs in ((lr[0], vd, gd), (lr[1], vg, gg)):
+            for v, g in zip(vs, gs):
+                m, vv = adam.setdefault(v.tf_name, (torch.zeros_like(v), torch.zeros_like(v)))
+                tf_adam_inplace(v, g, m, vv, step + 1, lr_i)
+        tf.run_update_ops()
+        if record is not None and key == 'f64' and step == warm + n_steps - 1:
+            for k, v in tf.STATE.variables.items():                  # every variable after the last recorded step
+                record['final/' + k + '_f64'] = npy(v).astype(np.float32)
+
+    # phase 1: the warm-up, once, in fp64
+    tf.set_dtype(torch.float64)
+    tf.STATE.reset()
+    tf.STATE.rng = np.random.RandomState(5)
+    G, D = build()
+    D({'x': torch.cat([torch.tensor(reals[0], dtype=torch.float64), G({'x': torch.tensor(zs[0], dtype=torch.float64)})['x']], 0)})
+    tf.STATE.update_ops = []
+    adam = {}
+    for step in range(warm):
+        one_step(step, torch.float64, adam)
+    start = {k: npy(v).astype(np.float32) for k, v in tf.STATE.variables.items()}
+    start_m = {k: npy(m).astype(np.float32) for k, (m, _) in adam.items()}
+    start_v = {k: npy(v).astype(np.float32) for k, (_, v) in adam.items()}
+    for k, v in start.items():
+        out['init/' + k] = v
+    for k in start_m:
+        out['adam_m/' + k], out['adam_v/' + k] = start_m[k], start_v[k]
+    out['adam_t'] = np.asarray(warm)
+    # phase 2: the recorded steps, from the fp32-rounded state, in both precisions
+    for key, dt in DT.items():
+        tf.set_dtype(dt)
+        tf.STATE.reset()
+        tf.STATE.rng = np.random.RandomState(5)
+        G, D = build()
+        D({'x': torch.cat([torch.tensor(reals[0], dtype=dt), G({'x': torch.tensor(zs[0], dtype=dt)})['x']], 0)})
+        for k, v in tf.STATE.variables.items():
+            with torch.no_grad():
+                v.copy_(torch.tensor(start[k], dtype=dt))
+        tf.STATE.update_ops = []
+        adam = {k: (torch.tensor(start_m[k], dtype=dt), torch.tensor(start_v[k], dtype=dt)) for k in start_m}
+        for step in range(warm, warm + n_steps):
+            one_step(step, dt, adam, record=out, key=key)
+    FLAGS.SPECTRAL_NORM_MODE = 'default'
+    tag = tag or loss_type
+    np.savez_compressed(os.path.join(OUT, 'step_warm_{}.npz'.format(tag)), **out)
+    gmax = max(float(np.abs(v).max()) for k, v in out.items() if k.startswith('step0/grad/'))
+    print('warm-start step fixture:', tag, 'largest step-0 gradient entry %.3g' % gmax)
+
+
+# ---------------------------------------------------------------------------
 # 5. eval helpers: NumPy FID on supplied pool3 features (graph_func.py:1733-1745,
 #    math_func.py:56-67, 2671-2699) and the sprite grid (graph_func.py:222-266)
 # ---------------------------------------------------------------------------
@@ -427,8 +522,59 @@ def make_eval():
     print('eval fixtures: fid %.6f, sprites %s' % (out['fid'], [sp[k + '/sprite'].shape for k in cases]))
 
 
+# ---------------------------------------------------------------------------
+# 6. initialisers: what the reference's weight_initializer / bias_initializer return in each
+#    FLAGS.WEIGHT_INITIALIZER mode (layer_func.py:14-80) - sample statistics of the draws, per activation and kernel
+#    shape.  The random stream is the shim's, so the statistics (not the samples) are the fixture.
+# ---------------------------------------------------------------------------
+def make_init_stats():
+    tf.set_dtype(torch.float64)
+    out, n = {}, 0
+    shapes = {'dense': [512, 384], 'conv3': [3, 3, 64, 128], 'tconv4': [4, 4, 32, 256]}     # tc kernels are [k,k,Cout,Cin]
+    for mode in ('default', 'sn_paper', 'pg_paper'):
+        FLAGS.WEIGHT_INITIALIZER = mode
+        for act in ('relu', 'lrelu', 'tanh', 'linear'):
+            for sname, shape in shapes.items():
+                tf.STATE.rng = np.random.RandomState(1000 + n)
+                w = npy(ref_layer.weight_initializer(act)(shape))
+                key = '{}/{}/{}/'.format(mode, act, sname)
+                out[key + 'std'], out[key + 'absmax'], out[key + 'mean'] = np.float64(w.std()), np.float64(np.abs(w).max()), np.float64(w.mean())
+                out[key + 'kurt'] = np.float64(((w - w.mean()) ** 4).mean() / w.var() ** 2)   # 1.8 uniform, ~2.1 truncated normal
+                out[key + 'shape'] = np.asarray(shape)
+                n += 1
+    FLAGS.WEIGHT_INITIALIZER = 'default'
+    for act, scale in (('relu', 0.25), ('linear', 4.0), ('relu', 0.0)):                    # init_w_scale (layer_func.py:719-720)
+        tf.STATE.rng = np.random.RandomState(2000 + n)
+        w = npy(ref_layer.weight_initializer(act, scale)(shapes['conv3']))
+        key = 'default/{}/conv3/scale{}/'.format(act, scale)
+        out[key + 'std'], out[key + 'absmax'] = np.float64(w.std()), np.float64(np.abs(w).max())
+        n += 1
+    tf.STATE.rng = np.random.RandomState(3000)
+    b = npy(ref_layer.bias_initializer(1e-5)([4096]))
+    out['bias/std'], out['bias/absmax'] = np.float64(b.std()), np.float64(np.abs(b).max())
+    out['bias0/absmax'] = np.float64(np.abs(npy(ref_layer.bias_initializer(0.0)([64]))).max())
+    try:
+        FLAGS.WEIGHT_INITIALIZER = 'no_such_mode'
+        ref_layer.weight_initializer('relu')
+        out['unknown_mode_error'] = np.asarray('')
+    except NotImplementedError as err:
+        out['unknown_mode_error'] = np.asarray(str(err))
+    FLAGS.WEIGHT_INITIALIZER = 'default'
+    tf.set_dtype(torch.float32)
+    np.savez_compressed(os.path.join(OUT, 'init_stats.npz'), **out)
+    print('initialiser fixture: %d cases' % n)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
+    if '--only-init' in sys.argv:
+        make_init_stats()
+        sys.exit(0)
+    if '--only-warm' in sys.argv:
+        make_step_warm('rep')
+        make_step_warm('rep', arch_fn=tiny_res_architecture, tag='res_rep')
+        make_step_warm('rep', sn_mode='sn_paper', tag='rep_pim')
+        sys.exit(0)
     torch.manual_seed(0)
     torch.set_num_threads(4)
     make_mmd()
@@ -451,5 +597,9 @@ if __name__ == '__main__':
     make_step('rep', arch_fn=tiny_res_bil_architecture, tag='res_bil_rep')
     make_step('rep', arch_fn=tiny_res_max_architecture, tag='res_max_rep')
     make_eval()
+    make_init_stats()
+    make_step_warm('rep')
+    make_step_warm('rep', arch_fn=tiny_res_architecture, tag='res_rep')
+    make_step_warm('rep', sn_mode='sn_paper', tag='rep_pim')
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print('tests/golden total bytes:', total)

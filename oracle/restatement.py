@@ -714,6 +714,15 @@ class OracleGan:
         self.opt_g = AdamTF(self.gen_names, self.params, lr_list[1])
         self.global_step = 0
 
+    def set_adam_state(self, m, v, t):
+        """resume both optimisers mid-run: first / second moments by variable name and the steps taken so far"""
+        for opt in (self.opt_d, self.opt_g):
+            for n in opt.m:
+                opt.m[n] = torch.as_tensor(np.asarray(m[n]), dtype=self.dtype).clone()
+                opt.v[n] = torch.as_tensor(np.asarray(v[n]), dtype=self.dtype).clone()
+            opt.t = int(t)
+        self.global_step = int(t)
+
     def forward_losses(self, z, real, collect=None):
         p = self.params
         gen, up_g = net_forward(self.gen_specs, p, z, True, collect)

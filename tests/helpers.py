@@ -21,6 +21,15 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b)) / scale)
 
 
+def elementwise_err(a, b, floor_frac=1e-5):
+    """the ELEMENT-WISE companion of rel_err: max over elements of |a-b| / (|b| + floor_frac * max|b|).  rel_err is
+    norm-wise (max|a-b| / max|b|) and leaves small-magnitude entries unconstrained; here every entry is held to the
+    relative bar on its own, down to an absolute floor of floor_frac of the tensor's scale (below that an fp32
+    accumulation over hundreds of terms of either sign has no significant digits left to compare)."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b) / (np.abs(b) + floor_frac * np.max(np.abs(b)))))
+
+
 def golden(pattern):
     return sorted(glob.glob(os.path.join(GOLDEN, pattern)))
 

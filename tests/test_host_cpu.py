@@ -116,6 +116,33 @@ def test_agent_checkpoint_rotation(tmp_path):
     assert agent.load(eng2) and eng2.global_step == 15
     with pytest.raises(AssertionError, match='Model diverged'):                                    # graph_func.py:856
         agent.train([step], lambda: (float('nan'), 0.0), eng, 2)
+    # a diverged model is never written, also when nothing is ever printed (query_step=None): the next run would reload it
+    quiet = Agent('unit', 'nan', load_ckpt=False, do_save=True, query_step=None, print_loss=False)
+    with pytest.raises(AssertionError, match='Model diverged'):
+        quiet.train([step], lambda: (0.0, float('nan')), eng, 3)
+    assert os.listdir(os.path.join(str(tmp_path), 'unit_ckpt', 'nan')) == []
+    # data-parallel replicas hold identical variables: only rank 0 writes
+    other = FakeEngine()
+    other.rank = 1
+    Agent('unit', 'rank1', do_save=True, query_step=None, print_loss=False).train([step], lambda: (0.1, 0.2), other, 2)
+    assert os.listdir(os.path.join(str(tmp_path), 'unit_ckpt', 'rank1')) == []
+    # checkpoints hold tensors and plain containers only (loaded with weights_only=True): variables round-trip as arrays
+    class VarEngine(FakeEngine):
+        def __init__(self):
+            self.vars = {'gen/l1/kernel/kernel': np.arange(6, dtype=np.float32).reshape(2, 3)}
+
+        def state_dict(self):
+            return {'global_step': self.global_step, 'variables': dict(self.vars)}
+
+        def load_state_dict(self, sd):
+            self.global_step, self.vars = sd['global_step'], sd['variables']
+    a, b = VarEngine(), VarEngine()
+    a.global_step = 7
+    b.vars = {}
+    ag = Agent('unit', 'vars', load_ckpt=True, do_save=True, query_step=None, print_loss=False)
+    ag.save(a)
+    assert ag.load(b) and b.global_step == 7
+    assert isinstance(b.vars['gen/l1/kernel/kernel'], np.ndarray) and np.array_equal(b.vars['gen/l1/kernel/kernel'], a.vars['gen/l1/kernel/kernel'])
     FLAGS.SILENT_MODE = False
 
 

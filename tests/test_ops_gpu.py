@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import RTOL, golden, load, rel_err
+from helpers import RTOL, elementwise_err, golden, load, rel_err
 from oracle import c_oracle, restatement as R
 
 pytestmark = pytest.mark.gpu
@@ -221,6 +221,8 @@ def test_conv2d_fwd(ops, case):
                      + torch.tensor(b, dtype=torch.float64).reshape(1, -1, 1, 1), act).numpy()
         y = ops.conv2d_fwd(nhwc(x), dev(w), s, bias=dev(b), scale=dev([sc]), act=act)
         assert rel_err(to_nchw(y), ref) <= RTOL, act
+        # ... and element by element: 1e-4 of EACH activation down to a floor of 1e-5 of the tensor's scale
+        assert elementwise_err(to_nchw(y), ref) <= RTOL, (act, elementwise_err(to_nchw(y), ref))
 
 
 @pytest.mark.parametrize('case', CONV_CASES, ids=[str(c) for c in CONV_CASES])
@@ -386,6 +388,8 @@ def test_conv2d_winograd_path(ops, case):
             ref = R._act(yt.detach() * float(sc) + torch.tensor(b, dtype=torch.float64).reshape(1, -1, 1, 1), act).numpy()
             y = ops.conv2d_fwd(nhwc(x), dev(w), s, bias=dev(b), scale=dev([sc]), act=act)
             assert rel_err(to_nchw(y), ref) <= RTOL, act
+            # element by element too (the Winograd transforms cost about one decimal digit against the direct form)
+            assert elementwise_err(to_nchw(y), ref, floor_frac=1e-4) <= RTOL, (act, elementwise_err(to_nchw(y), ref, 1e-4))
         dx = ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s)
         assert rel_err(to_nchw(dx), gx.numpy()) <= RTOL
         if N % 3 == 0:                                   # [2B ; B] rows against 2B activations

@@ -168,6 +168,43 @@ def test_full_step_restatement_matches_reference(loss_type):
                     assert rel_err(gan.params[n].numpy(), v) <= 2e-6, n
 
 
+@pytest.mark.parametrize('tag', ['rep', 'res_rep', 'rep_pim'])
+def test_warm_start_restatement_matches_reference(tag):
+    """the fixtures recorded after 20 warm-up steps of the reference code (oracle/make_golden.py:make_step_warm): from
+    their state (variables, Adam moments, step count) the restatement's free-running fp64 trajectory reproduces
+    losses, every gradient and every final variable of the reference run to 1e-6 - no step-0 noise regime here, so the
+    bounds are rounding-level on every step"""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
+    from tiny_arch import tiny_architecture, tiny_res_architecture
+    fx = load(golden('step_warm_%s.npz' % tag)[0])
+    arch = tiny_res_architecture() if tag.startswith('res_') else tiny_architecture()
+    init = {k[len('init/'):]: v for k, v in fx.items() if k.startswith('init/')}
+    m = {k[len('adam_m/'):]: v for k, v in fx.items() if k.startswith('adam_m/')}
+    v2 = {k[len('adam_v/'):]: v for k, v in fx.items() if k.startswith('adam_v/')}
+    gan = R.OracleGan(arch, str(fx['loss_type']), tuple(fx['lr']), dtype=torch.float64, params=init,
+                      sn_mode=str(fx['sn_mode']))
+    gan.set_adam_state(m, v2, int(fx['adam_t']))
+    n_steps = fx['z'].shape[0]
+    for step in range(n_steps):
+        z, real = torch.tensor(fx['z'][step], dtype=torch.float64), torch.tensor(fx['real'][step], dtype=torch.float64)
+        pre = 'step%d/' % step
+        if any(k.startswith(pre + 'grad/') for k in fx):
+            lg, ld, stats, upd, gd, gg, aux = gan.grads(z, real)
+            for n, g in list(gd.items()) + list(gg.items()):
+                ref = fx[pre + 'grad/' + n + '_f64']
+                gscale = max(np.abs(fx[pre + 'grad/' + k + '_f64']).max() for k in (gd if n in gd else gg))
+                assert np.abs(g.numpy() - ref).max() <= 2e-6 * np.abs(ref).max() + 1e-9 * gscale, (step, n)
+        lg, ld = gan.step(z, real)
+        for got, name in ((lg, 'loss_gen_f64'), (ld, 'loss_dis_f64')):
+            ref = float(fx[pre + name])
+            assert abs(got - ref) <= 1e-9 * max(abs(ref), 1e-6), (step, name, got, ref)
+    for k, v in fx.items():
+        if k.startswith('final/'):
+            n = k[len('final/'):-len('_f64')]
+            assert rel_err(gan.params[n].numpy(), v) <= 2e-6, n
+
+
 def test_reference_fp32_noise_floor():
     """Why the GPU loss tolerance carries an absolute floor: the reference's OWN fp32 evaluation
     (torch-CPU under the shim) misses its fp64 evaluation by more than 1e-4 of the loss on the

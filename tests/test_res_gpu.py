@@ -196,6 +196,122 @@ def test_res_step_matches_oracle_on_mfma_sized_blocks(loss_type, sn_mode):
                 assert np.linalg.norm(du - dr) <= 0.1 * np.linalg.norm(dr) + 1e-12, (step, n)
 
 
+def test_step_on_the_shipped_resnet_architecture():
+    """BASELINE.json config 5: the FULL-WIDTH LSUN 64x64 ResNet-SN dict of configs.lsun_resnet() (1024-channel blocks,
+    the bench workload) at batch 4 - two teacher-forced steps against the fp64 oracle, as
+    test_step_gpu.py::test_step_on_the_shipped_architectures does for the DCGAN dicts: generated images, D scores and
+    losses at 1e-4 each step, every gradient in L2 at the second."""
+    import configs
+    from mmdgan_hip.tape import TapeEngine
+    arch, lr = configs.lsun_resnet()
+    B = 4
+    c, h, w = arch['input'][0]
+    eng = TapeEngine(arch, 'rep', tuple(lr), batch_size=B, seed=5)
+    ora = R.OracleGan(arch, 'rep', tuple(lr), dtype=torch.float64, params=eng.get_variables())
+    rs = np.random.RandomState(7)
+    for step in range(2):
+        z = rs.randn(B, arch['code'][0][0]).astype(np.float32)
+        real = rs.uniform(-1, 1, (B, c, h, w)).astype(np.float32)
+        prev_vars = {k: v.numpy().copy() for k, v in ora.params.items()}
+        eng.set_variables(prev_vars)
+        zt, rt = torch.tensor(z, dtype=torch.float64), torch.tensor(real, dtype=torch.float64)
+        lg, ld, stats, upd, gd, gg, (gen, s_x, s_gen) = ora.grads(zt, rt)
+        ora.step(zt, rt)
+        eng.step(nhwc(real), torch.as_tensor(z).cuda())
+        fake = np.transpose(eng._dis_in[B:].cpu().numpy(), (0, 3, 1, 2))
+        assert close(fake, gen.detach().numpy(), RTOL, 0.0), step
+        losses = eng.losses.cpu().numpy().astype(np.float64)
+        escale = float(max(losses[2:5]))
+        assert abs(losses[0] - float(lg)) <= RTOL * abs(float(lg)) + 1e-5 * escale, (step, losses[0], float(lg))
+        assert abs(losses[1] - float(ld)) <= RTOL * abs(float(ld)) + 1e-5 * escale, (step, losses[1], float(ld))
+        sig = eng.sigmas()                               # every kernel of every D block carries its own power iteration
+        assert len(sig) == sum(1 for k in eng.dis.kernels if k.sn) >= 14 and all(np.isfinite(v) and v > 0 for v in sig.values())
+        if step == 0:
+            continue
+        grads = eng.get_variables(grad=True)
+        ref_g = dict(gd)
+        ref_g.update(gg)
+        floor32 = None
+        for net in ('gen', 'dis'):
+            gscale = max(float(ref_g[n].abs().max()) for n in grads if n.startswith(net))
+            n_noise = 0
+            for n in grads:
+                if not n.startswith(net):
+                    continue
+                r = ref_g[n].numpy()
+                if np.abs(r).max() <= 1e-9 * gscale:     # analytically zero (see the mid-size test): magnitude only
+                    assert np.abs(grads[n]).max() <= 1e-4 * gscale, (step, n)
+                    n_noise += 1
+                    continue
+                l2 = np.linalg.norm(grads[n].astype(np.float64) - r) / (np.linalg.norm(r) + 1e-6 * gscale)
+                if l2 > 5e-3:
+                    # relu masks behind a batch norm that flip between an fp32 and an fp64 evaluation: the bar is what
+                    # the oracle ITSELF loses when run in fp32 on the same step (see the mid-size test above)
+                    if floor32 is None:
+                        o32 = R.OracleGan(arch, 'rep', tuple(lr), dtype=torch.float32, params=prev_vars)
+                        r32 = o32.grads(torch.tensor(z), torch.tensor(real))
+                        floor32 = dict(r32[4])
+                        floor32.update(r32[5])
+                    fl = np.linalg.norm(floor32[n].double().numpy() - r) / (np.linalg.norm(r) + 1e-6 * gscale)
+                    assert l2 <= 2.0 * fl + 1e-3, (step, n, l2, fl)
+            assert n_noise <= 5, (net, n_noise)
+
+
+def test_batch_norm_in_the_discriminator_takes_the_primitive_op_engine():
+    """batch norm in D couples the rows of the batch, which the hand-scheduled engine's 3B-row backward pass does not
+    model: GanEngine refuses such a dict, SNGan.init_net routes it to the primitive-op engine, and that engine's step
+    (two full passes through D) matches the fp64 oracle"""
+    from DeepLearning.my_sngan import SNGan
+    from mmdgan_hip.engine import GanEngine
+    from mmdgan_hip.tape import TapeEngine
+    ak = float(np.power(64.0, 0.125))
+    arch = {'input': [(3, 16, 16)], 'code': [(16, 'linear')],
+            'generator': [{'name': 'l1', 'out': 32 * 4 * 4, 'op': 'd', 'out_reshape': [32, 4, 4]},
+                          {'name': 'l2_up', 'out': 16, 'op': 'tc', 'act': 'relu', 'act_nm': 'bn', 'kernel': 4, 'strides': 2},
+                          {'name': 'l3_up', 'out': 8, 'op': 'tc', 'act': 'relu', 'act_nm': 'bn', 'kernel': 4, 'strides': 2},
+                          {'name': 'l4_t', 'out': 3, 'act': 'tanh'}],
+            'discriminator': [{'name': 'l1', 'out': 16, 'act': 'lrelu', 'act_k': ak, 'w_nm': 's'},
+                              {'name': 'l2_ds', 'out': 32, 'act': 'lrelu', 'act_nm': 'bn', 'kernel': 4, 'strides': 2},
+                              {'name': 'l3_ds', 'out': 32, 'act': 'lrelu', 'act_k': ak, 'w_nm': 's', 'kernel': 4, 'strides': 2,
+                               'out_reshape': [4 * 4 * 32]},
+                              {'name': 'l4_s', 'out': 16, 'op': 'd', 'act_k': ak, 'w_nm': 's'}]}
+    with pytest.raises(NotImplementedError, match='batch norm in the discriminator'):
+        GanEngine(arch, 'rep', (5e-4, 2e-4), batch_size=8)
+    g_sn = {**arch, 'generator': [dict(arch['generator'][0], w_nm='s', act_k=1.0)] + arch['generator'][1:]}
+    with pytest.raises(NotImplementedError, match='spectral norm in the generator'):
+        GanEngine(g_sn, 'rep', (5e-4, 2e-4), batch_size=8)
+    mdl = SNGan(arch, num_class=0, loss_type='rep', optimizer='adam')
+    assert isinstance(mdl.init_net((5e-4, 2e-4), 8), TapeEngine)
+    B = 8
+    eng = TapeEngine(arch, 'rep', (5e-4, 2e-4), batch_size=B, seed=2)
+    ora = R.OracleGan(arch, 'rep', (5e-4, 2e-4), dtype=torch.float64, params=eng.get_variables())
+    rs = np.random.RandomState(3)
+    for step in range(3):
+        z = rs.randn(B, 16).astype(np.float32)
+        real = rs.uniform(-1, 1, (B, 3, 16, 16)).astype(np.float32)
+        eng.set_variables({k: v.numpy().copy() for k, v in ora.params.items()})
+        zt, rt = torch.tensor(z, dtype=torch.float64), torch.tensor(real, dtype=torch.float64)
+        lg, ld, stats, upd, gd, gg, aux = ora.grads(zt, rt)
+        ora.step(zt, rt)
+        eng.step(nhwc(real), torch.as_tensor(z).cuda())
+        losses = eng.losses.cpu().numpy().astype(np.float64)
+        escale = float(max(losses[2:5]))
+        assert abs(losses[0] - float(lg)) <= RTOL * abs(float(lg)) + 1e-5 * escale, (step, losses[0], float(lg))
+        assert abs(losses[1] - float(ld)) <= RTOL * abs(float(ld)) + 1e-5 * escale, (step, losses[1], float(ld))
+        if step == 0:
+            continue
+        grads = eng.get_variables(grad=True)
+        ref_g = dict(gd)
+        ref_g.update(gg)
+        for net in ('gen', 'dis'):
+            gscale = max(float(ref_g[n].abs().max()) for n in grads if n.startswith(net))
+            for n in grads:
+                if n.startswith(net) and np.abs(ref_g[n].numpy()).max() > 1e-9 * gscale:
+                    r = ref_g[n].numpy()
+                    l2 = np.linalg.norm(grads[n].astype(np.float64) - r) / (np.linalg.norm(r) + 1e-6 * gscale)
+                    assert l2 <= 5e-3, (step, n, l2)
+
+
 def test_res_inference_and_api_selection(tmp_path):
     """SNGan picks the primitive-op engine for an architecture with blocks; eval_sampling runs it in inference mode"""
     from DeepLearning.my_sngan import SNGan

@@ -91,6 +91,70 @@ def test_step_matches_reference_golden(loss_type, use_graph):
             assert np.linalg.norm(du - dr) <= 0.01 * np.linalg.norm(dr) + 1e-12, n       # the 3-step update, in L2
 
 
+@pytest.mark.parametrize('tag,engine', [('rep', 'dcgan'), ('rep_pim', 'dcgan'), ('rep', 'tape'), ('res_rep', 'tape')])
+def test_free_run_from_warm_start_matches_reference(tag, engine):
+    """three FREE-RUNNING steps from a state the reference code reached after 20 warm-up steps (variables, Adam
+    moments, step count; tests/golden/step_warm_*.npz).  No step-0 noise regime here - the gradients are O(1e-2), Adam
+    runs far above its eps - so every step is held to the 1e-4 bar against the reference's fp64 run: losses, the
+    spectral norm of every D kernel, all gradients (first and last step), every variable at the end, and the 3-step
+    update in L2.  'dcgan': the hand-scheduled engine; 'tape': the primitive-op engine ('res_rep': residual blocks)."""
+    from tiny_arch import tiny_res_architecture
+    if engine == 'tape':
+        from mmdgan_hip.tape import TapeEngine as Engine
+    else:
+        from mmdgan_hip.engine import GanEngine as Engine
+    fx = load(golden('step_warm_%s.npz' % tag)[0])
+    arch = tiny_res_architecture() if tag.startswith('res_') else tiny_architecture()
+    B, lr = int(fx['B']), tuple(fx['lr'])
+    eng = Engine(arch, str(fx['loss_type']), lr, batch_size=B, sn_mode=str(fx['sn_mode']))
+    init = {k[len('init/'):]: v for k, v in fx.items() if k.startswith('init/')}
+    assert sorted(init) == sorted(eng.variable_names())
+    eng.set_variables(init)
+    eng.set_adam_state({k[len('adam_m/'):]: v for k, v in fx.items() if k.startswith('adam_m/')},
+                       {k[len('adam_v/'):]: v for k, v in fx.items() if k.startswith('adam_v/')}, int(fx['adam_t']))
+    n_steps = fx['z'].shape[0]
+    for step in range(n_steps):
+        eng.step(nhwc(fx['real'][step]), torch.as_tensor(fx['z'][step]).cuda())
+        pre = 'step%d/' % step
+        losses = eng.losses.cpu().numpy().astype(np.float64)
+        escale = float(max(losses[2:5]))
+        for idx, name in ((0, 'loss_gen'), (1, 'loss_dis')):
+            ref = float(fx[pre + name + '_f64'])
+            assert abs(losses[idx] - ref) <= RTOL * abs(ref) + 4e-7 * escale, (step, name, losses[idx], ref)
+        sig = eng.sigmas()
+        n_sig = 0
+        for k, v in fx.items():
+            if k.startswith(pre + 'sigma/') and k.endswith('_f64'):
+                scope = k[len(pre + 'sigma/'):-len('_f64')]
+                assert abs(sig[scope] - float(v)) <= RTOL * float(v), (step, scope, sig[scope], float(v))
+                n_sig += 1
+        assert n_sig == len(sig) > 0
+        if any(k.startswith(pre + 'grad/') for k in fx):
+            grads = eng.get_variables(grad=True)
+            gscale = {net: max(np.abs(fx[pre + 'grad/' + n + '_f64']).max() for n in grads if n.startswith(net))
+                      for net in ('gen', 'dis')}
+            for n, g in grads.items():
+                ref = fx[pre + 'grad/' + n + '_f64']
+                # floor: gradients that are analytically zero (a bias behind which only score differences matter, a
+                # bias in front of a batch norm) are rounding noise in every implementation: 1e-6 of the net's scale
+                assert close(g, ref, RTOL, 1e-6 * gscale[n[:3]]), (step, n, np.abs(g - ref).max(), np.abs(ref).max())
+    pre = 'step%d/' % (n_steps - 1)
+    gsc = {net: max(np.abs(fx[pre + 'grad/' + n + '_f64']).max() for n in init if (pre + 'grad/' + n + '_f64') in fx
+                    and n.startswith(net)) for net in ('gen', 'dis')}
+    noise = {n for n in init if (pre + 'grad/' + n + '_f64') in fx
+             and np.abs(fx[pre + 'grad/' + n + '_f64']).max() <= 1e-5 * gsc[n[:3]]}
+    assert len(noise) <= 4, noise
+    for n, v in eng.get_variables().items():
+        if n in noise:                      # analytically zero gradient: Adam turns its rounding noise into lr-sized steps
+            assert np.abs(v - fx['init/' + n]).max() <= 3.5 * max(lr), n
+            continue
+        ref = fx['final/' + n + '_f64']
+        assert close(v, ref, RTOL, 0.0), (n, np.abs(v - ref).max(), np.abs(ref).max())
+        if not (n.endswith('in_rand') or '/moving_' in n):
+            du, dr = v.astype(np.float64) - fx['init/' + n], ref.astype(np.float64) - fx['init/' + n]
+            assert np.linalg.norm(du - dr) <= 1e-3 * np.linalg.norm(dr) + 1e-12, (n, np.linalg.norm(du - dr) / np.linalg.norm(dr))
+
+
 def mid_architecture():
     ak = float(np.power(64.0, 0.125))
     s = 's'
@@ -187,19 +251,21 @@ def test_step_matches_oracle_mfma_path(loss_type):
                 assert np.abs(v - ref).max() <= 2.5 * 5e-4, (step, n)
 
 
-@pytest.mark.parametrize('config', ['cifar', 'stl', 'celeba'])
-def test_step_on_the_shipped_architectures(config):
-    """the full-width architectures of configs.py (the bench workloads) at batch 8: with the test thresholds every
-    3x3 layer runs the Winograd kernels (forward, input-gradient, weight-gradient) and every 4x4 stride-2 layer the
-    F(2x2,2x2) ones, in their real channel counts and image sizes.  Two teacher-forced steps against the fp64
-    oracle: generated images, D scores and losses each step, all gradients (L2) at the second."""
+@pytest.mark.parametrize('config,loss,B', [('cifar', 'rep', 8), ('cifar', 'rep', 64), ('stl', 'rep', 8), ('stl', 'rmb', 64),
+                                           ('celeba', 'rep', 8)])
+def test_step_on_the_shipped_architectures(config, loss, B):
+    """the full-width architectures of configs.py (the bench workloads = BASELINE.json's configs, with the loss each is
+    quoted with): at batch 8 - with the test thresholds every 3x3 layer runs the Winograd kernels (forward,
+    input-gradient, weight-gradient) and every 4x4 stride-2 layer the F(2x2,2x2) ones, in their real channel counts
+    and image sizes - and CIFAR `rep` / STL `rmb` at their own batch 64, where the library's production kernel choice
+    applies.  Two teacher-forced steps against the fp64 oracle: generated images, D scores and losses each step, all
+    gradients (L2) at the second."""
     import configs
     from mmdgan_hip.engine import GanEngine
     arch, lr = configs.CONFIGS[config]()
-    B = 8
     c, h, w = arch['input'][0]
-    eng = GanEngine(arch, 'rep', tuple(lr), batch_size=B, seed=5)
-    ora = R.OracleGan(arch, 'rep', tuple(lr), dtype=torch.float64, params=eng.get_variables())
+    eng = GanEngine(arch, loss, tuple(lr), batch_size=B, seed=5)
+    ora = R.OracleGan(arch, loss, tuple(lr), dtype=torch.float64, params=eng.get_variables())
     rs = np.random.RandomState(7)
     last = eng.dis.specs[-1].scope
     for step in range(2):
@@ -232,6 +298,44 @@ def test_step_on_the_shipped_architectures(config):
                     r = ref_g[n].numpy()
                     l2 = np.linalg.norm(grads[n].astype(np.float64) - r) / (np.linalg.norm(r) + 1e-6 * gscale)
                     assert l2 <= 5e-3, (config, n, l2)
+
+
+def test_dense_on_dense_generator_keeps_its_gradients_past_the_first_step():
+    """a generator whose second dense layer (K = 1024 >= 512) sits on a dense + BN layer: the input-gradient gemm of the
+    upper layer has a linear epilogue and a long K - the shape that used to take the split-K path into a buffer
+    nobody zeroed after the first step (mmdgan_gemm now splits under mmdgan_set_outputs_prezeroed(1) only on
+    MMDGAN_ACT_FLAG_OUT_ZEROED).  Four teacher-forced steps against the fp64 oracle: gradients of steps 1..3."""
+    from mmdgan_hip.engine import GanEngine
+    ak = float(np.power(64.0, 0.125))
+    arch = {'input': [(3, 8, 8)], 'code': [(32, 'linear')],
+            'generator': [{'name': 'l1', 'out': 1024, 'op': 'd', 'act': 'relu', 'act_nm': 'bn'},
+                          {'name': 'l2', 'out': 64 * 4 * 4, 'op': 'd', 'act': 'linear', 'out_reshape': [64, 4, 4]},
+                          {'name': 'l3_up', 'out': 32, 'op': 'tc', 'act': 'relu', 'act_nm': 'bn', 'kernel': 4, 'strides': 2},
+                          {'name': 'l4_t', 'out': 3, 'act': 'tanh'}],
+            'discriminator': [{'name': 'l1', 'out': 32, 'act': 'lrelu', 'act_k': ak, 'w_nm': 's'},
+                              {'name': 'l2_ds', 'out': 64, 'act': 'lrelu', 'act_k': ak, 'w_nm': 's', 'kernel': 4, 'strides': 2,
+                               'out_reshape': [4 * 4 * 64]},
+                              {'name': 'l3_s', 'out': 16, 'op': 'd', 'act_k': ak, 'w_nm': 's'}]}
+    B = 16
+    eng = GanEngine(arch, 'rep', (5e-4, 2e-4), batch_size=B, seed=4)
+    ora = R.OracleGan(arch, 'rep', (5e-4, 2e-4), dtype=torch.float64, params=eng.get_variables())
+    rs = np.random.RandomState(8)
+    for step in range(4):
+        z = rs.randn(B, 32).astype(np.float32)
+        real = rs.uniform(-1, 1, (B, 3, 8, 8)).astype(np.float32)
+        eng.set_variables({k: v.numpy().copy() for k, v in ora.params.items()})
+        zt, rt = torch.tensor(z, dtype=torch.float64), torch.tensor(real, dtype=torch.float64)
+        lg, ld, stats, upd, gd, gg, aux = ora.grads(zt, rt)
+        ora.step(zt, rt)
+        eng.step(nhwc(real), torch.as_tensor(z).cuda())
+        if step == 0:
+            continue
+        grads = eng.get_variables(grad=True)
+        gscale = max(float(g.abs().max()) for g in gg.values())
+        for n, r in gg.items():
+            r = r.numpy()
+            l2 = np.linalg.norm(grads[n].astype(np.float64) - r) / (np.linalg.norm(r) + 1e-6 * gscale)
+            assert l2 <= 5e-3, (step, n, l2)
 
 
 _RCCL_CHILD = r"""
