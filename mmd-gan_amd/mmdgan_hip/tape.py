@@ -96,6 +96,7 @@ class _Net:
         # instead of 9, no up-sampled tensor in HBM; ResNet-SN config 7.32 -> 6.57 ms per step); MMDGAN_TAPE_COMPOSE=0: two ops
         self.compose = os.environ.get('MMDGAN_TAPE_COMPOSE', '1') != '0'
         self.prims, self.kernels, self.bns = [], [], []
+        self._bn_perm = {}                                               # BN prefix -> feature permutation (see _allocate)
         self._nval = 1                                                   # value 0 is the net input
         self.shapes = {0: list(in_ref)}                                  # value id -> reference shape (no batch)
         cur = 0
@@ -324,17 +325,19 @@ class _Net:
                 if src is not None and src['kind'] == 'reshape' and len(src['src_shape']) == 3:
                     p['k'].row_perm = _chw_perm(*src['src_shape'])
             if p['kind'] == 'reshape' and len(self.shapes[p['out']]) == 3:
+                # the dense layer's columns are stored in NHWC order of the image they become; a per-feature batch
+                # norm / activation in between (my_test_stl.py:12: dense -> BN -> relu -> [512,6,6]) works on the
+                # permuted features unchanged - its gamma / beta / moving statistics carry the same permutation
+                perm = _chw_perm(*self.shapes[p['out']])
                 src = produced_by.get(p['ins'][0])
+                while src is not None and src['kind'] in ('bn', 'act'):
+                    if src['kind'] == 'bn':
+                        self._bn_perm[src['prefix']] = perm
+                    src = produced_by.get(src['ins'][0])
                 if src is not None and src['kind'] == 'dense':
-                    src['k'].col_perm = _chw_perm(*self.shapes[p['out']])
+                    src['k'].col_perm = perm
                 else:
                     raise NotImplementedError('a reshape to an image must follow a dense layer')
-        for p in self.prims:
-            if p['kind'] == 'bn':
-                src = produced_by.get(p['ins'][0])
-                if src is not None and src['kind'] == 'dense' and src['k'].col_perm is not None:
-                    raise NotImplementedError('batch norm between a dense layer and its image reshape is served by the '
-                                              'DCGAN engine only')
         entries = []
         for item in self._creation_order():
             if isinstance(item, _Kernel):
@@ -392,6 +395,8 @@ class _Net:
         k = self._kernel_by_name.get(name)
         if k is not None and k.op == 'd' and name == k.bias_name:
             return k.col_perm
+        if '/BN/' in name:
+            return self._bn_perm.get(name[:name.rindex('/BN/')])
         return None
 
     def to_native(self, name, ref):
@@ -1010,8 +1015,8 @@ class TapeEngine:
         for k in m:
             net = self._net_of(k)
             for flat, src in ((net.adam_m, m[k]), (net.adam_v, v[k])):
-                t = net.arena.view(k, flat)
-                t.copy_(torch.as_tensor(net.to_native(k, src), device=self.device).reshape(t.shape))
+                dst = net.arena.view(k, flat)
+                dst.copy_(torch.as_tensor(net.to_native(k, src), device=self.device).reshape(dst.shape))
         for net in (self.gen, self.dis):
             net.opt.step_counter.fill_(int(t))
 

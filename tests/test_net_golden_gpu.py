@@ -109,18 +109,25 @@ def test_forward_backward_kernels_reproduce_the_reference_net_fixtures(case):
         vals = eng._forward(net, x, True, 'fx')
         y = vals[net.out_val]
         y_ref = fx[pre + 'y_f64']
-        got_y = _to_ref(y).reshape(y_ref.shape) if y.dim() == 4 else y.cpu().numpy().reshape(y_ref.shape)
+        if y.dim() == 2 and y_ref.ndim == 4:
+            # the engine's flatten of a feature map is a view of its NHWC memory (the permutation to the reference's
+            # C,H,W order lives in the rows of the dense layer that follows - here there is none): un-flatten as NHWC
+            got_y = y.cpu().numpy().reshape(batch, y_ref.shape[2], y_ref.shape[3], y_ref.shape[1]).transpose(0, 3, 1, 2)
+        else:
+            got_y = _to_ref(y) if y.dim() == 4 else y.cpu().numpy()
         assert rel_err(got_y, y_ref) <= RTOL, (case, step, 'y', rel_err(got_y, y_ref))
         for k, v in fx.items():                                   # sigma of every SN kernel
             if k.startswith(pre + 'sigma/') and k.endswith('_f64'):
                 scope = k[len(pre + 'sigma/'):-len('_f64')]
                 got = float(net.sn[scope + '/kernel']['sigma'].item())
                 assert abs(got - float(v)) <= RTOL * abs(float(v)), (case, step, scope, got, float(v))
-        # upstream gradient in the engine's layout: NHWC for a feature map, the fixture's C,H,W flatten for a vector
+        # upstream gradient in the engine's layout
         if y.dim() == 4:
             dy = _to_dev(dy_ref)
+        elif dy_ref.ndim == 4:                                    # the same NHWC flatten as above
+            dy = torch.as_tensor(np.ascontiguousarray(dy_ref.transpose(0, 2, 3, 1).reshape(batch, -1))).cuda()
         else:
-            dy = torch.as_tensor(np.ascontiguousarray(dy_ref.reshape(batch, -1))).cuda()
+            dy = torch.as_tensor(np.ascontiguousarray(dy_ref)).cuda()
         net.grads.zero_()
         dx = eng._backward(net, vals, dy.contiguous(), 'fxb', param_grads=True, need_input_grad=True)
         torch.cuda.synchronize()

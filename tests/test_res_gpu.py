@@ -277,7 +277,9 @@ def test_batch_norm_in_the_discriminator_takes_the_primitive_op_engine():
                               {'name': 'l4_s', 'out': 16, 'op': 'd', 'act_k': ak, 'w_nm': 's'}]}
     with pytest.raises(NotImplementedError, match='batch norm in the discriminator'):
         GanEngine(arch, 'rep', (5e-4, 2e-4), batch_size=8)
-    g_sn = {**arch, 'generator': [dict(arch['generator'][0], w_nm='s', act_k=1.0)] + arch['generator'][1:]}
+    g_sn = {**arch, 'generator': [dict(arch['generator'][0], w_nm='s', act_k=1.0)] + arch['generator'][1:],
+            'discriminator': [d if 'act_nm' not in d else dict({k: v for k, v in d.items() if k != 'act_nm'}, act_k=ak, w_nm='s')
+                              for d in arch['discriminator']]}
     with pytest.raises(NotImplementedError, match='spectral norm in the generator'):
         GanEngine(g_sn, 'rep', (5e-4, 2e-4), batch_size=8)
     mdl = SNGan(arch, num_class=0, loss_type='rep', optimizer='adam')
@@ -309,7 +311,9 @@ def test_batch_norm_in_the_discriminator_takes_the_primitive_op_engine():
                 if n.startswith(net) and np.abs(ref_g[n].numpy()).max() > 1e-9 * gscale:
                     r = ref_g[n].numpy()
                     l2 = np.linalg.norm(grads[n].astype(np.float64) - r) / (np.linalg.norm(r) + 1e-6 * gscale)
-                    assert l2 <= 5e-3, (step, n, l2)
+                    # G: a relu behind a batch norm whose input is ~1e-7 flips between an fp32 and an fp64 evaluation
+                    # and moves every gradient upstream of it by up to ~1e-2 in L2 (see the mid-size test above)
+                    assert l2 <= (2e-2 if net == 'gen' else 5e-3), (step, n, l2)
 
 
 def test_res_inference_and_api_selection(tmp_path):
