@@ -55,6 +55,10 @@ extern "C" {
 #define MMDGAN_LOSS_MGB 3      /* 'mgb': sigma-1 Gaussian with bounds (0.25, 4) on the D side, math_func.py:2175-2193 */
 #define MMDGAN_LOSS_HINGE 4    /* math_func.py:2137-2143 (w, bounds, masks, dist, workspace unused) */
 #define MMDGAN_LOSS_LOGISTIC 5 /* 'logistic' / '': non-saturating, math_func.py:2128-2135 */
+/* 'mmd_g_mix' / 'fixed_g_mix' (GANLoss._mmd_g_mix_, math_func.py:2195-2228) and 'sgm' (_single_mmd_g_mix_, :2230-2263):
+ * served by mmdgan_mmd_mix_loss, not by mmdgan_mmd_loss */
+#define MMDGAN_LOSS_MMD_G_MIX 6
+#define MMDGAN_LOSS_SGM 7
 /* OR-ed into loss_type: write the four gradient blocks of mmdgan_mmd_loss in the order
  * [dL_dis/ds_x, dL_dis/ds_gen, dL_gen/ds_gen, dL_gen/ds_x] instead of [dL_gen/ds_gen, dL_gen/ds_x, dL_dis/ds_gen,
  * dL_dis/ds_x]: the first 3B rows are then exactly the score gradient a discriminator fed [real ; fake] (and the
@@ -205,6 +209,29 @@ size_t mmdgan_mmd_workspace_bytes(int B, int d);
 int mmdgan_mmd_loss(const float *s_gen, const float *s_x, int B, int d, int loss_type, float w0, float w1,
                     float lower_bound, float upper_bound, float *out_scalars, float *grads,
                     unsigned char *masks, float *dist, void *workspace, void *stream);
+
+/* The `*_mix` losses: MMD with a coin that swaps generated and real scores between the two sets when the generator
+ * loss has been above a threshold (math_func.py: get_mix_coin :2061-2085, slice_pairwise_distance :2038-2058,
+ * moving_average_copy / moving_average_update :1979-2035, GANLoss._mmd_g_mix_ :2195-2228, _single_mmd_g_mix_ :2230-2263).
+ *   loss_type     MMDGAN_LOSS_MMD_G_MIX (five-scale mixture) or MMDGAN_LOSS_SGM (sigma 1), | MMDGAN_LOSS_FLAG_GRADS_DIS_FIRST
+ *   uni           [B] DEVICE floats: this step's tf.random_uniform([B], 0, 1) draw (:2079) - an input, so the
+ *                 reference's boolean masks are reproducible bit for bit:  mix_indices = uni > mix_prob (:2080)
+ *   mix_threshold 1.0 for mmd_g_mix, 0.2 for sgm in the reference (:2195, :2230)
+ *   loss_average_update, mix_prob_update   both 0.01 in the reference (:2062)
+ *   state         [2] DEVICE floats {loss_average ('coin/gen_average'), mix_prob ('coin/prob')}: read for this step,
+ *                 then updated in place (the UPDATE_OPS; both right-hand sides use the pre-update values):
+ *                   loss_average <- (1 - rho) loss_average + rho loss_gen
+ *                   mix_prob     <- clip(mix_prob + rho (loss_average - mix_threshold), 0, 0.5)
+ *   out_scalars   [8] loss_gen (un-mixed MMD), loss_dis (= -MMD between the mixed groups), e_kxx, e_kxy, e_kyy of the
+ *                 un-mixed sets, loss_average and mix_prob as used (pre-update), number of true mix_indices
+ *   grads         [4,B,d] as mmdgan_mmd_loss (NULL = forward only)
+ *   masks         [5B] bytes: mix_indices [B], mix_group_1 = [idx, !idx] [2B], mix_group_2 = [!idx, idx] [2B]  (:2052-2053;
+ *                 NULL = skip)
+ *   workspace     mmdgan_mmd_mix_workspace_bytes(B, d) bytes, zero before the first call (B <= 8192) */
+size_t mmdgan_mmd_mix_workspace_bytes(int B, int d);
+int mmdgan_mmd_mix_loss(const float *s_gen, const float *s_x, int B, int d, int loss_type, const float *uni,
+                        float mix_threshold, float loss_average_update, float mix_prob_update, float *state,
+                        float *out_scalars, float *grads, unsigned char *masks, void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * TF-semantics Adam over a list of tensors in one launch          graph_func.py:518-527

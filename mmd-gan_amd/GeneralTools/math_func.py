@@ -6,16 +6,29 @@ Kept names and signatures: get_squared_dist (math_func.py:767) and GANLoss (:208
 entry (the B x B matrices they take are never materialised).  Inputs are [B, d] fp32 CUDA tensors; results are
 device tensors (no host synchronisation).  Implemented loss names: the hot path's 'rep', 'rmb' and their
 aliases (math_func.py:2644-2647) and, from SURVEY 8(f) row 1, 'mmd_g' / 'fixed_g', 'mgb', 'hinge' and
-'logistic' / '' (:2602-2611); every other name raises exactly as the reference does for an unknown one.
+'logistic' / '' (:2602-2611), and the coin-mixed 'mmd_g_mix' / 'fixed_g_mix' / 'sgm' (:2613-2622; the uniform draw can be
+injected as `uni=`, the boolean masks are exposed as .mix_indices / .mix_group_1 / .mix_group_2); every other name raises
+exactly as the reference does for an unknown one.
 """
 import numpy as np
 
 from GeneralTools.misc_fun import FLAGS
 from mmdgan_hip import ops
 
-_NOT_ON_HOT_PATH = {'wasserstein', 'fixed_t', 'mmd_t',
-                    'mmd_g_mix', 'fixed_g_mix', 'sgm', 'rand_g', 'rgb', 'rand_g_mix', 'sym_rg_mix', 'sym_rg',
+_NOT_ON_HOT_PATH = {'wasserstein', 'fixed_t', 'mmd_t', 'rand_g', 'rgb', 'rand_g_mix', 'sym_rg_mix', 'sym_rg',
                     'sym_rand_g', 'instance_noise', 'ins_noise', 'rep_gp', 'rep_ds', 'rmb_gp', 'rmb_ds', 'test'}
+
+# the two non-trainable variables of get_mix_coin (math_func.py:2073-2078), 'mmd_g_mix/coin/gen_average' and
+# 'mmd_g_mix/coin/prob': created once per device and shared by every GANLoss (tf.AUTO_REUSE), [loss_average, mix_prob]
+_MIX_STATE = {}
+
+
+def mix_state(device):
+    import torch
+    key = str(device)
+    if key not in _MIX_STATE:
+        _MIX_STATE[key] = torch.zeros(2, device=device)
+    return _MIX_STATE[key]
 
 
 def get_squared_dist(x, y=None, scale=None, z_score=False, mode='xxxyyy', name='squared_dist',
@@ -60,6 +73,20 @@ class GANLoss(object):
         w = self.repulsive_weights
         if ops.LOSS[loss_type] <= 1:
             assert w[0] - w[1] == 1.0, 'w[0]-w[1] must be 1'      # math_func.py:1340
+        if ops.is_mix_loss(loss_type):                            # math_func.py:2613-2622 -> :2195-2263
+            import torch
+            # the coin: tf.random_uniform([batch_size]) in the reference (:2079); `uni=` injects a recorded draw.  The
+            # moving averages are updated in place by the call (the reference's UPDATE_OPS, run with every train step)
+            uni = kwargs.get('uni')
+            uni = torch.rand(score_gen.shape[0], device=score_gen.device) if uni is None else \
+                torch.as_tensor(uni, dtype=torch.float32, device=score_gen.device).contiguous()
+            out = ops.mmd_mix_loss(score_gen.contiguous(), score_data.contiguous(), uni, mix_state(score_gen.device),
+                                   loss_type, kwargs.get('mix_threshold'), need_grads=True, need_masks=True)
+            self.loss_gen, self.loss_dis = out['scalars'][0], out['scalars'][1]
+            self.stats, self.grads = out['scalars'][2:7], out['grads']
+            self.mix_indices, self.mix_group_1, self.mix_group_2 = (out['masks'][k] for k in
+                                                                    ('mix_indices', 'mix_group_1', 'mix_group_2'))
+            return self.loss_gen, self.loss_dis
         out = ops.mmd_loss(score_gen.contiguous(), score_data.contiguous(), loss_type, tuple(w), need_grads=True)
         self.loss_gen, self.loss_dis = out['scalars'][0], out['scalars'][1]
         self.stats, self.grads = out['scalars'][2:7], out['grads']

@@ -319,6 +319,31 @@ extern "C" size_t mmdgan_mmd_workspace_bytes(int B, int d) {
     return 64 + blocks * kNumSums * sizeof(double);    // [counter | pad][partials]
 }
 
+// the pairwise launch itself (arguments validated by the callers)
+static int launch_pairwise(const float *s_gen, const float *s_x, int B, int d, int loss_type, int dis_first, float w0, float w1,
+                           float lower_bound, float upper_bound, float *out_scalars, float *grads, unsigned char *masks,
+                           float *dist, void *workspace, hipStream_t st) {
+    MmdArgs a;
+    a.x = s_gen; a.y = s_x; a.B = B; a.d = d; a.loss_type = loss_type; a.dis_first = dis_first;
+    a.w0 = w0; a.w1 = w1; a.lb = lower_bound; a.ub = upper_bound;
+    a.counter = (unsigned *)workspace;
+    a.partials = (double *)((char *)workspace + 64);
+    a.out = out_scalars; a.grads = grads; a.masks = masks; a.dist = dist;
+    if (zero_output(a.counter, 64, st) != hipSuccess) return check_launch("mmd_loss memset");
+    const int blocks = (B + kMmdRows - 1) / kMmdRows;
+    const size_t lds = mmd_lds_bytes(d);
+    void (*kern)(MmdArgs) = loss_type == MMDGAN_LOSS_REP ? mmd_kernel<MMDGAN_LOSS_REP>
+                          : loss_type == MMDGAN_LOSS_RMB ? mmd_kernel<MMDGAN_LOSS_RMB>
+                          : loss_type == MMDGAN_LOSS_MMD_G ? mmd_kernel<MMDGAN_LOSS_MMD_G> : mmd_kernel<MMDGAN_LOSS_MGB>;
+    static bool attr_set[4] = {false, false, false, false};
+    if (!attr_set[loss_type] && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set[loss_type] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, a);
+    return check_launch("mmd_loss");
+}
+
 extern "C" int mmdgan_mmd_loss(const float *s_gen, const float *s_x, int B, int d, int loss_type, float w0, float w1,
                                float lower_bound, float upper_bound, float *out_scalars, float *grads,
                                unsigned char *masks, float *dist, void *workspace, void *stream) {
@@ -341,23 +366,151 @@ extern "C" int mmdgan_mmd_loss(const float *s_gen, const float *s_x, int B, int 
     MMDGAN_REQUIRE(d >= 1 && d <= kMmdMaxD, "mmd_loss: d must be in [1,%d] (got %d)", kMmdMaxD, d);
     if (loss_type == MMDGAN_LOSS_MMD_G || loss_type == MMDGAN_LOSS_MGB) { w0 = 2.0f; w1 = 1.0f; }   // loss_dis = -mmd
     MMDGAN_REQUIRE(w0 - w1 == 1.0f, "w[0]-w[1] must be 1");       // math_func.py:1340
-    MmdArgs a;
-    a.x = s_gen; a.y = s_x; a.B = B; a.d = d; a.loss_type = loss_type; a.dis_first = dis_first;
-    a.w0 = w0; a.w1 = w1; a.lb = lower_bound; a.ub = upper_bound;
-    a.counter = (unsigned *)workspace;
-    a.partials = (double *)((char *)workspace + 64);
-    a.out = out_scalars; a.grads = grads; a.masks = masks; a.dist = dist;
-    if (zero_output(a.counter, 64, st) != hipSuccess) return check_launch("mmd_loss memset");
-    const int blocks = (B + kMmdRows - 1) / kMmdRows;
-    const size_t lds = mmd_lds_bytes(d);
-    void (*kern)(MmdArgs) = loss_type == MMDGAN_LOSS_REP ? mmd_kernel<MMDGAN_LOSS_REP>
-                          : loss_type == MMDGAN_LOSS_RMB ? mmd_kernel<MMDGAN_LOSS_RMB>
-                          : loss_type == MMDGAN_LOSS_MMD_G ? mmd_kernel<MMDGAN_LOSS_MMD_G> : mmd_kernel<MMDGAN_LOSS_MGB>;
-    static bool attr_set[4] = {false, false, false, false};
-    if (!attr_set[loss_type] && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set[loss_type] = true;
+    return launch_pairwise(s_gen, s_x, B, d, loss_type, dis_first, w0, w1, lower_bound, upper_bound, out_scalars, grads, masks,
+                           dist, workspace, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 'mmd_g_mix' / 'fixed_g_mix' / 'sgm' (math_func.py:2195-2263): four launches on one stream
+//   mix_prepare   coin, group row lists, the two mixed sets gathered          (get_mix_coin, slice_pairwise_distance)
+//   mmd_kernel    loss_gen and its gradients on (s_gen, s_x)
+//   mmd_kernel    -loss_mix and its gradients on the two mixed sets
+//   mix_finish    gradients gathered back to s_gen / s_x rows, scalars, state UPDATE_OPS
+// workspace (floats unless noted): [pairwise counter+partials][out2 8][out3 8][pos 2B int][XX 2B*d][G2 4*B*d][G3 4*B*d]
+// ------------------------------------------------------------------------------------------------
+namespace mmdgan {
+constexpr int kMixMaxB = 8192;           // the coin's prefix counts live in LDS (33 KB)
+
+struct MixLayout {
+    size_t pair_bytes, out2, out3, misc, pos, xx, g2, g3, total;     // byte offsets
+};
+static MixLayout mix_layout(int B, int d) {
+    MixLayout L;
+    L.pair_bytes = (mmdgan_mmd_workspace_bytes(B, d) + 255) / 256 * 256;
+    L.out2 = L.pair_bytes;
+    L.out3 = L.out2 + 8 * sizeof(float);
+    L.misc = L.out3 + 8 * sizeof(float);
+    L.pos = L.misc + 8 * sizeof(float);
+    L.xx = (L.pos + 2 * (size_t)B * sizeof(int) + 255) / 256 * 256;
+    L.g2 = L.xx + 2 * (size_t)B * d * sizeof(float);
+    L.g3 = L.g2 + 4 * (size_t)B * d * sizeof(float);
+    L.total = L.g3 + 4 * (size_t)B * d * sizeof(float);
+    return L;
+}
+
+// one block.  Row k of set X1 (XX rows 0..B-1) / X2 (rows B..2B-1) in tf.boolean_mask order:
+//   X1 = [gen_i : coin_i] ++ [data_i : !coin_i],  X2 = [gen_i : !coin_i] ++ [data_i : coin_i]
+// pos[i] = XX row of gen_i, pos[B + i] = XX row of data_i.
+__global__ __launch_bounds__(256) void mix_prepare_kernel(const float *__restrict__ sg, const float *__restrict__ sx, int B, int d,
+                                                          const float *__restrict__ uni, const float *__restrict__ state,
+                                                          unsigned char *masks, int *pos, float *XX, float *misc) {
+    extern __shared__ int sm[];
+    int *coin = sm;                    // [B]
+    int *tcount = sm + B;              // [256] chunk counts -> exclusive prefix
+    __shared__ int total_true;
+    const int tid = threadIdx.x;
+    const float mix_prob = state[1];
+    for (int i = tid; i < B; i += 256) coin[i] = uni[i] > mix_prob ? 1 : 0;       // tf.greater(uni, mix_prob), :2080
+    __syncthreads();
+    const int chunk = (B + 255) / 256;
+    const int lo = min(tid * chunk, B), hi = min(lo + chunk, B);
+    int c = 0;
+    for (int i = lo; i < hi; ++i) c += coin[i];
+    tcount[tid] = c;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int t = 0; t < 256; ++t) { const int v = tcount[t]; tcount[t] = run; run += v; }
+        total_true = run;
     }
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, a);
-    return check_launch("mmd_loss");
+    __syncthreads();
+    const int T = total_true;
+    int t_i = tcount[tid];
+    for (int i = lo; i < hi; ++i) {
+        const int ci = coin[i], f_i = i - t_i;
+        pos[i] = ci ? t_i : B + f_i;                      // gen_i
+        pos[B + i] = ci ? B + (B - T) + t_i : T + f_i;    // data_i
+        if (masks) {
+            masks[i] = (unsigned char)ci;                                                  // mix_indices
+            masks[B + i] = (unsigned char)ci; masks[2 * B + i] = (unsigned char)(1 - ci);   // mix_group_1 = [idx, !idx]
+            masks[3 * B + i] = (unsigned char)(1 - ci); masks[4 * B + i] = (unsigned char)ci;   // mix_group_2 = [!idx, idx]
+        }
+        t_i += ci;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int t = tid; t < B * d; t += 256) {
+        const int i = t / d, k = t - i * d;
+        XX[(size_t)pos[i] * d + k] = sg[t];
+        XX[(size_t)pos[B + i] * d + k] = sx[t];
+    }
+    if (tid == 0) misc[0] = (float)T;
+}
+
+__global__ __launch_bounds__(256) void mix_finish_kernel(int B, int d, int dis_first, const int *__restrict__ pos,
+                                                         const float *__restrict__ G2, const float *__restrict__ G3,
+                                                         const float *__restrict__ out2, const float *__restrict__ out3,
+                                                         const float *__restrict__ misc, float threshold, float rho_avg, float rho_prob, float *state,
+                                                         float *out, float *grads) {
+    const size_t n = (size_t)B * d;
+    // natural order [dLg/ds_gen, dLg/ds_x, dLd/ds_gen, dLd/ds_x]; dis_first as in mmd_kernel
+    const int s0 = dis_first ? 2 : 0, s1 = dis_first ? 3 : 1, s2 = dis_first ? 1 : 2, s3 = dis_first ? 0 : 3;
+    const float *Gd = G3 + 2 * n;          // the loss_dis slots of the mixed launch: d(-loss_mix)/d[X1 ; X2], 2B rows
+    if (grads) {
+        for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (size_t)gridDim.x * 256) {
+            const int i = (int)(t / d), k = (int)(t - (size_t)i * d);
+            grads[s0 * n + t] = G2[t];
+            grads[s1 * n + t] = G2[n + t];
+            grads[s2 * n + t] = Gd[(size_t)pos[i] * d + k];
+            grads[s3 * n + t] = Gd[(size_t)pos[B + i] * d + k];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const float lg = out2[0], la = state[0], mp = state[1];
+        out[0] = lg; out[1] = out3[1];
+        out[2] = out2[2]; out[3] = out2[3]; out[4] = out2[4];
+        out[5] = la; out[6] = mp; out[7] = misc[0];
+        // UPDATE_OPS (math_func.py:2031-2033, 1999-2011): both right-hand sides read the pre-update values
+        const float keep = (float)(1.0 - (double)rho_avg);
+        state[0] = keep * la + rho_avg * lg;
+        state[1] = fminf(fmaxf(mp + rho_prob * (la - threshold), 0.0f), 0.5f);
+    }
+}
+}  // namespace mmdgan
+
+extern "C" size_t mmdgan_mmd_mix_workspace_bytes(int B, int d) {
+    if (B < 2 || d < 1) return 0;
+    return mix_layout(B, d).total;
+}
+
+extern "C" int mmdgan_mmd_mix_loss(const float *s_gen, const float *s_x, int B, int d, int loss_type, const float *uni,
+                                   float mix_threshold, float loss_average_update, float mix_prob_update, float *state,
+                                   float *out_scalars, float *grads, unsigned char *masks, void *workspace, void *stream) {
+    const int dis_first = (loss_type & MMDGAN_LOSS_FLAG_GRADS_DIS_FIRST) != 0;
+    loss_type &= ~MMDGAN_LOSS_FLAG_GRADS_DIS_FIRST;
+    MMDGAN_REQUIRE(loss_type == MMDGAN_LOSS_MMD_G_MIX || loss_type == MMDGAN_LOSS_SGM, "mmd_mix_loss: unknown loss %d", loss_type);
+    MMDGAN_REQUIRE(B >= 2 && B <= kMixMaxB, "mmd_mix_loss: batch_size must be in [2,%d] (got %d)", kMixMaxB, B);
+    MMDGAN_REQUIRE(d >= 1 && d <= kMmdMaxD, "mmd_mix_loss: d must be in [1,%d] (got %d)", kMmdMaxD, d);
+    MMDGAN_REQUIRE(s_gen && s_x && uni && state && out_scalars && workspace, "mmd_mix_loss: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const MixLayout L = mix_layout(B, d);
+    char *ws = (char *)workspace;
+    float *out2 = (float *)(ws + L.out2), *out3 = (float *)(ws + L.out3), *misc = (float *)(ws + L.misc);
+    int *pos = (int *)(ws + L.pos);
+    float *XX = (float *)(ws + L.xx), *G2 = (float *)(ws + L.g2), *G3 = (float *)(ws + L.g3);
+    hipLaunchKernelGGL(mix_prepare_kernel, dim3(1), dim3(256), (size_t)(B + 256) * sizeof(int), st, s_gen, s_x, B, d, uni,
+                       (const float *)state, masks, pos, XX, misc);
+    if (int rc = check_launch("mmd_mix_loss prepare")) return rc;
+    // the mixture of five Gaussians, or the single sigma-1 one; w = (2, 1) makes the loss_dis slots -MMD
+    const int pair = loss_type == MMDGAN_LOSS_SGM ? MMDGAN_LOSS_REP : MMDGAN_LOSS_MMD_G;
+    if (int rc = launch_pairwise(s_gen, s_x, B, d, pair, 0, 2.0f, 1.0f, 0.25f, 4.0f, out2, G2, nullptr, nullptr, ws, st)) return rc;
+    if (int rc = launch_pairwise(XX, XX + (size_t)B * d, B, d, pair, 0, 2.0f, 1.0f, 0.25f, 4.0f, out3, G3, nullptr, nullptr, ws, st))
+        return rc;
+    const size_t n = (size_t)B * d;
+    const int blocks = (int)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);
+    hipLaunchKernelGGL(mix_finish_kernel, dim3(blocks), dim3(256), 0, st, B, d, dis_first, (const int *)pos, (const float *)G2,
+                       (const float *)G3, (const float *)out2, (const float *)out3, (const float *)misc, mix_threshold,
+                       loss_average_update,
+                       mix_prob_update, state, out_scalars, grads);
+    return check_launch("mmd_mix_loss finish");
 }

@@ -42,6 +42,8 @@ SIGNATURES = {
     'mmdgan_sn_wgrad_fixup': (_I, [_P, _P, _P, _P, _P, _L, _P]),
     'mmdgan_mmd_workspace_bytes': (ctypes.c_size_t, [_I, _I]),
     'mmdgan_mmd_loss': (_I, [_P, _P, _I, _I, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P]),
+    'mmdgan_mmd_mix_workspace_bytes': (ctypes.c_size_t, [_I, _I]),
+    'mmdgan_mmd_mix_loss': (_I, [_P, _P, _I, _I, _I, _P, _F, _F, _F, _P, _P, _P, _P, _P, _P]),
     'mmdgan_adam_multi': (_I, [_P, _P, _I, _L, _F, _F, _F, _F, _I, _P, _P, _F, _P]),
     'mmdgan_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'mmdgan_nhwc_to_nchw': (_I, [_P, _P, _I, _I, _I, _I, _P]),

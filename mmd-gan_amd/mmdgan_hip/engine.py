@@ -375,7 +375,7 @@ class GanEngine:
 
     def __init__(self, architecture, loss_type='rep', lr_list=(5e-4, 2e-4), rep_weights=(0.0, -1.0),
                  batch_size=64, seed=0, device=None, dist_group=None, use_graph=False, sn_mode='default',
-                 weight_init='default'):
+                 weight_init='default', mix_threshold=None):
         ops.require_device()
         initializers.check_mode(weight_init)
         if loss_type not in ops.LOSS:
@@ -440,6 +440,8 @@ class GanEngine:
             ops.set_workspace(device=self.device)
         self._alloc(self.B)
         self.losses = torch.zeros(8, device=self.device)       # filled by the loss kernel each step
+        self._loss = ops.GanLossLauncher(loss_type, self.rep_weights, self.B, self.score_size, self.device, mix_threshold)
+        self.buf['mmd_grads'] = self._loss.grads
         self.use_graph, self._graph = use_graph, None
         self._in_step = False                                  # True while step() runs (buffers on the zero list ARE zero)
         self._static_z = torch.zeros(self.B, self.code_size, device=self.device)
@@ -611,17 +613,7 @@ class GanEngine:
             if s.out_reshape is not None:
                 x = x.view(_native_shape(s.out_shape_ref, x.shape[0]))
         scores = x                                                           # [2B, d]; s_x = [:B], s_gen = [B:]
-        lib = ops.require_device()
-        key = (B, self.score_size, self.device)
-        if key not in ops._mmd_ws:
-            ops._mmd_ws[key] = torch.zeros(lib.mmdgan_mmd_workspace_bytes(B, self.score_size), device=self.device,
-                                           dtype=torch.uint8)
-        if 'mmd_grads' not in b:
-            b['mmd_grads'] = torch.zeros(4, B, self.score_size, device=self.device)
-        ops.check(lib.mmdgan_mmd_loss(scores[B:].data_ptr(), scores[:B].data_ptr(), B, self.score_size,
-                                      ops.LOSS[self.loss_type] | 0x100, self.rep_weights[0], self.rep_weights[1], 0.25, 4.0,
-                                      self.losses.data_ptr(), b['mmd_grads'].data_ptr(), None, None,
-                                      ops._mmd_ws[key].data_ptr(), ops._stream()), 'mmd_loss')
+        self._loss.launch(scores, self.losses)
         return scores
 
     # ---------------------------------------------------------------------------------------
@@ -846,13 +838,15 @@ class GanEngine:
             self._in_step = False
             lib.mmdgan_set_outputs_prezeroed(0)
 
-    def step(self, real_nhwc=None, z=None):
+    def step(self, real_nhwc=None, z=None, uni=None):
         """one training step; returns nothing on the host (losses stay in self.losses on the device:
-        [0] loss_gen, [1] loss_dis, [2..6] e_kxx e_kxy e_kyy e_kxx_b e_kyy_b, pre-update values)."""
+        [0] loss_gen, [1] loss_dis, [2..6] e_kxx e_kxy e_kyy e_kxx_b e_kyy_b, pre-update values).
+        uni: the `*_mix` losses' uniform draw of this step ([B]; default: sampled like z)"""
         if z is None:
             self._static_z.normal_(generator=self._z_gen)                    # my_sngan.py:123-124
         else:
             self._static_z.copy_(z)
+        self._loss.draw(self._z_gen, uni)                                    # math_func.py:2079 (the *_mix coin)
         graph = self.use_graph and self.dist_group is None
         if real_nhwc is not None and graph:
             self._static_real.copy_(real_nhwc)                               # the captured graph reads this buffer
@@ -886,6 +880,7 @@ class GanEngine:
         for net in (self.gen, self.dis):
             out.append([net.params.clone(), net.adam_m.clone(), net.adam_v.clone(), net.opt.step_counter.clone(),
                         {k: v.clone() for k, v in net.state.items()}])
+        out.append(self._loss.state.clone() if self._loss.mix else None)       # the *_mix coin's moving averages
         return out
 
     def _restore(self, snap):
@@ -893,6 +888,8 @@ class GanEngine:
             net.params.copy_(p); net.adam_m.copy_(m); net.adam_v.copy_(v); net.opt.step_counter.copy_(t)
             for k, val in st.items():
                 net.state[k].copy_(val)
+        if snap[-1] is not None:
+            self._loss.state.copy_(snap[-1])
 
     # ---------------------------------------------------------------------------------------
     # reference-layout import / export (checkpoint keys follow TF scopes)
@@ -926,7 +923,7 @@ class GanEngine:
         return OrderedDict((s.scope, float(self.dis.state[s.scope + '#sigma'].item())) for s in self.dis.specs if s.sn)
 
     def state_dict(self):
-        sd = {'global_step': self.global_step, 'variables': self.get_variables()}
+        sd = {'global_step': self.global_step, 'variables': self.get_variables(), 'loss_state': self._loss.state_dict()}
         for tag, net in (('gen', self.gen), ('dis', self.dis)):
             sd[tag + '/adam_m'] = net.adam_m.cpu()
             sd[tag + '/adam_v'] = net.adam_v.cpu()
@@ -936,6 +933,7 @@ class GanEngine:
     def load_state_dict(self, sd):
         self.set_variables(sd['variables'])
         self.global_step = int(sd['global_step'])
+        self._loss.load_state_dict(sd.get('loss_state', {}))
         for tag, net in (('gen', self.gen), ('dis', self.dis)):
             net.adam_m.copy_(sd[tag + '/adam_m'])
             net.adam_v.copy_(sd[tag + '/adam_v'])

@@ -13,7 +13,13 @@ from ._lib import ConvGeom, check
 
 ACT = {'linear': 0, 'relu': 1, 'lrelu': 2, 'tanh': 3}
 LOSS = {'rep': 0, 'rep_mmd_g': 0, 'rmb': 1, 'rep_b': 1, 'rep_mmd_b': 1,                  # math_func.py:2644-2647
-        'mmd_g': 2, 'fixed_g': 2, 'mgb': 3, 'hinge': 4, 'logistic': 5, '': 5}                  # :2602-2611
+        'mmd_g': 2, 'fixed_g': 2, 'mgb': 3, 'hinge': 4, 'logistic': 5, '': 5,                  # :2602-2611
+        'mmd_g_mix': 6, 'fixed_g_mix': 6, 'sgm': 7}                                            # :2613-2622
+MIX_THRESHOLD = {6: 1.0, 7: 0.2}                     # default mix_threshold of _mmd_g_mix_ / _single_mmd_g_mix_ (:2195, :2230)
+
+
+def is_mix_loss(loss_type):
+    return LOSS.get(loss_type, -1) in MIX_THRESHOLD
 
 _device_checked = False
 
@@ -271,6 +277,8 @@ def mmd_loss(s_gen, s_x, loss_type='rep', rep_weights=(0.0, -1.0), lower_bound=0
     lib = require_device()
     if loss_type not in LOSS:
         raise NotImplementedError('Not implemented.')                            # math_func.py:2651
+    if is_mix_loss(loss_type):
+        raise ValueError('{}: the *_mix losses carry state and a coin, use mmd_mix_loss'.format(loss_type))
     B, d = s_gen.shape
     assert s_x.shape == s_gen.shape
     dev = s_gen.device
@@ -286,6 +294,99 @@ def mmd_loss(s_gen, s_x, loss_type='rep', rep_weights=(0.0, -1.0), lower_bound=0
                               masks.data_ptr() if masks is not None else None, _p(dist), _mmd_ws[key].data_ptr(),
                               _stream()), 'mmd_loss')
     return {'scalars': out, 'grads': grads, 'masks': masks.bool() if masks is not None else None, 'dist': dist}
+
+
+_mix_ws = {}
+
+
+def mix_workspace(B, d, device):
+    key = (B, d, device)
+    if key not in _mix_ws:
+        _mix_ws[key] = torch.zeros(_lib.load().mmdgan_mmd_mix_workspace_bytes(B, d), device=device, dtype=torch.uint8)
+    return _mix_ws[key]
+
+
+def mmd_mix_loss(s_gen, s_x, uni, state, loss_type='mmd_g_mix', mix_threshold=None, loss_average_update=0.01,
+                 mix_prob_update=0.01, need_grads=True, need_masks=False, grads_dis_first=False, out=None, grads=None,
+                 workspace=None):
+    """'mmd_g_mix' / 'fixed_g_mix' / 'sgm' (math_func.py:2195-2263).  uni [B]: this step's uniform(0,1) draw; state [2]:
+    {loss_average, mix_prob}, read and then UPDATED IN PLACE (the UPDATE_OPS).  Returns dict(scalars[8] = loss_gen,
+    loss_dis, e_kxx, e_kxy, e_kyy, loss_average and mix_prob as used, number of un-mixed rows; grads[4,B,d];
+    masks = {mix_indices [B], mix_group_1 [2B], mix_group_2 [2B]} as bool tensors)."""
+    lib = require_device()
+    code = LOSS.get(loss_type, -1)
+    if code not in MIX_THRESHOLD:
+        raise NotImplementedError('Not implemented.')                            # math_func.py:2651
+    B, d = s_gen.shape
+    assert s_x.shape == s_gen.shape and uni.numel() == B and state.numel() == 2
+    dev = s_gen.device
+    ws = workspace if workspace is not None else mix_workspace(B, d, dev)
+    out = out if out is not None else torch.empty(8, device=dev, dtype=torch.float32)
+    if grads is None and need_grads:
+        grads = torch.empty((4, B, d), device=dev, dtype=torch.float32)
+    masks = torch.empty(5 * B, device=dev, dtype=torch.uint8) if need_masks else None
+    thr = MIX_THRESHOLD[code] if mix_threshold is None else float(mix_threshold)
+    check(lib.mmdgan_mmd_mix_loss(_p(s_gen), _p(s_x), B, d, code | (0x100 if grads_dis_first else 0), _p(uni), thr,
+                                  float(loss_average_update), float(mix_prob_update), _p(state), _p(out), _p(grads),
+                                  masks.data_ptr() if masks is not None else None, ws.data_ptr(), _stream()), 'mmd_mix_loss')
+    m = None
+    if masks is not None:
+        m = {'mix_indices': masks[:B].bool(), 'mix_group_1': masks[B:3 * B].bool(), 'mix_group_2': masks[3 * B:].bool()}
+    return {'scalars': out, 'grads': grads, 'masks': m}
+
+
+class GanLossLauncher:
+    """the loss node of a training step (my_sngan.py:282-289 -> GANLoss.apply): owns the loss kernel's workspace, the
+    [4,B,d] score-gradient block in the order the engines back-propagate it ([dLd/ds_x ; dLd/ds_gen ; dLg/ds_gen ;
+    dLg/ds_x], MMDGAN_LOSS_FLAG_GRADS_DIS_FIRST) and - for the `*_mix` losses - the coin's two state variables
+    ('mmd_g_mix/coin/gen_average', 'mmd_g_mix/coin/prob', math_func.py:2073-2078) and this step's uniform draw."""
+
+    def __init__(self, loss_type, rep_weights, B, d, device, mix_threshold=None):
+        lib = require_device()
+        if loss_type not in LOSS:
+            raise NotImplementedError('Not implemented.')                        # math_func.py:2651
+        self.loss_type, self.code, self.B, self.d = loss_type, LOSS[loss_type], int(B), int(d)
+        self.w = (float(rep_weights[0]), float(rep_weights[1]))
+        self.mix = self.code in MIX_THRESHOLD
+        self.grads = torch.zeros(4, B, d, device=device)
+        if self.mix:
+            self.ws = torch.zeros(lib.mmdgan_mmd_mix_workspace_bytes(B, d), device=device, dtype=torch.uint8)
+            self.state = torch.zeros(2, device=device)                           # zeros_initializer, :1995, :2027
+            self.uni = torch.zeros(B, device=device)
+            self.mix_threshold = MIX_THRESHOLD[self.code] if mix_threshold is None else float(mix_threshold)
+        else:
+            self.ws = torch.zeros(max(lib.mmdgan_mmd_workspace_bytes(B, d), 64), device=device, dtype=torch.uint8)
+            self.state = self.uni = None
+
+    def draw(self, generator=None, uni=None):
+        """this step's tf.random_uniform([B]) (math_func.py:2079), or the caller's"""
+        if not self.mix:
+            return
+        if uni is not None:
+            self.uni.copy_(torch.as_tensor(uni, dtype=torch.float32).reshape(-1))
+        else:
+            self.uni.uniform_(0.0, 1.0, generator=generator)
+
+    def launch(self, scores, losses_out):
+        """scores [2B, d]: rows [:B] = s_x (real), [B:] = s_gen, as D produced them from [real ; fake]"""
+        lib, B, d = require_device(), self.B, self.d
+        s_x, s_gen = scores[:B], scores[B:]
+        if self.mix:
+            check(lib.mmdgan_mmd_mix_loss(s_gen.data_ptr(), s_x.data_ptr(), B, d, self.code | 0x100, self.uni.data_ptr(),
+                                          self.mix_threshold, 0.01, 0.01, self.state.data_ptr(), losses_out.data_ptr(),
+                                          self.grads.data_ptr(), None, self.ws.data_ptr(), _stream()), 'mmd_mix_loss')
+        else:
+            check(lib.mmdgan_mmd_loss(s_gen.data_ptr(), s_x.data_ptr(), B, d, self.code | 0x100, self.w[0], self.w[1], 0.25,
+                                      4.0, losses_out.data_ptr(), self.grads.data_ptr(), None, None, self.ws.data_ptr(),
+                                      _stream()), 'mmd_loss')
+
+    def state_dict(self):
+        return {} if not self.mix else {'mmd_g_mix/coin/gen_average': float(self.state[0].item()),
+                                        'mmd_g_mix/coin/prob': float(self.state[1].item())}
+
+    def load_state_dict(self, sd):
+        if self.mix and 'mmd_g_mix/coin/gen_average' in sd:
+            self.state.copy_(torch.tensor([float(sd['mmd_g_mix/coin/gen_average']), float(sd['mmd_g_mix/coin/prob'])]))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -475,7 +475,8 @@ class TapeEngine:
     """G + D + loss + two TF-Adam optimisers for nets with residual blocks; same interface as GanEngine."""
 
     def __init__(self, architecture, loss_type='rep', lr_list=(5e-4, 2e-4), rep_weights=(0.0, -1.0), batch_size=64,
-                 seed=0, device=None, dist_group=None, use_graph=False, sn_mode='default', weight_init='default'):
+                 seed=0, device=None, dist_group=None, use_graph=False, sn_mode='default', weight_init='default',
+                 mix_threshold=None):
         ops.require_device()
         initializers.check_mode(weight_init)
         if loss_type not in ops.LOSS:
@@ -514,7 +515,6 @@ class TapeEngine:
         self._z_gen.manual_seed((int(seed) * 1000003 + 7919 * self.rank + 12345) % (2 ** 63 - 1))
         self._static_real = torch.zeros(_native(self.in_shape_ref, self.B), device=self.device)
         self._dis_in = torch.zeros(_native(self.in_shape_ref, 2 * self.B), device=self.device)
-        self._mmd_grads = torch.zeros(4, self.B, self.score_size, device=self.device)
         self._bufs = {}
         self._in_step = False                                            # transformed weights are valid inside step() only
         self._exchange_pending = False
@@ -583,8 +583,7 @@ class TapeEngine:
             off += (n + 3) // 4 * 4
         for entry in self._folded.values():
             entry[1] = entry[1].view(entry[0].shape)
-        self._mmd_ws = torch.zeros(max(lib.mmdgan_mmd_workspace_bytes(self.B, self.score_size), 64), device=self.device,
-                                   dtype=torch.uint8)
+        self._loss = ops.GanLossLauncher(loss_type, self.rep_weights, self.B, self.score_size, self.device, mix_threshold)
 
     # ---- buffers ----------------------------------------------------------------------------------------------
     def _buf(self, key, shape, zero=False):
@@ -917,7 +916,7 @@ class TapeEngine:
             mdist.allreduce_sum_(net.grads, self.dist_group)
         self._exchange_pending = True
 
-    def step(self, real_nhwc=None, z=None):
+    def step(self, real_nhwc=None, z=None, uni=None):
         B = self.B
         lib = ops.require_device()
         main = torch.cuda.current_stream()
@@ -925,6 +924,7 @@ class TapeEngine:
             self._static_z.normal_(generator=self._z_gen)                # my_sngan.py:123-124
         else:
             self._static_z.copy_(z)
+        self._loss.draw(self._z_gen, uni)                                # the *_mix coin (math_func.py:2079)
         if real_nhwc is not None:
             self._static_real.copy_(real_nhwc)
         if self._side:
@@ -963,18 +963,18 @@ class TapeEngine:
             main.wait_event(self._dis_ready)
         dvals = self._forward(self.dis, self._dis_in, True, 'd')
         scores = dvals[self.dis.out_val]                                 # [2B, d]: s_x = [:B], s_gen = [B:]
-        ops.check(lib.mmdgan_mmd_loss(scores[B:].data_ptr(), scores[:B].data_ptr(), B, self.score_size,
-                                      ops.LOSS[self.loss_type] | 0x100, self.rep_weights[0], self.rep_weights[1], 0.25,
-                                      4.0, self.losses.data_ptr(), self._mmd_grads.data_ptr(), None, None,
-                                      self._mmd_ws.data_ptr(), ops._stream()), 'mmd_loss')
-        ds = self._mmd_grads.view(4 * B, -1)        # [dLd/ds_x ; dLd/ds_gen ; dLg/ds_gen ; dLg/ds_x]
+        self._loss.launch(scores, self.losses)
+        ds = self._loss.grads.view(4 * B, -1)       # [dLd/ds_x ; dLd/ds_gen ; dLg/ds_gen ; dLg/ds_x]
         lib.mmdgan_set_outputs_prezeroed(1)         # gradient arenas and the scratch were zeroed at step start
         try:
             self._backward(self.dis, dvals, ds[:2 * B], 'bd', param_grads=True)
             self._allreduce(self.dis)
-            if self._d_has_bn:                      # batch statistics couple the rows: full pass, zero on the real half
+            if self._d_has_bn:
+                # batch statistics couple the rows: the REAL scores depend on the fake images too (through the batch
+                # mean / variance), so loss_gen reaches G along dLg/ds_x as well - a full 2B-row pass with both halves
+                # of the loss_gen score gradient, [dLg/ds_x ; dLg/ds_gen] in D's [real ; fake] row order
                 dg = self._buf('dg_full', [2 * B, self.score_size])
-                dg[:B].zero_()
+                dg[:B].copy_(ds[3 * B:4 * B])
                 dg[B:].copy_(ds[2 * B:3 * B])
                 d_in = self._backward(self.dis, dvals, dg, 'bg', param_grads=False, need_input_grad=True)[B:]
             else:
@@ -1031,7 +1031,7 @@ class TapeEngine:
         return out
 
     def state_dict(self):
-        sd = {'global_step': self.global_step, 'variables': self.get_variables()}
+        sd = {'global_step': self.global_step, 'variables': self.get_variables(), 'loss_state': self._loss.state_dict()}
         for tag, net in (('gen', self.gen), ('dis', self.dis)):
             sd[tag + '/adam_m'], sd[tag + '/adam_v'] = net.adam_m.cpu(), net.adam_v.cpu()
             sd[tag + '/adam_t'] = int(net.opt.step_counter.item())
@@ -1040,6 +1040,7 @@ class TapeEngine:
     def load_state_dict(self, sd):
         self.set_variables(sd['variables'])
         self.global_step = int(sd['global_step'])
+        self._loss.load_state_dict(sd.get('loss_state', {}))
         for tag, net in (('gen', self.gen), ('dis', self.dis)):
             net.adam_m.copy_(sd[tag + '/adam_m'])
             net.adam_v.copy_(sd[tag + '/adam_v'])

@@ -157,6 +157,87 @@ def make_loss_next():
 
 
 # ---------------------------------------------------------------------------
+# 1c. SURVEY 8(f) row 1, the `*_mix` family: 'mmd_g_mix' / 'fixed_g_mix' (GANLoss._mmd_g_mix_, math_func.py:2195-2228)
+#     and 'sgm' (_single_mmd_g_mix_, :2230-2263) with their coin (get_mix_coin :2061-2085), the group masks
+#     (slice_pairwise_distance :2038-2058) and the moving-average state (:1979-2035).  The uniform draw is recorded
+#     as an INPUT (`uni`), the two state variables are set to non-trivial values before the recorded call, and the
+#     boolean masks are captured where the reference builds them (the arguments of mat_slice).
+# ---------------------------------------------------------------------------
+def run_mix(loss_type, s_gen_np, s_x_np, state_in, seed, threshold=None):
+    out = {}
+    B = s_gen_np.shape[0]
+    captured = {}
+    real_mat_slice = ref_math.mat_slice
+
+    def spy(mat, row_index, col_index=None, name='slice'):
+        captured.setdefault('calls', []).append((npy(row_index), npy(col_index) if col_index is not None else None))
+        return real_mat_slice(mat, row_index, col_index, name)
+    for key, dt in DT.items():
+        tf.set_dtype(dt)
+        tf.STATE.reset()
+        kwargs = {} if threshold is None else {'mix_threshold': threshold}
+        # a first call creates the two non-trainable variables (zero); then give them the fixture's state
+        sg = torch.tensor(s_gen_np, dtype=dt, requires_grad=True)
+        sx = torch.tensor(s_x_np, dtype=dt, requires_grad=True)
+        ref_math.GANLoss(False).apply(sg, sx, loss_type, batch_size=B, d=s_gen_np.shape[1], **kwargs)
+        tf.STATE.update_ops = []
+        names = sorted(tf.STATE.variables)
+        assert names == ['mmd_g_mix/coin/gen_average', 'mmd_g_mix/coin/prob'], names
+        with torch.no_grad():
+            tf.STATE.variables['mmd_g_mix/coin/gen_average'].copy_(torch.tensor(float(state_in[0]), dtype=dt))
+            tf.STATE.variables['mmd_g_mix/coin/prob'].copy_(torch.tensor(float(state_in[1]), dtype=dt))
+        tf.STATE.rng = np.random.RandomState(seed)
+        captured.clear()
+        ref_math.mat_slice = spy
+        try:
+            lg, ld = ref_math.GANLoss(False).apply(sg, sx, loss_type, batch_size=B, d=s_gen_np.shape[1], **kwargs)
+        finally:
+            ref_math.mat_slice = real_mat_slice
+        glg = torch.autograd.grad(lg, [sg, sx], retain_graph=True)
+        gld = torch.autograd.grad(ld, [sg, sx])
+        out.update({'loss_gen_' + key: npy(lg), 'loss_dis_' + key: npy(ld),
+                    'dLg_dsgen_' + key: npy(glg[0]), 'dLg_dsx_' + key: npy(glg[1]),
+                    'dLd_dsgen_' + key: npy(gld[0]), 'dLd_dsx_' + key: npy(gld[1])})
+        tf.run_update_ops()
+        out['state_out_' + key] = np.asarray([float(tf.STATE.variables['mmd_g_mix/coin/gen_average']),
+                                              float(tf.STATE.variables['mmd_g_mix/coin/prob'])], np.float64)
+        calls = captured['calls']                                   # dist_g1, dist_g2, dist_g1g2 (:2054-2056)
+        assert len(calls) == 3 and calls[0][1] is None and calls[1][1] is None
+        g1, g2 = calls[0][0], calls[1][0]
+        assert np.array_equal(calls[2][0], g1) and np.array_equal(calls[2][1], g2)
+        masks = {'uni': tf.STATE.last_uniform.copy(), 'mix_group_1': g1.astype(bool), 'mix_group_2': g2.astype(bool),
+                 'mix_indices': g1[:B].astype(bool)}
+        assert np.array_equal(g1[B:], ~g1[:B]) and np.array_equal(g2, ~g1)
+        if key == 'f32':
+            out.update(masks)
+        else:                                                       # the same coin in both precisions
+            for k, v in masks.items():
+                assert np.array_equal(out[k], v), k
+    out.update({'s_gen': s_gen_np, 's_x': s_x_np, 'loss_type': np.asarray(loss_type),
+                'state_in': np.asarray(state_in, np.float32),
+                'mix_threshold': np.asarray(-1.0 if threshold is None else threshold),
+                'margin': np.float64(np.abs(out['uni'] - np.float32(state_in[1])).min())})
+    return out
+
+
+def make_mix():
+    n = 0
+    for loss_type in ('mmd_g_mix', 'sgm'):
+        for B in (8, 64):
+            for (sg, sx, off, state, thr) in ((0.25, 0.3, 0.1, (1.5, 0.3), None), (1.0, 1.0, 0.2, (0.05, 0.45), None),
+                                              (0.5, 0.6, 0.1, (0.6, 0.0), 0.5), (0.5, 0.6, 0.1, (2.0, 0.5), None)):
+                state = (np.float32(state[0]), np.float32(state[1]))
+                s_gen, s_x = mmd_inputs(B, 16, sg, sx, off, 9000 + 100 * n)
+                fx = run_mix(loss_type, s_gen, s_x, state, seed=400 + n, threshold=thr)
+                assert fx['margin'] > 1e-6 or state[1] in (0.0,), fx['margin']       # no coin on the threshold
+                np.savez_compressed(os.path.join(OUT, 'lossmix_{}_B{}_c{:02d}.npz'.format(loss_type, B, n)), **fx)
+                n += 1
+    fx = run_mix('fixed_g_mix', *mmd_inputs(8, 16, 0.25, 0.3, 0.1, 9990), (np.float32(1.2), np.float32(0.25)), seed=77)
+    np.savez_compressed(os.path.join(OUT, 'lossmix_fixed_g_mix_B8_c{:02d}.npz'.format(n)), **fx)
+    print('mix-loss fixtures:', n + 1)
+
+
+# ---------------------------------------------------------------------------
 # 2. layers through the reference's Net / Routine (layer_func.py)
 # ---------------------------------------------------------------------------
 def build_routine(designs, net_name, input_shape):
@@ -570,6 +651,9 @@ if __name__ == '__main__':
     if '--only-init' in sys.argv:
         make_init_stats()
         sys.exit(0)
+    if '--only-mix' in sys.argv:
+        make_mix()
+        sys.exit(0)
     if '--only-warm' in sys.argv:
         make_step_warm('rep')
         make_step_warm('rep', arch_fn=tiny_res_architecture, tag='res_rep')
@@ -598,6 +682,7 @@ if __name__ == '__main__':
     make_step('rep', arch_fn=tiny_res_max_architecture, tag='res_max_rep')
     make_eval()
     make_init_stats()
+    make_mix()
     make_step_warm('rep')
     make_step_warm('rep', arch_fn=tiny_res_architecture, tag='res_rep')
     make_step_warm('rep', sn_mode='sn_paper', tag='rep_pim')

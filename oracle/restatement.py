@@ -648,6 +648,52 @@ def gan_loss(score_gen, score_data, loss_type, batch_size, rep_weights=(0.0, -1.
 
 MIXTURE_SIGMA = [1.0, math.sqrt(2.0), 2.0, math.sqrt(8.0), 4.0]      # math_func.py:2108
 
+MIX_LOSSES = {'mmd_g_mix': 1.0, 'fixed_g_mix': 1.0, 'sgm': 0.2}       # default mix_threshold, math_func.py:2195, 2230
+
+
+def mix_groups(mix_indices):
+    """slice_pairwise_distance with indices (math_func.py:2052-2053): over the 2B rows [gen ; data], group 1 takes
+    gen_i where the coin says 'original' and data_i where it does not, group 2 the complement."""
+    return torch.cat([mix_indices, ~mix_indices]), torch.cat([~mix_indices, mix_indices])
+
+
+def gan_loss_mix(score_gen, score_data, loss_type, batch_size, uni, state, mix_threshold=None,
+                 loss_average_update=0.01, mix_prob_update=0.01):
+    """GANLoss._mmd_g_mix_ / _single_mmd_g_mix_ (math_func.py:2195-2263) with get_mix_coin (:2061-2085):
+      pair_dist over concat(score_gen, score_data) (:2203), loss_gen = the un-mixed (mixture) MMD (:2208-2210),
+      mix_indices = uni > mix_prob (:2079-2080; `uni` is tf.random_uniform([B]) - an INPUT here),
+      loss_dis = -MMD between the two mixed groups, boolean_mask row order (:2215-2220, mat_slice :377-378).
+    state = (loss_average, mix_prob), the two non-trainable variables 'coin/gen_average' and 'coin/prob'; their
+    UPDATE_OPS (:1999-2011, 2031-2033) give new_state - every read sees the pre-update values:
+      loss_average' = (1 - rho) loss_average + rho loss_gen;  mix_prob' = clip(mix_prob + rho (loss_average - thr), 0, 0.5)
+    Returns (loss_gen, loss_dis, info)."""
+    if mix_threshold is None:
+        mix_threshold = MIX_LOSSES[loss_type]
+    sigmas = [1.0] if loss_type == 'sgm' else MIXTURE_SIGMA
+    both = torch.cat([score_gen, score_data], 0)
+    gram = both @ both.t()                                            # get_squared_dist mode 'xx', :801-805
+    diag = torch.diagonal(gram)
+    pair = torch.maximum(diag[:, None] - 2.0 * gram + diag[None, :], torch.zeros((), dtype=both.dtype))
+    b = int(batch_size)
+
+    def mmd_of(dxx, dxy, dyy):
+        total = 0.0
+        for sg in sigmas:
+            total = total + mmd_g(dxx, dxy, dyy, batch_size, sigma=sg)[0]
+        return total
+    loss_gen = mmd_of(pair[:b, :b], pair[:b, b:], pair[b:, b:])       # slice_pairwise_distance without indices, :2047-2050
+    loss_average, mix_prob = state
+    dt = both.dtype
+    mix_indices = torch.as_tensor(np.asarray(uni), dtype=dt) > torch.as_tensor(np.asarray(mix_prob), dtype=dt)
+    g1, g2 = mix_groups(mix_indices)
+    i1, i2 = torch.nonzero(g1).reshape(-1), torch.nonzero(g2).reshape(-1)
+    loss_mix = mmd_of(pair[i1][:, i1], pair[i1][:, i2], pair[i2][:, i2])
+    la, mp = float(loss_average), float(mix_prob)
+    new_state = ((1.0 - loss_average_update) * la + loss_average_update * float(loss_gen.detach()),
+                 min(max(mp + mix_prob_update * (la - mix_threshold), 0.0), 0.5))
+    info = {'mix_indices': mix_indices, 'mix_group_1': g1, 'mix_group_2': g2, 'new_state': new_state}
+    return loss_gen, -loss_mix, info
+
 
 def mmd_g_clamped(dist_xx, dist_xy, dist_yy, batch_size, sigma=1.0, upper_bound=None, lower_bound=None):
     """mmd_g with its bounds arguments (math_func.py:1312-1322, 1324-1335): k_xx, k_yy from max(dist, lower_bound),
@@ -693,7 +739,7 @@ class OracleGan:
     """G + D + losses + two TF-Adam optimisers; one `step` = one sess.run of graph_func.py:853."""
 
     def __init__(self, architecture, loss_type='rep', lr_list=(5e-4, 2e-4), rep_weights=(0.0, -1.0),
-                 seed=0, dtype=torch.float32, params=None, sn_mode='default'):
+                 seed=0, dtype=torch.float32, params=None, sn_mode='default', mix_threshold=None):
         self.arch, self.loss_type, self.rep_weights, self.dtype = architecture, loss_type, rep_weights, dtype
         self.code_size = architecture['code'][0][0]
         self.gen_specs = build_net(architecture['generator'], [self.code_size], 'gen', sn_mode)
@@ -713,6 +759,7 @@ class OracleGan:
         self.opt_d = AdamTF(self.dis_names, self.params, lr_list[0])
         self.opt_g = AdamTF(self.gen_names, self.params, lr_list[1])
         self.global_step = 0
+        self.mix_state, self.mix_threshold = (0.0, 0.0), mix_threshold     # 'coin/gen_average', 'coin/prob' (zeros_initializer)
 
     def set_adam_state(self, m, v, t):
         """resume both optimisers mid-run: first / second moments by variable name and the steps taken so far"""
@@ -723,24 +770,29 @@ class OracleGan:
             opt.t = int(t)
         self.global_step = int(t)
 
-    def forward_losses(self, z, real, collect=None):
+    def forward_losses(self, z, real, collect=None, uni=None):
         p = self.params
         gen, up_g = net_forward(self.gen_specs, p, z, True, collect)
         dis_out, up_d = net_forward(self.dis_specs, p, torch.cat([real, gen], 0), True, collect)   # my_sngan.py:278
         b = z.shape[0]
         s_x, s_gen = dis_out[:b], dis_out[b:]                                                    # my_sngan.py:279
-        loss_gen, loss_dis, stats = gan_loss(s_gen, s_x, self.loss_type, b, self.rep_weights)
+        if self.loss_type in MIX_LOSSES:          # the coin's state is two more UPDATE_OPS variables
+            assert uni is not None, 'the *_mix losses need this step\'s uniform draw'
+            loss_gen, loss_dis, stats = gan_loss_mix(s_gen, s_x, self.loss_type, b, uni, self.mix_state, self.mix_threshold)
+            self._pending_mix_state = stats['new_state']
+        else:
+            loss_gen, loss_dis, stats = gan_loss(s_gen, s_x, self.loss_type, b, self.rep_weights)
         updates = OrderedDict(up_g)
         updates.update(up_d)
         return loss_gen, loss_dis, stats, updates, (gen, s_x, s_gen)
 
-    def grads(self, z, real, collect=None):
+    def grads(self, z, real, collect=None, uni=None):
         leaves = {n: self.params[n].detach().clone().requires_grad_(True)
                   for n in self.dis_names + self.gen_names}
         saved = dict(self.params)
         self.params.update(leaves)
         try:
-            loss_gen, loss_dis, stats, updates, aux = self.forward_losses(z, real, collect)
+            loss_gen, loss_dis, stats, updates, aux = self.forward_losses(z, real, collect, uni)
             gd = torch.autograd.grad(loss_dis, [leaves[n] for n in self.dis_names], retain_graph=True)
             gg = torch.autograd.grad(loss_gen, [leaves[n] for n in self.gen_names])
         finally:
@@ -748,14 +800,16 @@ class OracleGan:
         return (loss_gen.detach(), loss_dis.detach(), stats, updates,
                 dict(zip(self.dis_names, gd)), dict(zip(self.gen_names, gg)), aux)
 
-    def step(self, z, real):
+    def step(self, z, real, uni=None):
         """losses are pre-update values; D and G update simultaneously from one forward
         (SURVEY 3.1); all reads precede all writes for the UPDATE_OPS."""
-        loss_gen, loss_dis, stats, updates, gd, gg, _ = self.grads(z, real)
+        loss_gen, loss_dis, stats, updates, gd, gg, _ = self.grads(z, real, uni=uni)
         self.opt_d.apply(self.params, gd)
         self.opt_g.apply(self.params, gg)
         for n, v in updates.items():
             self.params[n] = v
+        if self.loss_type in MIX_LOSSES:
+            self.mix_state = self._pending_mix_state
         self.global_step += 1                                  # my_sngan.py:424
         return float(loss_gen), float(loss_dis)
 

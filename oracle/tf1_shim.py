@@ -124,6 +124,8 @@ def get_variable(name, shape=None, dtype=None, initializer=None, trainable=True,
                 value = initializer(list(shape))
             except TypeError:                     # initializer class, not instance
                 value = initializer()(list(shape))
+            if callable(value) and not isinstance(value, torch.Tensor):
+                value = initializer()(list(shape))  # the factory itself was passed (tf.zeros_initializer, math_func.py:1995)
         else:
             value = _t(initializer)
         value = value.to(DTYPE).clone().detach()
@@ -336,6 +338,35 @@ def zeros(shape, dtype=None, name=None):
 
 def random_normal(shape, mean=0.0, stddev=1.0, dtype=None, name=None):
     return torch.as_tensor(STATE.rng.randn(*shape) * stddev + mean, dtype=DTYPE)
+
+
+def random_uniform(shape, minval=0.0, maxval=1.0, dtype=None, name=None):
+    """tf.random_uniform; the draw is kept in STATE.last_uniform so that a fixture can record it as an INPUT (the
+    build takes `uni` as an argument instead of reproducing TF's random stream, math_func.py:2079)"""
+    u = STATE.rng.uniform(minval, maxval, size=list(shape)).astype(np.float32)      # tf.float32 draws in every precision
+    STATE.last_uniform = u
+    return torch.as_tensor(u, dtype=DTYPE)
+
+
+def greater(a, b, name=None):
+    return _t(a) > _t(b)
+
+
+def logical_not(x, name=None):
+    return torch.logical_not(x)
+
+
+def boolean_mask(tensor, mask, axis=0, name=None):
+    idx = torch.nonzero(mask, as_tuple=False).reshape(-1)
+    return torch.index_select(tensor, axis, idx)
+
+
+def gather(params, indices, axis=0, name=None):
+    return torch.index_select(params, axis, indices.long())
+
+
+def clip_by_value(t, clip_value_min, clip_value_max, name=None):
+    return torch.clamp(_t(t), min=clip_value_min, max=clip_value_max)
 
 
 float32 = torch.float32

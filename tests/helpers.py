@@ -33,6 +33,19 @@ def elementwise_err(a, b, floor_frac=1e-2):
     return float(np.max(np.abs(a - b) / (np.abs(b) + floor_frac * np.max(np.abs(b)))))
 
 
+def sign_flips(got_nhwc, ref_nchw):
+    """how many activation outputs have a different SIGN in an fp32 evaluation (engine buffer, NHWC or [N,F]) than in
+    the fp64 oracle's (NCHW or [N,F]): the lrelu / relu derivative masks that differ between the two.  One such flip
+    moves ONE element of the back-propagated gradient by 0.9 (lrelu) or 1.0 (relu) of itself - against a tensor of N
+    elements that is ~1/sqrt(N) of its L2 norm times the element's relative size, i.e. 2e-3 ... 1e-2 for the 1e5 ... 1e6
+    elements of a D layer (tools/flip_probe.py: with NO flip above a layer its gradients agree to 3e-6, with one flip
+    to 6e-3).  Pre-activations land within fp32 resolution (~1e-6 of their scale) of zero about once per million."""
+    got, ref = np.asarray(got_nhwc), np.asarray(ref_nchw)
+    if ref.ndim == 4:
+        ref = ref.transpose(0, 2, 3, 1)
+    return int(((got.reshape(ref.shape) > 0) != (ref > 0)).sum())
+
+
 def golden(pattern):
     return sorted(glob.glob(os.path.join(GOLDEN, pattern)))
 

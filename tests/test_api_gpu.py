@@ -47,6 +47,25 @@ def test_ganloss_and_squared_dist_api():
         assert abs(float(ld) - float(rd)) <= RTOL * abs(float(rd)) + 4e-7
     with pytest.raises(NotImplementedError, match='Not implemented.'):
         GANLoss().apply(sg, sx, 'wasserstein', batch_size=64)
+    # the coin-mixed losses (math_func.py:2613-2622): two calls share the coin's variables like the reference's
+    # AUTO_REUSE scope does; the uniform draw is injected, the masks are exposed
+    from GeneralTools.math_func import mix_state
+    mix_state(sg.device).copy_(torch.tensor([0.9, 0.4]))
+    state = (float(np.float32(0.9)), float(np.float32(0.4)))
+    for loss in ('mmd_g_mix', 'sgm'):
+        uni = rs.uniform(0, 1, 64).astype(np.float32)
+        gl = GANLoss(False)
+        lg, ld = gl.apply(sg, sx, loss, batch_size=64, d=16, uni=uni)
+        rg, rd, info = R.gan_loss_mix(sg.cpu().double(), sx.cpu().double(), loss, 64, uni, state)
+        assert abs(float(lg) - float(rg)) <= RTOL * abs(float(rg)) + 2e-6
+        assert abs(float(ld) - float(rd)) <= RTOL * abs(float(rd)) + 2e-6
+        assert np.array_equal(gl.mix_indices.cpu().numpy(), info['mix_indices'].numpy())
+        assert np.array_equal(gl.mix_group_1.cpu().numpy(), info['mix_group_1'].numpy())
+        assert np.array_equal(gl.mix_group_2.cpu().numpy(), info['mix_group_2'].numpy())
+        state = info['new_state']
+        assert np.abs(mix_state(sg.device).cpu().numpy() - np.asarray(state)).max() <= 1e-6
+        state = tuple(float(v) for v in mix_state(sg.device).cpu().numpy())
+    GANLoss(False).apply(sg, sx, 'fixed_g_mix', batch_size=64, d=16)           # its own uniform draw
     dxx, dxy, dyy = get_squared_dist(sg, sx)
     ref = R.get_squared_dist(sg.cpu().double(), sx.cpu().double())
     for got, r in zip((dxx, dxy, dyy), ref):

@@ -133,6 +133,73 @@ def test_next_row_losses_match_oracle(ops, B, d, loss_type):
         assert torch.equal(h[slot], out['grads'][src]), (loss_type, slot)
 
 
+MIX = golden('lossmix_*.npz')
+
+
+@pytest.mark.parametrize('path', MIX, ids=[p.split('/')[-1] for p in MIX])
+def test_mix_losses_match_reference_golden(ops, path):
+    """'mmd_g_mix' / 'fixed_g_mix' / 'sgm' (math_func.py:2195-2263) with the reference's uniform draw and state injected:
+    mix_indices and both concatenated group masks BIT-EXACT (np.array_equal), losses and the four gradients at 1e-4,
+    the two state variables after the UPDATE_OPS, in both gradient orders"""
+    fx = load(path)
+    thr = float(fx['mix_threshold'])
+    B = fx['s_gen'].shape[0]
+    for dis_first in (False, True):
+        state = dev(fx['state_in'])
+        out = ops.mmd_mix_loss(dev(fx['s_gen']), dev(fx['s_x']), dev(fx['uni']), state, str(fx['loss_type']),
+                               None if thr < 0 else thr, need_masks=True, grads_dis_first=dis_first)
+        for k in ('mix_indices', 'mix_group_1', 'mix_group_2'):
+            assert np.array_equal(out['masks'][k].cpu().numpy(), fx[k]), k
+        sc = out['scalars'].cpu().numpy().astype(np.float64)
+        # the losses are differences of kernel means (five of them summed for the mixture): floor as loss_tol
+        escale = max(sc[2:5].max(), 1.0)
+        assert abs(sc[0] - float(fx['loss_gen_f64'])) <= loss_tol(float(fx['loss_gen_f64']), escale), (sc[0], fx['loss_gen_f64'])
+        assert abs(sc[1] - float(fx['loss_dis_f64'])) <= loss_tol(float(fx['loss_dis_f64']), escale), (sc[1], fx['loss_dis_f64'])
+        assert sc[5] == np.float32(fx['state_in'][0]) and sc[6] == np.float32(fx['state_in'][1])       # as used
+        assert int(sc[7]) == int(fx['mix_indices'].sum())
+        g = out['grads'].cpu().numpy()
+        order = ('dLd_dsx', 'dLd_dsgen', 'dLg_dsgen', 'dLg_dsx') if dis_first else ('dLg_dsgen', 'dLg_dsx', 'dLd_dsgen', 'dLd_dsx')
+        gscale = max(np.abs(fx[k + '_f64']).max() for k in order)
+        for i, key in enumerate(order):
+            ref = fx[key + '_f64']
+            assert np.abs(g[i] - ref).max() <= RTOL * np.abs(ref).max() + 1e-6 * gscale, key
+        got_state = state.cpu().numpy().astype(np.float64)
+        assert np.abs(got_state - fx['state_out_f64']).max() <= 1e-6, (got_state, fx['state_out_f64'])
+
+
+def test_mix_loss_at_larger_batches_and_errors(ops):
+    """the coin and the group bookkeeping against the oracle restatement where the fixtures do not reach: ragged
+    batches, all / no rows mixed, B in the thousands; and the entry's argument checks"""
+    rs = np.random.RandomState(11)
+    for B, d, loss_type, prob in ((100, 7, 'sgm', 0.3), (257, 16, 'mmd_g_mix', 0.5), (1024, 16, 'mmd_g_mix', 0.1),
+                                  (64, 16, 'sgm', 0.0), (64, 3, 'mmd_g_mix', 1.5), (2, 1, 'sgm', 0.4)):
+        sg = (rs.randn(B, d) * 0.4).astype(np.float32)
+        sx = (rs.randn(B, d) * 0.5 + 0.1).astype(np.float32)
+        uni = rs.uniform(0, 1, B).astype(np.float32)
+        st_in = (np.float32(0.7), np.float32(prob))
+        tg, tx = torch.tensor(sg, dtype=torch.float64, requires_grad=True), torch.tensor(sx, dtype=torch.float64, requires_grad=True)
+        lg, ld, info = R.gan_loss_mix(tg, tx, loss_type, B, uni, st_in)
+        gld = torch.autograd.grad(ld, [tg, tx])
+        state = dev(np.asarray(st_in))
+        out = ops.mmd_mix_loss(dev(sg), dev(sx), dev(uni), state, loss_type, need_masks=True)
+        for k in ('mix_indices', 'mix_group_1', 'mix_group_2'):
+            assert np.array_equal(out['masks'][k].cpu().numpy(), info[k].numpy()), (B, k)
+        sc = out['scalars'].cpu().numpy().astype(np.float64)
+        escale = max(sc[2:5].max(), 1.0)
+        assert abs(sc[0] - float(lg)) <= loss_tol(float(lg), escale) and abs(sc[1] - float(ld)) <= loss_tol(float(ld), escale)
+        g = out['grads'].cpu().numpy()
+        gscale = max(float(gld[0].abs().max()), float(gld[1].abs().max()), 1e-12)
+        assert np.abs(g[2] - gld[0].numpy()).max() <= RTOL * gscale and np.abs(g[3] - gld[1].numpy()).max() <= RTOL * gscale
+        assert np.abs(state.cpu().numpy() - np.asarray(info['new_state'])).max() <= 1e-6
+    z = dev(np.zeros((4, 2), np.float32))
+    with pytest.raises(ValueError, match='use mmd_mix_loss'):
+        ops.mmd_loss(z, z, 'sgm')
+    with pytest.raises(NotImplementedError, match='Not implemented.'):
+        ops.mmd_mix_loss(z, z, dev(np.zeros(4)), dev(np.zeros(2)), 'rep')
+    with pytest.raises(ValueError, match='batch_size'):
+        ops.mmd_mix_loss(z[:1], z[:1], dev(np.zeros(1)), dev(np.zeros(2)), 'sgm')
+
+
 def test_mmd_size_independent_properties(ops):
     """at the benchmark's full sweep sizes: permutation invariance, x<->y symmetry of loss_gen,
     zero loss_gen for identical sets, translation invariance."""

@@ -205,6 +205,32 @@ def test_warm_start_restatement_matches_reference(tag):
             assert rel_err(gan.params[n].numpy(), v) <= 2e-6, n
 
 
+MIX = golden('lossmix_*.npz')
+
+
+@pytest.mark.parametrize('path', MIX, ids=[p.split('/')[-1] for p in MIX])
+def test_mix_loss_restatement_matches_reference(path):
+    """'mmd_g_mix' / 'fixed_g_mix' / 'sgm' (math_func.py:2195-2263): with the recorded uniform draw and state as inputs,
+    the restatement's coin, both group masks (bit for bit), losses, gradients and the state after the UPDATE_OPS"""
+    fx = load(path)
+    thr = float(fx['mix_threshold'])
+    for prec, dt, tol in (('f32', torch.float32, 2e-5), ('f64', torch.float64, 1e-12)):
+        sg = torch.tensor(fx['s_gen'], dtype=dt, requires_grad=True)
+        sx = torch.tensor(fx['s_x'], dtype=dt, requires_grad=True)
+        lg, ld, info = R.gan_loss_mix(sg, sx, str(fx['loss_type']), sg.shape[0], fx['uni'], tuple(fx['state_in']),
+                                      None if thr < 0 else thr)
+        for k in ('mix_indices', 'mix_group_1', 'mix_group_2'):
+            assert np.array_equal(info[k].numpy(), fx[k]), k
+        scale = max(abs(float(fx['loss_gen_f64'])), abs(float(fx['loss_dis_f64'])), 1e-3)
+        assert abs(float(lg) - float(fx['loss_gen_' + prec])) <= tol * scale
+        assert abs(float(ld) - float(fx['loss_dis_' + prec])) <= tol * scale
+        glg = torch.autograd.grad(lg, [sg, sx], retain_graph=True)
+        gld = torch.autograd.grad(ld, [sg, sx])
+        for g, key in zip(list(glg) + list(gld), ('dLg_dsgen_', 'dLg_dsx_', 'dLd_dsgen_', 'dLd_dsx_')):
+            assert np.abs(g.numpy() - fx[key + prec]).max() <= tol * max(np.abs(fx[key + prec]).max(), 1e-6), key
+        assert np.abs(np.asarray(info['new_state']) - fx['state_out_' + prec]).max() <= 1e-6
+
+
 def test_reference_fp32_noise_floor():
     """Why the GPU loss tolerance carries an absolute floor: the reference's OWN fp32 evaluation
     (torch-CPU under the shim) misses its fp64 evaluation by more than 1e-4 of the loss on the
