@@ -69,10 +69,23 @@ const char *mmdgan_last_error(void);
 int mmdgan_version(void);
 /* 1 if a gfx950 device is visible to this process, 0 otherwise (never an error) */
 int mmdgan_device_ok(void);
+/* ------------------------------------------------------------------------------------------------
+ * Handles.  All mutable library state - the registered workspace, the prezeroed mode, recorded launch plans and the
+ * events of the stream helpers - lives in an opaque handle, one per engine ("one handle per (process,
+ * device); a handle is not thread-safe, distinct handles are; no global mutable state").  The entries below and every
+ * compute entry act on the CALLING THREAD's current handle; a thread that never called mmdgan_make_current uses the
+ * process default handle, so a single-engine caller needs none of this.  Two engines in one process each create a
+ * handle and make it current around their own calls: their workspaces and plans no longer meet.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mmdgan_handle mmdgan_handle;
+int mmdgan_create(mmdgan_handle **out);
+int mmdgan_destroy(mmdgan_handle *h);          /* destroys its plans and events; the caller's device memory is untouched */
+int mmdgan_make_current(mmdgan_handle *h);     /* NULL: back to the process default handle */
+
 /* Optional caller-owned device scratch (the library itself allocates nothing).  Kernels that would
  * otherwise combine per-workgroup partial results with contended atomics (thin-layer weight
  * gradients) write their partials here and reduce them in a second pass when the registered region
- * is large enough; without it they fall back to atomics.  One region per process; calls that use it
+ * is large enough; without it they fall back to atomics.  One region per HANDLE; calls that use it
  * must be ordered on one stream.  ptr == NULL unregisters. */
 int mmdgan_set_workspace(void *ptr, size_t bytes);
 /* Several entries accumulate into their output with atomics (split reductions, column sums, dot)
@@ -82,6 +95,40 @@ int mmdgan_set_workspace(void *ptr, size_t bytes);
  * conv2d_dgrad split their reduction (and so accumulate) only for batch-1 geometries (N == 1, the
  * spectral-norm power iteration) and gemm splits only when the call carries MMDGAN_ACT_FLAG_OUT_ZEROED.  Default 0. */
 int mmdgan_set_outputs_prezeroed(int on);
+
+/* ------------------------------------------------------------------------------------------------
+ * Launch plans: take the host out of a static step.  The reference's step is one `sess.run` of a fixed graph
+ * (graph_func.py:851-854); here it is a fixed sequence of ~200 launches on a few streams.  Between mmdgan_plan_begin()
+ * and mmdgan_plan_end() every entry of this library still EXECUTES normally and is also RECORDED - kernel, grid,
+ * arguments by value, stream, plus the memsets and the stream dependencies below - so one ordinary step records itself.
+ * mmdgan_plan_replay() then re-issues the recorded work from one C call: same streams, same overlap as the eager
+ * issue, none of the per-entry host work (argument marshalling, dispatch, geometry / tile selection).
+ *   - pointers are recorded by value: a replayed step reads and writes the SAME buffers (keep them allocated; feed
+ *     new inputs by copying into them before the replay)
+ *   - device-side state (Adam's step counter, spectral-norm vectors, the *_mix coin's averages) advances normally
+ *   - work the library does not issue (an RCCL all-reduce through torch.distributed) is NOT recorded: close a segment
+ *     with mmdgan_plan_mark() where it goes, and replay segment by segment with that work issued in between
+ *   mmdgan_plan_mark    returns the index of the segment that starts at this point
+ *   mmdgan_plan_replay  segment = -1: the whole plan; else segment 0 .. mmdgan_plan_segments()-1
+ * Stream plumbing of a recorded step (what a framework's wait_stream / event / memset / copy would do un-recorded):
+ *   mmdgan_stream_wait(w, s)   everything issued so far on stream s completes before anything issued later on stream w
+ *   mmdgan_event_record(slot, s) / mmdgan_event_wait(slot, w)   the same, with the wait issued later than the record
+ *                              (slot 0..63, per handle)
+ *   mmdgan_memset_zero, mmdgan_copy (device to device)
+ * ---------------------------------------------------------------------------------------------- */
+int mmdgan_plan_begin(void);
+int mmdgan_plan_mark(void);
+int mmdgan_plan_end(int *plan_id);
+int mmdgan_plan_abort(void);                   /* drop a recording in progress (an entry failed) */
+int mmdgan_plan_segments(int plan_id);         /* < 0: no such plan */
+long mmdgan_plan_nodes(int plan_id);           /* recorded launches / memsets / dependencies; < 0: no such plan */
+int mmdgan_plan_replay(int plan_id, int segment);
+int mmdgan_plan_destroy(int plan_id);
+int mmdgan_stream_wait(void *waiting_stream, void *signalling_stream);
+int mmdgan_event_record(int slot, void *stream);
+int mmdgan_event_wait(int slot, void *stream);
+int mmdgan_memset_zero(void *ptr, size_t bytes, void *stream);
+int mmdgan_copy(void *dst, const void *src, size_t bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Convolution family.  Geometry: input [N,H,W,C], kernel [R,R,C,K], stride, 'SAME' padding with

@@ -122,36 +122,58 @@ class SNGan(object):
 
     # --------------------------------------------------------------------------------------
     def eval_sampling(self, filename, sub_folder, mesh_num=None, mesh_mode=0, if_invert=False, code_x=None,
-                      code_y=None, real_sample=False, sample_same_class=False, get_dis_score=False, do_embedding=False,
-                      do_sprite=True, ckpt_file=None, num_threads=7):
-        """G(code_x) with BN moving statistics, clipped to [-1,1], written as the reference's sprite
-        <summary_folder>/<filename>_g_<sub_folder>_<step>_<mesh_mode>.png (my_sngan.py:499-581); returns the NCHW
-        array.  code_x defaults to MeshCode(...).get_batch(mesh_mode) (real-sample sprites, discriminator scores and the
-        TensorBoard embedding are not built)."""
+                      code_y=None, real_sample=False, sample_same_class=False, get_dis_score=True, do_sprite=True,
+                      do_embedding=False, ckpt_file=None, num_threads=7):
+        """my_sngan.py:499-581, signature and defaults as there: G(code_x) with BN moving statistics, clipped to [-1,1],
+        written as the sprite <summary_folder>/<filename>_g_<sub_folder>_<step>_<mesh_mode>.png; with real_sample a batch
+        of data is drawn too, written as ..._r_... (:567-571), and - when get_dis_score is set as well (:558) - D scores
+        both in inference mode (`self.Dis(concat(data, gen), is_training=False)`, :559-560).  code_x defaults to
+        MeshCode(...).get_batch(mesh_mode).  Returns the generated NCHW array (the reference returns nothing); the rest
+        is left in self.eval_outputs = {x_gen, x_real, s_x, s_gen}.  The TensorBoard embedding (do_embedding) is not
+        built.  The model evaluated is the one in memory (trained or loaded by an Agent): there is no `rollback`."""
         if self.engine is None:
             raise RuntimeError('eval_sampling: train (or load) a model first')
-        if real_sample or get_dis_score or do_embedding:
-            raise NotImplementedError('eval_sampling: real_sample / get_dis_score / do_embedding are not built')
+        if do_embedding:
+            raise NotImplementedError('eval_sampling: the TensorBoard embedding (do_embedding) is not built')
+        if ckpt_file is not None:
+            raise NotImplementedError('eval_sampling: load older checkpoints through Agent(load_ckpt=True)')
         _, summary_folder, _ = prepare_folder(filename, sub_folder=sub_folder)
         if mesh_num is None:
             mesh_num = (10, 10)                                              # my_sngan.py:524-525
         elif code_x is not None:
             assert code_x.shape[0] == mesh_num[0] * mesh_num[1]               # my_sngan.py:526-527
-        n = mesh_num[0] * mesh_num[1]
+        batch_size = mesh_num[0] * mesh_num[1]
+        x_real_nhwc = None
+        if real_sample:                                                       # my_sngan.py:538-541
+            self.sample_same_class = sample_same_class
+            x_real_nhwc = self.get_data_batch(filename, batch_size, batch_size, num_threads=num_threads)().clone()
         if code_x is None:                                                    # my_sngan.py:545-547
             from GeneralTools.math_func import MeshCode
             code_x = MeshCode(self.code_size, mesh_num=mesh_num).get_batch(mesh_mode, name='code_x')
         code_x = torch.as_tensor(np.asarray(code_x, np.float32)).cuda()
-        outs = []
+        gen_nhwc = []
         for i in range(0, code_x.shape[0], self.engine.B):
             z = code_x[i:i + self.engine.B].contiguous()
-            img = self.engine.generate(z, is_training=False)
-            outs.append(ops.nhwc_to_nchw(img.contiguous()).clamp_(-1, 1).cpu().numpy())
-        x_gen = np.concatenate(outs, 0)
-        if do_sprite:
+            gen_nhwc.append(self.engine.generate(z, is_training=False).clone().clamp_(-1, 1))   # :553-555
+        gen_nhwc = torch.cat(gen_nhwc, 0)
+        x_gen = ops.nhwc_to_nchw(gen_nhwc.contiguous()).cpu().numpy()
+        self.eval_outputs = {'x_gen': x_gen, 'x_real': None, 's_x': None, 's_gen': None}
+        if real_sample:
+            self.eval_outputs['x_real'] = ops.nhwc_to_nchw(x_real_nhwc.contiguous()).cpu().numpy()
+            if get_dis_score:                                                 # my_sngan.py:558-560
+                scores = self.engine.discriminate(torch.cat([x_real_nhwc, gen_nhwc], 0))
+                self.eval_outputs['s_x'] = scores[:batch_size].cpu().numpy()
+                self.eval_outputs['s_gen'] = scores[batch_size:].cpu().numpy()
+        if do_sprite:                                                         # my_sngan.py:566-575
+            step = str(self.engine.global_step)
+            if real_sample:
+                write_sprite_wrapper(
+                    self.eval_outputs['x_real'], mesh_num, filename, file_folder=summary_folder,
+                    file_index='_r_' + sub_folder + '_' + step + '_' + str(mesh_mode),
+                    if_invert=if_invert, image_format=FLAGS.IMAGE_FORMAT)
             write_sprite_wrapper(
                 x_gen, mesh_num, filename, file_folder=summary_folder,
-                file_index='_g_' + sub_folder + '_' + str(self.engine.global_step) + '_' + str(mesh_mode),
+                file_index='_g_' + sub_folder + '_' + step + '_' + str(mesh_mode),
                 if_invert=if_invert, image_format=FLAGS.IMAGE_FORMAT)
         return x_gen
 

@@ -110,6 +110,23 @@ class GenerativeModelMetric(object):
     inception_v1 = inception_v1_one_batch = inception_score_and_fid_v1
 
 
+class _KernelTimeline(object):
+    """the reference's TimeLiner (graph_func.py:578-603) for this build: a Chrome trace of the traced steps' HIP kernels"""
+
+    def __init__(self):
+        from torch.profiler import ProfilerActivity, profile
+        self._prof = profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA])
+
+    def start(self):
+        self._prof.__enter__()
+
+    def save(self, trace_file):
+        torch.cuda.synchronize()
+        self._prof.__exit__(None, None, None)
+        self._prof.export_chrome_trace(trace_file)
+        return trace_file
+
+
 class Agent(object):
     def __init__(self, filename, sub_folder, load_ckpt=False, do_trace=False, do_save=True, debug_mode=False,
                  debug_step=800, query_step=500, log_device=False, imbalanced_update=None, print_loss=True):
@@ -121,6 +138,7 @@ class Agent(object):
             raise NotImplementedError('imbalanced / dynamic update schedules are outside the hot path')
         self.imbalanced_update = None
         self.step_times = []
+        self.trace_file = None                                  # <summary_folder>/timeline.json after a do_trace run
 
     # -- checkpoints (torch.save of the reference-layout state dict; TF ckpt format is out of scope)
     def latest_ckpt(self):
@@ -161,7 +179,14 @@ class Agent(object):
         engine, step_fn, read_losses = global_step, op_list[0], loss_list
         self.load(engine)
         start = time.time()
+        tracer = None
         for step in range(max_step):
+            if self.do_trace and step == max(max_step - 5, 0):
+                # graph_func.py:996-998, 1015-1025: the LAST FIVE steps run traced and the per-step timelines are merged into
+                # one Chrome trace, <summary_folder>/timeline.json (:1139-1141).  Here the tracer is the ROCm kernel
+                # tracer behind torch.profiler: every HIP kernel launch of those steps with its stream, start and duration
+                tracer = _KernelTimeline()
+                tracer.start()
             step_fn()
             last = step == max_step - 1
             # the reference keys its periodic print on the GLOBAL step (graph_func.py:860), so a resumed run keeps the
@@ -185,4 +210,6 @@ class Agent(object):
                 self.save(engine)
         duration = time.time() - start
         FLAGS.print('Training for {} steps took {:.3f} sec.'.format(max_step, duration))
+        if tracer is not None:
+            self.trace_file = tracer.save(os.path.join(self.summary_folder, 'timeline.json'))
         return duration

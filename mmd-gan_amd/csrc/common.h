@@ -5,6 +5,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <functional>
+#include <tuple>
+#include <type_traits>
+
 #include "../../include/mmdgan_hip.h"
 
 namespace mmdgan {
@@ -14,11 +18,30 @@ constexpr float kLreluAlpha = 0.1f;   // layer_func.py:112
 constexpr float kEpsi = 1e-10f;       // misc_fun.py:29 FLAGS.EPSI
 
 void set_error(const char *fmt, ...);
-void *workspace(size_t need);
-bool outputs_prezeroed();         // mmdgan_set_outputs_prezeroed: skip internal zeroing memsets
+void *workspace(size_t need);     // caller-registered scratch of the current handle (mmdgan_set_workspace) or nullptr
+bool outputs_prezeroed();         // mmdgan_set_outputs_prezeroed of the current handle: skip internal zeroing memsets
+
+// ---- launch plans (mmdgan_plan_*): every kernel launch, memset and stream dependency the library issues goes through the
+// three functions below.  Normally they just issue; while the calling thread's handle is RECORDING they also append a
+// node that re-issues exactly the same work (same kernel, grid, arguments by value, same stream) - a step whose launch
+// sequence is static can then be replayed from one C call without its ~200 host-side entry calls.
+bool plan_recording();
+void plan_push(std::function<void()> &&node);
+hipError_t memset_async(void *p, int value, size_t bytes, hipStream_t st);
 inline hipError_t zero_output(void *p, size_t bytes, hipStream_t st) {
-    return outputs_prezeroed() ? hipSuccess : hipMemsetAsync(p, 0, bytes, st);
-}     // caller-registered scratch (mmdgan_set_workspace) or nullptr
+    return outputs_prezeroed() ? hipSuccess : memset_async(p, 0, bytes, st);
+}
+
+template <typename... KArgs, typename... Args>
+inline void launch_k(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shmem, hipStream_t st, Args &&...args) {
+    // convert to the kernel's own parameter types first: a recorded node must hold exactly what the kernel receives
+    std::tuple<std::decay_t<KArgs>...> pack{static_cast<std::decay_t<KArgs>>(args)...};
+    std::apply([&](auto &...a) { kernel<<<grid, block, shmem, st>>>(a...); }, pack);
+    if (plan_recording())
+        plan_push([kernel, grid, block, shmem, st, pack]() mutable {
+            std::apply([&](auto &...a) { kernel<<<grid, block, shmem, st>>>(a...); }, pack);
+        });
+}
 
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
@@ -28,6 +51,12 @@ inline int check_launch(const char *what) {
     }
     return MMDGAN_OK;
 }
+
+// every launch site of the library is spelled hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...): route them
+// through launch_k (this is not a portability shim - there is one backend - but the single choke point plans need)
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    ::mmdgan::launch_k(kernel, dim3(grid), dim3(block), (size_t)(shmem), (hipStream_t)(stream), ##__VA_ARGS__)
 
 #define MMDGAN_REQUIRE(cond, ...)            \
     do {                                     \

@@ -376,7 +376,7 @@ static int wino_launch(const ConvDims &d, const ConvEpilogue &ep, const float *i
         const int sps = (nstages + split - 1) / split;
         split = (nstages + sps - 1) / sps;
         const long total = (long)d.N * d.H * d.W * ko;
-        if (hipMemsetAsync(out, 0, sizeof(float) * total, st) != hipSuccess) return check_launch("conv2d(winograd) memset");
+        if (memset_async(out, 0, sizeof(float) * total, st) != hipSuccess) return check_launch("conv2d(winograd) memset");
         const dim3 grid((unsigned)((T + 31) / 32), ko / 64, split);
         hipLaunchKernelGGL((wino_kernel<64, true>), grid, dim3(256), (wino::Cfg<64>::LDS_BYTES), st, d.N, d.H, d.W, cr, ko, ep, in,
                            U, out, sps);

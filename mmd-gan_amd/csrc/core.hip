@@ -1,5 +1,9 @@
-// error state, version, device probe
+// error state, version, device probe, handles (workspace / prezeroed mode / launch plans / events)
 #include "common.h"
+
+#include <memory>
+#include <mutex>
+#include <vector>
 
 namespace mmdgan {
 static thread_local char g_err[512] = "";
@@ -9,15 +13,60 @@ void set_error(const char *fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
-static void *g_ws = nullptr;
-static size_t g_ws_bytes = 0;
-static bool g_prezeroed = false;
-bool outputs_prezeroed() { return g_prezeroed; }
-void *workspace(size_t need) { return (g_ws && need <= g_ws_bytes) ? g_ws : nullptr; }
+
+// A launch plan: the recorded work of one static step, cut into segments at mmdgan_plan_mark() so that a caller can run
+// work the library does not issue (an RCCL collective) between two segments.
+struct Plan {
+    std::vector<std::function<void()>> nodes;
+    std::vector<size_t> segment_end;          // node count at the end of each closed segment
+};
+
 }  // namespace mmdgan
 
+// One handle per engine: the state that used to be process-global.  A handle is used by one thread at a time; distinct
+// handles are independent.  Entry points act on the calling thread's CURRENT handle (mmdgan_make_current); a thread that
+// never made one current uses the process default handle, which keeps single-engine callers as simple as before.
+struct mmdgan_handle {
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    bool prezeroed = false;
+    std::unique_ptr<mmdgan::Plan> recording;
+    std::vector<std::unique_ptr<mmdgan::Plan>> plans;      // plan id = index (destroyed plans leave a null slot)
+    std::vector<hipEvent_t> plan_events;                   // one per recorded stream_wait node (re-used on every replay)
+    std::vector<hipEvent_t> pool;                          // round-robin pool of the un-recorded stream_wait calls
+    size_t pool_next = 0;
+    std::vector<hipEvent_t> slots;                         // named slots of mmdgan_event_record / _wait
+    ~mmdgan_handle() {
+        for (auto *v : {&plan_events, &pool, &slots})
+            for (hipEvent_t e : *v)
+                if (e) (void)hipEventDestroy(e);
+    }
+};
+
+namespace mmdgan {
+static mmdgan_handle g_default_handle;
+static thread_local mmdgan_handle *t_current = nullptr;
+static inline mmdgan_handle &cur() { return t_current ? *t_current : g_default_handle; }
+
+bool outputs_prezeroed() { return cur().prezeroed; }
+void *workspace(size_t need) {
+    mmdgan_handle &h = cur();
+    return (h.ws && need <= h.ws_bytes) ? h.ws : nullptr;
+}
+bool plan_recording() { return cur().recording != nullptr; }
+void plan_push(std::function<void()> &&node) { cur().recording->nodes.emplace_back(std::move(node)); }
+
+hipError_t memset_async(void *p, int value, size_t bytes, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(p, value, bytes, st);
+    if (e == hipSuccess && plan_recording()) plan_push([=]() { (void)hipMemsetAsync(p, value, bytes, st); });
+    return e;
+}
+}  // namespace mmdgan
+
+using namespace mmdgan;
+
 extern "C" const char *mmdgan_last_error(void) { return mmdgan::g_err; }
-extern "C" int mmdgan_version(void) { return 100; }
+extern "C" int mmdgan_version(void) { return 200; }
 extern "C" int mmdgan_device_ok(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return 0; }
@@ -25,12 +74,147 @@ extern "C" int mmdgan_device_ok(void) {
     if (hipGetDeviceProperties(&p, 0) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return strncmp(p.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
 }
+
+extern "C" int mmdgan_create(mmdgan_handle **out) {
+    MMDGAN_REQUIRE(out, "create: null pointer");
+    *out = new mmdgan_handle();
+    return MMDGAN_OK;
+}
+extern "C" int mmdgan_destroy(mmdgan_handle *h) {
+    if (!h) return MMDGAN_OK;
+    MMDGAN_REQUIRE(h != &g_default_handle, "destroy: not a handle of mmdgan_create");
+    if (t_current == h) t_current = nullptr;
+    delete h;
+    return MMDGAN_OK;
+}
+extern "C" int mmdgan_make_current(mmdgan_handle *h) {
+    t_current = h;                     // NULL: back to the process default handle
+    return MMDGAN_OK;
+}
 extern "C" int mmdgan_set_workspace(void *ptr, size_t bytes) {
-    mmdgan::g_ws = ptr;
-    mmdgan::g_ws_bytes = ptr ? bytes : 0;
+    cur().ws = ptr;
+    cur().ws_bytes = ptr ? bytes : 0;
     return MMDGAN_OK;
 }
 extern "C" int mmdgan_set_outputs_prezeroed(int on) {
-    mmdgan::g_prezeroed = on != 0;
+    const bool v = on != 0;
+    if (plan_recording()) {            // a mode switch inside a recorded step is part of the step
+        mmdgan_handle *h = &cur();
+        plan_push([h, v]() { h->prezeroed = v; });
+    }
+    cur().prezeroed = v;
+    return MMDGAN_OK;
+}
+
+// ---- stream plumbing a recorded step needs (what torch's wait_stream / Event / zero_ / copy_ do, as library calls) ----
+extern "C" int mmdgan_stream_wait(void *waiting_stream, void *signalling_stream) {
+    // everything issued so far on `signalling_stream` completes before anything issued later on `waiting_stream` starts
+    hipStream_t w = (hipStream_t)waiting_stream, s = (hipStream_t)signalling_stream;
+    if (w == s) return MMDGAN_OK;
+    mmdgan_handle &h = cur();
+    hipEvent_t ev = nullptr;
+    if (plan_recording()) {                    // the node keeps an event of its own
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return check_launch("stream_wait event");
+        h.plan_events.push_back(ev);
+    } else {                                   // a wait captures the event's state when it is issued: re-use is safe
+        constexpr size_t kPool = 64;
+        if (h.pool.size() < kPool) {
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return check_launch("stream_wait event");
+            h.pool.push_back(ev);
+        } else {
+            ev = h.pool[h.pool_next++ % kPool];
+        }
+    }
+    if (hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(w, ev, 0) != hipSuccess) return check_launch("stream_wait");
+    if (plan_recording()) plan_push([=]() { (void)hipEventRecord(ev, s); (void)hipStreamWaitEvent(w, ev, 0); });
+    return MMDGAN_OK;
+}
+
+// named events: record at one point of a stream, wait for that point later from another stream
+extern "C" int mmdgan_event_record(int slot, void *stream) {
+    MMDGAN_REQUIRE(slot >= 0 && slot < 64, "event_record: slot %d outside [0,64)", slot);
+    std::vector<hipEvent_t> &t = cur().slots;
+    if ((int)t.size() <= slot) t.resize(slot + 1, nullptr);
+    if (!t[slot] && hipEventCreateWithFlags(&t[slot], hipEventDisableTiming) != hipSuccess) return check_launch("event_record");
+    hipEvent_t ev = t[slot];
+    hipStream_t s = (hipStream_t)stream;
+    if (hipEventRecord(ev, s) != hipSuccess) return check_launch("event_record");
+    if (plan_recording()) plan_push([=]() { (void)hipEventRecord(ev, s); });
+    return MMDGAN_OK;
+}
+extern "C" int mmdgan_event_wait(int slot, void *stream) {
+    std::vector<hipEvent_t> &t = cur().slots;
+    MMDGAN_REQUIRE(slot >= 0 && slot < (int)t.size() && t[slot], "event_wait: slot %d was never recorded", slot);
+    hipEvent_t ev = t[slot];
+    hipStream_t s = (hipStream_t)stream;
+    if (hipStreamWaitEvent(s, ev, 0) != hipSuccess) return check_launch("event_wait");
+    if (plan_recording()) plan_push([=]() { (void)hipStreamWaitEvent(s, ev, 0); });
+    return MMDGAN_OK;
+}
+extern "C" int mmdgan_memset_zero(void *ptr, size_t bytes, void *stream) {
+    MMDGAN_REQUIRE(ptr || bytes == 0, "memset_zero: null pointer");
+    if (bytes == 0) return MMDGAN_OK;
+    if (memset_async(ptr, 0, bytes, (hipStream_t)stream) != hipSuccess) return check_launch("memset_zero");
+    return MMDGAN_OK;
+}
+extern "C" int mmdgan_copy(void *dst, const void *src, size_t bytes, void *stream) {
+    MMDGAN_REQUIRE((dst && src) || bytes == 0, "copy: null pointer");
+    if (bytes == 0) return MMDGAN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return check_launch("copy");
+    if (plan_recording()) plan_push([=]() { (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st); });
+    return MMDGAN_OK;
+}
+
+// ---- launch plans ----------------------------------------------------------------------------------------------
+extern "C" int mmdgan_plan_begin(void) {
+    MMDGAN_REQUIRE(!plan_recording(), "plan_begin: already recording");
+    cur().recording.reset(new Plan());
+    return MMDGAN_OK;
+}
+extern "C" int mmdgan_plan_mark(void) {
+    MMDGAN_REQUIRE(plan_recording(), "plan_mark: not recording");
+    Plan &p = *cur().recording;
+    p.segment_end.push_back(p.nodes.size());
+    return (int)p.segment_end.size();          // index of the segment that starts here
+}
+extern "C" int mmdgan_plan_end(int *plan_id) {
+    MMDGAN_REQUIRE(plan_recording() && plan_id, "plan_end: not recording");
+    mmdgan_handle &h = cur();
+    h.recording->segment_end.push_back(h.recording->nodes.size());
+    h.plans.emplace_back(std::move(h.recording));
+    *plan_id = (int)h.plans.size() - 1;
+    return MMDGAN_OK;
+}
+extern "C" int mmdgan_plan_abort(void) {
+    cur().recording.reset();
+    return MMDGAN_OK;
+}
+extern "C" int mmdgan_plan_segments(int plan_id) {
+    mmdgan_handle &h = cur();
+    if (plan_id < 0 || plan_id >= (int)h.plans.size() || !h.plans[plan_id]) return MMDGAN_E_ARG;
+    return (int)h.plans[plan_id]->segment_end.size();
+}
+extern "C" long mmdgan_plan_nodes(int plan_id) {
+    mmdgan_handle &h = cur();
+    if (plan_id < 0 || plan_id >= (int)h.plans.size() || !h.plans[plan_id]) return MMDGAN_E_ARG;
+    return (long)h.plans[plan_id]->nodes.size();
+}
+extern "C" int mmdgan_plan_replay(int plan_id, int segment) {
+    mmdgan_handle &h = cur();
+    MMDGAN_REQUIRE(!plan_recording(), "plan_replay: a plan is being recorded");
+    MMDGAN_REQUIRE(plan_id >= 0 && plan_id < (int)h.plans.size() && h.plans[plan_id], "plan_replay: no plan %d", plan_id);
+    Plan &p = *h.plans[plan_id];
+    const int nseg = (int)p.segment_end.size();
+    MMDGAN_REQUIRE(segment >= -1 && segment < nseg, "plan_replay: plan %d has %d segments (asked for %d)", plan_id, nseg, segment);
+    const size_t lo = segment <= 0 ? 0 : p.segment_end[segment - 1];
+    const size_t hi = segment < 0 ? p.nodes.size() : p.segment_end[segment];
+    for (size_t i = lo; i < hi; ++i) p.nodes[i]();
+    return check_launch("plan_replay");
+}
+extern "C" int mmdgan_plan_destroy(int plan_id) {
+    mmdgan_handle &h = cur();
+    MMDGAN_REQUIRE(plan_id >= 0 && plan_id < (int)h.plans.size(), "plan_destroy: no plan %d", plan_id);
+    h.plans[plan_id].reset();
     return MMDGAN_OK;
 }

@@ -20,8 +20,24 @@ SIGNATURES = {
     'mmdgan_last_error': (ctypes.c_char_p, []),
     'mmdgan_version': (_I, []),
     'mmdgan_device_ok': (_I, []),
+    'mmdgan_create': (_I, [ctypes.POINTER(ctypes.c_void_p)]),
+    'mmdgan_destroy': (_I, [_P]),
+    'mmdgan_make_current': (_I, [_P]),
     'mmdgan_set_workspace': (_I, [_P, ctypes.c_size_t]),
     'mmdgan_set_outputs_prezeroed': (_I, [_I]),
+    'mmdgan_plan_begin': (_I, []),
+    'mmdgan_plan_mark': (_I, []),
+    'mmdgan_plan_end': (_I, [ctypes.POINTER(_I)]),
+    'mmdgan_plan_abort': (_I, []),
+    'mmdgan_plan_segments': (_I, [_I]),
+    'mmdgan_plan_nodes': (_L, [_I]),
+    'mmdgan_plan_replay': (_I, [_I, _I]),
+    'mmdgan_plan_destroy': (_I, [_I]),
+    'mmdgan_stream_wait': (_I, [_P, _P]),
+    'mmdgan_event_record': (_I, [_I, _P]),
+    'mmdgan_event_wait': (_I, [_I, _P]),
+    'mmdgan_memset_zero': (_I, [_P, ctypes.c_size_t, _P]),
+    'mmdgan_copy': (_I, [_P, _P, ctypes.c_size_t, _P]),
     'mmdgan_conv2d_fwd': (_I, [_G, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     'mmdgan_conv2d_dgrad': (_I, [_G, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     'mmdgan_conv2d_wgrad': (_I, [_G, _P, _P, _P, _P]),

@@ -33,6 +33,8 @@ import torch
 
 from . import initializers, ops
 
+_EV_WINO_GEN = 0                      # named event slot (mmdgan_event_record / _wait): G's Winograd weights are ready
+
 _TEMPLATE = {'name': None, 'type': 'default', 'op': 'c', 'out': None, 'bias': 'b',
              'act': 'linear', 'act_nm': None, 'act_k': False, 'w_nm': None, 'w_p': None,
              'kernel': 3, 'strides': 1, 'dilation': 1, 'padding': 'SAME', 'scale': None,
@@ -375,7 +377,7 @@ class GanEngine:
 
     def __init__(self, architecture, loss_type='rep', lr_list=(5e-4, 2e-4), rep_weights=(0.0, -1.0),
                  batch_size=64, seed=0, device=None, dist_group=None, use_graph=False, sn_mode='default',
-                 weight_init='default', mix_threshold=None):
+                 weight_init='default', mix_threshold=None, launch_mode=None):
         ops.require_device()
         initializers.check_mode(weight_init)
         if loss_type not in ops.LOSS:
@@ -421,7 +423,7 @@ class GanEngine:
         # same fake half of the batch
         self._z_gen = torch.Generator(device=self.device)
         self._z_gen.manual_seed((int(seed) * 1000003 + 7919 * self.rank + 12345) % (2 ** 63 - 1))
-        self._exchange_pending = False
+        self._recording, self._d_updated_early = False, False
         # the power iterations of different layers are independent of each other too: two chains.
         # weight / bias gradients of a layer depend only on dz of that layer, not on the dgrad chain that
         # continues below it: they go to another stream so their blocks fill the tail of the dgrad
@@ -431,21 +433,61 @@ class GanEngine:
         n_sn = int(os.environ.get('MMDGAN_SN_STREAMS', '2'))
         side = distinct_queue_streams(n_sn + 1, self.device)
         self._wg_stream, self._sn_streams = side[0], side[1:]
-        self._comm_stream = side[1] if len(side) > 1 else side[0]      # gradient exchange, see _allreduce
-        self._dis_exchanged = torch.cuda.Event()
+        self._comm_stream = side[1] if len(side) > 1 else side[0]      # gradient exchange, see _exchange
+        self._wg_raw, self._comm_raw = self._wg_stream.cuda_stream, self._comm_stream.cuda_stream
+        self._sn_raw = [st.cuda_stream for st in self._sn_streams]
         self._early_d_adam = os.environ.get('MMDGAN_EARLY_D_ADAM', '1') != '0'
         self._thin_on_main = os.environ.get('MMDGAN_THIN_ON_MAIN') == '1'
         self._side_wgrad = os.environ.get('MMDGAN_SIDE_WGRAD', '1') != '0'
         if ops._workspace is None:
-            ops.set_workspace(device=self.device)
+            ops.set_workspace(device=self.device)                        # the default handle's (eval paths, stand-alone ops)
+        # this engine's own library state (include/mmdgan_hip.h "Handles"): workspace, prezeroed mode, launch plan
+        self._handle = ops.Handle(device=self.device)
         self._alloc(self.B)
         self.losses = torch.zeros(8, device=self.device)       # filled by the loss kernel each step
         self._loss = ops.GanLossLauncher(loss_type, self.rep_weights, self.B, self.score_size, self.device, mix_threshold)
         self.buf['mmd_grads'] = self._loss.grads
-        self.use_graph, self._graph = use_graph, None
+        # how a step reaches the GPU.  'eager': ~200 library calls from Python per step; 'graph': one captured hipGraph
+        # (few host microseconds, but its branches overlap less: 2.69 vs 2.35 ms per CIFAR step); 'plan': the library
+        # records one eager step and re-issues it from ONE C call (mmdgan_plan_replay) - the eager step's streams and
+        # overlap with the graph's host cost.  MMDGAN_LAUNCH_MODE overrides; use_graph=True is the old spelling of 'graph'
+        self.launch_mode = launch_mode or os.environ.get('MMDGAN_LAUNCH_MODE') or ('graph' if use_graph else 'eager')
+        assert self.launch_mode in ('eager', 'graph', 'plan'), self.launch_mode
+        self._graph, self._plan, self._plan_stream, self._plan_collectives = None, None, None, []
+        self._baked_lr = (self.lr_d, self.lr_g)
         self._in_step = False                                  # True while step() runs (buffers on the zero list ARE zero)
+        self._grad_buckets = {id(net): self._make_buckets(net) for net in (self.gen, self.dis)}
         self._static_z = torch.zeros(self.B, self.code_size, device=self.device)
         self._static_real = torch.zeros(_native_shape(self.in_shape_ref, self.B), device=self.device)
+
+    @property
+    def use_graph(self):
+        return self.launch_mode == 'graph'
+
+    @use_graph.setter
+    def use_graph(self, on):
+        self.launch_mode = 'graph' if on else ('eager' if self.launch_mode == 'graph' else self.launch_mode)
+
+    def _make_buckets(self, net):
+        """the gradient arena of `net` cut into exchange buckets, in BACKWARD order: [(lowest layer index, start, end)].
+        A bucket is exchanged as soon as the parameter gradients of its lowest layer have been issued, so all but the
+        last one travel underneath the rest of the backward pass.  Layers are contiguous in the arena (forward order);
+        a bucket closes once it holds MMDGAN_DP_BUCKET_MB (default 8) - xGMI rings are latency-bound below a few MB."""
+        target = int(float(os.environ.get('MMDGAN_DP_BUCKET_MB', '8')) * (1 << 20)) // 4
+        first = {}                                   # layer index -> (start, end) float offsets of its entries
+        for name, (o, size, _) in net.arena.offsets.items():
+            li = next(i for i, sp in enumerate(net.specs) if name.startswith(sp.scope + '/'))
+            lo, hi = first.get(li, (o, o))
+            first[li] = (min(lo, o), max(hi, o + (size + 3) // 4 * 4))
+        buckets, hi_end, acc = [], None, 0
+        for li in range(len(net.specs) - 1, -1, -1):
+            lo_off, hi_off = first[li]
+            hi_end = hi_off if hi_end is None else hi_end
+            acc += hi_off - lo_off
+            if acc >= target or li == 0:
+                buckets.append((li, lo_off, min(hi_end, net.arena.size)))
+                hi_end, acc = None, 0
+        return buckets
 
     # ---------------------------------------------------------------------------------------
     def _alloc(self, B):
@@ -498,7 +540,6 @@ class GanEngine:
         # G w G^T is computed once per step on the parameter-gradient stream (idle during the forward pass)
         # instead of inside every conv call.  scope -> [forward tensor or None, input-gradient tensor or None]
         self._wino = {}
-        self._wino_gen_ready = torch.cuda.Event()
         if self._side_wgrad:
             for net, nf, nb in ((self.dis, 2 * B, 3 * B), (self.gen, B, B)):
                 for s in net.specs:
@@ -586,26 +627,42 @@ class GanEngine:
                 x = x.view(_native_shape(s.out_shape_ref, x.shape[0]))
         return x
 
+    def discriminate(self, x_nhwc):
+        """D(x) in INFERENCE mode (my_sngan.py:558-560, `self.Dis(..., is_training=False)`): spectral norms from the stored
+        power-iteration vectors WITHOUT updating them (UPDATE_OPS run in training sessions only); [n, d] scores.
+        Rows are independent in inference, so the batch is walked in chunks of the engine's 2B-row buffers."""
+        scales = {s.scope: (sn_power_iteration(self.dis, s, self.buf, update=False, out_zeroed=False) if s.sn else None)
+                  for s in self.dis.specs}
+        outs = []
+        for i in range(0, x_nhwc.shape[0], 2 * self.B):
+            x = x_nhwc[i:i + 2 * self.B].contiguous()
+            for s in self.dis.specs:
+                x = self._layer_forward(self.dis, s, x, False, scales[s.scope])
+                if s.out_reshape is not None:
+                    x = x.view(_native_shape(s.out_shape_ref, x.shape[0]))
+            outs.append(x.clone())
+        return torch.cat(outs, 0)
+
     # ---------------------------------------------------------------------------------------
     def _forward(self, z, real):
         B, b = self.B, self.buf
         # the spectral-norm power iteration depends on D's weights only, not on the batch: its ~50
         # small launches run on a second HIP stream underneath G's forward pass
-        main = torch.cuda.current_stream()
+        main = ops._stream()
         self._scales = {}
-        for st in self._sn_streams:
-            st.wait_stream(main)
+        for st in self._sn_raw:
+            ops.stream_wait(st, main)
         for i, s in enumerate(self.dis.specs):
             with torch.cuda.stream(self._sn_streams[i % len(self._sn_streams)]):
                 self._scales[s.scope] = self._sn_step(s) if s.sn else None
-        b['dis_in'][:B].copy_(real)
+        ops.copy(b['dis_in'][:B], real)                                      # my_sngan.py:278: D sees [real ; fake]
         if any(net is self.gen for _, _, net in self._wino.values()):
-            main.wait_event(self._wino_gen_ready)
+            ops.event_wait(_EV_WINO_GEN, main)
         self.generate(z, is_training=True)                                   # writes dis_in[B:]
-        for st in self._sn_streams:
-            main.wait_stream(st)
+        for st in self._sn_raw:
+            ops.stream_wait(main, st)
         if self._wino:
-            main.wait_stream(self._wg_stream)                                # transformed weights of this step
+            ops.stream_wait(main, self._wg_raw)                              # transformed weights of this step
         x = b['dis_in']
         for s in self.dis.specs:
             scale = self._scales[s.scope]
@@ -649,6 +706,7 @@ class GanEngine:
                     ops.sn_wgrad_fixup(gw.view(-1), net.state[s.scope + '#dsigma'].view(-1), dot,
                                        net.state[s.scope + '#sigma'], scale)
             self._on_wg_stream(param_grads, s)
+            self._exchange(net, li)
             if li > 0:
                 prev = specs[li - 1]
                 dprev, yprev = b[prev.scope + '#dz'], b[prev.scope + '#y']
@@ -684,13 +742,13 @@ class GanEngine:
         if not self._side_wgrad or (thin and self._thin_on_main):
             fn()
             return
-        self._wg_stream.wait_stream(torch.cuda.current_stream())
+        ops.stream_wait(self._wg_raw, ops._stream())
         with torch.cuda.stream(self._wg_stream):
             fn()
 
     def _join_wg_stream(self):
         if self._side_wgrad:
-            torch.cuda.current_stream().wait_stream(self._wg_stream)
+            ops.stream_wait(ops._stream(), self._wg_raw)
 
     def _backward_gen(self, dz, z):
         B, b, net = self.B, self.buf, self.gen
@@ -727,6 +785,7 @@ class GanEngine:
                 else:                                                        # tc: W[R,R,Cout,Cin]; y = dgrad(v, W)
                     ops.conv2d_wgrad(dz, x_in, s.R, s.stride, out=gw)
             self._on_wg_stream(param_grads, s)
+            self._exchange(net, li)
             if li > 0:
                 prev = specs[li - 1]
                 # a BN layer below gets d/d(its activated output) and applies act' itself in bn_bwd;
@@ -750,52 +809,67 @@ class GanEngine:
                 dz = dprev
 
     # ---------------------------------------------------------------------------------------
-    def _allreduce(self, net):
-        """start the bucketed SUM all-reduce of one network's gradient arena; it overlaps with whatever backward
-        work is issued next and is awaited before Adam.  The collectives are issued as blocking ones on a stream
-        of our own choosing - ProcessGroupNCCL then runs them there, not on its internal stream, whose hardware
-        queue it shares with whichever of our streams happens to map to it (streams.py).  The stream used is the
-        first power-iteration stream: idle from the start of D's forward pass to the next step, on a queue of
-        its own, and the spectral-norm chain of the next step has to wait for this step's Adam anyway."""
-        if self.dist_group is None or (self.world == 1 and not self._dp_force):
-            return                                       # MMDGAN_DP_FORCE=1: exchange even with one rank (plumbing test)
-        from . import dist as mdist
-        comm = self._comm_stream
-        # the arena is complete once the parameter-gradient stream has drained AND the main stream has reached
-        # this point (thin layers' gradients stay there); the main stream itself goes straight on
-        comm.wait_stream(torch.cuda.current_stream())
+    # data-parallel gradient exchange (the reference's dormant tower helper, graph_func.py:69-94)
+    # ---------------------------------------------------------------------------------------
+    def _dp_active(self):
+        return self.dist_group is not None and (self.world > 1 or self._dp_force)   # MMDGAN_DP_FORCE=1: one-rank plumbing test
+
+    def _exchange(self, net, li):
+        """called right after the parameter gradients of layer `li` of `net` have been issued: if that completes an
+        exchange bucket (_make_buckets), its SUM all-reduce starts NOW on the exchange stream and travels underneath
+        the backward kernels still to come - only the last bucket of G (its first dense layer, 4 MB for CIFAR) is
+        exposed.  The collectives are issued as blocking ones on a stream of our own choosing - ProcessGroupNCCL then
+        runs them there, not on its internal stream, whose hardware queue it shares with whichever of our streams
+        happens to map to it (streams.py).  The stream used is the first power-iteration stream: idle from the start
+        of D's forward pass to the next step, on a queue of its own.  Averaging is Adam's grad_scale = 1/world."""
+        if not self._dp_active():
+            return
+        bucket = next((b for b in self._grad_buckets[id(net)] if b[0] == li), None)
+        if bucket is None:
+            return
+        _, lo, hi = bucket
+        # the bucket is complete once the parameter-gradient stream has drained what it holds now (and the main stream
+        # has reached this point, for gradients that stay there)
         if self._side_wgrad:
-            comm.wait_stream(self._wg_stream)
-        with torch.cuda.stream(comm):
-            mdist.allreduce_sum_(net.grads, self.dist_group)
-            if net is self.dis:
-                self._dis_exchanged.record(comm)
-        self._exchange_pending = True
+            ops.stream_wait(self._comm_raw, self._wg_raw)
+        ops.stream_wait(self._comm_raw, ops._stream())
+        lib = ops.require_device()
+        if self._recording:
+            lib.mmdgan_plan_mark()                       # the collective is not the library's: a segment boundary
+            self._plan_collectives.append((net, lo, hi))
+        self._issue_collective(net, lo, hi)
+        last = bucket is self._grad_buckets[id(net)][-1]
+        if last and net is self.dis and self._early_d_adam:
+            # D's exchange is complete and nothing in G's backward pass reads D's weights: its Adam runs on the exchange
+            # stream, beside G's backward pass, instead of at the tail of the step
+            with torch.cuda.stream(self._comm_stream):
+                self.dis.opt.step(self.lr_d, grad_scale=1.0 / self.world)
+            self._d_updated_early = True
+
+    def _issue_collective(self, net, lo, hi):
+        from . import dist as mdist
+        with torch.cuda.stream(self._comm_stream):
+            mdist.allreduce_sum_(net.grads[lo:hi], self.dist_group)
 
     def _update(self):
         gs = 1.0 / self.world
-        if self._exchange_pending:
-            # D's exchange finished long ago (it ran under G's backward pass): its Adam goes first and hides part
-            # of G's exchange, the only one that is exposed
-            torch.cuda.current_stream().wait_event(self._dis_exchanged)
-            self.dis.opt.step(self.lr_d, grad_scale=gs)
-            torch.cuda.current_stream().wait_stream(self._comm_stream)
-            self._exchange_pending = False
-            self.gen.opt.step(self.lr_g, grad_scale=gs)
-            return
-        if not getattr(self, '_d_updated_early', False):
+        main = ops._stream()
+        if self._dp_active():
+            ops.stream_wait(main, self._comm_raw)        # all buckets (and D's early Adam) have landed
+        if not self._d_updated_early:
             self.dis.opt.step(self.lr_d, grad_scale=gs)
         self.gen.opt.step(self.lr_g, grad_scale=gs)
 
     def _step_body(self, z, real):
         lib = ops.require_device()
         lib.mmdgan_set_outputs_prezeroed(1)
+        main = ops._stream()
         try:
             # the two gradient arenas (61 MB of memset) are first touched in the backward pass: zero them
             # on the parameter-gradient stream, underneath the forward pass
             arenas = (self.gen.grads, self.dis.grads) if self._side_wgrad else ()
             if arenas:
-                self._wg_stream.wait_stream(torch.cuda.current_stream())      # after the previous step's Adam
+                ops.stream_wait(self._wg_raw, main)                          # after the previous step's Adam
                 with torch.cuda.stream(self._wg_stream):
                     # G's transformed weights first (its forward pass starts right away and waits on this event),
                     # then the memsets, then D's (needed after G's forward / in the backward pass)
@@ -809,29 +883,27 @@ class GanEngine:
                             if ub is not None:
                                 ops.wino_transform(w, True, out=ub)
                         if first:
-                            self._wino_gen_ready.record(self._wg_stream)
+                            ops.event_record(_EV_WINO_GEN, self._wg_raw)
                             for t in arenas:
-                                t.zero_()
+                                ops.memset_zero(t)
             for t in self._zero_each_step:
                 if not any(t is a for a in arenas):
-                    t.zero_()
+                    ops.memset_zero(t)
             self._in_step = True
+            self._d_updated_early = False
             self._forward(z, real)
             if arenas:
-                torch.cuda.current_stream().wait_stream(self._wg_stream)
+                ops.stream_wait(main, self._wg_raw)
             dz = self._backward_dis()
-            self._allreduce(self.dis)
-            self._d_updated_early = False
-            if self._early_d_adam and self.dist_group is None and self._side_wgrad:
+            if self._early_d_adam and not self._dp_active() and self._side_wgrad:
                 # D's gradients are complete once the parameter-gradient stream has drained what it holds now and
                 # the main stream has reached this point (thin layers); nothing in G's backward pass reads D's
                 # weights, so D's Adam runs there, beside G's backward pass, instead of at the tail of the step
-                self._wg_stream.wait_stream(torch.cuda.current_stream())
+                ops.stream_wait(self._wg_raw, main)
                 with torch.cuda.stream(self._wg_stream):
                     self.dis.opt.step(self.lr_d, grad_scale=1.0)
                 self._d_updated_early = True
             self._backward_gen(dz, z)
-            self._allreduce(self.gen)
             self._join_wg_stream()
             self._update()
         finally:
@@ -847,18 +919,63 @@ class GanEngine:
         else:
             self._static_z.copy_(z)
         self._loss.draw(self._z_gen, uni)                                    # math_func.py:2079 (the *_mix coin)
-        graph = self.use_graph and self.dist_group is None
-        if real_nhwc is not None and graph:
-            self._static_real.copy_(real_nhwc)                               # the captured graph reads this buffer
-        if graph:
-            if self._graph is None:
-                self._capture()
+        mode = self.launch_mode
+        if mode == 'graph' and self.dist_group is not None:
+            mode = 'eager'                               # a collective cannot sit inside the captured graph
+        if (self.lr_d, self.lr_g) != self._baked_lr:     # a captured graph / recorded plan holds the learning rates by value
+            self._graph, self._baked_lr = None, (self.lr_d, self.lr_g)
+            if self._plan is not None:
+                with self._handle:
+                    ops.require_device().mmdgan_plan_destroy(self._plan)
+                self._plan = None
+        with self._handle:                               # this engine's workspace / prezeroed mode / plans
+            if mode == 'eager':
+                # the batch goes straight into the first half of D's input buffer (one copy, not two)
+                self._step_body(self._static_z, real_nhwc if real_nhwc is not None else self._static_real)
             else:
-                self._graph.replay()
-        else:
-            # eager issue: the batch goes straight into the first half of D's input buffer (one copy, not two)
-            self._step_body(self._static_z, real_nhwc if real_nhwc is not None else self._static_real)
+                if real_nhwc is not None:
+                    self._static_real.copy_(real_nhwc)                       # graph / plan read this buffer
+                if mode == 'graph':
+                    if self._graph is None:
+                        self._capture()
+                    else:
+                        self._graph.replay()
+                else:
+                    self._plan_step()
         self.global_step += 1                                                # tied to the D update, my_sngan.py:424
+
+    def _plan_step(self):
+        """record the step once (an ordinary eager step that the library notes down, include/mmdgan_hip.h "Launch
+        plans"), replay it from one C call afterwards.  Under data parallelism the plan is cut where the exchange
+        collectives go; they are issued between the segments, on the exchange stream, exactly as in the eager step."""
+        lib = ops.require_device()
+        main = ops._stream()
+        if self._plan is not None and self._plan_stream != main:
+            lib.mmdgan_plan_destroy(self._plan)          # recorded for another stream: record again
+            self._plan = None
+        if self._plan is None:
+            self._plan_collectives = []
+            ops.check(lib.mmdgan_plan_begin(), 'plan_begin')
+            self._recording = True
+            try:
+                self._step_body(self._static_z, self._static_real)
+            except Exception:
+                lib.mmdgan_plan_abort()
+                raise
+            finally:
+                self._recording = False
+            import ctypes
+            pid = ctypes.c_int(-1)
+            ops.check(lib.mmdgan_plan_end(ctypes.byref(pid)), 'plan_end')
+            self._plan, self._plan_stream = pid.value, main
+            return
+        if not self._plan_collectives:
+            ops.check(lib.mmdgan_plan_replay(self._plan, -1), 'plan_replay')
+            return
+        for i, (net, lo, hi) in enumerate(self._plan_collectives):
+            ops.check(lib.mmdgan_plan_replay(self._plan, i), 'plan_replay')
+            self._issue_collective(net, lo, hi)
+        ops.check(lib.mmdgan_plan_replay(self._plan, len(self._plan_collectives)), 'plan_replay')
 
     def _capture(self):
         # warm-up on a side stream (allocates lazily-created buffers), then capture one step

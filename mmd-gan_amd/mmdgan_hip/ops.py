@@ -48,6 +48,59 @@ def set_workspace(nbytes=32 << 20, device=None):
     return _workspace
 
 
+class Handle:
+    """an mmdgan_handle (include/mmdgan_hip.h): one engine's workspace, prezeroed mode, launch plans and events.
+    `with handle:` makes it the calling thread's current handle and restores the process default afterwards."""
+
+    def __init__(self, workspace_bytes=32 << 20, device=None):
+        lib = require_device()
+        h = ctypes.c_void_p()
+        check(lib.mmdgan_create(ctypes.byref(h)), 'create')
+        self._h, self._lib = h, lib
+        self.workspace = torch.empty(workspace_bytes, dtype=torch.uint8, device=device or 'cuda') if workspace_bytes else None
+        if self.workspace is not None:
+            with self:
+                check(lib.mmdgan_set_workspace(self.workspace.data_ptr(), workspace_bytes), 'set_workspace')
+
+    def __enter__(self):
+        self._lib.mmdgan_make_current(self._h)
+        return self
+
+    def __exit__(self, *exc):
+        self._lib.mmdgan_make_current(None)
+        return False
+
+    def __del__(self):
+        try:
+            self._lib.mmdgan_destroy(self._h)
+        except Exception:
+            pass
+
+
+def stream_wait(waiting, signalling):
+    """raw hipStream_t handles (ints): work issued later on `waiting` starts after what `signalling` holds now"""
+    check(require_device().mmdgan_stream_wait(waiting, signalling), 'stream_wait')
+
+
+def event_record(slot, stream):
+    check(require_device().mmdgan_event_record(int(slot), stream), 'event_record')
+
+
+def event_wait(slot, stream):
+    check(require_device().mmdgan_event_wait(int(slot), stream), 'event_wait')
+
+
+def memset_zero(t, stream=None):
+    check(require_device().mmdgan_memset_zero(t.data_ptr(), t.numel() * t.element_size(), _stream() if stream is None else stream),
+          'memset_zero')
+
+
+def copy(dst, src, stream=None):
+    assert dst.numel() * dst.element_size() == src.numel() * src.element_size() and dst.is_contiguous() and src.is_contiguous()
+    check(require_device().mmdgan_copy(dst.data_ptr(), src.data_ptr(), dst.numel() * dst.element_size(),
+                                       _stream() if stream is None else stream), 'copy')
+
+
 def _p(t):
     if t is None:
         return None

@@ -596,7 +596,8 @@ class TapeEngine:
         return t
 
     # ---- spectral norm (math_func.py:661-672), as engine.py:_sn_step -------------------------------------------
-    def _sn_step(self, net, k):
+    def _sn_step(self, net, k, update=True):
+        """update=False: sigma / scale from the stored vector only (inference: no UPDATE_OPS)"""
         st = net.sn[k.scope]
         w, x = net.p(k.w_name), net.state[k.scope + '/SN/in_rand']
         sigma, scale, dsig, u, un, xb, xbn = st['sigma'], st['scale'], st['dsigma'], st['u'], st['un'], st['xb'], st['xbn']
@@ -608,29 +609,33 @@ class TapeEngine:
             elif k.use_u:
                 ops.gemm(x, w, out=u)
                 ops.sn_norm_scale(u.view(-1), k.act_k, sigma, scale, un.view(-1))
-                ops.gemm(x, un, trans_a=True, out=dsig)
-                ops.gemm(un, w, trans_b=True, out=xb)
-                ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
+                if update:
+                    ops.gemm(x, un, trans_a=True, out=dsig)
+                    ops.gemm(un, w, trans_b=True, out=xb)
+                    ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
             else:
                 ops.gemm(x, w, trans_b=True, out=u)
                 ops.sn_norm_scale(u.view(-1), k.act_k, sigma, scale, un.view(-1))
-                ops.gemm(un, x, trans_a=True, out=dsig)
-                ops.gemm(un, w, out=xb)
-                ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
+                if update:
+                    ops.gemm(un, x, trans_a=True, out=dsig)
+                    ops.gemm(un, w, out=xb)
+                    ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
         else:
             h, wd = k.in_ref[1], k.in_ref[2]
             if k.use_u:
                 ops.conv2d_fwd(x, w, k.stride, out=u)
                 ops.sn_norm_scale(u.view(-1), k.act_k, sigma, scale, un.view(-1))
-                ops.conv2d_wgrad(x, un, k.R, k.stride, out=dsig)
-                ops.conv2d_dgrad(un, w, (h, wd), k.stride, out=xb)
-                ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
+                if update:
+                    ops.conv2d_wgrad(x, un, k.R, k.stride, out=dsig)
+                    ops.conv2d_dgrad(un, w, (h, wd), k.stride, out=xb)
+                    ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
             else:
                 ops.conv2d_dgrad(x, w, (h, wd), k.stride, out=u)
                 ops.sn_norm_scale(u.view(-1), k.act_k, sigma, scale, un.view(-1))
-                ops.conv2d_wgrad(un, x, k.R, k.stride, out=dsig)
-                ops.conv2d_fwd(un, w, k.stride, out=xb)
-                ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
+                if update:
+                    ops.conv2d_wgrad(un, x, k.R, k.stride, out=dsig)
+                    ops.conv2d_fwd(un, w, k.stride, out=xb)
+                    ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
         return scale
 
     # ---- forward ----------------------------------------------------------------------------------------------
@@ -898,6 +903,15 @@ class TapeEngine:
     def generate(self, z, is_training=False):
         vals = self._forward(self.gen, z, is_training, 'gen%d' % z.shape[0])
         return vals[self.gen.out_val]
+
+    def discriminate(self, x_nhwc):
+        """D(x) in INFERENCE mode (my_sngan.py:558-560, `self.Dis(..., is_training=False)`): spectral norms from the stored
+        power-iteration vectors without updating them, batch norm from its moving statistics; [n, d] scores"""
+        for k in self.dis.kernels:
+            if k.sn:
+                self._sn_step(self.dis, k, update=False)
+        vals = self._forward(self.dis, x_nhwc.contiguous(), False, 'score%d' % x_nhwc.shape[0])
+        return vals[self.dis.out_val].clone()
 
     def _allreduce(self, net):
         """SUM all-reduce of one network's gradient arena as blocking collectives on the power-iteration stream (idle

@@ -45,3 +45,30 @@ def test_argument_errors_do_not_need_a_device():
     assert lib.mmdgan_mmd_loss(1, 1, 8, 16, 0, 0.5, -1.0, 0.25, 4.0, 1, None, None, None, 1, None) == -1
     assert b'w[0]-w[1] must be 1' in lib.mmdgan_last_error()       # math_func.py:1340
     assert lib.mmdgan_mmd_loss(1, 1, 8, 16, 7, 0.0, -1.0, 0.25, 4.0, 1, None, None, None, 1, None) == -1
+
+
+def test_handles_and_plan_bookkeeping_without_a_device():
+    """handles own what used to be process-global state; a plan's segment bookkeeping is host logic"""
+    import ctypes
+    lib = _lib.load()
+    h1, h2 = ctypes.c_void_p(), ctypes.c_void_p()
+    assert lib.mmdgan_create(ctypes.byref(h1)) == 0 and lib.mmdgan_create(ctypes.byref(h2)) == 0 and h1.value != h2.value
+    assert lib.mmdgan_make_current(h1) == 0
+    assert lib.mmdgan_plan_end(ctypes.byref(ctypes.c_int())) == -1 and b'not recording' in lib.mmdgan_last_error()
+    assert lib.mmdgan_plan_begin() == 0
+    assert lib.mmdgan_plan_begin() == -1 and b'already recording' in lib.mmdgan_last_error()
+    assert lib.mmdgan_set_outputs_prezeroed(1) == 0          # a mode switch inside a recording is a node
+    assert lib.mmdgan_plan_mark() == 1
+    assert lib.mmdgan_set_outputs_prezeroed(0) == 0
+    pid = ctypes.c_int(-1)
+    assert lib.mmdgan_plan_end(ctypes.byref(pid)) == 0 and pid.value == 0
+    assert lib.mmdgan_plan_segments(0) == 2 and lib.mmdgan_plan_nodes(0) == 2
+    # the other handle knows nothing of it
+    assert lib.mmdgan_make_current(h2) == 0
+    assert lib.mmdgan_plan_segments(0) < 0
+    assert lib.mmdgan_plan_replay(0, -1) == -1 and b'no plan 0' in lib.mmdgan_last_error()
+    assert lib.mmdgan_make_current(h1) == 0
+    assert lib.mmdgan_plan_replay(0, 2) == -1 and b'has 2 segments' in lib.mmdgan_last_error()
+    assert lib.mmdgan_plan_destroy(0) == 0 and lib.mmdgan_plan_segments(0) < 0
+    assert lib.mmdgan_make_current(None) == 0
+    assert lib.mmdgan_destroy(h1) == 0 and lib.mmdgan_destroy(h2) == 0 and lib.mmdgan_destroy(None) == 0

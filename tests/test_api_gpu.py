@@ -122,8 +122,60 @@ def test_eval_sampling_writes_the_reference_sprite_from_inference_mode_images(tm
         assert rel_err(x, ref.clamp(-1, 1).numpy()) <= RTOL
         path = '{}cifar_log/ev/cifar_g_ev_7_0.png'.format(FLAGS.DEFAULT_OUT)
         assert np.array_equal(np.asarray(Image.open(path)), sprite_array(x.transpose(0, 2, 3, 1), (3, 4)))
+        # real_sample (+ the reference's default get_dis_score=True, my_sngan.py:501, 538-541, 558-560): a data batch, its
+        # '_r_' sprite, and D's scores of [data ; generated] in INFERENCE mode - sigma from the stored power-iteration
+        # vectors, which stay untouched
+        before = {k: v.copy() for k, v in var.items() if k.endswith('in_rand')}
+        import inspect
+        assert inspect.signature(mdl.eval_sampling).parameters['get_dis_score'].default is True
+        x2 = mdl.eval_sampling('cifar', 'ev2', mesh_num=(3, 4), code_x=code, real_sample=True)
+        out = mdl.eval_outputs
+        assert np.array_equal(x2, x) and out['x_real'].shape == (12, 3, 32, 32) and np.abs(out['x_real']).max() <= 1.0
+        path_r = '{}cifar_log/ev2/cifar_r_ev2_7_0.png'.format(FLAGS.DEFAULT_OUT)
+        assert np.array_equal(np.asarray(Image.open(path_r)), sprite_array(out['x_real'].transpose(0, 2, 3, 1), (3, 4)))
+        dspecs = R.build_net(arch['discriminator'], [3, 32, 32], 'dis')
+        dparams = {k: torch.tensor(v, dtype=torch.float64) for k, v in var.items() if k.startswith('dis/')}
+        both = np.concatenate([out['x_real'], x], 0)
+        sref, upd = R.net_forward(dspecs, dparams, torch.tensor(both, dtype=torch.float64), False)
+        assert rel_err(np.concatenate([out['s_x'], out['s_gen']], 0), sref.numpy()) <= RTOL
+        after = mdl.engine.get_variables()
+        for k, v in before.items():
+            assert np.array_equal(after[k], v), k
+        x3 = mdl.eval_sampling('cifar', 'ev3', mesh_num=(3, 4), code_x=code, real_sample=True, get_dis_score=False,
+                               do_sprite=False)
+        assert mdl.eval_outputs['s_x'] is None and np.array_equal(x3, x)
         with pytest.raises(NotImplementedError):
-            mdl.eval_sampling('cifar', 'ev', mesh_num=(3, 4), code_x=code, real_sample=True)
+            mdl.eval_sampling('cifar', 'ev', mesh_num=(3, 4), code_x=code, do_embedding=True)
+    finally:
+        FLAGS.SYNTHETIC_DATA, FLAGS.SILENT_MODE = False, False
+
+
+def test_do_trace_writes_the_kernel_timeline(tmp_path):
+    """Agent(do_trace=True) (graph_func.py:996-1025, 1139-1141): the last five steps are traced and their timeline is
+    written to <summary_folder>/timeline.json as a Chrome trace - here the HIP kernels of those steps"""
+    import json
+    from GeneralTools.misc_fun import FLAGS
+    from GeneralTools.graph_func import Agent
+    from DeepLearning.my_sngan import SNGan
+    sys_path_hack = None  # noqa: F841
+    FLAGS.DEFAULT_OUT = str(tmp_path) + '/'
+    FLAGS.SYNTHETIC_DATA, FLAGS.SILENT_MODE = True, True
+    try:
+        import sys, os
+        sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
+        from tiny_arch import tiny_architecture
+        mdl = SNGan(tiny_architecture(), num_class=0, loss_type='rep', optimizer='adam')
+        agent = Agent('toy', 'tr', load_ckpt=False, do_trace=True, do_save=False, query_step=None)
+        mdl.training('toy', agent, 8 * 2, (5e-4, 2e-4), max_step=7, batch_size=8)
+        assert agent.trace_file == '{}toy_log/tr/timeline.json'.format(FLAGS.DEFAULT_OUT)
+        with open(agent.trace_file) as f:
+            events = json.load(f)['traceEvents']
+        kernels = [e for e in events if e.get('cat') == 'kernel']
+        names = {e['name'] for e in kernels}
+        assert any('mmd_kernel' in n for n in names) and any('adam' in n for n in names), sorted(names)[:20]
+        n_loss = sum(1 for e in kernels if 'mmd_kernel' in e['name'])
+        assert n_loss == 5, n_loss                                     # one loss launch per traced step, five steps
+        assert all(e.get('dur', 0) >= 0 and 'ts' in e for e in kernels)
     finally:
         FLAGS.SYNTHETIC_DATA, FLAGS.SILENT_MODE = False, False
 

@@ -442,6 +442,131 @@ print('RESULT ' + json.dumps({'worst': worst, 'loss_dp': out['dp'][1][:2].tolist
 """
 
 
+_DP2_CHILD = r"""
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path[:0] = [os.path.join(ROOT, 'mmd-gan_amd'), os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'oracle'), ROOT]
+from mmdgan_hip.engine import GanEngine
+from mmdgan_hip import dist as mdist
+from test_step_gpu import mid_architecture
+torch.cuda.set_device(0)
+rank = int(os.environ['RANK'])
+mdist.init_process_group(0, backend='gloo')                      # two replicas on ONE GPU: gloo carries CUDA tensors
+arch, B, lr, mode = mid_architecture(), 16, (5e-4, 2e-4), os.environ['DP2_MODE']
+os.environ['MMDGAN_DP_BUCKET_MB'] = '0.25'                        # several buckets per net on this small model
+
+
+def batch(r, k):
+    rs = np.random.RandomState(100 + 10 * r + k)
+    z = torch.as_tensor(rs.randn(B, 64).astype(np.float32)).cuda()
+    real = torch.as_tensor(rs.uniform(-1, 1, (B, 32, 32, 3)).astype(np.float32)).cuda()
+    return real, z
+
+
+eng = GanEngine(arch, 'rep', lr, batch_size=B, seed=3 + rank, dist_group=dist.group.WORLD, launch_mode=mode)
+mdist.broadcast_state(eng, dist.group.WORLD)                     # rank 0's variables everywhere
+n_buckets = [len(eng._grad_buckets[id(n)]) for n in (eng.gen, eng.dis)]
+eng.step(*batch(rank, 0))        # the first step's gradients are rounding noise (un-normalised SN vectors, SURVEY A.5 #1)
+torch.cuda.synchronize()
+mid = eng.get_variables()
+before = {id(n): (n.params.clone(), n.adam_m.clone(), n.adam_v.clone()) for n in (eng.gen, eng.dis)}
+eng.step(*batch(rank, 1))        # the step under test
+torch.cuda.synchronize()
+out = {'rank': rank, 'buckets': n_buckets}
+if rank == 0:
+    # what one replica computes alone on either batch, from the same variables (engines without a process group)
+    local = []
+    for r in (0, 1):
+        e = GanEngine(arch, 'rep', lr, batch_size=B, seed=3)
+        e.set_variables(mid)
+        e.step(*batch(r, 1))
+        local.append(e.get_variables(grad=True))
+    summed = eng.get_variables(grad=True)                        # the arenas hold the all-reduced SUM
+    worst_g = {'gen': 0.0, 'dis': 0.0}
+    for n, g in summed.items():
+        ref = local[0][n].astype(np.float64) + local[1][n]
+        if np.abs(ref).max() <= 1e-5 * max(np.abs(v).max() for k, v in local[0].items() if k[:3] == n[:3]):
+            continue                                             # analytically zero gradients (the last bias)
+        worst_g[n[:3]] = max(worst_g[n[:3]], float(np.linalg.norm(g - ref) / np.linalg.norm(ref)))
+    # TF-Adam's second step on the MEAN gradient (graph_func.py:518-527), on the flat arenas
+    worst_u = 0.0
+    for net, lr_n in ((eng.dis, lr[0]), (eng.gen, lr[1])):
+        p1, m1, v1 = (t.double() for t in before[id(net)])
+        g = net.grads.double() / 2.0
+        m2, v2 = 0.5 * m1 + 0.5 * g, 0.999 * v1 + 0.001 * g * g
+        lr_t = lr_n * np.sqrt(1 - 0.999 ** 2) / (1 - 0.5 ** 2)
+        upd = lr_t * m2 / (v2.sqrt() + 1e-8)
+        got = p1 - net.params.double()
+        worst_u = max(worst_u, float((got - upd).norm() / upd.norm()))
+    out.update(worst_grad_dis=worst_g['dis'], worst_grad_gen=worst_g['gen'], worst_update=worst_u)
+# both replicas hold the same trainable variables and spectral-norm vectors after the step, and again after two more
+for k in range(2, 4):
+    eng.step(*batch(rank, k))
+torch.cuda.synchronize()
+spread, spread_sn = 0.0, 0.0
+for n, v in eng.get_variables().items():
+    if '/moving_' in n:
+        continue                                                 # BN statistics stay per replica (SURVEY 8(e))
+    t = torch.as_tensor(v).cuda()
+    hi, lo = t.clone(), t.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    d = float((hi - lo).abs().max())
+    if n.endswith('in_rand'):      # each replica's own power iteration on identical weights: equal up to the order of its atomics
+        spread_sn = max(spread_sn, d / float(t.abs().max()))
+    else:
+        spread = max(spread, d)
+out['spread'], out['spread_sn'] = spread, spread_sn
+out['plan_segments'] = len(eng._plan_collectives) + 1 if mode == 'plan' else 0
+dist.barrier()
+dist.destroy_process_group()
+print('RESULT ' + json.dumps(out), flush=True)
+"""
+
+
+@pytest.mark.parametrize('mode', ['eager', 'plan'])
+def test_data_parallel_step_equals_the_mean_gradient_step(mode):
+    """the ENGINE with world size 2 (two replicas on this one GPU, gloo carrying the CUDA tensors): after a step on two
+    different batches the gradient arenas hold the sum of what each replica computes alone, the variables moved by
+    TF-Adam's step on the MEAN gradient, and both replicas stay identical over further steps.  Buckets are exchanged
+    layer group by layer group during the backward pass; 'plan': the recorded step, cut into segments at the collectives."""
+    import json
+    import socket
+    import subprocess
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in (0, 1):
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2',
+                   LOCAL_RANK='0', DP2_MODE=mode)
+        procs.append(subprocess.Popen([sys.executable, '-c', 'ROOT = %r\n' % root + _DP2_CHILD], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = {}
+    for p in procs:
+        try:
+            so, se = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, se[-3000:]
+        line = [ln for ln in so.splitlines() if ln.startswith('RESULT ')][-1]
+        r = json.loads(line[7:])
+        res[r['rank']] = r
+    assert min(res[0]['buckets']) >= 2, res[0]                     # really exchanged in several buckets
+    assert res[0]['worst_grad_dis'] <= 1e-4, res[0]                # sum of the two local gradients (measured 1e-6)
+    # G's gradients pass its relu-after-BN masks, which the atomics' order flips between any two runs of the same
+    # step (tools/determinism_probe.py): 2e-3 measured, the run-to-run noise of one engine
+    assert res[0]['worst_grad_gen'] <= 1e-2, res[0]
+    assert res[0]['worst_update'] <= 1e-5, res[0]                  # Adam on their mean
+    assert res[0]['spread'] == 0.0 and res[1]['spread'] == 0.0, res   # trainable variables bit-identical after three steps
+    assert res[0]['spread_sn'] <= 1e-5, res
+    if mode == 'plan':
+        assert res[0]['plan_segments'] == sum(res[0]['buckets']) + 1, res[0]
+
+
 @pytest.mark.parametrize('engine', ['dcgan', 'tape'])
 def test_data_parallel_exchange_runs_over_rccl(engine):
     """the gradient exchange of the multi-GPU path (bucketed all-reduce on the engine's exchange stream between the D and G
