@@ -36,9 +36,12 @@ def parse():
     ap.add_argument('--config', default='cifar', choices=['cifar', 'stl', 'celeba', 'lsun_resnet'])
     ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: 64; 128 for celeba; 32 for lsun_resnet = 256 on 8 GPUs)')
     ap.add_argument('--loss', default='rep', choices=['rep', 'rmb'])
-    ap.add_argument('--no-graph', action='store_true', help='issue launches eagerly instead of one hipGraph')
-    ap.add_argument('--graph', action='store_true', help='always replay the captured hipGraph (default: try both during '
-                    'warm-up and keep the faster one - eager issue wins when the host keeps up, the graph when it does not)')
+    ap.add_argument('--launch-mode', default='auto', choices=['auto', 'eager', 'graph', 'plan'],
+                    help="how a step reaches the GPU (mmdgan_hip/engine.py): 'eager' ~200 library calls from Python, 'graph' "
+                         "one captured hipGraph, 'plan' the library's recorded launch plan replayed from one C call; "
+                         "'auto' (default) times a few untimed steps of each during warm-up and keeps the fastest")
+    ap.add_argument('--no-graph', action='store_true', help="same as --launch-mode eager")
+    ap.add_argument('--graph', action='store_true', help="same as --launch-mode graph")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--probe-only', action='store_true',
@@ -132,7 +135,7 @@ def main():
         args.no_graph = True
     # the engine starts in eager mode (its lazily-created buffers are then allocated on the stream that uses
     # them); the hipGraph, if wanted, is captured after the warm-up steps
-    eng = GanEngine(arch, args.loss, lr, batch_size=B, seed=0, dist_group=group, use_graph=False)
+    eng = GanEngine(arch, args.loss, lr, batch_size=B, seed=0, dist_group=group)
     if group is not None:
         from mmdgan_hip import dist as mdist
         mdist.broadcast_state(eng, group)                # identical weights / SN vectors on every replica
@@ -149,7 +152,7 @@ def main():
         torch.cuda.synchronize()
 
     if args.probe_only:
-        eng.use_graph = False
+        eng.launch_mode = 'eager'
         eng.step(real)                                   # fills the activations / gradients the probe reads
         torch.cuda.synchronize()
         probe = dominant_kernel_probe(eng, reps=args.probe_reps, warm=0)
@@ -158,17 +161,16 @@ def main():
     for _ in range(args.warmup):
         eng.step(real)
     barrier()
-    mode = 'eager' if (args.no_graph or group is not None) else 'graph'
-    eng.use_graph = mode == 'graph'
-    if mode == 'graph' and args.graph:                   # forced replay: capture outside the timed region
-        for _ in range(3):
-            eng.step(real)
-        barrier()
-    if group is None and not args.no_graph and not args.graph:
-        # untimed: a few steps each way, keep the faster launch mode
-        trial = {}
-        for m in ('eager', 'graph'):
-            eng.use_graph = m == 'graph'
+    want = 'eager' if args.no_graph else 'graph' if args.graph else args.launch_mode
+    if tape:
+        want = 'eager'                                   # the primitive-op engine issues eagerly
+    elif group is not None and want in ('auto', 'graph'):
+        want = 'eager'                                   # collectives between the launches: no hipGraph; plan on request
+    trial = {}
+    if want == 'auto':
+        # untimed: a few steps each way, keep the fastest launch mode
+        for m in ('eager', 'graph', 'plan'):
+            eng.launch_mode = m
             for _ in range(5):
                 eng.step(real)
             torch.cuda.synchronize()
@@ -177,11 +179,15 @@ def main():
                 eng.step(real)
             torch.cuda.synchronize()
             trial[m] = (time.perf_counter() - t0) / 25
-        mode = min(trial, key=trial.get)
+        want = min(trial, key=trial.get)
         if os.environ.get('BENCH_VERBOSE'):
             print('launch-mode trial (ms/step):', {k: round(v * 1e3, 3) for k, v in trial.items()}, file=sys.stderr)
-        eng.use_graph = mode == 'graph'
-        barrier()
+    mode = want
+    if not tape:
+        eng.launch_mode = mode
+        for _ in range(3):                               # capture / record outside the timed region
+            eng.step(real)
+    barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
@@ -213,7 +219,8 @@ def main():
             'config': {'workload': '%s %dx%d %s, batch %d per GPU, %s loss, lr %g/%g, TF-Adam, one G+D step'
                                    % (args.config, h, w, ('ResNet-SN' if has_residual_blocks(arch) else 'DCGAN-SN (primitive-op engine)') if tape else 'DCGAN-SN',
                                       B, args.loss, lr[0], lr[1]),
-                       'global_batch': B * world, 'parallelism': 'dp%d' % world, 'launch_mode': mode},
+                       'global_batch': B * world, 'parallelism': 'dp%d' % world, 'launch_mode': mode,
+                       'launch_mode_trial_ms': {k: round(v * 1e3, 4) for k, v in trial.items()} or None},
             'loss_gen': float(losses[0]), 'loss_dis': float(losses[1]),
         }
         whole = {'achieved': achieved, 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,

@@ -1,14 +1,18 @@
-"""eager vs hipGraph replay in one process: CPU issue time and total time per step"""
+"""eager issue vs hipGraph replay vs launch-plan replay in one process: CPU issue time and total time per step
+    python tools/issue_time.py [config] [batch]"""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, 'mmd-gan_amd'), ROOT]
 import configs
 from mmdgan_hip.engine import GanEngine
-arch, lr = configs.CONFIGS['cifar']()
-eng = GanEngine(arch, 'rep', lr, batch_size=64, seed=0, use_graph=False)
-real = torch.empty(64, 32, 32, 3, device='cuda').uniform_(-1, 1)
-def run(tag, graph, N=50):
-    eng.use_graph = graph
+config = sys.argv[1] if len(sys.argv) > 1 else 'cifar'
+B = int(sys.argv[2]) if len(sys.argv) > 2 else {'celeba': 128}.get(config, 64)
+arch, lr = configs.CONFIGS[config]()
+eng = GanEngine(arch, 'rep', lr, batch_size=B, seed=0)
+c, h, w = arch['input'][0]
+real = torch.empty(B, h, w, c, device='cuda').uniform_(-1, 1)
+def run(tag, mode, N=50):
+    eng.launch_mode = mode
     for _ in range(5): eng.step(real)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -17,5 +21,9 @@ def run(tag, graph, N=50):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print('%-14s CPU issue %.3f ms/step, total %.3f ms/step' % (tag, (t1 - t0) / N * 1e3, (t2 - t0) / N * 1e3))
-for tag, g in (('eager', False), ('graph', True), ('eager again', False), ('graph again', True), ('eager 3', False)):
-    run(tag, g)
+for tag, m in (('eager', 'eager'), ('graph', 'graph'), ('plan', 'plan'), ('eager again', 'eager'), ('graph again', 'graph'), ('plan again', 'plan')):
+    run(tag, m)
+with eng._handle:
+    from mmdgan_hip import ops
+    lib = ops.require_device()
+    print('plan: %d recorded nodes (launches, memsets, stream dependencies), %d segment(s)' % (lib.mmdgan_plan_nodes(eng._plan), lib.mmdgan_plan_segments(eng._plan)))
