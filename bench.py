@@ -89,6 +89,19 @@ def dominant_kernel_probe(eng, reps=20, warm=3):
             'flops': flops, 'ms': ms, 'tflops': flops / ms / 1e9}
 
 
+def committed_profile(key, per_config=True):
+    """the newest profiles/rNN_dominant_kernel_<config>.json (or rNN_<key>.json): {} if this config was never profiled"""
+    import glob
+    pat = 'r[0-9][0-9]_dominant_kernel_%s.json' % key if per_config else 'r[0-9][0-9]_%s.json' % key
+    hits = sorted(glob.glob(os.path.join(ROOT, 'profiles', pat)))
+    if not hits:
+        return {}
+    with open(hits[-1]) as f:
+        d = json.load(f)
+    d['_file'] = 'profiles/' + os.path.basename(hits[-1])
+    return d
+
+
 def cpu_baseline(arch, lr, loss, B, steps):
     """the oracle restatement (fp32 torch-CPU) of the same step on the host cores: a reported
     baseline, not the optimisation target."""
@@ -227,20 +240,32 @@ def main():
                  'scope': 'whole step: B*(3*F_G+7*F_D) = %.1f GFLOP algorithmic over the HIP-event step time %.3f ms'
                           % (flops_step / 1e9, ev_ms)}
         probe = None if tape else dominant_kernel_probe(eng, reps=args.probe_reps)
+        committed = committed_profile(args.config)
         if probe:
-            # the roofline object is about the dominant kernel (HIP-event time of its launches, algorithmic FLOPs);
-            # the whole-step figure - the more conservative one - rides along
-            traffic, source = None, None
-            pmc = os.path.join(ROOT, 'profiles', 'r01_dominant_kernel_pmc.json')
-            if os.path.exists(pmc):                      # HBM bytes per launch from the committed rocprofv3 --pmc passes
-                with open(pmc) as f:
-                    traffic, source = json.load(f).get('hbm_bytes_per_launch'), 'profiles/r01_dominant_kernel_pmc.json'
+            # the roofline object is about the dominant kernel: algorithmic FLOPs of one launch over its HIP-event time,
+            # measured live here.  Beside it, from the committed rocprofv3 evidence of THIS config (profiles/, written by
+            # tools/collect_profiles.sh + tools/make_profiles.py): the same launch's average duration in the kernel trace
+            # and the fraction that follows from it (the tracer costs this kernel ~1 %, an un-traced HIP-event run is the
+            # `frac` above), and its HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes.  No committed profile for
+            # a config -> traffic null, never another config's number.
             out['roofline'] = {'bound': 'mfma', 'achieved': probe['tflops'], 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': probe['tflops'] / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_source': source,
+                               'frac': probe['tflops'] / PEAK_FP32_MFMA_TFLOPS,
+                               'traffic': committed.get('hbm_bytes_per_launch'),
+                               'traffic_over_algorithmic': committed.get('traffic_over_algorithmic'),
+                               'algorithmic_bytes_per_launch': (committed.get('algorithmic_bytes_per_launch') or {}).get('total'),
+                               'traffic_source': committed.get('_file'),
                                'kernel': probe['kernel'], 'gflop_per_launch': probe['flops'] / 1e9,
-                               'ms_per_launch': probe['ms'], 'whole_step': whole}
+                               'ms_per_launch': probe['ms'],
+                               'profiled': None if not committed else {
+                                   'avg_us': committed['avg_us_profiled'], 'frac': committed['frac_from_profiled_duration'],
+                                   'launches': committed['probe_launches_isolated'], 'source': committed['_file']},
+                               'whole_step': whole}
         else:
             out['roofline'] = dict(whole, bound='mfma', peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s', traffic=None)
+        busy = committed_profile('whole_step_mfma_busy', per_config=False)
+        if busy and args.config == 'cifar':
+            out['roofline']['whole_step']['mfma_busy_frac'] = busy.get('mfma_busy_frac_whole_step')
+            out['roofline']['whole_step']['mfma_busy_source'] = busy['_file']
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(arch, lr, args.loss, B, 1 if tape else args.cpu_steps)
         print(json.dumps(out))

@@ -85,9 +85,11 @@ __global__ __launch_bounds__(256) void thinm_n2w_kernel(ConvDims d, ConvEpilogue
     }
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(in, M * Cn * 4);
     const float sc = ep.scale ? ep.scale[0] : 1.f;
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    // the patch gather of tile t+1 is in flight while tile t is multiplied and stored: a wave walks several tiles
+    // (launch_n2w sizes the grid for ~4), so the weight prologue and the gather latency are paid once, not per tile
+    auto gather = [&](int tile, float (&bq)[kJP]) {
         const long m = (long)tile * 32 + l31;
-        const bool ok = m < M;
+        const bool ok = tile < ntiles && m < M;
         const int mm = ok ? (int)m : 0;
         const int wq = mm % IW, hq = (mm / IW) % IH;
         unsigned cols = 0, mask = 0;
@@ -101,9 +103,19 @@ __global__ __launch_bounds__(256) void thinm_n2w_kernel(ConvDims d, ConvEpilogue
         }
         if (!ok) mask = 0;
         const unsigned pixbase = (unsigned)(mm * Cn * 4);
+#pragma unroll
+        for (int jp = 0; jp < kJP; ++jp) bq[jp] = bufld1(rs, (mask & tbit[jp]) ? pixbase + (unsigned)delta[jp] : kOOB);
+    };
+    const int tstep = gridDim.x * 4;
+    float bnext[kJP];
+    gather(blockIdx.x * 4 + wave, bnext);
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += tstep) {
+        const long m = (long)tile * 32 + l31;
+        const bool ok = m < M;
         float b[kJP];
 #pragma unroll
-        for (int jp = 0; jp < kJP; ++jp) b[jp] = bufld1(rs, (mask & tbit[jp]) ? pixbase + (unsigned)delta[jp] : kOOB);
+        for (int jp = 0; jp < kJP; ++jp) b[jp] = bnext[jp];
+        gather(tile + tstep, bnext);
         f32x16 acc[WB];
 #pragma unroll
         for (int wb = 0; wb < WB; ++wb)
@@ -113,8 +125,54 @@ __global__ __launch_bounds__(256) void thinm_n2w_kernel(ConvDims d, ConvEpilogue
         for (int jp = 0; jp < kJP; ++jp)
 #pragma unroll
             for (int wb = 0; wb < WB; ++wb) acc[wb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[wb][jp], b[jp], acc[wb], 0, 0, 0);
+        if constexpr (WB <= 2) {
+            // The wide tensor is what this kernel moves (33.5 MB for D l1 at batch 128): its stores decide the time.
+            // A lane holds one PIXEL's channel quads, so direct stores put 16 bytes at a 256-byte stride per lane - every
+            // 128-byte line is written by four different instructions (18 % of the HBM rate, profiles/r01_conv_layers.txt).
+            // Transposed through a wave-private LDS slab [32 pixels][Wd + 4] the same data leaves as whole pixel rows:
+            // lane L stores the float4 of channel quad L % (Wd/4) of pixel L / (Wd/4) - 1 KB contiguous per instruction.
+            constexpr int LDP = Wd + 4;                    // +4 floats: the 16 pixel rows of a b128 phase cover all 64 banks
+            __shared__ __attribute__((aligned(16))) float slab[4][32 * LDP];
+            float *sl = slab[wave];
+#pragma unroll
+            for (int wb = 0; wb < WB; ++wb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4 *>(sl + l31 * LDP + wb * 32 + 8 * g + 4 * kh) =
+                        make_float4(acc[wb][4 * g], acc[wb][4 * g + 1], acc[wb][4 * g + 2], acc[wb][4 * g + 3]);
+            __builtin_amdgcn_wave_barrier();               // same wave, in-order LDS queue: a scheduling fence is enough
+            asm volatile("" ::: "memory");
+            constexpr int QP = Wd / 4, PPI = 64 / QP;      // lanes per pixel row, pixels per store instruction
+            const int cq = lane % QP, pp = lane / QP, ch = 4 * cq;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ep.bias) bv = *reinterpret_cast<const float4 *>(ep.bias + ch);
+            const long m0 = (long)tile * 32;
+#pragma unroll
+            for (int it = 0; it < 32 / PPI; ++it) {
+                const int px = it * PPI + pp;
+                const long mo = m0 + px;
+                float4 v = *reinterpret_cast<const float4 *>(sl + px * LDP + ch);
+                if (mo < M) {
+                    const long o = mo * Wd + ch;
+                    v.x = v.x * sc + bv.x; v.y = v.y * sc + bv.y; v.z = v.z * sc + bv.z; v.w = v.w * sc + bv.w;
+                    if (ep.dact) {
+                        const float4 y = *reinterpret_cast<const float4 *>(ep.dact + ep.dact_index(o));
+                        v.x *= act_bwd_from_out(y.x, ep.act); v.y *= act_bwd_from_out(y.y, ep.act);
+                        v.z *= act_bwd_from_out(y.z, ep.act); v.w *= act_bwd_from_out(y.w, ep.act);
+                    } else {
+                        v.x = act_fwd(v.x, ep.act); v.y = act_fwd(v.y, ep.act);
+                        v.z = act_fwd(v.z, ep.act); v.w = act_fwd(v.w, ep.act);
+                    }
+                    *reinterpret_cast<float4 *>(out + o) = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+            continue;
+        }
         if (!ok) continue;
-        // lane = one pixel; registers 4g..4g+3 are 4 consecutive channels -> float4 stores
+        // (128 wide channels: the slab would not fit the default LDS cap) lane = one pixel; registers 4g..4g+3 are 4
+        // consecutive channels -> float4 stores
 #pragma unroll
         for (int wb = 0; wb < WB; ++wb)
 #pragma unroll
@@ -303,7 +361,9 @@ static void launch_n2w(const ConvDims &d, const ConvEpilogue &ep, const float *i
     const long M = (long)d.N * d.H * d.W;
     const int ntiles = (int)((M + 31) / 32);
     int blocks = (ntiles + 3) / 4;
-    if (blocks > 1024) blocks = 1024;
+    static int cap = -1;                 // MMDGAN_N2W_BLOCKS: tuning aid
+    if (cap < 0) { const char *e = getenv("MMDGAN_N2W_BLOCKS"); cap = e ? atoi(e) : 512; }
+    if (blocks > cap) blocks = cap;
     const PatchTab tab = make_patch_tab<FLIP>(d, FLIP ? d.K : d.C);
     if (wide == 32) hipLaunchKernelGGL((thinm_n2w_kernel<FLIP, 1>), dim3(blocks), dim3(256), 0, st, d, ep, in, w, out, ntiles, tab);
     else if (wide == 64) hipLaunchKernelGGL((thinm_n2w_kernel<FLIP, 2>), dim3(blocks), dim3(256), 0, st, d, ep, in, w, out, ntiles, tab);

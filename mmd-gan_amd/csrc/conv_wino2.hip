@@ -41,6 +41,8 @@ struct Params {
     int OH, OW, Ko;         // output image, channels
     int otile, ostep;       // output row = ty * otile + a * ostep + o0r[phase]
     int o0r[4], o0c[4];
+    int ntb, nkb, nph;      // workgroups = tile blocks x column blocks x phases, launched as a 1-D grid
+    int xcd_remap;          // 1: workgroup -> (tile block, phase, column block) through the XCD-aware map below
 };
 }  // namespace wino2
 
@@ -106,7 +108,21 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
     // wave-dependent scalar offset became a waterfall loop and every `m < nm` an exec-mask branch (2x slower)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long T = (long)P.N * P.TH * P.TW;
-    const int t0 = blockIdx.x * 32, n0 = blockIdx.y * 64, phase = blockIdx.z;
+    // XCD-aware placement: the 4 parity phases (and the column blocks) of one tile block read the SAME 3x3 input patches.
+    // Launched phase-major they run hundreds of microseconds apart on all 8 XCDs and every phase fetches its patches
+    // from HBM again (FETCH_SIZE 2.4x the algorithmic reads, profiles/r01_dominant_kernel_pmc.json).  The dispatcher
+    // deals workgroup b to XCD b % 8 (observed, a speed assumption only): give each XCD a contiguous range of tile
+    // blocks and walk (phase, column block) innermost, so the re-reads of a patch hit that XCD's 4 MB L2.
+    int wg = blockIdx.x;
+    if (P.xcd_remap) {
+        const int nwg = gridDim.x, xcd = wg & 7, q = nwg >> 3, r = nwg & 7;      // bijective for any nwg
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+    }
+    const int per_tb = P.nkb * P.nph;
+    const int tblk = wg / per_tb, rem = wg - tblk * per_tb;
+    const int phase = P.xcd_remap ? rem / P.nkb : wg / (P.ntb * P.nkb);
+    const int t0 = (P.xcd_remap ? tblk : wg % P.ntb) * 32;
+    const int n0 = (P.xcd_remap ? rem % P.nkb : (wg / P.ntb) % P.nkb) * 64;
     const int spc = P.Cr / BC;                           // stages per segment
     const int nstages = P.nseg * spc;
     // ---- producer: thread = (tile pt, channel quad cq)
@@ -146,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
     // ---- consumer: wave owns column block cb and frequencies fq + 2m
     // 18 accumulators over 4 waves = 5,5,4,4: odd workgroups rotate the roles so that, with two workgroups per CU,
     // every SIMD carries 9 of them
-    const int wrole = (wave + ((blockIdx.x & 1) << 1)) & 3;
+    const int wrole = (wave + ((wg & 1) << 1)) & 3;
     const int cb = wrole & 1, fq = wrole >> 1;
     const unsigned ubase = (unsigned)(((long)kh * P.Ko + n0 + cb * 32 + l31) * 4);
     const unsigned ufreq = (unsigned)((long)P.Cr * P.Ko * 4), ukp = (unsigned)(2 * P.Ko * 4), ustage = (unsigned)(BC * P.Ko * 4);
@@ -375,7 +391,11 @@ static int wino2_launch(const ConvDims &d, const ConvEpilogue &ep, const float *
         P.OH = d.H; P.OW = d.W; P.Ko = d.C; P.otile = 4; P.ostep = 2;
     }
     const long T = (long)d.N * P.TH * P.TW;
-    const dim3 grid((unsigned)((T + 31) / 32), P.Ko / 64, dgrad ? 4 : 1);
+    P.ntb = (int)((T + 31) / 32); P.nkb = P.Ko / 64; P.nph = dgrad ? 4 : 1;
+    static int remap = -1;
+    if (remap < 0) { const char *e = getenv("MMDGAN_XCD_REMAP"); remap = (e && e[0] == '0') ? 0 : 1; }
+    P.xcd_remap = remap;
+    const dim3 grid((unsigned)((long)P.ntb * P.nkb * P.nph), 1, 1);
     static bool cap_raised = false;                     // 76 KB of dynamic LDS: above the 64 KB default cap
     if (!cap_raised) {
         (void)hipFuncSetAttribute((const void *)wino2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino2::LDS_BYTES);
