@@ -48,6 +48,7 @@ def parse():
                     help='one step, then only the dominant-kernel probe (for rocprofv3: its kernel stats row is then '
                          'exactly the launches that roofline.dominant_kernel times)')
     ap.add_argument('--probe-reps', type=int, default=20)
+    ap.add_argument('--probe-warm', type=int, default=400, help='untimed launches before the timed ones of --probe-only')
     ap.add_argument('--engine', default='auto', choices=['auto', 'tape'],
                     help="'tape': run a DCGAN config on the primitive-op engine too (it is what residual-block configs use)")
     return ap.parse_args()
@@ -168,8 +169,10 @@ def main():
         eng.launch_mode = 'eager'
         eng.step(real)                                   # fills the activations / gradients the probe reads
         torch.cuda.synchronize()
-        probe = dominant_kernel_probe(eng, reps=args.probe_reps, warm=0)
-        print(json.dumps({'dominant_kernel': probe, 'reps': args.probe_reps}))
+        # 400 untimed launches first (~40 ms): the shader clock and the power state need that long to settle - measured
+        # 107-110 us per launch right after start-up against 97-98 us for the same launch at the end of a bench run
+        probe = dominant_kernel_probe(eng, reps=args.probe_reps, warm=args.probe_warm)
+        print(json.dumps({'dominant_kernel': probe, 'reps': args.probe_reps, 'warm': args.probe_warm}))
         return
     for _ in range(args.warmup):
         eng.step(real)

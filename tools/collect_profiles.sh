@@ -8,12 +8,14 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py"
+if [ "${2:-all}" != "probes" ]; then
 # 1. the default bench command (launch mode chosen during warm-up; 4 streams): kernel trace + stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/default -o g -- $B --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_default_profiled.json 2> $OUT/bench_default.err
 # 2. the same step issued eagerly on ONE compute stream + one SN stream (per-kernel durations without overlap inflation)
 MMDGAN_SIDE_WGRAD=0 MMDGAN_SN_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/single -o e -- $B --steps 20 --warmup 5 --launch-mode eager --no-cpu-baseline > $OUT/bench_single_profiled.json 2> $OUT/bench_single.err
 # 3. one steady-state step as a timeline (plan replay, 4 streams)
 rocprofv3 --kernel-trace --output-format csv -d $OUT/timeline -o t -- $B --steps 10 --warmup 5 --launch-mode plan --no-cpu-baseline > /dev/null 2> $OUT/timeline.err
+fi
 # 4. the dominant kernel alone, per config: kernel trace (the probe launches are isolated by grid size in make_profiles.py)
 #    and the PMC passes (own runs, kernel-trace only): HBM read / write bytes, MFMA busy
 for c in cifar stl celeba; do
@@ -24,6 +26,7 @@ for c in cifar stl celeba; do
 done
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq_cifar -o q -- $B --probe-only --probe-reps 50 > /dev/null 2> $OUT/pmc_sq.err
 rocprofv3 --kernel-trace --pmc TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_ta_cifar -o a -- $B --probe-only --probe-reps 50 > /dev/null 2> $OUT/pmc_ta.err
+if [ "${2:-all}" = "probes" ]; then exit 0; fi
 # 5. whole-step MFMA busy: the SQ counters over every kernel of 8 eagerly issued single-stream steps
 MMDGAN_SIDE_WGRAD=0 MMDGAN_SN_STREAMS=1 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_step -o s -- $B --steps 5 --warmup 3 --launch-mode eager --no-cpu-baseline > /dev/null 2> $OUT/pmc_step.err
 # 6. the ResNet-SN config: kernel stats of its bench command

@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(ROOT, 'gpurun_out', tag), os.path.join(ROOT, 'profiles')
 os.makedirs(dst, exist_ok=True)
 PEAK = 157.3e12
+REPS = 50                                    # --probe-reps of tools/collect_profiles.sh
 sys.path[:0] = [os.path.join(ROOT, 'mmd-gan_amd')]
 import configs  # noqa: E402
 
@@ -67,21 +68,23 @@ def dominant_kernel_name(sub):
 def probe_rows(sub, name):
     """the probe launches: same kernel, the most frequent grid (the engine's own step holds each grid once or twice)"""
     rows = [r for r in csv.DictReader(open(find(sub, '_kernel_trace.csv'))) if r['Kernel_Name'] == name]
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
     by = collections.defaultdict(list)
     for r in rows:
         by[(r['Grid_Size_X'], r['Grid_Size_Y'], r['Grid_Size_Z'])].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
     grid, d = max(by.items(), key=lambda kv: len(kv[1]))
-    return grid, d, len(rows)
+    return grid, d[-REPS:], len(rows)                    # the timed launches are the last REPS (clock warm-up launches first)
 
 
 def pmc_avg(sub, name, counter, grid=None):
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(find(sub, '_counter_collection.csv'))):
+    for r in sorted(csv.DictReader(open(find(sub, '_counter_collection.csv'))), key=lambda r: int(r['Dispatch_Id'])):
         if r['Kernel_Name'] == name and r['Counter_Name'] == counter:
             acc[r['Grid_Size']].append(float(r['Counter_Value']))
     if not acc:
         return None, 0
     g, v = max(acc.items(), key=lambda kv: len(kv[1]))
+    v = v[-REPS:]
     return sum(v) / len(v), len(v)
 
 
@@ -176,25 +179,44 @@ open(os.path.join(dst, tag + '_dominant_kernel_stats.txt'), 'w').write(
 f = find('pmc_step', '_counter_collection.csv')
 if f:
     busy = gui = 0.0
+    steps = 0
     per = collections.defaultdict(lambda: [0.0, 0.0])
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name'].replace('mmdgan::', '').replace('void ', '').split('(')[0].split('<')[0]
+        if k.startswith('at::cuda::'):
+            continue                                     # the spin kernels of the stream picker at engine construction
         if r['Counter_Name'] == 'SQ_VALU_MFMA_BUSY_CYCLES':
             busy += float(r['Counter_Value']); per[k][0] += float(r['Counter_Value'])
+            steps += k.startswith('mmd_kernel')
         elif r['Counter_Name'] == 'GRBM_GUI_ACTIVE':
             gui += float(r['Counter_Value']); per[k][1] += float(r['Counter_Value'])
     simd_cycles = gui / 8 * 1024
+    dom = json.load(open(os.path.join(dst, tag + '_dominant_kernel_cifar.json')))
+    gui_hz = dom['sq']['GRBM_GUI_ACTIVE'] / 8 / (dom['avg_us_profiled'] * 1e-6) if 'sq' in dom else None
+    b = bench_line(os.path.join(src, 'bench.json'))
     out = {'command': 'MMDGAN_SIDE_WGRAD=0 MMDGAN_SN_STREAMS=1 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE '
                       '-- python bench.py --steps 5 --warmup 3 --launch-mode eager --no-cpu-baseline',
-           'definition': 'sum over EVERY kernel launch of the run of SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); '
-                         'counters serialise the kernels, so this is the busy fraction of the SIMD cycles the step occupies when its '
-                         'kernels run one after another',
-           'SQ_VALU_MFMA_BUSY_CYCLES': busy, 'GRBM_GUI_ACTIVE_sum_over_xcd': gui,
-           'mfma_busy_frac_whole_step': busy / simd_cycles,
-           'by_kernel': {k: {'mfma_busy_frac': v[0] / (v[1] / 8 * 1024) if v[1] else None, 'share_of_gpu_cycles': v[1] / gui}
+           'steps_in_the_run': steps,
+           'SQ_VALU_MFMA_BUSY_CYCLES_per_step': busy / max(steps, 1), 'GRBM_GUI_ACTIVE_sum_over_xcd_per_step': gui / max(steps, 1),
+           'serialised': {
+               'definition': 'sum over every kernel launch of SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): counter '
+                             'collection runs the kernels one at a time, each with its own start-up and drain, so the ~100 small '
+                             'kernels of a step (no MFMA; in a real step they hide under the convolutions on other streams) '
+                             'weigh in with half of the cycles',
+               'mfma_busy_frac': busy / simd_cycles},
+           'by_kernel': {k: {'mfma_busy_frac': v[0] / (v[1] / 8 * 1024) if v[1] else None, 'share_of_serialised_cycles': v[1] / gui}
                          for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])[:16]}}
+    if gui_hz and b:
+        out['at_the_measured_step_time'] = {
+            'definition': 'MFMA-busy SIMD cycles of one step / (1024 SIMDs x the un-profiled step time x the clock GRBM_GUI_ACTIVE '
+                          'counts at, taken from the dominant-kernel passes: cycles / 8 / duration)',
+            'gui_clock_hz': gui_hz, 'ms_per_step': b['ms_per_step'],
+            'mfma_busy_frac': busy / max(steps, 1) / (1024 * b['ms_per_step'] * 1e-3 * gui_hz)}
+        out['mfma_busy_frac_whole_step'] = out['at_the_measured_step_time']['mfma_busy_frac']
+    else:
+        out['mfma_busy_frac_whole_step'] = busy / simd_cycles
     json.dump(out, open(os.path.join(dst, tag + '_whole_step_mfma_busy.json'), 'w'), indent=1)
-    print('whole-step MFMA busy', out['mfma_busy_frac_whole_step'])
+    print('whole-step MFMA busy', out['mfma_busy_frac_whole_step'], out['serialised']['mfma_busy_frac'], steps)
 
 for name in ('conv_layers.txt', 'conv_layers_direct.txt', 'launch_modes.txt', 'bench.json', 'bench_stl.json', 'bench_celeba.json',
              'bench_lsun_resnet.json', 'bench_dp_one_rank.json', 'bench_default_profiled.json'):
