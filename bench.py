@@ -87,6 +87,42 @@ def dominant_kernel_probe(eng, reps=20, warm=3):
     ms = e0.elapsed_time(e1) / reps
     return {'kernel': 'conv2d_dgrad(%s: %dx%dx%d <- %d 4x4/2, %d rows; %s)' % (
                 s.scope, h, w, c, s.out, 3 * B, 'wino2_kernel F(2x2,2x2)' if wino is not None else 'library choice'),
+            # algorithmic bytes: dy [3B,h/2,w/2,K] + the activations act'(y) for 3B rows + the transformed weights read, dx written
+            'alg_bytes_read': 4.0 * (3 * B * (h // 2) * (w // 2) * s.out + 3 * B * h * w * c + 36 * c * s.out),
+            'alg_bytes_write': 4.0 * 3 * B * h * w * c,
+            'flops': flops, 'ms': ms, 'tflops': flops / ms / 1e9}
+
+
+def dominant_kernel_probe_tape(eng, reps=20, warm=3):
+    """the residual-block configs: the kernel with the largest share of their step is `wino_wgrad_kernel`, the
+    Winograd-domain weight gradient of the blocks' 3x3 convolutions (profiles/*_resnet_kernel_stats.txt).  Timed here on
+    the first un-folded 3x3 kernel of D whose channels are tile multiples, at D's batch 2B, on stand-alone buffers of
+    its shapes (the kernel's time does not depend on the data).  FLOPs are the algorithmic ones of the weight gradient."""
+    from mmdgan_hip import ops
+    k = next((k for k in eng.dis.kernels if k.op == 'c' and k.R == 3 and k.stride == 1 and k.fold is None
+              and k.kernel_shape[2] % 32 == 0 and k.kernel_shape[3] % 64 == 0), None)
+    if k is None:
+        return None
+    c, h, w = k.in_ref
+    n, kout = 2 * eng.B, k.out
+    x = torch.randn(n, h, w, c, device='cuda')
+    dy = torch.randn(n, h, w, kout, device='cuda')
+    dw = torch.empty(3, 3, c, kout, device='cuda')
+    flops = 2.0 * n * h * w * 9 * c * kout
+
+    def launch():
+        ops.conv2d_wgrad(x, dy, 3, 1, out=dw)
+    for _ in range(warm):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    return {'kernel': 'conv2d_wgrad(%s: %dx%dx%d -> %d 3x3, %d rows; wino_wgrad_kernel F(2x2,3x3))' % (k.scope, h, w, c, kout, n),
+            'alg_bytes_read': 4.0 * n * h * w * (c + kout), 'alg_bytes_write': 4.0 * 9 * c * kout,
             'flops': flops, 'ms': ms, 'tflops': flops / ms / 1e9}
 
 
@@ -171,7 +207,7 @@ def main():
         torch.cuda.synchronize()
         # 400 untimed launches first (~40 ms): the shader clock and the power state need that long to settle - measured
         # 107-110 us per launch right after start-up against 97-98 us for the same launch at the end of a bench run
-        probe = dominant_kernel_probe(eng, reps=args.probe_reps, warm=args.probe_warm)
+        probe = (dominant_kernel_probe_tape if tape else dominant_kernel_probe)(eng, reps=args.probe_reps, warm=args.probe_warm)
         print(json.dumps({'dominant_kernel': probe, 'reps': args.probe_reps, 'warm': args.probe_warm}))
         return
     for _ in range(args.warmup):
@@ -242,7 +278,7 @@ def main():
         whole = {'achieved': achieved, 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
                  'scope': 'whole step: B*(3*F_G+7*F_D) = %.1f GFLOP algorithmic over the HIP-event step time %.3f ms'
                           % (flops_step / 1e9, ev_ms)}
-        probe = None if tape else dominant_kernel_probe(eng, reps=args.probe_reps)
+        probe = dominant_kernel_probe_tape(eng, reps=args.probe_reps) if tape else dominant_kernel_probe(eng, reps=args.probe_reps)
         committed = committed_profile(args.config)
         if probe:
             # the roofline object is about the dominant kernel: algorithmic FLOPs of one launch over its HIP-event time,

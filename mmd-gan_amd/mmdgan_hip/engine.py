@@ -33,7 +33,10 @@ import torch
 
 from . import initializers, ops
 
-_EV_WINO_GEN = 0                      # named event slot (mmdgan_event_record / _wait): G's Winograd weights are ready
+# named event slots (mmdgan_event_record / _wait)
+_EV_WINO_GEN = 0                      # G's Winograd weights are ready
+_EV_WINO_DIS = 1                      # D's
+_EV_SN0 = 8                           # + i: the power iteration of D layer i has produced its scale
 
 _TEMPLATE = {'name': None, 'type': 'default', 'op': 'c', 'out': None, 'bias': 'b',
              'act': 'linear', 'act_nm': None, 'act_k': False, 'w_nm': None, 'w_p': None,
@@ -539,7 +542,7 @@ class GanEngine:
         # 3x3 / stride-1 D layers that the library runs through Winograd: their weights change once per step, so
         # G w G^T is computed once per step on the parameter-gradient stream (idle during the forward pass)
         # instead of inside every conv call.  scope -> [forward tensor or None, input-gradient tensor or None]
-        self._wino = {}
+        self._wino, self._wino_ok = {}, {}
         if self._side_wgrad:
             for net, nf, nb in ((self.dis, 2 * B, 3 * B), (self.gen, B, B)):
                 for s in net.specs:
@@ -593,8 +596,8 @@ class GanEngine:
             zeroed = self._in_step and tgt.data_ptr() in self._zeroed_ptrs
             ops.gemm(x.reshape(n, -1), w, bias=bias, scale=scale, act=fused_act, out=tgt.view(n, -1), out_zeroed=zeroed)
         elif s.op == 'c':
-            full = n == (2 * self.B if net is self.dis else self.B)      # the batch the transforms were sized for
-            wino = self._wino.get(s.scope, (None, None, None))[0] if full and is_training else None
+            # transformed weights only for a batch the library runs Winograd at (its thresholds count tiles)
+            wino = self._wino.get(s.scope, (None, None, None))[0] if is_training and self._wino_fwd_ok(net, s, n) else None
             ops.conv2d_fwd(x, w, s.stride, bias=bias, scale=scale, act=fused_act, out=tgt, wino=wino)
         else:
             wino = self._wino.get(s.scope, (None, None, None))[1] if n == self.B and is_training else None
@@ -617,6 +620,14 @@ class GanEngine:
                     raw2d.data_ptr(), raw2d.shape[0], raw2d.shape[1], gamma.data_ptr(), beta.data_ptr(), 1e-3,
                     ops.act_id(s.act), mm.data_ptr(), mv.data_ptr(), y.data_ptr(), ops._stream()), 'bn_fwd_infer')
         return y
+
+    def _wino_fwd_ok(self, net, s, n):
+        key = (s.scope, n)
+        if key not in self._wino_ok:
+            c, h, w = s.in_shape_ref
+            self._wino_ok[key] = s.scope in self._wino and self._wino[s.scope][0] is not None and \
+                ops.wino_eligible(n, h, w, c, s.out, s.R, s.stride, False)
+        return self._wino_ok[key]
 
     def generate(self, z, is_training=False):
         """G(z) -> NHWC images (the fake half of D's input buffer when the batch is B)."""
@@ -653,22 +664,30 @@ class GanEngine:
         for st in self._sn_raw:
             ops.stream_wait(st, main)
         for i, s in enumerate(self.dis.specs):
-            with torch.cuda.stream(self._sn_streams[i % len(self._sn_streams)]):
+            k = i % len(self._sn_streams)
+            with torch.cuda.stream(self._sn_streams[k]):
                 self._scales[s.scope] = self._sn_step(s) if s.sn else None
+                if s.sn:
+                    ops.event_record(_EV_SN0 + i, self._sn_raw[k])
         ops.copy(b['dis_in'][:B], real)                                      # my_sngan.py:278: D sees [real ; fake]
         if any(net is self.gen for _, _, net in self._wino.values()):
             ops.event_wait(_EV_WINO_GEN, main)
         self.generate(z, is_training=True)                                   # writes dis_in[B:]
-        for st in self._sn_raw:
-            ops.stream_wait(main, st)
         if self._wino:
-            ops.stream_wait(main, self._wg_raw)                              # transformed weights of this step
+            ops.event_wait(_EV_WINO_DIS, main)                               # D's transformed weights of this step
         x = b['dis_in']
-        for s in self.dis.specs:
+        for i, s in enumerate(self.dis.specs):
+            if s.sn:
+                # a layer waits for ITS power iteration only, not for both chains (measured: no difference at CIFAR B=64, where
+                # the chains finish under G's forward pass; tried with it: D's real half as a separate half-batch pass on the
+                # parameter-gradient stream underneath G's forward pass - 3.05 instead of 2.33 ms per step, dropped)
+                ops.event_wait(_EV_SN0 + i, main)
             scale = self._scales[s.scope]
             x = self._layer_forward(self.dis, s, x, True, scale)
             if s.out_reshape is not None:
                 x = x.view(_native_shape(s.out_shape_ref, x.shape[0]))
+        for st in self._sn_raw:
+            ops.stream_wait(main, st)                                        # the chains' tails (x <- normalised F^T(y))
         scores = x                                                           # [2B, d]; s_x = [:B], s_gen = [B:]
         self._loss.launch(scores, self.losses)
         return scores
@@ -886,6 +905,7 @@ class GanEngine:
                             ops.event_record(_EV_WINO_GEN, self._wg_raw)
                             for t in arenas:
                                 ops.memset_zero(t)
+                    ops.event_record(_EV_WINO_DIS, self._wg_raw)
             for t in self._zero_each_step:
                 if not any(t is a for a in arenas):
                     ops.memset_zero(t)

@@ -18,7 +18,7 @@ rocprofv3 --kernel-trace --output-format csv -d $OUT/timeline -o t -- $B --steps
 fi
 # 4. the dominant kernel alone, per config: kernel trace (the probe launches are isolated by grid size in make_profiles.py)
 #    and the PMC passes (own runs, kernel-trace only): HBM read / write bytes, MFMA busy
-for c in cifar stl celeba; do
+for c in cifar stl celeba lsun_resnet; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/probe_$c -o p -- $B --config $c --probe-only --probe-reps 50 > $OUT/probe_$c.json 2> $OUT/probe_$c.err
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$c -o f -- $B --config $c --probe-only --probe-reps 50 > /dev/null 2> $OUT/pmc_fetch_$c.err
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$c -o w -- $B --config $c --probe-only --probe-reps 50 > /dev/null 2> $OUT/pmc_write_$c.err

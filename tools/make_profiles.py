@@ -120,16 +120,20 @@ open(os.path.join(dst, tag + '_step_timeline.txt'), 'w').write(
     '# host is ahead of the GPU in an unprofiled run - is stretched; the GPU-bound backward pass is representative)\n' + tl)
 
 stats_txt = []
-for config in ('cifar', 'stl', 'celeba'):
+for config in ('cifar', 'stl', 'celeba', 'lsun_resnet'):
     if not find('probe_' + config, '_kernel_trace.csv'):
         continue
     name = dominant_kernel_name('probe_' + config)
     grid, durs, total_calls = probe_rows('probe_' + config, name)
     avg = sum(durs) / len(durs)
-    flops, rd, wr = algorithmic(config)
     ev_prof = json.load(open(os.path.join(src, 'probe_%s.json' % config)))['dominant_kernel']
     ev_free = json.load(open(os.path.join(src, 'probe_unprofiled_%s.json' % config)))['dominant_kernel']
-    assert abs(ev_prof['flops'] - flops) < 1e-6 * flops, (ev_prof['flops'], flops)
+    if config == 'lsun_resnet':          # the weight-gradient probe of the residual-block engine: figures from the bench line
+        flops, rd, wr = ev_prof['flops'], ev_prof['alg_bytes_read'], ev_prof['alg_bytes_write']
+    else:
+        flops, rd, wr = algorithmic(config)
+        assert abs(ev_prof['flops'] - flops) < 1e-6 * flops, (ev_prof['flops'], flops)
+        assert abs(ev_prof['alg_bytes_read'] - rd) < 1e-6 * rd and ev_prof['alg_bytes_write'] == wr
     fetch, nf = pmc_avg('pmc_fetch_' + config, name, 'FETCH_SIZE')
     write, nw = pmc_avg('pmc_write_' + config, name, 'WRITE_SIZE')
     out = {
