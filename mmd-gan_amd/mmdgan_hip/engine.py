@@ -810,7 +810,9 @@ class GanEngine:
                 # a BN layer below gets d/d(its activated output) and applies act' itself in bn_bwd;
                 # otherwise the epilogue multiplies by act'(y_prev) and the result is d/d(pre-activation)
                 yprev = b[prev.scope + '#y'].view(in_shape)
-                act_prev, dact = ('linear', None) if prev.bn else (prev.act, yprev)
+                # (a linear layer below has derivative 1: no dact either - which also lets a launch with few tiles split its
+                # reduction into the zeroed buffer: G l2's input-gradient, 128 tiles, 80 -> 45 us)
+                act_prev, dact = ('linear', None) if (prev.bn or prev.act == 'linear') else (prev.act, yprev)
                 dprev = b[prev.scope + ('#dy' if prev.bn else '#dz')].view(in_shape)
                 if s.op == 'd':
                     # dprev is NOT on the step's zero list: no out_zeroed, so no split-K accumulation into last

@@ -560,7 +560,7 @@ def test_data_parallel_step_equals_the_mean_gradient_step(mode):
     # G's gradients pass its relu-after-BN masks, which the atomics' order flips between any two runs of the same
     # step (tools/determinism_probe.py): 2e-3 measured, the run-to-run noise of one engine
     assert res[0]['worst_grad_gen'] <= 1e-2, res[0]
-    assert res[0]['worst_update'] <= 1e-5, res[0]                  # Adam on their mean
+    assert res[0]['worst_update'] <= 1e-4, res[0]                  # Adam on their mean (fp32 kernel vs fp64 arithmetic: 2e-5)
     assert res[0]['spread'] == 0.0 and res[1]['spread'] == 0.0, res   # trainable variables bit-identical after three steps
     assert res[0]['spread_sn'] <= 1e-5, res
     if mode == 'plan':
