@@ -39,6 +39,23 @@ def buckets(numel, bucket_bytes=DEFAULT_BUCKET_BYTES, elem_bytes=4):
     return [(s, min(numel, s + per)) for s in range(0, numel, per)]
 
 
+def layer_buckets(layer_ranges, target_elems):
+    """the gradient arena of one net cut into exchange buckets in BACKWARD order.
+    layer_ranges[i] = (start, end) of layer i's gradients in the flat arena (layers contiguous, forward order);
+    returns [(lowest layer index, start, end)]: a bucket closes once it holds `target_elems` (or at layer 0) and is
+    exchanged as soon as the gradients of its LOWEST layer exist - the backward pass produces them last - so every bucket
+    but the final one travels underneath the backward kernels still to come.  The buckets tile [0, arena end) exactly."""
+    out, hi_end, acc = [], None, 0
+    for li in range(len(layer_ranges) - 1, -1, -1):
+        lo, hi = layer_ranges[li]
+        hi_end = hi if hi_end is None else hi_end
+        acc += hi - lo
+        if acc >= target_elems or li == 0:
+            out.append((li, lo, hi_end))
+            hi_end, acc = None, 0
+    return out
+
+
 def allreduce_sum_async(flat, group=None, bucket_bytes=DEFAULT_BUCKET_BYTES):
     """start a SUM all-reduce of `flat` bucket by bucket; returns the work handles.  The caller
     divides by the world size (the Adam kernel's grad_scale does it for free)."""

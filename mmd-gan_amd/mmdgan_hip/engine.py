@@ -476,21 +476,16 @@ class GanEngine:
         A bucket is exchanged as soon as the parameter gradients of its lowest layer have been issued, so all but the
         last one travel underneath the rest of the backward pass.  Layers are contiguous in the arena (forward order);
         a bucket closes once it holds MMDGAN_DP_BUCKET_MB (default 8) - xGMI rings are latency-bound below a few MB."""
+        from .dist import layer_buckets
         target = int(float(os.environ.get('MMDGAN_DP_BUCKET_MB', '8')) * (1 << 20)) // 4
         first = {}                                   # layer index -> (start, end) float offsets of its entries
         for name, (o, size, _) in net.arena.offsets.items():
             li = next(i for i, sp in enumerate(net.specs) if name.startswith(sp.scope + '/'))
             lo, hi = first.get(li, (o, o))
             first[li] = (min(lo, o), max(hi, o + (size + 3) // 4 * 4))
-        buckets, hi_end, acc = [], None, 0
-        for li in range(len(net.specs) - 1, -1, -1):
-            lo_off, hi_off = first[li]
-            hi_end = hi_off if hi_end is None else hi_end
-            acc += hi_off - lo_off
-            if acc >= target or li == 0:
-                buckets.append((li, lo_off, min(hi_end, net.arena.size)))
-                hi_end, acc = None, 0
-        return buckets
+        ranges = [first[li] for li in range(len(net.specs))]
+        ranges[-1] = (ranges[-1][0], min(ranges[-1][1], net.arena.size))
+        return layer_buckets(ranges, target)
 
     # ---------------------------------------------------------------------------------------
     def _alloc(self, B):

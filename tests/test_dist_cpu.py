@@ -58,6 +58,18 @@ def _worker(rank, world, port, q):
         mdist.broadcast_state(eng)
         ok_bc = all(float(n.params[0]) == 0.0 and float(n.adam_m[0]) == 10.0 and float(n.state['a'][0]) == 7.0
                     and int(n.opt.step_counter[0]) == 3 for n in (eng.gen, eng.dis))
+        # the engine's per-layer exchange: the arena cut into buckets in backward order, each bucket all-reduced on its own
+        # as the backward pass reaches its lowest layer == one all-reduce of the whole arena
+        sizes = [7, 8192, 600, 20000, 36, 65000, 6268]                 # layers in forward order (sum = 100003)
+        ranges, o = [], 0
+        for n in sizes:
+            ranges.append((o, o + n))
+            o += n
+        bl = mdist.layer_buckets(ranges, 16384)
+        arena = mine.clone()
+        for li, lo, hi in bl:                                           # issue order = backward order
+            tdist.all_reduce(arena[lo:hi], op=tdist.ReduceOp.SUM)
+        ok_sum = ok_sum and torch.allclose(arena, ref, rtol=0, atol=1e-5) and [b[0] for b in bl] == sorted([b[0] for b in bl], reverse=True)
         q.put((rank, ok_sum, ok_avg, ok_bc, mdist.shard_of(50000, rank, world)))
     finally:
         tdist.destroy_process_group()
@@ -76,6 +88,30 @@ def test_gloo_world2_gradient_average_and_broadcast():
         assert p.exitcode == 0
     assert [r[1:4] for r in results] == [(True, True, True)] * world
     assert results[0][4] == (0, 25000) and results[1][4] == (25000, 50000)
+
+
+def test_layer_buckets_tile_the_arena_in_backward_order():
+    ranges = [(0, 7), (8, 8200), (8200, 8800), (8800, 28800), (28800, 28836), (28836, 93836), (93836, 100104)]
+    for target in (1, 5000, 16384, 10 ** 9):
+        bl = mdist.layer_buckets(ranges, target)
+        assert bl[0][2] == 100104 and bl[-1][1] == 0 and bl[-1][0] == 0                 # from the arena's end down to layer 0
+        assert all(a[1] == b[2] or (a[1], b[2]) == (8, 7) for a, b in zip(bl, bl[1:]))     # contiguous (alignment gaps stay inside)
+        assert [b[0] for b in bl] == sorted((b[0] for b in bl), reverse=True)
+        assert all(hi - lo >= target or li == 0 for li, lo, hi in bl)
+    assert len(mdist.layer_buckets(ranges, 10 ** 9)) == 1 and len(mdist.layer_buckets(ranges, 1)) == len(ranges)
+    # the CIFAR nets of the shipped config: D [l8+l7 | l6 | l5..l1], G [l5..l2 | l1] at the default 8 MiB
+    import configs
+    from mmdgan_hip.engine import build_specs
+    arch, _ = configs.cifar()
+    for key, in_shape, want in (('discriminator', [3, 32, 32], [6, 5, 0]), ('generator', [128], [1, 0])):
+        specs = build_specs(arch[key], in_shape, key[:3])
+        sizes = [int(__import__('numpy').prod(s.kernel_shape)) + (s.channels if s.has_bias else 0) + (2 * s.channels if s.bn else 0)
+                 for s in specs]
+        rng, o = [], 0
+        for n in sizes:
+            rng.append((o, o + n))
+            o += n
+        assert [b[0] for b in mdist.layer_buckets(rng, (8 << 20) // 4)] == want, key
 
 
 def test_buckets_cover_exactly():
