@@ -131,6 +131,24 @@ int mmdgan_memset_zero(void *ptr, size_t bytes, void *stream);
 int mmdgan_copy(void *dst, const void *src, size_t bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Gradient exchange (the reference's dormant tower helper graph_func.py:69-94 averages the towers'
+ * gradients): RCCL from inside the library, one replica = one process = one GPU.  RCCL is bound at run time (dlopen):
+ * without it these entries return MMDGAN_E_UNSUPPORTED and everything else works.
+ *   mmdgan_comm_unique_id(out)        rank 0: 128 bytes to hand to the other ranks (any side channel)
+ *   mmdgan_comm_init(id, nranks, rank) every rank: ncclCommInitRank
+ *   mmdgan_allreduce_bucket(buf, count, stream)   in-place SUM over the replicas of `count` floats, asynchronous on
+ *                                     `stream`; the mean is Adam's grad_scale = 1/nranks.  Recorded by launch plans like
+ *                                     any other entry: a data-parallel step replays from one mmdgan_plan_replay call.
+ * A caller may instead keep its own communicator (torch.distributed, as mmdgan_hip/engine.py does by default) and cut
+ * its plan into segments around the collectives (mmdgan_plan_mark).
+ * ---------------------------------------------------------------------------------------------- */
+int mmdgan_comm_unique_id(void *out128);
+int mmdgan_comm_init(const void *id128, int nranks, int rank);
+int mmdgan_comm_size(void);                     /* 0 = no communicator */
+int mmdgan_comm_destroy(void);
+int mmdgan_allreduce_bucket(float *buf, size_t count, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Convolution family.  Geometry: input [N,H,W,C], kernel [R,R,C,K], stride, 'SAME' padding with
  * pad_before = max((ceil(H/stride)-1)*stride + R - H, 0)/2 (tf.nn.conv2d, layer_func.py:914),
  * output [N,P,Q,K], P = ceil(H/stride).

@@ -38,6 +38,11 @@ SIGNATURES = {
     'mmdgan_event_wait': (_I, [_I, _P]),
     'mmdgan_memset_zero': (_I, [_P, ctypes.c_size_t, _P]),
     'mmdgan_copy': (_I, [_P, _P, ctypes.c_size_t, _P]),
+    'mmdgan_comm_unique_id': (_I, [_P]),
+    'mmdgan_comm_init': (_I, [_P, _I, _I]),
+    'mmdgan_comm_size': (_I, []),
+    'mmdgan_comm_destroy': (_I, []),
+    'mmdgan_allreduce_bucket': (_I, [_P, ctypes.c_size_t, _P]),
     'mmdgan_conv2d_fwd': (_I, [_G, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     'mmdgan_conv2d_dgrad': (_I, [_G, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     'mmdgan_conv2d_wgrad': (_I, [_G, _P, _P, _P, _P]),

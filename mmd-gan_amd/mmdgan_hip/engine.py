@@ -380,7 +380,7 @@ class GanEngine:
 
     def __init__(self, architecture, loss_type='rep', lr_list=(5e-4, 2e-4), rep_weights=(0.0, -1.0),
                  batch_size=64, seed=0, device=None, dist_group=None, use_graph=False, sn_mode='default',
-                 weight_init='default', mix_threshold=None, launch_mode=None):
+                 weight_init='default', mix_threshold=None, launch_mode=None, dp_backend=None):
         ops.require_device()
         initializers.check_mode(weight_init)
         if loss_type not in ops.LOSS:
@@ -427,6 +427,13 @@ class GanEngine:
         self._z_gen = torch.Generator(device=self.device)
         self._z_gen.manual_seed((int(seed) * 1000003 + 7919 * self.rank + 12345) % (2 ** 63 - 1))
         self._recording, self._d_updated_early = False, False
+        # who carries the gradient exchange: 'torch' = torch.distributed on `dist_group` (RCCL through ProcessGroupNCCL; gloo in
+        # the tests); 'capi' = the library's own RCCL communicator (mmdgan_comm_init / mmdgan_allreduce_bucket), whose
+        # collectives are plan nodes like any launch - a data-parallel step then replays from one C call
+        self._dp_backend = dp_backend or os.environ.get('MMDGAN_DP_BACKEND', 'torch')
+        assert self._dp_backend in ('torch', 'capi'), self._dp_backend
+        if self._dp_backend == 'capi' and dist_group is not None:
+            self._init_capi_comm()
         # the power iterations of different layers are independent of each other too: two chains.
         # weight / bias gradients of a layer depend only on dz of that layer, not on the dgrad chain that
         # continues below it: they go to another stream so their blocks fill the tail of the dgrad
@@ -850,7 +857,7 @@ class GanEngine:
             ops.stream_wait(self._comm_raw, self._wg_raw)
         ops.stream_wait(self._comm_raw, ops._stream())
         lib = ops.require_device()
-        if self._recording:
+        if self._recording and self._dp_backend != 'capi':
             lib.mmdgan_plan_mark()                       # the collective is not the library's: a segment boundary
             self._plan_collectives.append((net, lo, hi))
         self._issue_collective(net, lo, hi)
@@ -863,9 +870,29 @@ class GanEngine:
             self._d_updated_early = True
 
     def _issue_collective(self, net, lo, hi):
+        if self._dp_backend == 'capi':
+            ops.check(ops.require_device().mmdgan_allreduce_bucket(net.grads.data_ptr() + 4 * lo, hi - lo, self._comm_raw),
+                      'allreduce_bucket')
+            return
         from . import dist as mdist
         with torch.cuda.stream(self._comm_stream):
             mdist.allreduce_sum_(net.grads[lo:hi], self.dist_group)
+
+    def _init_capi_comm(self):
+        """one RCCL communicator inside the library for this process: rank 0's unique id travels over `dist_group`"""
+        import ctypes
+        import torch.distributed as tdist
+        lib = ops.require_device()
+        if lib.mmdgan_comm_size() == self.world:
+            return                                       # an earlier engine of this process made it
+        ident = (ctypes.c_char * 128)()
+        if self.rank == 0:
+            ops.check(lib.mmdgan_comm_unique_id(ident), 'comm_unique_id')
+        dev = self.device if tdist.get_backend(self.dist_group) == 'nccl' else torch.device('cpu')
+        t = torch.tensor(list(bytes(ident)), dtype=torch.uint8, device=dev)
+        tdist.broadcast(t, src=0, group=self.dist_group)
+        raw = bytes(t.cpu().tolist())
+        ops.check(lib.mmdgan_comm_init(raw, self.world, self.rank), 'comm_init')
 
     def _update(self):
         gs = 1.0 / self.world
