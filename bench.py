@@ -139,6 +139,25 @@ def committed_profile(key, per_config=True):
     return d
 
 
+def loss_rel_err(eng, arch, lr, loss, B):
+    """the second half of BASELINE.json's metric ("MMD-loss rel-err vs ref"): one more step of the timed engine on a known
+    batch, against the CPU oracle (the checker, fp64) started from the engine's variables before that step - the losses
+    of the HIP path relative to the reference algorithm on identical inputs, at the bench configuration itself."""
+    from oracle import restatement as R
+    ora = R.OracleGan(arch, loss, tuple(lr), dtype=torch.float64, params=eng.get_variables())
+    rs = np.random.RandomState(4321)
+    c, h, w = arch['input'][0]
+    z = rs.randn(B, arch['code'][0][0]).astype(np.float32)
+    real = rs.uniform(-1, 1, (B, c, h, w)).astype(np.float32)
+    with torch.no_grad():
+        lg, ld, stats, _, _ = ora.forward_losses(torch.tensor(z, dtype=torch.float64), torch.tensor(real, dtype=torch.float64))
+    eng.step(torch.as_tensor(np.ascontiguousarray(real.transpose(0, 2, 3, 1))).cuda(), torch.as_tensor(z).cuda())
+    got = eng.losses.cpu().numpy().astype(np.float64)
+    return {'loss_gen': abs(got[0] - float(lg)) / abs(float(lg)), 'loss_dis': abs(got[1] - float(ld)) / abs(float(ld)),
+            'values': {'loss_gen': [float(got[0]), float(lg)], 'loss_dis': [float(got[1]), float(ld)]},
+            'vs': 'oracle/restatement.py in fp64 from the engine\'s variables, same z and batch (B=%d)' % B, 'bar': 1e-4}
+
+
 def cpu_baseline(arch, lr, loss, B, steps):
     """the oracle restatement (fp32 torch-CPU) of the same step on the host cores: a reported
     baseline, not the optimisation target."""
@@ -307,6 +326,7 @@ def main():
             out['roofline']['whole_step']['mfma_busy_source'] = busy['_file']
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(arch, lr, args.loss, B, 1 if tape else args.cpu_steps)
+            out['mmd_loss_rel_err'] = loss_rel_err(eng, arch, lr, args.loss, B)
         print(json.dumps(out))
     if group is not None:
         import torch.distributed as dist
