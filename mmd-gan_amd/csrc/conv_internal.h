@@ -70,7 +70,7 @@ int wino2_transform(const ConvDims &d, const float *w, bool dgrad, float *U, hip
 int wino2_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, const float *U, float *y, hipStream_t st);
 int wino2_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, const float *U, float *dx, hipStream_t st);
 bool wino2_wgrad_ok(const ConvDims &d);
-int wino2_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st);
+int wino2_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, float *dbias, bool *dbias_done, hipStream_t st);
 
 // split-bf16 (three exact bf16 terms per fp32 operand, six products) gather-GEMM on the bf16 MFMA pipe (conv_bfx.hip);
 // Wp = weights already split by bfx_transform, or nullptr (then w is split into the workspace)

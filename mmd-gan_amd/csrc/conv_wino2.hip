@@ -18,6 +18,10 @@
 #include "conv_internal.h"
 #include "bufload.h"
 
+#ifndef W2W_DEFAULT
+#define W2W_DEFAULT 1
+#endif
+
 namespace mmdgan {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -418,65 +422,95 @@ int wino2_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, cons
 // Weight gradient of the 4x4 / stride-2 layers in the F(2x2,2x2) domain.  The 16 taps split into four 2x2 filters
 // (tap parities a,b), each the gradient of a 2x2 stride-1 correlation on a parity sub-image of x:
 //   dW^{ab} = G^T [ sum_tiles (B^T d^{ab} B) (.) (A dY A^T) ] G        - 9 multiplies per tile and (c,k) instead of 16
-// blockIdx.z = (split of the tile range) * 4 + parity.  Three waves, wave i owns row i of the 3x3 frequency grid:
-//   * V = B^T d B: a stage is 24 tiles, thread = (tile of the stage, channel quad): the 9 patch pixels as float4,
-//     the whole transform in registers, 9 ds_write_b128 into V[f][tile][c];
-//   * dM = A dY A^T row i is built in registers from the 2x2 dY pixels of the lane's tile (tile offsets published by
-//     the producer lanes through an LDS ring, as in wino_wgrad_kernel);
-//   * epilogue: G^T dU G on the partial sums (j in registers, i across the waves through LDS), 4 coalesced fp32
-//     atomics per (c,k) into the zeroed dW.
+// Workgroup = 64 input channels x 128 output channels x one parity x a split of the tile range, eight waves; wave
+// (c half, k quarter) keeps all nine 32x32 frequency accumulators of its sub-block (144 registers), so
+//   * V = B^T d B: a stage is 16 tiles; thread = (tile of the stage, channel quad) loads the 9 patch pixels as float4, does the
+//     transform in registers and writes V[f][k-pair][c half][tile parity][32 c] (the A fragment of a k-pair is 64 consecutive
+//     words: conflict-free);
+//   * the 2x2 dY pixels of the stage's tiles go through LDS as well, coalesced float4 loads by all threads;
+//   * dM = A dY A^T (nine values) is built in registers from four LDS words, 13 LDS words per 9 MFMAs;
+//   * the epilogue G^T dU G is register-only (every wave owns all frequencies of its outputs) and stores the workgroup's
+//     4 taps x 64 x 128 partial result into its slab of the library workspace [split][16][C][K]; one reduction pass sums the
+//     slabs (no zeroing, no atomics, deterministic).  Without a workspace: fp32 atomics into the zeroed dw.
+// History (D l2 / l4 / l6 at batch 128, direct implicit-GEMM kernel 92 / 86 / 78 us): 32c x 64k tiles with every lane
+// fetching its own dY words from global memory 114 / 110 / 99 us; dY through LDS, six waves, operand prefetch 100 / 89 / 90 us
+// - a 32 x 64 tile moves 17 flop per byte of L2 traffic and spends as many VALU cycles producing V as MFMA cycles using
+// it; 64 x 128 doubles both ratios.
 namespace wino2w {
-constexpr int BT = 24;                        // tiles per stage = 12 MFMA k-pairs: 24 tiles x 8 channel quads = one producer item per thread
-constexpr int LDC = 36;                       // V: floats per tile row (32 channels + 4: 16-byte aligned, conflict-free)
-constexpr int FS = BT * LDC + 4;              // V: floats per frequency
+constexpr int BT = 16;                        // tiles per stage = 8 MFMA k-pairs
+constexpr int BC = 64, BK = 128;              // workgroup tile
+constexpr int NT = 512;                       // 8 waves
+constexpr int FS = BT * BC;                   // V: floats per frequency, [k-pair 8][c half 2][tile parity 2][32]
 constexpr int V_FLOATS = 9 * FS;
-constexpr int TS_FLOATS = 3 * 2 * 32 * 32;    // epilogue exchange buffer, one column block at a time
-constexpr int SMEM_FLOATS = 2 * V_FLOATS > TS_FLOATS ? 2 * V_FLOATS : TS_FLOATS;
+constexpr int DYT = 4 * BK + 32;              // dY stage tile: floats per tile ([4 pixels][128 channels]; +32: the two half-waves of
+                                              // a read (tiles 2kp, 2kp+1) land on disjoint banks)
+constexpr int DY_FLOATS = BT * DYT;
+constexpr int SMEM_FLOATS = 2 * V_FLOATS + 2 * DY_FLOATS;
 constexpr size_t LDS_BYTES = sizeof(float) * SMEM_FLOATS + sizeof(unsigned) * 4 * BT;
+constexpr int DYV = BT * 4 * (BK / 4) / NT;   // float4 items of the dY stage tile per thread (4)
+static_assert(BT * 4 * (BK / 4) % NT == 0, "dY items");
+static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 }  // namespace wino2w
 
-__global__ __launch_bounds__(192) void wino2_wgrad_kernel(int N, int H, int W, int C, int K, const float *__restrict__ x,
-                                                          const float *__restrict__ dy, float *__restrict__ dw,
-                                                          int stages_per_split) {
+template <bool PART, bool DBIAS>
+__global__ __launch_bounds__(wino2w::NT) void wino2_wgrad_kernel(int N, int H, int W, int C, int K, const float *__restrict__ x,
+                                                                 const float *__restrict__ dy, float *__restrict__ dw,
+                                                                 float *__restrict__ dbpart, int stages_per_split) {
     using namespace wino2w;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // = frequency row i
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wv & 1, wk = wv >> 1;                                   // 32-channel half of the 64, 32-column quarter of the 128
     const int P = H >> 1, Q = W >> 1, TH = P >> 1, TW = Q >> 1;
     const long T = (long)N * TH * TW;
     const int nst_all = (int)((T + BT - 1) / BT);
-    const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 64;
+    const int c0 = blockIdx.x * BC, n0 = blockIdx.y * BK;
     const int par = blockIdx.z & 3, pa = par >> 1, pb = par & 1;
     const int s0 = (blockIdx.z >> 2) * stages_per_split, s1 = min(nst_all, s0 + stages_per_split);
     if (s0 >= s1) return;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (long)N * H * W * C * 4);
     const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, (long)N * P * Q * K * 4);
+    float *Vs = smem, *DYs = smem + 2 * V_FLOATS;
     unsigned *dyoff = reinterpret_cast<unsigned *>(smem + SMEM_FLOATS);      // [stage & 3][tile of the stage]
-    // ---- producer: thread = (tile of the stage pt, channel quad cq)
-    const int pt = tid >> 3, cq = tid & 7;
-    long ptile = (long)s0 * BT + pt;
+    // ---- producer of V: thread = (tile of the stage pt, channel quad cq), threads 0 .. 16*BT-1 (waves 0..3)
+    const int pt = tid >> 4, cq = tid & 15;
+    const bool xprod = tid < 16 * BT;
     int pstage = s0;
+    // tile coordinates of this thread's tile, advanced by BT tiles per stage without divisions
+    const int adv_tx = BT % TW, adv_ty = (BT / TW) % TH, adv_n = (BT / TW) / TH;
+    int tx, ty, n;
+    {
+        const long ii = (long)s0 * BT + pt;
+        tx = ii % TW, ty = (ii / TW) % TH, n = ii / ((long)TW * TH);
+    }
     float4 rin[3][3];
     auto xload = [&]() {
-        const bool ok = ptile < T;
-        const long ii = ok ? ptile : 0;
-        const int tx = ii % TW, ty = (ii / TW) % TH, n = ii / ((long)TW * TH);
-        if (cq == 0)          // byte offset of dY pixel (2ty, 2tx), channel 0, of this tile (consumers add the rest)
-            dyoff[(pstage & 3) * BT + pt] = ok ? (unsigned)((((n * P + 2 * ty) * Q + 2 * tx) * K) * 4) : kOOB;
+        if (xprod) {
+            const bool ok = n < N && pstage < s1;          // beyond the batch (ragged last stage) or the split: no traffic
+            if (cq == 0)          // byte offset of dY pixel (2ty, 2tx), channel 0, of this tile (the dY producers add the rest)
+                dyoff[(pstage & 3) * BT + pt] = ok ? (unsigned)((((n * P + 2 * ty) * Q + 2 * tx) * K) * 4) : kOOB;
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int row = 4 * ty - 1 + pa + 2 * u;
-            const bool rowok = ok && row >= 0 && row < H;
+            for (int u = 0; u < 3; ++u) {
+                const int row = 4 * ty - 1 + pa + 2 * u;
+                const bool rowok = ok && row >= 0 && row < H;
 #pragma unroll
-            for (int v = 0; v < 3; ++v) {
-                const int col = 4 * tx - 1 + pb + 2 * v;
-                rin[u][v] = bufld4(rx, (rowok && col >= 0 && col < W) ? (unsigned)(((((long)n * H + row) * W + col) * C + c0 + 4 * cq) * 4) : kOOB);
+                for (int v = 0; v < 3; ++v) {
+                    const int col = 4 * tx - 1 + pb + 2 * v;
+                    rin[u][v] = bufld4(rx, (rowok && col >= 0 && col < W) ? (unsigned)((((n * H + row) * W + col) * C + c0 + 4 * cq) * 4) : kOOB);
+                }
             }
+            tx += adv_tx;
+            const int cx = tx >= TW;
+            tx -= cx ? TW : 0;
+            ty += adv_ty + cx;
+            const int cy = ty >= TH;
+            ty -= cy ? TH : 0;
+            n += adv_n + cy;
         }
-        ptile += BT;
         ++pstage;
     };
-    auto vstore = [&](float *buf) {           // V[f = 3i + j][tile][4 channels of the quad]
+    auto vstore = [&](float *buf) {           // V[f = 3i + j][k-pair][c half][tile parity][4 channels of the quad]
+        if (!xprod) return;
         float4 X[3][3];
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
@@ -485,7 +519,7 @@ __global__ __launch_bounds__(192) void wino2_wgrad_kernel(int N, int H, int W, i
             X[u][1] = d1;
             X[u][2] = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
         }
-        float *dst = buf + pt * LDC + 4 * cq;
+        float *dst = buf + (pt >> 1) * 128 + (cq >> 3) * 64 + (pt & 1) * 32 + (cq & 7) * 4;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const float4 m = X[1][j];
@@ -494,109 +528,184 @@ __global__ __launch_bounds__(192) void wino2_wgrad_kernel(int N, int H, int W, i
             *reinterpret_cast<float4 *>(dst + (2 * 3 + j) * FS) = make_float4(X[2][j].x - m.x, X[2][j].y - m.y, X[2][j].z - m.z, X[2][j].w - m.w);
         }
     };
-    // ---- consumer: this lane's tile for k-pair kp of a stage is s*8 + 2*kp + kh, its channel n0 + cb*32 + l31
-    const unsigned kcol = (unsigned)((n0 + l31) * 4);
+    // ---- producer of the dY stage tile: item = (tile, pixel of its 2x2, channel quad of the 128), all threads
     const unsigned dyrow = (unsigned)(Q * K * 4), dypix = (unsigned)(K * 4);
-    // A dY A^T, row i = wave, A = [1 0; 1 1; 0 1]: e[b] = wa*dY[0][b] + wb*dY[1][b];  dM[i][.] = (e0, e0 + e1, e1)
-    const float wa = wave == 2 ? 0.f : 1.f, wb = wave == 0 ? 0.f : 1.f;
-
-    f32x16 acc[3][2];
+    float4 rdyv[DYV];
+    auto dyload = [&](int stage) {            // needs dyoff[stage], written at least one barrier ago
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+        for (int it = 0; it < DYV; ++it) {
+            const int e = tid + it * NT;
+            const int tile = e >> 7, px = (e >> 5) & 3, kq = e & 31;
+            const unsigned off = dyoff[(stage & 3) * BT + tile];
+            rdyv[it] = bufld4(rdy, off == kOOB ? kOOB : off + (px >> 1) * dyrow + (px & 1) * dypix + (unsigned)((n0 + 4 * kq) * 4));
+        }
+    };
+    // column sums of dY (the bias gradient) ride along in the workgroups of channel block 0 / parity 0: every dY pixel passes
+    // through exactly one of them per column block; thread's items all have the same channel quad (tid & 31)
+    const bool dosum = DBIAS && blockIdx.x == 0 && par == 0;
+    float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto dystore = [&](float *buf) {          // (tiles beyond the split were not loaded: zeros)
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][cb][r] = 0.f;
-    float dyv[2][2][4];
-    auto dyload = [&](int slot, int stage, int kp) {
-        const unsigned off = dyoff[(stage & 3) * BT + 2 * kp + kh] + kcol;     // kOOB + kcol stays out of range
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-                dyv[slot][cb][p] = bufld1s(rdy, off, (unsigned)(cb * 128) + (p >> 1) * dyrow + (p & 1) * dypix);
+        for (int it = 0; it < DYV; ++it) {
+            const int e = tid + it * NT;
+            const int tile = e >> 7, px = (e >> 5) & 3, kq = e & 31;
+            *reinterpret_cast<float4 *>(buf + tile * DYT + px * BK + 4 * kq) = rdyv[it];
+            if (dosum) { dbs.x += rdyv[it].x; dbs.y += rdyv[it].y; dbs.z += rdyv[it].z; dbs.w += rdyv[it].w; }
+        }
     };
 
+    f32x16 acc[9];
+#pragma unroll
+    for (int f = 0; f < 9; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
     xload();
-    vstore(smem);
+    vstore(Vs);
     xload();
+    __syncthreads();                          // dyoff[s0], dyoff[s0 + 1] visible
+    dyload(s0);
+    dystore(DYs);
     __syncthreads();
-    dyload(0, s0, 0);
-    const int abase = (3 * wave) * FS + kh * LDC + l31;
+    const int abase = wc * 64 + lane;                        // + f * FS + kp * 128
+    const int dbase = kh * DYT + wk * 32 + l31;              // + 2 kp * DYT + pixel * BK
+    float fa[9], dv[4];
+    auto opload = [&](const float *cur, const float *dcur, int kp) {     // operands of k-pair kp: 9 + 4 LDS words
+#pragma unroll
+        for (int f = 0; f < 9; ++f) fa[f] = cur[abase + f * FS + kp * 128];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dv[q] = dcur[dbase + 2 * kp * DYT + q * BK];
+    };
     for (int s = s0; s < s1; ++s) {
-        const float *cur = smem + ((s - s0) & 1) * V_FLOATS;
-        float *nxt = smem + ((s - s0 + 1) & 1) * V_FLOATS;
+        const int b = (s - s0) & 1;
+        const float *cur = Vs + b * V_FLOATS, *dcur = DYs + b * DY_FLOATS;
+        float *nxt = Vs + (b ^ 1) * V_FLOATS, *dnxt = DYs + (b ^ 1) * DY_FLOATS;
+        opload(cur, dcur, 0);
 #pragma unroll
         for (int kp = 0; kp < BT / 2; ++kp) {
-            float fa[3];
+            // A dY A^T, A = [1 0; 1 1; 0 1]
+            const float m00 = dv[0], m02 = dv[1], m20 = dv[2], m22 = dv[3];
+            const float m01 = m00 + m02, m21 = m20 + m22, m10 = m00 + m20, m12 = m02 + m22, m11 = m01 + m21;
+            const float bm[9] = {m00, m01, m02, m10, m11, m12, m20, m21, m22};
+            float a[9];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) fa[j] = cur[abase + j * FS + 2 * kp * LDC];
-            if (kp + 1 < BT / 2) dyload((kp + 1) & 1, s, kp + 1);
-            else dyload(0, s + 1, 0);
+            for (int f = 0; f < 9; ++f) a[f] = fa[f];
+            if (kp + 1 < BT / 2) opload(cur, dcur, kp + 1);           // next k-pair's operands fly under this one's MFMAs
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                const float *d = dyv[kp & 1][cb];
-                const float e0 = fmaf(wb, d[2], wa * d[0]), e1 = fmaf(wb, d[3], wa * d[1]);
-                const float bq[3] = {e0, e0 + e1, e1};
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    acc[j][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], bq[j], acc[j][cb], 0, 0, 0);
-            }
-            if (kp == 0) vstore(nxt);              // tile s+1 -> LDS
-            else if (kp == 4) xload();             // tile s+2 -> registers
-            __builtin_amdgcn_sched_barrier(0);
+            for (int f = 0; f < 9; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[f], bm[f], acc[f], 0, 0, 0);
+            if (kp == 0) { vstore(nxt); dyload(s + 1); }      // tile s+1: V -> LDS, its dY -> registers
+            else if (kp == 4) xload();                        // tile s+2 -> registers (and its dY offsets)
+            else if (kp == 6) dystore(dnxt);
         }
         __syncthreads();
     }
 
-    // ---- G^T dU G on the partial sums (G = [1 0; 1 1; 0 1]), then atomics.  Ts[i][v][c][k 32], one column block at a time
-    float *Ts = smem;
-    const long CK = (long)C * K;
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int cl = (r & 3) + 8 * (r >> 2) + 4 * kh;
-            Ts[((wave * 2 + 0) * 32 + cl) * 32 + l31] = acc[0][cb][r] + acc[1][cb][r];
-            Ts[((wave * 2 + 1) * 32 + cl) * 32 + l31] = acc[1][cb][r] + acc[2][cb][r];
-        }
+    if (DBIAS && dosum) {                      // (workgroup-uniform) 16 threads per channel quad -> one partial row of the split
+        float *red = smem;                     // the last stage ended with a barrier
+        *reinterpret_cast<float4 *>(red + (tid >> 5) * BK + 4 * (tid & 31)) = dbs;
         __syncthreads();
-        for (int e = tid; e < 32 * 32; e += 192) {
-            const int cc = e >> 5, kk = e & 31;
+        if (tid < BK) {
+            float a = 0.f;
 #pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                const float t0 = Ts[((0 * 2 + v) * 32 + cc) * 32 + kk], t1 = Ts[((1 * 2 + v) * 32 + cc) * 32 + kk];
-                const float t2 = Ts[((2 * 2 + v) * 32 + cc) * 32 + kk];
-                float *dst = dw + (long)(pa * 4 + 2 * v + pb) * CK + (long)(c0 + cc) * K + n0 + cb * 32 + kk;   // tap (r = pa, t = 2v + pb)
-                atomicAdd(dst, t0 + t1);                        // u = 0: tap row 2*0 + pa
-                atomicAdd(dst + 8 * CK, t1 + t2);               // u = 1: tap row 2*1 + pa
+            for (int q = 0; q < NT / 32; ++q) a += red[q * BK + tid];
+            dbpart[(long)(blockIdx.z >> 2) * K + n0 + tid] = a;
+        }
+    }
+    // ---- G^T dU G in registers (G = [1 0; 1 1; 0 1]): tap (row 2u + pa, col 2v + pb) = sum_{i in {u,u+1}, j in {v,v+1}} dU[i][j]
+    const long CK = (long)C * K;
+    float *dst0 = dw + (long)(c0 + wc * 32 + 4 * kh) * K + n0 + wk * 32 + l31;
+    if (PART) dst0 += (long)(blockIdx.z >> 2) * 16 * CK;                // this split's slab of the workspace
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            float *dt = dst0 + (long)((2 * u + pa) * 4 + 2 * v + pb) * CK;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float val = (acc[3 * u + v][r] + acc[3 * u + v + 1][r]) + (acc[3 * u + 3 + v][r] + acc[3 * u + 4 + v][r]);
+                float *d1 = dt + (long)((r & 3) + 8 * (r >> 2)) * K;
+                if (PART) *d1 = val;
+                else atomicAdd(d1, val);
             }
         }
-        __syncthreads();
-    }
 }
 
-// Measured (CIFAR batch 128): 114 / 110 / 99 us on D l2 / l4 / l6 vs 90 / 84 / 78 for the direct split kernel - with
-// only 16/9 fewer multiplies, one VMEM load per MFMA for dY and the atomics it does not pay off yet.  Parity-tested
-// and kept behind MMDGAN_WINO2_WGRAD=1 (or MMDGAN_WINO2=2, which the tests set).
+// dw[e] = sum over the splits' slabs (fixed order: deterministic).  One float4 per thread, eight slab loads in flight.
+// Elements n4 .. n4 + k4 - 1 are the bias gradient: partial rows [split][K] -> dbias.
+__global__ __launch_bounds__(64) void wino2_wgrad_reduce_kernel(const float4 *__restrict__ part, int nsplit, long n4, float4 *__restrict__ dw,
+                                                                const float4 *__restrict__ dbpart, long k4, float4 *__restrict__ dbias) {
+    long e = (long)blockIdx.x * 64 + threadIdx.x;
+    if (e >= n4 + k4) return;
+    long stride = n4;
+    if (e >= n4) { e -= n4; part = dbpart; stride = k4; dw = dbias; }
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0;
+    for (; s + 8 <= nsplit; s += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = part[(long)(s + q) * stride + e];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { a.x += v[q].x; a.y += v[q].y; a.z += v[q].z; a.w += v[q].w; }
+    }
+    for (; s < nsplit; ++s) {
+        const float4 b = part[(long)s * stride + e];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    dw[e] = a;
+}
+
+// MMDGAN_WINO2_WGRAD=0 keeps the stride-2 weight gradients on the direct implicit-GEMM kernel, =1 uses this one;
+// MMDGAN_WINO2=2 (the parity tests) always.
 bool wino2_wgrad_ok(const ConvDims &d) {
     static int en = -1;
-    if (en < 0) { const char *e = getenv("MMDGAN_WINO2_WGRAD"); en = e ? atoi(e) : 0; }
+    if (en < 0) { const char *e = getenv("MMDGAN_WINO2_WGRAD"); en = e ? atoi(e) : W2W_DEFAULT; }
     if ((!en && wino2_mode() < 2) || wino2_mode() == 0) return false;
-    return d.R == 4 && d.stride == 2 && d.pad == 1 && d.H % 4 == 0 && d.W % 4 == 0 && d.C % 32 == 0 && d.K % 64 == 0;
+    return d.R == 4 && d.stride == 2 && d.pad == 1 && d.H % 4 == 0 && d.W % 4 == 0 && d.C % wino2w::BC == 0 && d.K % wino2w::BK == 0;
 }
 
-int wino2_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st) {
+// dbias (optional): the column sums of dy.  Returns 0 with *dbias_done = whether dbias was produced here (workspace path);
+// otherwise the caller sums dy itself.
+int wino2_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, float *dbias, bool *dbias_done, hipStream_t st) {
     const long T = (long)d.N * (d.P / 2) * (d.Q / 2);
     const int nst = (int)((T + wino2w::BT - 1) / wino2w::BT);
-    const long base = (long)(d.C / 32) * (d.K / 64) * 4;
-    int split = (int)((768 + base - 1) / base);                    // ~768 workgroups of 3 waves
-    if (split > nst / 4) split = nst / 4 > 0 ? nst / 4 : 1;         // >= 4 stages (288 MFMAs per wave) per workgroup
-    int sps = (nst + split - 1) / split;
-    split = (nst + sps - 1) / sps;
-    if (zero_output(dw, sizeof(float) * 16 * (size_t)d.C * d.K, st) != hipSuccess) return check_launch("conv2d_wgrad memset");
-    hipLaunchKernelGGL(wino2_wgrad_kernel, dim3(d.C / 32, d.K / 64, 4 * split), dim3(192), wino2w::LDS_BYTES, st, d.N, d.H, d.W, d.C,
-                       d.K, x, dy, dw, sps);
+    const long base = (long)(d.C / wino2w::BC) * (d.K / wino2w::BK) * 4;
+    int split = (int)(256 / base);                                  // one 8-wave workgroup per CU (140 KB of LDS), one round
+    if (split > nst / 2) split = nst / 2;                           // >= 2 stages (144 MFMAs per wave) per workgroup
+    if (split < 1) split = 1;
+    const int sps = (nst + split - 1) / split;
+    split = (nst + sps - 1) / sps;                                  // every slab gets written
+    const size_t n = 16 * (size_t)d.C * d.K;
+    static bool cap_raised = false;
+    if (!cap_raised) {
+        (void)hipFuncSetAttribute((const void *)wino2_wgrad_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino2w::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)wino2_wgrad_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino2w::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)wino2_wgrad_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino2w::LDS_BYTES);
+        cap_raised = true;
+    }
+    if (dbias_done) *dbias_done = false;
+    const dim3 grid(d.C / wino2w::BC, d.K / wino2w::BK, 4 * split);
+    if (float *part = (float *)workspace(sizeof(float) * (n + d.K) * split)) {
+        float *dbpart = part + n * split;
+        if (dbias)
+            hipLaunchKernelGGL((wino2_wgrad_kernel<true, true>), grid, dim3(wino2w::NT), wino2w::LDS_BYTES, st, d.N, d.H, d.W, d.C, d.K, x, dy, part,
+                               dbpart, sps);
+        else
+            hipLaunchKernelGGL((wino2_wgrad_kernel<true, false>), grid, dim3(wino2w::NT), wino2w::LDS_BYTES, st, d.N, d.H, d.W, d.C, d.K, x, dy, part,
+                               dbpart, sps);
+        const long n4 = (long)(n / 4), k4 = dbias ? d.K / 4 : 0;
+        hipLaunchKernelGGL(wino2_wgrad_reduce_kernel, dim3((unsigned)((n4 + k4 + 63) / 64)), dim3(64), 0, st, (const float4 *)part, split, n4,
+                           (float4 *)dw, (const float4 *)dbpart, k4, (float4 *)dbias);
+        if (dbias_done) *dbias_done = dbias != nullptr;
+        return check_launch("conv2d_wgrad(winograd 2x2)");
+    }
+    if (split == 1) {                           // one slab: straight into dw
+        hipLaunchKernelGGL((wino2_wgrad_kernel<true, false>), grid, dim3(wino2w::NT), wino2w::LDS_BYTES, st, d.N, d.H, d.W, d.C, d.K, x, dy, dw,
+                           (float *)nullptr, sps);
+        return check_launch("conv2d_wgrad(winograd 2x2)");
+    }
+    if (zero_output(dw, sizeof(float) * n, st) != hipSuccess) return check_launch("conv2d_wgrad memset");
+    hipLaunchKernelGGL((wino2_wgrad_kernel<false, false>), grid, dim3(wino2w::NT), wino2w::LDS_BYTES, st, d.N, d.H, d.W, d.C, d.K, x, dy, dw,
+                       (float *)nullptr, sps);
     return check_launch("conv2d_wgrad(winograd 2x2)");
 }
 

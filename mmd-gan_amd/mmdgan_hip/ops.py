@@ -39,7 +39,7 @@ def require_device():
 _workspace = None
 
 
-def set_workspace(nbytes=32 << 20, device=None):
+def set_workspace(nbytes=64 << 20, device=None):
     """register a torch-owned scratch buffer with the library (mmdgan_set_workspace)."""
     global _workspace
     lib = require_device()
@@ -52,7 +52,7 @@ class Handle:
     """an mmdgan_handle (include/mmdgan_hip.h): one engine's workspace, prezeroed mode, launch plans and events.
     `with handle:` makes it the calling thread's current handle and restores the process default afterwards."""
 
-    def __init__(self, workspace_bytes=32 << 20, device=None):
+    def __init__(self, workspace_bytes=64 << 20, device=None):
         lib = require_device()
         h = ctypes.c_void_p()
         check(lib.mmdgan_create(ctypes.byref(h)), 'create')

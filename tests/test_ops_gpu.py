@@ -371,7 +371,7 @@ def test_conv_full_size_adjointness_and_linearity(ops, case):
 
 
 WINO2_CASES = [(16, 16, 16, 64, 128, 4, 2), (30, 12, 12, 32, 64, 4, 2), (6, 8, 16, 64, 64, 4, 2), (9, 4, 4, 128, 64, 4, 2),
-               (33, 8, 8, 96, 192, 4, 2)]
+               (33, 8, 8, 96, 192, 4, 2), (5, 12, 8, 64, 128, 4, 2), (9, 4, 4, 128, 256, 4, 2), (70, 8, 8, 64, 128, 4, 2)]
 
 
 @pytest.mark.parametrize('case', WINO2_CASES, ids=[str(c) for c in WINO2_CASES])
@@ -389,7 +389,7 @@ def test_conv2d_winograd_stride2_path(ops, case):
     wt.requires_grad_(True)
     gx, gw = torch.autograd.grad((R.conv2d_same(xt, wt, s) * torch.tensor(dy, dtype=torch.float64)).sum(), [xt, wt])
     wt = wt.detach()
-    if C % 32 == 0 and K % 64 == 0:                      # F(2x2,2x2)-domain weight gradient, four tap-parity problems
+    if C % 64 == 0 and K % 128 == 0:                     # F(2x2,2x2)-domain weight gradient, four tap-parity problems
         dw = ops.conv2d_wgrad(nhwc(x), nhwc(dy), ksz, s)
         assert rel_err(dw.cpu().numpy(), gw.numpy()) <= RTOL
     fwd_ok, bwd_ok = ops.wino_eligible(N, H, W, C, K, ksz, s, False), ops.wino_eligible(N, H, W, C, K, ksz, s, True)
@@ -422,6 +422,16 @@ def test_conv2d_winograd_stride2_path(ops, case):
         assert rel_err(to_nchw(y), yt.detach().numpy()) <= RTOL
         dx = ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s)
         assert rel_err(to_nchw(dx), gx.numpy()) <= RTOL
+        if C % 64 == 0 and K % 128 == 0:       # weight gradient: per-split partial slabs in the workspace + one reduction pass
+            dw2 = torch.full((ksz, ksz, C, K), float('nan'), device='cuda')      # no zeroing needed, and twice the same bits
+            ops.conv2d_wgrad(nhwc(x), nhwc(dy), ksz, s, out=dw2)
+            assert rel_err(dw2.cpu().numpy(), gw.numpy()) <= RTOL
+            dw3 = ops.conv2d_wgrad(nhwc(x), nhwc(dy), ksz, s)
+            assert torch.equal(dw2, dw3)
+            db = torch.full((K,), float('nan'), device='cuda')                   # the bias gradient rides along in the same kernel
+            dw4 = ops.conv2d_wgrad(nhwc(x), nhwc(dy), ksz, s, dbias=db)
+            assert torch.equal(dw2, dw4)
+            assert rel_err(db.cpu().numpy(), dy.astype(np.float64).sum((0, 2, 3))) <= RTOL
     finally:
         ops.require_device().mmdgan_set_workspace(None, 0)
 
