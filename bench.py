@@ -90,6 +90,7 @@ def dominant_kernel_probe(eng, reps=20, warm=3):
             # algorithmic bytes: dy [3B,h/2,w/2,K] + the activations act'(y) for 3B rows + the transformed weights read, dx written
             'alg_bytes_read': 4.0 * (3 * B * (h // 2) * (w // 2) * s.out + 3 * B * h * w * c + 36 * c * s.out),
             'alg_bytes_write': 4.0 * 3 * B * h * w * c,
+            'mfma_share': 9.0 / 16 if wino is not None else 1.0,       # F(2x2,2x2): 9 multiplies per 16 algorithmic ones
             'flops': flops, 'ms': ms, 'tflops': flops / ms / 1e9}
 
 
@@ -121,8 +122,10 @@ def dominant_kernel_probe_tape(eng, reps=20, warm=3):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    return {'kernel': 'conv2d_wgrad(%s: %dx%dx%d -> %d 3x3, %d rows; wino_wgrad_kernel F(2x2,3x3))' % (k.scope, h, w, c, kout, n),
+    return {'kernel': 'conv2d_wgrad(%s: %dx%dx%d -> %d 3x3, %d rows; %s F(2x2,3x3))' % (
+                k.scope, h, w, c, kout, n, 'wino_wgrad_slab_kernel + slab_reduce_kernel' if kout % 128 == 0 else 'wino_wgrad_kernel'),
             'alg_bytes_read': 4.0 * n * h * w * (c + kout), 'alg_bytes_write': 4.0 * 9 * c * kout,
+            'mfma_share': 16.0 / 36,                                   # F(2x2,3x3): 16 multiplies per 36 algorithmic ones
             'flops': flops, 'ms': ms, 'tflops': flops / ms / 1e9}
 
 
@@ -308,6 +311,10 @@ def main():
             # a config -> traffic null, never another config's number.
             out['roofline'] = {'bound': 'mfma', 'achieved': probe['tflops'], 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': probe['tflops'] / PEAK_FP32_MFMA_TFLOPS,
+                               # `achieved` counts the ALGORITHMIC FLOPs of the convolution; the Winograd kernels issue only
+                               # `mfma_share` of them as MFMAs (so `frac` can pass 1): the pipe itself is busy frac_issued
+                               'mfma_share': probe.get('mfma_share', 1.0),
+                               'frac_issued': probe['tflops'] * probe.get('mfma_share', 1.0) / PEAK_FP32_MFMA_TFLOPS,
                                'traffic': committed.get('hbm_bytes_per_launch'),
                                'traffic_over_algorithmic': committed.get('traffic_over_algorithmic'),
                                'algorithmic_bytes_per_launch': (committed.get('algorithmic_bytes_per_launch') or {}).get('total'),

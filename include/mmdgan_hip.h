@@ -83,10 +83,16 @@ int mmdgan_destroy(mmdgan_handle *h);          /* destroys its plans and events;
 int mmdgan_make_current(mmdgan_handle *h);     /* NULL: back to the process default handle */
 
 /* Optional caller-owned device scratch (the library itself allocates nothing).  Kernels that would
- * otherwise combine per-workgroup partial results with contended atomics (thin-layer weight
- * gradients) write their partials here and reduce them in a second pass when the registered region
- * is large enough; without it they fall back to atomics.  One region per HANDLE; calls that use it
- * must be ordered on one stream.  ptr == NULL unregisters. */
+ * otherwise combine per-workgroup partial results with contended atomics write their partials here
+ * and reduce them in a second pass when the registered region is large enough; without it they fall
+ * back to atomics (or to the direct kernels).  Users: the thin-layer weight gradients, the
+ * Winograd-domain weight gradients of the 3x3 / stride-1 and 4x4 / stride-2 layers (one slab of
+ * dw's size per split of the pixel range: <= 256 workgroups x 4 x 64 x 128 floats = 33.6 MB and
+ * <= 256 x 9 x 32 x 128 floats = 37.8 MB, plus the bias-gradient rows), and the in-call Winograd
+ * weight transforms of callers that do not pass transformed weights.  64 MB covers every shape of
+ * the reference's architectures.  One region per HANDLE; calls that use it must be ordered on ONE
+ * stream (the engines issue every weight gradient on their weight-gradient stream and transform
+ * weights once per step).  ptr == NULL unregisters. */
 int mmdgan_set_workspace(void *ptr, size_t bytes);
 /* Several entries accumulate into their output with atomics (split reductions, column sums, dot)
  * and zero it first with an internal memset node.  A caller that zeroes those outputs itself - e.g.
@@ -179,7 +185,8 @@ int mmdgan_conv2d_dgrad(const mmdgan_conv_geom *g, const float *dy, const float 
                         const float *scale, int act, const float *dact_of, int dact_batch, float *dx, void *stream);
 
 /* dw[R,R,C,K] = sum over pixels x (x) dy                   autodiff of conv2d / conv2d_transpose
- * dw is overwritten. */
+ * dw is overwritten.  With a workspace registered the 3x3 / stride-1 (C % 32, K % 128) and 4x4 / stride-2 (C % 64,
+ * K % 128) layers run in the Winograd domain with slab partial sums: no atomics, bit-reproducible. */
 int mmdgan_conv2d_wgrad(const mmdgan_conv_geom *g, const float *x, const float *dy, float *dw, void *stream);
 /* the same plus dbias[K] = column sums of dy (tf.nn.bias_add's gradient, layer_func.py:946): the MFMA kernel adds up
  * the dy tiles it streams anyway instead of a second pass over dy.  dbias is overwritten. */

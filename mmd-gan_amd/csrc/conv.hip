@@ -133,8 +133,9 @@ static int wgrad_impl(const mmdgan_conv_geom *g, const float *x, const float *dy
     MMDGAN_REQUIRE(x && dy && dw, "%s: null pointer", what);
     const ConvDims d = conv_dims(*g);
     if (!force_direct() && (wino_wgrad_ok(d) || wino2_wgrad_ok(d))) {
-        bool db_done = false;                      // the stride-2 kernel sums dy on the way when it has a workspace
-        int rcw = d.R == 3 ? wino_wgrad(d, x, dy, dw, (hipStream_t)stream) : wino2_wgrad(d, x, dy, dw, dbias, &db_done, (hipStream_t)stream);
+        bool db_done = false;                      // the slab kernels sum dy on the way
+        int rcw = d.R == 3 ? wino_wgrad(d, x, dy, dw, dbias, &db_done, (hipStream_t)stream)
+                           : wino2_wgrad(d, x, dy, dw, dbias, &db_done, (hipStream_t)stream);
         if (rcw == 0 && dbias && !db_done) rcw = mmdgan_colsum(dy, (long)d.N * d.P * d.Q, d.K, dbias, stream);
         return rcw;
     }

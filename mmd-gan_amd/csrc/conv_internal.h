@@ -60,7 +60,9 @@ int wino_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const
 // in-place bias / activation / activation-derivative pass after a split-reduction launch (conv_wino.hip)
 int epilogue_pass(float *y, long total, int Ko, const ConvEpilogue &ep, hipStream_t st);
 bool wino_wgrad_ok(const ConvDims &d);
-int wino_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st);
+int wino_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, float *dbias, bool *dbias_done, hipStream_t st);
+// dw[n] = sum of nsplit slabs of n floats; dbias[k] = sum of nsplit rows of k floats (k = 0: none).  conv_wino2.hip
+void slab_reduce(const float *part, int nsplit, size_t n, float *dw, const float *dbpart, int k, float *dbias, hipStream_t st);
 
 // Winograd F(2x2,2x2) for 4x4 / stride-2 layers and their input-gradient (conv_wino2.hip); U = 36*C*K floats
 bool wino2_eligible(const ConvDims &d, bool dgrad);

@@ -607,6 +607,225 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(int N, int H, int W,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Second design of the same product (what the stride-2 kernel in conv_wino2.hip taught): workgroup = 32 input channels x
+// 128 output channels, eight waves = (column quarter, frequency rows {0,1} | {2,3}), each with eight 32x32 accumulators;
+//   * a stage is 16 tiles = 8 k-pairs = 64 MFMAs per wave; V as above (all 512 threads: tile, channel quad, patch row) but
+//     stored [f][k-pair][tile parity][32 c] with one ds_write_b128 per frequency (the A fragment of a k-pair is 64 consecutive
+//     words);
+//   * the 2x2 dY pixels of the stage's tiles go through LDS (coalesced float4 loads by all threads, 4 each) instead of eight
+//     dword gathers per lane and k-pair; dM rows are built in registers from four LDS words: 12 LDS words per 8 MFMAs;
+//   * the two frequency-row halves swap half of their j-transformed partial sums through LDS, finish G^T dU G in registers
+//     and store the workgroup's 9 x 32 x 128 partial result into its slab of the library workspace [split][9][C][K]; the
+//     slab reduction of conv_wino2.hip sums them (no zeroing, no atomics, deterministic) together with the bias gradient,
+//     which rides along in the workgroups of channel block 0.
+namespace winos {
+constexpr int BT = 16, BC = 32, BK = 128, NT = 512;
+constexpr int FS = BT * BC + 4;               // V: floats per frequency (+4: the four patch-row lanes of a quad hit different banks)
+constexpr int V_FLOATS = 16 * FS;
+constexpr int DYT = 4 * BK + 32;              // dY stage tile: floats per tile, [4 pixels][128 channels] (+32: half-waves on disjoint banks)
+constexpr int DY_FLOATS = BT * DYT;
+constexpr int EX_FLOATS = 8 * 48 * 64;        // epilogue exchange: [wave][48 values][lane]
+constexpr int MAIN_FLOATS = 2 * V_FLOATS + 2 * DY_FLOATS;
+constexpr int SMEM_FLOATS = MAIN_FLOATS > EX_FLOATS ? MAIN_FLOATS : EX_FLOATS;
+constexpr size_t LDS_BYTES = sizeof(float) * SMEM_FLOATS + sizeof(unsigned) * 4 * BT;
+constexpr int DYV = BT * 4 * (BK / 4) / NT;   // float4 items of the dY stage tile per thread (4)
+static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+}  // namespace winos
+
+template <bool DBIAS>
+__global__ __launch_bounds__(winos::NT) void wino_wgrad_slab_kernel(int N, int H, int W, int C, int K, const float *__restrict__ x,
+                                                                    const float *__restrict__ dy, float *__restrict__ part,
+                                                                    float *__restrict__ dbpart, int stages_per_split) {
+    using namespace winos;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wv & 3, fh = wv >> 2;                       // 32-column quarter of the 128, frequency rows 2fh, 2fh + 1
+    const int TH = H >> 1, TW = W >> 1;
+    const long T = (long)N * TH * TW;
+    const int nst_all = (int)((T + BT - 1) / BT);
+    const int c0 = blockIdx.x * BC, n0 = blockIdx.y * BK;
+    const int s0 = blockIdx.z * stages_per_split, s1 = min(nst_all, s0 + stages_per_split);
+    if (s0 >= s1) return;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (long)N * H * W * C * 4);
+    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, (long)N * H * W * K * 4);
+    float *Vs = smem, *DYs = smem + 2 * V_FLOATS;
+    unsigned *dyoff = reinterpret_cast<unsigned *>(smem + SMEM_FLOATS);      // [stage & 3][tile of the stage]
+    // ---- producer of V: thread = (tile of the stage pt, channel quad pp, patch row pr)
+    const int pt = tid >> 5, pp = (tid >> 2) & 7, pr = tid & 3;
+    TileWalk pw = make_walk((long)s0 * BT + pt, TW, TH);
+    const TileStep stepT = make_step(BT, TW, TH);
+    const float sa = pr == 3 ? -1.f : 1.f, sb = (pr & 1) ? 1.f : -1.f;
+    const int vdst = (pr * 4) * FS + (pt >> 1) * 64 + (pt & 1) * 32 + 4 * pp;
+    float4 rin[4];
+    int pstage = s0;                          // stage the producer is loading
+    auto xload = [&]() {                      // the 4 pixels of patch row pr of the producer's current tile, then advance
+        const bool ok = pw.n < N && pstage < s1;             // beyond the batch (ragged last stage) or the split: no traffic
+        if ((tid & 31) == 0)                  // byte offset of dY pixel (2ty, 2tx), channel 0, of this tile (the dY producers add the rest)
+            dyoff[(pstage & 3) * BT + pt] = ok ? (unsigned)((((pw.n * H + 2 * pw.ty) * W + 2 * pw.tx) * K) * 4) : kOOB;
+        ++pstage;
+        const int y = 2 * pw.ty - 1 + pr;
+        const bool rowok = ok && y >= 0 && y < H;
+        const unsigned base = (unsigned)((((pw.n * H + y) * W + 2 * pw.tx - 1) * C + c0 + 4 * pp) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int xx = 2 * pw.tx - 1 + j;
+            rin[j] = bufld4(rx, (rowok && xx >= 0 && xx < W) ? base + (unsigned)(j * C * 4) : kOOB);
+        }
+        advance(pw, stepT, TW, TH);
+    };
+    auto vstore = [&](float *buf) {
+        float X[4][4];
+        X[0][0] = rin[0].x - rin[2].x; X[0][1] = rin[0].y - rin[2].y; X[0][2] = rin[0].z - rin[2].z; X[0][3] = rin[0].w - rin[2].w;
+        X[1][0] = rin[1].x + rin[2].x; X[1][1] = rin[1].y + rin[2].y; X[1][2] = rin[1].z + rin[2].z; X[1][3] = rin[1].w + rin[2].w;
+        X[2][0] = rin[2].x - rin[1].x; X[2][1] = rin[2].y - rin[1].y; X[2][2] = rin[2].z - rin[1].z; X[2][3] = rin[2].w - rin[1].w;
+        X[3][0] = rin[1].x - rin[3].x; X[3][1] = rin[1].y - rin[3].y; X[3][2] = rin[1].z - rin[3].z; X[3][3] = rin[1].w - rin[3].w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int other = __builtin_amdgcn_update_dpp(0, __float_as_int(X[j][e]), 0x5A, 0xF, 0xF, false);   // quad_perm [2,2,1,1]
+                o[e] = fmaf(sb, __int_as_float(other), sa * X[j][e]);
+            }
+            *reinterpret_cast<float4 *>(buf + vdst + j * FS) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    };
+    // ---- producer of the dY stage tile: item = (tile, pixel of its 2x2, channel quad of the 128), all threads
+    const unsigned dyrow = (unsigned)(W * K * 4), dypix = (unsigned)(K * 4);
+    const bool dosum = DBIAS && blockIdx.x == 0;
+    float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 rdyv[DYV];
+    auto dyload = [&](int stage) {            // needs dyoff[stage], written at least one barrier ago
+#pragma unroll
+        for (int it = 0; it < DYV; ++it) {
+            const int e = tid + it * NT;
+            const int tile = e >> 7, px = (e >> 5) & 3, kq = e & 31;
+            const unsigned off = dyoff[(stage & 3) * BT + tile];
+            rdyv[it] = bufld4(rdy, off == kOOB ? kOOB : off + (px >> 1) * dyrow + (px & 1) * dypix + (unsigned)((n0 + 4 * kq) * 4));
+        }
+    };
+    auto dystore = [&](float *buf) {          // (tiles beyond the split were not loaded: zeros)
+#pragma unroll
+        for (int it = 0; it < DYV; ++it) {
+            const int e = tid + it * NT;
+            const int tile = e >> 7, px = (e >> 5) & 3, kq = e & 31;
+            *reinterpret_cast<float4 *>(buf + tile * DYT + px * BK + 4 * kq) = rdyv[it];
+            if (dosum) { dbs.x += rdyv[it].x; dbs.y += rdyv[it].y; dbs.z += rdyv[it].z; dbs.w += rdyv[it].w; }
+        }
+    };
+    // A dY A^T, A = [1 0; 1 1; 1 -1; 0 -1]: this wave's rows i = 2fh, 2fh + 1 of e = A dY:  (1,0),(1,1) | (1,-1),(0,-1)
+    const float a0 = 1.f, a1 = fh ? -1.f : 0.f, b0 = fh ? 0.f : 1.f, b1 = fh ? -1.f : 1.f;
+
+    f32x16 acc[8];                             // [row of the wave 2][j 4]
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    xload();
+    vstore(Vs);
+    xload();
+    __syncthreads();                          // dyoff[s0], dyoff[s0 + 1] visible
+    dyload(s0);
+    dystore(DYs);
+    __syncthreads();
+    const int abase = (8 * fh) * FS + lane;                  // + f * FS + kp * 64
+    const int dbase = kh * DYT + wk * 32 + l31;              // + 2 kp * DYT + pixel * BK
+    float fa[8], dv[4];
+    auto opload = [&](const float *cur, const float *dcur, int kp) {     // operands of k-pair kp: 8 + 4 LDS words
+#pragma unroll
+        for (int f = 0; f < 8; ++f) fa[f] = cur[abase + f * FS + kp * 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dv[q] = dcur[dbase + 2 * kp * DYT + q * BK];
+    };
+    for (int s = s0; s < s1; ++s) {
+        const int b = (s - s0) & 1;
+        const float *cur = Vs + b * V_FLOATS, *dcur = DYs + b * DY_FLOATS;
+        float *nxt = Vs + (b ^ 1) * V_FLOATS, *dnxt = DYs + (b ^ 1) * DY_FLOATS;
+        opload(cur, dcur, 0);
+#pragma unroll
+        for (int kp = 0; kp < BT / 2; ++kp) {
+            const float ea0 = fmaf(a1, dv[2], a0 * dv[0]), ea1 = fmaf(a1, dv[3], a0 * dv[1]);     // row 2fh
+            const float eb0 = fmaf(b1, dv[2], b0 * dv[0]), eb1 = fmaf(b1, dv[3], b0 * dv[1]);     // row 2fh + 1
+            const float bm[8] = {ea0, ea0 + ea1, ea0 - ea1, -ea1, eb0, eb0 + eb1, eb0 - eb1, -eb1};
+            float a[8];
+#pragma unroll
+            for (int f = 0; f < 8; ++f) a[f] = fa[f];
+            if (kp + 1 < BT / 2) opload(cur, dcur, kp + 1);           // next k-pair's operands fly under this one's MFMAs
+#pragma unroll
+            for (int f = 0; f < 8; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[f], bm[f], acc[f], 0, 0, 0);
+            if (kp == 0) { vstore(nxt); dyload(s + 1); }      // tile s+1: V -> LDS, its dY -> registers
+            else if (kp == 4) xload();                        // tile s+2 -> registers (and its dY offsets)
+            else if (kp == 6) dystore(dnxt);
+        }
+        __syncthreads();
+    }
+
+    if (dosum) {                               // (workgroup-uniform) 16 threads per channel quad -> one partial row of the split
+        *reinterpret_cast<float4 *>(smem + (tid >> 5) * BK + 4 * (tid & 31)) = dbs;
+        __syncthreads();
+        if (tid < BK) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < NT / 32; ++q) t += smem[q * BK + tid];
+            dbpart[(long)blockIdx.z * K + n0 + tid] = t;
+        }
+        __syncthreads();
+    }
+    // ---- G^T dU G, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1].  j direction in registers: rows (2fh, 2fh+1) x taps t = 0..2;
+    // then the wave keeps accumulator registers [8 fh, 8 fh + 8) and gets the partner wave's rows for them through LDS.
+    float *ex = smem;
+    {
+        float *mine = ex + (wv * 48) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = q + 8 * (1 - fh);              // the half the partner keeps
+#pragma unroll
+            for (int row = 0; row < 2; ++row) {
+                const float u0 = acc[4 * row][r], u1 = acc[4 * row + 1][r], u2 = acc[4 * row + 2][r], u3 = acc[4 * row + 3][r];
+                const float h = 0.5f * (u1 + u2);
+                mine[((row * 3 + 0) * 8 + q) * 64] = u0 + h;
+                mine[((row * 3 + 1) * 8 + q) * 64] = 0.5f * (u1 - u2);
+                mine[((row * 3 + 2) * 8 + q) * 64] = h + u3;
+            }
+        }
+    }
+    __syncthreads();
+    const long CK = (long)C * K;
+    float *dst0 = part + (long)blockIdx.z * 9 * CK + (long)(c0 + 4 * kh) * K + n0 + wk * 32 + l31;
+    const float *theirs = ex + ((wv ^ 4) * 48) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int r = q + 8 * fh;
+        float *dr = dst0 + (long)((r & 3) + 8 * (r >> 2)) * K;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            float own[2];
+#pragma unroll
+            for (int row = 0; row < 2; ++row) {
+                const float u0 = acc[4 * row][r], u1 = acc[4 * row + 1][r], u2 = acc[4 * row + 2][r], u3 = acc[4 * row + 3][r];
+                const float h = 0.5f * (u1 + u2);
+                own[row] = t == 0 ? u0 + h : (t == 1 ? 0.5f * (u1 - u2) : h + u3);
+            }
+            const float o0 = theirs[((0 * 3 + t) * 8 + q) * 64], o1 = theirs[((1 * 3 + t) * 8 + q) * 64];
+            // rows i = 0..3 of the j-transformed sums
+            const float T0 = fh ? o0 : own[0], T1 = fh ? o1 : own[1], T2 = fh ? own[0] : o0, T3 = fh ? own[1] : o1;
+            const float hh = 0.5f * (T1 + T2);
+            dr[(long)(0 * 3 + t) * CK] = T0 + hh;
+            dr[(long)(1 * 3 + t) * CK] = 0.5f * (T1 - T2);
+            dr[(long)(2 * 3 + t) * CK] = hh + T3;
+        }
+    }
+}
+
+bool wino_wgrad_slab_ok(const ConvDims &d) {
+    static int en = -1;
+    if (en < 0) { const char *e = getenv("MMDGAN_WINO_WGRAD_SLAB"); en = (e && e[0] == '0') ? 0 : 1; }
+    return en && d.C % winos::BC == 0 && d.K % winos::BK == 0;
+}
+
 bool wino_wgrad_ok(const ConvDims &d) {
     static int en = -1;
     if (en < 0) { const char *e = getenv("MMDGAN_WINO_WGRAD"); en = (e && e[0] == '0') ? 0 : 1; }
@@ -614,8 +833,39 @@ bool wino_wgrad_ok(const ConvDims &d) {
            d.K % 64 == 0 && (long)d.N * (d.H / 2) * (d.W / 2) >= (wino_min_tiles() < 256 ? wino_min_tiles() : 256);   // 79 vs 89 us at 512 tiles (D l7)
 }
 
-int wino_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st) {
+// dbias (optional): the column sums of dy; *dbias_done says whether they were produced here (slab path)
+int wino_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, float *dbias, bool *dbias_done, hipStream_t st) {
     const long T = (long)d.N * (d.H / 2) * (d.W / 2);
+    if (dbias_done) *dbias_done = false;
+    if (wino_wgrad_slab_ok(d)) {
+        const int nst = (int)((T + winos::BT - 1) / winos::BT);
+        const long base = (long)(d.C / winos::BC) * (d.K / winos::BK);
+        int split = (int)(256 / base);                                  // one 8-wave workgroup per CU, one round
+        if (split > nst / 2) split = nst / 2;                           // >= 2 stages (128 MFMAs per wave) per workgroup
+        if (split < 1) split = 1;
+        const int sps = (nst + split - 1) / split;
+        split = (nst + sps - 1) / sps;                                  // every slab gets written
+        const size_t n = 9 * (size_t)d.C * d.K;
+        if (float *part = (float *)workspace(sizeof(float) * (n + d.K) * split)) {
+            static bool cap_raised = false;
+            if (!cap_raised) {
+                (void)hipFuncSetAttribute((const void *)wino_wgrad_slab_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)winos::LDS_BYTES);
+                (void)hipFuncSetAttribute((const void *)wino_wgrad_slab_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)winos::LDS_BYTES);
+                cap_raised = true;
+            }
+            float *dbpart = part + n * split;
+            const dim3 grid(d.C / winos::BC, d.K / winos::BK, split);
+            if (dbias)
+                hipLaunchKernelGGL(wino_wgrad_slab_kernel<true>, grid, dim3(winos::NT), winos::LDS_BYTES, st, d.N, d.H, d.W, d.C, d.K, x, dy, part,
+                                   dbpart, sps);
+            else
+                hipLaunchKernelGGL(wino_wgrad_slab_kernel<false>, grid, dim3(winos::NT), winos::LDS_BYTES, st, d.N, d.H, d.W, d.C, d.K, x, dy, part,
+                                   dbpart, sps);
+            slab_reduce(part, split, n, dw, dbpart, dbias ? d.K : 0, dbias, st);
+            if (dbias_done) *dbias_done = dbias != nullptr;
+            return check_launch("conv2d_wgrad(winograd)");
+        }
+    }
     const int nst = (int)((T + winow::BT - 1) / winow::BT);
     const long base = (long)(d.C / 32) * (d.K / 64);
     int split = (int)((512 + base - 1) / base);                    // ~512 workgroups

@@ -632,7 +632,7 @@ __global__ __launch_bounds__(wino2w::NT) void wino2_wgrad_kernel(int N, int H, i
 
 // dw[e] = sum over the splits' slabs (fixed order: deterministic).  One float4 per thread, eight slab loads in flight.
 // Elements n4 .. n4 + k4 - 1 are the bias gradient: partial rows [split][K] -> dbias.
-__global__ __launch_bounds__(64) void wino2_wgrad_reduce_kernel(const float4 *__restrict__ part, int nsplit, long n4, float4 *__restrict__ dw,
+__global__ __launch_bounds__(64) void slab_reduce_kernel(const float4 *__restrict__ part, int nsplit, long n4, float4 *__restrict__ dw,
                                                                 const float4 *__restrict__ dbpart, long k4, float4 *__restrict__ dbias) {
     long e = (long)blockIdx.x * 64 + threadIdx.x;
     if (e >= n4 + k4) return;
@@ -652,6 +652,12 @@ __global__ __launch_bounds__(64) void wino2_wgrad_reduce_kernel(const float4 *__
         a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
     dw[e] = a;
+}
+
+void slab_reduce(const float *part, int nsplit, size_t n, float *dw, const float *dbpart, int k, float *dbias, hipStream_t st) {
+    const long n4 = (long)(n / 4), k4 = k / 4;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n4 + k4 + 63) / 64)), dim3(64), 0, st, (const float4 *)part, nsplit, n4, (float4 *)dw,
+                       (const float4 *)dbpart, k4, (float4 *)dbias);
 }
 
 // MMDGAN_WINO2_WGRAD=0 keeps the stride-2 weight gradients on the direct implicit-GEMM kernel, =1 uses this one;
@@ -692,9 +698,7 @@ int wino2_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, f
         else
             hipLaunchKernelGGL((wino2_wgrad_kernel<true, false>), grid, dim3(wino2w::NT), wino2w::LDS_BYTES, st, d.N, d.H, d.W, d.C, d.K, x, dy, part,
                                dbpart, sps);
-        const long n4 = (long)(n / 4), k4 = dbias ? d.K / 4 : 0;
-        hipLaunchKernelGGL(wino2_wgrad_reduce_kernel, dim3((unsigned)((n4 + k4 + 63) / 64)), dim3(64), 0, st, (const float4 *)part, split, n4,
-                           (float4 *)dw, (const float4 *)dbpart, k4, (float4 *)dbias);
+        slab_reduce(part, split, n, dw, dbpart, dbias ? d.K : 0, dbias, st);
         if (dbias_done) *dbias_done = dbias != nullptr;
         return check_launch("conv2d_wgrad(winograd 2x2)");
     }

@@ -447,7 +447,6 @@ class GanEngine:
         self._wg_raw, self._comm_raw = self._wg_stream.cuda_stream, self._comm_stream.cuda_stream
         self._sn_raw = [st.cuda_stream for st in self._sn_streams]
         self._early_d_adam = os.environ.get('MMDGAN_EARLY_D_ADAM', '1') != '0'
-        self._thin_on_main = os.environ.get('MMDGAN_THIN_ON_MAIN') == '1'
         self._side_wgrad = os.environ.get('MMDGAN_SIDE_WGRAD', '1') != '0'
         if ops._workspace is None:
             ops.set_workspace(device=self.device)                        # the default handle's (eval paths, stand-alone ops)
@@ -756,11 +755,10 @@ class GanEngine:
     def _on_wg_stream(self, fn, spec):
         """run the parameter-gradient launches of one layer on the weight-gradient stream (ordered after
         everything issued so far on the current stream).  That includes the thin first / last layers, whose weight
-        gradients put their partial sums in the library's shared workspace: in the backward pass this stream is the
-        workspace's only user - every Winograd launch of the main stream gets weights transformed at step start,
-        never an in-call transform (MMDGAN_THIN_ON_MAIN=1 keeps them on the main stream)."""
-        thin = spec.op != 'd' and (spec.kernel_shape[2] % 64 or spec.kernel_shape[3] % 64)
-        if not self._side_wgrad or (thin and self._thin_on_main):
+        gradients put their partial sums in the library's shared workspace, and the Winograd-domain weight gradients
+        with their per-split slabs: in the backward pass this stream is the workspace's only user - every Winograd
+        launch of the main stream gets weights transformed at step start, never an in-call transform."""
+        if not self._side_wgrad:
             fn()
             return
         ops.stream_wait(self._wg_raw, ops._stream())

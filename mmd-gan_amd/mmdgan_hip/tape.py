@@ -769,9 +769,10 @@ class TapeEngine:
                             st = net.sn[k.scope]
                             ops.dot(gw.view(-1), w.view(-1), out=st['dot'])
                             ops.sn_wgrad_fixup(gw.view(-1), st['dsigma'].view(-1), st['dot'], st['sigma'], scale)
-                    # kernels that use the library's shared workspace (thin first / last layers) stay on this stream
-                    thin = kind == 'conv' and (k.kernel_shape[2] % 64 or k.kernel_shape[3] % 64)
-                    if self._side and not thin:
+                    # every weight gradient goes to the side stream: it is the only user of the library's shared workspace
+                    # during the backward pass (slab partial sums of the Winograd-domain kernels, partials of the thin
+                    # first / last layers); the main stream's Winograd launches get weights transformed at step start
+                    if self._side:
                         self._wg_stream.wait_stream(torch.cuda.current_stream())
                         with torch.cuda.stream(self._wg_stream):
                             param_grads_of()
@@ -805,8 +806,7 @@ class TapeEngine:
                             st = net.sn[k.scope]
                             ops.dot(gw.view(-1), w.view(-1), out=st['dot'])
                             ops.sn_wgrad_fixup(gw.view(-1), st['dsigma'].view(-1), st['dot'], st['sigma'], scale)
-                    thin = k.kernel_shape[2] % 64 or k.kernel_shape[3] % 64
-                    if self._side and not thin:
+                    if self._side:
                         self._wg_stream.wait_stream(torch.cuda.current_stream())
                         with torch.cuda.stream(self._wg_stream):
                             folded_grads()
@@ -828,8 +828,7 @@ class TapeEngine:
                         if k.bias_name is not None:
                             ops.colsum(dy.reshape(-1, dy.shape[-1]), out=net.g(k.bias_name))
                         ops.conv2d_wgrad(dy, a, k.R, k.stride, out=net.g(k.w_name))    # W[R,R,out,in]: roles swapped
-                    thin = k.kernel_shape[2] % 64 or k.kernel_shape[3] % 64
-                    if self._side and not thin:
+                    if self._side:
                         self._wg_stream.wait_stream(torch.cuda.current_stream())
                         with torch.cuda.stream(self._wg_stream):
                             tconv_grads()

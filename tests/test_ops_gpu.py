@@ -437,7 +437,7 @@ def test_conv2d_winograd_stride2_path(ops, case):
 
 
 WINO_CASES = [(16, 16, 16, 128, 128, 3, 1), (32, 8, 8, 64, 128, 3, 1), (9, 12, 12, 32, 64, 3, 1), (130, 4, 4, 64, 64, 3, 1),
-              (5, 14, 18, 40, 192, 3, 1), (9, 10, 12, 64, 64, 3, 1)]
+              (5, 14, 18, 40, 192, 3, 1), (9, 10, 12, 64, 64, 3, 1), (7, 6, 10, 32, 256, 3, 1), (67, 4, 4, 96, 128, 3, 1)]
 
 
 @pytest.mark.parametrize('case', WINO_CASES, ids=[str(c) for c in WINO_CASES])
@@ -469,6 +469,13 @@ def test_conv2d_winograd_path(ops, case):
             assert elementwise_err(to_nchw(y), ref) <= RTOL, (act, elementwise_err(to_nchw(y), ref))   # element by element
         dx = ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s)
         assert rel_err(to_nchw(dx), gx.numpy()) <= RTOL
+        if C % 32 == 0:        # weight gradient with the workspace: (K % 128 == 0) per-split slabs + one reduction pass, bias gradient fused
+            dw2, db2 = torch.full((ksz, ksz, C, K), float('nan'), device='cuda'), torch.full((K,), float('nan'), device='cuda')
+            ops.conv2d_wgrad(nhwc(x), nhwc(dy), ksz, s, out=dw2, dbias=db2)
+            assert rel_err(dw2.cpu().numpy(), gw.numpy()) <= RTOL
+            assert rel_err(db2.cpu().numpy(), dy.astype(np.float64).sum((0, 2, 3))) <= RTOL
+            if K % 128 == 0:
+                assert torch.equal(dw2, ops.conv2d_wgrad(nhwc(x), nhwc(dy), ksz, s))      # deterministic, with or without dbias
         if N % 3 == 0:                                   # [2B ; B] rows against 2B activations
             B = N // 3
             yprev = rs.randn(2 * B, C, H, W).astype(np.float32)

@@ -73,7 +73,13 @@ def probe_rows(sub, name):
     for r in rows:
         by[(r['Grid_Size_X'], r['Grid_Size_Y'], r['Grid_Size_Z'])].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
     grid, d = max(by.items(), key=lambda kv: len(kv[1]))
-    return grid, d[-REPS:], len(rows)                    # the timed launches are the last REPS (clock warm-up launches first)
+    d = d[-REPS:]                                        # the timed launches are the last REPS (clock warm-up launches first)
+    if 'slab_kernel' in name:                            # the slab kernels' results are summed by slab_reduce_kernel: one probe
+        red = [r for r in csv.DictReader(open(find(sub, '_kernel_trace.csv'))) if 'slab_reduce_kernel' in r['Kernel_Name']]
+        red.sort(key=lambda r: int(r['Start_Timestamp']))      # launch = the pair
+        rd = [int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in red][-len(d):]
+        d = [a + b for a, b in zip(d, rd)]
+    return grid, d, len(rows)
 
 
 def pmc_avg(sub, name, counter, grid=None):
