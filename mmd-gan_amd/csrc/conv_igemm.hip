@@ -679,8 +679,11 @@ static void pick_tile(long M, int N, int &bm, int &bn) {
 }
 
 static int pick_split(long tiles, int nstages, bool allowed) {
+    static int forced = -2;                      // MMDGAN_FWD_SPLIT=n forces the reduction split of forward / input-gradient launches (tuning aid)
+    if (forced == -2) { const char *e = getenv("MMDGAN_FWD_SPLIT"); forced = e ? atoi(e) : -1; }
     if (!allowed || tiles >= kTargetBlocks / 2) return 1;
     int s = (int)(kTargetBlocks / tiles);
+    if (forced > 0) s = forced;
     const int maxs = nstages / 4;                // keep >= 4 stages (128 deep) per split
     if (s > maxs) s = maxs;
     return s < 1 ? 1 : s;

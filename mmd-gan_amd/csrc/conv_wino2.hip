@@ -21,6 +21,9 @@
 #ifndef W2W_DEFAULT
 #define W2W_DEFAULT 1
 #endif
+#ifndef W2_FUSE_MIN_WGS
+#define W2_FUSE_MIN_WGS 0
+#endif
 
 namespace mmdgan {
 
@@ -103,11 +106,18 @@ __global__ __launch_bounds__(256) void wino2_weight_kernel(const float *__restri
 //             its time re-fetching lines from L2), the whole B^T d B in registers, 36 ds_write_b32;
 //   consumer  A fragments from LDS one k-pair ahead, B fragments straight from L2, every register refilled for 4
 //             k-pairs later right after the MFMA that consumed it.
-__global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpilogue ep, const float *__restrict__ x,
-                                                       const float *__restrict__ U, float *__restrict__ out) {
+// FUSE: two neighbouring tile blocks of the same (phase, column block) run as ONE 512-thread workgroup - two groups of four
+// waves with the same instruction stream, their own halves of LDS and shared barriers.  Both groups read the SAME B fragments
+// at about the same time, so the second read is an L1 hit (or merges with the pending miss): the B traffic between L2 and the
+// CU - the vector-memory path this kernel is bound by - halves, with no more registers or LDS per CU than two workgroups.
+template <bool FUSE>
+__global__ __launch_bounds__(FUSE ? 512 : 256, FUSE ? 1 : 2) void wino2_kernel(wino2::Params P, ConvEpilogue ep, const float *__restrict__ x,
+                                                                               const float *__restrict__ U, float *__restrict__ out) {
     using namespace wino2;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    const int grp = FUSE ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
+    float *smem = smem_all + grp * (int)(LDS_BYTES / sizeof(float));
+    const int tid = threadIdx.x & 255, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     // wave-uniform by construction, but hipcc only knows once it sits in an SGPR: without this every B load with a
     // wave-dependent scalar offset became a waterfall loop and every `m < nm` an exec-mask branch (2x slower)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -125,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
     const int per_tb = P.nkb * P.nph;
     const int tblk = wg / per_tb, rem = wg - tblk * per_tb;
     const int phase = P.xcd_remap ? rem / P.nkb : wg / (P.ntb * P.nkb);
-    const int t0 = (P.xcd_remap ? tblk : wg % P.ntb) * 32;
+    const int t0 = ((P.xcd_remap ? tblk : wg % P.ntb) * (FUSE ? 2 : 1) + grp) * 32;   // (P.ntb counts workgroups)
     const int n0 = (P.xcd_remap ? rem % P.nkb : (wg / P.ntb) % P.nkb) * 64;
     const int spc = P.Cr / BC;                           // stages per segment
     const int nstages = P.nseg * spc;
@@ -166,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
     // ---- consumer: wave owns column block cb and frequencies fq + 2m
     // 18 accumulators over 4 waves = 5,5,4,4: odd workgroups rotate the roles so that, with two workgroups per CU,
     // every SIMD carries 9 of them
-    const int wrole = (wave + ((wg & 1) << 1)) & 3;
+    const int wrole = (wave + (((FUSE ? grp : wg) & 1) << 1)) & 3;
     const int cb = wrole & 1, fq = wrole >> 1;
     const unsigned ubase = (unsigned)(((long)kh * P.Ko + n0 + cb * 32 + l31) * 4);
     const unsigned ufreq = (unsigned)((long)P.Cr * P.Ko * 4), ukp = (unsigned)(2 * P.Ko * 4), ustage = (unsigned)(BC * P.Ko * 4);
@@ -396,16 +406,22 @@ static int wino2_launch(const ConvDims &d, const ConvEpilogue &ep, const float *
     }
     const long T = (long)d.N * P.TH * P.TW;
     P.ntb = (int)((T + 31) / 32); P.nkb = P.Ko / 64; P.nph = dgrad ? 4 : 1;
-    static int remap = -1;
+    static int remap = -1, fuse_min = -1;
     if (remap < 0) { const char *e = getenv("MMDGAN_XCD_REMAP"); remap = (e && e[0] == '0') ? 0 : 1; }
+    if (fuse_min < 0) { const char *e = getenv("MMDGAN_WINO2_FUSE"); fuse_min = e ? atoi(e) : W2_FUSE_MIN_WGS; }   // 0: never
     P.xcd_remap = remap;
+    // pairs of tile blocks as one workgroup where that still leaves every CU its workgroup
+    const bool fuse = fuse_min > 0 && (long)P.ntb * P.nkb * P.nph >= fuse_min;
+    if (fuse) P.ntb = (P.ntb + 1) / 2;
     const dim3 grid((unsigned)((long)P.ntb * P.nkb * P.nph), 1, 1);
     static bool cap_raised = false;                     // 76 KB of dynamic LDS: above the 64 KB default cap
     if (!cap_raised) {
-        (void)hipFuncSetAttribute((const void *)wino2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino2::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)wino2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino2::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)wino2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * wino2::LDS_BYTES));
         cap_raised = true;
     }
-    hipLaunchKernelGGL(wino2_kernel, grid, dim3(256), wino2::LDS_BYTES, st, P, ep, in, U, out);
+    if (fuse) hipLaunchKernelGGL(wino2_kernel<true>, grid, dim3(512), 2 * wino2::LDS_BYTES, st, P, ep, in, U, out);
+    else hipLaunchKernelGGL(wino2_kernel<false>, grid, dim3(256), wino2::LDS_BYTES, st, P, ep, in, U, out);
     return check_launch(dgrad ? "conv2d_dgrad(winograd 2x2)" : "conv2d_fwd(winograd 2x2)");
 }
 
@@ -666,6 +682,8 @@ bool wino2_wgrad_ok(const ConvDims &d) {
     static int en = -1;
     if (en < 0) { const char *e = getenv("MMDGAN_WINO2_WGRAD"); en = e ? atoi(e) : W2W_DEFAULT; }
     if ((!en && wino2_mode() < 2) || wino2_mode() == 0) return false;
+    // the batch-1 weight gradients of the power iteration (64 tiles) stay direct: 7.7 us against 7 + the 6 us reduction pass
+    if (wino2_mode() < 2 && (long)d.N * (d.P / 2) * (d.Q / 2) < 256) return false;
     return d.R == 4 && d.stride == 2 && d.pad == 1 && d.H % 4 == 0 && d.W % 4 == 0 && d.C % wino2w::BC == 0 && d.K % wino2w::BK == 0;
 }
 

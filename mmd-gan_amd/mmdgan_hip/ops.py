@@ -155,8 +155,9 @@ def conv2d_fwd(x, w, stride, bias=None, scale=None, act='linear', dact_of=None, 
 
 
 def conv2d_dgrad(dy, w, in_hw, stride, bias=None, scale=None, act='linear', dact_of=None, out=None, dact_batch=0,
-                 wino=None):
-    """dy [N,P,Q,K], w [R,R,C,K] -> dx [N,H,W,C]; forward form = tf.nn.conv2d_transpose (layer_func.py:926)"""
+                 wino=None, out_zeroed=False):
+    """dy [N,P,Q,K], w [R,R,C,K] -> dx [N,H,W,C]; forward form = tf.nn.conv2d_transpose (layer_func.py:926)
+    out_zeroed: `out` is zero on entry - a launch with a linear epilogue may split its reduction over workgroups"""
     lib = require_device()
     N, P, Q, K = dy.shape
     R, C = w.shape[0], w.shape[2]
@@ -166,7 +167,7 @@ def conv2d_dgrad(dy, w, in_hw, stride, bias=None, scale=None, act='linear', dact
     dx = out if out is not None else torch.empty((N, H, W, C), device=dy.device, dtype=torch.float32)
     g = geom(N, H, W, C, K, R, stride)
     check(lib.mmdgan_conv2d_dgrad(ctypes.byref(g), _p(dy), _p(w if wino is None else wino), _p(bias), _p(scale),
-                                  act_id(act) | (0 if wino is None else 0x200), _p(dact_of),
+                                  act_id(act) | (0x100 if out_zeroed else 0) | (0 if wino is None else 0x200), _p(dact_of),
                                   int(dact_batch), _p(dx), _stream()), 'conv2d_dgrad')
     return dx
 
