@@ -344,6 +344,10 @@ int mmdgan_periodic_shuffle(const float *src, float *dst, int N, int H, int W, i
  * (grad = 0), or its adjoint (grad = 1: src = dy [N,OH,OW,C], dst = dx [N,H,W,C], accumulated with atomics into a dx
  * the entry zeroes itself unless mmdgan_set_outputs_prezeroed(1) is in force). */
 int mmdgan_bilinear_resize(const float *src, float *dst, int N, int H, int W, int C, int OH, int OW, int grad, void *stream);
+/* ImageScaling 'bic' (layer_func.py:1138-1147): tf.image.resize_bicubic(align_corners=True) with TF 1.x's legacy sampling
+ * (Keys cubic A = -0.75, fractional position rounded to 1/1024, taps clamped to the image; resize_bicubic_op.cc), same
+ * arguments and gradient convention as mmdgan_bilinear_resize. */
+int mmdgan_bicubic_resize(const float *src, float *dst, int N, int H, int W, int C, int OH, int OW, int grad, void *stream);
 /* ImageScaling 'max' (layer_func.py:1149-1153): tf.nn.max_pool with window = stride = factor on x [N, P*factor, Q*factor, C].
  * dy == NULL: out [N,P,Q,C] = window maxima.  dy != NULL ([N,P,Q,C]): out [N, P*factor, Q*factor, C] = the gradient
  * w.r.t. x - dy at the first maximum of each window (row-major), zero elsewhere; every element of out is written. */

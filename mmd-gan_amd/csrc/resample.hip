@@ -143,6 +143,58 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const float *__restrict__
     }
 }
 
+// ImageScaling 'bic' (layer_func.py:1138-1147): tf.image.resize_bicubic(align_corners=True) as TF 1.x computes it (legacy
+// sampling, resize_bicubic_op.cc): source coordinate y * (H - 1) / (OH - 1) in fp32; its fractional part is rounded to a
+// 1/1024 grid (lrintf(delta * 1024), the kernel's coefficient table) and the four taps floor-1 .. floor+2, clamped to the
+// image, are weighted with the Keys cubic for A = -0.75 evaluated in double and rounded to fp32 (the table's entries):
+//   w(x) = ((A+2)x - (A+3))x^2 + 1 for |x| <= 1,   ((Ax - 5A)x + 8A)x - 4A for 1 < |x| < 2.
+// Rows are interpolated along x first, then along y (Interpolate1D order).  GRAD: the adjoint scatter (fp32 atomics).
+__device__ __forceinline__ void bicubic_taps(int o, float scale, int limit, int idx[4], float wgt[4]) {
+    const float loc = scale * (float)o;
+    const int in = (int)loc;                                   // int64 cast of a non-negative float
+    const float delta = loc - (float)in;
+    const int off = (int)lrintf(delta * 1024.f);
+    const double A = -0.75;
+    auto near = [&](int i) { const double x = (double)((float)i / 1024.f); return (float)(((A + 2) * x - (A + 3)) * x * x + 1); };
+    auto far = [&](int i) { const double x = (double)((float)i / 1024.f + 1.f); return (float)(((A * x - 5 * A) * x + 8 * A) * x - 4 * A); };
+    wgt[0] = far(off); wgt[1] = near(off); wgt[2] = near(1024 - off); wgt[3] = far(1024 - off);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) idx[t] = min(limit - 1, max(0, in - 1 + t));
+}
+
+template <bool GRAD>
+__global__ __launch_bounds__(256) void bicubic_kernel(const float *__restrict__ src, float *__restrict__ dst, long total, int H,
+                                                      int W, int C, int OH, int OW, float sy, float sx) {
+    const long stride = (long)gridDim.x * 256;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {     // o indexes the OH x OW side
+        const int c = (int)(o % C);
+        long t = o / C;
+        const int x = (int)(t % OW);
+        t /= OW;
+        const int y = (int)(t % OH);
+        const long n = t / OH;
+        int iy[4], ix[4];
+        float wy[4], wx[4];
+        bicubic_taps(y, sy, H, iy, wy);
+        bicubic_taps(x, sx, W, ix, wx);
+        if (!GRAD) {
+            float rows[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const float *r = src + ((n * H + iy[a]) * W) * C + c;
+                rows[a] = r[(long)ix[0] * C] * wx[0] + r[(long)ix[1] * C] * wx[1] + r[(long)ix[2] * C] * wx[2] + r[(long)ix[3] * C] * wx[3];
+            }
+            dst[o] = rows[0] * wy[0] + rows[1] * wy[1] + rows[2] * wy[2] + rows[3] * wy[3];
+        } else {
+            const float g = src[o];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) atomicAdd(dst + ((n * H + iy[a]) * W + ix[b]) * C + c, g * wy[a] * wx[b]);
+        }
+    }
+}
+
 // ImageScaling 'max' (layer_func.py:1149-1153): tf.nn.max_pool, window = stride = f.  Windows do not overlap, so the
 // gradient needs no atomics: the thread of a window writes dy to its first maximum (row-major order, the element a
 // strict '>' scan keeps - what TF's and the oracle's max-pool gradients pick) and zero to the rest.
@@ -350,6 +402,22 @@ extern "C" int mmdgan_bilinear_resize(const float *src, float *dst, int N, int H
         hipLaunchKernelGGL(bilinear_kernel<false>, dim3(grid_of(total)), dim3(256), 0, st, src, dst, total, H, W, C, OH, OW, sy, sx);
     }
     return check_launch("bilinear_resize");
+}
+
+extern "C" int mmdgan_bicubic_resize(const float *src, float *dst, int N, int H, int W, int C, int OH, int OW, int grad,
+                                     void *stream) {
+    MMDGAN_REQUIRE(src && dst && N >= 1 && H >= 1 && W >= 1 && C >= 1 && OH >= 1 && OW >= 1, "bicubic_resize: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const float sy = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : (float)H / (float)OH;      // CalculateResizeScale, align_corners
+    const float sx = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : (float)W / (float)OW;
+    const long total = (long)N * OH * OW * C;
+    if (grad) {                              // src = dy [N,OH,OW,C], dst = dx [N,H,W,C]
+        if (zero_output(dst, sizeof(float) * (size_t)N * H * W * C, st) != hipSuccess) return check_launch("bicubic_resize memset");
+        hipLaunchKernelGGL(bicubic_kernel<true>, dim3(grid_of(total)), dim3(256), 0, st, src, dst, total, H, W, C, OH, OW, sy, sx);
+    } else {
+        hipLaunchKernelGGL(bicubic_kernel<false>, dim3(grid_of(total)), dim3(256), 0, st, src, dst, total, H, W, C, OH, OW, sy, sx);
+    }
+    return check_launch("bicubic_resize");
 }
 
 extern "C" int mmdgan_max_pool(const float *x, const float *dy, float *out, int N, int P, int Q, int C, int factor,

@@ -72,6 +72,7 @@ SIGNATURES = {
     'mmdgan_resample_up': (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     'mmdgan_periodic_shuffle': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'mmdgan_bilinear_resize': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'mmdgan_bicubic_resize': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'mmdgan_max_pool': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'mmdgan_compose_scaled_conv': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'mmdgan_act_fwd': (_I, [_P, _P, _L, _I, _P]),

@@ -548,6 +548,29 @@ def bilinear_resize_grad(dy, in_hw, out=None):
     return out
 
 
+def bicubic_resize(x, size, out=None):
+    """ImageScaling 'bic' (layer_func.py:1138-1147): tf.image.resize_bicubic(align_corners=True) of an NHWC tensor"""
+    lib = require_device()
+    n, h, w, c = x.shape
+    oh, ow = int(size[0]), int(size[1])
+    if out is None:
+        out = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.float32)
+    check(lib.mmdgan_bicubic_resize(_p(x), _p(out), n, h, w, c, oh, ow, 0, _stream()), 'bicubic_resize')
+    return out
+
+
+def bicubic_resize_grad(dy, in_hw, out=None):
+    """gradient of bicubic_resize w.r.t. its input: dy [N,OH,OW,C] -> dx [N,H,W,C]; `out` must be zero when
+    mmdgan_set_outputs_prezeroed(1) is in force"""
+    lib = require_device()
+    n, oh, ow, c = dy.shape
+    h, w = int(in_hw[0]), int(in_hw[1])
+    if out is None:
+        out = torch.zeros((n, h, w, c), device=dy.device, dtype=torch.float32)
+    check(lib.mmdgan_bicubic_resize(_p(dy), _p(out), n, h, w, c, oh, ow, 1, _stream()), 'bicubic_resize_grad')
+    return out
+
+
 def max_pool(x, factor=2, dy=None, out=None):
     """ImageScaling 'max' (layer_func.py:1149-1153).  dy=None: window maxima of x [N,H,W,C]; with dy [N,H/f,W/f,C]: the
     gradient w.r.t. x (dy at each window's first maximum, zero elsewhere)"""

@@ -178,9 +178,9 @@ class _Net:
             if h % f or w % f:
                 raise NotImplementedError('max pooling of a size its window does not divide is not built')
             return self._emit('maxpool', [x], [c, h // f, w // f], f=f)
-        if method == 'bil':                                              # tf.image.resize_bilinear, :1128-1137
+        if method in ('bil', 'bic'):                                     # tf.image.resize_bilinear / _bicubic, :1128-1147
             nh, nw = (int(h * factor), int(w * factor)) if factor > 0 else (int(-h / factor), int(-w / factor))
-            return self._emit('bilinear', [x], [c, nh, nw])
+            return self._emit('bilinear' if method == 'bil' else 'bicubic', [x], [c, nh, nw])
         if method == 'ps':                                               # periodic shuffling, :1125-1127 / :197-244
             f = abs(int(factor))
             if factor > 0:
@@ -707,8 +707,8 @@ class TapeEngine:
                 y = ops.resample_up(a, p['f'], out=self._buf(key, out_shape))
             elif kind == 'shuffle':
                 y = ops.periodic_shuffle(a, p['f'], p['to_big'], out=self._buf(key, out_shape))
-            elif kind == 'bilinear':
-                y = ops.bilinear_resize(a, out_shape[1:3], out=self._buf(key, out_shape))
+            elif kind in ('bilinear', 'bicubic'):
+                y = (ops.bilinear_resize if kind == 'bilinear' else ops.bicubic_resize)(a, out_shape[1:3], out=self._buf(key, out_shape))
             elif kind == 'maxpool':
                 y = ops.max_pool(a, p['f'], out=self._buf(key, out_shape))
             elif kind == 'add':
@@ -866,8 +866,9 @@ class TapeEngine:
                 give(vin, ops.resample_down(dy, p['f'], scale=1.0, out=self._buf(key, in_shape)))
             elif kind == 'maxpool':                                      # dy to each window's first maximum
                 give(vin, ops.max_pool(a.contiguous(), p['f'], dy=dy.contiguous(), out=self._buf(key, in_shape)))
-            elif kind == 'bilinear':                                     # scatter with the forward weights (atomics)
-                give(vin, ops.bilinear_resize_grad(dy.contiguous(), in_shape[1:3], out=self._buf(key, in_shape, zero=True)))
+            elif kind in ('bilinear', 'bicubic'):                        # scatter with the forward weights (atomics)
+                grad_of = ops.bilinear_resize_grad if kind == 'bilinear' else ops.bicubic_resize_grad
+                give(vin, grad_of(dy.contiguous(), in_shape[1:3], out=self._buf(key, in_shape, zero=True)))
             elif kind == 'shuffle':                                      # a permutation: its gradient is the inverse one
                 give(vin, ops.periodic_shuffle(dy.contiguous(), p['f'], not p['to_big'], out=self._buf(key, in_shape)))
             elif kind == 'add':

@@ -343,7 +343,7 @@ def make_layers():
 # 3. full G+D step on a width/8 CIFAR-shaped net, 3 consecutive steps
 # ---------------------------------------------------------------------------
 from tiny_arch import (tiny_architecture, tiny_res_architecture, tiny_res_ps_architecture,  # noqa: E402
-                       tiny_res_bil_architecture, tiny_res_max_architecture)  # noqa: E402
+                       tiny_res_bil_architecture, tiny_res_max_architecture, tiny_res_bic_architecture)  # noqa: E402
 
 
 def tf_adam_inplace(var, g, m, v, t, lr, b1=0.5, b2=0.999, eps=1e-8):
@@ -659,6 +659,11 @@ if __name__ == '__main__':
         make_step_warm('rep', arch_fn=tiny_res_architecture, tag='res_rep')
         make_step_warm('rep', sn_mode='sn_paper', tag='rep_pim')
         sys.exit(0)
+    if '--only-bic' in sys.argv:
+        torch.manual_seed(0)
+        torch.set_num_threads(4)
+        make_step('rep', arch_fn=tiny_res_bic_architecture, tag='res_bic_rep', store_grads=True)
+        sys.exit(0)
     torch.manual_seed(0)
     torch.set_num_threads(4)
     make_mmd()
@@ -679,6 +684,7 @@ if __name__ == '__main__':
     make_step('rep', arch_fn=tiny_res_architecture, tag='res_rep')
     make_step('rmb', arch_fn=tiny_res_ps_architecture, tag='res_ps_rmb')
     make_step('rep', arch_fn=tiny_res_bil_architecture, tag='res_bil_rep')
+    make_step('rep', arch_fn=tiny_res_bic_architecture, tag='res_bic_rep')
     make_step('rep', arch_fn=tiny_res_max_architecture, tag='res_max_rep')
     make_eval()
     make_init_stats()

@@ -82,7 +82,7 @@ def _scaled_shape(shape, scale):
             raise AttributeError('unpool can only be used for upsampling')
         if factor != 2:
             raise AttributeError('unpool can only deal with factor = 2')
-    elif method == 'bil':                                     # any integer factor, either direction
+    elif method in ('bil', 'bic'):                            # any integer factor, either direction
         pass
     elif method == 'ps':                                      # periodic shuffling moves pixels into / out of channels
         nh, nw = (int(h * factor), int(w * factor)) if factor > 0 else (int(-h / factor), int(-w / factor))
@@ -104,6 +104,10 @@ def _rescale(x, scale):
         n, c, h, w = x.shape                                  # align_corners=True
         size = (int(h * factor), int(w * factor)) if factor > 0 else (int(-h / factor), int(-w / factor))
         return bilinear_resize(x, size)
+    if method == 'bic':                                       # layer_func.py:1138-1147: tf.image.resize_bicubic,
+        n, c, h, w = x.shape                                  # align_corners=True
+        size = (int(h * factor), int(w * factor)) if factor > 0 else (int(-h / factor), int(-w / factor))
+        return bicubic_resize(x, size)
     if method == 'ps':                                        # layer_func.py:197-244, 1125-1127: tf.depth_to_space /
         r = abs(int(factor))                                  # tf.space_to_depth on NCHW, block-major channel order
         n, c, h, w = x.shape
@@ -132,6 +136,40 @@ def bilinear_resize(x, size):
     top = x[:, :, y0][:, :, :, x0] * (1 - wx) + x[:, :, y0][:, :, :, x1] * wx
     bot = x[:, :, y1][:, :, :, x0] * (1 - wx) + x[:, :, y1][:, :, :, x1] * wx
     return top * (1 - wy)[:, None] + bot * wy[:, None]
+
+
+def bicubic_taps(out_n, in_n):
+    """indices [out_n,4] and weights [out_n,4] (fp32 values, as TF's coefficient table holds them) of
+    tf.image.resize_bicubic(align_corners=True), TF 1.x legacy sampling (resize_bicubic_op.cc GetWeightsAndIndices):
+    source = o * (in - 1) / (out - 1) in fp32, floor, the fraction rounded half-to-even onto a 1/1024 grid, Keys cubic with
+    A = -0.75 evaluated in double and stored as fp32, taps floor-1 .. floor+2 clamped to the image."""
+    scale = np.float32(in_n - 1) / np.float32(out_n - 1) if out_n > 1 else np.float32(in_n) / np.float32(out_n)
+    loc = (np.float32(scale) * np.arange(out_n, dtype=np.float32)).astype(np.float32)
+    base = loc.astype(np.int64)
+    off = np.rint((loc - base.astype(np.float32)).astype(np.float32) * np.float32(1024)).astype(np.int64)
+    A = -0.75
+
+    def near(i):
+        x = (i.astype(np.float32) / np.float32(1024)).astype(np.float64)
+        return (((A + 2) * x - (A + 3)) * x * x + 1).astype(np.float32)
+
+    def far(i):
+        x = (i.astype(np.float32) / np.float32(1024) + np.float32(1)).astype(np.float64)
+        return (((A * x - 5 * A) * x + 8 * A) * x - 4 * A).astype(np.float32)
+    wgt = np.stack([far(off), near(off), near(1024 - off), far(1024 - off)], 1)
+    idx = np.clip(base[:, None] + np.arange(-1, 3)[None, :], 0, in_n - 1)
+    return idx, wgt
+
+
+def bicubic_resize(x, size):
+    """tf.image.resize_bicubic(align_corners=True): rows interpolated along x, then along y.  NCHW in, NCHW out."""
+    n, c, h, w = x.shape
+    oh, ow = size
+    iy, wy = bicubic_taps(oh, h)
+    ix, wx = bicubic_taps(ow, w)
+    wy_t, wx_t = torch.tensor(wy, dtype=x.dtype), torch.tensor(wx, dtype=x.dtype)
+    cols = sum(x[:, :, :, torch.as_tensor(ix[:, b])] * wx_t[:, b] for b in range(4))              # [n,c,h,ow]
+    return sum(cols[:, :, torch.as_tensor(iy[:, a])] * wy_t[:, a][:, None] for a in range(4))     # [n,c,oh,ow]
 
 
 def _kernel_spec(layer_scope, op_name, d, index, in_shape, sn_mode):

@@ -512,7 +512,43 @@ def _resize_bilinear(images, size, align_corners=False, name=None):
     return y.permute(0, 2, 3, 1)
 
 
-image = types.SimpleNamespace(resize_bilinear=_resize_bilinear)
+def _bicubic_matrix(out_n, in_n):
+    """dense [out_n, in_n] interpolation matrix of tf.image.resize_bicubic(align_corners=True), TF 1.x legacy kernel
+    (resize_bicubic_op.cc): per output position the four clamped taps around floor(o * (in-1)/(out-1)), weights from the
+    1024-entry Keys-cubic table (A = -0.75); clamped taps that coincide add up.  Built entry by entry (independent of
+    oracle/restatement.py's gather form)."""
+    import math
+    import numpy as np
+    table = np.zeros((1025, 2), np.float32)
+    for i in range(1025):
+        x = float(np.float32(i / 1024.0))
+        table[i, 0] = np.float32((((-0.75 + 2) * x - (-0.75 + 3)) * x * x + 1))
+        x = float(np.float32(np.float32(x) + np.float32(1.0)))
+        table[i, 1] = np.float32((((-0.75 * x - 5 * -0.75) * x + 8 * -0.75) * x - 4 * -0.75))
+    scale = np.float32(in_n - 1) / np.float32(out_n - 1) if out_n > 1 else np.float32(in_n) / np.float32(out_n)
+    m = np.zeros((out_n, in_n), np.float64)
+    for o in range(out_n):
+        loc = np.float32(scale * np.float32(o))
+        base = int(loc)
+        delta = np.float32(loc - np.float32(base))
+        f = float(delta * np.float32(1024))
+        off = int(round(f)) if abs(f - math.floor(f) - 0.5) > 0 else int(2 * round(f / 2))        # lrintf: half to even
+        w4 = (table[off, 1], table[off, 0], table[1024 - off, 0], table[1024 - off, 1])
+        for t in range(4):
+            m[o, min(in_n - 1, max(0, base - 1 + t))] += float(w4[t])
+    return m
+
+
+def _resize_bicubic(images, size, align_corners=False, name=None):
+    """tf.image.resize_bicubic on NHWC with align_corners=True (ImageScaling 'bic', layer_func.py:1138-1147)"""
+    assert align_corners
+    n, h, w, c = images.shape
+    my = torch.tensor(_bicubic_matrix(int(size[0]), int(h)), dtype=images.dtype)
+    mx = torch.tensor(_bicubic_matrix(int(size[1]), int(w)), dtype=images.dtype)
+    return torch.einsum('ph,nhwc,qw->npqc', my, images, mx)
+
+
+image = types.SimpleNamespace(resize_bilinear=_resize_bilinear, resize_bicubic=_resize_bicubic)
 layers = types.SimpleNamespace(batch_normalization=_batch_normalization)
 summary = types.SimpleNamespace(scalar=lambda *a, **k: None, histogram=lambda *a, **k: None,
                                 image=lambda *a, **k: None)

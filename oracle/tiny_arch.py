@@ -87,6 +87,17 @@ def tiny_res_bil_architecture():
                               {'name': 'l3_s', 'out': 16, 'op': 'd', 'act_k': ak, 'w_nm': 's'}]}
 
 
+def tiny_res_bic_architecture():
+    """the same pair with bicubic resizing ('bic', tf.image.resize_bicubic align_corners=True, layer_func.py:1138-1147):
+    x2 twice in G, /2 and /3 in D - taps that run off the image (clamped) on every border"""
+    arch = tiny_res_bil_architecture()
+    for net in ('generator', 'discriminator'):
+        for layer in arch[net]:
+            if 'scale' in layer:
+                layer['scale'] = ['bic', layer['scale'][1]]
+    return arch
+
+
 def tiny_res_max_architecture():
     """max pooling ('max', layer_func.py:1149-1153) as the down-sampling method, and scaling on PLAIN layers as well
     (layer_func.py:1627-1642: up-sampling in front of the kernel, down-sampling behind the activation): G's second

@@ -725,6 +725,26 @@ def test_bilinear_resize_and_its_gradient(ops, n, c, h, w, oh, ow):
         assert np.allclose(to_nchw(got)[:, :, -1, -1], x[:, :, -1, -1], rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize('n,c,h,w,oh,ow', [(2, 3, 3, 3, 6, 6), (3, 5, 6, 6, 3, 3), (2, 4, 6, 9, 2, 3), (2, 8, 3, 3, 12, 12),
+                                           (1, 1, 1, 1, 2, 2), (2, 2, 5, 7, 5, 7), (4, 16, 16, 16, 32, 32), (2, 3, 4, 4, 1, 1),
+                                           (2, 3, 12, 12, 4, 4)])
+def test_bicubic_resize_and_its_gradient(ops, n, c, h, w, oh, ow):
+    """'bic' = tf.image.resize_bicubic(align_corners=True) (layer_func.py:1138-1147, TF 1.x legacy kernel: Keys cubic A = -0.75
+    on a 1/1024 grid, clamped taps) against the oracle's written-out interpolation in fp64, and the adjoint against autograd"""
+    rs = np.random.RandomState(n + c + oh)
+    x = rs.randn(n, c, h, w).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    ref = R.bicubic_resize(xt, (oh, ow))
+    got = ops.bicubic_resize(nhwc(x), (oh, ow))
+    assert rel_err(to_nchw(got), ref.detach().numpy()) <= 2e-6
+    dy = rs.randn(n, c, oh, ow).astype(np.float32)
+    gx, = torch.autograd.grad(ref, xt, torch.tensor(dy, dtype=torch.float64))
+    dx = ops.bicubic_resize_grad(nhwc(dy), (h, w))
+    assert rel_err(to_nchw(dx), gx.numpy()) <= 5e-6
+    if oh > 1 and ow > 1:                      # align_corners: the corner pixels are copied (weights 0, 1, 0, 0 exactly)
+        assert np.array_equal(to_nchw(got)[:, :, 0, 0], x[:, :, 0, 0])
+
+
 @pytest.mark.parametrize('n,c,h,w,f', [(2, 3, 4, 4, 2), (3, 5, 6, 9, 3), (8, 64, 16, 16, 2), (1, 1, 2, 2, 2)])
 def test_max_pool_and_its_gradient(ops, n, c, h, w, f):
     """'max' = tf.nn.max_pool(window = stride = f) (layer_func.py:1149-1153); ties (plenty after a relu) send the

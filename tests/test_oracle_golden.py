@@ -118,17 +118,17 @@ def test_net_restatement_matches_reference(path):
                 params[n] = v
 
 
-@pytest.mark.parametrize('loss_type', ['rep', 'rmb', 'rep_pim', 'res_rep', 'res_ps_rmb', 'res_bil_rep', 'res_max_rep'])
+@pytest.mark.parametrize('loss_type', ['rep', 'rmb', 'rep_pim', 'res_rep', 'res_ps_rmb', 'res_bil_rep', 'res_bic_rep', 'res_max_rep'])
 def test_full_step_restatement_matches_reference(loss_type):
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
     fx = load(golden('step_tiny_%s.npz' % loss_type)[0])
     from tiny_arch import (tiny_architecture, tiny_res_architecture, tiny_res_ps_architecture, tiny_res_bil_architecture,
-                           tiny_res_max_architecture)
+                           tiny_res_max_architecture, tiny_res_bic_architecture)
     # 'res_': the ResNet-shaped pair - every kind of residual block of layer_func.py:1687-1842
     is_res = loss_type.startswith('res_')
     res_arch = {'res_rep': tiny_res_architecture, 'res_ps_rmb': tiny_res_ps_architecture, 'res_bil_rep': tiny_res_bil_architecture,
-                'res_max_rep': tiny_res_max_architecture}
+                'res_max_rep': tiny_res_max_architecture, 'res_bic_rep': tiny_res_bic_architecture}
     arch = res_arch[loss_type]() if is_res else tiny_architecture()
     # '_pim': FLAGS.SPECTRAL_NORM_MODE = 'sn_paper' in the reference run (layer_func.py:811-814)
     sn_mode = str(fx['sn_mode']) if 'sn_mode' in fx else 'default'
@@ -248,3 +248,27 @@ def test_reference_fp32_noise_floor():
                 worst_rel_loss = max(worst_rel_loss, err / abs(float(fx[name + '_f64'])))
     assert worst_rel_loss > 1e-4          # the reference's fp32 path itself is outside 1e-4
     assert worst_rel_scale < 1e-3
+
+
+@pytest.mark.parametrize('h,w,oh,ow', [(3, 3, 6, 6), (6, 6, 12, 12), (12, 12, 6, 6), (6, 6, 2, 2), (5, 7, 11, 4), (4, 4, 1, 1), (1, 1, 3, 3)])
+def test_bicubic_restatement(h, w, oh, ow):
+    """'bic' = tf.image.resize_bicubic(align_corners=True), TF 1.x legacy kernel.  No TF here, so the pin is three-fold: the
+    restatement's gather form equals the TF shim's dense-matrix form (written separately, the one the golden fixtures were
+    generated through) to rounding; every row of weights sums to 1 within the table's fp32 rounding; and both agree with
+    torch's bicubic (same Keys kernel A = -0.75, exact fractions instead of TF's 1/1024 grid) to the grid's resolution."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
+    import tf1_shim
+    rs = np.random.RandomState(h * 100 + ow)
+    x = torch.tensor(rs.randn(2, 3, h, w), dtype=torch.float64)
+    got = R.bicubic_resize(x, (oh, ow))
+    via_shim = tf1_shim.image.resize_bicubic(x.permute(0, 2, 3, 1), (oh, ow), align_corners=True).permute(0, 3, 1, 2)
+    assert float((got - via_shim).abs().max()) <= 1e-12 * float(x.abs().max())
+    for out_n, in_n in ((oh, h), (ow, w)):
+        idx, wgt = R.bicubic_taps(out_n, in_n)
+        assert np.abs(wgt.astype(np.float64).sum(1) - 1).max() <= 4e-7
+        assert idx.min() >= 0 and idx.max() <= in_n - 1
+    if oh > 1 and ow > 1:
+        ref = torch.nn.functional.interpolate(x, size=(oh, ow), mode='bicubic', align_corners=True)
+        assert float((got - ref).abs().max()) <= 4e-3 * float(x.abs().max())      # 1/2048 in position x the kernel's slope
+        assert torch.allclose(got[:, :, 0, 0], x[:, :, 0, 0], atol=1e-6) and torch.allclose(got[:, :, -1, -1], x[:, :, -1, -1], atol=1e-6)

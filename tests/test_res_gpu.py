@@ -12,7 +12,7 @@ from helpers import RTOL, golden, load
 from oracle import restatement as R
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
-from tiny_arch import (tiny_res_architecture, tiny_res_bil_architecture, tiny_res_max_architecture,  # noqa: E402
+from tiny_arch import (tiny_res_architecture, tiny_res_bil_architecture, tiny_res_max_architecture, tiny_res_bic_architecture,  # noqa: E402
                        tiny_res_ps_architecture)
 
 pytestmark = pytest.mark.gpu
@@ -27,16 +27,18 @@ def close(got, ref, rtol, floor):
     return np.max(np.abs(got - ref)) <= rtol * np.max(np.abs(ref)) + floor
 
 
-@pytest.mark.parametrize('tag', ['res_rep', 'res_ps_rmb', 'res_bil_rep', 'res_max_rep'])
+@pytest.mark.parametrize('tag', ['res_rep', 'res_ps_rmb', 'res_bil_rep', 'res_bic_rep', 'res_max_rep'])
 def test_res_step_matches_reference_golden(tag):
     """'res_rep': res / res_i / res_v1 blocks with 'avg' and 'unpool' scaling and an identity layer, rep loss;
-    'res_ps_rmb': blocks whose scaling is periodic shuffling, rmb loss; 'res_bil_rep': bilinear resizing (x2, /2, /3);
+    'res_ps_rmb': blocks whose scaling is periodic shuffling, rmb loss; 'res_bil_rep' / 'res_bic_rep': bilinear / bicubic
+    resizing (x2, /2, /3);
     'res_max_rep': max pooling, and scaling on plain (non-block) layers"""
     from mmdgan_hip.tape import TapeEngine
     fx = load(golden('step_tiny_%s.npz' % tag)[0])
     B = int(fx['B'])
     arch = {'res_rep': tiny_res_architecture, 'res_ps_rmb': tiny_res_ps_architecture,
-            'res_bil_rep': tiny_res_bil_architecture, 'res_max_rep': tiny_res_max_architecture}[tag]()
+            'res_bil_rep': tiny_res_bil_architecture, 'res_max_rep': tiny_res_max_architecture,
+            'res_bic_rep': tiny_res_bic_architecture}[tag]()
     eng = TapeEngine(arch, str(fx['loss_type']), tuple(fx['lr']), batch_size=B)
     init = {k[len('init/'):]: v for k, v in fx.items() if k.startswith('init/')}
     assert sorted(init) == sorted(eng.variable_names())              # the reference's variable names, all of them
@@ -92,6 +94,7 @@ def test_res_step_matches_reference_golden(tag):
                 # (shuffled-up biases are no per-channel constants any more: BN does not remove them)
                 'res_ps_rmb': {'dis/l3_s/bias/bias', 'dis/l2_res/bias_1/bias', 'dis/l2_res/bias_sc/bias'},
                 'res_bil_rep': {'dis/l3_s/bias/bias', 'dis/l2_res/bias_1/bias', 'dis/l2_res/bias_sc/bias'},
+                'res_bic_rep': {'dis/l3_s/bias/bias', 'dis/l2_res/bias_1/bias', 'dis/l2_res/bias_sc/bias'},
                 'res_max_rep': {'dis/l4_s/bias/bias', 'dis/l3_res/bias_1/bias'}}[tag]
     assert expected <= noise and len(noise) <= 8, noise
     for n, v in final.items():
