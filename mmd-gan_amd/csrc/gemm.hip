@@ -105,6 +105,53 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 }
 
+// The discriminator's head (D l8: [2B, 8192] x [8192, 16], layer_func.py:909-911) is a skinny-N product on the step's critical
+// path between D's forward and backward passes: the tiled kernel above spends 23 us on it (a 64-wide N tile for 16 columns,
+// 262 k atomics).  Here: v_mfma_f32_16x16x4_f32, one wave = 16 rows x 16 columns x a slice of K; a lane loads 16 bytes of its
+// row per 16-deep block (lanes permute k consistently on both operands), four waves of a workgroup take neighbouring K
+// slices and add up through LDS, one atomic per output and workgroup into the zeroed C.   C += scale * A[M,K] B[K,16] (+ bias once)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void gemm_skinny16_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
+                                                            const float *__restrict__ bias, const float *__restrict__ scale,
+                                                            float *__restrict__ C, int ldc, int K, int kchunk) {
+    __shared__ float red[4][16][17];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.x * 16;
+    const int per_wave = kchunk / 4;                       // multiple of 64
+    const int k0 = blockIdx.y * kchunk + wave * per_wave, k1 = min(K, k0 + per_wave);
+    const float *ap = A + (size_t)(m0 + row) * lda + 4 * kq;
+    const float *bp = B + (size_t)(4 * kq) * ldb + row;    // (row doubles as the column index of the B operand)
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k = k0; k < k1; k += 64) {                     // (slices are multiples of 64: four blocks of loads in flight)
+        float4 a[4];
+        float b[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = *reinterpret_cast<const float4 *>(ap + k + 16 * u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[u][j] = bp[(size_t)(k + 16 * u + j) * ldb];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u][3], acc, 0, 0, 0);
+        }
+    }
+    // accumulator layout of 16x16x4: register r of lane (col = lane & 15, group = lane >> 4) is C[4 * group + r][col]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][4 * kq + r][row] = acc[r];
+    __syncthreads();
+    const int t = threadIdx.x;                              // 256 threads = 16 x 16 outputs
+    const int om = t >> 4, on = t & 15;
+    float v = (red[0][om][on] + red[1][om][on]) + (red[2][om][on] + red[3][om][on]);
+    v *= scale ? scale[0] : 1.f;
+    if (bias && blockIdx.y == 0) v += bias[on];
+    atomicAdd(C + (size_t)(m0 + om) * ldc + on, v);
+}
+
 }  // namespace mmdgan
 
 using namespace mmdgan;
@@ -128,12 +175,32 @@ extern "C" int mmdgan_gemm(int transA, int transB, int M, int N, int K, const fl
         MMDGAN_REQUIRE(dact_rows > 0 && dact_rows < M && M - dact_rows <= dact_rows, "gemm: bad dact_rows %d for M %d", dact_rows, M);
         g.wrap_from = (long)dact_rows * ldc; g.wrap_sub = (long)(M - dact_rows) * ldc;
     }
+    if (!transA && !transB && N == 16 && M % 16 == 0 && K % 256 == 0 && K >= 1024 && act == MMDGAN_ACT_LINEAR && !dact_of &&
+        lda % 4 == 0 && (!outputs_prezeroed() || out_zeroed)) {
+        static int en = -1;
+        if (en < 0) { const char *e = getenv("MMDGAN_GEMM_SKINNY"); en = (e && e[0] == '0') ? 0 : 1; }
+        if (en) {
+            // ~512 waves: K split so that every wave keeps >= 64 of K (4 blocks of loads in flight)
+            int ksplit = 128 / (M / 16);
+            if (ksplit < 1) ksplit = 1;
+            while (ksplit > 1 && K / (ksplit * 4) < 64) ksplit >>= 1;
+            int kchunk = (K + ksplit - 1) / ksplit;
+            kchunk = (kchunk + 255) / 256 * 256;
+            ksplit = (K + kchunk - 1) / kchunk;
+            if (!out_zeroed && zero_output(C, sizeof(float) * (size_t)M * ldc, st) != hipSuccess) return check_launch("gemm memset");
+            hipLaunchKernelGGL(gemm_skinny16_kernel, dim3(M / 16, ksplit), dim3(256), 0, st, A, lda, B, ldb, bias, scale, C, ldc, K, kchunk);
+            return check_launch("gemm");
+        }
+    }
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.transA = transA; g.transB = transB; g.act = act;
     const int tiles = ((M + GT - 1) / GT) * ((N + GT - 1) / GT);
     int ksplit = 1;
     if (act == MMDGAN_ACT_LINEAR && !dact_of && tiles < 128 && K >= 512 && ldc == N &&
         (!outputs_prezeroed() || out_zeroed)) {
         ksplit = 512 / tiles;
+        static int cap = -1;                   // MMDGAN_GEMM_KSPLIT: upper bound of the K split (tuning aid)
+        if (cap < 0) { const char *e = getenv("MMDGAN_GEMM_KSPLIT"); cap = e ? atoi(e) : 0; }
+        if (cap > 0 && ksplit > cap) ksplit = cap;
         const int maxs = K / 64;
         if (ksplit > maxs) ksplit = maxs;
         if (ksplit < 1) ksplit = 1;

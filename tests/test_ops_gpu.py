@@ -566,7 +566,10 @@ def test_dact_batch_wrap(ops):
                                          (128, 8192, 16, False, True), (8192, 16, 128, True, False),
                                          (128, 8192, 64, True, False), (1, 8192, 16, False, True),
                                          (1, 16, 8192, False, False), (37, 53, 29, False, False),
-                                         (37, 53, 29, True, True)])
+                                         (37, 53, 29, True, True),
+                                         # the skinny-N MFMA kernel of D's head (N = 16, M % 16 == 0, K % 256 == 0) and its neighbours
+                                         (256, 16, 18432, False, False), (16, 16, 1024, False, False), (48, 16, 4608, False, False),
+                                         (128, 16, 8192 + 128, False, False), (120, 16, 8192, False, False)])
 def test_gemm(ops, M, N, K, ta, tb):
     rs = np.random.RandomState(M + N + K)
     a = rs.randn(*((K, M) if ta else (M, K))).astype(np.float32)
