@@ -134,6 +134,8 @@ int mmdgan_stream_wait(void *waiting_stream, void *signalling_stream);
 int mmdgan_event_record(int slot, void *stream);
 int mmdgan_event_wait(int slot, void *stream);
 int mmdgan_memset_zero(void *ptr, size_t bytes, void *stream);
+/* n buffers zeroed by one launch (16-byte aligned sizes and pointers; anything else falls back to plain memsets) */
+int mmdgan_memset_zero_multi(void *const *ptrs, const size_t *bytes, int n, void *stream);
 int mmdgan_copy(void *dst, const void *src, size_t bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -157,6 +157,51 @@ extern "C" int mmdgan_memset_zero(void *ptr, size_t bytes, void *stream) {
     if (memset_async(ptr, 0, bytes, (hipStream_t)stream) != hipSuccess) return check_launch("memset_zero");
     return MMDGAN_OK;
 }
+// several small buffers in ONE launch (a step zeroes half a dozen scratch buffers before its first kernel: six memset
+// dispatches of 4-11 us each on the critical path, or one of these)
+namespace mmdgan {
+constexpr int kZeroMultiMax = 16;
+struct ZeroTable {
+    uint4 *ptr[kZeroMultiMax];
+    unsigned first_block[kZeroMultiMax + 1];     // blocks of 256 threads x 16 bytes, prefix sums
+    unsigned long long vec16[kZeroMultiMax];     // 16-byte words per buffer
+    int n;
+};
+__global__ __launch_bounds__(256) void zero_multi_kernel(ZeroTable t) {
+    int i = 0;
+    while (i + 1 < t.n && blockIdx.x >= t.first_block[i + 1]) ++i;
+    const unsigned long long e = (unsigned long long)(blockIdx.x - t.first_block[i]) * 256 + threadIdx.x;
+    if (e < t.vec16[i]) t.ptr[i][e] = make_uint4(0u, 0u, 0u, 0u);
+}
+}  // namespace mmdgan
+extern "C" int mmdgan_memset_zero_multi(void *const *ptrs, const size_t *bytes, int n, void *stream) {
+    MMDGAN_REQUIRE(n >= 0 && (n == 0 || (ptrs && bytes)), "memset_zero_multi: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    int i = 0;
+    while (i < n) {
+        ZeroTable t;
+        t.n = 0;
+        unsigned blocks = 0;
+        for (; i < n && t.n < kZeroMultiMax; ++i) {
+            if (bytes[i] == 0) continue;
+            MMDGAN_REQUIRE(ptrs[i], "memset_zero_multi: null pointer");
+            if (((uintptr_t)ptrs[i] & 15) || (bytes[i] & 15) || bytes[i] > ((size_t)1 << 30)) {      // odd or huge: a plain memset
+                if (memset_async(ptrs[i], 0, bytes[i], st) != hipSuccess) return check_launch("memset_zero_multi");
+                continue;
+            }
+            t.ptr[t.n] = (uint4 *)ptrs[i];
+            t.vec16[t.n] = bytes[i] / 16;
+            t.first_block[t.n] = blocks;
+            blocks += (unsigned)((bytes[i] / 16 + 255) / 256);
+            ++t.n;
+        }
+        if (t.n == 0) continue;
+        t.first_block[t.n] = blocks;
+        hipLaunchKernelGGL(zero_multi_kernel, dim3(blocks), dim3(256), 0, st, t);
+        if (int rc = check_launch("memset_zero_multi")) return rc;
+    }
+    return MMDGAN_OK;
+}
 extern "C" int mmdgan_copy(void *dst, const void *src, size_t bytes, void *stream) {
     MMDGAN_REQUIRE((dst && src) || bytes == 0, "copy: null pointer");
     if (bytes == 0) return MMDGAN_OK;

@@ -37,6 +37,7 @@ SIGNATURES = {
     'mmdgan_event_record': (_I, [_I, _P]),
     'mmdgan_event_wait': (_I, [_I, _P]),
     'mmdgan_memset_zero': (_I, [_P, ctypes.c_size_t, _P]),
+    'mmdgan_memset_zero_multi': (_I, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t), _I, _P]),
     'mmdgan_copy': (_I, [_P, _P, ctypes.c_size_t, _P]),
     'mmdgan_comm_unique_id': (_I, [_P]),
     'mmdgan_comm_init': (_I, [_P, _I, _I]),

@@ -928,9 +928,8 @@ class GanEngine:
                             for t in arenas:
                                 ops.memset_zero(t)
                     ops.event_record(_EV_WINO_DIS, self._wg_raw)
-            for t in self._zero_each_step:
-                if not any(t is a for a in arenas):
-                    ops.memset_zero(t)
+            # the small scratch buffers of the step (power-iteration scratch, batch-norm totals, split-K outputs): one launch
+            ops.memset_zero_multi([t for t in self._zero_each_step if not any(t is a for a in arenas)])
             self._in_step = True
             self._d_updated_early = False
             self._forward(z, real)

@@ -95,6 +95,16 @@ def memset_zero(t, stream=None):
           'memset_zero')
 
 
+def memset_zero_multi(tensors, stream=None):
+    """zero several (small) tensors with one launch (mmdgan_memset_zero_multi)"""
+    n = len(tensors)
+    if n == 0:
+        return
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    sizes = (ctypes.c_size_t * n)(*[t.numel() * t.element_size() for t in tensors])
+    check(require_device().mmdgan_memset_zero_multi(ptrs, sizes, n, _stream() if stream is None else stream), 'memset_zero_multi')
+
+
 def copy(dst, src, stream=None):
     assert dst.numel() * dst.element_size() == src.numel() * src.element_size() and dst.is_contiguous() and src.is_contiguous()
     check(require_device().mmdgan_copy(dst.data_ptr(), src.data_ptr(), dst.numel() * dst.element_size(),

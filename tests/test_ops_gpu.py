@@ -807,3 +807,17 @@ def test_act_and_axpby(ops, act):
     assert rel_err(out.cpu().numpy(), 0.5 * x - 2.0 * dy) <= 1e-6
     ops.axpby(a, b, out=a)                                                                              # in place
     assert rel_err(a.cpu().numpy(), x + dy) <= 1e-6
+
+
+def test_memset_zero_multi(ops):
+    """several scratch buffers zeroed by one launch; odd sizes / alignments take the plain-memset route"""
+    ts = [torch.randn(n, device='cuda') for n in (4, 1024, 100000, 12, 7, 0, 524288)]
+    odd = torch.randn(64, device='cuda')[1:33]                    # 4-byte aligned only
+    d64 = torch.randn(300, device='cuda', dtype=torch.float64)
+    guard = torch.ones(8, device='cuda')
+    many = [torch.randn(16, device='cuda') for _ in range(40)]    # more than one table's worth
+    ops.memset_zero_multi(ts + [odd, d64] + many)
+    torch.cuda.synchronize()
+    for t in ts + [odd, d64] + many:
+        assert float(t.abs().sum()) == 0.0
+    assert float(guard.sum()) == 8.0
