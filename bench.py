@@ -238,12 +238,13 @@ def main():
     want = 'eager' if args.no_graph else 'graph' if args.graph else args.launch_mode
     if tape:
         want = 'eager'                                   # the primitive-op engine issues eagerly
-    elif group is not None and want in ('auto', 'graph'):
-        want = 'eager'                                   # collectives between the launches: no hipGraph; plan on request
+    elif group is not None and want == 'graph':
+        want = 'eager'                                   # collectives between the launches: no hipGraph
     trial = {}
     if want == 'auto':
-        # untimed: a few steps each way, keep the fastest launch mode
-        for m in ('eager', 'graph', 'plan'):
+        # untimed: a few steps each way, keep the fastest launch mode (data-parallel: eager or plan, the slowest rank's
+        # time decides so that every rank makes the same choice)
+        for m in (('eager', 'plan') if group is not None else ('eager', 'graph', 'plan')):
             eng.launch_mode = m
             for _ in range(5):
                 eng.step(real)
@@ -253,6 +254,11 @@ def main():
                 eng.step(real)
             torch.cuda.synchronize()
             trial[m] = (time.perf_counter() - t0) / 25
+            if group is not None:
+                import torch.distributed as dist
+                t = torch.tensor([trial[m]], device='cuda', dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                trial[m] = float(t.item())
         want = min(trial, key=trial.get)
         if os.environ.get('BENCH_VERBOSE'):
             print('launch-mode trial (ms/step):', {k: round(v * 1e3, 3) for k, v in trial.items()}, file=sys.stderr)
