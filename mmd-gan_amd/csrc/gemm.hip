@@ -152,46 +152,6 @@ __global__ __launch_bounds__(256) void gemm_skinny16_kernel(const float *__restr
     atomicAdd(C + (size_t)(m0 + om) * ldc + on, v);
 }
 
-// The generator's first layer (G l1: [B, 128] x [128, 8192], layer_func.py:909-911) opens every step: few rows, short K, wide N.
-// One workgroup = all M rows x 64 columns: A (M x K, <= 64 KB) goes through LDS once, k-major; B fragments are 128-byte runs of a
-// weight row straight from global memory; 32x32x2 MFMAs, (M / 32) x 2 accumulator tiles dealt to the four waves.
-//   C[M,N] = act(scale * A[M,K] B[K,N] + bias)
-typedef float f32x16g __attribute__((ext_vector_type(16)));
-__global__ __launch_bounds__(256) void gemm_wide_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
-                                                        const float *__restrict__ bias, const float *__restrict__ scale, int act,
-                                                        float *__restrict__ C, int ldc, int M, int K, int LDA) {
-    extern __shared__ __attribute__((aligned(16))) float As[];          // [K][LDA]
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5, wave = tid >> 6;
-    const int n0 = blockIdx.x * 64;
-    for (int e = tid; e < M * (K / 4); e += 256) {                     // float4 along k, stored transposed
-        const int m = e / (K / 4), q = e - m * (K / 4);
-        const float4 v = *reinterpret_cast<const float4 *>(A + (size_t)m * lda + 4 * q);
-        As[(4 * q + 0) * LDA + m] = v.x; As[(4 * q + 1) * LDA + m] = v.y;
-        As[(4 * q + 2) * LDA + m] = v.z; As[(4 * q + 3) * LDA + m] = v.w;
-    }
-    __syncthreads();
-    const int ntiles = (M / 32) * 2;
-    const float sc = scale ? scale[0] : 1.f;
-    for (int t = wave; t < ntiles; t += 4) {
-        const int mt = t >> 1, nt = t & 1;
-        const float *bp = B + (size_t)kh * ldb + n0 + nt * 32 + l31;
-        const float *ap = As + kh * LDA + mt * 32 + l31;
-        f32x16g acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 8
-        for (int kp = 0; kp < K / 2; ++kp)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kp * LDA], bp[(size_t)2 * kp * ldb], acc, 0, 0, 0);
-        const int col = n0 + nt * 32 + l31;
-        const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            C[(size_t)row * ldc + col] = act_fwd(acc[r] * sc + bv, act);
-        }
-    }
-}
-
 }  // namespace mmdgan
 
 using namespace mmdgan;
@@ -229,22 +189,6 @@ extern "C" int mmdgan_gemm(int transA, int transB, int M, int N, int K, const fl
             ksplit = (K + kchunk - 1) / kchunk;
             if (!out_zeroed && zero_output(C, sizeof(float) * (size_t)M * ldc, st) != hipSuccess) return check_launch("gemm memset");
             hipLaunchKernelGGL(gemm_skinny16_kernel, dim3(M / 16, ksplit), dim3(256), 0, st, A, lda, B, ldb, bias, scale, C, ldc, K, kchunk);
-            return check_launch("gemm");
-        }
-    }
-    if (!transA && !transB && !dact_of && M % 32 == 0 && M <= 128 && K % 4 == 0 && K <= 256 && N % 64 == 0 && N >= 1024 && lda % 4 == 0 &&
-        (((uintptr_t)A) & 15) == 0) {
-        static int en = -1;
-        if (en < 0) { const char *e = getenv("MMDGAN_GEMM_WIDE"); en = (e && e[0] == '0') ? 0 : 1; }
-        const int LDA = (M % 64 == 0) ? M + 32 : M;         // the two k rows of a fragment read on disjoint banks
-        const size_t lds = sizeof(float) * (size_t)K * LDA;
-        if (en && lds <= 160 * 1024 - 1024) {
-            static bool cap_raised = false;
-            if (!cap_raised) {
-                (void)hipFuncSetAttribute((const void *)gemm_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-                cap_raised = true;
-            }
-            hipLaunchKernelGGL(gemm_wide_kernel, dim3(N / 64), dim3(256), lds, st, A, lda, B, ldb, bias, scale, act, C, ldc, M, K, LDA);
             return check_launch("gemm");
         }
     }

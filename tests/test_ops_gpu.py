@@ -570,7 +570,6 @@ def test_dact_batch_wrap(ops):
                                          # the skinny-N MFMA kernel of D's head (N = 16, M % 16 == 0, K % 256 == 0) and its neighbours
                                          (256, 16, 18432, False, False), (16, 16, 1024, False, False), (48, 16, 4608, False, False),
                                          (128, 16, 8192 + 128, False, False), (120, 16, 8192, False, False),
-                                         # the wide-N MFMA kernel of G's first layer (M % 32 == 0, M <= 128, K <= 256, N % 64 == 0)
                                          (128, 8192, 128, False, False), (32, 1024, 64, False, False), (96, 2048, 256, False, False),
                                          (64, 4160, 100, False, False)])
 def test_gemm(ops, M, N, K, ta, tb):
