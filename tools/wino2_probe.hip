@@ -2,7 +2,9 @@
 #include "../mmd-gan_amd/csrc/conv_wino2.hip"
 #include <vector>
 namespace mmdgan { void set_error(const char *, ...) {} bool outputs_prezeroed() { return false; }
-static void *g_ws = nullptr; static size_t g_wsb = 0; void *workspace(size_t b) { return b <= g_wsb ? g_ws : nullptr; } }
+static void *g_ws = nullptr; static size_t g_wsb = 0; void *workspace(size_t b) { return b <= g_wsb ? g_ws : nullptr; }
+bool plan_recording() { return false; } void plan_push(std::function<void()> &&) {}
+hipError_t memset_async(void *p, int v, size_t b, hipStream_t s) { return hipMemsetAsync(p, v, b, s); } }
 int main(int argc, char **argv) {
     using namespace mmdgan;
     const int N = argc > 1 ? atoi(argv[1]) : 128, H = argc > 2 ? atoi(argv[2]) : 32, C = argc > 3 ? atoi(argv[3]) : 64, K = argc > 4 ? atoi(argv[4]) : 128;
