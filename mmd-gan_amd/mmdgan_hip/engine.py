@@ -852,8 +852,12 @@ class GanEngine:
         # the bucket is complete once the parameter-gradient stream has drained what it holds now (and the main stream
         # has reached this point, for gradients that stay there)
         if self._side_wgrad:
+            # every parameter gradient is issued there, and that stream was ordered behind the main stream (batch-norm
+            # gradients of this layer included) when the layer's launches went in (_on_wg_stream): no second marker in the
+            # main queue - six of them per step cost the one-rank exchange 0.05 ms
             ops.stream_wait(self._comm_raw, self._wg_raw)
-        ops.stream_wait(self._comm_raw, ops._stream())
+        else:
+            ops.stream_wait(self._comm_raw, ops._stream())
         lib = ops.require_device()
         if self._recording and self._dp_backend != 'capi':
             lib.mmdgan_plan_mark()                       # the collective is not the library's: a segment boundary
