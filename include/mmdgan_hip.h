@@ -120,7 +120,7 @@ int mmdgan_set_outputs_prezeroed(int on);
  *   mmdgan_stream_wait(w, s)   everything issued so far on stream s completes before anything issued later on stream w
  *   mmdgan_event_record(slot, s) / mmdgan_event_wait(slot, w)   the same, with the wait issued later than the record
  *                              (slot 0..63, per handle)
- *   mmdgan_memset_zero, mmdgan_copy (device to device)
+ *   mmdgan_memset_zero, mmdgan_memset_zero_multi, mmdgan_copy (device to device)
  * ---------------------------------------------------------------------------------------------- */
 int mmdgan_plan_begin(void);
 int mmdgan_plan_mark(void);
