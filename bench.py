@@ -42,6 +42,9 @@ def parse():
                          "'auto' (default) times a few untimed steps of each during warm-up and keeps the fastest")
     ap.add_argument('--no-graph', action='store_true', help="same as --launch-mode eager")
     ap.add_argument('--graph', action='store_true', help="same as --launch-mode graph")
+    ap.add_argument('--repeats', type=int, default=5,
+                    help='the timed region (exactly --steps steps between barriers) is run this many times; the line reports '
+                         'the MEDIAN region and every region\'s ms/step (SURVEY 8(d): median of 5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--probe-only', action='store_true',
@@ -161,23 +164,54 @@ def loss_rel_err(eng, arch, lr, loss, B):
             'vs': 'oracle/restatement.py in fp64 from the engine\'s variables, same z and batch (B=%d)' % B, 'bar': 1e-4}
 
 
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for ln in f:
+                if ln.lower().startswith('model name'):
+                    return ln.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or 'unknown'
+
+
 def cpu_baseline(arch, lr, loss, B, steps):
-    """the oracle restatement (fp32 torch-CPU) of the same step on the host cores: a reported
-    baseline, not the optimisation target."""
+    """the oracle restatement (fp32 torch-CPU) of the same step on the host cores, with all of torch's threads and with
+    one ("N = all host cores and N = 1, core count and CPU model printed"): a reported baseline, not the
+    optimisation target."""
     from oracle import restatement as R
     threads = torch.get_num_threads()
-    gan = R.OracleGan(arch, loss, tuple(lr), dtype=torch.float32, seed=0)
     rs = np.random.RandomState(1234)
     real = torch.tensor(rs.uniform(-1, 1, (B,) + tuple(arch['input'][0])).astype(np.float32))
     z = torch.tensor(rs.randn(B, arch['code'][0][0]).astype(np.float32))
-    gan.step(z, real)                                   # warm-up (allocator, oneDNN primitive cache)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        gan.step(z, real)
-    dt = time.perf_counter() - t0
-    return {'value': B * steps / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
-            'sample': '%d G+D steps of the same %dx%d B=%d workload, oracle/restatement.py fp32 on torch-CPU '
-                      '(%.1f s)' % (steps, arch['input'][0][1], arch['input'][0][2], B, dt)}
+
+    def timed(n_threads, n_steps, warm):
+        torch.set_num_threads(n_threads)
+        try:
+            gan = R.OracleGan(arch, loss, tuple(lr), dtype=torch.float32, seed=0)
+            for _ in range(warm):
+                gan.step(z, real)                       # warm-up (allocator, oneDNN primitive cache)
+            t0 = time.perf_counter()
+            for _ in range(n_steps):
+                gan.step(z, real)
+            return time.perf_counter() - t0
+        finally:
+            torch.set_num_threads(threads)
+    what = 'G+D steps of the same %dx%d B=%d workload, oracle/restatement.py fp32 on torch-CPU' % (
+        arch['input'][0][1], arch['input'][0][2], B)
+    dt = timed(threads, steps, 1)
+    out = {'value': B * steps / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port', 'cpu_model': cpu_model(),
+           'host_cpus': os.cpu_count(), 'sample': '%d %s, %d threads (%.1f s)' % (steps, what, threads, dt)}
+    # one thread: ONE step after an un-timed one, and only while that stays a bounded sample (the all-thread time says how
+    # long a single thread will take: ~threads/2 times longer at best)
+    if dt / steps * threads <= 120.0:
+        dt1 = timed(1, 1, 1)
+        out['single_thread'] = {'value': B / dt1, 'unit': 'images/sec', 'cores': 1,
+                                'sample': '1 %s, 1 thread (%.1f s)' % (what[:-len(' on torch-CPU')] + ' on torch-CPU', dt1)}
+    else:
+        out['single_thread'] = None
+    return out
 
 
 def main():
@@ -267,21 +301,28 @@ def main():
         eng.launch_mode = mode
         for _ in range(3):                               # capture / record outside the timed region
             eng.step(real)
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        eng.step(real)
-    ev1.record()
-    barrier()
-    dt = time.perf_counter() - t0
-    ev_ms = ev0.elapsed_time(ev1) / args.steps
-    if group is not None:
-        import torch.distributed as dist
-        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # the timed region: EXACTLY args.steps steps between barrier + synchronize on both sides, max over ranks; run
+    # args.repeats times back to back, the line reports the median region (and every region's ms/step)
+    regions = []
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(args.steps):
+            eng.step(real)
+        ev1.record()
+        barrier()
+        dt = time.perf_counter() - t0
+        ev_ms = ev0.elapsed_time(ev1) / args.steps
+        if group is not None:
+            import torch.distributed as dist
+            t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        regions.append((dt, ev_ms))
+    order = sorted(range(len(regions)), key=lambda i: regions[i][0])
+    dt, ev_ms = regions[order[(len(order) - 1) // 2]]                     # the median region (lower middle for an even count)
     losses = eng.losses.cpu().numpy()
     assert np.all(np.isfinite(losses)), 'Model diverged with loss = NaN'               # graph_func.py:856
 
@@ -295,6 +336,8 @@ def main():
                       else 'images/sec/node (G+D step), %s B=%d' % (args.config, B),
             'value': B * world * args.steps / dt, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
+            'repeats': len(regions), 'ms_per_step_regions': [round(r[0] / args.steps * 1e3, 4) for r in regions],
+            'ms_per_step_spread': round((max(r[0] for r in regions) - min(r[0] for r in regions)) / args.steps * 1e3, 4),
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%s %dx%d %s, batch %d per GPU, %s loss, lr %g/%g, TF-Adam, one G+D step'
                                    % (args.config, h, w, ('ResNet-SN' if has_residual_blocks(arch) else 'DCGAN-SN (primitive-op engine)') if tape else 'DCGAN-SN',
@@ -303,7 +346,9 @@ def main():
                        'launch_mode_trial_ms': {k: round(v * 1e3, 4) for k, v in trial.items()} or None},
             'loss_gen': float(losses[0]), 'loss_dis': float(losses[1]),
         }
-        whole = {'achieved': achieved, 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
+        # (algorithmic FLOPs: with Winograd kernels in the step this fraction can pass 1 - the share of SIMD cycles the MFMA
+        # pipes are busy is `mfma_busy_frac`, from the committed counter pass)
+        whole = {'achieved_algorithmic': achieved, 'frac_algorithmic': achieved / PEAK_FP32_MFMA_TFLOPS,
                  'scope': 'whole step: B*(3*F_G+7*F_D) = %.1f GFLOP algorithmic over the HIP-event step time %.3f ms'
                           % (flops_step / 1e9, ev_ms)}
         probe = dominant_kernel_probe_tape(eng, reps=args.probe_reps) if tape else dominant_kernel_probe(eng, reps=args.probe_reps)
@@ -315,12 +360,15 @@ def main():
             # and the fraction that follows from it (the tracer costs this kernel ~1 %, an un-traced HIP-event run is the
             # `frac` above), and its HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes.  No committed profile for
             # a config -> traffic null, never another config's number.
-            out['roofline'] = {'bound': 'mfma', 'achieved': probe['tflops'], 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': probe['tflops'] / PEAK_FP32_MFMA_TFLOPS,
-                               # `achieved` counts the ALGORITHMIC FLOPs of the convolution; the Winograd kernels issue only
-                               # `mfma_share` of them as MFMAs (so `frac` can pass 1): the pipe itself is busy frac_issued
-                               'mfma_share': probe.get('mfma_share', 1.0),
-                               'frac_issued': probe['tflops'] * probe.get('mfma_share', 1.0) / PEAK_FP32_MFMA_TFLOPS,
+            share = probe.get('mfma_share', 1.0)
+            out['roofline'] = {'bound': 'mfma', 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                               # the Winograd kernels issue only `mfma_share` of the convolution's algorithmic FLOPs as MFMAs.
+                               # `achieved` / `frac` are what the MFMA pipe actually does (<= 1 by construction);
+                               # `achieved_algorithmic` / `frac_algorithmic` count the convolution's own FLOPs and can pass 1
+                               'achieved': probe['tflops'] * share, 'frac': probe['tflops'] * share / PEAK_FP32_MFMA_TFLOPS,
+                               'achieved_algorithmic': probe['tflops'],
+                               'frac_algorithmic': probe['tflops'] / PEAK_FP32_MFMA_TFLOPS,
+                               'mfma_share': share,
                                'traffic': committed.get('hbm_bytes_per_launch'),
                                'traffic_over_algorithmic': committed.get('traffic_over_algorithmic'),
                                'algorithmic_bytes_per_launch': (committed.get('algorithmic_bytes_per_launch') or {}).get('total'),
@@ -328,11 +376,13 @@ def main():
                                'kernel': probe['kernel'], 'gflop_per_launch': probe['flops'] / 1e9,
                                'ms_per_launch': probe['ms'],
                                'profiled': None if not committed else {
-                                   'avg_us': committed['avg_us_profiled'], 'frac': committed['frac_from_profiled_duration'],
+                                   'avg_us': committed['avg_us_profiled'], 'frac': committed['frac_from_profiled_duration'] * share,
+                                   'frac_algorithmic': committed['frac_from_profiled_duration'],
                                    'launches': committed['probe_launches_isolated'], 'source': committed['_file']},
                                'whole_step': whole}
         else:
-            out['roofline'] = dict(whole, bound='mfma', peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s', traffic=None)
+            out['roofline'] = dict(whole, bound='mfma', peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s', traffic=None,
+                                   achieved=None, frac=None)
         busy = committed_profile('whole_step_mfma_busy', per_config=False)
         if busy and args.config == 'cifar':
             out['roofline']['whole_step']['mfma_busy_frac'] = busy.get('mfma_busy_frac_whole_step')

@@ -44,7 +44,9 @@ Api &api() {
 // (one replica = one process = one GPU), so the communicator is process-wide and the handle only records its use
 Comm g_comm = nullptr;
 int g_nranks = 0;
+unsigned g_generation = 1;
 }  // namespace
+unsigned comm_generation() { return g_generation; }
 }  // namespace mmdgan
 
 using namespace mmdgan;
@@ -70,11 +72,13 @@ extern "C" int mmdgan_comm_init(const void *id128, int nranks, int rank) {
     const int rc = a.CommInitRank(&g_comm, nranks, id, rank);
     if (rc != 0) { g_comm = nullptr; set_error("ncclCommInitRank: %s", a.GetErrorString ? a.GetErrorString(rc) : "error"); return MMDGAN_E_LAUNCH; }
     g_nranks = nranks;
+    ++g_generation;
     return MMDGAN_OK;
 }
 
 extern "C" int mmdgan_comm_destroy(void) {
-    if (g_comm) { (void)api().CommDestroy(g_comm); g_comm = nullptr; g_nranks = 0; }
+    // recorded plans hold the communicator by value: they refuse to replay once the generation has moved on
+    if (g_comm) { (void)api().CommDestroy(g_comm); g_comm = nullptr; g_nranks = 0; ++g_generation; }
     return MMDGAN_OK;
 }
 
@@ -91,6 +95,7 @@ extern "C" int mmdgan_allreduce_bucket(float *buf, size_t count, void *stream) {
     if (rc != 0) { set_error("ncclAllReduce: %s", a.GetErrorString ? a.GetErrorString(rc) : "error"); return MMDGAN_E_LAUNCH; }
     if (plan_recording()) {
         auto fn = a.AllReduce;
+        plan_note_collective();
         plan_push([=]() { (void)fn(buf, buf, count, kNcclFloat32, kNcclSum, comm, st); });
     }
     return MMDGAN_OK;

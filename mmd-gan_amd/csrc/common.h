@@ -18,7 +18,10 @@ constexpr float kLreluAlpha = 0.1f;   // layer_func.py:112
 constexpr float kEpsi = 1e-10f;       // misc_fun.py:29 FLAGS.EPSI
 
 void set_error(const char *fmt, ...);
-void *workspace(size_t need);     // caller-registered scratch of the current handle (mmdgan_set_workspace) or nullptr
+void *workspace(size_t need);     // caller-registered scratch of the current handle (mmdgan_set_workspace) or nullptr: availability only
+// the same buffer for a launch on `st` that is about to USE it: ordered behind the previous user's stream if that was another
+// one.  Batch-1 launches (the power iteration's, issued on concurrent streams) never take a workspace path at all.
+void *workspace_acquire(size_t need, hipStream_t st);
 bool outputs_prezeroed();         // mmdgan_set_outputs_prezeroed of the current handle: skip internal zeroing memsets
 
 // ---- launch plans (mmdgan_plan_*): every kernel launch, memset and stream dependency the library issues goes through the
@@ -27,6 +30,7 @@ bool outputs_prezeroed();         // mmdgan_set_outputs_prezeroed of the current
 // sequence is static can then be replayed from one C call without its ~200 host-side entry calls.
 bool plan_recording();
 void plan_push(std::function<void()> &&node);
+void plan_note_collective();      // the plan being recorded holds a collective of the library's current communicator
 hipError_t memset_async(void *p, int value, size_t bytes, hipStream_t st);
 inline hipError_t zero_output(void *p, size_t bytes, hipStream_t st) {
     return outputs_prezeroed() ? hipSuccess : memset_async(p, 0, bytes, st);

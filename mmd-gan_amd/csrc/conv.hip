@@ -29,12 +29,6 @@ bool force_valu_thin() {
     return v == 1;
 }
 inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }    // also true for nullptr
-// MMDGAN_BFX=2: the split-bf16 kernel takes every shape it is eligible for (A/B and the parity tests)
-bool bfx_first() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("MMDGAN_BFX"); v = (e && atoi(e) >= 2) ? 1 : 0; }
-    return v == 1;
-}
 }  // namespace
 
 namespace {
@@ -68,7 +62,6 @@ extern "C" int mmdgan_conv2d_fwd(const mmdgan_conv_geom *g, const float *x, cons
                        "conv2d_fwd: MMDGAN_ACT_FLAG_W_WINOGRAD on a geometry mmdgan_wino_eligible() rejects");
         return d.R == 3 ? wino_fwd(d, ep, x, nullptr, w, y, (hipStream_t)stream) : wino2_fwd(d, ep, x, nullptr, w, y, (hipStream_t)stream);
     }
-    if (!force_direct() && bfx_first() && bfx_fwd_ok(d)) return bfx_fwd(d, ep, x, w, nullptr, y, (hipStream_t)stream);
     if (!force_direct() && wino2_fwd_ok(d)) return wino2_fwd(d, ep, x, w, nullptr, y, (hipStream_t)stream);
     if (!force_direct() && wino_fwd_ok(d)) return wino_fwd(d, ep, x, w, nullptr, y, (hipStream_t)stream);
     if (!force_direct() && igemm_fwd_ok(d)) return igemm_fwd(d, ep, x, w, y, (hipStream_t)stream);
@@ -96,7 +89,6 @@ extern "C" int mmdgan_conv2d_dgrad(const mmdgan_conv_geom *g, const float *dy, c
                        "conv2d_dgrad: MMDGAN_ACT_FLAG_W_WINOGRAD on a geometry mmdgan_wino_eligible() rejects");
         return d.R == 3 ? wino_dgrad(d, ep, dy, nullptr, w, dx, (hipStream_t)stream) : wino2_dgrad(d, ep, dy, nullptr, w, dx, (hipStream_t)stream);
     }
-    if (!force_direct() && bfx_first() && bfx_dgrad_ok(d)) return bfx_dgrad(d, ep, dy, w, nullptr, dx, (hipStream_t)stream);
     if (!force_direct() && wino2_dgrad_ok(d)) return wino2_dgrad(d, ep, dy, w, nullptr, dx, (hipStream_t)stream);
     if (!force_direct() && wino_dgrad_ok(d)) return wino_dgrad(d, ep, dy, w, nullptr, dx, (hipStream_t)stream);
     if (!force_direct() && igemm_dgrad_ok(d)) return igemm_dgrad(d, ep, dy, w, dx, (hipStream_t)stream);

@@ -125,23 +125,11 @@ __device__ __forceinline__ void mainloop(P &p, int s_begin, int s_end, float *sm
         _Pragma("unroll") for (int mi = 0; mi < T::TM; ++mi) fa[J][mi] = ap[2 * KG * (J) * T::LDA + mi * 32]; \
         _Pragma("unroll") for (int ni = 0; ni < T::TN; ++ni) fb[J][ni] = bp[2 * KG * (J) * T::LDB + ni * 32]; \
     }
-#ifdef MMDGAN_ABLATE_FRAG
-#pragma unroll
-        for (int j = 0; j < NKP; ++j) {
-#pragma unroll
-            for (int mi = 0; mi < T::TM; ++mi) fa[j][mi] = (float)(s + j + mi + lane);
-#pragma unroll
-            for (int ni = 0; ni < T::TN; ++ni) fb[j][ni] = (float)(s - j + ni + lane);
-        }
-#else
 #pragma unroll
         for (int j = 0; j < PF; ++j) MMDGAN_FRAG(j)
-#endif
 #pragma unroll
         for (int j = 0; j < NKP; ++j) {
-#ifndef MMDGAN_ABLATE_FRAG
             if (j + PF < NKP) MMDGAN_FRAG(j + PF)
-#endif
 #pragma unroll
             for (int mi = 0; mi < T::TM; ++mi)
 #pragma unroll
@@ -150,39 +138,21 @@ __device__ __forceinline__ void mainloop(P &p, int s_begin, int s_end, float *sm
 #pragma unroll
             for (int q = 0; q < 2 * NP; ++q) {
                 if ((q * NKP) / (2 * NP) != j) continue;
-#ifdef MMDGAN_PIECES_LOADS_LATE
-                // (old order: all LDS stores in the first half of the stage, all global loads in the second)
-#ifndef MMDGAN_ABLATE_STORE
-                if (q < T::A_F4) MMDGAN_W_A(An, q)
-                else if (q < NP) MMDGAN_W_B(Bn, q - T::A_F4)
-#endif
-#ifndef MMDGAN_ABLATE_GLOBAL
-                if (q >= NP && q < NP + T::A_F4) ra[q - NP] = p.load_a1(s + 2, q - NP);
-                else if (q >= NP + T::A_F4) rb[q - NP - T::A_F4] = p.load_b1(s + 2, q - NP - T::A_F4);
-#endif
-#else
                 // store register i to LDS (tile s+1), then immediately refill it from global (tile s+2):
                 // every load has a full stage of MFMAs between its issue and the ds_write that consumes it
                 const int i = q >> 1;
                 if ((q & 1) == 0) {
-#ifndef MMDGAN_ABLATE_STORE
                     if (i < T::A_F4) MMDGAN_W_A(An, i)
                     else MMDGAN_W_B(Bn, i - T::A_F4)
-#endif
                 } else {
-#ifndef MMDGAN_ABLATE_GLOBAL
                     if (i < T::A_F4) ra[i] = p.load_a1(s + 2, i);
                     else rb[i - T::A_F4] = p.load_b1(s + 2, i - T::A_F4);
-#endif
                 }
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef MMDGAN_FRAG
-#ifndef MMDGAN_ABLATE_BARRIER
         __syncthreads();
-#endif
     }
 #undef MMDGAN_W_A
 #undef MMDGAN_W_B
@@ -375,25 +345,9 @@ __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(ConvDims d, ConvEpi
         for (int ni = 0; ni < T::TN; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-#ifdef MMDGAN_TIMELINE          // tools/igemm_probe.hip: wall-clock (100 MHz) stamps per workgroup
-    extern __device__ unsigned long long g_timeline[];
-    const int tl = (blockIdx.y * gridDim.x + blockIdx.x) * 4;
-    if ((MMDGAN_TIMELINE & 1) && threadIdx.x == 0) g_timeline[tl + 0] = wall_clock64();
-    if ((MMDGAN_TIMELINE & 16) && threadIdx.x == 0)       // where did this workgroup run: XCC_ID (hwreg 20), HW_ID (hwreg 4)
-        g_timeline[tl + 1] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32) |
-                             (unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
-#endif
     FwdProblem<BM, BN, KG> p;
     p.init(d, x, w, m0, n0, M);
-#ifdef MMDGAN_TIMELINE
-    if ((MMDGAN_TIMELINE & 2) && threadIdx.x == 0) g_timeline[tl + 1] = wall_clock64();
-    if ((MMDGAN_TIMELINE & 32) && threadIdx.x == 0) g_timeline[tl + 1] = clock64();      // shader clock at entry
-#endif
     mainloop<BM, BN, KG>(p, s0, s1, smem, acc);
-#ifdef MMDGAN_TIMELINE
-    if ((MMDGAN_TIMELINE & 4) && threadIdx.x == 0) g_timeline[tl + 2] = wall_clock64();
-    if ((MMDGAN_TIMELINE & 32) && threadIdx.x == 0) g_timeline[tl + 2] = clock64();      // ... and after the main loop
-#endif
     const float sc = ep.scale ? ep.scale[0] : 1.f;
     const int Kc = d.K;
     auto rowoff = [=](int row) -> long {
@@ -401,9 +355,6 @@ __global__ __launch_bounds__(256 * KG) void igemm_fwd_kernel(ConvDims d, ConvEpi
         return m < M ? m * Kc + n0 : -1;
     };
     epilogue_store<BM, BN, SPLIT, KG>(smem, acc, rowoff, n0, ep, sc, y, !SPLIT || blockIdx.z == 0, false);
-#ifdef MMDGAN_TIMELINE
-    if ((MMDGAN_TIMELINE & 8) && threadIdx.x == 0) g_timeline[tl + 3] = wall_clock64();
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -74,16 +74,6 @@ int wino2_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, cons
 bool wino2_wgrad_ok(const ConvDims &d);
 int wino2_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, float *dbias, bool *dbias_done, hipStream_t st);
 
-// split-bf16 (three exact bf16 terms per fp32 operand, six products) gather-GEMM on the bf16 MFMA pipe (conv_bfx.hip);
-// Wp = weights already split by bfx_transform, or nullptr (then w is split into the workspace)
-bool bfx_eligible(const ConvDims &d, bool dgrad);
-bool bfx_fwd_ok(const ConvDims &d);
-bool bfx_dgrad_ok(const ConvDims &d);
-size_t bfx_weight_bytes(const ConvDims &d);
-int bfx_transform(const ConvDims &d, const float *w, bool dgrad, void *Wp, hipStream_t st);
-int bfx_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, const void *Wp, float *y, hipStream_t st);
-int bfx_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, const void *Wp, float *dx, hipStream_t st);
-
 // MFMA implicit-GEMM path (conv_igemm.hip); *_ok() say whether a geometry is eligible
 bool igemm_fwd_ok(const ConvDims &d);
 bool igemm_dgrad_ok(const ConvDims &d);

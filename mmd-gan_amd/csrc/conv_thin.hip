@@ -319,7 +319,8 @@ int thin_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hi
     if (rpb < 1) rpb = 1;
     const int xblocks = (nrows + rpb - 1) / rpb;
     // measured: 512 blocks x 1728 contended fp32 atomics cost 125-265 us; partials + reduce ~15 us
-    float *partials = (float *)workspace(sizeof(float) * nout * xblocks);
+    // (a batch-1 launch belongs to a power iteration, which shares the handle with concurrent chains: atomics, not the workspace)
+    float *partials = d.N > 1 ? (float *)workspace_acquire(sizeof(float) * nout * xblocks, st) : nullptr;
     if (!partials && zero_output(dw, sizeof(float) * nout, st) != hipSuccess) return check_launch("conv2d_wgrad memset");
     if (wide_k) hipLaunchKernelGGL(thin_wgrad_kernel<true>, dim3(xblocks, ychunks), dim3(256), 0, st, d, x, dy, dw, rpb, partials);
     else hipLaunchKernelGGL(thin_wgrad_kernel<false>, dim3(xblocks, ychunks), dim3(256), 0, st, d, x, dy, dw, rpb, partials);

@@ -412,7 +412,8 @@ int thinm_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, h
     if (blocks > 256) blocks = 256;
     const int rpw = (nrows + blocks * 4 - 1) / (blocks * 4);
     blocks = (nrows + rpw * 4 - 1) / (rpw * 4);
-    float *partials = (float *)workspace(sizeof(float) * nout * blocks);
+    if (d.N == 1) return 1;                       // batch-1 (power iteration, concurrent chains): never the shared workspace
+    float *partials = (float *)workspace_acquire(sizeof(float) * nout * blocks, st);
     if (!partials) return 1;
     const bool thin_in = d.R * d.R * d.C <= 32 && (d.K == 32 || d.K == 64);
     if (thin_in) {

@@ -344,8 +344,9 @@ static bool wino_shape_ok(const ConvDims &d, int cr, int ko) {
 }
 // would the library run this geometry through Winograd (given transformed weights or a workspace for them)?
 bool wino_eligible(const ConvDims &d, bool dgrad) { return dgrad ? wino_shape_ok(d, d.K, d.C) : wino_shape_ok(d, d.C, d.K); }
-bool wino_fwd_ok(const ConvDims &d) { return wino_shape_ok(d, d.C, d.K) && workspace(sizeof(float) * 16 * (size_t)d.C * d.K) != nullptr; }
-bool wino_dgrad_ok(const ConvDims &d) { return wino_shape_ok(d, d.K, d.C) && workspace(sizeof(float) * 16 * (size_t)d.C * d.K) != nullptr; }
+// (without transformed weights the call transforms into the workspace: not for batch-1 launches, which run on concurrent chains)
+bool wino_fwd_ok(const ConvDims &d) { return d.N > 1 && wino_shape_ok(d, d.C, d.K) && workspace(sizeof(float) * 16 * (size_t)d.C * d.K) != nullptr; }
+bool wino_dgrad_ok(const ConvDims &d) { return d.N > 1 && wino_shape_ok(d, d.K, d.C) && workspace(sizeof(float) * 16 * (size_t)d.C * d.K) != nullptr; }
 
 int wino_transform(const ConvDims &d, const float *w, bool flip, float *U, hipStream_t st) {
     const dim3 wg((d.K + 31) / 32, (d.C + 31) / 32);
@@ -359,7 +360,8 @@ static int wino_launch(const ConvDims &d, const ConvEpilogue &ep, const float *i
                        bool flip, hipStream_t st) {
     const int cr = flip ? d.K : d.C, ko = flip ? d.C : d.K;
     if (!U) {
-        float *ws = (float *)workspace(sizeof(float) * 16 * (size_t)cr * ko);
+        float *ws = (float *)workspace_acquire(sizeof(float) * 16 * (size_t)cr * ko, st);
+        if (!ws) { set_error("conv2d (winograd): no workspace for the transformed weights"); return MMDGAN_E_ARG; }
         if (int rc = wino_transform(d, w, flip, ws, st)) return rc;
         U = ws;
     }
@@ -486,11 +488,7 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(int N, int H, int W,
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int xx = 2 * pw.tx - 1 + j;
-#ifdef WW_ABLATE_XLOAD
-            rin[j] = make_float4(1.f, 2.f, 3.f, (float)j);
-#else
             rin[j] = bufld4(rx, (rowok && xx >= 0 && xx < W) ? base + (unsigned)(j * C * 4) : kOOB);
-#endif
         }
         advance(pw, step8, TW, TH);
     };
@@ -529,11 +527,7 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(int N, int H, int W,
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-#ifdef WW_ABLATE_DYLOAD
-                dyv[slot][cb][p] = (float)(p + cb);
-#else
                 dyv[slot][cb][p] = bufld1s(rdy, off, (unsigned)(cb * 128) + (p >> 1) * dyrow + (p & 1) * dypix);
-#endif
             }
     };
 
@@ -594,13 +588,9 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(int N, int H, int W,
                 const float z2 = Ts[((2 * 3 + t) * 32 + cc) * 32 + kk], z3 = Ts[((3 * 3 + t) * 32 + cc) * 32 + kk];
                 float *dst = dw + ((long)t * CK) + (long)(c0 + cc) * K + n0 + cb * 32 + kk;      // dw[r][t][c][k], r = 0
                 const float h = 0.5f * (z1 + z2);
-#ifdef WW_ABLATE_ATOMICS
-                if (h == 123.456f) dst[0] = z0 + z3;
-#else
                 atomicAdd(dst, z0 + h);
                 atomicAdd(dst + 3 * CK, 0.5f * (z1 - z2));
                 atomicAdd(dst + 6 * CK, h + z3);
-#endif
             }
         }
         __syncthreads();
@@ -829,7 +819,7 @@ bool wino_wgrad_slab_ok(const ConvDims &d) {
 bool wino_wgrad_ok(const ConvDims &d) {
     static int en = -1;
     if (en < 0) { const char *e = getenv("MMDGAN_WINO_WGRAD"); en = (e && e[0] == '0') ? 0 : 1; }
-    return en && wino_enabled() && d.R == 3 && d.stride == 1 && d.pad == 1 && d.H % 2 == 0 && d.W % 2 == 0 && d.C % 32 == 0 &&
+    return en && d.N > 1 && wino_enabled() && d.R == 3 && d.stride == 1 && d.pad == 1 && d.H % 2 == 0 && d.W % 2 == 0 && d.C % 32 == 0 &&
            d.K % 64 == 0 && (long)d.N * (d.H / 2) * (d.W / 2) >= (wino_min_tiles() < 256 ? wino_min_tiles() : 256);   // 79 vs 89 us at 512 tiles (D l7)
 }
 
@@ -846,7 +836,7 @@ int wino_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, fl
         const int sps = (nst + split - 1) / split;
         split = (nst + sps - 1) / sps;                                  // every slab gets written
         const size_t n = 9 * (size_t)d.C * d.K;
-        if (float *part = (float *)workspace(sizeof(float) * (n + d.K) * split)) {
+        if (float *part = (float *)workspace_acquire(sizeof(float) * (n + d.K) * split, st)) {
             static bool cap_raised = false;
             if (!cap_raised) {
                 (void)hipFuncSetAttribute((const void *)wino_wgrad_slab_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)winos::LDS_BYTES);

@@ -162,11 +162,7 @@ __global__ __launch_bounds__(FUSE ? 512 : 256, FUSE ? 1 : 2) void wino2_kernel(w
 #pragma unroll
             for (int v = 0; v < 3; ++v) {
                 const int col = tx * P.tstep + P.c0[gs] + v * P.pstep;
-#ifdef W2_ABLATE_XSAME        /* every tile reads image 0: the loads stay, their HBM / L2-miss part goes */
-                xoff[u][v] = (rowok && col >= 0 && col < P.IW) ? (unsigned)(((((long)0 * P.IH + row) * P.IW + col) * P.Cr + 4 * cq) * 4) : kOOB;
-#else
                 xoff[u][v] = (rowok && col >= 0 && col < P.IW) ? (unsigned)(((((long)tn * P.IH + row) * P.IW + col) * P.Cr + 4 * cq) * 4) : kOOB;
-#endif
             }
         }
     };
@@ -193,21 +189,9 @@ __global__ __launch_bounds__(FUSE ? 512 : 256, FUSE ? 1 : 2) void wino2_kernel(w
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
-#ifdef W2_ABLATE_XLOAD
-#define W2_XL(E) make_float4(1.f, 2.f, 3.f, 4.f)
-#else
 #define W2_XL(E) (E)
-#endif
-#ifdef W2_ABLATE_VSTORE
-#define W2_VS(DST, VAL) asm volatile("" ::"v"(VAL))
-#else
 #define W2_VS(DST, VAL) DST = VAL
-#endif
-#ifdef W2_ABLATE_BLOAD
-#define W2_BL 1.f + 0.f *
-#else
 #define W2_BL
-#endif
     float4 rin[3][3];
     float fb[BD][NM];
     // global -> registers: patch row U_ of stage S
@@ -286,17 +270,6 @@ __global__ __launch_bounds__(FUSE ? 512 : 256, FUSE ? 1 : 2) void wino2_kernel(w
 #undef W2_VSTORE_CH
 #undef W2_BLOAD
 
-#ifdef W2_ABLATE_EPILOGUE
-    {
-        float t = 0.f;
-#pragma unroll
-        for (int m = 0; m < NM; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) t += acc[m][r];
-        if (t == 123.456f) out[tid] = t;
-        return;
-    }
-#endif
     // ---- output transform + epilogue: Ms[f][tile][k 32], one column block at a time
     const float sc = ep.scale ? ep.scale[0] : 1.f;
     float *Ms = smem;
@@ -374,8 +347,8 @@ static bool wino2_shape_ok(const ConvDims &d, bool dgrad) {
 }
 bool wino2_eligible(const ConvDims &d, bool dgrad) { return wino2_shape_ok(d, dgrad); }
 static size_t wino2_bytes(const ConvDims &d) { return sizeof(float) * 36 * (size_t)d.C * d.K; }
-bool wino2_fwd_ok(const ConvDims &d) { return wino2_shape_ok(d, false) && workspace(wino2_bytes(d)) != nullptr; }
-bool wino2_dgrad_ok(const ConvDims &d) { return wino2_shape_ok(d, true) && workspace(wino2_bytes(d)) != nullptr; }
+bool wino2_fwd_ok(const ConvDims &d) { return d.N > 1 && wino2_shape_ok(d, false) && workspace(wino2_bytes(d)) != nullptr; }
+bool wino2_dgrad_ok(const ConvDims &d) { return d.N > 1 && wino2_shape_ok(d, true) && workspace(wino2_bytes(d)) != nullptr; }
 
 int wino2_transform(const ConvDims &d, const float *w, bool dgrad, float *U, hipStream_t st) {
     const dim3 wg((d.K + 31) / 32, (d.C + 31) / 32, 4);
@@ -387,7 +360,8 @@ int wino2_transform(const ConvDims &d, const float *w, bool dgrad, float *U, hip
 static int wino2_launch(const ConvDims &d, const ConvEpilogue &ep, const float *in, const float *w, const float *U, float *out,
                         bool dgrad, hipStream_t st) {
     if (!U) {
-        float *ws = (float *)workspace(wino2_bytes(d));
+        float *ws = (float *)workspace_acquire(wino2_bytes(d), st);
+        if (!ws) { set_error("conv2d (winograd 2x2): no workspace for the transformed weights"); return MMDGAN_E_ARG; }
         if (int rc = wino2_transform(d, w, dgrad, ws, st)) return rc;
         U = ws;
     }
@@ -682,6 +656,7 @@ bool wino2_wgrad_ok(const ConvDims &d) {
     static int en = -1;
     if (en < 0) { const char *e = getenv("MMDGAN_WINO2_WGRAD"); en = e ? atoi(e) : W2W_DEFAULT; }
     if ((!en && wino2_mode() < 2) || wino2_mode() == 0) return false;
+    if (d.N == 1) return false;     // batch-1 = a power iteration's launch, on a chain concurrent with others: no workspace slabs
     // the batch-1 weight gradients of the power iteration (64 tiles) stay direct: 7.7 us against 7 + the 6 us reduction pass
     if (wino2_mode() < 2 && (long)d.N * (d.P / 2) * (d.Q / 2) < 256) return false;
     return d.R == 4 && d.stride == 2 && d.pad == 1 && d.H % 4 == 0 && d.W % 4 == 0 && d.C % wino2w::BC == 0 && d.K % wino2w::BK == 0;
@@ -708,7 +683,7 @@ int wino2_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, f
     }
     if (dbias_done) *dbias_done = false;
     const dim3 grid(d.C / wino2w::BC, d.K / wino2w::BK, 4 * split);
-    if (float *part = (float *)workspace(sizeof(float) * (n + d.K) * split)) {
+    if (float *part = (float *)workspace_acquire(sizeof(float) * (n + d.K) * split, st)) {
         float *dbpart = part + n * split;
         if (dbias)
             hipLaunchKernelGGL((wino2_wgrad_kernel<true, true>), grid, dim3(wino2w::NT), wino2w::LDS_BYTES, st, d.N, d.H, d.W, d.C, d.K, x, dy, part,

@@ -19,7 +19,14 @@ void set_error(const char *fmt, ...) {
 struct Plan {
     std::vector<std::function<void()>> nodes;
     std::vector<size_t> segment_end;          // node count at the end of each closed segment
+    std::vector<hipEvent_t> events;           // one per recorded stream_wait node (re-used on every replay), freed with the plan
+    unsigned comm_generation = 0;             // of the library's communicator when a collective was recorded (0: none recorded)
+    ~Plan() {
+        for (hipEvent_t e : events)
+            if (e) (void)hipEventDestroy(e);
+    }
 };
+unsigned comm_generation();                   // comm.hip: bumped by every mmdgan_comm_init / _destroy
 
 }  // namespace mmdgan
 
@@ -30,14 +37,15 @@ struct mmdgan_handle {
     void *ws = nullptr;
     size_t ws_bytes = 0;
     bool prezeroed = false;
+    bool ws_used = false;                                  // the workspace has had a user since it was registered
+    hipStream_t ws_stream = nullptr;                       // ... the stream of its latest user (workspace_acquire)
     std::unique_ptr<mmdgan::Plan> recording;
     std::vector<std::unique_ptr<mmdgan::Plan>> plans;      // plan id = index (destroyed plans leave a null slot)
-    std::vector<hipEvent_t> plan_events;                   // one per recorded stream_wait node (re-used on every replay)
     std::vector<hipEvent_t> pool;                          // round-robin pool of the un-recorded stream_wait calls
     size_t pool_next = 0;
     std::vector<hipEvent_t> slots;                         // named slots of mmdgan_event_record / _wait
     ~mmdgan_handle() {
-        for (auto *v : {&plan_events, &pool, &slots})
+        for (auto *v : {&pool, &slots})
             for (hipEvent_t e : *v)
                 if (e) (void)hipEventDestroy(e);
     }
@@ -53,8 +61,20 @@ void *workspace(size_t need) {
     mmdgan_handle &h = cur();
     return (h.ws && need <= h.ws_bytes) ? h.ws : nullptr;
 }
+// The workspace is ONE buffer with one user at a time.  A launch that writes it on another stream than the previous user
+// is ordered behind that stream (event record + wait, recorded into a plan like any dependency), so two chains of an
+// engine that both reach a workspace path serialise there instead of corrupting each other's partial sums.
+void *workspace_acquire(size_t need, hipStream_t st) {
+    mmdgan_handle &h = cur();
+    if (!h.ws || need > h.ws_bytes) return nullptr;
+    if (h.ws_used && h.ws_stream != st && mmdgan_stream_wait((void *)st, (void *)h.ws_stream) != MMDGAN_OK) return nullptr;
+    h.ws_used = true;
+    h.ws_stream = st;
+    return h.ws;
+}
 bool plan_recording() { return cur().recording != nullptr; }
 void plan_push(std::function<void()> &&node) { cur().recording->nodes.emplace_back(std::move(node)); }
+void plan_note_collective() { cur().recording->comm_generation = comm_generation(); }
 
 hipError_t memset_async(void *p, int value, size_t bytes, hipStream_t st) {
     hipError_t e = hipMemsetAsync(p, value, bytes, st);
@@ -94,6 +114,7 @@ extern "C" int mmdgan_make_current(mmdgan_handle *h) {
 extern "C" int mmdgan_set_workspace(void *ptr, size_t bytes) {
     cur().ws = ptr;
     cur().ws_bytes = ptr ? bytes : 0;
+    cur().ws_used = false;
     return MMDGAN_OK;
 }
 extern "C" int mmdgan_set_outputs_prezeroed(int on) {
@@ -115,7 +136,7 @@ extern "C" int mmdgan_stream_wait(void *waiting_stream, void *signalling_stream)
     hipEvent_t ev = nullptr;
     if (plan_recording()) {                    // the node keeps an event of its own
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return check_launch("stream_wait event");
-        h.plan_events.push_back(ev);
+        h.recording->events.push_back(ev);
     } else {                                   // a wait captures the event's state when it is issued: re-use is safe
         constexpr size_t kPool = 64;
         if (h.pool.size() < kPool) {
@@ -250,6 +271,8 @@ extern "C" int mmdgan_plan_replay(int plan_id, int segment) {
     MMDGAN_REQUIRE(!plan_recording(), "plan_replay: a plan is being recorded");
     MMDGAN_REQUIRE(plan_id >= 0 && plan_id < (int)h.plans.size() && h.plans[plan_id], "plan_replay: no plan %d", plan_id);
     Plan &p = *h.plans[plan_id];
+    MMDGAN_REQUIRE(p.comm_generation == 0 || p.comm_generation == comm_generation(),
+                   "plan_replay: plan %d holds collectives of a communicator that has been destroyed since (record it again)", plan_id);
     const int nseg = (int)p.segment_end.size();
     MMDGAN_REQUIRE(segment >= -1 && segment < nseg, "plan_replay: plan %d has %d segments (asked for %d)", plan_id, nseg, segment);
     const size_t lo = segment <= 0 ? 0 : p.segment_end[segment - 1];

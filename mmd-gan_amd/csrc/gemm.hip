@@ -4,6 +4,8 @@
 // bound by streaming the weight matrix once, so this is an LDS-tiled fp32 VALU kernel with
 // split-K for the K >> M*N shapes rather than an MFMA kernel.
 //   C[M,N] = act(scale * op(A) op(B) + bias)           (or * act'(dact_of) in backward form)
+#include <stdint.h>
+
 #include "common.h"
 
 namespace mmdgan {
@@ -176,7 +178,7 @@ extern "C" int mmdgan_gemm(int transA, int transB, int M, int N, int K, const fl
         g.wrap_from = (long)dact_rows * ldc; g.wrap_sub = (long)(M - dact_rows) * ldc;
     }
     if (!transA && !transB && N == 16 && M % 16 == 0 && K % 256 == 0 && K >= 1024 && act == MMDGAN_ACT_LINEAR && !dact_of &&
-        lda % 4 == 0 && (!outputs_prezeroed() || out_zeroed)) {
+        lda % 4 == 0 && ((uintptr_t)A & 15) == 0 && ldc == N && (!outputs_prezeroed() || out_zeroed)) {
         static int en = -1;
         if (en < 0) { const char *e = getenv("MMDGAN_GEMM_SKINNY"); en = (e && e[0] == '0') ? 0 : 1; }
         if (en) {

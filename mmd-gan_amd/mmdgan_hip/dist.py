@@ -93,6 +93,9 @@ def broadcast_state(eng, group=None, src=0):
             tdist.broadcast(t, src=src, group=group)
         for k in sorted(net.state):
             tdist.broadcast(net.state[k], src=src, group=group)
+    loss = getattr(eng, '_loss', None)                   # the *_mix coin's two moving averages are training state too
+    if loss is not None and getattr(loss, 'state', None) is not None:
+        tdist.broadcast(loss.state, src=src, group=group)
 
 
 def shard_of(n_items, rank, world):

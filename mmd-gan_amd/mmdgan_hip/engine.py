@@ -561,15 +561,9 @@ class GanEngine:
                         lead = (16,) if s.R == 3 else (4, 9)     # F(2x2,3x3) / F(2x2,2x2) on 4 parity segments
                         self._wino[s.scope] = [torch.empty(lead + (c, k), device=dev) if fw else None,
                                                torch.empty(lead + (k, c), device=dev) if bw else None, net]
-        # The batch-1 convolutions of the power iteration take the library's own route; should one of them be
-        # Winograd-eligible (tiny thresholds, as in the parity tests) the library transforms its weights into the
-        # shared workspace inside the call - one user at a time, so then all SN chains share one stream.
-        for s in self.dis.specs:
-            if s.sn and s.op == 'c':
-                c, h, w = s.in_shape_ref
-                if ops.wino_eligible(1, h, w, c, s.out, s.R, s.stride, False) or ops.wino_eligible(1, h, w, c, s.out, s.R, s.stride, True):
-                    self._sn_streams = self._sn_streams[:1]
-                    break
+        # The batch-1 convolutions of the power iteration run on two concurrent chains and take the library's own route: a
+        # batch-1 launch never goes through the handle's shared workspace (no in-call Winograd transform, no slab / partial-sum
+        # weight gradient - csrc: "d.N > 1"), and any other cross-stream workspace user is ordered by workspace_acquire.
         gs = self.gen.specs
         for below, above in zip(gs, gs[1:]):     # input-gradient of a tc layer into a linear layer: split-K target
             if above.op == 'tc' and (below.bn or below.act == 'linear'):
@@ -726,8 +720,8 @@ class GanEngine:
                     ops.sn_wgrad_fixup(gw.view(-1), net.state[s.scope + '#dsigma'].view(-1), dot,
                                        net.state[s.scope + '#sigma'], scale)
             self._on_wg_stream(param_grads, s)
-            self._exchange(net, li)
             if li > 0:
+                self._exchange(net, li)
                 prev = specs[li - 1]
                 dprev, yprev = b[prev.scope + '#dz'], b[prev.scope + '#y']
                 if s.op == 'd':
@@ -750,6 +744,9 @@ class GanEngine:
                 else:
                     ops.conv2d_dgrad(dzg, w, (yprev.shape[1], yprev.shape[2]), s.stride, scale=scale, act=act_prev,
                                      dact_of=yprev, out=out)
+                # D's last bucket goes AFTER the launch above: D's early Adam (which follows that bucket on the exchange
+                # stream) rewrites the kernel this input-gradient reads
+                self._exchange(net, li)
         return b['d_fake']                                                   # gradient w.r.t. G's last pre-activation
 
     def _on_wg_stream(self, fn, spec):
@@ -866,7 +863,9 @@ class GanEngine:
         last = bucket is self._grad_buckets[id(net)][-1]
         if last and net is self.dis and self._early_d_adam:
             # D's exchange is complete and nothing in G's backward pass reads D's weights: its Adam runs on the exchange
-            # stream, beside G's backward pass, instead of at the tail of the step
+            # stream, beside G's backward pass, instead of at the tail of the step - behind everything the main stream
+            # holds now (the last reader of D's weights, the input-gradient of D's first layer, was issued just before)
+            ops.stream_wait(self._comm_raw, ops._stream())
             with torch.cuda.stream(self._comm_stream):
                 self.dis.opt.step(self.lr_d, grad_scale=1.0 / self.world)
             self._d_updated_early = True
@@ -968,11 +967,8 @@ class GanEngine:
         if mode == 'graph' and self.dist_group is not None:
             mode = 'eager'                               # a collective cannot sit inside the captured graph
         if (self.lr_d, self.lr_g) != self._baked_lr:     # a captured graph / recorded plan holds the learning rates by value
-            self._graph, self._baked_lr = None, (self.lr_d, self.lr_g)
-            if self._plan is not None:
-                with self._handle:
-                    ops.require_device().mmdgan_plan_destroy(self._plan)
-                self._plan = None
+            self._baked_lr = (self.lr_d, self.lr_g)
+            self._drop_recordings()
         with self._handle:                               # this engine's workspace / prezeroed mode / plans
             if mode == 'eager':
                 # the batch goes straight into the first half of D's input buffer (one copy, not two)
@@ -1079,7 +1075,7 @@ class GanEngine:
             net.arena.view(k, net.adam_v).copy_(torch.as_tensor(net._to_native(k, v[k]), device=self.device))
         for net in (self.gen, self.dis):
             net.opt.step_counter.fill_(int(t))
-        self._graph = None
+        self._drop_recordings()
 
     def sigmas(self):
         return OrderedDict((s.scope, float(self.dis.state[s.scope + '#sigma'].item())) for s in self.dis.specs if s.sn)
@@ -1100,4 +1096,12 @@ class GanEngine:
             net.adam_m.copy_(sd[tag + '/adam_m'])
             net.adam_v.copy_(sd[tag + '/adam_v'])
             net.opt.step_counter.fill_(int(sd[tag + '/adam_t']))
+        self._drop_recordings()
+
+    def _drop_recordings(self):
+        """forget the captured graph and the recorded plan (both are re-made by the next step)"""
         self._graph = None
+        if self._plan is not None:
+            with self._handle:
+                ops.require_device().mmdgan_plan_destroy(self._plan)
+            self._plan = None

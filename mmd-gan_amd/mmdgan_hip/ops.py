@@ -48,9 +48,14 @@ def set_workspace(nbytes=64 << 20, device=None):
     return _workspace
 
 
+import threading as _threading
+_current_handles = _threading.local()
+
+
 class Handle:
     """an mmdgan_handle (include/mmdgan_hip.h): one engine's workspace, prezeroed mode, launch plans and events.
-    `with handle:` makes it the calling thread's current handle and restores the process default afterwards."""
+    `with handle:` makes it the calling thread's current handle and restores the handle that was current before (a
+    per-thread stack: constructing or stepping another engine inside the block does not strand the outer one)."""
 
     def __init__(self, workspace_bytes=64 << 20, device=None):
         lib = require_device()
@@ -63,11 +68,17 @@ class Handle:
                 check(lib.mmdgan_set_workspace(self.workspace.data_ptr(), workspace_bytes), 'set_workspace')
 
     def __enter__(self):
+        stack = getattr(_current_handles, 'stack', None)
+        if stack is None:
+            stack = _current_handles.stack = []
+        stack.append(self)
         self._lib.mmdgan_make_current(self._h)
         return self
 
     def __exit__(self, *exc):
-        self._lib.mmdgan_make_current(None)
+        stack = _current_handles.stack
+        stack.pop()
+        self._lib.mmdgan_make_current(stack[-1]._h if stack else None)     # None: the process default handle
         return False
 
     def __del__(self):

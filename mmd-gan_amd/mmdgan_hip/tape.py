@@ -976,6 +976,7 @@ class TapeEngine:
             main.wait_stream(self._sn_stream)
             main.wait_event(self._dis_ready)
         dvals = self._forward(self.dis, self._dis_in, True, 'd')
+        self._last_vals = (gvals, dvals)                                 # (the parity tests read activations from here)
         scores = dvals[self.dis.out_val]                                 # [2B, d]: s_x = [:B], s_gen = [B:]
         self._loss.launch(scores, self.losses)
         ds = self._loss.grads.view(4 * B, -1)       # [dLd/ds_x ; dLd/ds_gen ; dLg/ds_gen ; dLg/ds_x]

@@ -454,7 +454,14 @@ def sn_power_iteration(w, x, spec):
 # ---------------------------------------------------------------------------
 # forward pass of one net (layer_func.py:870-928, 946-966, 1646-1685, 2078-2100)
 # ---------------------------------------------------------------------------
-def _act(x, name):
+def _act(x, name, mask=None):
+    """mask (tests only, see net_forward): the SIGN DECISIONS of another evaluation of the same layer (bool tensor, True where that
+    evaluation's output was positive).  relu / lrelu then take their slope from it instead of from x - the two differ only
+    where a pre-activation lies within rounding of zero.  An fp32 run of this oracle forced to an fp32 kernel's masks is the
+    floor the kernel's gradients are measured against: what fp32 arithmetic loses against fp64 under the SAME decisions."""
+    if mask is not None and name in ('relu', 'lrelu'):
+        lo = 0.0 if name == 'relu' else LRELU_ALPHA
+        return x * torch.where(mask, torch.ones((), dtype=x.dtype), torch.full((), lo, dtype=x.dtype))
     if name == 'linear':
         return x
     if name == 'relu':
@@ -466,10 +473,16 @@ def _act(x, name):
     raise NotImplementedError('Function {} is not implemented.'.format(name))
 
 
-def net_forward(specs, params, x, is_training=True, collect=None):
+def net_forward(specs, params, x, is_training=True, collect=None, masks=None):
     """returns (output, updates) - updates maps variable name -> new value (the UPDATE_OPS of
     graph_func.py:848: SN in_rand assignments and BN moving statistics)."""
     updates = OrderedDict()
+    # masks (tests only): {'gen': [...], 'dis': [...]} - for every relu / lrelu this net evaluates, in evaluation order,
+    # the sign decisions another evaluation took there (_act)
+    mask_iter = iter(masks[specs[0]['scope'].split('/')[0]]) if masks is not None else None
+
+    def act(t, name):
+        return _act(t, name, next(mask_iter) if (mask_iter is not None and name in ('relu', 'lrelu')) else None)
 
     def batch_norm(t, prefix):                                # layer_func.py:953-966, SURVEY A.4
         axis_shape, dims = [1, -1, 1, 1], [0, 2, 3]
@@ -511,20 +524,20 @@ def net_forward(specs, params, x, is_training=True, collect=None):
             if d['op'] == 'i':                                # identity kernel, then BN and activation (:1646-1685)
                 if d['act_nm'] in ('bn', 'BN'):
                     x = batch_norm(x, sc + '/BN')
-                x = _act(x, d['act'])
+                x = act(x, d['act'])
             else:                                             # Layer._apply_layer_res_, layer_func.py:1773-1842
                 r = s['res']
                 res = x
                 if d['type'] != 'res_v1':
                     if r['bn0']:
                         res = batch_norm(res, sc + '/BN_0')
-                    res = _act(res, d['act'])
+                    res = act(res, d['act'])
                 if r['up']:
                     res = _rescale(res, d['scale'])
                 res = conv_op(res, r['k0'], sc + '/bias_0/bias' if r['bias'] else None)
                 if r['bn1']:
                     res = batch_norm(res, sc + '/BN_1')
-                res = _act(res, d['act'])
+                res = act(res, d['act'])
                 res = conv_op(res, r['k1'], sc + '/bias_1/bias' if r['bias'] else None)
                 if r['down']:
                     res = _rescale(res, d['scale'])
@@ -579,7 +592,7 @@ def net_forward(specs, params, x, is_training=True, collect=None):
                 mean, var = params[sc + '/BN/BN/moving_mean'], params[sc + '/BN/BN/moving_variance']
             x = (x - mean.reshape(axis_shape)) / torch.sqrt(var.reshape(axis_shape) + BN_EPS)
             x = x * params[sc + '/BN/BN/gamma'].reshape(axis_shape) + params[sc + '/BN/BN/beta'].reshape(axis_shape)
-        x = _act(x, d['act'])
+        x = act(x, d['act'])
         if d['scale'] is not None and d['scale'][1] < 0:     # layer_func.py:1682-1684
             x = _rescale(x, d['scale'])
         if collect is not None:
@@ -808,10 +821,10 @@ class OracleGan:
             opt.t = int(t)
         self.global_step = int(t)
 
-    def forward_losses(self, z, real, collect=None, uni=None):
+    def forward_losses(self, z, real, collect=None, uni=None, masks=None):
         p = self.params
-        gen, up_g = net_forward(self.gen_specs, p, z, True, collect)
-        dis_out, up_d = net_forward(self.dis_specs, p, torch.cat([real, gen], 0), True, collect)   # my_sngan.py:278
+        gen, up_g = net_forward(self.gen_specs, p, z, True, collect, masks)
+        dis_out, up_d = net_forward(self.dis_specs, p, torch.cat([real, gen], 0), True, collect, masks)   # my_sngan.py:278
         b = z.shape[0]
         s_x, s_gen = dis_out[:b], dis_out[b:]                                                    # my_sngan.py:279
         if self.loss_type in MIX_LOSSES:          # the coin's state is two more UPDATE_OPS variables
@@ -824,13 +837,13 @@ class OracleGan:
         updates.update(up_d)
         return loss_gen, loss_dis, stats, updates, (gen, s_x, s_gen)
 
-    def grads(self, z, real, collect=None, uni=None):
+    def grads(self, z, real, collect=None, uni=None, masks=None):
         leaves = {n: self.params[n].detach().clone().requires_grad_(True)
                   for n in self.dis_names + self.gen_names}
         saved = dict(self.params)
         self.params.update(leaves)
         try:
-            loss_gen, loss_dis, stats, updates, aux = self.forward_losses(z, real, collect, uni)
+            loss_gen, loss_dis, stats, updates, aux = self.forward_losses(z, real, collect, uni, masks)
             gd = torch.autograd.grad(loss_dis, [leaves[n] for n in self.dis_names], retain_graph=True)
             gg = torch.autograd.grad(loss_gen, [leaves[n] for n in self.gen_names])
         finally:

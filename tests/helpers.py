@@ -57,3 +57,124 @@ def load(path):
 
 def designs_of(fx):
     return ast.literal_eval(str(fx['designs_repr']))
+
+
+def l2_err(got, ref, gscale=0.0):
+    """||got - ref|| / (||ref|| + 1e-6 * gscale): the L2 distance of a gradient tensor from its reference, relative"""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    return float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-6 * gscale))
+
+
+def engine_masks(eng):
+    """the relu / lrelu sign decisions of an engine's last training step in the oracle's layouts (NCHW / reference
+    feature order): {'gen': [...], 'dis': [...]}, one bool tensor per relu / lrelu in evaluation order - what
+    OracleGan.grads(masks=...) takes to evaluate fp32 arithmetic under the SAME decisions (oracle/restatement.py:_act)"""
+    import torch
+
+    def to_ref(y, perm):
+        y = y.detach().cpu()
+        if y.dim() == 4:
+            y = y.permute(0, 3, 1, 2)
+        elif perm is not None:                           # features of a dense layer that feeds an image reshape: NHWC order
+            t = torch.empty_like(y)
+            t[:, torch.as_tensor(perm)] = y
+            y = t
+        return (y > 0).contiguous()
+    out = {'gen': [], 'dis': []}
+    if hasattr(eng, 'buf'):                              # the hand-scheduled engine: one activation per layer
+        for name, net in (('gen', eng.gen), ('dis', eng.dis)):
+            for s in net.specs:
+                if s.act in ('relu', 'lrelu'):
+                    out[name].append(to_ref(eng.buf[s.scope + '#y'], s.col_perm))
+        return out
+    for name, net, vals in (('gen', eng.gen, eng._last_vals[0]), ('dis', eng.dis, eng._last_vals[1])):   # primitive-op engine
+        produced_by = {p['out']: p for p in net.prims}
+        for p in net.prims:
+            if p['kind'] in ('bn', 'act') and p['act'] in ('relu', 'lrelu'):
+                perm = None
+                if p['kind'] == 'bn':
+                    perm = net._bn_perm.get(p['prefix'])
+                else:
+                    src = produced_by.get(p['ins'][0])
+                    if src is not None and src['kind'] == 'dense':
+                        perm = src['k'].col_perm
+                out[name].append(to_ref(vals[p['out']], perm))
+    return out
+
+
+GRAD_BAR = 5e-4
+
+
+def assert_grads_within_fp32_floor(grads, ref64, floor32, skip=(), what=''):
+    """THE rule for gradients of a step against the fp64 oracle (one rule, every step test): each tensor within 5e-4 in L2,
+    or within twice what an fp32 evaluation of the oracle itself loses against its fp64 evaluation on the same step.
+    grads / ref64: name -> array; floor32: a callable returning name -> array (the fp32 oracle's gradients; evaluated
+    lazily, once, only when some tensor is above the plain bar) or a dict."""
+    cache = {}
+
+    def f32():
+        if 'v' not in cache:
+            cache['v'] = floor32() if callable(floor32) else floor32
+        return cache['v']
+    for net in ('gen', 'dis'):
+        names = [n for n in grads if n.startswith(net)]
+        if not names:
+            continue
+        gscale = max(float(np.abs(np.asarray(ref64[n])).max()) for n in names)
+        for n in names:
+            if n in skip:
+                continue
+            r = np.asarray(ref64[n], np.float64)
+            err = l2_err(grads[n], r, gscale)
+            if err <= GRAD_BAR:
+                continue
+            fl = l2_err(np.asarray(f32()[n], np.float64), r, gscale)
+            assert err <= 2.0 * fl + GRAD_BAR, (what, n, err, fl)
+
+
+def fp32_floor(arch, loss_type, lr, prev_vars, z, real, eng, uni=None, mix_state=None, **kw):
+    """the fp32 side of helpers.assert_grads_within_fp32_floor for a teacher-forced step: the oracle in fp32 from the same
+    variables on the same batch, its relu / lrelu sign decisions forced to the ones the engine's kernels took (two fp32
+    evaluations decide differently where a pre-activation lies within rounding of zero - about once per million elements;
+    forcing makes the floor the loss of fp32 ARITHMETIC, not the luck of which evaluation met such an element)"""
+    def run():
+        o32 = _R().OracleGan(arch, loss_type, lr, dtype=_torch().float32, params=prev_vars, **kw)
+        if mix_state is not None:
+            o32.mix_state = mix_state
+        r32 = o32.grads(_torch().tensor(z), _torch().tensor(real), uni=uni, masks=engine_masks(eng))
+        out = {n: g.numpy() for n, g in r32[4].items()}
+        out.update({n: g.numpy() for n, g in r32[5].items()})
+        return out
+    return run
+
+
+
+def fp32_oracle_trajectory_grads(fx, arch, sn_mode):
+    """the gradients of the fixture's LAST step as the restatement computes them free-running in fp32 from the fixture's
+    initial variables on the fixture's inputs: what an fp32 evaluation of the same trajectory loses against the fp64 one"""
+    init = {k[len('init/'):]: v for k, v in fx.items() if k.startswith('init/')}
+    o32 = _R().OracleGan(arch, str(fx['loss_type']), tuple(fx['lr']), dtype=_torch().float32, params=init, sn_mode=sn_mode)
+    if 'adam_t' in fx:
+        o32.set_adam_state({k[len('adam_m/'):]: v for k, v in fx.items() if k.startswith('adam_m/')},
+                           {k[len('adam_v/'):]: v for k, v in fx.items() if k.startswith('adam_v/')}, int(fx['adam_t']))
+    n_steps = fx['z'].shape[0]
+    for step in range(n_steps):
+        z, real = _torch().tensor(fx['z'][step]), _torch().tensor(fx['real'][step])
+        if step == n_steps - 1:
+            r = o32.grads(z, real)
+            out = {n: g.numpy() for n, g in r[4].items()}
+            out.update({n: g.numpy() for n, g in r[5].items()})
+            return out
+        o32.step(z, real)
+
+
+
+
+def _R():
+    from oracle import restatement
+    return restatement
+
+
+def _torch():
+    import torch
+    return torch

@@ -502,24 +502,6 @@ def test_conv2d_winograd_path(ops, case):
         ops.conv2d_fwd(nhwc(x), dev(np.zeros((5, 5, C, K), np.float32)), 1, wino=uf)
 
 
-def test_split_bf16_prototype_kernel_is_fp32_accurate():
-    """csrc/conv_bfx.hip (opt-in, MMDGAN_BFX=2): convolutions on the bf16 MFMA pipe with every fp32 operand split EXACTLY
-    into three bf16 terms and six products per block - forward, stride-1 and stride-2 input-gradients, the transposed-conv
-    forward form and the 3B-row dact wrap all go through its one gather-GEMM.  The switch is read once per process, so
-    the conv parity tests of this file are re-run in a child process with it set; they must pass unchanged (1e-4
-    norm-wise AND the element-wise bar) - a prototype that needed looser bars would not ship even as opt-in."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, MMDGAN_BFX='2')
-    here = os.path.abspath(__file__)
-    r = subprocess.run([sys.executable, '-m', 'pytest', here, '-m', 'gpu', '-q', '-x', '-k',
-                        'conv2d_fwd or conv2d_dgrad_and_wgrad or transpose_forward_form or dact_batch_wrap'],
-                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(here)))
-    assert r.returncode == 0, r.stdout[-3000:]
-    assert ' passed' in r.stdout and 'failed' not in r.stdout, r.stdout[-500:]
-
-
 @pytest.mark.parametrize('case', [(4, 4, 4, 512, 256, 4, 2), (3, 8, 8, 256, 128, 4, 2), (2, 16, 16, 128, 64, 4, 2),
                                   (3, 4, 4, 32, 16, 4, 2), (2, 3, 3, 16, 8, 4, 2)],
                          ids=lambda c: str(c))

@@ -1,5 +1,7 @@
 """The oracle (oracle/restatement.py, oracle/mmd_oracle.c) against the golden vectors that
 oracle/make_golden.py produced by running the reference's own code.  CPU only."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -272,3 +274,47 @@ def test_bicubic_restatement(h, w, oh, ow):
         ref = torch.nn.functional.interpolate(x, size=(oh, ow), mode='bicubic', align_corners=True)
         assert float((got - ref).abs().max()) <= 4e-3 * float(x.abs().max())      # 1/2048 in position x the kernel's slope
         assert torch.allclose(got[:, :, 0, 0], x[:, :, 0, 0], atol=1e-6) and torch.allclose(got[:, :, -1, -1], x[:, :, -1, -1], atol=1e-6)
+
+
+def test_forced_activation_masks_are_a_no_op_on_the_oracles_own_decisions():
+    """OracleGan.grads(masks=...) (the fp32 floor of the step tests, helpers.fp32_floor): forcing every relu / lrelu to the
+    sign decisions the SAME evaluation takes anyway changes nothing, for plain layers and for residual blocks; forcing one
+    different decision does change the gradients (the option is live)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
+    from tiny_arch import tiny_architecture, tiny_res_architecture
+    for arch in (tiny_architecture(), tiny_res_architecture()):
+        B = 4
+        ora = R.OracleGan(arch, 'rep', (5e-4, 2e-4), dtype=torch.float64, seed=3)
+        rs = np.random.RandomState(1)
+        z = torch.tensor(rs.randn(B, arch['code'][0][0]))
+        real = torch.tensor(rs.uniform(-1, 1, (B,) + tuple(arch['input'][0])))
+        ora.step(z, real)                                # normalised SN vectors: gradients above rounding noise
+        ora.step(z, real)
+        seen = {'gen': [], 'dis': []}
+        orig = R._act
+
+        def spy(x, name, mask=None):
+            y = orig(x, name, mask)
+            if name in ('relu', 'lrelu'):
+                seen[spy.net].append((y.detach() > 0))
+            return y
+        # record the decisions of a plain evaluation, net by net (G runs first, then D on [real ; fake])
+        R._act = spy
+        try:
+            spy.net = 'gen'
+            gen, _ = R.net_forward(ora.gen_specs, ora.params, z, True)
+            spy.net = 'dis'
+            R.net_forward(ora.dis_specs, ora.params, torch.cat([real, gen], 0), True)
+        finally:
+            R._act = orig
+        assert seen['gen'] and seen['dis']
+        plain = ora.grads(z, real)
+        forced = ora.grads(z, real, masks=seen)
+        for a, b in zip(list(plain[4].values()) + list(plain[5].values()), list(forced[4].values()) + list(forced[5].values())):
+            assert float((a - b).abs().max()) <= 1e-12 * max(float(a.abs().max()), 1e-30)
+        flipped = {k: [m.clone() for m in v] for k, v in seen.items()}
+        flipped['dis'][0].view(-1)[::7] ^= True
+        other = ora.grads(z, real, masks=flipped)
+        name = next(iter(plain[4]))
+        assert float((other[4][name] - plain[4][name]).abs().max()) > 1e-6 * float(plain[4][name].abs().max())
