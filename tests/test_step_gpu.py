@@ -67,7 +67,7 @@ def test_step_matches_reference_golden(loss_type, launch_mode):
             # below), so no fp32 evaluation of the trajectory tracks the fp64 one entry by entry: the one gradient rule
             # of these tests (helpers.assert_grads_within_fp32_floor), the floor being the restatement's own fp32 run
             ref64 = {n: fx[pre + 'grad/' + n + '_f64'] for n in grads}
-            assert_grads_withinfp32_floor(grads, ref64, lambda: fp32_oracle_trajectory_grads(fx, tiny_architecture(), sn_mode),
+            assert_grads_within_fp32_floor(grads, ref64, lambda: fp32_oracle_trajectory_grads(fx, tiny_architecture(), sn_mode),
                                            skip=('dis/l8_s/bias/bias',), what=loss_type)
         else:
             for n, g in grads.items():
@@ -232,7 +232,7 @@ def test_step_matches_oracle_mfma_path(loss_type):
         # L2-relative, not max-abs: one ReLU mask flip at an element whose BN output is ~1e-7 (fp32 vs fp64 rounding;
         # measured: 1 of 1M elements) moves a handful of gradient entries by ~1e-3 of the max and leaves the rest at ~2e-6.
         # The one rule: 5e-4 in L2, or twice what the oracle ITSELF loses in fp32 on this step under the kernel's masks
-        assert_grads_withinfp32_floor(grads, ref_g, fp32_floor(arch, loss_type, (5e-4, 2e-4), prev_vars, z, real, eng),
+        assert_grads_within_fp32_floor(grads, ref_g, fp32_floor(arch, loss_type, (5e-4, 2e-4), prev_vars, z, real, eng),
                                        skip=(last_bias,), what=(loss_type, step))
         final = eng.get_variables()
         for n, v in final.items():
@@ -313,7 +313,7 @@ def test_step_on_the_shipped_architectures(config, loss, B, mode):
         assert sum(flips_d) + sum(flips_g) <= 1e-5 * sum(eng.buf[s.scope + '#y'].numel() for s in eng.dis.specs + eng.gen.specs) + 3
         # ... and the gradients follow the one rule: 5e-4 in L2 (measured 3e-6 ... 2e-5 with no flipped mask on the path), or
         # twice what the oracle itself loses in fp32 under the same sign decisions
-        assert_grads_withinfp32_floor(grads, ref_g, fp32_floor(arch, loss, tuple(lr), prev_vars, z, real, eng),
+        assert_grads_within_fp32_floor(grads, ref_g, fp32_floor(arch, loss, tuple(lr), prev_vars, z, real, eng),
                                        skip=(last + '/bias/bias',), what=(config, B, mode))
 
 
@@ -353,7 +353,7 @@ def test_step_with_the_coin_mixed_losses(loss_type, use_graph):
             continue
         grads = eng.get_variables(grad=True)
         ref_g = {n: g.numpy() for n, g in list(gd.items()) + list(gg.items())}
-        assert_grads_withinfp32_floor(grads, ref_g, fp32_floor(arch, loss_type, (5e-4, 2e-4), prev_vars, z, real, eng, uni=uni,
+        assert_grads_within_fp32_floor(grads, ref_g, fp32_floor(arch, loss_type, (5e-4, 2e-4), prev_vars, z, real, eng, uni=uni,
                                                                  mix_state=prev_mix, mix_threshold=thr),
                                        skip=(last_bias,), what=(loss_type, step))
     sd = eng.state_dict()
@@ -395,7 +395,7 @@ def test_dense_on_dense_generator_keeps_its_gradients_past_the_first_step():
         if step == 0:
             continue
         grads = {n: g for n, g in eng.get_variables(grad=True).items() if n.startswith('gen')}
-        assert_grads_withinfp32_floor(grads, {n: g.numpy() for n, g in gg.items()},
+        assert_grads_within_fp32_floor(grads, {n: g.numpy() for n, g in gg.items()},
                                        fp32_floor(arch, 'rep', (5e-4, 2e-4), prev_vars, z, real, eng), what=step)
 
 
