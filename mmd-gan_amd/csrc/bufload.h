@@ -31,4 +31,16 @@ __device__ __forceinline__ float bufld1s(__amdgpu_buffer_rsrc_t r, unsigned byte
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, s_off, 0));
 }
 
+__device__ __forceinline__ float4 bufld4s(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned s_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, s_off, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// 16-byte store through a buffer resource: an offset beyond num_records is dropped by the hardware (no branch for ragged tiles)
+__device__ __forceinline__ void bufst4(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 v) {
+    u32x4 d;
+    d.x = __float_as_uint(v.x); d.y = __float_as_uint(v.y); d.z = __float_as_uint(v.z); d.w = __float_as_uint(v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, byte_off, 0, 0);
+}
+
 }  // namespace mmdgan

@@ -15,14 +15,13 @@
 // Structure as conv_wino.hip: 32 tiles x 64 output channels per workgroup, V through LDS, B fragments
 // straight from L2 into registers, output transform through LDS in the epilogue.  The 9 frequencies x 2
 // column blocks = 18 accumulators are dealt round-robin to the 4 waves (5,5,4,4).
+#include <type_traits>
+
 #include "conv_internal.h"
 #include "bufload.h"
 
 #ifndef W2W_DEFAULT
 #define W2W_DEFAULT 1
-#endif
-#ifndef W2_FUSE_MIN_WGS
-#define W2_FUSE_MIN_WGS 0
 #endif
 
 namespace mmdgan {
@@ -30,32 +29,35 @@ namespace mmdgan {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace wino2 {
-constexpr int BC = 32;                  // reduction channels per stage: one 128-byte line of every patch pixel
-constexpr int LDT = 33;                 // V: floats per channel row (32 tiles + 1)
-constexpr int FSV = BC * LDT + 2;       // V: floats per frequency
+constexpr int BC = 32;                  // reduction channels per stage: one 128-byte line of every patch pixel = 4 groups of 8
+constexpr int ROW = 32 * 4 + 4;         // V: floats per (channel group, k half) row = [32 tiles][4 k-pairs] + 4 (write banks, below)
+constexpr int FSV = 8 * ROW;            // V: floats per frequency = 4 channel groups x 2 k halves
 constexpr int V_FLOATS = 9 * FSV;
-constexpr int MS_FLOATS = 9 * 32 * 32;  // epilogue exchange buffer (one column block at a time)
-constexpr int SMEM_FLOATS = 2 * V_FLOATS > MS_FLOATS ? 2 * V_FLOATS : MS_FLOATS;
-constexpr size_t LDS_BYTES = sizeof(float) * SMEM_FLOATS + sizeof(long) * 32;
-constexpr int NM = 5;                   // frequencies per wave (waves 2, 3 use 4)
+constexpr int MS_FLOATS = 9 * 32 * 32;       // epilogue exchange buffer (one column block at a time), Ms[f][tile][k 32]
+static_assert(MS_FLOATS <= V_FLOATS, "the epilogue buffer is the V buffer the last stage released");
+constexpr int SMEM_FLOATS = 2 * V_FLOATS;
+constexpr size_t LDS_BYTES = sizeof(float) * SMEM_FLOATS + sizeof(unsigned) * 64 + sizeof(int) * 4;
+constexpr int NM = 5;                   // frequencies per wave (the waves with the odd frequencies use 4)
 
 struct Params {
     int N, TH, TW;          // tiles per image (rows, cols)
     int IH, IW, Cr;         // input image, reduction channels per segment
-    int nseg;               // segments per phase (1 or 4); phase = blockIdx.z
+    int nseg;               // segments per phase (1 or 4)
     int r0[4], c0[4];       // patch origin (input row / col of patch element (0,0) for tile (0,0)) per global segment
     int tstep, pstep;       // input rows (cols) between consecutive tiles / consecutive patch rows (cols)
     int OH, OW, Ko;         // output image, channels
     int otile, ostep;       // output row = ty * otile + a * ostep + o0r[phase]
     int o0r[4], o0c[4];
-    int ntb, nkb, nph;      // workgroups = tile blocks x column blocks x phases, launched as a 1-D grid
-    int xcd_remap;          // 1: workgroup -> (tile block, phase, column block) through the XCD-aware map below
+    int ntb, nkb, nph;      // work items = tile blocks x column blocks x phases
 };
 }  // namespace wino2
 
-// U[seg][f][cr][ko] = (G g G^T)[f], f = 3i + j, g = the 2x2 filter of the segment
+// U[seg][f][cr / 8][cr & 1][ko][(cr & 7) >> 1] = (G g G^T)[f], f = 3i + j, g = the 2x2 filter of the segment
 //   FWD  : seg = (a,b);  g[u][v] = w[2u + a][2v + b][c][k];            cr = c, ko = k
 //   DGRAD: seg = (al,be); g[u][v] = w[rho(al,1-u)][rho(be,1-v)][c][k], rho(0,r') = 1 + 2r', rho(1,r') = 2r';  cr = k, ko = c
+// The innermost four floats are the B operands of four consecutive MFMA k-pairs for one lane (k half = cr & 1, column
+// = ko): the convolution kernel fetches them with ONE 16-byte load per lane, 512 contiguous bytes per half-wave.
+// C and K are multiples of 32 (every geometry the F(2x2,2x2) kernels accept).
 template <bool DGRAD>
 __global__ __launch_bounds__(256) void wino2_weight_kernel(const float *__restrict__ w, float *__restrict__ U, int C, int K) {
     __shared__ float tile[9][32][33];
@@ -63,7 +65,6 @@ __global__ __launch_bounds__(256) void wino2_weight_kernel(const float *__restri
     const int tk = threadIdx.x & 31, tq = threadIdx.x >> 5;
     for (int cc = tq; cc < 32; cc += 8) {
         const int c = c0 + cc, k = k0 + tk;
-        const bool ok = c < C && k < K;
         float g[2][2];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
@@ -71,255 +72,365 @@ __global__ __launch_bounds__(256) void wino2_weight_kernel(const float *__restri
             for (int v = 0; v < 2; ++v) {
                 const int r = DGRAD ? (sa == 0 ? 1 + 2 * (1 - u) : 2 * (1 - u)) : 2 * u + sa;
                 const int t = DGRAD ? (sb == 0 ? 1 + 2 * (1 - v) : 2 * (1 - v)) : 2 * v + sb;
-                g[u][v] = ok ? w[((size_t)(r * 4 + t) * C + c) * K + k] : 0.f;
+                g[u][v] = w[((size_t)(r * 4 + t) * C + c) * K + k];
             }
         float gg[3][2], uu[3][3];
 #pragma unroll
         for (int v = 0; v < 2; ++v) { gg[0][v] = g[0][v]; gg[1][v] = g[0][v] + g[1][v]; gg[2][v] = g[1][v]; }
 #pragma unroll
         for (int i = 0; i < 3; ++i) { uu[i][0] = gg[i][0]; uu[i][1] = gg[i][0] + gg[i][1]; uu[i][2] = gg[i][1]; }
-        if (!DGRAD) {
-            if (ok) {
 #pragma unroll
-                for (int f = 0; f < 9; ++f) U[(((size_t)seg * 9 + f) * C + c) * K + k] = uu[f / 3][f % 3];
-            }
-        } else {
-#pragma unroll
-            for (int f = 0; f < 9; ++f) tile[f][cc][tk] = uu[f / 3][f % 3];
-        }
+        for (int f = 0; f < 9; ++f) tile[f][cc][tk] = uu[f / 3][f % 3];
     }
-    if (DGRAD) {             // transposed write: U[seg][f][k][c], threads along c
-        __syncthreads();
-        for (int kk = tq; kk < 32; kk += 8) {
-            const int k = k0 + kk, c = c0 + tk;
-            if (c < C && k < K) {
+    __syncthreads();
+    // thread = (output channel of the block tk, channel group of the block tq >> 1, k half tq & 1)
+    const int Cr = DGRAD ? K : C, Ko = DGRAD ? C : K, cr0 = DGRAD ? k0 : c0, ko0 = DGRAD ? c0 : k0;
+    const int g8 = tq >> 1, kh = tq & 1;
 #pragma unroll
-                for (int f = 0; f < 9; ++f) U[(((size_t)seg * 9 + f) * K + k) * C + c] = tile[f][tk][kk];
-            }
+    for (int f = 0; f < 9; ++f) {
+        float4 v;
+        float *pv = reinterpret_cast<float *>(&v);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int crl = g8 * 8 + 2 * q + kh;
+            pv[q] = DGRAD ? tile[f][tk][crl] : tile[f][crl][tk];
         }
+        const size_t row = (((size_t)seg * 9 + f) * (Cr >> 3) + (cr0 >> 3) + g8) * 2 + kh;
+        *reinterpret_cast<float4 *>(U + (row * Ko + ko0 + tk) * 4) = v;
     }
 }
 
-// A stage is 32 reduction channels of one segment = 80 (64) MFMAs per wave between barriers:
-//   producer  thread = (tile, channel quad): the 9 pixels of its 3x3 patch as float4 (8 neighbouring lanes read one
-//             full 128-byte line of each pixel; the first version read 32 bytes per pixel and stage and paid a third of
-//             its time re-fetching lines from L2), the whole B^T d B in registers, 36 ds_write_b32;
-//   consumer  A fragments from LDS one k-pair ahead, B fragments straight from L2, every register refilled for 4
-//             k-pairs later right after the MFMA that consumed it.
-// FUSE: two neighbouring tile blocks of the same (phase, column block) run as ONE 512-thread workgroup - two groups of four
-// waves with the same instruction stream, their own halves of LDS and shared barriers.  Both groups read the SAME B fragments
-// at about the same time, so the second read is an L1 hit (or merges with the pending miss): the B traffic between L2 and the
-// CU - the vector-memory path this kernel is bound by - halves, with no more registers or LDS per CU than two workgroups.
-template <bool FUSE>
-__global__ __launch_bounds__(FUSE ? 512 : 256, FUSE ? 1 : 2) void wino2_kernel(wino2::Params P, ConvEpilogue ep, const float *__restrict__ x,
-                                                                               const float *__restrict__ U, float *__restrict__ out) {
+// PERSISTENT and CONTINUOUS: the grid is (at most) two workgroups per CU, every workgroup walks a contiguous run of work
+// items (tile block, phase, column block), and the stages of ALL its items form one software pipeline: while stage L is
+// multiplied, stage L+1 goes registers -> LDS and stage L+2 global -> registers, across item boundaries.  An item of the
+// launch this was built for (the 3B-row input-gradient of D l2: 1536 items) is only four stages long; as one workgroup per
+// item (round 2) each paid a serial prologue (patch load -> transform -> barrier), and its epilogue's stores sat in front
+// of the next workgroup's first loads.  Now the only thing between two items is the epilogue (accumulators -> LDS -> output
+// transform -> stores) - into the ONE V buffer that is free then, a column block at a time - and the other workgroup of
+// the CU, which is somewhere else in its own item, has the MFMA pipes to itself meanwhile.  Measured on that launch
+// (tools/wino2_probe.hip history, in-kernel stamps): 97 us as one workgroup per item -> 80 us persistent with the vector
+// fragments below (95 with the epilogue's activation-derivative operands, which the first probe forgot) -> 79 us continuous,
+// operands included.  Per item now: main loop 17 us against 15.5 us of MFMA issue per pair of workgroups at the 2.37 GHz the
+// part holds in this kernel, epilogue 6 us - 4 of them the output stores and operand loads of ALL workgroups of the chip
+// arriving together (they run in lock step); fetching the operands earlier (last stage, or touching their lines in the
+// first) and starting the second workgroup of every CU late did not shorten the item (23.3 us in every variant).
+//
+// A stage is 32 reduction channels of one segment = 4 groups of 4 MFMA k-pairs, 80 (64) MFMAs per wave between barriers:
+//   producer  thread = (tile, channel quad): the 9 pixels of its 3x3 patch as float4 (8 neighbouring lanes read one full
+//             128-byte line of each pixel), the whole B^T d B in registers, 18 ds_write_b64 into V[f][group][k half][tile][4]
+//             (row stride 132 floats: the four groups of a wave's store land on disjoint banks);
+//   consumer  B fragments of a group = ONE 16-byte load per frequency straight from L2 (layout above), a group ahead; A
+//             fragments = one ds_read_b64 per frequency and k-pair PAIR, two k-pairs ahead: a quarter / half of the vector-
+//             memory / LDS instructions of the one-dword-per-MFMA form this kernel had before.
+// Workgroup -> wave roles: 18 accumulators over 4 waves = 5,5,4,4.  The roles are rotated by where the workgroup's first
+// wave sits (hardware slot and SIMD, read once) so that, with the placement observed on gfx950 (tools/wg_census.hip: the
+// two workgroups of a CU on slots 0 / 1, waves on SIMDs in cyclic order), every SIMD carries a 5-wave of one workgroup and
+// a 4-wave of the other.  A speed assumption only: any placement computes the same result.
+__global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpilogue ep, const float *__restrict__ x,
+                                                       const float *__restrict__ U, float *__restrict__ out) {
     using namespace wino2;
-    extern __shared__ __attribute__((aligned(16))) float smem_all[];
-    const int grp = FUSE ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
-    float *smem = smem_all + grp * (int)(LDS_BYTES / sizeof(float));
-    const int tid = threadIdx.x & 255, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned *obase = reinterpret_cast<unsigned *>(smem + SMEM_FLOATS);  // [item parity][tile]: output byte offset of the tile
+    int *wgctl = reinterpret_cast<int *>(obase + 64);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     // wave-uniform by construction, but hipcc only knows once it sits in an SGPR: without this every B load with a
     // wave-dependent scalar offset became a waterfall loop and every `m < nm` an exec-mask branch (2x slower)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long T = (long)P.N * P.TH * P.TW;
-    // XCD-aware placement: the 4 parity phases (and the column blocks) of one tile block read the SAME 3x3 input patches.
-    // Launched phase-major they run hundreds of microseconds apart on all 8 XCDs and every phase fetches its patches
-    // from HBM again (FETCH_SIZE 2.4x the algorithmic reads, profiles/r01_dominant_kernel_pmc.json).  The dispatcher
-    // deals workgroup b to XCD b % 8 (observed, a speed assumption only): give each XCD a contiguous range of tile
-    // blocks and walk (phase, column block) innermost, so the re-reads of a patch hit that XCD's 4 MB L2.
-    int wg = blockIdx.x;
-    if (P.xcd_remap) {
-        const int nwg = gridDim.x, xcd = wg & 7, q = nwg >> 3, r = nwg & 7;      // bijective for any nwg
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+    if (tid == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));       // HW_ID: wave slot [3:0], SIMD [5:4]
+        const int simd = (hw >> 4) & 3;
+        wgctl[0] = hw & 1;                                                               // second workgroup of the CU: odd slot
+        wgctl[1] = (simd & 1) * 2 + (simd >> 1);                                         // position in the cycle 0,2,1,3
     }
-    const int per_tb = P.nkb * P.nph;
-    const int tblk = wg / per_tb, rem = wg - tblk * per_tb;
-    const int phase = P.xcd_remap ? rem / P.nkb : wg / (P.ntb * P.nkb);
-    const int t0 = ((P.xcd_remap ? tblk : wg % P.ntb) * (FUSE ? 2 : 1) + grp) * 32;   // (P.ntb counts workgroups)
-    const int n0 = (P.xcd_remap ? rem % P.nkb : (wg / P.ntb) % P.nkb) * 64;
-    const int spc = P.Cr / BC;                           // stages per segment
-    const int nstages = P.nseg * spc;
-    // ---- producer: thread = (tile pt, channel quad cq)
-    const int pt = tid >> 3, cq = tid & 7;
-    int ty, tx, tn;
-    bool tile_ok;
+    __syncthreads();
+    const int second = __builtin_amdgcn_readfirstlane(wgctl[0]), pos0 = __builtin_amdgcn_readfirstlane(wgctl[1]);
+    const int wrole = (wave + pos0 + 2 * second) & 3;
+    const int cb = wrole & 1, fq = wrole >> 1;           // this wave: column block cb, frequencies fq + 2m
+    const int nm = fq == 0 ? 5 : 4;
+    // ---- this workgroup's run of items: XCD x (speed assumption: workgroup b runs on XCD b % 8) gets a contiguous eighth of
+    // the items, ordered (tile block, phase, column block) so that the re-reads of a patch by the other phases / column
+    // blocks hit that XCD's L2, and deals it in contiguous runs to its workgroups
+    const int nitems = P.ntb * P.nkb * P.nph, nwg = gridDim.x;
+    int first, count;
     {
-        const long id = (long)t0 + pt;
-        tile_ok = id < T;
-        const long ii = tile_ok ? id : 0;
-        tx = ii % P.TW; ty = (ii / P.TW) % P.TH; tn = ii / ((long)P.TW * P.TH);
-        if (cq == 0)         // element offset of this tile's output pixel (a=0, b=0), channel 0 (-1: no such tile)
-            reinterpret_cast<long *>(smem + SMEM_FLOATS)[pt] =
-                tile_ok ? (((long)tn * P.OH + ty * P.otile + P.o0r[phase]) * P.OW + tx * P.otile + P.o0c[phase]) * P.Ko : -1;
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int nx = min(8, nwg);                                   // XCDs in use
+        const int wx = nwg / nx + (xcd < nwg % nx ? 1 : 0);           // workgroups on this XCD
+        const int iq = nitems / nx, ir = nitems % nx;
+        const int xfirst = xcd * iq + min(xcd, ir), xcount = iq + (xcd < ir ? 1 : 0);
+        const int q = xcount / wx, r = xcount % wx;
+        first = xfirst + j * q + min(j, r);
+        count = q + (j < r ? 1 : 0);
     }
-    unsigned xoff[3][3];
-    auto set_segment = [&](int sidx) {                  // byte offsets of the 9 patch pixels, channel 4*cq
-        const int gs = phase * P.nseg + sidx;
+    if (count <= 0) return;
+    const unsigned T = (unsigned)P.N * P.TH * P.TW;
+    const int spc = P.Cr / BC;                           // stages per segment
+    const int nstages = P.nseg * spc;                    // >= 2 (the launcher checks): the pipeline reaches one item ahead at most
+    const int per_tb = P.nkb * P.nph;
+    const int pt = tid >> 3, cq = tid & 7;               // producer: thread = (tile pt, channel quad cq)
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (long)P.N * P.IH * P.IW * P.Cr * 4);
+    const __amdgpu_buffer_rsrc_t ru = make_rsrc(U, (long)4 * 9 * P.Cr * P.Ko * 4);
+    // V[f][group g][k half][tile][4 k-pairs]: channel 4 cq + e of the stage -> group cq >> 1, k half e & 1, k-pair 2 (cq & 1) + (e >> 1)
+    const int vdst = (cq >> 1) * 2 * ROW + pt * 4 + (cq & 1) * 2;
+    const int abase = fq * FSV + kh * ROW + l31 * 4;
+    const unsigned ufreq = (unsigned)((long)P.Cr * P.Ko * 4), ugrp = (unsigned)(2 * P.Ko * 16), ustage = 4u * ugrp;
+    const unsigned useg = 9u * ufreq;
+    const unsigned ubase = (unsigned)(((long)kh * P.Ko + cb * 32 + l31) * 16) + (unsigned)fq * ufreq;   // + per-item / per-stage scalar part
+    const float sc = ep.scale ? ep.scale[0] : 1.f;
+    const int kq = tid & 7, tb = tid >> 3;               // epilogue: thread = (output item tb, channel quad kq)
+    // output and activation-derivative operands go through buffer resources with 32-bit byte offsets (every tensor is
+    // < 2 GiB): a tile beyond the ragged end carries offset kOOB - its loads return 0, its stores are dropped, no branch
+    const unsigned arow = (unsigned)(P.ostep * P.OW * P.Ko * 4), bcol = (unsigned)(P.ostep * P.Ko * 4);
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(out, (long)P.N * P.OH * P.OW * P.Ko * 4);
+    const bool wraps = ep.wrap_from < 0x20000000L;       // the operand tensor holds fewer images than the output (ConvEpilogue)
+    const unsigned wrap_from = wraps ? (unsigned)(ep.wrap_from * 4) : 0xffffffffu, wrap_sub = (unsigned)(ep.wrap_sub * 4);
+    const __amdgpu_buffer_rsrc_t rd = make_rsrc(ep.dact ? ep.dact : x, wraps ? ep.wrap_from * 4 : (long)P.N * P.OH * P.OW * P.Ko * 4);
+    auto dact_off = [&](unsigned o) { return (o >= wrap_from ? o - wrap_sub : o) | (o & kOOB); };   // (a missing tile stays out of range)
+
+    // ---- the LOAD cursor (stage L+2: global -> registers): item, segment, channel block; per thread the tile it loads
+    int l_it = 0, l_seg = 0, l_cs = 0, l_phase = 0;
+    int ty = 0, tx = 0, tn = 0;
+    bool tile_ok = false;
+    unsigned xbase = 0, xmask = 0;                       // byte offset of patch pixel (0,0), channel 4 cq; bit 3u+v: pixel (u,v) exists
+    const unsigned xrow = (unsigned)(P.pstep * P.IW * P.Cr * 4), xcol = (unsigned)(P.pstep * P.Cr * 4);
+    auto enter_item = [&]() {                            // the load cursor has reached item l_it (< count)
+        const int item = first + l_it;
+        const int tblk = item / per_tb, rem = item - tblk * per_tb;
+        l_phase = rem / P.nkb;
+        const unsigned id = (unsigned)tblk * 32u + pt;
+        tile_ok = id < T;
+        const unsigned ii = tile_ok ? id : 0u;
+        const unsigned q1 = ii / (unsigned)P.TW;
+        tx = (int)(ii - q1 * P.TW);
+        tn = (int)(q1 / (unsigned)P.TH);
+        ty = (int)(q1 - (unsigned)tn * P.TH);
+        if (cq == 0)             // byte offset of this tile's output pixel (a=0, b=0), channel 0 (kOOB: no such tile)
+            obase[(l_it & 1) * 32 + pt] =
+                tile_ok ? (unsigned)((((long)tn * P.OH + ty * P.otile + P.o0r[l_phase]) * P.OW + tx * P.otile + P.o0c[l_phase]) * P.Ko * 4) : kOOB;
+    };
+    auto set_segment = [&]() {                           // the 9 patch pixels of segment l_seg: (possibly wrapped) offset of pixel
+        const int gs = l_phase * P.nseg + l_seg;         // (0,0) + which of them lie inside the image (tensors are < 2 GiB)
+        const int row0 = ty * P.tstep + P.r0[gs], col0 = tx * P.tstep + P.c0[gs];
+        xbase = (unsigned)(((((long)tn * P.IH + row0) * P.IW + col0) * P.Cr + 4 * cq) * 4);
+        xmask = 0;
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
-            const int row = ty * P.tstep + P.r0[gs] + u * P.pstep;
+            const int row = row0 + u * P.pstep;
             const bool rowok = tile_ok && row >= 0 && row < P.IH;
 #pragma unroll
             for (int v = 0; v < 3; ++v) {
-                const int col = tx * P.tstep + P.c0[gs] + v * P.pstep;
-                xoff[u][v] = (rowok && col >= 0 && col < P.IW) ? (unsigned)(((((long)tn * P.IH + row) * P.IW + col) * P.Cr + 4 * cq) * 4) : kOOB;
+                const int col = col0 + v * P.pstep;
+                xmask |= (rowok && col >= 0 && col < P.IW) ? 1u << (3 * u + v) : 0u;
             }
         }
     };
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (long)P.N * P.IH * P.IW * P.Cr * 4);
-    const __amdgpu_buffer_rsrc_t ru = make_rsrc(U, (long)4 * 9 * P.Cr * P.Ko * 4);
-    const int vdst = (4 * cq) * LDT + pt;
-    // ---- consumer: wave owns column block cb and frequencies fq + 2m
-    // 18 accumulators over 4 waves = 5,5,4,4: odd workgroups rotate the roles so that, with two workgroups per CU,
-    // every SIMD carries 9 of them
-    const int wrole = (wave + (((FUSE ? grp : wg) & 1) << 1)) & 3;
-    const int cb = wrole & 1, fq = wrole >> 1;
-    const unsigned ubase = (unsigned)(((long)kh * P.Ko + n0 + cb * 32 + l31) * 4);
-    const unsigned ufreq = (unsigned)((long)P.Cr * P.Ko * 4), ukp = (unsigned)(2 * P.Ko * 4), ustage = (unsigned)(BC * P.Ko * 4);
-    const unsigned useg = 9u * ufreq;
-    const int nm = fq == 0 ? 5 : 4;
-#ifndef W2_BD
-#define W2_BD 4
-#endif
-    constexpr int NKP = BC / 2, BD = W2_BD;              // k-pairs per stage, B prefetch distance in k-pairs
+    auto advance_load = [&]() {
+        if (++l_cs == spc) {
+            l_cs = 0;
+            if (++l_seg == P.nseg) {
+                l_seg = 0;
+                if (++l_it < count) enter_item();
+                else tile_ok = false;                    // past the last item: every patch pixel "outside", the loads fetch nothing
+            }
+        }
+    };
+    float4 rin[3][3];
+    // global -> registers: patch row U_ of the load cursor's stage (padded taps: an offset beyond the buffer reads zeros)
+#define W2_XLOAD_ROW(U_)                                                                                 \
+    {                                                                                                    \
+        if ((U_) == 0 && l_cs == 0) set_segment();                                                       \
+        const unsigned sx = xbase + (unsigned)(U_) * xrow + (unsigned)(l_cs * BC * 4);                   \
+        _Pragma("unroll") for (int v = 0; v < 3; ++v)                                                    \
+            rin[U_][v] = bufld4(rx, (xmask >> (3 * (U_) + v)) & 1u ? sx + (unsigned)v * xcol : kOOB);    \
+    }
+    // registers -> LDS: B^T d B for the channel pair (e, e + 2) of the quad: k-pairs 2 (cq & 1), 2 (cq & 1) + 1 of k half e
+#define W2_VSTORE_PAIR(BUF, E_, CA, CB)                                                                  \
+    {                                                                                                    \
+        float XA[3][3], XB[3][3];                                                                        \
+        _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                                  \
+            XA[u][0] = rin[u][0].CA - rin[u][1].CA; XA[u][1] = rin[u][1].CA; XA[u][2] = rin[u][2].CA - rin[u][1].CA; \
+            XB[u][0] = rin[u][0].CB - rin[u][1].CB; XB[u][1] = rin[u][1].CB; XB[u][2] = rin[u][2].CB - rin[u][1].CB; \
+        }                                                                                                \
+        float *d_ = (BUF) + vdst + (E_) * ROW;                                                           \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                  \
+            *reinterpret_cast<float2 *>(d_ + (0 * 3 + j) * FSV) = make_float2(XA[0][j] - XA[1][j], XB[0][j] - XB[1][j]); \
+            *reinterpret_cast<float2 *>(d_ + (1 * 3 + j) * FSV) = make_float2(XA[1][j], XB[1][j]);         \
+            *reinterpret_cast<float2 *>(d_ + (2 * 3 + j) * FSV) = make_float2(XA[2][j] - XA[1][j], XB[2][j] - XB[1][j]); \
+        }                                                                                                \
+    }
+    // ---- the B cursor (stage L+1): scalar byte offset of its (item, segment, channel block) slice of U
+    int b_it = 0, b_seg = 0, b_cs = 0;
+    unsigned b_off;
+    auto b_item = [&]() {
+        const int item = first + b_it;
+        const int tblk = item / per_tb, rem = item - tblk * per_tb;
+        const int phase = rem / P.nkb, n0 = (rem - phase * P.nkb) * 64;
+        b_off = (unsigned)(phase * P.nseg) * useg + (unsigned)(n0 * 16);
+    };
+    auto advance_b = [&]() {                             // (only called while a next stage exists)
+        if (++b_cs == spc) {
+            b_cs = 0;
+            if (++b_seg == P.nseg) {
+                b_seg = 0;
+                ++b_it;
+                b_item();
+            }
+        }
+    };
+    auto stage_boff = [&]() { return b_off + (unsigned)b_seg * useg + (unsigned)b_cs * ustage; };
+    float4 fb[2][NM];
+    float2 fa[2][NM];
+    // B fragments of group G (4 k-pairs) of the stage whose scalar offset is OFF, frequency fq + 2*M, into slot SL
+#define W2_BLOAD(SL, G, M, OFF) fb[SL][M] = bufld4s(ru, ubase, (OFF) + (unsigned)(2 * (M)) * ufreq + (unsigned)(G) * ugrp);
+    // A fragments of k-pairs 2H, 2H+1 of group G from buffer BUF into slot SL
+#define W2_ALOAD(SL, BUF, G, H, M) fa[SL][M] = *reinterpret_cast<const float2 *>((BUF) + abase + 2 * (M) * FSV + (G) * 2 * ROW + 2 * (H));
 
-    f32x16 acc[NM];
+    // ---- fill the pipeline: stage 0 -> LDS, stage 1 -> registers, B fragments of stage 0 / group 0
+    enter_item();
+    b_item();
+    unsigned boff_cur = stage_boff();
+    W2_XLOAD_ROW(0) W2_XLOAD_ROW(1) W2_XLOAD_ROW(2)
+    advance_load();
 #pragma unroll
     for (int m = 0; m < NM; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-
-#define W2_XL(E) (E)
-#define W2_VS(DST, VAL) DST = VAL
-#define W2_BL
-    float4 rin[3][3];
-    float fb[BD][NM];
-    // global -> registers: patch row U_ of stage S
-#define W2_XLOAD_ROW(S, U_)                                                                              \
-    {                                                                                                    \
-        const int sidx_ = (S) / spc, cs_ = (S) - sidx_ * spc;                                            \
-        if ((U_) == 0 && cs_ == 0 && sidx_ < P.nseg) set_segment(sidx_);                                 \
-        const unsigned sx = (unsigned)(cs_ * BC * 4);          /* padded taps: kOOB + sx stays out of range */ \
-        _Pragma("unroll") for (int v = 0; v < 3; ++v) rin[U_][v] = W2_XL(bufld4(rx, xoff[U_][v] + sx));  \
-    }
-    // registers -> LDS: B^T d B for channel E_ of the quad (row pass over the 3 columns, column pass over the 3 rows)
-#define W2_VSTORE_CH(BUF, E_, C_)                                                                        \
-    {                                                                                                    \
-        float X[3][3];                                                                                   \
-        _Pragma("unroll") for (int u = 0; u < 3; ++u) {                                                  \
-            X[u][0] = rin[u][0].C_ - rin[u][1].C_; X[u][1] = rin[u][1].C_; X[u][2] = rin[u][2].C_ - rin[u][1].C_; \
-        }                                                                                                \
-        _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                  \
-            W2_VS((BUF)[vdst + (0 * 3 + j) * FSV + (E_) * LDT], X[0][j] - X[1][j]);                       \
-            W2_VS((BUF)[vdst + (1 * 3 + j) * FSV + (E_) * LDT], X[1][j]);                                 \
-            W2_VS((BUF)[vdst + (2 * 3 + j) * FSV + (E_) * LDT], X[2][j] - X[1][j]);                       \
-        }                                                                                                \
-    }
-    // B fragment (k-pair KP of stage S, frequency fq + 2*M) into register slot KP % BD
-#define W2_BLOAD(KP, M, S)                                                                               \
-    {                                                                                                    \
-        const int sidx_ = (S) / spc, cs_ = (S) - sidx_ * spc;                                            \
-        fb[(KP) % BD][M] = W2_BL bufld1s(ru, ubase, (unsigned)(phase * P.nseg + sidx_) * useg + (unsigned)(fq + 2 * (M)) * ufreq + \
-                                                    (unsigned)cs_ * ustage + (KP) * ukp);                \
-    }
-
-    W2_XLOAD_ROW(0, 0) W2_XLOAD_ROW(0, 1) W2_XLOAD_ROW(0, 2)
-#pragma unroll
-    for (int kp = 0; kp < BD; ++kp)
-#pragma unroll
-        for (int m = 0; m < NM; ++m)
-            if (m < nm) W2_BLOAD(kp, m, 0)
-    W2_VSTORE_CH(smem, 0, x) W2_VSTORE_CH(smem, 1, y) W2_VSTORE_CH(smem, 2, z) W2_VSTORE_CH(smem, 3, w)
-    W2_XLOAD_ROW(1, 0) W2_XLOAD_ROW(1, 1) W2_XLOAD_ROW(1, 2)
+        if (m < nm) W2_BLOAD(0, 0, m, boff_cur)
+    W2_VSTORE_PAIR(smem, 0, x, z) W2_VSTORE_PAIR(smem, 1, y, w)
+    W2_XLOAD_ROW(0) W2_XLOAD_ROW(1) W2_XLOAD_ROW(2)          // (nstages >= 2: stage 1 exists)
+    advance_load();
     __syncthreads();
-    const int abase = fq * FSV + kh * LDT + l31;
-    for (int s = 0; s < nstages; ++s) {
-        const float *cur = smem + (s & 1) * V_FLOATS;
-        float *nxt = smem + ((s + 1) & 1) * V_FLOATS;
-        const int sn = s + 1 < nstages ? s + 1 : s;           // the last refills re-read the last stage (unused)
-        float fa[2][NM];                                   // A fragments of k-pair kp+1 are read while kp's MFMAs issue
+    int par = 0;
+
+    for (int it = 0; it < count; ++it) {
+        const int item = first + it;
+        const int c_tblk = item / per_tb, c_rem = item - c_tblk * per_tb;
+        const int c_phase = c_rem / P.nkb;
+        const int n0 = (c_rem - c_phase * P.nkb) * 64;
+        const unsigned *ob_it = obase + (it & 1) * 32;
+        const bool last_item = it + 1 == count;
+        f32x16 acc[NM];
 #pragma unroll
         for (int m = 0; m < NM; ++m)
-            if (m < nm) fa[0][m] = cur[abase + 2 * m * FSV];
 #pragma unroll
-        for (int kp = 0; kp < NKP; ++kp) {
-            if (kp + 1 < NKP) {
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        float4 dv[2][2][2];                              // activation-derivative operands of this thread's 8 output float4s
+
+        for (int s = 0; s < nstages; ++s) {
+            const float *cur = smem + par * V_FLOATS;
+            float *nxt = smem + (par ^ 1) * V_FLOATS;
+            // -> stage L+1 (its group 0 is loaded under group 3 below).  After the very last stage there is none: the loads,
+            // the transform and the stores below then run once more on stale operands into the idle buffer (no branches here)
+            unsigned boff_nxt = boff_cur;
+            if (!(last_item && s + 1 == nstages)) { advance_b(); boff_nxt = stage_boff(); }
+#pragma unroll
+            for (int m = 0; m < NM; ++m)
+                if (m < nm) W2_ALOAD(0, cur, 0, 0, m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    // operands that fly under this half-group's MFMAs: the A fragments of the next two k-pairs, and (once per
+                    // group) the B fragments of the next group
+#pragma unroll
+                    for (int m = 0; m < NM; ++m)
+                        if (m < nm) {
+                            if (h == 0) W2_ALOAD(1, cur, g, 1, m)
+                            else if (g + 1 < 4) W2_ALOAD(0, cur, g + 1, 0, m)
+                        }
+                    if (h == 0) {
+#pragma unroll
+                        for (int m = 0; m < NM; ++m)
+                            if (m < nm) {
+                                if (g + 1 < 4) W2_BLOAD((g + 1) & 1, g + 1, m, boff_cur)
+                                else W2_BLOAD(0, 0, m, boff_nxt)
+                            }
+                    }
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        const int q = 2 * h + qq;
+#pragma unroll
+                        for (int m = 0; m < NM; ++m)
+                            if (m < nm) {
+                                const float a = qq == 0 ? fa[h][m].x : fa[h][m].y;
+                                const float b = q == 0 ? fb[g & 1][m].x : q == 1 ? fb[g & 1][m].y : q == 2 ? fb[g & 1][m].z : fb[g & 1][m].w;
+                                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[m], 0, 0, 0);
+                            }
+                        // stage L+1 -> LDS (groups 0, 1: one channel pair each), stage L+2 -> registers (group 2: one patch row per step)
+                        if (g == 0 && q == 1) W2_VSTORE_PAIR(nxt, 0, x, z)
+                        else if (g == 1 && q == 1) W2_VSTORE_PAIR(nxt, 1, y, w)
+                        else if (g == 2 && q == 0) W2_XLOAD_ROW(0)
+                        else if (g == 2 && q == 1) W2_XLOAD_ROW(1)
+                        else if (g == 2 && q == 2) { W2_XLOAD_ROW(2) advance_load(); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            __syncthreads();
+            par ^= 1;
+            boff_cur = boff_nxt;
+        }
+        // ---- output transform + epilogue in the V buffer the last stage has just released (the other one holds the next
+        // item's first stage): Ms[f][tile][k 32], one column block at a time
+        float *Ms = smem + (par ^ 1) * V_FLOATS;
+        if (ep.dact) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2) {
+                    const int e = tb + 32 * i2;
+                    const unsigned o = ob_it[e >> 1] + (e & 1) * bcol + (unsigned)((n0 + c * 32 + kq * 4) * 4);
+                    dv[c][i2][0] = bufld4(rd, dact_off(o));
+                    dv[c][i2][1] = bufld4(rd, dact_off(o + arow));
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (cb == c) {
 #pragma unroll
                 for (int m = 0; m < NM; ++m)
-                    if (m < nm) fa[(kp + 1) & 1][m] = cur[abase + 2 * m * FSV + 2 * (kp + 1) * LDT];
-            }
+                    if (m < nm) {
 #pragma unroll
-            for (int m = 0; m < NM; ++m)
-                if (m < nm) {
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kp & 1][m], fb[kp % BD][m], acc[m], 0, 0, 0);
-                    if (kp + BD < NKP) W2_BLOAD(kp + BD, m, s) else W2_BLOAD(kp + BD - NKP, m, sn)
+                        for (int r = 0; r < 16; ++r) Ms[((fq + 2 * m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * 32 + l31] = acc[m][r];
+                    }
+            }
+            __syncthreads();
+            const int ch = n0 + c * 32 + kq * 4;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ep.bias) bv = *reinterpret_cast<const float4 *>(ep.bias + ch);
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2) {
+                const int e = tb + 32 * i2, tile = e >> 1, b = e & 1;
+                const unsigned ob = ob_it[tile];
+                {
+                    float4 z[3];                           // Z[i][b] = M[i][b] + M[i][b+1]
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const float4 p0 = *reinterpret_cast<const float4 *>(Ms + ((3 * i + b) * 32 + tile) * 32 + kq * 4);
+                        const float4 p1 = *reinterpret_cast<const float4 *>(Ms + ((3 * i + b + 1) * 32 + tile) * 32 + kq * 4);
+                        z[i] = make_float4(p0.x + p1.x, p0.y + p1.y, p0.z + p1.z, p0.w + p1.w);
+                    }
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {          // Y[a][b] = Z[a][b] + Z[a+1][b]
+                        float4 v = make_float4(z[a].x + z[a + 1].x, z[a].y + z[a + 1].y, z[a].z + z[a + 1].z, z[a].w + z[a + 1].w);
+                        v.x = v.x * sc + bv.x; v.y = v.y * sc + bv.y; v.z = v.z * sc + bv.z; v.w = v.w * sc + bv.w;
+                        if (ep.dact) {
+                            const float4 yv = dv[c][i2][a];
+                            v.x *= act_bwd_from_out(yv.x, ep.act); v.y *= act_bwd_from_out(yv.y, ep.act);
+                            v.z *= act_bwd_from_out(yv.z, ep.act); v.w *= act_bwd_from_out(yv.w, ep.act);
+                        } else {
+                            v.x = act_fwd(v.x, ep.act); v.y = act_fwd(v.y, ep.act);
+                            v.z = act_fwd(v.z, ep.act); v.w = act_fwd(v.w, ep.act);
+                        }
+                        bufst4(ro, ob + a * arow + b * bcol + (unsigned)(ch * 4), v);
+                    }
                 }
-            // tile s+1 -> LDS (one channel of the quad per k-pair), then tile s+2 -> registers (one patch row per k-pair)
-            if (kp == 0) W2_VSTORE_CH(nxt, 0, x)
-            else if (kp == 1) W2_VSTORE_CH(nxt, 1, y)
-            else if (kp == 2) W2_VSTORE_CH(nxt, 2, z)
-            else if (kp == 3) W2_VSTORE_CH(nxt, 3, w)
-            else if (kp == 5) W2_XLOAD_ROW(s + 2, 0)
-            else if (kp == 6) W2_XLOAD_ROW(s + 2, 1)
-            else if (kp == 7) W2_XLOAD_ROW(s + 2, 2)
-            __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();                             // Ms is rewritten by the next column block / the next item's stage 1
         }
-        __syncthreads();
     }
 #undef W2_XLOAD_ROW
-#undef W2_VSTORE_CH
+#undef W2_VSTORE_PAIR
 #undef W2_BLOAD
-
-    // ---- output transform + epilogue: Ms[f][tile][k 32], one column block at a time
-    const float sc = ep.scale ? ep.scale[0] : 1.f;
-    float *Ms = smem;
-    const long *obase = reinterpret_cast<const long *>(smem + SMEM_FLOATS);
-    const int kq = tid & 7, tb = tid >> 3;
-    const long arow = (long)P.ostep * P.OW * P.Ko, bcol = (long)P.ostep * P.Ko;
-    for (int c = 0; c < 2; ++c) {
-        if (cb == c) {
-#pragma unroll
-            for (int m = 0; m < NM; ++m)
-                if (m < nm) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) Ms[((fq + 2 * m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * 32 + l31] = acc[m][r];
-                }
-        }
-        __syncthreads();
-        const int ch = n0 + c * 32 + kq * 4;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ep.bias) bv = *reinterpret_cast<const float4 *>(ep.bias + ch);
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int item = tb + 32 * it, tile = item >> 1, b = item & 1;
-            const long ob = obase[tile];
-            if (ob >= 0) {
-                float4 z[3];                           // Z[i][b] = M[i][b] + M[i][b+1]
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const float4 p0 = *reinterpret_cast<const float4 *>(Ms + ((3 * i + b) * 32 + tile) * 32 + kq * 4);
-                    const float4 p1 = *reinterpret_cast<const float4 *>(Ms + ((3 * i + b + 1) * 32 + tile) * 32 + kq * 4);
-                    z[i] = make_float4(p0.x + p1.x, p0.y + p1.y, p0.z + p1.z, p0.w + p1.w);
-                }
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {          // Y[a][b] = Z[a][b] + Z[a+1][b]
-                    float4 v = make_float4(z[a].x + z[a + 1].x, z[a].y + z[a + 1].y, z[a].z + z[a + 1].z, z[a].w + z[a + 1].w);
-                    const long o = ob + a * arow + b * bcol + ch;
-                    v.x = v.x * sc + bv.x; v.y = v.y * sc + bv.y; v.z = v.z * sc + bv.z; v.w = v.w * sc + bv.w;
-                    if (ep.dact) {
-                        const float4 yv = *reinterpret_cast<const float4 *>(ep.dact + ep.dact_index(o));
-                        v.x *= act_bwd_from_out(yv.x, ep.act); v.y *= act_bwd_from_out(yv.y, ep.act);
-                        v.z *= act_bwd_from_out(yv.z, ep.act); v.w *= act_bwd_from_out(yv.w, ep.act);
-                    } else {
-                        v.x = act_fwd(v.x, ep.act); v.y = act_fwd(v.y, ep.act);
-                        v.z = act_fwd(v.z, ep.act); v.w = act_fwd(v.w, ep.act);
-                    }
-                    *reinterpret_cast<float4 *>(out + o) = v;
-                }
-            }
-        }
-        __syncthreads();
-    }
+#undef W2_ALOAD
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -340,10 +451,11 @@ static bool wino2_shape_ok(const ConvDims &d, bool dgrad) {
     if (mode == 0 || d.R != 4 || d.stride != 2 || d.pad != 1 || d.H % 4 || d.W % 4) return false;
     const int cr = dgrad ? d.K : d.C, ko = dgrad ? d.C : d.K;
     if (cr % wino2::BC || cr < 32 || ko % 64) return false;
+    if (dgrad && cr < 2 * wino2::BC) return false;                  // the kernel's pipeline needs >= 2 stages per item (forward: 4 segments)
     if (mode >= 2) return true;
     const long tiles = (long)d.N * (d.P / 2) * (d.Q / 2);          // per phase
     const long wgs = ((tiles + 31) / 32) * (ko / 64) * (dgrad ? 4 : 1);
-    return wgs >= (dgrad ? 384 : 256);
+    return wgs >= 256;        // one round of two workgroups per CU at least (measured against the direct kernels, header above)
 }
 bool wino2_eligible(const ConvDims &d, bool dgrad) { return wino2_shape_ok(d, dgrad); }
 static size_t wino2_bytes(const ConvDims &d) { return sizeof(float) * 36 * (size_t)d.C * d.K; }
@@ -351,7 +463,8 @@ bool wino2_fwd_ok(const ConvDims &d) { return d.N > 1 && wino2_shape_ok(d, false
 bool wino2_dgrad_ok(const ConvDims &d) { return d.N > 1 && wino2_shape_ok(d, true) && workspace(wino2_bytes(d)) != nullptr; }
 
 int wino2_transform(const ConvDims &d, const float *w, bool dgrad, float *U, hipStream_t st) {
-    const dim3 wg((d.K + 31) / 32, (d.C + 31) / 32, 4);
+    if (d.C % 32 || d.K % 32) { set_error("wino_transform (4x4 stride 2): C and K must be multiples of 32 (got %d, %d)", d.C, d.K); return MMDGAN_E_ARG; }
+    const dim3 wg(d.K / 32, d.C / 32, 4);
     if (dgrad) hipLaunchKernelGGL(wino2_weight_kernel<true>, wg, dim3(256), 0, st, w, U, d.C, d.K);
     else hipLaunchKernelGGL(wino2_weight_kernel<false>, wg, dim3(256), 0, st, w, U, d.C, d.K);
     return check_launch("wino2_transform");
@@ -380,22 +493,22 @@ static int wino2_launch(const ConvDims &d, const ConvEpilogue &ep, const float *
     }
     const long T = (long)d.N * P.TH * P.TW;
     P.ntb = (int)((T + 31) / 32); P.nkb = P.Ko / 64; P.nph = dgrad ? 4 : 1;
-    static int remap = -1, fuse_min = -1;
-    if (remap < 0) { const char *e = getenv("MMDGAN_XCD_REMAP"); remap = (e && e[0] == '0') ? 0 : 1; }
-    if (fuse_min < 0) { const char *e = getenv("MMDGAN_WINO2_FUSE"); fuse_min = e ? atoi(e) : W2_FUSE_MIN_WGS; }   // 0: never
-    P.xcd_remap = remap;
-    // pairs of tile blocks as one workgroup where that still leaves every CU its workgroup
-    const bool fuse = fuse_min > 0 && (long)P.ntb * P.nkb * P.nph >= fuse_min;
-    if (fuse) P.ntb = (P.ntb + 1) / 2;
-    const dim3 grid((unsigned)((long)P.ntb * P.nkb * P.nph), 1, 1);
+    const long nitems = (long)P.ntb * P.nkb * P.nph;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    const long slots = 2L * ncu;                        // two workgroups per CU (76 KB of LDS each)
+    const dim3 grid((unsigned)(nitems < slots ? nitems : slots), 1, 1);
     static bool cap_raised = false;                     // 76 KB of dynamic LDS: above the 64 KB default cap
     if (!cap_raised) {
-        (void)hipFuncSetAttribute((const void *)wino2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino2::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void *)wino2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * wino2::LDS_BYTES));
+        (void)hipFuncSetAttribute((const void *)wino2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino2::LDS_BYTES);
         cap_raised = true;
     }
-    if (fuse) hipLaunchKernelGGL(wino2_kernel<true>, grid, dim3(512), 2 * wino2::LDS_BYTES, st, P, ep, in, U, out);
-    else hipLaunchKernelGGL(wino2_kernel<false>, grid, dim3(256), wino2::LDS_BYTES, st, P, ep, in, U, out);
+    hipLaunchKernelGGL(wino2_kernel, grid, dim3(256), wino2::LDS_BYTES, st, P, ep, in, U, out);
     return check_launch(dgrad ? "conv2d_dgrad(winograd 2x2)" : "conv2d_fwd(winograd 2x2)");
 }
 
