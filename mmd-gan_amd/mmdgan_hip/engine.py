@@ -446,6 +446,7 @@ class GanEngine:
         self._comm_stream = side[1] if len(side) > 1 else side[0]      # gradient exchange, see _exchange
         self._wg_raw, self._comm_raw = self._wg_stream.cuda_stream, self._comm_stream.cuda_stream
         self._sn_raw = [st.cuda_stream for st in self._sn_streams]
+        self._gen_tail_on_main = int(os.environ.get('MMDGAN_GEN_TAIL_MAIN', '2')) if os.environ.get('MMDGAN_SIDE_WGRAD', '1') != '0' else 0
         self._early_d_adam = os.environ.get('MMDGAN_EARLY_D_ADAM', '1') != '0'
         self._side_wgrad = os.environ.get('MMDGAN_SIDE_WGRAD', '1') != '0'
         if ops._workspace is None:
@@ -769,6 +770,7 @@ class GanEngine:
     def _backward_gen(self, dz, z):
         B, b, net = self.B, self.buf, self.gen
         specs = net.specs
+        deferred = []
         for li in range(len(specs) - 1, -1, -1):
             s = specs[li]
             in_shape = _native_shape(s.in_shape_ref, B)
@@ -800,8 +802,21 @@ class GanEngine:
                     ops.conv2d_wgrad(x_in, dz, s.R, s.stride, out=gw, dbias=gb)
                 else:                                                        # tc: W[R,R,Cout,Cin]; y = dgrad(v, W)
                     ops.conv2d_wgrad(dz, x_in, s.R, s.stride, out=gw)
-            self._on_wg_stream(param_grads, s)
-            self._exchange(net, li)
+            if li < self._gen_tail_on_main and li > 0:
+                # the tail of G's backward pass: the input-gradient chain of the main stream ends at layer 1 while the
+                # weight-gradient stream still holds the gradients of the layers above - the last layers' parameter gradients
+                # go behind their own input-gradient on the main stream instead (the workspace is handed over by
+                # workspace_acquire: one user at a time)
+                deferred.append((param_grads, li))
+            elif li == 0 and deferred:
+                for fn, lj in deferred:
+                    fn()
+                    self._exchange(net, lj, on_main=True)
+                param_grads()
+                self._exchange(net, li, on_main=True)
+            else:
+                self._on_wg_stream(param_grads, s)
+                self._exchange(net, li)
             if li > 0:
                 prev = specs[li - 1]
                 # a BN layer below gets d/d(its activated output) and applies act' itself in bn_bwd;
@@ -832,7 +847,7 @@ class GanEngine:
     def _dp_active(self):
         return self.dist_group is not None and (self.world > 1 or self._dp_force)   # MMDGAN_DP_FORCE=1: one-rank plumbing test
 
-    def _exchange(self, net, li):
+    def _exchange(self, net, li, on_main=False):
         """called right after the parameter gradients of layer `li` of `net` have been issued: if that completes an
         exchange bucket (_make_buckets), its SUM all-reduce starts NOW on the exchange stream and travels underneath
         the backward kernels still to come - only the last bucket of G (its first dense layer, 4 MB for CIFAR) is
@@ -853,7 +868,7 @@ class GanEngine:
             # gradients of this layer included) when the layer's launches went in (_on_wg_stream): no second marker in the
             # main queue - six of them per step cost the one-rank exchange 0.05 ms
             ops.stream_wait(self._comm_raw, self._wg_raw)
-        else:
+        if on_main or not self._side_wgrad:               # (the tail of G's backward pass puts its gradients on the main stream)
             ops.stream_wait(self._comm_raw, ops._stream())
         lib = ops.require_device()
         if self._recording and self._dp_backend != 'capi':
