@@ -95,7 +95,8 @@ class Routine(object):
             elif s.op == 'c':
                 y = ops.conv2d_fwd(x, w, s.stride, bias=bias, scale=scale, act=act)
             else:
-                y = ops.conv2d_dgrad(x, w, (x.shape[1] * s.stride, x.shape[2] * s.stride), s.stride, bias=bias, act=act)
+                y = ops.conv2d_dgrad(x, w, (x.shape[1] * s.stride, x.shape[2] * s.stride), s.stride, bias=bias, scale=scale,
+                                     act=act)
             if s.bn:
                 y2 = y.view(-1, y.shape[-1])
                 g, b_ = net.p(s.scope + '/BN/BN/gamma'), net.p(s.scope + '/BN/BN/beta')

@@ -36,7 +36,8 @@ from . import initializers, ops
 # named event slots (mmdgan_event_record / _wait)
 _EV_WINO_GEN = 0                      # G's Winograd weights are ready
 _EV_WINO_DIS = 1                      # D's
-_EV_SN0 = 8                           # + i: the power iteration of D layer i has produced its scale
+_EV_SN0 = 8                           # + i: the power iteration of D layer i has produced its scale (i < 24)
+_EV_SN_GEN0 = 32                      # + i: ... of G layer i
 
 _TEMPLATE = {'name': None, 'type': 'default', 'op': 'c', 'out': None, 'bias': 'b',
              'act': 'linear', 'act_nm': None, 'act_k': False, 'w_nm': None, 'w_p': None,
@@ -104,19 +105,21 @@ class LayerSpec:
             if self.op == 'd':
                 self.use_u = in_shape_ref[0] <= self.out
                 self.sn_x_ref = [1, in_shape_ref[0]] if self.use_u else [1, self.out]
-            elif self.op == 'c' and sn_mode in ('sn_paper', 'PIM', 'pim'):
-                # layer_func.py:811-814: power iteration on the kernel flattened to [k*k*c_in, c_out]
-                # (HWIO is already that matrix, row-major) through the dense routine
-                num_in = int(np.prod(self.kernel_shape[:3]))
+            elif sn_mode in ('sn_paper', 'PIM', 'pim'):
+                # layer_func.py:801, 811-814: power iteration on the kernel flattened to [k*k*shape[2], shape[3]] (the stored
+                # kernel is already that matrix, row-major; a 'tc' kernel is [k,k,out,in]) through the dense routine
+                num_in, num_out = int(np.prod(self.kernel_shape[:3])), self.kernel_shape[3]
                 self.pim = True
-                self.use_u = num_in <= self.out
-                self.sn_x_ref = [1, num_in] if self.use_u else [1, self.out]
+                self.use_u = num_in <= num_out
+                self.sn_x_ref = [1, num_in] if self.use_u else [1, num_out]
             else:
+                # math_func.py:512-528.  'tc': the iteration runs on the CONV whose transpose the layer is (same kernel, same
+                # spectral norm): its input is the layer's output - x has the layer's output shape when use_u
                 self.use_u = int(np.prod(in_shape_ref)) <= int(np.prod(out))
                 if self.op == 'c':
                     self.sn_x_ref = [1] + (list(in_shape_ref) if self.use_u else list(out))
                 else:
-                    raise NotImplementedError('{}: spectral norm on tc layers is outside the hot path'.format(self.scope))
+                    self.sn_x_ref = [1] + (list(out) if self.use_u else list(in_shape_ref))
         self.out_reshape = d['out_reshape']
         self.out_shape_ref = list(self.out_reshape) if self.out_reshape is not None else list(out)
         assert int(np.prod(self.out_shape_ref)) == int(np.prod(out)), \
@@ -209,10 +212,11 @@ class Network:
     @staticmethod
     def _sn_u_shape(s):
         if s.op == 'd' or s.pim:
-            return [1, s.out] if s.use_u else [1, int(np.prod(s.kernel_shape[:-1]))]
-        c, h, w = s.in_shape_ref
-        k, p, q = s.op_out_ref
-        return [1, p, q, k] if s.use_u else [1, h, w, c]
+            return [1, s.kernel_shape[-1]] if s.use_u else [1, int(np.prod(s.kernel_shape[:-1]))]
+        # F(x): the conv's output when use_u, its input otherwise; the conv of a 'tc' layer maps the layer's output to its input
+        cin, cout = (s.in_shape_ref, s.op_out_ref) if s.op == 'c' else (s.op_out_ref, s.in_shape_ref)
+        src = cout if s.use_u else cin
+        return [1, src[1], src[2], src[0]]
 
     def p(self, name):
         return self.arena.view(name)
@@ -339,7 +343,7 @@ def sn_power_iteration(net, s, b, update=True, out_zeroed=True):
     oz = bool(out_zeroed)
     if s.op == 'd' or s.pim:
         if s.pim:                                                        # layer_func.py:811-814
-            w, dsig = w.view(-1, s.out), dsig.view(-1, s.out)
+            w, dsig = w.view(-1, w.shape[-1]), dsig.view(-1, w.shape[-1])
         if 1 in w.shape:                                                 # math_func.py:702-704
             ops.sn_norm_scale(w.view(-1), s.act_k, sigma, scale, dsig.view(-1))
         elif s.use_u:
@@ -357,7 +361,9 @@ def sn_power_iteration(net, s, b, update=True, out_zeroed=True):
                 ops.gemm(un, w, out=xb, out_zeroed=oz)                   # y W              [1,out]
                 ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
     else:
-        c, h, wd = s.in_shape_ref
+        # the conv with kernel w [R,R,C,K]: for a 'tc' layer ([R,R,out,in]) the conv whose transpose the layer is - its input is
+        # the layer's output (math_func.py:520-528: forward / backward swap roles, the code below is the same)
+        c, h, wd = s.in_shape_ref if s.op == 'c' else s.op_out_ref
         if s.use_u:
             ops.conv2d_fwd(x, w, s.stride, out=u)
             ops.sn_norm_scale(u.view(-1), s.act_k, sigma, scale, un.view(-1))
@@ -400,16 +406,13 @@ class GanEngine:
                            weight_init)
         self.dis = Network(build_specs(architecture['discriminator'], self.in_shape_ref, 'dis', sn_mode), self.device, rng,
                            weight_init)
-        # this engine's hand-written schedule covers the shipped DCGAN-SN shape of the reference's drivers: batch norm
-        # in G only (my_test_*.py), spectral norm in D only.  Anything else must not train silently wrong:
-        # mmdgan_hip.tape.TapeEngine takes batch norm in D (SNGan.init_net routes there), nothing here takes SN in G
+        # this engine's hand-written schedule covers the DCGAN shape of the reference's drivers: batch norm in G only
+        # (my_test_*.py); spectral norm anywhere, transposed-conv kernels included.  Anything else must not train silently
+        # wrong: mmdgan_hip.tape.TapeEngine takes batch norm in D (SNGan.init_net routes there)
         for s in self.dis.specs:
             if s.bn:
                 raise NotImplementedError('{}: batch norm in the discriminator is not on this engine\'s schedule; use '
                                           'mmdgan_hip.tape.TapeEngine (SNGan.init_net does)'.format(s.scope))
-        for s in self.gen.specs:
-            if s.sn:
-                raise NotImplementedError('{}: spectral norm in the generator is not implemented.'.format(s.scope))
         if self.gen.specs[-1].out_shape_ref != self.in_shape_ref:
             raise AssertionError('gen: the output shape {} does not match existed shape {}.'.format(
                 self.gen.specs[-1].out_shape_ref, self.in_shape_ref))
@@ -517,16 +520,19 @@ class GanEngine:
                 self.buf[s.scope + '#dz'] = torch.zeros(_native_shape(s.op_out_ref, 3 * B) if net is self.dis else shp,
                                                         device=dev)
         self.buf['d_fake'] = torch.zeros(B, h, w, c, device=dev)
-        # SN scratch per D layer (u / xb live in the network's zero-once-per-step arena)
-        for s in self.dis.specs:
-            if s.sn:
-                self.buf[s.scope + '#u'] = self.dis.state[s.scope + '#u']
-                self.buf[s.scope + '#un'] = torch.zeros_like(self.dis.state[s.scope + '#u'])
-                self.buf[s.scope + '#xb'] = self.dis.state[s.scope + '#xb']
-                self.buf[s.scope + '#xbnorm'] = torch.zeros(1, device=dev)
+        # SN scratch per spectrally normalised layer (u / xb live in the network's zero-once-per-step arena)
+        for net in (self.gen, self.dis):
+            for s in net.specs:
+                if s.sn:
+                    self.buf[s.scope + '#u'] = net.state[s.scope + '#u']
+                    self.buf[s.scope + '#un'] = torch.zeros_like(net.state[s.scope + '#u'])
+                    self.buf[s.scope + '#xb'] = net.state[s.scope + '#xb']
+                    self.buf[s.scope + '#xbnorm'] = torch.zeros(1, device=dev)
         # buffers some kernel accumulates into with atomics: zeroed once at the start of every step
         # (4 memset nodes instead of one per kernel, see mmdgan_set_outputs_prezeroed)
         self._zero_each_step = [self.gen.grads, self.dis.grads, self.dis.sn_scratch.flat]
+        if any(s.sn for s in self.gen.specs):
+            self._zero_each_step.append(self.gen.sn_scratch.flat)
         # batch-norm statistics are accumulated with fp64 atomics into per-layer totals ([forward | backward] x 2C),
         # which must be zero when the layer runs: one flat buffer, one memset per step
         bn = [(s.scope, s.out if s.op == 'd' else s.channels) for net in (self.gen, self.dis) for s in net.specs if s.bn]
@@ -574,8 +580,8 @@ class GanEngine:
     # ---------------------------------------------------------------------------------------
     # spectral norm: one power-iteration step per D layer (math_func.py:661-672)
     # ---------------------------------------------------------------------------------------
-    def _sn_step(self, s):
-        return sn_power_iteration(self.dis, s, self.buf)
+    def _sn_step(self, net, s):
+        return sn_power_iteration(net, s, self.buf)
 
     # ---------------------------------------------------------------------------------------
     def _layer_forward(self, net, s, x, is_training, scale):
@@ -626,10 +632,18 @@ class GanEngine:
         return self._wino_ok[key]
 
     def generate(self, z, is_training=False):
-        """G(z) -> NHWC images (the fake half of D's input buffer when the batch is B)."""
+        """G(z) -> NHWC images (the fake half of D's input buffer when the batch is B).  Inference: spectral norms (if G
+        has any) from the stored power-iteration vectors, not updated - as discriminate()"""
+        if is_training:
+            scales = self._scales
+        else:
+            scales = {s.scope: sn_power_iteration(self.gen, s, self.buf, update=False, out_zeroed=False)
+                      for s in self.gen.specs if s.sn}
         x = z
-        for s in self.gen.specs:
-            x = self._layer_forward(self.gen, s, x, is_training, None)
+        for i, s in enumerate(self.gen.specs):
+            if s.sn and is_training:
+                ops.event_wait(_EV_SN_GEN0 + i, ops._stream())               # this layer's power iteration (_forward)
+            x = self._layer_forward(self.gen, s, x, is_training, scales.get(s.scope))
             if s.out_reshape is not None:
                 x = x.view(_native_shape(s.out_shape_ref, x.shape[0]))
         return x
@@ -659,12 +673,14 @@ class GanEngine:
         self._scales = {}
         for st in self._sn_raw:
             ops.stream_wait(st, main)
-        for i, s in enumerate(self.dis.specs):
-            k = i % len(self._sn_streams)
-            with torch.cuda.stream(self._sn_streams[k]):
-                self._scales[s.scope] = self._sn_step(s) if s.sn else None
-                if s.sn:
-                    ops.event_record(_EV_SN0 + i, self._sn_raw[k])
+        # (G's first: its forward pass is what the main stream runs next)
+        for net, ev0 in ((self.gen, _EV_SN_GEN0), (self.dis, _EV_SN0)):
+            for i, s in enumerate(net.specs):
+                k = i % len(self._sn_streams)
+                with torch.cuda.stream(self._sn_streams[k]):
+                    self._scales[s.scope] = self._sn_step(net, s) if s.sn else None
+                    if s.sn:
+                        ops.event_record(ev0 + i, self._sn_raw[k])
         ops.copy(b['dis_in'][:B], real)                                      # my_sngan.py:278: D sees [real ; fake]
         if any(net is self.gen for _, _, net in self._wino.values()):
             ops.event_wait(_EV_WINO_GEN, main)
@@ -777,6 +793,7 @@ class GanEngine:
             x_in = (z if li == 0 else b[specs[li - 1].scope + '#y']).view(in_shape)
             w = net.p(s.scope + '/kernel/kernel')
             gw = net.g(s.scope + '/kernel/kernel')
+            scale = self._scales[s.scope]                                    # None unless the layer is spectrally normalised
             if s.bn:                                                         # dz is d/d(BN output after act)
                 raw, y = b[s.scope + '#raw'], b[s.scope + '#y']
                 lib = ops.require_device()
@@ -792,7 +809,7 @@ class GanEngine:
                 dz = draw
             dz = dz.view(_native_shape(s.op_out_ref, B))
 
-            def param_grads(s=s, x_in=x_in, gw=gw, dz=dz):
+            def param_grads(s=s, x_in=x_in, gw=gw, dz=dz, w=w, scale=scale):
                 gb = net.g(s.scope + '/bias/bias') if s.has_bias else None
                 if gb is not None and s.op != 'c':
                     ops.colsum(dz.view(-1, dz.shape[-1]), out=gb)
@@ -802,6 +819,11 @@ class GanEngine:
                     ops.conv2d_wgrad(x_in, dz, s.R, s.stride, out=gw, dbias=gb)
                 else:                                                        # tc: W[R,R,Cout,Cin]; y = dgrad(v, W)
                     ops.conv2d_wgrad(dz, x_in, s.R, s.stride, out=gw)
+                if s.sn:                                                     # SURVEY A.2 fix-up, as in D
+                    dot = net.state[s.scope + '#dot']
+                    ops.dot(gw.view(-1), w.view(-1), out=dot)
+                    ops.sn_wgrad_fixup(gw.view(-1), net.state[s.scope + '#dsigma'].view(-1), dot,
+                                       net.state[s.scope + '#sigma'], scale)
             if li < self._gen_tail_on_main and li > 0:
                 # the tail of G's backward pass: the input-gradient chain of the main stream ends at layer 1 while the
                 # weight-gradient stream still holds the gradients of the layers above - the last layers' parameter gradients
@@ -829,15 +851,15 @@ class GanEngine:
                 if s.op == 'd':
                     # dprev is NOT on the step's zero list: no out_zeroed, so no split-K accumulation into last
                     # step's values (a dense layer above a BN dense layer meets every other split condition)
-                    ops.gemm(dz, w, trans_b=True, act=act_prev, dact_of=dact, out=dprev)
+                    ops.gemm(dz, w, trans_b=True, scale=scale, act=act_prev, dact_of=dact, out=dprev)
                 elif s.op == 'c':
-                    ops.conv2d_dgrad(dz, w, (in_shape[1], in_shape[2]), s.stride, act=act_prev, dact_of=dact, out=dprev,
-                                     wino=self._wino.get(s.scope, (None, None, None))[1])
+                    ops.conv2d_dgrad(dz, w, (in_shape[1], in_shape[2]), s.stride, scale=scale, act=act_prev, dact_of=dact,
+                                     out=dprev, wino=self._wino.get(s.scope, (None, None, None))[1])
                 else:                                                        # d/dv of dgrad(v, W) = conv(dz, W)
                     # few tiles (M = B*h*w is small at the top of G): if the epilogue is linear let the
                     # kernel split its K = R*R*Cout reduction into a buffer zeroed at step start
                     zeroed = dact is None and act_prev == 'linear' and dprev.data_ptr() in self._zeroed_ptrs
-                    ops.conv2d_fwd(dz, w, s.stride, act=act_prev, dact_of=dact, out=dprev, out_zeroed=zeroed,
+                    ops.conv2d_fwd(dz, w, s.stride, scale=scale, act=act_prev, dact_of=dact, out=dprev, out_zeroed=zeroed,
                                    wino=self._wino.get(s.scope, (None, None, None))[0])
                 dz = dprev
 
@@ -1093,7 +1115,8 @@ class GanEngine:
         self._drop_recordings()
 
     def sigmas(self):
-        return OrderedDict((s.scope, float(self.dis.state[s.scope + '#sigma'].item())) for s in self.dis.specs if s.sn)
+        return OrderedDict((s.scope, float(net.state[s.scope + '#sigma'].item()))
+                           for net in (self.dis, self.gen) for s in net.specs if s.sn)
 
     def state_dict(self):
         sd = {'global_step': self.global_step, 'variables': self.get_variables(), 'loss_state': self._loss.state_dict()}

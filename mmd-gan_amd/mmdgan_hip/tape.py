@@ -52,8 +52,6 @@ class _Kernel:
         self.act_init, self.bias_name, self.stride = act, bias_name, stride
         self.R = kernel_shape[0] if op in ('c', 'tc') else 1
         self.out = kernel_shape[-1] if out is None else out           # a tc kernel is [R, R, out, in]
-        if op == 'tc' and w_nm is not None:
-            raise NotImplementedError('{}: spectral norm on tc layers is outside the hot path'.format(scope))
         self.sn, self.act_k, self.pim = w_nm == 's', act_k, False
         self.fold = None                                                 # 'unpool' / 'avg': scaling folded into this conv
         self.row_perm = self.col_perm = None                             # dense kernels at an NCHW <-> NHWC seam
@@ -62,14 +60,16 @@ class _Kernel:
         if self.sn:
             if act_k is False or not isinstance(act_k, (float, int)):
                 raise ValueError('{}: w_nm="s" needs a numeric act_k'.format(scope))
-            if op == 'd' or sn_mode in _PIM:                             # math_func.py:481-486, layer_func.py:811-814
-                num_in = int(np.prod(kernel_shape[:-1]))
-                self.pim = op == 'c'
-                self.use_u = num_in <= self.out
-                self.sn_x_ref = [1, num_in] if self.use_u else [1, self.out]
+            if op == 'd' or sn_mode in _PIM:                             # math_func.py:481-486, layer_func.py:801, 811-814
+                num_in, num_out = int(np.prod(kernel_shape[:-1])), kernel_shape[-1]     # (a tc kernel is [R, R, out, in])
+                self.pim = op in ('c', 'tc')
+                self.use_u = num_in <= num_out
+                self.sn_x_ref = [1, num_in] if self.use_u else [1, num_out]
             else:                                                        # math_func.py:512-528
+                # 'tc': the iteration runs on the conv whose transpose the layer is - its input is the layer's output
                 self.use_u = int(np.prod(in_ref)) <= int(np.prod(out_ref))
-                self.sn_x_ref = [1] + (list(in_ref) if self.use_u else list(out_ref))
+                cin, cout = (in_ref, out_ref) if op == 'c' else (out_ref, in_ref)
+                self.sn_x_ref = [1] + (list(cin) if self.use_u else list(cout))
 
     @property
     def w_name(self):
@@ -81,8 +81,9 @@ class _Kernel:
 
     def sn_u_shape(self):
         if self.op == 'd' or self.pim:
-            return [1, self.out] if self.use_u else [1, int(np.prod(self.kernel_shape[:-1]))]
-        src = self.out_ref if self.use_u else self.in_ref
+            return [1, self.kernel_shape[-1]] if self.use_u else [1, int(np.prod(self.kernel_shape[:-1]))]
+        cin, cout = (self.in_ref, self.out_ref) if self.op == 'c' else (self.out_ref, self.in_ref)
+        src = cout if self.use_u else cin
         return [1, src[1], src[2], src[0]]
 
 
@@ -496,8 +497,6 @@ class TapeEngine:
         assert self.gen.shapes[self.gen.out_val] == self.in_shape_ref, \
             'generator output {} does not match the input shape {}'.format(self.gen.shapes[self.gen.out_val], self.in_shape_ref)
         assert len(self.dis.shapes[self.dis.out_val]) == 1, 'the discriminator must end in a score vector'
-        if any(k.sn for k in self.gen.kernels):
-            raise NotImplementedError('spectral norm in the generator is not built')
         self.score_size = self.dis.shapes[self.dis.out_val][0]
         self.global_step = 0
         self.dist_group, self.world, self.rank = dist_group, 1, 0
@@ -526,7 +525,7 @@ class TapeEngine:
         if self._side:
             from .streams import distinct_queue_streams
             self._wg_stream, self._sn_stream = distinct_queue_streams(2, self.device)
-            self._gen_ready, self._dis_ready = torch.cuda.Event(), torch.cuda.Event()
+            self._gen_ready, self._dis_ready, self._gen_sn_ready = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
         # Winograd-eligible convolutions get their weights transformed once per step, off the critical path, instead
         # of inside every call (forward, and up to two input-gradient passes) - which also keeps the library's
         # shared workspace out of every launch of the main stream.  kernel scope -> {(dgrad, batch): tensor}
@@ -603,7 +602,7 @@ class TapeEngine:
         sigma, scale, dsig, u, un, xb, xbn = st['sigma'], st['scale'], st['dsigma'], st['u'], st['un'], st['xb'], st['xbn']
         if k.op == 'd' or k.pim:
             if k.pim:
-                w, dsig = w.view(-1, k.out), dsig.view(-1, k.out)
+                w, dsig = w.view(-1, w.shape[-1]), dsig.view(-1, w.shape[-1])
             if 1 in w.shape:                                             # math_func.py:702-704
                 ops.sn_norm_scale(w.reshape(-1), k.act_k, sigma, scale, dsig.view(-1))
             elif k.use_u:
@@ -621,7 +620,7 @@ class TapeEngine:
                     ops.gemm(un, w, out=xb)
                     ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
         else:
-            h, wd = k.in_ref[1], k.in_ref[2]
+            h, wd = (k.in_ref if k.op == 'c' else k.out_ref)[1:]         # input of the conv ('tc': the layer's OUTPUT)
             if k.use_u:
                 ops.conv2d_fwd(x, w, k.stride, out=u)
                 ops.sn_norm_scale(u.view(-1), k.act_k, sigma, scale, un.view(-1))
@@ -677,8 +676,9 @@ class TapeEngine:
             elif kind == 'tconv':                                        # y = the input-gradient of a conv with kernel w
                 k = p['k']
                 bias = net.p(k.bias_name) if k.bias_name is not None else None
+                scale = net.sn[k.scope]['scale'] if k.sn else None
                 y = self._buf(key, out_shape)
-                ops.conv2d_dgrad(a, net.p(k.w_name), (out_shape[1], out_shape[2]), k.stride, bias=bias, out=y,
+                ops.conv2d_dgrad(a, net.p(k.w_name), (out_shape[1], out_shape[2]), k.stride, bias=bias, scale=scale, out=y,
                                  wino=self._wino_of(k, True, n) if (training and self._in_step) else None)
             elif kind == 'bn':
                 y = self._buf(key, out_shape)
@@ -823,11 +823,17 @@ class TapeEngine:
             elif kind == 'tconv':
                 k = p['k']
                 w = net.p(k.w_name)
+                scale = net.sn[k.scope]['scale'] if k.sn else None
                 if param_grads:
-                    def tconv_grads(k=k, a=a, dy=dy):
+                    def tconv_grads(k=k, a=a, dy=dy, w=w, scale=scale):
                         if k.bias_name is not None:
                             ops.colsum(dy.reshape(-1, dy.shape[-1]), out=net.g(k.bias_name))
-                        ops.conv2d_wgrad(dy, a, k.R, k.stride, out=net.g(k.w_name))    # W[R,R,out,in]: roles swapped
+                        gw = net.g(k.w_name)
+                        ops.conv2d_wgrad(dy, a, k.R, k.stride, out=gw)                 # W[R,R,out,in]: roles swapped
+                        if k.sn:                                                        # SURVEY A.2 fix-up
+                            st = net.sn[k.scope]
+                            ops.dot(gw.view(-1), w.view(-1), out=st['dot'])
+                            ops.sn_wgrad_fixup(gw.view(-1), st['dsigma'].view(-1), st['dot'], st['sigma'], scale)
                     if self._side:
                         self._wg_stream.wait_stream(torch.cuda.current_stream())
                         with torch.cuda.stream(self._wg_stream):
@@ -836,7 +842,7 @@ class TapeEngine:
                         tconv_grads()
                 if want_dx:                                              # d/dx of dgrad(x, W) = conv(dy, W)
                     dx = self._buf(key, in_shape)
-                    ops.conv2d_fwd(dy, w, k.stride, out=dx, wino=self._wino_of(k, False, n))
+                    ops.conv2d_fwd(dy, w, k.stride, scale=scale, out=dx, wino=self._wino_of(k, False, n))
                     give(vin, dx)
             elif kind == 'bn':
                 if rows is not None:
@@ -901,6 +907,9 @@ class TapeEngine:
 
     # ---- one training step -----------------------------------------------------------------------------------
     def generate(self, z, is_training=False):
+        for k in self.gen.kernels:                       # inference: spectral norms from the stored vectors, not updated
+            if k.sn:
+                self._sn_step(self.gen, k, update=False)
         vals = self._forward(self.gen, z, is_training, 'gen%d' % z.shape[0])
         return vals[self.gen.out_val]
 
@@ -954,7 +963,13 @@ class TapeEngine:
                 self._transform_weights(self.dis)
                 self._dis_ready.record(self._wg_stream)
             self._sn_stream.wait_stream(main)
-            with torch.cuda.stream(self._sn_stream):                     # depends on D's weights only
+            with torch.cuda.stream(self._sn_stream):                     # depend on the weights only; G's first
+                for k in self.gen.kernels:
+                    if k.sn:
+                        self._sn_step(self.gen, k)
+                if any(k.sn for k in self.gen.kernels):
+                    self._gen_sn_ready.record(self._sn_stream)
+                    main.wait_event(self._gen_sn_ready)
                 for k in self.dis.kernels:
                     if k.sn:
                         self._sn_step(self.dis, k)
@@ -965,9 +980,10 @@ class TapeEngine:
             self._zero_scratch.zero_()
             self._compose_weights(self.gen)
             self._compose_weights(self.dis)
-            for k in self.dis.kernels:
-                if k.sn:
-                    self._sn_step(self.dis, k)
+            for net in (self.gen, self.dis):
+                for k in net.kernels:
+                    if k.sn:
+                        self._sn_step(net, k)
         self._in_step = True
         gvals = self._forward(self.gen, self._static_z, True, 'g')
         self._dis_in[:B].copy_(self._static_real)                        # my_sngan.py:278: D sees [real ; fake]
@@ -1039,10 +1055,11 @@ class TapeEngine:
         """spectral norms of the last step, keyed like the reference's op scopes (<layer> for a plain layer's
         kernel, <layer>/kernel_0 ... inside a block)"""
         out = OrderedDict()
-        for k in self.dis.kernels:
-            if k.sn:
-                scope = k.scope[:-len('/kernel')] if k.scope.endswith('/kernel') else k.scope
-                out[scope] = float(self.dis.sn[k.scope]['sigma'].item())
+        for net in (self.dis, self.gen):
+            for k in net.kernels:
+                if k.sn:
+                    scope = k.scope[:-len('/kernel')] if k.scope.endswith('/kernel') else k.scope
+                    out[scope] = float(net.sn[k.scope]['sigma'].item())
         return out
 
     def state_dict(self):

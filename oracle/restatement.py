@@ -284,9 +284,10 @@ def build_net(designs, input_shape, net_name, sn_mode='default'):
             if d['op'] == 'd':
                 use_u = shape[0] <= d['out']
                 s['sn_x_shape'] = [1, shape[0]] if use_u else [1, d['out']]
-            elif d['op'] == 'c' and sn_mode in ('sn_paper', 'PIM', 'pim'):
-                # layer_func.py:811-814: the kernel flattened to [k*k*c_in, c_out] goes through the dense routine
-                num_in, num_out = int(np.prod(s['kernel_shape'][:3])), d['out']
+            elif d['op'] in ('c', 'tc') and sn_mode in ('sn_paper', 'PIM', 'pim'):
+                # layer_func.py:801, 811-814: the kernel flattened to [k*k*shape[2], shape[3]] goes through the dense routine
+                # (a 'tc' kernel is [k, k, out, in]: its LAST axis is the layer's input channels)
+                num_in, num_out = int(np.prod(s['kernel_shape'][:3])), s['kernel_shape'][3]
                 use_u = num_in <= num_out
                 s['sn_x_shape'] = [1, num_in] if use_u else [1, num_out]
                 s['pim'] = True
@@ -851,10 +852,10 @@ class OracleGan:
         return (loss_gen.detach(), loss_dis.detach(), stats, updates,
                 dict(zip(self.dis_names, gd)), dict(zip(self.gen_names, gg)), aux)
 
-    def step(self, z, real, uni=None):
+    def step(self, z, real, uni=None, masks=None):
         """losses are pre-update values; D and G update simultaneously from one forward
         (SURVEY 3.1); all reads precede all writes for the UPDATE_OPS."""
-        loss_gen, loss_dis, stats, updates, gd, gg, _ = self.grads(z, real, uni=uni)
+        loss_gen, loss_dis, stats, updates, gd, gg, _ = self.grads(z, real, uni=uni, masks=masks)
         self.opt_d.apply(self.params, gd)
         self.opt_g.apply(self.params, gg)
         for n, v in updates.items():

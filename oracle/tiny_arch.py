@@ -23,6 +23,28 @@ def tiny_architecture(loss_base=4):
                               {'name': 'l8_s', 'out': 16, 'op': 'd', 'act_k': ak, 'bias': 'b', 'w_nm': s}]}
 
 
+def tiny_gsn_architecture():
+    """the width/8 pair again with spectral norm in the GENERATOR as well: on its dense layer, on transposed-conv kernels
+    (SpectralNorm's 'tc' branch, math_func.py:512-528: the power iteration runs on the conv the layer is the transpose of)
+    with and without batch norm behind them, and on its last conv - every kernel kind a DCGAN generator has.  D is a
+    shortened tiny_architecture()."""
+    ak = float(np.power(64.0, 0.125))
+    s = 's'
+    return {'input': [(3, 16, 16)], 'code': [(24, 'linear')],
+            'generator': [{'name': 'l1', 'out': 32 * 4 * 4, 'op': 'd', 'act': 'linear', 'act_k': 1.0, 'w_nm': s,
+                           'out_reshape': [32, 4, 4]},
+                          {'name': 'l2_up', 'out': 16, 'op': 'tc', 'act': 'relu', 'act_nm': 'bn', 'act_k': ak, 'w_nm': s,
+                           'kernel': 4, 'strides': 2},
+                          {'name': 'l3_up', 'out': 8, 'op': 'tc', 'act': 'lrelu', 'act_k': ak, 'w_nm': s, 'kernel': 4, 'strides': 2},
+                          {'name': 'l4_t16', 'out': 3, 'act': 'tanh', 'act_k': 1.0, 'w_nm': s}],
+            'discriminator': [{'name': 'l1_f16', 'out': 8, 'act': 'lrelu', 'act_k': ak, 'w_nm': s},
+                              {'name': 'l2_ds', 'out': 16, 'act': 'lrelu', 'act_k': ak, 'w_nm': s, 'kernel': 4, 'strides': 2},
+                              {'name': 'l3', 'out': 16, 'act': 'lrelu', 'act_k': ak, 'w_nm': s},
+                              {'name': 'l4_ds', 'out': 32, 'act': 'lrelu', 'act_k': ak, 'w_nm': s, 'kernel': 4, 'strides': 2,
+                               'out_reshape': [4 * 4 * 32]},
+                              {'name': 'l5_s', 'out': 16, 'op': 'd', 'act_k': ak, 'bias': 'b', 'w_nm': s}]}
+
+
 def tiny_res_architecture():
     """width/16 ResNet-SN shaped pair: G = dense -> two up-sampling residual blocks with BN ->
     BN/relu -> conv/tanh at 16x16; D = the 'optimised' first block (res_v1), a down-sampling block, an identity-

@@ -149,25 +149,33 @@ def fp32_floor(arch, loss_type, lr, prev_vars, z, real, eng, uni=None, mix_state
 
 
 
-def fp32_oracle_trajectory_grads(fx, arch, sn_mode):
-    """the gradients of the fixture's LAST step as the restatement computes them free-running in fp32 from the fixture's
-    initial variables on the fixture's inputs: what an fp32 evaluation of the same trajectory loses against the fp64 one"""
+def oracle_trajectory(fx, arch, sn_mode, dtype, at_step=None, masks_per_step=None, want='grads'):
+    """the restatement free-running from the fixture's initial state on the fixture's inputs.  want='grads': the gradients
+    of step `at_step` (default: the last); want='final': every variable after the last step.  masks_per_step: the relu /
+    lrelu sign decisions an engine took at each step (engine_masks) - the run then takes the same ones (_act)"""
     init = {k[len('init/'):]: v for k, v in fx.items() if k.startswith('init/')}
-    o32 = _R().OracleGan(arch, str(fx['loss_type']), tuple(fx['lr']), dtype=_torch().float32, params=init, sn_mode=sn_mode)
+    gan = _R().OracleGan(arch, str(fx['loss_type']), tuple(fx['lr']), dtype=dtype, params=init, sn_mode=sn_mode)
     if 'adam_t' in fx:
-        o32.set_adam_state({k[len('adam_m/'):]: v for k, v in fx.items() if k.startswith('adam_m/')},
+        gan.set_adam_state({k[len('adam_m/'):]: v for k, v in fx.items() if k.startswith('adam_m/')},
                            {k[len('adam_v/'):]: v for k, v in fx.items() if k.startswith('adam_v/')}, int(fx['adam_t']))
     n_steps = fx['z'].shape[0]
-    for step in range(n_steps):
-        z, real = _torch().tensor(fx['z'][step]), _torch().tensor(fx['real'][step])
-        if step == n_steps - 1:
-            r = o32.grads(z, real)
+    last = n_steps - 1 if at_step is None else at_step
+    for step in range(n_steps if want == 'final' else last + 1):
+        z, real = _torch().tensor(fx['z'][step], dtype=dtype), _torch().tensor(fx['real'][step], dtype=dtype)
+        masks = masks_per_step[step] if masks_per_step is not None else None
+        if want == 'grads' and step == last:
+            r = gan.grads(z, real, masks=masks)
             out = {n: g.numpy() for n, g in r[4].items()}
             out.update({n: g.numpy() for n, g in r[5].items()})
             return out
-        o32.step(z, real)
+        gan.step(z, real, masks=masks)
+    return {n: v.numpy() for n, v in gan.params.items()}
 
 
+def fp32_oracle_trajectory_grads(fx, arch, sn_mode, at_step=None, masks_per_step=None):
+    """what an fp32 evaluation of the fixture's trajectory loses against the fp64 one: the fp32 side of
+    assert_grads_within_fp32_floor for the free-running fixture tests"""
+    return oracle_trajectory(fx, arch, sn_mode, _torch().float32, at_step, masks_per_step)
 
 
 def _R():

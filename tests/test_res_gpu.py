@@ -256,11 +256,6 @@ def test_batch_norm_in_the_discriminator_takes_the_primitive_op_engine():
                               {'name': 'l4_s', 'out': 16, 'op': 'd', 'act_k': ak, 'w_nm': 's'}]}
     with pytest.raises(NotImplementedError, match='batch norm in the discriminator'):
         GanEngine(arch, 'rep', (5e-4, 2e-4), batch_size=8)
-    g_sn = {**arch, 'generator': [dict(arch['generator'][0], w_nm='s', act_k=1.0)] + arch['generator'][1:],
-            'discriminator': [d if 'act_nm' not in d else dict({k: v for k, v in d.items() if k != 'act_nm'}, act_k=ak, w_nm='s')
-                              for d in arch['discriminator']]}
-    with pytest.raises(NotImplementedError, match='spectral norm in the generator'):
-        GanEngine(g_sn, 'rep', (5e-4, 2e-4), batch_size=8)
     mdl = SNGan(arch, num_class=0, loss_type='rep', optimizer='adam')
     assert isinstance(mdl.init_net((5e-4, 2e-4), 8), TapeEngine)
     B = 8

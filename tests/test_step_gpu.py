@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import RTOL, assert_grads_within_fp32_floor, fp32_floor, fp32_oracle_trajectory_grads, golden, load, sign_flips
+from helpers import (RTOL, assert_grads_within_fp32_floor, engine_masks, fp32_floor, fp32_oracle_trajectory_grads, golden, load,
+                     oracle_trajectory, sign_flips)
 from oracle import restatement as R
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
@@ -26,20 +27,27 @@ def close(got, ref, rtol, floor):
     return np.max(np.abs(got - ref)) <= rtol * np.max(np.abs(ref)) + floor
 
 
-@pytest.mark.parametrize('loss_type', ['rep', 'rmb', 'rep_pim'])
+@pytest.mark.parametrize('loss_type', ['rep', 'rmb', 'rep_pim', 'gsn_rep', 'gsn_rmb_pim'])
 @pytest.mark.parametrize('launch_mode', ['eager', 'graph', 'plan'])
 def test_step_matches_reference_golden(loss_type, launch_mode):
     """three steps of the width/8 net against the trajectory the reference's own code produced, in each of the three
     ways a step reaches the GPU: 'eager' (library calls from Python), 'graph' (one hipGraph), 'plan' (the library's own
     recorded launch plan - the mode bench.py measures: step 0 records while it runs, steps 1 and 2 are replays)"""
     from mmdgan_hip.engine import GanEngine
+    from tiny_arch import tiny_gsn_architecture
     fx = load(golden('step_tiny_%s.npz' % loss_type)[0])
     B = int(fx['B'])
+    # 'gsn_': spectral norm in the generator too - dense, transposed-conv (math_func.py:512-528) and conv kernels
+    arch = tiny_gsn_architecture() if loss_type.startswith('gsn_') else tiny_architecture()
+    last_bias = 'dis/%s/bias/bias' % arch['discriminator'][-1]['name']
     # '_pim': the reference ran with FLAGS.SPECTRAL_NORM_MODE = 'sn_paper' (layer_func.py:811-814)
     sn_mode = str(fx['sn_mode']) if 'sn_mode' in fx else 'default'
+    # the step-0 gradients of these runs (~1e-9) sit at Adam's eps = 1e-8, where rounding noise decides single entries of the
+    # update: later steps are compared by the bounds explained at the checks below.  (The 8-layer D of the plain fixtures
+    # starts at ~1e-14, far below eps: no such drift there.)
+    eps_regime = sn_mode != 'default' or loss_type.startswith('gsn_')
     loss_type = str(fx['loss_type'])
-    eng = GanEngine(tiny_architecture(), loss_type, tuple(fx['lr']), batch_size=B, launch_mode=launch_mode,
-                    sn_mode=sn_mode)
+    eng = GanEngine(arch, loss_type, tuple(fx['lr']), batch_size=B, launch_mode=launch_mode, sn_mode=sn_mode)
     eng.set_variables({k[len('init/'):]: v for k, v in fx.items() if k.startswith('init/')})
     n_steps = fx['z'].shape[0]
     for step in range(n_steps):
@@ -50,25 +58,25 @@ def test_step_matches_reference_golden(loss_type, launch_mode):
         for idx, name in ((0, 'loss_gen'), (1, 'loss_dis')):
             ref = float(fx[pre + name + '_f64'])
             # 'sn_paper': steps after the first carry the Adam-eps-regime drift explained at the final-variable check
-            floor = (4e-7 if (sn_mode == 'default' or step == 0) else 1e-5) * escale
+            floor = (4e-7 if (not eps_regime or step == 0) else 1e-5) * escale
             assert abs(losses[idx] - ref) <= RTOL * abs(ref) + floor, (step, name, losses[idx], ref)
         for k, v in fx.items():                      # spectral norms of every D layer, every step
             if k.startswith(pre + 'sigma/') and k.endswith('_f64'):
                 scope = k[len(pre + 'sigma/'):-len('_f64')]
-                tol = RTOL if (sn_mode == 'default' or step == 0) else 1e-3
+                tol = RTOL if (not eps_regime or step == 0) else 1e-3
                 assert abs(eng.sigmas()[scope] - float(v)) <= tol * float(v), (step, scope)
     pre = 'step%d/' % (n_steps - 1)
     if (pre + 'grad/dis/l1_f32/kernel/kernel_f64') in fx:          # gradients of the last step
         grads = eng.get_variables(grad=True)
         gscale = {net: max(np.abs(fx[pre + 'grad/' + n + '_f64']).max() for n in grads if n.startswith(net))
                   for net in ('gen', 'dis')}
-        if sn_mode != 'default':
+        if eps_regime:
             # 'sn_paper': two Adam updates taken in its eps regime lie between the initial variables and this step (see
             # below), so no fp32 evaluation of the trajectory tracks the fp64 one entry by entry: the one gradient rule
             # of these tests (helpers.assert_grads_within_fp32_floor), the floor being the restatement's own fp32 run
             ref64 = {n: fx[pre + 'grad/' + n + '_f64'] for n in grads}
-            assert_grads_within_fp32_floor(grads, ref64, lambda: fp32_oracle_trajectory_grads(fx, tiny_architecture(), sn_mode),
-                                           skip=('dis/l8_s/bias/bias',), what=loss_type)
+            assert_grads_within_fp32_floor(grads, ref64, lambda: fp32_oracle_trajectory_grads(fx, arch, sn_mode),
+                                           skip=(last_bias,), what=loss_type)
         else:
             for n, g in grads.items():
                 ref = fx[pre + 'grad/' + n + '_f64']
@@ -76,7 +84,7 @@ def test_step_matches_reference_golden(loss_type, launch_mode):
                 assert close(g, ref, RTOL, 1e-6 * gscale[n[:3]]), (n, np.abs(g - ref).max(), np.abs(ref).max())
     final = eng.get_variables()
     for n, v in final.items():                                     # weights, SN vectors, BN moving stats
-        if n == 'dis/l8_s/bias/bias':
+        if n == last_bias:
             # the loss sees only score DIFFERENCES, so dL/d(last bias) == 0 analytically; what every
             # implementation (the reference too) feeds Adam there is rounding noise ~1e-17, which Adam
             # normalises into +-lr-sized random steps.  Not comparable; bounded instead.
@@ -90,7 +98,7 @@ def test_step_matches_reference_golden(loss_type, launch_mode):
         # build (tools/determinism_probe.py: up to 0.5 lr), as between any two fp32 implementations.  There the
         # per-entry bound is lr-sized; the gradients of the last step (above) and the update in L2 (below) are the
         # checks with teeth.
-        floor = (2.5 if sn_mode != 'default' else 0.02) * float(fx['lr'].max())
+        floor = (2.5 if eps_regime else 0.02) * float(fx['lr'].max())
         assert close(v, ref, RTOL, floor), (n, np.abs(v - ref).max(), np.abs(ref).max())
         if not (n.endswith('in_rand') or '/moving_' in n):
             du, dr = v.astype(np.float64) - fx['init/' + n], ref.astype(np.float64) - fx['init/' + n]
@@ -99,14 +107,14 @@ def test_step_matches_reference_golden(loss_type, launch_mode):
             # (|g|max / eps) * lr per entry, whichever fp32 implementation produced g (40 runs of this build: the L2 deviation of
             # G's last BN beta, 8 entries, ranges from 0.2 to 11 times 1 % of the update).  That much is allowed on top.
             noise = 0.0
-            if sn_mode != 'default' and ('step0/grad/' + n + '_f64') in fx:
+            if eps_regime and ('step0/grad/' + n + '_f64') in fx:
                 g0 = float(np.abs(fx['step0/grad/' + n + '_f64']).max())
                 noise = 4.0 * min(1.0, g0 / 1e-8) * float(fx['lr'].max()) * np.sqrt(v.size)
             assert np.linalg.norm(du - dr) <= 0.01 * np.linalg.norm(dr) + noise + 1e-12, n
 
 
 @pytest.mark.parametrize('tag,engine', [('rep', 'dcgan'), ('rep', 'dcgan-plan'), ('rep_pim', 'dcgan'), ('rep_pim', 'dcgan-plan'),
-                                        ('rep', 'tape'), ('res_rep', 'tape')])
+                                        ('gsn_rep', 'dcgan'), ('gsn_rep', 'dcgan-plan'), ('rep', 'tape'), ('res_rep', 'tape'), ('gsn_rep', 'tape')])
 def test_free_run_from_warm_start_matches_reference(tag, engine):
     """three FREE-RUNNING steps from a state the reference code reached after 20 warm-up steps (variables, Adam
     moments, step count; tests/golden/step_warm_*.npz).  No step-0 noise regime here - the gradients are O(1e-2), Adam
@@ -123,7 +131,8 @@ def test_free_run_from_warm_start_matches_reference(tag, engine):
         from mmdgan_hip.engine import GanEngine as Engine
         kw['launch_mode'] = 'plan' if engine.endswith('-plan') else 'eager'
     fx = load(golden('step_warm_%s.npz' % tag)[0])
-    arch = tiny_res_architecture() if tag.startswith('res_') else tiny_architecture()
+    from tiny_arch import tiny_gsn_architecture
+    arch = tiny_res_architecture() if tag.startswith('res_') else (tiny_gsn_architecture() if tag.startswith('gsn_') else tiny_architecture())
     B, lr = int(fx['B']), tuple(fx['lr'])
     eng = Engine(arch, str(fx['loss_type']), lr, batch_size=B, sn_mode=str(fx['sn_mode']), **kw)
     init = {k[len('init/'):]: v for k, v in fx.items() if k.startswith('init/')}
@@ -132,8 +141,10 @@ def test_free_run_from_warm_start_matches_reference(tag, engine):
     eng.set_adam_state({k[len('adam_m/'):]: v for k, v in fx.items() if k.startswith('adam_m/')},
                        {k[len('adam_v/'):]: v for k, v in fx.items() if k.startswith('adam_v/')}, int(fx['adam_t']))
     n_steps = fx['z'].shape[0]
+    masks_per_step, flipped = [], False
     for step in range(n_steps):
         eng.step(nhwc(fx['real'][step]), torch.as_tensor(fx['z'][step]).cuda())
+        masks_per_step.append(engine_masks(eng))
         pre = 'step%d/' % step
         losses = eng.losses.cpu().numpy().astype(np.float64)
         escale = float(max(losses[2:5]))
@@ -152,11 +163,21 @@ def test_free_run_from_warm_start_matches_reference(tag, engine):
             grads = eng.get_variables(grad=True)
             gscale = {net: max(np.abs(fx[pre + 'grad/' + n + '_f64']).max() for n in grads if n.startswith(net))
                       for net in ('gen', 'dis')}
+            forced = None
             for n, g in grads.items():
                 ref = fx[pre + 'grad/' + n + '_f64']
                 # floor: gradients that are analytically zero (a bias behind which only score differences matter, a
                 # bias in front of a batch norm) are rounding noise in every implementation: 1e-6 of the net's scale
-                assert close(g, ref, RTOL, 1e-6 * gscale[n[:3]]), (step, n, np.abs(g - ref).max(), np.abs(ref).max())
+                if close(g, ref, RTOL, 1e-6 * gscale[n[:3]]):
+                    continue
+                # a relu / lrelu output within fp32 resolution of zero (the fixtures report their margin: ~1e-7 of the layer's
+                # scale - about one element in a million) is decided differently by an fp32 and an fp64 evaluation of the
+                # SAME algebra, and every gradient below that element moves by up to 1e-2.  The reference then is the
+                # restatement's fp64 trajectory under the engine's sign decisions - same bar
+                if forced is None:
+                    forced, flipped = oracle_trajectory(fx, arch, str(fx['sn_mode']), torch.float64, step, masks_per_step), True
+                assert close(g, forced[n], RTOL, 1e-6 * gscale[n[:3]]), (step, n, np.abs(g - forced[n]).max(), np.abs(ref).max())
+    final_ref = oracle_trajectory(fx, arch, str(fx['sn_mode']), torch.float64, None, masks_per_step, want='final') if flipped else None
     pre = 'step%d/' % (n_steps - 1)
     gsc = {net: max(np.abs(fx[pre + 'grad/' + n + '_f64']).max() for n in init if (pre + 'grad/' + n + '_f64') in fx
                     and n.startswith(net)) for net in ('gen', 'dis')}
@@ -167,11 +188,12 @@ def test_free_run_from_warm_start_matches_reference(tag, engine):
         if n in noise:                      # analytically zero gradient: Adam turns its rounding noise into lr-sized steps
             assert np.abs(v - fx['init/' + n]).max() <= 3.5 * max(lr), n
             continue
-        ref = fx['final/' + n + '_f64']
+        ref = fx['final/' + n + '_f64'] if final_ref is None else final_ref[n]
         assert close(v, ref, RTOL, 0.0), (n, np.abs(v - ref).max(), np.abs(ref).max())
         if not (n.endswith('in_rand') or '/moving_' in n):
             du, dr = v.astype(np.float64) - fx['init/' + n], ref.astype(np.float64) - fx['init/' + n]
             assert np.linalg.norm(du - dr) <= 1e-3 * np.linalg.norm(dr) + 1e-12, (n, np.linalg.norm(du - dr) / np.linalg.norm(dr))
+    assert not flipped or tag == 'gsn_rep', 'only the G-side-SN fixture is known to hold a knife-edge activation'   # keeps the others strict
 
 
 def mid_architecture():
