@@ -343,6 +343,7 @@ def main():
                                    % (args.config, h, w, ('ResNet-SN' if has_residual_blocks(arch) else 'DCGAN-SN (primitive-op engine)') if tape else 'DCGAN-SN',
                                       B, args.loss, lr[0], lr[1]),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world, 'launch_mode': mode,
+                       'dp_backend': getattr(eng, '_dp_backend', None) if group is not None else None,
                        'launch_mode_trial_ms': {k: round(v * 1e3, 4) for k, v in trial.items()} or None},
             'loss_gen': float(losses[0]), 'loss_dis': float(losses[1]),
         }

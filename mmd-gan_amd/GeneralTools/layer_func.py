@@ -2,8 +2,9 @@
 an API so that `Net(design, net_name, data_format, num_class)` + `Routine(net).add_input_layers /
 seq_links / add_output_layers / __call__` read as they do in my_sngan.py:85-108.
 
-Only sequential default-type layers with ops d / c / tc (spectral norm and batch norm included) are on the hot path
-(SURVEY.md section 2);
+Sequential nets of default-type layers with ops d / c / tc (spectral norm and batch norm included) run on the hand-scheduled
+layer chain; nets with residual blocks ('type': 'res' / 'res_i' / 'res_v1', layer_func.py:2043-2067), identity layers, scaling
+ops or an input reshape are lowered to primitive ops (mmdgan_hip.tape) - every architecture SNGan accepts also runs here;
 anything else raises the reference's error for an unsupported op or type.  Tensors crossing this
 API are NCHW like the reference's (misc_fun.py:50-51); inside they are NHWC and every op is a HIP
 kernel (mmdgan_hip.ops).  Training uses mmdgan_hip.engine.GanEngine (preallocated buffers, one
@@ -18,6 +19,8 @@ from mmdgan_hip.engine import Network, build_specs, _native_shape, sn_power_iter
 
 
 class Net(object):
+    primitive, lowered = False, None     # the design needs primitive ops / its mmdgan_hip.tape.NetForward (set by Routine)
+
     def __init__(self, net_design, net_name='net', data_format=None, num_class=0):
         if num_class not in (0, 1):
             raise NotImplementedError('{}: conditional layers are outside the hot path'.format(net_name))
@@ -42,8 +45,14 @@ class Routine(object):
         """input_shape = [batch, features] or [batch, C, H, W]; only dims [1:] matter (layer_func.py:694)."""
         if out_layer_indices != [0]:
             raise NotImplementedError('only sequential routines are on the hot path')
-        self.net.specs = build_specs(self.net.net_def, list(input_shape[1:]), self.net.net_name,
-                                    FLAGS.SPECTRAL_NORM_MODE)
+        from mmdgan_hip.tape import needs_primitive_ops
+        self.net.in_shape_ref = list(input_shape[1:])
+        self.net.primitive = needs_primitive_ops(self.net.net_def)
+        if self.net.primitive:
+            self.net.specs = list(self.net.net_def)      # lowered on first use (needs the device)
+        else:
+            self.net.specs = build_specs(self.net.net_def, list(input_shape[1:]), self.net.net_name,
+                                         FLAGS.SPECTRAL_NORM_MODE)
         self.layer_indices.append(0)
 
     def seq_links(self, in_layer_indices):
@@ -62,7 +71,13 @@ class Routine(object):
 
     def _ensure_network(self, device):
         if self.net.network is None:
-            self.net.network = Network(self.net.specs, device, np.random.RandomState(0), FLAGS.WEIGHT_INITIALIZER)
+            if self.net.primitive:                       # residual blocks / scaling ops: the primitive-op lowering
+                from mmdgan_hip.tape import NetForward
+                self.net.lowered = NetForward(self.net.net_def, self.net.in_shape_ref, self.net.net_name, device,
+                                              FLAGS.SPECTRAL_NORM_MODE, FLAGS.WEIGHT_INITIALIZER)
+                self.net.network = self.net.lowered.net  # same variable interface: set_variable / get_variable / state
+            else:
+                self.net.network = Network(self.net.specs, device, np.random.RandomState(0), FLAGS.WEIGHT_INITIALIZER)
         return self.net.network
 
     def __call__(self, routine_inputs, is_training=True):
@@ -71,6 +86,12 @@ class Routine(object):
             raise NotImplementedError('Output layer has not been defined.')
         x = routine_inputs['x'] if isinstance(routine_inputs, dict) else routine_inputs
         net = self._ensure_network(x.device)
+        if self.net.lowered is not None:
+            assert list(x.shape[1:]) == self.net.in_shape_ref, \
+                '{}: the input shape {} does not match existed shape {}.'.format(self.net.net_name, list(x.shape[1:]),
+                                                                                self.net.in_shape_ref)
+            y = self.net.lowered(ops.nchw_to_nhwc(x.contiguous()) if x.dim() == 4 else x.contiguous(), is_training)
+            return {'x': ops.nhwc_to_nchw(y.contiguous()) if y.dim() == 4 else y}
         specs = net.specs
         assert list(x.shape[1:]) == specs[0].in_shape_ref, \
             '{}: the input shape {} does not match existed shape {}.'.format(specs[0].scope, list(x.shape[1:]),

@@ -433,10 +433,22 @@ class GanEngine:
         # who carries the gradient exchange: 'torch' = torch.distributed on `dist_group` (RCCL through ProcessGroupNCCL; gloo in
         # the tests); 'capi' = the library's own RCCL communicator (mmdgan_comm_init / mmdgan_allreduce_bucket), whose
         # collectives are plan nodes like any launch - a data-parallel step then replays from one C call
-        self._dp_backend = dp_backend or os.environ.get('MMDGAN_DP_BACKEND', 'torch')
+        # Default: 'capi' under an nccl (= RCCL) group - it depends on nothing ProcessGroupNCCL does with streams and the
+        # whole data-parallel step replays from one C call; 'torch' for any other backend (gloo in the tests)
+        self._dp_backend = dp_backend or os.environ.get('MMDGAN_DP_BACKEND')
+        if self._dp_backend is None:
+            import torch.distributed as tdist
+            self._dp_backend = 'capi' if (dist_group is not None and tdist.get_backend(dist_group) == 'nccl') else 'torch'
         assert self._dp_backend in ('torch', 'capi'), self._dp_backend
         if self._dp_backend == 'capi' and dist_group is not None:
-            self._init_capi_comm()
+            try:
+                self._init_capi_comm()
+            except Exception as err:                     # no RCCL to bind, or its rendezvous failed: say so and carry on
+                import sys
+                if dp_backend == 'capi' or os.environ.get('MMDGAN_DP_BACKEND') == 'capi':
+                    raise
+                sys.stderr.write('mmdgan: library-owned RCCL exchange unavailable (%s); using torch.distributed\n' % err)
+                self._dp_backend = 'torch'
         # the power iterations of different layers are independent of each other too: two chains.
         # weight / bias gradients of a layer depend only on dz of that layer, not on the dgrad chain that
         # continues below it: they go to another stream so their blocks fill the tail of the dgrad

@@ -28,9 +28,14 @@ RES_TYPES = ('res', 'res_i', 'res_v1')                                   # layer
 _PIM = ('sn_paper', 'PIM', 'pim')
 
 
-def has_residual_blocks(architecture):
+def needs_primitive_ops(designs):
+    """a net the hand-scheduled chain does not express: residual blocks, identity layers, scaling ops, an input reshape"""
     return any(d.get('type', 'default') in RES_TYPES or d.get('op') == 'i' or d.get('scale') is not None
-               for net in ('generator', 'discriminator') for d in architecture[net])
+               or d.get('in_reshape') is not None for d in designs)
+
+
+def has_residual_blocks(architecture):
+    return any(needs_primitive_ops(architecture[net]) for net in ('generator', 'discriminator'))
 
 
 def needs_tape_engine(architecture):
@@ -466,6 +471,32 @@ class _Net:
                 self.set_variable(item.scope + '/SN/in_rand', _trunc_normal(rng, item.sn_x_ref, 1.0))
             if item.bias_name is not None:
                 self.set_variable(item.bias_name, _trunc_normal(rng, [item.out], 1e-5))
+
+
+class NetForward:
+    """ONE lowered net run forward eagerly: Routine.__call__ for architectures with residual blocks, scaling ops, identity
+    layers or an input reshape (layer_func.py:2043-2067 dispatch -> :1687-1842).  Spectral norms from one power-iteration
+    step on the stored vectors (updated in training mode only: UPDATE_OPS), batch norm from batch / moving statistics."""
+
+    def __init__(self, designs, in_ref, name, device, sn_mode='default', weight_init='default', rng=None):
+        ops.require_device()
+        self.device = torch.device(device)
+        self.net = _Net(designs, list(in_ref), name, self.device, rng if rng is not None else np.random.RandomState(0),
+                        sn_mode, weight_init)
+        if ops._workspace is None:
+            ops.set_workspace(device=self.device)
+        # the forward executor is TapeEngine's, on an instance that holds nothing but buffers
+        run = TapeEngine.__new__(TapeEngine)
+        run.device, run._bufs, run._wino, run._in_step = self.device, {}, {}, False
+        run._folded = {k.scope: [None, None] for k in self.net.kernels}
+        self._run = run
+
+    def __call__(self, x_nhwc, is_training=False):
+        for k in self.net.kernels:
+            if k.sn:
+                self._run._sn_step(self.net, k, update=bool(is_training))
+        vals = self._run._forward(self.net, x_nhwc.contiguous(), bool(is_training), 'fwd%d' % x_nhwc.shape[0])
+        return vals[self.net.out_val]
 
 
 def _native(ref_shape, n):

@@ -1,5 +1,7 @@
 """The reference-facing Python API on the GPU: SNGan.training / eval_sampling through Agent with
 synthetic data, GANLoss.apply, get_squared_dist, Net/Routine inference."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -93,6 +95,44 @@ def test_routine_inference_matches_oracle():
     params['gen/l2_up/BN/BN/moving_variance'] = torch.ones(16, dtype=torch.float64)
     ref, _ = R.net_forward(specs, params, z.cpu().double(), True)
     assert rel_err(y.cpu().numpy(), ref.numpy()) <= RTOL
+
+
+@pytest.mark.parametrize('which', ['generator', 'discriminator'])
+def test_routine_runs_residual_block_designs(which):
+    """Net / Routine on designs with 'type': 'res' / 'res_i' / 'res_v1' blocks, scaling ops and an identity layer
+    (layer_func.py:2043-2067 -> :1687-1842): the reference's front end covers every architecture SNGan accepts.  Both
+    nets of the tiny ResNet-SN pair, a training-mode call (UPDATE_OPS: spectral-norm vectors, BN moving statistics) and
+    an inference-mode call, against the oracle from the same variables."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
+    from tiny_arch import tiny_res_architecture
+    from GeneralTools.layer_func import Net, Routine
+    arch = tiny_res_architecture()
+    designs = arch[which]
+    name = 'gen' if which == 'generator' else 'dis'
+    in_ref = [arch['code'][0][0]] if which == 'generator' else list(arch['input'][0])
+    net = Net(designs, net_name=name, data_format='channels_first', num_class=0)
+    r = Routine(net)
+    r.add_input_layers([8] + in_ref, [0])
+    r.seq_links(list(range(net.num_layers)))
+    r.add_output_layers([net.num_layers - 1])
+    rs = np.random.RandomState(2)
+    x = torch.as_tensor(rs.randn(6, *in_ref).astype(np.float32)).cuda()
+    specs = R.build_net(designs, in_ref, name)
+    r({'x': x}, is_training=True)                        # first call creates the variables; the state moves
+    for training in (True, False):
+        params = {k: torch.tensor(net.network.get_variable(k), dtype=torch.float64) for k in net.network.variable_names()}
+        y = r({'x': x}, is_training=training)['x']
+        ref, upd = R.net_forward(specs, params, x.cpu().double(), training)
+        assert tuple(y.shape) == tuple(ref.shape)
+        assert rel_err(y.cpu().numpy(), ref.numpy()) <= RTOL, (which, training)
+        if training:                                     # the UPDATE_OPS: spectral-norm vectors, BN moving statistics
+            assert upd
+            for k, v in upd.items():
+                assert rel_err(net.network.get_variable(k), v.numpy()) <= RTOL, k
+        else:                                            # (the graph defines them; an inference session does not run them)
+            for k in net.network.variable_names():
+                assert np.array_equal(net.network.get_variable(k), params[k].float().numpy()), k
 
 
 def test_eval_sampling_writes_the_reference_sprite_from_inference_mode_images(tmp_path):
