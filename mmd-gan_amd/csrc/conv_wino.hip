@@ -28,11 +28,14 @@ namespace mmdgan {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace wino {
-constexpr int BC = 8;                  // reduction channels per stage: 32 MFMAs per wave between barriers
-constexpr int LDT = 33;                // V: floats per channel row (32 tiles + 1)
-constexpr int FSV = BC * LDT + 2;      // V: floats per frequency; 4*FSV = 8 (mod 32) spreads the 4 tile rows over the banks
-static_assert((4 * FSV) % 32 == 8, "V frequency stride");
-constexpr int V_FLOATS = 16 * FSV;     // one stage of transformed activations
+constexpr int BC = 8;                  // reduction channels per stage = 4 MFMA k-pairs: 32 MFMAs per wave between barriers
+constexpr int ROW = 32 * 4 + 4;        // V: floats per (frequency, k half) row = [32 tiles][4 k-pairs] + 4
+constexpr int FSV = 2 * ROW;           // V: floats per frequency
+constexpr int IPAD = 8;                // ... + 8 floats per frequency ROW i = f >> 2: the four patch rows of a producer wave's
+                                       // store (f = 4 pr + j) land 8 banks apart, every offset stays 16-byte aligned
+__host__ __device__ constexpr int voff(int f) { return f * FSV + (f >> 2) * IPAD; }
+static_assert((voff(4) - voff(0)) % 32 == 8 && voff(1) % 4 == 0, "V frequency stride");
+constexpr int V_FLOATS = voff(16);     // one stage of transformed activations
 template <int BN>
 struct Cfg {
     static constexpr int NCB = BN / 32;
@@ -42,14 +45,18 @@ struct Cfg {
 };
 }  // namespace wino
 
-// U[f][cr][ko] = (G g G^T)[f]  with g = w[.][.][c][k] (cr = c, ko = k)                      FLIP = false
-//                               or g = w[2-.][2-.][c][k] read as (cr = k, ko = c)            FLIP = true
+// U[f][cr / 8][cr & 1][ko][(cr & 7) >> 1] = (G g G^T)[f]  with g = w[.][.][c][k] (cr = c, ko = k)          FLIP = false
+//                                                      or g = w[2-.][2-.][c][k] read as (cr = k, ko = c)  FLIP = true
+// The innermost four floats are the B operands of the four MFMA k-pairs of one 8-channel stage for one lane (k half = cr & 1,
+// column = ko): the convolution kernel fetches them with ONE 16-byte load per lane, 512 contiguous bytes per half-wave.
+// The reduction-side channel count is a multiple of 8 (what the F(2x2,3x3) kernels accept); ragged 32-blocks are guarded.
 template <bool FLIP>
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float *__restrict__ w, float *__restrict__ U, int C, int K) {
     __shared__ float tile[8][32][33];
     const int c0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
     const int tk = threadIdx.x & 31, tq = threadIdx.x >> 5;
-    for (int half = 0; half < (FLIP ? 2 : 1); ++half) {
+    const int Cr = FLIP ? K : C, Ko = FLIP ? C : K, cr0 = FLIP ? k0 : c0, ko0 = FLIP ? c0 : k0;
+    for (int half = 0; half < 2; ++half) {              // 8 of the 16 frequencies at a time (LDS)
         for (int cc = tq; cc < 32; cc += 8) {
             const int c = c0 + cc, k = k0 + tk;
             const bool ok = c < C && k < K;
@@ -74,27 +81,27 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float *__restric
                 u[i][2] = 0.5f * (gg[i][0] - gg[i][1] + gg[i][2]);
                 u[i][3] = gg[i][2];
             }
-            if (!FLIP) {
-                if (ok) {
 #pragma unroll
-                    for (int f = 0; f < 16; ++f) U[((size_t)f * C + c) * K + k] = u[f >> 2][f & 3];
-                }
-            } else {
-#pragma unroll
-                for (int f = 0; f < 8; ++f) tile[f][cc][tk] = half ? u[2 + (f >> 2)][f & 3] : u[f >> 2][f & 3];
-            }
+            for (int f = 0; f < 8; ++f) tile[f][cc][tk] = half ? u[2 + (f >> 2)][f & 3] : u[f >> 2][f & 3];
         }
-        if (FLIP) {          // transposed write: U[f][k][c], threads along c
-            __syncthreads();
-            for (int kk = tq; kk < 32; kk += 8) {
-                const int k = k0 + kk, c = c0 + tk;
-                if (c < C && k < K) {
+        __syncthreads();
+        // thread = (output channel of the block tk, channel group of the block tq >> 1, k half tq & 1)
+        const int g8 = tq >> 1, kh = tq & 1;
+        const bool st_ok = cr0 + g8 * 8 < Cr && ko0 + tk < Ko;
 #pragma unroll
-                    for (int f = 0; f < 8; ++f) U[((size_t)(half * 8 + f) * K + k) * C + c] = tile[f][tk][kk];
-                }
+        for (int f = 0; f < 8; ++f) {
+            if (!st_ok) break;
+            float4 v;
+            float *pv = reinterpret_cast<float *>(&v);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int crl = g8 * 8 + 2 * q + kh;
+                pv[q] = FLIP ? tile[f][tk][crl] : tile[f][crl][tk];
             }
-            __syncthreads();
+            const size_t row = (((size_t)(half * 8 + f)) * (Cr >> 3) + (cr0 >> 3) + g8) * 2 + kh;
+            *reinterpret_cast<float4 *>(U + (row * Ko + ko0 + tk) * 4) = v;
         }
+        __syncthreads();
     }
 }
 
@@ -109,17 +116,15 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float *__restric
 #ifndef WINO_WAVES
 #define WINO_WAVES 2
 #endif
-#ifndef WINO_BD
-#define WINO_BD 16          // B-fragment prefetch distance in MFMA groups (16 = one full stage)
-#endif
 template <int BN, bool SPLIT>
 __global__ __launch_bounds__(256, WINO_WAVES) void wino_kernel(int N, int H, int W, int Cr, int Ko, ConvEpilogue ep,
                                                       const float *__restrict__ x, const float *__restrict__ U,
                                                       float *__restrict__ out, int stages_per_split) {
     using Cf = wino::Cfg<BN>;
-    constexpr int BC = wino::BC, LDT = wino::LDT, FSV = wino::FSV, NCB = Cf::NCB, VF = wino::V_FLOATS;
+    constexpr int BC = wino::BC, ROW = wino::ROW, FSV = wino::FSV, NCB = Cf::NCB, VF = wino::V_FLOATS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int TH = H >> 1, TW = W >> 1;
     const long T = (long)N * TH * TW;
     const int t0 = blockIdx.x * 32, n0 = blockIdx.y * BN;
@@ -144,13 +149,13 @@ __global__ __launch_bounds__(256, WINO_WAVES) void wino_kernel(int N, int H, int
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (long)N * H * W * Cr * 4);
     const __amdgpu_buffer_rsrc_t ru = make_rsrc(U, (long)16 * Cr * Ko * 4);
     const float sa = pr == 3 ? -1.f : 1.f, sb = (pr & 1) ? 1.f : -1.f;      // V[i=pr] = sa * X[pr] + sb * X[other]
-    const int vdst = (pr * 4) * FSV + (4 * pp) * LDT + pt;
-    // B fragment of group g = (kp = g>>2, fl = g&3), column block cb: U[4*wave + fl][c0 + 2*kp + kh][n0 + cb*32 + l31]
-    const unsigned ubase = (unsigned)(((((long)4 * wave) * Cr + kh) * Ko + n0 + l31) * 4);
-    const unsigned ustage = (unsigned)(BC * Ko * 4), ufreq = (unsigned)((long)Cr * Ko * 4), ukp = (unsigned)(2 * Ko * 4);
+    // V[f][k half][tile][4 k-pairs]: channel 4 pp + e of the stage -> k half e & 1, k-pair 2 pp + (e >> 1); f = 4 pr + j
+    const int vdst = wino::voff(4 * pr) + pt * 4 + pp * 2;
+    // B fragments of frequency 4 wave + fl, column block cb: U[f][stage][kh][n0 + cb*32 + l31][4 k-pairs]: one 16-byte load
+    const unsigned ubase = (unsigned)(((long)kh * Ko + n0 + l31) * 16);
+    const unsigned ustage = (unsigned)(2 * Ko * 16), ufreq = (unsigned)((long)Cr * Ko * 4);
     const int s_begin = SPLIT ? blockIdx.z * stages_per_split : 0;
     const int nstages = SPLIT ? min(Cr / BC, s_begin + stages_per_split) : Cr / BC;      // = end of this block's stage range
-    constexpr int NG = 2 * BC, PF = 3;                  // MFMA groups per stage, A-fragment prefetch distance
 
     f32x16 acc[4][NCB];
 #pragma unroll
@@ -161,70 +166,77 @@ __global__ __launch_bounds__(256, WINO_WAVES) void wino_kernel(int N, int H, int
             for (int r = 0; r < 16; ++r) acc[fl][cb][r] = 0.f;
 
     float4 rin[4];
-    constexpr int BD = WINO_BD;
-    float fb[BD][NCB], X[4][4];
+    float4 fb[4][NCB], fa[2];
+    float X[4][4];
     // row pass X = d B along the 4 columns of this thread's patch row, 4 channels
 #define WINO_ROWPASS                                                                                     \
     X[0][0] = rin[0].x - rin[2].x; X[0][1] = rin[0].y - rin[2].y; X[0][2] = rin[0].z - rin[2].z; X[0][3] = rin[0].w - rin[2].w; \
     X[1][0] = rin[1].x + rin[2].x; X[1][1] = rin[1].y + rin[2].y; X[1][2] = rin[1].z + rin[2].z; X[1][3] = rin[1].w + rin[2].w; \
     X[2][0] = rin[2].x - rin[1].x; X[2][1] = rin[2].y - rin[1].y; X[2][2] = rin[2].z - rin[1].z; X[2][3] = rin[2].w - rin[1].w; \
     X[3][0] = rin[1].x - rin[3].x; X[3][1] = rin[1].y - rin[3].y; X[3][2] = rin[1].z - rin[3].z; X[3][3] = rin[1].w - rin[3].w;
-    // column pass V = B^T X: row i = pr needs its own row and row {2,2,1,1}[pr] of the same quad
+    // column pass V = B^T X: row i = pr needs its own row and row {2,2,1,1}[pr] of the same quad; frequency 4 pr + J gets the
+    // channel pairs (0,2) -> k half 0 and (1,3) -> k half 1 as two 8-byte stores
 #define WINO_VSTORE(BUF, J)                                                                              \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                      \
-        const int other = __builtin_amdgcn_update_dpp(0, __float_as_int(X[J][e]), 0x5A, 0xF, 0xF, false); /* quad_perm [2,2,1,1] */ \
-        (BUF)[vdst + (J) * FSV + e * LDT] = fmaf(sb, __int_as_float(other), sa * X[J][e]);                \
+    {                                                                                                    \
+        float v_[4];                                                                                     \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                  \
+            const int other = __builtin_amdgcn_update_dpp(0, __float_as_int(X[J][e]), 0x5A, 0xF, 0xF, false); /* quad_perm [2,2,1,1] */ \
+            v_[e] = fmaf(sb, __int_as_float(other), sa * X[J][e]);                                       \
+        }                                                                                                \
+        *reinterpret_cast<float2 *>((BUF) + vdst + (J) * FSV) = make_float2(v_[0], v_[2]);               \
+        *reinterpret_cast<float2 *>((BUF) + vdst + (J) * FSV + ROW) = make_float2(v_[1], v_[3]);         \
     }
 #define WINO_XLOAD(S)                                                                                    \
     {                                                                                                    \
         const unsigned sx = (unsigned)((S) * BC * 4);          /* padded taps: kOOB + sx stays out of range */ \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) rin[j] = bufld4(rx, xoff[j] + sx);                 \
     }
-#define WINO_BLOAD(G, S)                                                                                 \
+    // the B fragments (all four k-pairs) of frequency 4 wave + FL for stage S
+#define WINO_BLOAD(FL, S)                                                                                \
     _Pragma("unroll") for (int cb = 0; cb < NCB; ++cb)                                                   \
-        fb[(G) % BD][cb] = bufld1s(ru, ubase, (unsigned)(S) * ustage + ((G) & 3) * ufreq + ((G) >> 2) * ukp + cb * 128);
+        fb[FL][cb] = bufld4s(ru, ubase, (unsigned)(4 * wave + (FL)) * ufreq + (unsigned)(S) * ustage + cb * 512);
+#define WINO_ALOAD(SL, BUF, FL) fa[SL] = *reinterpret_cast<const float4 *>((BUF) + abase + (FL) * FSV);
 
     // prologue: tile 0 -> LDS, tile 1 -> registers, B fragments of stage 0
     WINO_XLOAD(s_begin)
 #pragma unroll
-    for (int g = 0; g < BD; ++g) WINO_BLOAD(g, s_begin)
+    for (int fl = 0; fl < 4; ++fl) WINO_BLOAD(fl, s_begin)
     WINO_ROWPASS
     WINO_VSTORE(smem, 0) WINO_VSTORE(smem, 1) WINO_VSTORE(smem, 2) WINO_VSTORE(smem, 3)
     WINO_XLOAD(s_begin + 1)
     __syncthreads();
-    // Same hand pipeline as the direct kernels (conv_igemm.hip mainloop): per stage a wave issues NG groups
-    // of NCB MFMAs; A fragments are read from LDS PF groups ahead; each group's B registers are refilled
-    // for the next stage right after its MFMAs; the transform + LDS stores of tile s+1 and the global loads
-    // of tile s+2 sit behind individual groups (sched_barrier keeps hipcc from re-clumping them); one
-    // barrier per stage.
-    const int abase = (4 * wave) * FSV + kh * LDT + l31;
+    // A stage = 8 channels = 4 MFMA k-pairs.  The wave walks its four frequencies one after the other: the A fragments of a
+    // frequency are ONE ds_read_b128 (fetched while the previous frequency is multiplied), its B fragments ONE 16-byte
+    // load per column block, refilled for the next stage right after the last MFMA that reads them (3/4 of a stage ahead
+    // of their use) - a quarter of the LDS / vector-memory instructions of the one-dword-per-MFMA form.  Every accumulator
+    // still sees its k-pairs in ascending order (bitwise the same sums).  The transform + LDS stores of tile s+1 and the
+    // global loads of tile s+2 sit behind individual MFMA groups (sched_barrier keeps hipcc from re-clumping them).
+    const int abase = wino::voff(4 * wave) + kh * ROW + l31 * 4;
     for (int s = s_begin; s < nstages; ++s) {
         const float *cur = smem + ((s - s_begin) & 1) * VF;
         float *nxt = smem + ((s - s_begin + 1) & 1) * VF;
         const int sn = s + 1 < nstages ? s + 1 : s;           // the last refill re-reads the last stage (unused)
-        float fa[NG];
+        WINO_ALOAD(0, cur, 0)
 #pragma unroll
-        for (int g = 0; g < PF; ++g) fa[g] = cur[abase + (g & 3) * FSV + 2 * (g >> 2) * LDT];
+        for (int fl = 0; fl < 4; ++fl) {
+            if (fl + 1 < 4) WINO_ALOAD((fl + 1) & 1, cur, fl + 1)
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + PF < NG) fa[g + PF] = cur[abase + ((g + PF) & 3) * FSV + 2 * ((g + PF) >> 2) * LDT];
+            for (int q = 0; q < 4; ++q) {
+                const float a = q == 0 ? fa[fl & 1].x : q == 1 ? fa[fl & 1].y : q == 2 ? fa[fl & 1].z : fa[fl & 1].w;
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb)
-                acc[g & 3][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g], fb[g % BD][cb], acc[g & 3][cb], 0, 0, 0);
-            if (g + BD < NG) WINO_BLOAD(g + BD, s) else WINO_BLOAD(g + BD - NG, sn)
-            if (g == 0) {                              // tile s+1: row pass, then one frequency column per group
-                WINO_ROWPASS
-                WINO_VSTORE(nxt, 0)
-            } else if (g == 1) {
-                WINO_VSTORE(nxt, 1)
-            } else if (g == 2) {
-                WINO_VSTORE(nxt, 2)
-            } else if (g == 3) {
-                WINO_VSTORE(nxt, 3)
-            } else if (g == 4) {                       // tile s+2: activations
-                WINO_XLOAD(s + 2)
+                for (int cb = 0; cb < NCB; ++cb) {
+                    const float b = q == 0 ? fb[fl][cb].x : q == 1 ? fb[fl][cb].y : q == 2 ? fb[fl][cb].z : fb[fl][cb].w;
+                    acc[fl][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[fl][cb], 0, 0, 0);
+                }
+                if (q == 3) WINO_BLOAD(fl, sn)
+                // tile s+1: row pass, then one frequency column per group; tile s+2: activations
+                if (fl == 0 && q == 0) { WINO_ROWPASS WINO_VSTORE(nxt, 0) }
+                else if (fl == 0 && q == 2) WINO_VSTORE(nxt, 1)
+                else if (fl == 1 && q == 0) WINO_VSTORE(nxt, 2)
+                else if (fl == 1 && q == 2) WINO_VSTORE(nxt, 3)
+                else if (fl == 2 && q == 0) WINO_XLOAD(s + 2)
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
@@ -232,6 +244,7 @@ __global__ __launch_bounds__(256, WINO_WAVES) void wino_kernel(int N, int H, int
 #undef WINO_VSTORE
 #undef WINO_XLOAD
 #undef WINO_BLOAD
+#undef WINO_ALOAD
 
     // ---- output transform + epilogue
     const float sc = ep.scale ? ep.scale[0] : 1.f;
@@ -349,6 +362,10 @@ bool wino_fwd_ok(const ConvDims &d) { return d.N > 1 && wino_shape_ok(d, d.C, d.
 bool wino_dgrad_ok(const ConvDims &d) { return d.N > 1 && wino_shape_ok(d, d.K, d.C) && workspace(sizeof(float) * 16 * (size_t)d.C * d.K) != nullptr; }
 
 int wino_transform(const ConvDims &d, const float *w, bool flip, float *U, hipStream_t st) {
+    if ((flip ? d.K : d.C) % 8) {
+        set_error("wino_transform (3x3): the reduction-side channel count (%d) must be a multiple of 8", flip ? d.K : d.C);
+        return MMDGAN_E_ARG;
+    }
     const dim3 wg((d.K + 31) / 32, (d.C + 31) / 32);
     if (flip) hipLaunchKernelGGL(wino_weight_kernel<true>, wg, dim3(256), 0, st, w, U, d.C, d.K);
     else hipLaunchKernelGGL(wino_weight_kernel<false>, wg, dim3(256), 0, st, w, U, d.C, d.K);

@@ -16,6 +16,9 @@ from mmdgan_hip import ops  # noqa: E402
 ops.require_device()
 ops.set_workspace()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+CASES3 = [('D l3 fwd', 2 * B, 16, 128, 128, False), ('D l3 dgrad 3B', 3 * B, 16, 128, 128, True),
+          ('D l5 fwd', 2 * B, 8, 256, 256, False), ('D l5 dgrad 3B', 3 * B, 8, 256, 256, True),
+          ('D l7 fwd', 2 * B, 4, 512, 512, False), ('D l7 dgrad 3B', 3 * B, 4, 512, 512, True)]
 CASES = [('D l2 fwd', 2 * B, 32, 64, 128, False), ('D l2 dgrad 3B', 3 * B, 32, 64, 128, True),
          ('D l4 fwd', 2 * B, 16, 128, 256, False), ('D l4 dgrad 3B', 3 * B, 16, 128, 256, True),
          ('D l6 fwd', 2 * B, 8, 256, 512, False), ('D l6 dgrad 3B', 3 * B, 8, 256, 512, True),
@@ -37,6 +40,28 @@ def timeit(fn, reps=30, warm=200):
 
 
 torch.manual_seed(0)
+for name, N, H, C, K, dgrad in CASES3:                       # F(2x2,3x3), stride 1
+    w = torch.randn(3, 3, C, K, device='cuda') * 0.05
+    wt = w.permute(3, 2, 0, 1).contiguous()
+    u = None if os.environ.get('MMDGAN_WINO') == '0' else ops.wino_transform(w, dgrad)
+    fl = 2.0 * N * H * H * K * 9 * C
+    if not dgrad:
+        x = torch.randn(N, H, H, C, device='cuda')
+        y = torch.empty(N, H, H, K, device='cuda')
+        run = lambda: ops.conv2d_fwd(x, w, 1, out=y, wino=u)
+        run()
+        ref = F.conv2d(x.permute(0, 3, 1, 2), wt, stride=1, padding=1).permute(0, 2, 3, 1)
+        err = float((y - ref).abs().max() / ref.abs().max())
+    else:
+        dy = torch.randn(N, H, H, K, device='cuda')
+        dx = torch.empty(N, H, H, C, device='cuda')
+        run = lambda: ops.conv2d_dgrad(dy, w, (H, H), 1, out=dx, wino=u)
+        run()
+        ref = F.conv_transpose2d(dy.permute(0, 3, 1, 2), wt, stride=1, padding=1).permute(0, 2, 3, 1)
+        err = float((dx - ref).abs().max() / ref.abs().max())
+    t = timeit(run)
+    print('%-14s N=%3d %2dx%2d C=%3d K=%3d: %7.1f us  %6.1f TF alg  %5.1f TF issued   max rel err %.2e %s' % (
+        name, N, H, H, C, K, t * 1e3, fl / t / 1e9, fl * 16 / 36 / t / 1e9, err, '' if err < 1e-4 else '  <-- WRONG'))
 for name, N, H, C, K, dgrad in CASES:
     P = H // 2
     w = torch.randn(4, 4, C, K, device='cuda') * 0.05
