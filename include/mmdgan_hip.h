@@ -194,6 +194,14 @@ int mmdgan_conv2d_wgrad(const mmdgan_conv_geom *g, const float *x, const float *
  * the dy tiles it streams anyway instead of a second pass over dy.  dbias is overwritten. */
 int mmdgan_conv2d_wgrad_bias(const mmdgan_conv_geom *g, const float *x, const float *dy, float *dw, float *dbias,
                              void *stream);
+/* the weight gradient of a SPECTRALLY NORMALISED kernel: as above (dbias may be NULL) plus dot_gw[0] = <dw, w>, the scalar of
+ * the fix-up dL/dW = scale * dw - (scale / sigma) * <dw, w> * dsigma/dW (layer_func.py:884-887 + autodiff through
+ * math_func.py:661-672).  dw stays the RAW gradient w.r.t. the scaled kernel: the fix-up is linear in it and
+ * is applied where the gradient is consumed (mmdgan_adam_segments), after any data-parallel sum.  On the slab paths the
+ * dot product is formed by the slabs' reduction pass (no extra launch); dot_gw is overwritten (accumulated into when
+ * mmdgan_set_outputs_prezeroed(1) is in force). */
+int mmdgan_conv2d_wgrad_sn(const mmdgan_conv_geom *g, const float *x, const float *dy, float *dw, float *dbias,
+                           const float *w, float *dot_gw, void *stream);
 
 /* Winograd F(2x2,3x3) for 3x3 / stride-1 layers (csrc/conv_wino.hip) and F(2x2,2x2) on the parity decomposition of
  * 4x4 / stride-2 layers and their transposes (csrc/conv_wino2.hip); same tf.nn.conv2d / conv2d_transpose / autodiff
@@ -320,6 +328,25 @@ int mmdgan_mmd_mix_loss(const float *s_gen, const float *s_x, int B, int d, int 
 int mmdgan_adam_multi(const void *const *ptrs, const long *sizes, int n_tensors, long max_size, float lr,
                       float beta1, float beta2, float eps, int step, int *step_counter, float *lr_t_scratch,
                       float grad_scale, void *stream);
+
+/* The same update over ONE flat arena (params / grads / adam_m / adam_v share element offsets), cut into segments, with the
+ * spectral-norm fix-up of mmdgan_conv2d_wgrad_sn folded into the gradient read: a segment with dsigma != NULL uses
+ *     g_eff = grad_scale * (scale[0] * g - (scale[0] / sigma[0]) * dot[0] * dsigma)
+ * (all DEVICE pointers; dsigma 16-byte aligned, n elements), any other segment g_eff = grad_scale * g.
+ * segments_dev: DEVICE array of n_segments descriptors; blocks_dev: DEVICE array of n_blocks (segment index, block index
+ * within the segment) int pairs, one per 1024 elements of every segment - the caller builds both once.
+ * apply_fixup = 0: every segment is read plainly (the caller has applied mmdgan_sn_wgrad_fixup itself - what a data-parallel
+ * replica does BEFORE its all-reduce: sigma and dsigma/dW carry the order of each replica's own atomics in their last bits,
+ * and a fix-up applied after the sum would let the replicas' weights drift apart by an ulp per step).
+ * Elements of the arena that no segment covers are left alone. */
+typedef struct mmdgan_adam_segment {
+    long off, n;
+    const float *dsigma, *dot, *sigma, *scale;
+} mmdgan_adam_segment;
+int mmdgan_adam_segments(float *params, const float *grads, float *adam_m, float *adam_v,
+                         const mmdgan_adam_segment *segments_dev, int n_segments, const int *blocks_dev, long n_blocks,
+                         float lr, float beta1, float beta2, float eps, int step, int *step_counter, float *lr_t_scratch,
+                         float grad_scale, int apply_fixup, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Elementwise pieces of the residual blocks (layer_func.py:1687-1842), NHWC fp32.

@@ -119,26 +119,33 @@ extern "C" int mmdgan_wino_transform(const mmdgan_conv_geom *g, const float *w, 
     return g->R == 3 ? wino_transform(d, w, dgrad != 0, u, (hipStream_t)stream) : wino2_transform(d, w, dgrad != 0, u, (hipStream_t)stream);
 }
 
+// wdot / dot (optional): dot[0] = <dw, wdot> - the scalar of the spectral-norm fix-up (mmdgan_conv2d_wgrad_sn)
 static int wgrad_impl(const mmdgan_conv_geom *g, const float *x, const float *dy, float *dw, float *dbias, void *stream,
-                      const char *what) {
+                      const char *what, const float *wdot = nullptr, float *dot = nullptr) {
     if (int rc = validate(g, what)) return rc;
     MMDGAN_REQUIRE(x && dy && dw, "%s: null pointer", what);
     const ConvDims d = conv_dims(*g);
+    const long nw = (long)d.R * d.R * d.C * d.K;
     if (!force_direct() && (wino_wgrad_ok(d) || wino2_wgrad_ok(d))) {
-        bool db_done = false;                      // the slab kernels sum dy on the way
-        int rcw = d.R == 3 ? wino_wgrad(d, x, dy, dw, dbias, &db_done, (hipStream_t)stream)
-                           : wino2_wgrad(d, x, dy, dw, dbias, &db_done, (hipStream_t)stream);
+        bool db_done = false, dot_done = false;    // the slab kernels sum dy on the way, their reduction pass forms <dw, w>
+        if (wdot && zero_output(dot, sizeof(float), (hipStream_t)stream) != hipSuccess) return check_launch("conv2d_wgrad memset");
+        int rcw = d.R == 3 ? wino_wgrad(d, x, dy, dw, dbias, &db_done, (hipStream_t)stream, wdot, dot, &dot_done)
+                           : wino2_wgrad(d, x, dy, dw, dbias, &db_done, (hipStream_t)stream, wdot, dot, &dot_done);
         if (rcw == 0 && dbias && !db_done) rcw = mmdgan_colsum(dy, (long)d.N * d.P * d.Q, d.K, dbias, stream);
+        if (rcw == 0 && wdot && !dot_done) rcw = mmdgan_dot(dw, wdot, nw, dot, stream);
         return rcw;
     }
-    if (!force_direct() && igemm_wgrad_ok(d)) return igemm_wgrad(d, x, dy, dw, dbias, (hipStream_t)stream);   // sums dy on the way
     int rc = 1;
-    if (!force_direct() && !force_valu_thin() && thinm_wgrad_ok(d)) rc = thinm_wgrad(d, x, dy, dw, (hipStream_t)stream);
-    if (rc > 0) {                                                  // 1: no workspace registered -> VALU kernel
-        if (!force_direct() && thin_wgrad_ok(d)) rc = thin_wgrad(d, x, dy, dw, (hipStream_t)stream);
-        else rc = direct_wgrad(d, x, dy, dw, (hipStream_t)stream);
+    if (!force_direct() && igemm_wgrad_ok(d)) rc = igemm_wgrad(d, x, dy, dw, dbias, (hipStream_t)stream);   // sums dy on the way
+    else {
+        if (!force_direct() && !force_valu_thin() && thinm_wgrad_ok(d)) rc = thinm_wgrad(d, x, dy, dw, (hipStream_t)stream);
+        if (rc > 0) {                                              // 1: no workspace registered -> VALU kernel
+            if (!force_direct() && thin_wgrad_ok(d)) rc = thin_wgrad(d, x, dy, dw, (hipStream_t)stream);
+            else rc = direct_wgrad(d, x, dy, dw, (hipStream_t)stream);
+        }
+        if (rc == 0 && dbias) rc = mmdgan_colsum(dy, (long)d.N * d.P * d.Q, d.K, dbias, stream);
     }
-    if (rc == 0 && dbias) rc = mmdgan_colsum(dy, (long)d.N * d.P * d.Q, d.K, dbias, stream);
+    if (rc == 0 && wdot) rc = mmdgan_dot(dw, wdot, nw, dot, stream);
     return rc;
 }
 
@@ -150,4 +157,10 @@ extern "C" int mmdgan_conv2d_wgrad_bias(const mmdgan_conv_geom *g, const float *
                                         void *stream) {
     MMDGAN_REQUIRE(dbias, "conv2d_wgrad_bias: null pointer");
     return wgrad_impl(g, x, dy, dw, dbias, stream, "conv2d_wgrad_bias");
+}
+
+extern "C" int mmdgan_conv2d_wgrad_sn(const mmdgan_conv_geom *g, const float *x, const float *dy, float *dw, float *dbias,
+                                      const float *w, float *dot_gw, void *stream) {
+    MMDGAN_REQUIRE(w && dot_gw, "conv2d_wgrad_sn: null pointer");
+    return wgrad_impl(g, x, dy, dw, dbias, stream, "conv2d_wgrad_sn", w, dot_gw);
 }

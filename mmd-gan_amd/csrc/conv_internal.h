@@ -60,9 +60,13 @@ int wino_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const
 // in-place bias / activation / activation-derivative pass after a split-reduction launch (conv_wino.hip)
 int epilogue_pass(float *y, long total, int Ko, const ConvEpilogue &ep, hipStream_t st);
 bool wino_wgrad_ok(const ConvDims &d);
-int wino_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, float *dbias, bool *dbias_done, hipStream_t st);
-// dw[n] = sum of nsplit slabs of n floats; dbias[k] = sum of nsplit rows of k floats (k = 0: none).  conv_wino2.hip
-void slab_reduce(const float *part, int nsplit, size_t n, float *dw, const float *dbpart, int k, float *dbias, hipStream_t st);
+// wdot / dot (optional): dot[0] += <dw, wdot> (dot zeroed by the caller); *dot_done says whether it was produced on the way
+int wino_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, float *dbias, bool *dbias_done, hipStream_t st,
+               const float *wdot = nullptr, float *dot = nullptr, bool *dot_done = nullptr);
+// dw[n] = sum of nsplit slabs of n floats; dbias[k] = sum of nsplit rows of k floats (k = 0: none); dot[0] += <dw, wdot>.
+// conv_wino2.hip
+void slab_reduce(const float *part, int nsplit, size_t n, float *dw, const float *dbpart, int k, float *dbias, hipStream_t st,
+                 const float *wdot = nullptr, float *dot = nullptr);
 
 // Winograd F(2x2,2x2) for 4x4 / stride-2 layers and their input-gradient (conv_wino2.hip); U = 36*C*K floats
 bool wino2_eligible(const ConvDims &d, bool dgrad);
@@ -72,7 +76,8 @@ int wino2_transform(const ConvDims &d, const float *w, bool dgrad, float *U, hip
 int wino2_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, const float *U, float *y, hipStream_t st);
 int wino2_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, const float *U, float *dx, hipStream_t st);
 bool wino2_wgrad_ok(const ConvDims &d);
-int wino2_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, float *dbias, bool *dbias_done, hipStream_t st);
+int wino2_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, float *dbias, bool *dbias_done, hipStream_t st,
+                const float *wdot = nullptr, float *dot = nullptr, bool *dot_done = nullptr);
 
 // MFMA implicit-GEMM path (conv_igemm.hip); *_ok() say whether a geometry is eligible
 bool igemm_fwd_ok(const ConvDims &d);

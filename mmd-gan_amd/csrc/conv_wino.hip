@@ -841,9 +841,11 @@ bool wino_wgrad_ok(const ConvDims &d) {
 }
 
 // dbias (optional): the column sums of dy; *dbias_done says whether they were produced here (slab path)
-int wino_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, float *dbias, bool *dbias_done, hipStream_t st) {
+int wino_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, float *dbias, bool *dbias_done, hipStream_t st,
+               const float *wdot, float *dot, bool *dot_done) {
     const long T = (long)d.N * (d.H / 2) * (d.W / 2);
     if (dbias_done) *dbias_done = false;
+    if (dot_done) *dot_done = false;
     if (wino_wgrad_slab_ok(d)) {
         const int nst = (int)((T + winos::BT - 1) / winos::BT);
         const long base = (long)(d.C / winos::BC) * (d.K / winos::BK);
@@ -868,8 +870,9 @@ int wino_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, fl
             else
                 hipLaunchKernelGGL(wino_wgrad_slab_kernel<false>, grid, dim3(winos::NT), winos::LDS_BYTES, st, d.N, d.H, d.W, d.C, d.K, x, dy, part,
                                    dbpart, sps);
-            slab_reduce(part, split, n, dw, dbpart, dbias ? d.K : 0, dbias, st);
+            slab_reduce(part, split, n, dw, dbpart, dbias ? d.K : 0, dbias, st, wdot, dot);
             if (dbias_done) *dbias_done = dbias != nullptr;
+            if (dot_done) *dot_done = wdot != nullptr;
             return check_launch("conv2d_wgrad(winograd)");
         }
     }

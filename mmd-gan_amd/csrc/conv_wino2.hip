@@ -733,34 +733,56 @@ __global__ __launch_bounds__(wino2w::NT) void wino2_wgrad_kernel(int N, int H, i
         }
 }
 
-// dw[e] = sum over the splits' slabs (fixed order: deterministic).  One float4 per thread, eight slab loads in flight.
+// dw[e] = sum over the splits' slabs (fixed order: deterministic).  One float4 per thread and trip, eight slab loads in flight.
 // Elements n4 .. n4 + k4 - 1 are the bias gradient: partial rows [split][K] -> dbias.
-__global__ __launch_bounds__(64) void slab_reduce_kernel(const float4 *__restrict__ part, int nsplit, long n4, float4 *__restrict__ dw,
-                                                                const float4 *__restrict__ dbpart, long k4, float4 *__restrict__ dbias) {
-    long e = (long)blockIdx.x * 64 + threadIdx.x;
-    if (e >= n4 + k4) return;
-    long stride = n4;
-    if (e >= n4) { e -= n4; part = dbpart; stride = k4; dw = dbias; }
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    int s = 0;
-    for (; s + 8 <= nsplit; s += 8) {
-        float4 v[8];
+// wdot (optional): dot[0] += <dw, wdot> on the way - the scalar the spectral-norm fix-up of this gradient needs
+// (mmdgan_conv2d_wgrad_sn): one atomic per workgroup instead of a separate pass over dw and the kernel.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float4 *__restrict__ part, int nsplit, long n4, float4 *__restrict__ dw,
+                                                          const float4 *__restrict__ dbpart, long k4, float4 *__restrict__ dbias,
+                                                          const float4 *__restrict__ wdot, float *__restrict__ dot) {
+    __shared__ double red[4];
+    double acc = 0;
+    const long stride = (long)gridDim.x * 256;
+    for (long e0 = (long)blockIdx.x * 256 + threadIdx.x; e0 < n4 + k4; e0 += stride) {
+        long e = e0, slab = n4;
+        const float4 *src = part;
+        float4 *dst = dw;
+        const bool is_w = e < n4;
+        if (!is_w) { e -= n4; src = dbpart; slab = k4; dst = dbias; }
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        int s = 0;
+        for (; s + 8 <= nsplit; s += 8) {
+            float4 v[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = part[(long)(s + q) * stride + e];
+            for (int q = 0; q < 8; ++q) v[q] = src[(long)(s + q) * slab + e];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { a.x += v[q].x; a.y += v[q].y; a.z += v[q].z; a.w += v[q].w; }
+            for (int q = 0; q < 8; ++q) { a.x += v[q].x; a.y += v[q].y; a.z += v[q].z; a.w += v[q].w; }
+        }
+        for (; s < nsplit; ++s) {
+            const float4 b = src[(long)s * slab + e];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        dst[e] = a;
+        if (wdot && is_w) {
+            const float4 wv = wdot[e];
+            acc += (double)a.x * wv.x + (double)a.y * wv.y + (double)a.z * wv.z + (double)a.w * wv.w;
+        }
     }
-    for (; s < nsplit; ++s) {
-        const float4 b = part[(long)s * stride + e];
-        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    if (wdot) {                                            // (kernel-uniform)
+        acc = wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(dot, (float)(red[0] + red[1] + red[2] + red[3]));
     }
-    dw[e] = a;
 }
 
-void slab_reduce(const float *part, int nsplit, size_t n, float *dw, const float *dbpart, int k, float *dbias, hipStream_t st) {
+void slab_reduce(const float *part, int nsplit, size_t n, float *dw, const float *dbpart, int k, float *dbias, hipStream_t st,
+                 const float *wdot, float *dot) {
     const long n4 = (long)(n / 4), k4 = k / 4;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n4 + k4 + 63) / 64)), dim3(64), 0, st, (const float4 *)part, nsplit, n4, (float4 *)dw,
-                       (const float4 *)dbpart, k4, (float4 *)dbias);
+    long blocks = (n4 + k4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float4 *)part, nsplit, n4, (float4 *)dw,
+                       (const float4 *)dbpart, k4, (float4 *)dbias, (const float4 *)wdot, dot);
 }
 
 // MMDGAN_WINO2_WGRAD=0 keeps the stride-2 weight gradients on the direct implicit-GEMM kernel, =1 uses this one;
@@ -777,7 +799,9 @@ bool wino2_wgrad_ok(const ConvDims &d) {
 
 // dbias (optional): the column sums of dy.  Returns 0 with *dbias_done = whether dbias was produced here (workspace path);
 // otherwise the caller sums dy itself.
-int wino2_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, float *dbias, bool *dbias_done, hipStream_t st) {
+int wino2_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, float *dbias, bool *dbias_done, hipStream_t st,
+                const float *wdot, float *dot, bool *dot_done) {
+    if (dot_done) *dot_done = false;
     const long T = (long)d.N * (d.P / 2) * (d.Q / 2);
     const int nst = (int)((T + wino2w::BT - 1) / wino2w::BT);
     const long base = (long)(d.C / wino2w::BC) * (d.K / wino2w::BK) * 4;
@@ -804,8 +828,9 @@ int wino2_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, f
         else
             hipLaunchKernelGGL((wino2_wgrad_kernel<true, false>), grid, dim3(wino2w::NT), wino2w::LDS_BYTES, st, d.N, d.H, d.W, d.C, d.K, x, dy, part,
                                dbpart, sps);
-        slab_reduce(part, split, n, dw, dbpart, dbias ? d.K : 0, dbias, st);
+        slab_reduce(part, split, n, dw, dbpart, dbias ? d.K : 0, dbias, st, wdot, dot);
         if (dbias_done) *dbias_done = dbias != nullptr;
+        if (dot_done) *dot_done = wdot != nullptr;
         return check_launch("conv2d_wgrad(winograd 2x2)");
     }
     if (split == 1) {                           // one slab: straight into dw

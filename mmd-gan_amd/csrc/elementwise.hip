@@ -161,6 +161,61 @@ __global__ __launch_bounds__(256) void adam_kernel(const void *const *ptrs, cons
     }
 }
 
+// The same update over ONE flat arena (p / g / m / v share offsets) cut into segments, with the spectral-norm fix-up of a
+// segment's gradient folded in: a spectrally normalised kernel W enters the net as W * scale (scale = act_k / sigma(W)), so
+//     dL/dW = scale * G - (scale / sigma) * <G, W> * dsigma/dW          (G = the gradient w.r.t. the scaled kernel)
+// which is linear in G: the raw G stays in the gradient arena (and is what a data-parallel all-reduce sums, together with
+// the scalar <G, W>), and Adam reads the effective gradient here - no pass over every kernel for the fix-up.
+// Work is dealt in blocks of 1024 elements through a table (segment, first element), so a 3-element bias costs one block.
+struct AdamSegment {       // == mmdgan_adam_segment (include/mmdgan_hip.h)
+    long off, n;                         // elements, relative to the arena
+    const float *dsigma, *dot, *sigma, *scale;      // NULL / unused for a plain segment
+};
+static_assert(sizeof(AdamSegment) == sizeof(mmdgan_adam_segment), "ABI");
+__global__ __launch_bounds__(256) void adam_segments_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                            float *__restrict__ v, const AdamSegment *__restrict__ segs,
+                                                            const int2 *__restrict__ blocks, const float *lr_t_ptr, float b1,
+                                                            float b2, float eps, float gscale, int apply_fixup) {
+    const int2 bk = blocks[blockIdx.x];
+    AdamSegment s = segs[bk.x];
+    if (!apply_fixup) s.dsigma = nullptr;
+    const float lr_t = lr_t_ptr[0];
+    float a = gscale, c = 0.f;
+    if (s.dsigma) {
+        const float sc = s.scale[0];
+        a = gscale * sc;
+        c = gscale * (sc / s.sigma[0]) * s.dot[0];
+    }
+    const long i0 = (long)bk.y * 1024 + threadIdx.x * 4, base = s.off + i0;
+    if (i0 + 4 <= s.n && (base & 3) == 0) {
+        const float4 gv = *reinterpret_cast<const float4 *>(g + base);
+        float4 mv = *reinterpret_cast<const float4 *>(m + base), vv = *reinterpret_cast<const float4 *>(v + base);
+        float4 pv = *reinterpret_cast<const float4 *>(p + base);
+        float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s.dsigma) dv = *reinterpret_cast<const float4 *>(s.dsigma + i0);       // (16-byte aligned: checked by the host)
+        const float ge[4] = {a * gv.x - c * dv.x, a * gv.y - c * dv.y, a * gv.z - c * dv.z, a * gv.w - c * dv.w};
+        float *pm = reinterpret_cast<float *>(&mv), *pvv = reinterpret_cast<float *>(&vv), *pp = reinterpret_cast<float *>(&pv);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            pm[q] = b1 * pm[q] + (1.f - b1) * ge[q];
+            pvv[q] = b2 * pvv[q] + (1.f - b2) * ge[q] * ge[q];
+            pp[q] = pp[q] - lr_t * pm[q] / (sqrtf(pvv[q]) + eps);
+        }
+        *reinterpret_cast<float4 *>(m + base) = mv;
+        *reinterpret_cast<float4 *>(v + base) = vv;
+        *reinterpret_cast<float4 *>(p + base) = pv;
+    } else {
+        for (long i = i0; i < i0 + 4 && i < s.n; ++i) {
+            const float gi = a * g[s.off + i] - (s.dsigma ? c * s.dsigma[i] : 0.f);
+            const float mi = b1 * m[s.off + i] + (1.f - b1) * gi;
+            const float vi = b2 * v[s.off + i] + (1.f - b2) * gi * gi;
+            m[s.off + i] = mi;
+            v[s.off + i] = vi;
+            p[s.off + i] = p[s.off + i] - lr_t * mi / (sqrtf(vi) + eps);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restrict__ src, float *__restrict__ dst,
                                                            int N, int C, int HW) {
@@ -304,6 +359,21 @@ extern "C" int mmdgan_adam_multi(const void *const *ptrs, const long *sizes, int
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(max_size, 256, 1024), n_tensors), dim3(256), 0, st, ptrs, sizes,
                        lr_t_scratch, beta1, beta2, eps, grad_scale);
     return check_launch("adam_multi");
+}
+
+extern "C" int mmdgan_adam_segments(float *params, const float *grads, float *adam_m, float *adam_v,
+                                    const mmdgan_adam_segment *segments_dev, int n_segments, const int *blocks_dev, long n_blocks,
+                                    float lr, float beta1, float beta2, float eps, int step, int *step_counter,
+                                    float *lr_t_scratch, float grad_scale, int apply_fixup, void *stream) {
+    MMDGAN_REQUIRE(params && grads && adam_m && adam_v && segments_dev && blocks_dev && lr_t_scratch && n_segments >= 1 &&
+                   n_blocks >= 1, "adam_segments: bad arguments");
+    MMDGAN_REQUIRE(step_counter || step >= 1, "adam_segments: step must be >= 1 when no device counter is given");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, st, step_counter, step, lr, beta1, beta2, lr_t_scratch);
+    hipLaunchKernelGGL(adam_segments_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, params, grads, adam_m, adam_v,
+                       reinterpret_cast<const AdamSegment *>(segments_dev), reinterpret_cast<const int2 *>(blocks_dev), lr_t_scratch,
+                       beta1, beta2, eps, grad_scale, apply_fixup);
+    return check_launch("adam_segments");
 }
 
 extern "C" int mmdgan_nchw_to_nhwc(const float *src, float *dst, int N, int C, int H, int W, void *stream) {

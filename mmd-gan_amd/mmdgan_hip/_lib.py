@@ -48,6 +48,7 @@ SIGNATURES = {
     'mmdgan_conv2d_dgrad': (_I, [_G, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     'mmdgan_conv2d_wgrad': (_I, [_G, _P, _P, _P, _P]),
     'mmdgan_conv2d_wgrad_bias': (_I, [_G, _P, _P, _P, _P, _P]),
+    'mmdgan_conv2d_wgrad_sn': (_I, [_G, _P, _P, _P, _P, _P, _P, _P]),
     'mmdgan_wino_eligible': (_I, [_G, _I]),
     'mmdgan_wino_weight_bytes': (ctypes.c_size_t, [_G]),
     'mmdgan_wino_transform': (_I, [_G, _P, _I, _P, _P]),
@@ -67,6 +68,7 @@ SIGNATURES = {
     'mmdgan_mmd_mix_workspace_bytes': (ctypes.c_size_t, [_I, _I]),
     'mmdgan_mmd_mix_loss': (_I, [_P, _P, _I, _I, _I, _P, _F, _F, _F, _P, _P, _P, _P, _P, _P]),
     'mmdgan_adam_multi': (_I, [_P, _P, _I, _L, _F, _F, _F, _F, _I, _P, _P, _F, _P]),
+    'mmdgan_adam_segments': (_I, [_P, _P, _P, _P, _P, _I, _P, _L, _F, _F, _F, _F, _I, _P, _P, _F, _I, _P]),
     'mmdgan_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'mmdgan_nhwc_to_nchw': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'mmdgan_resample_down': (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),

@@ -169,6 +169,13 @@ class Network:
         self.specs, self.device = specs, device
         self.weight_init = initializers.check_mode(weight_init)            # FLAGS.WEIGHT_INITIALIZER, layer_func.py:27-64
         entries = []
+        self.name = specs[0].scope.split('/')[0]
+        sn_specs = [s for s in specs if s.sn]
+        # <G, W> of every spectrally normalised kernel (the scalar of its gradient's fix-up, below) lives at the HEAD of the
+        # gradient arena: it is zeroed with the arena and summed with it by a data-parallel exchange (the fix-up is linear)
+        self._dot_name = self.name + '/#sn_dot'
+        if sn_specs:
+            entries.append((self._dot_name, [len(sn_specs)]))
         for s in specs:
             entries.append((s.scope + '/kernel/kernel', s.kernel_shape))
             if s.has_bias:
@@ -180,7 +187,6 @@ class Network:
         self.arena = _Arena(entries, device)
         self.params = self.arena.flat
         self.grads, self.adam_m, self.adam_v = self.arena.like(), self.arena.like(), self.arena.like()
-        self.opt = ops.AdamGroup([self.params], [self.grads], [self.adam_m], [self.adam_v])
         self.state = OrderedDict()                      # non-trainable: SN vectors, BN moving stats
         # everything the SN chain accumulates into with atomics (split reductions, dot) lives in ONE
         # scratch arena so that the step zeroes it with a single memset
@@ -188,20 +194,54 @@ class Network:
         for s in specs:
             if s.sn:
                 sn_entries += [(s.scope + '#u', self._sn_u_shape(s)), (s.scope + '#xb', self._sn_native_shape(s)),
-                               (s.scope + '#dsigma', s.kernel_shape), (s.scope + '#dot', [1])]
+                               (s.scope + '#dsigma', s.kernel_shape)]
         self.sn_scratch = _Arena(sn_entries, device)
         for s in specs:
             if s.sn:
                 self.state[s.scope + '/kernel/SN/in_rand'] = torch.zeros(self._sn_native_shape(s), device=device)
                 for k in ('sigma', 'scale'):
                     self.state[s.scope + '#' + k] = torch.zeros(1, device=device)
-                for k in ('dot', 'dsigma', 'u', 'xb'):
+                for k in ('dsigma', 'u', 'xb'):
                     self.state[s.scope + '#' + k] = self.sn_scratch.view(s.scope + '#' + k)
+                i = sn_specs.index(s)
+                self.state[s.scope + '#dot'] = self.arena.view(self._dot_name, self.grads)[i:i + 1]
             if s.bn:
                 nfeat = s.out if s.op == 'd' else s.channels
                 self.state[s.scope + '/BN/BN/moving_mean'] = torch.zeros(nfeat, device=device)
                 self.state[s.scope + '/BN/BN/moving_variance'] = torch.ones(nfeat, device=device)
+        # TF-Adam over the arena, one segment per variable; a spectrally normalised kernel's segment carries the fix-up of its
+        # gradient  dL/dW = scale * G - (scale / sigma) * <G, W> * dsigma/dW  (SURVEY A.2): the arena holds the RAW G
+        segments = []
+        for name, (off, size, _) in self.arena.offsets.items():
+            if name == self._dot_name:
+                continue
+            s = self._spec_of(name)
+            sn = None
+            if s.sn and name.endswith('/kernel/kernel'):
+                sn = {k: self.state[s.scope + '#' + k] for k in ('dsigma', 'dot', 'sigma', 'scale')}
+            segments.append((off, size, sn))
+        self.opt = ops.AdamArena(self.params, self.grads, self.adam_m, self.adam_v, segments)
         self.init_variables(rng)
+
+    def effective_grad(self, name):
+        """the gradient of variable `name` as the optimiser uses it: for a spectrally normalised kernel the fix-up applied to
+        the raw gradient the arena holds (native layout, a new tensor)"""
+        g = self.arena.view(name, self.grads)
+        s = self._spec_of(name)
+        if not (s.sn and name.endswith('/kernel/kernel') and self.opt.fold_fixup):
+            return g.clone()
+        sc, sigma = self.state[s.scope + '#scale'], self.state[s.scope + '#sigma']
+        return sc * g - (sc / sigma) * self.state[s.scope + '#dot'] * self.state[s.scope + '#dsigma'].view(g.shape)
+
+    def effective_grads_flat(self):
+        """the whole gradient arena with every fix-up applied (tests / inspection)"""
+        out = self.grads.clone()
+        for name in self.arena.offsets:
+            if name != self._dot_name:
+                self.arena.view(name, out).copy_(self.effective_grad(name))
+            else:
+                self.arena.view(name, out).zero_()       # the <G, W> scalars are no variable's gradient
+        return out
 
     # ---- names / layouts -------------------------------------------------------------------
     @staticmethod
@@ -225,7 +265,7 @@ class Network:
         return self.arena.view(name, self.grads)
 
     def variable_names(self, trainable_only=False):
-        names = list(self.arena.offsets)
+        names = [n for n in self.arena.offsets if '#' not in n]
         if not trainable_only:
             names += [k for k in self.state if '#' not in k]
         return names
@@ -292,7 +332,7 @@ class Network:
 
     def get_variable(self, name, grad=False):
         if name in self.arena.offsets:
-            t = self.arena.view(name, self.grads if grad else None)
+            t = self.effective_grad(name) if grad else self.arena.view(name)
         else:
             t = self.state[name]
         return self._to_ref(name, t.detach().cpu().numpy())
@@ -482,6 +522,11 @@ class GanEngine:
         self._baked_lr = (self.lr_d, self.lr_g)
         self._in_step = False                                  # True while step() runs (buffers on the zero list ARE zero)
         self._grad_buckets = {id(net): self._make_buckets(net) for net in (self.gen, self.dis)}
+        # a single replica folds the spectral-norm fix-up of its gradients into Adam's read (Network.opt); data-parallel
+        # replicas apply it BEFORE their all-reduce - sigma and dsigma/dW carry each replica's own atomics order in their last
+        # bits, and replicas must stay bit-identical
+        for net in (self.gen, self.dis):
+            net.opt.fold_fixup = not self._dp_active()
         self._static_z = torch.zeros(self.B, self.code_size, device=self.device)
         self._static_real = torch.zeros(_native_shape(self.in_shape_ref, self.B), device=self.device)
 
@@ -502,7 +547,8 @@ class GanEngine:
         target = int(float(os.environ.get('MMDGAN_DP_BUCKET_MB', '8')) * (1 << 20)) // 4
         first = {}                                   # layer index -> (start, end) float offsets of its entries
         for name, (o, size, _) in net.arena.offsets.items():
-            li = next(i for i, sp in enumerate(net.specs) if name.startswith(sp.scope + '/'))
+            # (the <G, W> scalars at the head of the arena are complete with layer 0's gradients: they travel with the last bucket)
+            li = next((i for i, sp in enumerate(net.specs) if name.startswith(sp.scope + '/')), 0)
             lo, hi = first.get(li, (o, o))
             first[li] = (min(lo, o), max(hi, o + (size + 3) // 4 * 4))
         ranges = [first[li] for li in range(len(net.specs))]
@@ -737,17 +783,19 @@ class GanEngine:
 
             def param_grads(s=s, x_in=x_in, w=w, gw=gw, scale=scale, dz_main=dz_main):
                 gb = net.g(s.scope + '/bias/bias') if s.has_bias else None
+                # a spectrally normalised kernel: the arena keeps the RAW gradient plus <G, W>; the fix-up is
+                # applied where the gradient is read (Network.opt / effective_grad) - no pass over the kernel for it
+                dot = net.state[s.scope + '#dot'] if s.sn else None
                 if s.op == 'd':
                     if gb is not None:
                         ops.colsum(dz_main.reshape(-1, dz_main.shape[-1]), out=gb)
                     ops.gemm(x_in.reshape(2 * B, -1), dz_main.reshape(2 * B, -1), trans_a=True, out=gw, out_zeroed=True)
-                else:                                                        # bias gradient rides on the wgrad launch
-                    ops.conv2d_wgrad(x_in, dz_main, s.R, s.stride, out=gw, dbias=gb)
-                if s.sn:                                                     # SURVEY A.2 fix-up
-                    dot = net.state[s.scope + '#dot']
-                    ops.dot(gw.view(-1), w.view(-1), out=dot)
-                    ops.sn_wgrad_fixup(gw.view(-1), net.state[s.scope + '#dsigma'].view(-1), dot,
-                                       net.state[s.scope + '#sigma'], scale)
+                    if s.sn:
+                        ops.dot(gw.view(-1), w.view(-1), out=dot)
+                else:                                                        # bias gradient (and <G, W>) ride on the wgrad launch
+                    ops.conv2d_wgrad(x_in, dz_main, s.R, s.stride, out=gw, dbias=gb, w=w if s.sn else None, dot=dot)
+                if s.sn and not net.opt.fold_fixup:                          # data-parallel replicas fix up before the exchange
+                    ops.sn_wgrad_fixup(gw.view(-1), net.state[s.scope + '#dsigma'].view(-1), dot, net.state[s.scope + '#sigma'], scale)
             self._on_wg_stream(param_grads, s)
             if li > 0:
                 self._exchange(net, li)
@@ -823,19 +871,19 @@ class GanEngine:
 
             def param_grads(s=s, x_in=x_in, gw=gw, dz=dz, w=w, scale=scale):
                 gb = net.g(s.scope + '/bias/bias') if s.has_bias else None
+                dot = net.state[s.scope + '#dot'] if s.sn else None          # raw gradient + <G, W>, as in D
                 if gb is not None and s.op != 'c':
                     ops.colsum(dz.view(-1, dz.shape[-1]), out=gb)
                 if s.op == 'd':
                     ops.gemm(x_in, dz, trans_a=True, out=gw, out_zeroed=True)   # the gradient arena was zeroed
+                    if s.sn:
+                        ops.dot(gw.view(-1), w.view(-1), out=dot)
                 elif s.op == 'c':
-                    ops.conv2d_wgrad(x_in, dz, s.R, s.stride, out=gw, dbias=gb)
+                    ops.conv2d_wgrad(x_in, dz, s.R, s.stride, out=gw, dbias=gb, w=w if s.sn else None, dot=dot)
                 else:                                                        # tc: W[R,R,Cout,Cin]; y = dgrad(v, W)
-                    ops.conv2d_wgrad(dz, x_in, s.R, s.stride, out=gw)
-                if s.sn:                                                     # SURVEY A.2 fix-up, as in D
-                    dot = net.state[s.scope + '#dot']
-                    ops.dot(gw.view(-1), w.view(-1), out=dot)
-                    ops.sn_wgrad_fixup(gw.view(-1), net.state[s.scope + '#dsigma'].view(-1), dot,
-                                       net.state[s.scope + '#sigma'], scale)
+                    ops.conv2d_wgrad(dz, x_in, s.R, s.stride, out=gw, w=w if s.sn else None, dot=dot)
+                if s.sn and not net.opt.fold_fixup:
+                    ops.sn_wgrad_fixup(gw.view(-1), net.state[s.scope + '#dsigma'].view(-1), dot, net.state[s.scope + '#sigma'], scale)
             if li < self._gen_tail_on_main and li > 0:
                 # the tail of G's backward pass: the input-gradient chain of the main stream ends at layer 1 while the
                 # weight-gradient stream still holds the gradients of the layers above - the last layers' parameter gradients

@@ -211,13 +211,20 @@ def wino_transform(w, dgrad, out=None):
     return u
 
 
-def conv2d_wgrad(x, dy, R, stride, out=None, dbias=None):
-    """x [N,H,W,C], dy [N,P,Q,K] -> dw [R,R,C,K]; dbias [K] (optional) receives the column sums of dy"""
+def conv2d_wgrad(x, dy, R, stride, out=None, dbias=None, w=None, dot=None):
+    """x [N,H,W,C], dy [N,P,Q,K] -> dw [R,R,C,K]; dbias [K] (optional) receives the column sums of dy.
+    w, dot (both or neither): the spectrally normalised kernel and a [1] tensor that receives <dw, w> - the scalar of the
+    spectral-norm fix-up, which stays OUT of dw (mmdgan_conv2d_wgrad_sn; applied by AdamArena / Network.get_variable)"""
     lib = require_device()
     N, H, W, C = x.shape
     K = dy.shape[3]
     dw = out if out is not None else torch.empty((R, R, C, K), device=x.device, dtype=torch.float32)
     g = geom(N, H, W, C, K, R, stride)
+    if w is not None:
+        assert dot is not None and tuple(w.shape) == tuple(dw.shape)
+        check(lib.mmdgan_conv2d_wgrad_sn(ctypes.byref(g), _p(x), _p(dy), _p(dw), _p(dbias), _p(w), _p(dot), _stream()),
+              'conv2d_wgrad_sn')
+        return dw
     if dbias is None:
         check(lib.mmdgan_conv2d_wgrad(ctypes.byref(g), _p(x), _p(dy), _p(dw), _stream()), 'conv2d_wgrad')
     else:
@@ -488,6 +495,47 @@ class AdamGroup:
                                     float(beta1), float(beta2), float(eps), int(step or 0),
                                     self.step_counter.data_ptr() if step is None else None, self.lr_t.data_ptr(),
                                     float(grad_scale), _stream()), 'adam_multi')
+
+
+class AdamSegment(ctypes.Structure):
+    _fields_ = [('off', ctypes.c_long), ('n', ctypes.c_long), ('dsigma', ctypes.c_void_p), ('dot', ctypes.c_void_p),
+                ('sigma', ctypes.c_void_p), ('scale', ctypes.c_void_p)]
+
+
+class AdamArena:
+    """mmdgan_adam_segments: TF-Adam over ONE flat arena (params / grads / m / v share element offsets) cut into segments.
+    segments: [(off, n, sn)] with sn = None or dict(dsigma=, dot=, sigma=, scale=) of device tensors - the spectral-norm
+    fix-up of that segment's gradient is applied as the gradient is read (the arena keeps the raw gradient)."""
+
+    def __init__(self, params, grads, m, v, segments):
+        dev = params.device
+        self.keep = (params, grads, m, v, segments)
+        self.params, self.grads, self.m, self.v = params, grads, m, v
+        segs = (AdamSegment * len(segments))()
+        blocks = []
+        for i, (off, n, sn) in enumerate(segments):
+            segs[i].off, segs[i].n = int(off), int(n)
+            if sn is not None:
+                assert sn['dsigma'].numel() == n and sn['dsigma'].data_ptr() % 16 == 0
+                segs[i].dsigma, segs[i].dot = sn['dsigma'].data_ptr(), sn['dot'].data_ptr()
+                segs[i].sigma, segs[i].scale = sn['sigma'].data_ptr(), sn['scale'].data_ptr()
+            blocks += [(i, b) for b in range((int(n) + 1023) // 1024)]
+        raw = bytes(segs)
+        self.segs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self.blocks = torch.tensor(blocks, dtype=torch.int32, device=dev).contiguous()
+        self.n_segs, self.n_blocks = len(segments), len(blocks)
+        self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)     # device-side t (graph-capturable)
+        self.lr_t = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    fold_fixup = True        # False: the caller applied sn_wgrad_fixup itself (data-parallel replicas, before their all-reduce)
+
+    def step(self, lr, step=None, beta1=0.5, beta2=0.999, eps=1e-8, grad_scale=1.0):
+        lib = require_device()
+        check(lib.mmdgan_adam_segments(_p(self.params), _p(self.grads), _p(self.m), _p(self.v), self.segs.data_ptr(),
+                                       self.n_segs, self.blocks.data_ptr(), self.n_blocks, float(lr), float(beta1),
+                                       float(beta2), float(eps), int(step or 0),
+                                       self.step_counter.data_ptr() if step is None else None, self.lr_t.data_ptr(),
+                                       float(grad_scale), int(self.fold_fixup), _stream()), 'adam_segments')
 
 
 def nchw_to_nhwc(x):

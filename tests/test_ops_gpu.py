@@ -643,6 +643,67 @@ def test_sn_helpers_and_adam(ops):
     assert rel_err(dp[1].cpu().numpy(), params['b'].numpy()) <= 1e-6
 
 
+def test_segmented_adam_folds_the_spectral_norm_fixup(ops):
+    """mmdgan_adam_segments + mmdgan_conv2d_wgrad_sn: the gradient arena keeps the RAW gradient of a spectrally normalised
+    kernel plus the scalar <G, W>; the optimiser reads  scale * G - (scale / sigma) * <G, W> * dsigma/dW  (SURVEY A.2).
+    (a) the weight-gradient entry returns the plain weight gradient and the dot product, on the slab path (Winograd
+    domain, dot formed by the reduction pass) and on the direct path; (b) three TF-Adam steps over an arena of four
+    segments - an SN kernel, two plain ones of ragged size, one that starts un-aligned - against the oracle's AdamTF fed
+    with the fixed-up gradient, untouched gaps between segments included."""
+    rs = np.random.RandomState(21)
+    ops.set_workspace()
+    try:
+        for (N, H, C, K, R_, s) in ((16, 16, 64, 128, 3, 1), (16, 16, 64, 128, 4, 2), (4, 8, 24, 40, 3, 1)):
+            P = H // s
+            x = dev(rs.randn(N, H, H, C).astype(np.float32))
+            dy = dev(rs.randn(N, P, P, K).astype(np.float32))
+            w = dev(rs.randn(R_, R_, C, K).astype(np.float32))
+            plain = ops.conv2d_wgrad(x, dy, R_, s)
+            dot = torch.full((1,), float('nan'), device='cuda')
+            db = torch.empty(K, device='cuda')
+            got = ops.conv2d_wgrad(x, dy, R_, s, dbias=db, w=w, dot=dot)
+            assert rel_err(got.cpu().numpy(), plain.cpu().numpy()) <= 1e-6
+            want = float((plain.double() * w.double()).sum())
+            assert abs(dot.item() - want) <= 1e-5 * float((plain.double() * w.double()).abs().sum()), (N, H, C, K, R_)
+            assert rel_err(db.cpu().numpy(), dy.double().sum((0, 1, 2)).cpu().numpy()) <= 1e-5
+    finally:
+        ops.require_device().mmdgan_set_workspace(None, 0)
+    sizes = [(0, 4096 + 36), (4132, 77), (4212, 3), (4217, 1030)]          # (offset, n): gaps at 4209..4211 and 4215..4216
+    total = 4217 + 1030 + 5
+    p0 = rs.randn(total).astype(np.float32)
+    p, g, m, v = dev(p0), torch.zeros(total, device='cuda'), torch.zeros(total, device='cuda'), torch.zeros(total, device='cuda')
+    ds = dev(rs.randn(sizes[0][1]).astype(np.float32))
+    sigma, scale, dot = dev([2.5]), dev([0.6]), torch.zeros(1, device='cuda')
+    segs = [(sizes[0][0], sizes[0][1], dict(dsigma=ds, dot=dot, sigma=sigma, scale=scale))] + [(o, n, None) for o, n in sizes[1:]]
+    opt_dev = ops.AdamArena(p, g, m, v, segs)
+    names = ['s%d' % i for i in range(4)]
+    params = {nm: torch.tensor(p0[o:o + n]) for nm, (o, n) in zip(names, sizes)}
+    opt = R.AdamTF(names, params, 5e-4)
+    for step in range(3):
+        gnp = (rs.randn(total) * 1e-2).astype(np.float32)
+        g.copy_(torch.tensor(gnp))
+        d = float(rs.randn())
+        dot.fill_(d)
+        opt_dev.step(5e-4, grad_scale=0.5)
+        eff = {nm: 0.5 * torch.tensor(gnp[o:o + n]) for nm, (o, n) in zip(names, sizes)}
+        eff['s0'] = 0.5 * (0.6 * torch.tensor(gnp[:sizes[0][1]]) - (0.6 / 2.5) * d * ds.cpu())
+        opt.apply(params, eff)
+    got = p.cpu().numpy()
+    for nm, (o, n) in zip(names, sizes):
+        assert rel_err(got[o:o + n], params[nm].numpy()) <= 2e-6, nm
+    for lo, hi in ((4209, 4212), (4215, 4217), (total - 5, total)):
+        assert np.array_equal(got[lo:hi], p0[lo:hi])
+    assert int(opt_dev.step_counter.item()) == 3
+    # fold_fixup = False (data-parallel replicas fix up before their all-reduce): every segment is read plainly
+    p2 = dev(p0)
+    plain = ops.AdamArena(p2, g, torch.zeros_like(m), torch.zeros_like(v), segs)
+    plain.fold_fixup = False
+    plain.step(5e-4, grad_scale=1.0)
+    ref = {nm: torch.tensor(p0[o:o + n]) for nm, (o, n) in zip(names, sizes)}
+    R.AdamTF(names, ref, 5e-4).apply(ref, {nm: g.cpu()[o:o + n] for nm, (o, n) in zip(names, sizes)})
+    assert rel_err(p2.cpu().numpy()[:sizes[0][1]], ref['s0'].numpy()) <= 2e-6
+
+
 # ---------------------------------------------------------------------------------------------
 # elementwise pieces of the residual blocks (SURVEY 8(f) row 2)
 # ---------------------------------------------------------------------------------------------

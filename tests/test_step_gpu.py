@@ -597,7 +597,7 @@ if rank == 0:
     worst_u = 0.0
     for net, lr_n in ((eng.dis, lr[0]), (eng.gen, lr[1])):
         p1, m1, v1 = (t.double() for t in before[id(net)])
-        g = net.grads.double() / 2.0
+        g = net.effective_grads_flat().double() / 2.0          # (spectral-norm fix-ups applied to the all-reduced raw sums)
         m2, v2 = 0.5 * m1 + 0.5 * g, 0.999 * v1 + 0.001 * g * g
         lr_t = lr_n * np.sqrt(1 - 0.999 ** 2) / (1 - 0.5 ** 2)
         upd = lr_t * m2 / (v2.sqrt() + 1e-8)
