@@ -9,7 +9,7 @@ print('# mmdgan_mmd_loss, d = 16, fp32; forward+backward in one launch ("fwd" = 
 print('# algorithmic bytes: read 2*B*d*4, write 8 scalars (+ 4*B*d*4 gradients); pairs = 4*B^2 distance/kernel evaluations')
 print('%6s %5s %10s %12s %14s %12s' % ('B', 'loss', 'us', 'alg. GB/s', '% of 8 TB/s', 'Gpair/s'))
 for loss in ('rep', 'rmb', 'mmd_g'):
-    for B in (64, 256, 1024, 4096, 16384):
+    for B in (64, 128, 256, 1024, 4096, 16384):
         g = torch.Generator(device='cuda').manual_seed(B)
         a = torch.randn(B, d, device='cuda', generator=g) * 0.25
         b = torch.randn(B, d, device='cuda', generator=g) * 0.3 + 0.1
