@@ -19,7 +19,7 @@ import os
 import subprocess
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(ROOT, 'gpurun_out', tag), os.path.join(ROOT, 'profiles')
 os.makedirs(dst, exist_ok=True)
@@ -55,7 +55,7 @@ def trial_steps(path, steps, warmup):
     b = bench_line(path)
     n = steps + warmup + 3
     if b and b['config'].get('launch_mode_trial_ms'):
-        n += 3 * 30
+        n += len(b['config']['launch_mode_trial_ms']) * 30
     return n
 
 
@@ -228,7 +228,8 @@ if f:
     json.dump(out, open(os.path.join(dst, tag + '_whole_step_mfma_busy.json'), 'w'), indent=1)
     print('whole-step MFMA busy', out['mfma_busy_frac_whole_step'], out['serialised']['mfma_busy_frac'], steps)
 
-for name in ('conv_layers.txt', 'conv_layers_direct.txt', 'launch_modes.txt', 'bench.json', 'bench_stl.json', 'bench_celeba.json',
+for name in ('conv_layers.txt', 'conv_layers_direct.txt', 'winograd_kernels.txt', 'winograd_kernels_direct.txt', 'step_clock.txt',
+             'pairwise_kernel_sweep.txt', 'launch_modes.txt', 'bench.json', 'bench_stl.json', 'bench_celeba.json',
              'bench_lsun_resnet.json', 'bench_dp_one_rank.json', 'bench_default_profiled.json'):
     p = os.path.join(src, name)
     if os.path.exists(p):
