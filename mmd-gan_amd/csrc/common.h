@@ -19,8 +19,9 @@ constexpr float kEpsi = 1e-10f;       // misc_fun.py:29 FLAGS.EPSI
 
 void set_error(const char *fmt, ...);
 void *workspace(size_t need);     // caller-registered scratch of the current handle (mmdgan_set_workspace) or nullptr: availability only
-// the same buffer for a launch on `st` that is about to USE it: ordered behind the previous user's stream if that was another
-// one.  Batch-1 launches (the power iteration's, issued on concurrent streams) never take a workspace path at all.
+// scratch for a launch on `st` that is about to USE it: a half of the buffer (the whole of it if `need` does not fit a half),
+// ordered behind that part's previous user if that was another stream (core.hip).  Batch-1 launches (the power iteration's,
+// issued on concurrent streams) never take a workspace path at all.
 void *workspace_acquire(size_t need, hipStream_t st);
 bool outputs_prezeroed();         // mmdgan_set_outputs_prezeroed of the current handle: skip internal zeroing memsets
 

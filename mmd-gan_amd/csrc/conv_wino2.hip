@@ -48,7 +48,9 @@ struct Params {
     int OH, OW, Ko;         // output image, channels
     int otile, ostep;       // output row = ty * otile + a * ostep + o0r[phase]
     int o0r[4], o0c[4];
-    int ntb, nkb, nph;      // work items = tile blocks x column blocks x phases
+    int ntb, nkb, nph;      // work items = tile blocks x column blocks x phases x reduction parts
+    int ksplit, spp;        // the reduction of an output tile cut into ksplit parts of spp stages each: part k writes its partial
+    unsigned slab_bytes;    // result (plain sums, no epilogue) into slab k of `out` (= the workspace then), slab_bytes apart
 };
 }  // namespace wino2
 
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
     // ---- this workgroup's run of items: XCD x (speed assumption: workgroup b runs on XCD b % 8) gets a contiguous eighth of
     // the items, ordered (tile block, phase, column block) so that the re-reads of a patch by the other phases / column
     // blocks hit that XCD's L2, and deals it in contiguous runs to its workgroups
-    const int nitems = P.ntb * P.nkb * P.nph, nwg = gridDim.x;
+    const int nitems = P.ntb * P.nkb * P.nph * P.ksplit, nwg = gridDim.x;
     int first, count;
     {
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -165,8 +167,8 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
     if (count <= 0) return;
     const unsigned T = (unsigned)P.N * P.TH * P.TW;
     const int spc = P.Cr / BC;                           // stages per segment
-    const int nstages = P.nseg * spc;                    // >= 2 (the launcher checks): the pipeline reaches one item ahead at most
-    const int per_tb = P.nkb * P.nph;
+    const int nstages = P.spp;                           // stages per ITEM; >= 2 (the launcher checks): the pipeline reaches
+    const int per_tb = P.nkb * P.nph * P.ksplit;         // one item ahead at most
     const int pt = tid >> 3, cq = tid & 7;               // producer: thread = (tile pt, channel quad cq)
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (long)P.N * P.IH * P.IW * P.Cr * 4);
     const __amdgpu_buffer_rsrc_t ru = make_rsrc(U, (long)4 * 9 * P.Cr * P.Ko * 4);
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
     // output and activation-derivative operands go through buffer resources with 32-bit byte offsets (every tensor is
     // < 2 GiB): a tile beyond the ragged end carries offset kOOB - its loads return 0, its stores are dropped, no branch
     const unsigned arow = (unsigned)(P.ostep * P.OW * P.Ko * 4), bcol = (unsigned)(P.ostep * P.Ko * 4);
-    const __amdgpu_buffer_rsrc_t ro = make_rsrc(out, (long)P.N * P.OH * P.OW * P.Ko * 4);
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(out, P.ksplit > 1 ? (long)P.ksplit * P.slab_bytes : (long)P.N * P.OH * P.OW * P.Ko * 4);
     const bool wraps = ep.wrap_from < 0x20000000L;       // the operand tensor holds fewer images than the output (ConvEpilogue)
     const unsigned wrap_from = wraps ? (unsigned)(ep.wrap_from * 4) : 0xffffffffu, wrap_sub = (unsigned)(ep.wrap_sub * 4);
     const __amdgpu_buffer_rsrc_t rd = make_rsrc(ep.dact ? ep.dact : x, wraps ? ep.wrap_from * 4 : (long)P.N * P.OH * P.OW * P.Ko * 4);
@@ -195,7 +197,11 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
     const unsigned xrow = (unsigned)(P.pstep * P.IW * P.Cr * 4), xcol = (unsigned)(P.pstep * P.Cr * 4);
     auto enter_item = [&]() {                            // the load cursor has reached item l_it (< count)
         const int item = first + l_it;
-        const int tblk = item / per_tb, rem = item - tblk * per_tb;
+        const int tblk = item / per_tb, rem0 = item - tblk * per_tb;
+        const int rem = rem0 / P.ksplit, chunk = rem0 - rem * P.ksplit;
+        const int s0 = chunk * P.spp;                    // the item's first stage of the tile's reduction
+        l_seg = s0 / spc;
+        l_cs = s0 - l_seg * spc;
         l_phase = rem / P.nkb;
         const unsigned id = (unsigned)tblk * 32u + pt;
         tile_ok = id < T;
@@ -206,7 +212,8 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
         ty = (int)(q1 - (unsigned)tn * P.TH);
         if (cq == 0)             // byte offset of this tile's output pixel (a=0, b=0), channel 0 (kOOB: no such tile)
             obase[(l_it & 1) * 32 + pt] =
-                tile_ok ? (unsigned)((((long)tn * P.OH + ty * P.otile + P.o0r[l_phase]) * P.OW + tx * P.otile + P.o0c[l_phase]) * P.Ko * 4) : kOOB;
+                tile_ok ? (unsigned)((((long)tn * P.OH + ty * P.otile + P.o0r[l_phase]) * P.OW + tx * P.otile + P.o0c[l_phase]) * P.Ko * 4) +
+                              (unsigned)chunk * P.slab_bytes : kOOB;
     };
     auto set_segment = [&]() {                           // the 9 patch pixels of segment l_seg: (possibly wrapped) offset of pixel
         const int gs = l_phase * P.nseg + l_seg;         // (0,0) + which of them lie inside the image (tensors are < 2 GiB)
@@ -224,21 +231,22 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
             }
         }
     };
+    int l_left = P.spp;                                  // stages the load cursor's item still has
     auto advance_load = [&]() {
-        if (++l_cs == spc) {
+        if (--l_left == 0) {
+            l_left = P.spp;
+            if (++l_it < count) enter_item();
+            else tile_ok = false;                        // past the last item: every patch pixel "outside", the loads fetch nothing
+        } else if (++l_cs == spc) {
             l_cs = 0;
-            if (++l_seg == P.nseg) {
-                l_seg = 0;
-                if (++l_it < count) enter_item();
-                else tile_ok = false;                    // past the last item: every patch pixel "outside", the loads fetch nothing
-            }
+            ++l_seg;
         }
     };
     float4 rin[3][3];
     // global -> registers: patch row U_ of the load cursor's stage (padded taps: an offset beyond the buffer reads zeros)
 #define W2_XLOAD_ROW(U_)                                                                                 \
     {                                                                                                    \
-        if ((U_) == 0 && l_cs == 0) set_segment();                                                       \
+        if ((U_) == 0 && (l_cs == 0 || l_left == P.spp)) set_segment();   /* a new segment, or a new item's first stage */ \
         const unsigned sx = xbase + (unsigned)(U_) * xrow + (unsigned)(l_cs * BC * 4);                   \
         _Pragma("unroll") for (int v = 0; v < 3; ++v)                                                    \
             rin[U_][v] = bufld4(rx, (xmask >> (3 * (U_) + v)) & 1u ? sx + (unsigned)v * xcol : kOOB);    \
@@ -259,22 +267,26 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
         }                                                                                                \
     }
     // ---- the B cursor (stage L+1): scalar byte offset of its (item, segment, channel block) slice of U
-    int b_it = 0, b_seg = 0, b_cs = 0;
+    int b_it = 0, b_seg = 0, b_cs = 0, b_left = P.spp;
     unsigned b_off;
     auto b_item = [&]() {
         const int item = first + b_it;
-        const int tblk = item / per_tb, rem = item - tblk * per_tb;
+        const int tblk = item / per_tb, rem0 = item - tblk * per_tb;
+        const int rem = rem0 / P.ksplit, chunk = rem0 - rem * P.ksplit;
         const int phase = rem / P.nkb, n0 = (rem - phase * P.nkb) * 64;
+        const int s0 = chunk * P.spp;
+        b_seg = s0 / spc;
+        b_cs = s0 - b_seg * spc;
         b_off = (unsigned)(phase * P.nseg) * useg + (unsigned)(n0 * 16);
     };
     auto advance_b = [&]() {                             // (only called while a next stage exists)
-        if (++b_cs == spc) {
+        if (--b_left == 0) {
+            b_left = P.spp;
+            ++b_it;
+            b_item();
+        } else if (++b_cs == spc) {
             b_cs = 0;
-            if (++b_seg == P.nseg) {
-                b_seg = 0;
-                ++b_it;
-                b_item();
-            }
+            ++b_seg;
         }
     };
     auto stage_boff = [&]() { return b_off + (unsigned)b_seg * useg + (unsigned)b_cs * ustage; };
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
 
     for (int it = 0; it < count; ++it) {
         const int item = first + it;
-        const int c_tblk = item / per_tb, c_rem = item - c_tblk * per_tb;
+        const int c_tblk = item / per_tb, c_rem = (item - c_tblk * per_tb) / P.ksplit;
         const int c_phase = c_rem / P.nkb;
         const int n0 = (c_rem - c_phase * P.nkb) * 64;
         const unsigned *ob_it = obase + (it & 1) * 32;
@@ -446,7 +458,13 @@ static int wino2_mode() {
 }
 
 // d describes the CONV (4x4, stride 2, pad 1): x [N,H,W,C] -> y [N,P,Q,K]
-static bool wino2_shape_ok(const ConvDims &d, bool dgrad) {
+static int wino2_ksplit(long base_items, int nstages);
+static bool wino2_split_enabled() {            // MMDGAN_WINO2_KSPLIT=0: no reduction split (A/B)
+    static int en = -1;
+    if (en < 0) { const char *e = getenv("MMDGAN_WINO2_KSPLIT"); en = e ? atoi(e) : 1; }
+    return en != 0;
+}
+static bool wino2_shape_ok(const ConvDims &d, bool dgrad, bool split_ok = false) {
     const int mode = wino2_mode();
     if (mode == 0 || d.R != 4 || d.stride != 2 || d.pad != 1 || d.H % 4 || d.W % 4) return false;
     const int cr = dgrad ? d.K : d.C, ko = dgrad ? d.C : d.K;
@@ -455,9 +473,11 @@ static bool wino2_shape_ok(const ConvDims &d, bool dgrad) {
     if (mode >= 2) return true;
     const long tiles = (long)d.N * (d.P / 2) * (d.Q / 2);          // per phase
     const long wgs = ((tiles + 31) / 32) * (ko / 64) * (dgrad ? 4 : 1);
-    return wgs >= 256;        // one round of two workgroups per CU at least (measured against the direct kernels, header above)
+    // one round of two workgroups per CU at least (measured against the direct kernels, header above); with weights the
+    // caller has transformed, the reduction split multiplies the grid
+    return wgs * (split_ok && wino2_split_enabled() && d.N > 1 ? wino2_ksplit(wgs, (dgrad ? 1 : 4) * (cr / wino2::BC)) : 1) >= 256;
 }
-bool wino2_eligible(const ConvDims &d, bool dgrad) { return wino2_shape_ok(d, dgrad); }
+bool wino2_eligible(const ConvDims &d, bool dgrad) { return wino2_shape_ok(d, dgrad, true); }
 static size_t wino2_bytes(const ConvDims &d) { return sizeof(float) * 36 * (size_t)d.C * d.K; }
 bool wino2_fwd_ok(const ConvDims &d) { return d.N > 1 && wino2_shape_ok(d, false) && workspace(wino2_bytes(d)) != nullptr; }
 bool wino2_dgrad_ok(const ConvDims &d) { return d.N > 1 && wino2_shape_ok(d, true) && workspace(wino2_bytes(d)) != nullptr; }
@@ -470,8 +490,53 @@ int wino2_transform(const ConvDims &d, const float *w, bool dgrad, float *U, hip
     return check_launch("wino2_transform");
 }
 
+// the second half of a reduction-split launch: out = epilogue(sum of the ksplit partial results), float4 per thread
+__global__ __launch_bounds__(256) void wino2_slab_epilogue_kernel(const float4 *__restrict__ part, int ksplit, long n4, int Ko,
+                                                                  ConvEpilogue ep, float4 *__restrict__ out) {
+    const float sc = ep.scale ? ep.scale[0] : 1.f;
+    const long stride = (long)gridDim.x * 256;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += stride) {
+        float4 v = part[e];
+        for (int k = 1; k < ksplit; ++k) {
+            const float4 b = part[(long)k * n4 + e];
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        const int ch = (int)((e * 4) % Ko);
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ep.bias) bv = *reinterpret_cast<const float4 *>(ep.bias + ch);
+        v.x = v.x * sc + bv.x; v.y = v.y * sc + bv.y; v.z = v.z * sc + bv.z; v.w = v.w * sc + bv.w;
+        if (ep.dact) {
+            const float4 yv = *reinterpret_cast<const float4 *>(ep.dact + ep.dact_index(e * 4));
+            v.x *= act_bwd_from_out(yv.x, ep.act); v.y *= act_bwd_from_out(yv.y, ep.act);
+            v.z *= act_bwd_from_out(yv.z, ep.act); v.w *= act_bwd_from_out(yv.w, ep.act);
+        } else {
+            v.x = act_fwd(v.x, ep.act); v.y = act_fwd(v.y, ep.act);
+            v.z = act_fwd(v.z, ep.act); v.w = act_fwd(v.w, ep.act);
+        }
+        out[e] = v;
+    }
+}
+
+// reduction parts a launch with pre-transformed weights is cut into: enough to reach two workgroups per CU, each part
+// keeping >= 4 stages (one stage = 16 channels of one segment) so the extra epilogues stay a fraction of the work.
+// Only grids below 3/4 of the 512 slots: alone every split launch wins (CIFAR batch 64, us, direct kernel / unsplit / split:
+// D l6 forward, 128 items, 82 / 119 / 61; G l2 tc forward 48 / 64 / 39; G l2 tc input-gradient 47 / 119 / 40; G l3 tc
+// input-gradient, 256 items, 45 / 62 / 38; D l6 3B input-gradient, 384 items, 111 / 90 / 86), but inside the step the idle
+// slots of a 3/4-full grid are already used by the weight-gradient stream, and the second pass then costs more than the
+// split gains: ms per CIFAR / STL step with the split applied below 0 / 129 / 257 / 385 / 512 items:
+// 2.061 / 2.057 / 2.034 / 2.071 / 2.084 and 4.027 / 4.050 / 3.969 / 3.932 / 3.939 (STL's 288-item launches sit in between).
+static int wino2_ksplit(long base_items, int nstages) {
+    static long below = -1;
+    if (below < 0) { const char *e = getenv("MMDGAN_WINO2_KSPLIT_BELOW"); below = e ? atol(e) : 384; }
+    if (base_items >= below) return 1;
+    int k = 1;
+    while (k < 8 && base_items * k < 512 && nstages % (2 * k) == 0 && nstages / (2 * k) >= 4) k *= 2;
+    return k;
+}
+
 static int wino2_launch(const ConvDims &d, const ConvEpilogue &ep, const float *in, const float *w, const float *U, float *out,
                         bool dgrad, hipStream_t st) {
+    const bool own_u = U != nullptr;
     if (!U) {
         float *ws = (float *)workspace_acquire(wino2_bytes(d), st);
         if (!ws) { set_error("conv2d (winograd 2x2): no workspace for the transformed weights"); return MMDGAN_E_ARG; }
@@ -493,7 +558,17 @@ static int wino2_launch(const ConvDims &d, const ConvEpilogue &ep, const float *
     }
     const long T = (long)d.N * P.TH * P.TW;
     P.ntb = (int)((T + 31) / 32); P.nkb = P.Ko / 64; P.nph = dgrad ? 4 : 1;
-    const long nitems = (long)P.ntb * P.nkb * P.nph;
+    const int nstages = P.nseg * (P.Cr / wino2::BC);
+    // small grids with weights transformed by the caller (the workspace is free then): split the reduction, partial
+    // results into workspace slabs, one pass sums them and applies the epilogue
+    P.ksplit = own_u && wino2_split_enabled() && d.N > 1 ? wino2_ksplit((long)P.ntb * P.nkb * P.nph, nstages) : 1;
+    const size_t out_bytes = sizeof(float) * (size_t)d.N * P.OH * P.OW * P.Ko;
+    float *slabs = nullptr;
+    if (P.ksplit > 1 && (size_t)P.ksplit * out_bytes < (1ul << 31)) slabs = (float *)workspace_acquire((size_t)P.ksplit * out_bytes, st);
+    if (!slabs) P.ksplit = 1;
+    P.spp = nstages / P.ksplit;
+    P.slab_bytes = (unsigned)out_bytes;
+    const long nitems = (long)P.ntb * P.nkb * P.nph * P.ksplit;
     static int ncu = 0;
     if (!ncu) {
         int dev = 0;
@@ -508,7 +583,17 @@ static int wino2_launch(const ConvDims &d, const ConvEpilogue &ep, const float *
         (void)hipFuncSetAttribute((const void *)wino2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino2::LDS_BYTES);
         cap_raised = true;
     }
-    hipLaunchKernelGGL(wino2_kernel, grid, dim3(256), wino2::LDS_BYTES, st, P, ep, in, U, out);
+    if (P.ksplit > 1) {
+        ConvEpilogue plain{};
+        plain.wrap_from = kNoWrap;
+        hipLaunchKernelGGL(wino2_kernel, grid, dim3(256), wino2::LDS_BYTES, st, P, plain, in, U, slabs);
+        const long n4 = (long)(out_bytes / 16);
+        long blocks = (n4 + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(wino2_slab_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float4 *)slabs, P.ksplit, n4, P.Ko, ep,
+                           (float4 *)out);
+    } else
+        hipLaunchKernelGGL(wino2_kernel, grid, dim3(256), wino2::LDS_BYTES, st, P, ep, in, U, out);
     return check_launch(dgrad ? "conv2d_dgrad(winograd 2x2)" : "conv2d_fwd(winograd 2x2)");
 }
 

@@ -37,8 +37,7 @@ struct mmdgan_handle {
     void *ws = nullptr;
     size_t ws_bytes = 0;
     bool prezeroed = false;
-    bool ws_used = false;                                  // the workspace has had a user since it was registered
-    hipStream_t ws_stream = nullptr;                       // ... the stream of its latest user (workspace_acquire)
+    struct WsSlot { bool used = false; hipStream_t st = nullptr; } ws_slot[2];   // halves of the workspace: their latest users
     std::unique_ptr<mmdgan::Plan> recording;
     std::vector<std::unique_ptr<mmdgan::Plan>> plans;      // plan id = index (destroyed plans leave a null slot)
     std::vector<hipEvent_t> pool;                          // round-robin pool of the un-recorded stream_wait calls
@@ -61,16 +60,26 @@ void *workspace(size_t need) {
     mmdgan_handle &h = cur();
     return (h.ws && need <= h.ws_bytes) ? h.ws : nullptr;
 }
-// The workspace is ONE buffer with one user at a time.  A launch that writes it on another stream than the previous user
-// is ordered behind that stream (event record + wait, recorded into a plan like any dependency), so two chains of an
-// engine that both reach a workspace path serialise there instead of corrupting each other's partial sums.
+// The workspace is used as TWO halves (or whole, by a request that does not fit a half).  A stream keeps the half it used
+// last; another stream takes the other one - the two launch chains of a training step (input-gradients on the main stream,
+// weight gradients beside them) then never touch each other's partial sums and need no ordering.  Whoever must take a half
+// (or the whole buffer) after ANOTHER stream is ordered behind that stream first (event record + wait, recorded into a
+// plan like any dependency), so concurrent chains serialise there instead of corrupting each other.
 void *workspace_acquire(size_t need, hipStream_t st) {
     mmdgan_handle &h = cur();
     if (!h.ws || need > h.ws_bytes) return nullptr;
-    if (h.ws_used && h.ws_stream != st && mmdgan_stream_wait((void *)st, (void *)h.ws_stream) != MMDGAN_OK) return nullptr;
-    h.ws_used = true;
-    h.ws_stream = st;
-    return h.ws;
+    const size_t half = (h.ws_bytes / 2) & ~(size_t)255;
+    auto take = [&](int i) -> bool {                       // slot i goes to `st`, behind its previous user
+        mmdgan_handle::WsSlot &s = h.ws_slot[i];
+        if (s.used && s.st != st && mmdgan_stream_wait((void *)st, (void *)s.st) != MMDGAN_OK) return false;
+        s.used = true;
+        s.st = st;
+        return true;
+    };
+    if (need > half) return (take(0) && take(1)) ? h.ws : nullptr;
+    int i = (h.ws_slot[0].used && h.ws_slot[0].st == st) ? 0 : (h.ws_slot[1].used && h.ws_slot[1].st == st) ? 1
+          : !h.ws_slot[0].used ? 0 : !h.ws_slot[1].used ? 1 : 0;
+    return take(i) ? (char *)h.ws + (size_t)i * half : nullptr;
 }
 bool plan_recording() { return cur().recording != nullptr; }
 void plan_push(std::function<void()> &&node) { cur().recording->nodes.emplace_back(std::move(node)); }
@@ -114,7 +123,7 @@ extern "C" int mmdgan_make_current(mmdgan_handle *h) {
 extern "C" int mmdgan_set_workspace(void *ptr, size_t bytes) {
     cur().ws = ptr;
     cur().ws_bytes = ptr ? bytes : 0;
-    cur().ws_used = false;
+    cur().ws_slot[0] = cur().ws_slot[1] = mmdgan_handle::WsSlot();
     return MMDGAN_OK;
 }
 extern "C" int mmdgan_set_outputs_prezeroed(int on) {

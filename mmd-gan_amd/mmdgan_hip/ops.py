@@ -57,7 +57,7 @@ class Handle:
     `with handle:` makes it the calling thread's current handle and restores the handle that was current before (a
     per-thread stack: constructing or stepping another engine inside the block does not strand the outer one)."""
 
-    def __init__(self, workspace_bytes=64 << 20, device=None):
+    def __init__(self, workspace_bytes=128 << 20, device=None):
         lib = require_device()
         h = ctypes.c_void_p()
         check(lib.mmdgan_create(ctypes.byref(h)), 'create')

@@ -422,6 +422,19 @@ def test_conv2d_winograd_stride2_path(ops, case):
         assert rel_err(to_nchw(y), yt.detach().numpy()) <= RTOL
         dx = ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s)
         assert rel_err(to_nchw(dx), gx.numpy()) <= RTOL
+        # transformed weights + a workspace: a launch with few workgroups cuts its reduction into parts (partial sums in
+        # workspace slabs, a second pass sums them and applies the epilogue) - every case here is below the 384-workgroup line
+        if fwd_ok:
+            ref = R._act(yt.detach() * float(sc) + torch.tensor(b, dtype=torch.float64).reshape(1, -1, 1, 1), 'lrelu').numpy()
+            y = ops.conv2d_fwd(nhwc(x), dev(w), s, bias=dev(b), scale=dev([sc]), act='lrelu', wino=uf)
+            assert rel_err(to_nchw(y), ref) <= RTOL
+        if bwd_ok:
+            y2 = ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s, bias=dev(bc), act='relu', wino=ub)
+            assert rel_err(to_nchw(y2), np.maximum(gx.numpy() + bc.reshape(1, -1, 1, 1), 0)) <= RTOL
+            if N % 3 == 0:
+                dx2 = ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s, scale=dev([0.5]), act='lrelu', dact_of=nhwc(yprev),
+                                       dact_batch=2 * B, wino=ub)
+                assert rel_err(to_nchw(dx2), 0.5 * gx.numpy() * mask) <= RTOL
         if C % 64 == 0 and K % 128 == 0:       # weight gradient: per-split partial slabs in the workspace + one reduction pass
             dw2 = torch.full((ksz, ksz, C, K), float('nan'), device='cuda')      # no zeroing needed, and twice the same bits
             ops.conv2d_wgrad(nhwc(x), nhwc(dy), ksz, s, out=dw2)
