@@ -216,6 +216,15 @@ int mmdgan_conv2d_wgrad_sn(const mmdgan_conv_geom *g, const float *x, const floa
 int mmdgan_wino_eligible(const mmdgan_conv_geom *g, int dgrad);
 size_t mmdgan_wino_weight_bytes(const mmdgan_conv_geom *g);
 int mmdgan_wino_transform(const mmdgan_conv_geom *g, const float *w, int dgrad, float *u, void *stream);
+/* the same transform for MANY kernels in one launch (a training step re-transforms every eligible kernel of a network after
+ * each weight update: one dispatch instead of one per kernel and form).  jobs is a HOST array, read during the call. */
+typedef struct mmdgan_wino_job {
+    const float *w;      /* HWIO kernel [R,R,C,K] */
+    float *u;            /* mmdgan_wino_weight_bytes() of the geometry */
+    int C, K, R, stride; /* R = 3 / stride 1 or R = 4 / stride 2 */
+    int dgrad;           /* 0: forward form, 1: input-gradient form */
+} mmdgan_wino_job;
+int mmdgan_wino_transform_multi(const mmdgan_wino_job *jobs, int n_jobs, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense (tf.matmul, layer_func.py:909-911).  Row-major.  trans flags as in BLAS:

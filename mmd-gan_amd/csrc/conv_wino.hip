@@ -22,6 +22,7 @@
 // kernel by fp32 rounding of a different summation order (measured <= 2e-6 relative on the parity cases).
 #include "conv_internal.h"
 #include "bufload.h"
+#include "wino_weight.h"
 
 namespace mmdgan {
 
@@ -45,64 +46,10 @@ struct Cfg {
 };
 }  // namespace wino
 
-// U[f][cr / 8][cr & 1][ko][(cr & 7) >> 1] = (G g G^T)[f]  with g = w[.][.][c][k] (cr = c, ko = k)          FLIP = false
-//                                                      or g = w[2-.][2-.][c][k] read as (cr = k, ko = c)  FLIP = true
-// The innermost four floats are the B operands of the four MFMA k-pairs of one 8-channel stage for one lane (k half = cr & 1,
-// column = ko): the convolution kernel fetches them with ONE 16-byte load per lane, 512 contiguous bytes per half-wave.
-// The reduction-side channel count is a multiple of 8 (what the F(2x2,3x3) kernels accept); ragged 32-blocks are guarded.
 template <bool FLIP>
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float *__restrict__ w, float *__restrict__ U, int C, int K) {
-    __shared__ float tile[8][32][33];
-    const int c0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
-    const int tk = threadIdx.x & 31, tq = threadIdx.x >> 5;
-    const int Cr = FLIP ? K : C, Ko = FLIP ? C : K, cr0 = FLIP ? k0 : c0, ko0 = FLIP ? c0 : k0;
-    for (int half = 0; half < 2; ++half) {              // 8 of the 16 frequencies at a time (LDS)
-        for (int cc = tq; cc < 32; cc += 8) {
-            const int c = c0 + cc, k = k0 + tk;
-            const bool ok = c < C && k < K;
-            float g[3][3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-                    g[r][t] = ok ? w[((size_t)((FLIP ? 2 - r : r) * 3 + (FLIP ? 2 - t : t)) * C + c) * K + k] : 0.f;
-            float gg[4][3], u[4][4];
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                gg[0][t] = g[0][t];
-                gg[1][t] = 0.5f * (g[0][t] + g[1][t] + g[2][t]);
-                gg[2][t] = 0.5f * (g[0][t] - g[1][t] + g[2][t]);
-                gg[3][t] = g[2][t];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                u[i][0] = gg[i][0];
-                u[i][1] = 0.5f * (gg[i][0] + gg[i][1] + gg[i][2]);
-                u[i][2] = 0.5f * (gg[i][0] - gg[i][1] + gg[i][2]);
-                u[i][3] = gg[i][2];
-            }
-#pragma unroll
-            for (int f = 0; f < 8; ++f) tile[f][cc][tk] = half ? u[2 + (f >> 2)][f & 3] : u[f >> 2][f & 3];
-        }
-        __syncthreads();
-        // thread = (output channel of the block tk, channel group of the block tq >> 1, k half tq & 1)
-        const int g8 = tq >> 1, kh = tq & 1;
-        const bool st_ok = cr0 + g8 * 8 < Cr && ko0 + tk < Ko;
-#pragma unroll
-        for (int f = 0; f < 8; ++f) {
-            if (!st_ok) break;
-            float4 v;
-            float *pv = reinterpret_cast<float *>(&v);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int crl = g8 * 8 + 2 * q + kh;
-                pv[q] = FLIP ? tile[f][tk][crl] : tile[f][crl][tk];
-            }
-            const size_t row = (((size_t)(half * 8 + f)) * (Cr >> 3) + (cr0 >> 3) + g8) * 2 + kh;
-            *reinterpret_cast<float4 *>(U + (row * Ko + ko0 + tk) * 4) = v;
-        }
-        __syncthreads();
-    }
+    __shared__ float tile[8][32][33];                    // (layout of U: wino_weight.h)
+    wino_weight_block<FLIP>(tile, blockIdx.x, blockIdx.y, w, U, C, K);
 }
 
 // x [N,H,W,Cr] (*) U [16][Cr][Ko] -> out [N,H,W,Ko], 'SAME' padding, stride 1

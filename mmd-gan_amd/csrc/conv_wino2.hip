@@ -19,6 +19,7 @@
 
 #include "conv_internal.h"
 #include "bufload.h"
+#include "wino_weight.h"
 
 #ifndef W2W_DEFAULT
 #define W2W_DEFAULT 1
@@ -54,52 +55,10 @@ struct Params {
 };
 }  // namespace wino2
 
-// U[seg][f][cr / 8][cr & 1][ko][(cr & 7) >> 1] = (G g G^T)[f], f = 3i + j, g = the 2x2 filter of the segment
-//   FWD  : seg = (a,b);  g[u][v] = w[2u + a][2v + b][c][k];            cr = c, ko = k
-//   DGRAD: seg = (al,be); g[u][v] = w[rho(al,1-u)][rho(be,1-v)][c][k], rho(0,r') = 1 + 2r', rho(1,r') = 2r';  cr = k, ko = c
-// The innermost four floats are the B operands of four consecutive MFMA k-pairs for one lane (k half = cr & 1, column
-// = ko): the convolution kernel fetches them with ONE 16-byte load per lane, 512 contiguous bytes per half-wave.
-// C and K are multiples of 32 (every geometry the F(2x2,2x2) kernels accept).
 template <bool DGRAD>
 __global__ __launch_bounds__(256) void wino2_weight_kernel(const float *__restrict__ w, float *__restrict__ U, int C, int K) {
-    __shared__ float tile[9][32][33];
-    const int c0 = blockIdx.y * 32, k0 = blockIdx.x * 32, seg = blockIdx.z, sa = seg >> 1, sb = seg & 1;
-    const int tk = threadIdx.x & 31, tq = threadIdx.x >> 5;
-    for (int cc = tq; cc < 32; cc += 8) {
-        const int c = c0 + cc, k = k0 + tk;
-        float g[2][2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                const int r = DGRAD ? (sa == 0 ? 1 + 2 * (1 - u) : 2 * (1 - u)) : 2 * u + sa;
-                const int t = DGRAD ? (sb == 0 ? 1 + 2 * (1 - v) : 2 * (1 - v)) : 2 * v + sb;
-                g[u][v] = w[((size_t)(r * 4 + t) * C + c) * K + k];
-            }
-        float gg[3][2], uu[3][3];
-#pragma unroll
-        for (int v = 0; v < 2; ++v) { gg[0][v] = g[0][v]; gg[1][v] = g[0][v] + g[1][v]; gg[2][v] = g[1][v]; }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { uu[i][0] = gg[i][0]; uu[i][1] = gg[i][0] + gg[i][1]; uu[i][2] = gg[i][1]; }
-#pragma unroll
-        for (int f = 0; f < 9; ++f) tile[f][cc][tk] = uu[f / 3][f % 3];
-    }
-    __syncthreads();
-    // thread = (output channel of the block tk, channel group of the block tq >> 1, k half tq & 1)
-    const int Cr = DGRAD ? K : C, Ko = DGRAD ? C : K, cr0 = DGRAD ? k0 : c0, ko0 = DGRAD ? c0 : k0;
-    const int g8 = tq >> 1, kh = tq & 1;
-#pragma unroll
-    for (int f = 0; f < 9; ++f) {
-        float4 v;
-        float *pv = reinterpret_cast<float *>(&v);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int crl = g8 * 8 + 2 * q + kh;
-            pv[q] = DGRAD ? tile[f][tk][crl] : tile[f][crl][tk];
-        }
-        const size_t row = (((size_t)seg * 9 + f) * (Cr >> 3) + (cr0 >> 3) + g8) * 2 + kh;
-        *reinterpret_cast<float4 *>(U + (row * Ko + ko0 + tk) * 4) = v;
-    }
+    __shared__ float tile[9][32][33];                    // (layout of U: wino_weight.h)
+    wino2_weight_block<DGRAD>(tile, blockIdx.x, blockIdx.y, blockIdx.z, w, U, C, K);
 }
 
 // PERSISTENT and CONTINUOUS: the grid is (at most) two workgroups per CU, every workgroup walks a contiguous run of work

@@ -52,6 +52,7 @@ SIGNATURES = {
     'mmdgan_wino_eligible': (_I, [_G, _I]),
     'mmdgan_wino_weight_bytes': (ctypes.c_size_t, [_G]),
     'mmdgan_wino_transform': (_I, [_G, _P, _I, _P, _P]),
+    'mmdgan_wino_transform_multi': (_I, [_P, _I, _P]),
     'mmdgan_gemm': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P]),
     'mmdgan_colsum': (_I, [_P, _L, _I, _P, _P]),
     'mmdgan_dot': (_I, [_P, _P, _L, _P, _P]),

@@ -528,7 +528,9 @@ class GanEngine:
         for net in (self.gen, self.dis):
             net.opt.fold_fixup = not self._dp_active()
         self._static_z = torch.zeros(self.B, self.code_size, device=self.device)
-        self._static_real = torch.zeros(_native_shape(self.in_shape_ref, self.B), device=self.device)
+        # the real half of D's input buffer IS the batch buffer graph / plan replays read: a caller's batch is copied
+        # once, straight to where the first conv reads it (my_sngan.py:278: D sees [real ; fake])
+        self._static_real = self.buf['dis_in'][:self.B]
 
     @property
     def use_graph(self):
@@ -626,6 +628,9 @@ class GanEngine:
                         lead = (16,) if s.R == 3 else (4, 9)     # F(2x2,3x3) / F(2x2,2x2) on 4 parity segments
                         self._wino[s.scope] = [torch.empty(lead + (c, k), device=dev) if fw else None,
                                                torch.empty(lead + (k, c), device=dev) if bw else None, net]
+        self._wino_jobs = [ops.WinoTransforms([(net.p(scope + '/kernel/kernel'), u, dg) for scope, (uf, ub, net) in self._wino.items()
+                                               if net is which for u, dg in ((uf, False), (ub, True)) if u is not None])
+                           for which in (self.gen, self.dis)]
         # The batch-1 convolutions of the power iteration run on two concurrent chains and take the library's own route: a
         # batch-1 launch never goes through the handle's shared workspace (no in-call Winograd transform, no slab / partial-sum
         # weight gradient - csrc: "d.N > 1"), and any other cross-stream workspace user is ordered by workspace_acquire.
@@ -739,7 +744,8 @@ class GanEngine:
                     self._scales[s.scope] = self._sn_step(net, s) if s.sn else None
                     if s.sn:
                         ops.event_record(ev0 + i, self._sn_raw[k])
-        ops.copy(b['dis_in'][:B], real)                                      # my_sngan.py:278: D sees [real ; fake]
+        if real.data_ptr() != b['dis_in'].data_ptr():
+            ops.copy(b['dis_in'][:B], real)                                  # my_sngan.py:278: D sees [real ; fake]
         if any(net is self.gen for _, _, net in self._wino.values()):
             ops.event_wait(_EV_WINO_GEN, main)
         self.generate(z, is_training=True)                                   # writes dis_in[B:]
@@ -1014,19 +1020,11 @@ class GanEngine:
                 with torch.cuda.stream(self._wg_stream):
                     # G's transformed weights first (its forward pass starts right away and waits on this event),
                     # then the memsets, then D's (needed after G's forward / in the backward pass)
-                    for first in (True, False):
-                        for scope, (uf, ub, net) in self._wino.items():
-                            if (net is self.gen) != first:
-                                continue
-                            w = net.p(scope + '/kernel/kernel')
-                            if uf is not None:
-                                ops.wino_transform(w, False, out=uf)
-                            if ub is not None:
-                                ops.wino_transform(w, True, out=ub)
-                        if first:
-                            ops.event_record(_EV_WINO_GEN, self._wg_raw)
-                            for t in arenas:
-                                ops.memset_zero(t)
+                    # (one launch per network: ops.WinoTransforms)
+                    self._wino_jobs[0].run()
+                    ops.event_record(_EV_WINO_GEN, self._wg_raw)
+                    ops.memset_zero_multi(list(arenas))
+                    self._wino_jobs[1].run()
                     ops.event_record(_EV_WINO_DIS, self._wg_raw)
             # the small scratch buffers of the step (power-iteration scratch, batch-norm totals, split-K outputs): one launch
             ops.memset_zero_multi([t for t in self._zero_each_step if not any(t is a for a in arenas)])

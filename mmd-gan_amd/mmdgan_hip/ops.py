@@ -211,6 +211,28 @@ def wino_transform(w, dgrad, out=None):
     return u
 
 
+class WinoJob(ctypes.Structure):
+    _fields_ = [('w', ctypes.c_void_p), ('u', ctypes.c_void_p), ('C', ctypes.c_int), ('K', ctypes.c_int), ('R', ctypes.c_int),
+                ('stride', ctypes.c_int), ('dgrad', ctypes.c_int)]
+
+
+class WinoTransforms:
+    """mmdgan_wino_transform_multi: the transforms of many kernels as ONE launch.  jobs: [(w [R,R,C,K], u, dgrad)] -
+    pointers are taken once (weights and their transformed tensors stay where they are for the life of an engine)"""
+
+    def __init__(self, jobs):
+        self.keep = list(jobs)
+        self.table = (WinoJob * max(1, len(self.keep)))()
+        for j, (w, u, dgrad) in zip(self.table, self.keep):
+            R, _, C, K = w.shape
+            j.w, j.u, j.C, j.K, j.R, j.stride, j.dgrad = w.data_ptr(), u.data_ptr(), C, K, R, 1 if R == 3 else 2, int(bool(dgrad))
+
+    def run(self, stream=None):
+        if self.keep:
+            check(require_device().mmdgan_wino_transform_multi(ctypes.cast(self.table, ctypes.c_void_p), len(self.keep),
+                                                               _stream() if stream is None else stream), 'wino_transform_multi')
+
+
 def conv2d_wgrad(x, dy, R, stride, out=None, dbias=None, w=None, dot=None):
     """x [N,H,W,C], dy [N,P,Q,K] -> dw [R,R,C,K]; dbias [K] (optional) receives the column sums of dy.
     w, dot (both or neither): the spectrally normalised kernel and a [1] tensor that receives <dw, w> - the scalar of the

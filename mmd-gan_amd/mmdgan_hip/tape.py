@@ -356,7 +356,6 @@ class _Net:
         self.arena = _Arena(entries, self.device)
         self.params = self.arena.flat
         self.grads, self.adam_m, self.adam_v = self.arena.like(), self.arena.like(), self.arena.like()
-        self.opt = ops.AdamGroup([self.params], [self.grads], [self.adam_m], [self.adam_v])
         self.state, self.sn = OrderedDict(), {}
         for item in self._creation_order():
             if isinstance(item, _Kernel):
@@ -369,6 +368,7 @@ class _Net:
                 prefix, c = item
                 self.state[prefix + '/BN/moving_mean'] = torch.zeros(c, device=self.device)
                 self.state[prefix + '/BN/moving_variance'] = torch.ones(c, device=self.device)
+        self.build_optimizer()
         self._kernel_by_name = {}
         for k in self.kernels:
             self._kernel_by_name[k.w_name] = k
@@ -377,6 +377,29 @@ class _Net:
             if k.sn:
                 self._kernel_by_name[k.scope + '/SN/in_rand'] = k
         self.init_variables(rng)
+
+    def build_optimizer(self):
+        """TF-Adam over the arena, one segment per variable; a spectrally normalised kernel's segment carries the fix-up of
+        its gradient  dL/dW = scale * G - (scale / sigma) * <G, W> * dsigma/dW  (SURVEY A.2): the arena holds the RAW G and
+        Adam applies the fix-up as it reads it (engine.Network).  Called again by TapeEngine once the <G, W> scalars have
+        moved into its zero-each-step scratch."""
+        t = self.opt.step_counter.clone() if hasattr(self, 'opt') else None
+        sn_of = {k.w_name: self.sn[k.scope] for k in self.kernels if k.sn}
+        segments = [(off, size, ({q: sn_of[name][q] for q in ('dsigma', 'dot', 'sigma', 'scale')} if name in sn_of else None))
+                    for name, (off, size, _) in self.arena.offsets.items()]
+        self.opt = ops.AdamArena(self.params, self.grads, self.adam_m, self.adam_v, segments)
+        if t is not None:
+            self.opt.step_counter.copy_(t)
+
+    def effective_grad(self, name):
+        """the gradient of variable `name` as the optimiser uses it (native layout, a new tensor): the fix-up applied to
+        the raw gradient of a spectrally normalised kernel when Adam folds it in"""
+        g = self.g(name)
+        k = self._kernel_by_name.get(name)
+        if not (k is not None and k.sn and name == k.w_name and self.opt.fold_fixup):
+            return g.clone()
+        st = self.sn[k.scope]
+        return st['scale'] * g - (st['scale'] / st['sigma']) * st['dot'] * st['dsigma'].view(g.shape)
 
     def _creation_order(self):
         """kernels and BN ops in the order the primitives use them (= the reference's variable creation order)"""
@@ -449,7 +472,7 @@ class _Net:
 
     def tensor(self, name, grad=False):
         if name in self.arena.offsets:
-            return self.g(name) if grad else self.p(name)
+            return self.effective_grad(name) if grad else self.p(name)
         return self.state[name]
 
     def set_variable(self, name, value):
@@ -556,13 +579,18 @@ class TapeEngine:
         if self._side:
             from .streams import distinct_queue_streams
             self._wg_stream, self._sn_stream = distinct_queue_streams(2, self.device)
-            self._gen_ready, self._dis_ready, self._gen_sn_ready = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+            self._wg_raw, self._sn_raw = self._wg_stream.cuda_stream, self._sn_stream.cuda_stream
+        self._graphs = {}
+        # D without batch norm: its rows are independent, so loss_dis (2B rows) and loss_gen (the fake half again, B rows) go
+        # back through it TOGETHER as 3B rows (one launch per primitive instead of two passes) - _backward(extra_rows=B)
+        self._d_joint = (not self._d_has_bn and all(p['kind'] in self._ROW_WISE for p in self.dis.prims)
+                         and os.environ.get('MMDGAN_TAPE_JOINT', '1') != '0')
         # Winograd-eligible convolutions get their weights transformed once per step, off the critical path, instead
         # of inside every call (forward, and up to two input-gradient passes) - which also keeps the library's
         # shared workspace out of every launch of the main stream.  kernel scope -> {(dgrad, batch): tensor}
-        self._wino = {}
+        self._wino, self._wino_jobs = {}, {}
         self._folded = {}                              # kernel scope -> (4x4 kernel, its gradient buffer)
-        rows_d = (2 * self.B,) if self._d_has_bn else (2 * self.B, self.B)
+        rows_d = (2 * self.B,) if self._d_has_bn else (2 * self.B, 3 * self.B, self.B)
         for net, batches in ((self.gen, (self.B,)), (self.dis, rows_d)):
             for k in net.kernels:
                 if k.fold is not None:
@@ -602,6 +630,9 @@ class TapeEngine:
                 if p['kind'] == 'bn':
                     c = net.shapes[p['out']][0]
                     sizes.append((p, '_ws_bwd', max(lib.mmdgan_bn_workspace_bytes(c) // 4, 4)))
+                    sizes.append((p, '_ws_fwd', max(lib.mmdgan_bn_workspace_bytes(c) // 4, 4)))
+                    if net is self.dis:                # the loss_gen pass through a D with batch norm: totals of its own
+                        sizes += [(p, '_ws_bwd2', max(lib.mmdgan_bn_workspace_bytes(c) // 4, 4)), (p, '_gg2', c), (p, '_gb2', c)]
             for k in net.kernels:                          # weight gradients of the folded 4x4 kernels (atomics)
                 if k.fold is not None:
                     sizes.append((self._folded[k.scope], 1, self._folded[k.scope][0].numel()))
@@ -613,6 +644,11 @@ class TapeEngine:
             off += (n + 3) // 4 * 4
         for entry in self._folded.values():
             entry[1] = entry[1].view(entry[0].shape)
+        for net in (self.gen, self.dis):               # (the <G, W> scalars have moved: segments again)
+            net.build_optimizer()
+            # a single replica folds the spectral-norm fix-up into Adam's read of the gradient; data-parallel replicas apply
+            # it before their all-reduce (engine.py: replicas must stay bit-identical)
+            net.opt.fold_fixup = not (self.dist_group is not None and (self.world > 1 or self._dp_force))
         self._loss = ops.GanLossLauncher(loss_type, self.rep_weights, self.B, self.score_size, self.device, mix_threshold)
 
     # ---- buffers ----------------------------------------------------------------------------------------------
@@ -750,24 +786,70 @@ class TapeEngine:
         return vals
 
     # ---- backward ---------------------------------------------------------------------------------------------
-    def _backward(self, net, vals, dout, tag, rows=None, param_grads=True, need_input_grad=False):
-        """gradients of one scalar through the net.  rows = (lo, hi): only those batch rows carry gradient (the
-        loss_gen pass through D touches the fake half only); parameter gradients are then not formed."""
+    _ROW_WISE = ('reshape', 'dense', 'conv', 'upconv', 'convdown', 'tconv', 'act', 'down', 'up', 'shuffle', 'add')
+
+    def _graph_of(self, net):
+        """value id -> the primitive that produces it, value id -> number of consumers (the net's output counts as one)"""
+        g = self._graphs.get(id(net))
+        if g is None:
+            producer = {p['out']: p for p in net.prims}
+            uses = {}
+            for p in net.prims:
+                for v in p['ins']:
+                    uses[v] = uses.get(v, 0) + 1
+            uses[net.out_val] = uses.get(net.out_val, 0) + 1
+            g = self._graphs[id(net)] = (producer, uses)
+        return g
+
+    def _sn_grad_tail(self, net, k, gw, w, scale, dot_done):
+        """the spectral-norm fix-up of a kernel's gradient: <G, W> next to the RAW gradient; the fix-up itself
+        is applied by Adam as it reads the gradient (net.opt.fold_fixup) - or here, before a data-parallel exchange"""
+        st = net.sn[k.scope]
+        if not dot_done:
+            ops.dot(gw.view(-1), w.view(-1), out=st['dot'])
+        if not net.opt.fold_fixup:
+            ops.sn_wgrad_fixup(gw.view(-1), st['dsigma'].view(-1), st['dot'], st['sigma'], scale)
+
+    def _on_wg_stream(self, fn):
+        # every weight gradient goes to the side stream (the thin first / last layers' partial sums and the Winograd-domain
+        # slabs use the library workspace; workspace_acquire keeps the two streams' halves apart)
+        if self._side:
+            ops.stream_wait(self._wg_raw, ops._stream())
+            with torch.cuda.stream(self._wg_stream):
+                fn()
+        else:
+            fn()
+
+    def _backward(self, net, vals, dout, tag, rows=None, param_grads=True, need_input_grad=False, extra_rows=0):
+        """gradients of one scalar through the net.
+        rows = (lo, hi): only those batch rows carry gradient (the loss_gen pass through D touches the fake half only);
+        parameter gradients are then not formed.
+        extra_rows = B: `dout` has B rows MORE than the values - [the rows of the values ; the gradient of a second scalar
+        w.r.t. the LAST B rows of the values] (D: [loss_dis rows (2B) ; loss_gen rows of the fake half (B)]), back-
+        propagated together: one launch per primitive for both scalars, parameter gradients from the first rows only,
+        the input gradient (need_input_grad) for the extra rows only.  Row-wise primitives only (_ROW_WISE)."""
         lib = ops.require_device()
-        lo, hi = rows if rows is not None else (0, vals[0].shape[0])
-        n = hi - lo
+        nv = vals[0].shape[0]
+        lo, hi = rows if rows is not None else (0, nv)
+        n = hi - lo + extra_rows
         sl = (lambda t: t[lo:hi]) if rows is not None else (lambda t: t)
+        producer, uses = self._graph_of(net)
         grads = {net.out_val: dout}
 
         def give(v, g):
             # fan-in: a value with two consumers sums their gradients.  The sum goes to a buffer of its own - the
             # first gradient may be shared with another value (both inputs of an add receive the same tensor)
+            if v == 0 and extra_rows and g.shape[0] == n:    # the net's input: the gradient of the extra rows only
+                g = g[nv:]
             if v in grads:
                 acc = self._buf((tag, net.name, 'acc', v), list(g.shape))
                 ops.axpby(grads[v], g, out=acc)
                 grads[v] = acc
             else:
                 grads[v] = g
+
+        def first_rows(t):                                   # the rows parameter gradients are formed from
+            return t[:nv] if extra_rows else t
         for i in range(len(net.prims) - 1, -1, -1):
             p = net.prims[i]
             if p['out'] not in grads:
@@ -778,105 +860,54 @@ class TapeEngine:
                 continue
             key = (tag, net.name, i, 'd')
             a = sl(vals[vin])
-            in_shape = list(a.shape)
-            want_dx = vin != 0 or need_input_grad
+            if kind in ('dense', 'conv', 'upconv', 'convdown', 'tconv'):
+                k = p['k']
+                w = net.p(k.w_name)
+                scale = net.sn[k.scope]['scale'] if k.sn else None
+                if param_grads:
+                    self._on_wg_stream(lambda: self._param_grads(net, p, a, first_rows(dy), w, scale))
+                # the input-gradient.  An activation in front of this primitive that nothing else reads: its derivative rides
+                # on the epilogue (dact_of = the activation's output), the gradient goes straight to the activation's input
+                q = producer.get(vin)
+                fuse = q is not None and q['kind'] == 'act' and uses.get(vin, 0) == 1 and vin not in grads
+                tgt = q['ins'][0] if fuse else vin
+                if tgt == 0 and not need_input_grad:
+                    continue
+                act, dact, dact_batch, dyx = 'linear', None, 0, dy
+                if tgt == 0 and extra_rows:                  # the net's input: the extra rows only
+                    dyx = dy[nv:]
+                    dact = vals[vin][nv - extra_rows:] if fuse else None
+                elif fuse:
+                    dact = sl(vals[vin])
+                    dact_batch = nv if extra_rows else 0     # rows beyond the values take the LAST rows' activations
+                if fuse:
+                    act = q['act']
+                nx = dyx.shape[0]
+                in_shape = [nx] + list(a.shape[1:])
+                dx = self._buf(key, in_shape)
+                if kind == 'dense':
+                    ops.gemm(dyx.reshape(nx, -1), w, trans_b=True, scale=scale, act=act,
+                             dact_of=dact.reshape(dact.shape[0], -1) if dact is not None else None, dact_rows=dact_batch,
+                             out=dx.view(nx, -1))
+                elif kind == 'conv':
+                    ops.conv2d_dgrad(dyx, w, (in_shape[1], in_shape[2]), k.stride, scale=scale, act=act, dact_of=dact,
+                                     dact_batch=dact_batch, out=dx, wino=self._wino_of(k, True, nx))
+                elif kind == 'convdown':
+                    ops.conv2d_dgrad(dyx, self._folded[k.scope][0], (in_shape[1], in_shape[2]), 2, scale=scale, act=act,
+                                     dact_of=dact, dact_batch=dact_batch, out=dx, wino=self._wino_of(k, True, nx))
+                elif kind == 'upconv':
+                    ops.conv2d_fwd(dyx, self._folded[k.scope][0], 2, scale=scale, act=act, dact_of=dact,
+                                   dact_batch=dact_batch, out=dx, wino=self._wino_of(k, False, nx))
+                else:                                        # tconv: d/dx of dgrad(x, W) = conv(dy, W)
+                    ops.conv2d_fwd(dyx, w, k.stride, scale=scale, act=act, dact_of=dact, dact_batch=dact_batch, out=dx,
+                                   wino=self._wino_of(k, False, nx))
+                give(tgt, dx)
+                continue
+            in_shape = [dy.shape[0]] + list(a.shape[1:])
             if kind == 'reshape':
                 give(vin, dy.reshape(in_shape))
-            elif kind in ('dense', 'conv'):
-                k = p['k']
-                w = net.p(k.w_name)
-                scale = net.sn[k.scope]['scale'] if k.sn else None
-                if param_grads:
-                    def param_grads_of(k=k, kind=kind, a=a, dy=dy, w=w, scale=scale):
-                        gw = net.g(k.w_name)
-                        gb = net.g(k.bias_name) if k.bias_name is not None else None
-                        if kind == 'dense':
-                            if gb is not None:
-                                ops.colsum(dy.reshape(n, -1), out=gb)
-                            ops.gemm(a.reshape(n, -1), dy.reshape(n, -1), trans_a=True, out=gw)
-                        else:
-                            ops.conv2d_wgrad(a, dy, k.R, k.stride, out=gw, dbias=gb)
-                        if k.sn:                                         # SURVEY A.2 fix-up
-                            st = net.sn[k.scope]
-                            ops.dot(gw.view(-1), w.view(-1), out=st['dot'])
-                            ops.sn_wgrad_fixup(gw.view(-1), st['dsigma'].view(-1), st['dot'], st['sigma'], scale)
-                    # every weight gradient goes to the side stream: it is the only user of the library's shared workspace
-                    # during the backward pass (slab partial sums of the Winograd-domain kernels, partials of the thin
-                    # first / last layers); the main stream's Winograd launches get weights transformed at step start
-                    if self._side:
-                        self._wg_stream.wait_stream(torch.cuda.current_stream())
-                        with torch.cuda.stream(self._wg_stream):
-                            param_grads_of()
-                    else:
-                        param_grads_of()
-                if want_dx:
-                    dx = self._buf(key, in_shape)
-                    if kind == 'dense':
-                        ops.gemm(dy.reshape(n, -1), w, trans_b=True, scale=scale, out=dx.view(n, -1))
-                    else:
-                        ops.conv2d_dgrad(dy, w, (in_shape[1], in_shape[2]), k.stride, scale=scale, out=dx,
-                                         wino=self._wino_of(k, True, n))
-                    give(vin, dx)
-            elif kind in ('upconv', 'convdown'):
-                k = p['k']
-                w = net.p(k.w_name)
-                w4, g4 = self._folded[k.scope]
-                scale = net.sn[k.scope]['scale'] if k.sn else None
-                if param_grads:
-                    def folded_grads(k=k, kind=kind, a=a, dy=dy, w=w, g4=g4, scale=scale):
-                        gb = net.g(k.bias_name) if k.bias_name is not None else None
-                        if kind == 'convdown':
-                            ops.conv2d_wgrad(a, dy, 4, 2, out=g4, dbias=gb)
-                        else:                                            # transposed form: roles swapped
-                            if gb is not None:
-                                ops.colsum(dy.reshape(-1, dy.shape[-1]), out=gb)
-                            ops.conv2d_wgrad(dy, a, 4, 2, out=g4)
-                        gw = net.g(k.w_name)
-                        ops.compose_scaled_conv_grad(g4, k.fold, out=gw)
-                        if k.sn:
-                            st = net.sn[k.scope]
-                            ops.dot(gw.view(-1), w.view(-1), out=st['dot'])
-                            ops.sn_wgrad_fixup(gw.view(-1), st['dsigma'].view(-1), st['dot'], st['sigma'], scale)
-                    if self._side:
-                        self._wg_stream.wait_stream(torch.cuda.current_stream())
-                        with torch.cuda.stream(self._wg_stream):
-                            folded_grads()
-                    else:
-                        folded_grads()
-                if want_dx:
-                    dx = self._buf(key, in_shape)
-                    if kind == 'convdown':
-                        ops.conv2d_dgrad(dy, w4, (in_shape[1], in_shape[2]), 2, scale=scale, out=dx,
-                                         wino=self._wino_of(k, True, n))
-                    else:
-                        ops.conv2d_fwd(dy, w4, 2, scale=scale, out=dx, wino=self._wino_of(k, False, n))
-                    give(vin, dx)
-            elif kind == 'tconv':
-                k = p['k']
-                w = net.p(k.w_name)
-                scale = net.sn[k.scope]['scale'] if k.sn else None
-                if param_grads:
-                    def tconv_grads(k=k, a=a, dy=dy, w=w, scale=scale):
-                        if k.bias_name is not None:
-                            ops.colsum(dy.reshape(-1, dy.shape[-1]), out=net.g(k.bias_name))
-                        gw = net.g(k.w_name)
-                        ops.conv2d_wgrad(dy, a, k.R, k.stride, out=gw)                 # W[R,R,out,in]: roles swapped
-                        if k.sn:                                                        # SURVEY A.2 fix-up
-                            st = net.sn[k.scope]
-                            ops.dot(gw.view(-1), w.view(-1), out=st['dot'])
-                            ops.sn_wgrad_fixup(gw.view(-1), st['dsigma'].view(-1), st['dot'], st['sigma'], scale)
-                    if self._side:
-                        self._wg_stream.wait_stream(torch.cuda.current_stream())
-                        with torch.cuda.stream(self._wg_stream):
-                            tconv_grads()
-                    else:
-                        tconv_grads()
-                if want_dx:                                              # d/dx of dgrad(x, W) = conv(dy, W)
-                    dx = self._buf(key, in_shape)
-                    ops.conv2d_fwd(dy, w, k.stride, scale=scale, out=dx, wino=self._wino_of(k, False, n))
-                    give(vin, dx)
             elif kind == 'bn':
-                if rows is not None:
+                if rows is not None or extra_rows:
                     raise NotImplementedError('a row-restricted backward pass cannot cross batch norm')
                 c = in_shape[-1]
                 pre = p['prefix']
@@ -886,16 +917,22 @@ class TapeEngine:
                 if param_grads:                                          # zeroed with the step's arenas / scratch
                     ws, gg, gb = p['_ws_bwd'], net.g(pre + '/BN/gamma'), net.g(pre + '/BN/beta')
                 else:                                                    # a second pass through the same op
-                    ws = self._buf(key + ('ws',), [max(lib.mmdgan_bn_workspace_bytes(c) // 4, 4)], zero=True)
-                    gg, gb = self._buf(key + ('gg',), [c], zero=True), self._buf(key + ('gb',), [c], zero=True)
+                    ws, gg, gb = p['_ws_bwd2'], p['_gg2'], p['_gb2']
                 ops.check(lib.mmdgan_bn_bwd(
                     a.data_ptr(), y.data_ptr(), dy.data_ptr(), a.numel() // c, c, net.p(pre + '/BN/gamma').data_ptr(),
                     mean.data_ptr(), invstd.data_ptr(), ops.act_id(p['act']), dx.data_ptr(), gg.data_ptr(), gb.data_ptr(),
                     ws.data_ptr(), ops._stream()), 'bn_bwd')
-                if want_dx:
+                if vin != 0 or need_input_grad:
                     give(vin, dx)
             elif kind == 'act':
-                give(vin, ops.act_bwd(dy, sl(vals[p['out']]), p['act'], out=self._buf(key, in_shape)))
+                y = sl(vals[p['out']])
+                dx = self._buf(key, in_shape)
+                if extra_rows:                                           # the extra rows: the last rows' activations
+                    ops.act_bwd(dy[:nv], y, p['act'], out=dx[:nv])
+                    ops.act_bwd(dy[nv:], y[nv - extra_rows:], p['act'], out=dx[nv:])
+                else:
+                    ops.act_bwd(dy, y, p['act'], out=dx)
+                give(vin, dx)
             elif kind == 'down':                                         # d avg-pool: spread over the window
                 f = p['f']
                 give(vin, ops.resample_up(dy, f, scale=1.0 / (f * f), out=self._buf(key, in_shape)))
@@ -915,6 +952,38 @@ class TapeEngine:
                 raise AssertionError(kind)
         return grads.get(0)
 
+    def _param_grads(self, net, p, a, dy, w, scale):
+        """weight / bias gradient of one dense / conv-like primitive from its input `a` and output gradient `dy`"""
+        kind, k = p['kind'], p['k']
+        n = dy.shape[0]
+        gw = net.g(k.w_name)
+        gb = net.g(k.bias_name) if k.bias_name is not None else None
+        dot = net.sn[k.scope]['dot'] if k.sn else None
+        dot_done = False
+        if kind == 'dense':
+            if gb is not None:
+                ops.colsum(dy.reshape(n, -1), out=gb)
+            ops.gemm(a.reshape(n, -1), dy.reshape(n, -1), trans_a=True, out=gw)
+        elif kind == 'conv':                                             # (<G, W> rides on the weight-gradient launch)
+            ops.conv2d_wgrad(a, dy, k.R, k.stride, out=gw, dbias=gb, w=w if k.sn else None, dot=dot)
+            dot_done = True
+        elif kind == 'tconv':                                            # W[R,R,out,in]: roles swapped
+            if gb is not None:
+                ops.colsum(dy.reshape(-1, dy.shape[-1]), out=gb)
+            ops.conv2d_wgrad(dy, a, k.R, k.stride, out=gw, w=w if k.sn else None, dot=dot)
+            dot_done = True
+        else:                                                            # a 4x4 kernel with the block's scaling op folded in
+            g4 = self._folded[k.scope][1]
+            if kind == 'convdown':
+                ops.conv2d_wgrad(a, dy, 4, 2, out=g4, dbias=gb)
+            else:                                                        # transposed form: roles swapped
+                if gb is not None:
+                    ops.colsum(dy.reshape(-1, dy.shape[-1]), out=gb)
+                ops.conv2d_wgrad(dy, a, 4, 2, out=g4)
+            ops.compose_scaled_conv_grad(g4, k.fold, out=gw)
+        if k.sn:
+            self._sn_grad_tail(net, k, gw, w, scale, dot_done)
+
     def _wino_of(self, k, dgrad, n):
         entry = self._wino.get(k.scope)
         return entry[2].get((dgrad, n)) if entry is not None else None
@@ -926,15 +995,19 @@ class TapeEngine:
 
     def _transform_weights(self, net):
         self._compose_weights(net)
-        for scope, (owner, k, table) in self._wino.items():
-            if owner is not net:
-                continue
-            done = set()
-            src = self._folded[k.scope][0] if k.fold is not None else net.p(k.w_name)
-            for (dgrad, _), u in table.items():
-                if dgrad not in done:
-                    ops.wino_transform(src, dgrad, out=u)
-                    done.add(dgrad)
+        if id(net) not in self._wino_jobs:               # every transform of the net as ONE launch (ops.WinoTransforms)
+            jobs = []
+            for scope, (owner, k, table) in self._wino.items():
+                if owner is not net:
+                    continue
+                done = set()
+                src = self._folded[k.scope][0] if k.fold is not None else net.p(k.w_name)
+                for (dgrad, _), u in table.items():
+                    if dgrad not in done:
+                        jobs.append((src, u, dgrad))
+                        done.add(dgrad)
+            self._wino_jobs[id(net)] = ops.WinoTransforms(jobs)
+        self._wino_jobs[id(net)].run()
 
     # ---- one training step -----------------------------------------------------------------------------------
     def generate(self, z, is_training=False):

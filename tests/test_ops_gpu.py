@@ -515,6 +515,32 @@ def test_conv2d_winograd_path(ops, case):
         ops.conv2d_fwd(nhwc(x), dev(np.zeros((5, 5, C, K), np.float32)), 1, wino=uf)
 
 
+def test_winograd_weight_transforms_of_many_kernels_in_one_launch(ops):
+    """mmdgan_wino_transform_multi: 3x3 and 4x4 kernels, both forms, ragged 3x3 channel blocks, more jobs than one table
+    holds (24) - every transformed tensor bit-equal to its one-kernel launch"""
+    rs = np.random.RandomState(21)
+    shapes = [(3, 128, 128), (4, 64, 128), (3, 40, 192), (4, 32, 64), (3, 64, 64), (4, 128, 256), (3, 8, 32)]
+    jobs, want = [], []
+    for rep in range(2):
+        for R, C, K in shapes:
+            w = dev(rs.randn(R, R, C, K).astype(np.float32))
+            for dgrad in (False, True):
+                if R == 3 and (K if dgrad else C) % 8:
+                    continue
+                want.append(ops.wino_transform(w, dgrad))
+                jobs.append((w, torch.full_like(want[-1], float('nan')), dgrad))
+    assert len(jobs) > 24
+    ops.WinoTransforms(jobs).run()
+    torch.cuda.synchronize()
+    for (w, u, dgrad), ref in zip(jobs, want):
+        assert torch.equal(u, ref), (tuple(w.shape), dgrad)
+    ops.WinoTransforms([]).run()                                   # nothing to do: no launch, no error
+    bad = ops.WinoTransforms([(dev(rs.randn(4, 4, 32, 64).astype(np.float32)), torch.empty(4, 9, 32, 64, device='cuda'), False)])
+    bad.table[0].C = 24                                            # 4x4 kernels: multiples of 32 only
+    with pytest.raises(ValueError, match='multiples of 32'):
+        bad.run()
+
+
 @pytest.mark.parametrize('case', [(4, 4, 4, 512, 256, 4, 2), (3, 8, 8, 256, 128, 4, 2), (2, 16, 16, 128, 64, 4, 2),
                                   (3, 4, 4, 32, 16, 4, 2), (2, 3, 3, 16, 8, 4, 2)],
                          ids=lambda c: str(c))

@@ -541,6 +541,8 @@ real = [torch.as_tensor(rs.uniform(-1, 1, (B, h, w, c)).astype(np.float32)).cuda
 out = {}
 for name, group in (('dp', dist.group.WORLD), ('single', None)):
     eng = GanEngine(arch, 'rep', (5e-4, 2e-4), batch_size=B, seed=3, dist_group=group)
+    for net in (eng.gen, eng.dis):       # the same arithmetic on both sides (see the library-owned exchange test below)
+        net.opt.fold_fixup = False
     if group is not None:
         mdist.broadcast_state(eng, group)
     init = eng.get_variables()
@@ -704,7 +706,9 @@ real = [torch.as_tensor(rs.uniform(-1, 1, (B, 32, 32, 3)).astype(np.float32)).cu
 out = {}
 for name, kw in (('capi', dict(dist_group=dist.group.WORLD, dp_backend='capi', launch_mode='plan')), ('single', {})):
     eng = GanEngine(arch, 'rep', (5e-4, 2e-4), batch_size=B, seed=3, **kw)
-    init = eng.get_variables()
+    for net in (eng.gen, eng.dis):       # the same arithmetic on both sides: replicas fix their gradients up before the
+        net.opt.fold_fixup = False       # exchange, a lone engine folds that into Adam's read (other rounding, and the
+    init = eng.get_variables()           # first steps' Adam-eps regime amplifies rounding) - this test is about the exchange
     for k in range(4):
         eng.step(real[k], z[k])
     torch.cuda.synchronize()

@@ -18,7 +18,7 @@ rows.sort(key=lambda r: r['s'])
 loss = [i for i, r in enumerate(rows) if r['name'].startswith('mmd_kernel') or r['name'].startswith('score_loss')]
 assert len(loss) >= 3, 'need a few steps in the trace'
 # a step ends with G's Adam: the last adam_kernel before the next step's first kernel; steps are serialised on it
-adams = [i for i, r in enumerate(rows) if r['name'].startswith('adam_kernel')]
+adams = [i for i, r in enumerate(rows) if r['name'].startswith(('adam_kernel', 'adam_segments_kernel'))]
 ends = []
 for a, b in zip(loss[:-1], loss[1:]):
     cand = [i for i in adams if a < i < b]
