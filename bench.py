@@ -235,10 +235,9 @@ def main():
     arch, lr = configs.CONFIGS[args.config]()
     B = args.batch or {'celeba': 128, 'lsun_resnet': 32}.get(args.config, 64)
     from mmdgan_hip.tape import TapeEngine, has_residual_blocks
-    tape = has_residual_blocks(arch) or args.engine == 'tape'   # residual blocks: the primitive-op engine, eager issue only
+    tape = has_residual_blocks(arch) or args.engine == 'tape'   # residual blocks: the primitive-op engine (eager or plan)
     if tape:
         GanEngine = TapeEngine                           # noqa: F811
-        args.no_graph = True
     # the engine starts in eager mode (its lazily-created buffers are then allocated on the stream that uses
     # them); the hipGraph, if wanted, is captured after the warm-up steps
     eng = GanEngine(arch, args.loss, lr, batch_size=B, seed=0, dist_group=group)
@@ -270,15 +269,15 @@ def main():
         eng.step(real)
     barrier()
     want = 'eager' if args.no_graph else 'graph' if args.graph else args.launch_mode
-    if tape:
-        want = 'eager'                                   # the primitive-op engine issues eagerly
+    if tape and (want == 'graph' or group is not None):
+        want = 'eager'                                   # the primitive-op engine: no hipGraph capture; eager under data parallelism
     elif group is not None and want == 'graph':
         want = 'eager'                                   # collectives between the launches: no hipGraph
     trial = {}
     if want == 'auto':
         # untimed: a few steps each way, keep the fastest launch mode (data-parallel: eager or plan, the slowest rank's
         # time decides so that every rank makes the same choice)
-        for m in (('eager', 'plan') if group is not None else ('eager', 'graph', 'plan')):
+        for m in (('eager', 'plan') if (group is not None or tape) else ('eager', 'graph', 'plan')):
             eng.launch_mode = m
             for _ in range(5):
                 eng.step(real)
@@ -297,10 +296,9 @@ def main():
         if os.environ.get('BENCH_VERBOSE'):
             print('launch-mode trial (ms/step):', {k: round(v * 1e3, 3) for k, v in trial.items()}, file=sys.stderr)
     mode = want
-    if not tape:
-        eng.launch_mode = mode
-        for _ in range(3):                               # capture / record outside the timed region
-            eng.step(real)
+    eng.launch_mode = mode
+    for _ in range(3):                                   # capture / record outside the timed region
+        eng.step(real)
     # the timed region: EXACTLY args.steps steps between barrier + synchronize on both sides, max over ranks; run
     # args.repeats times back to back, the line reports the median region (and every region's ms/step)
     regions = []

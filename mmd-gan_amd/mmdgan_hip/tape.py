@@ -510,7 +510,7 @@ class NetForward:
             ops.set_workspace(device=self.device)
         # the forward executor is TapeEngine's, on an instance that holds nothing but buffers
         run = TapeEngine.__new__(TapeEngine)
-        run.device, run._bufs, run._wino, run._in_step = self.device, {}, {}, False
+        run.device, run._bufs, run._wino, run._in_step, run._sn_zeroed = self.device, {}, {}, False, False
         run._folded = {k.scope: [None, None] for k in self.net.kernels}
         self._run = run
 
@@ -522,6 +522,9 @@ class NetForward:
         return vals[self.net.out_val]
 
 
+_EV_GEN_READY, _EV_DIS_READY, _EV_GEN_SN_READY = 0, 1, 2                # named events of the engine's handle
+
+
 def _native(ref_shape, n):
     return [n, ref_shape[1], ref_shape[2], ref_shape[0]] if len(ref_shape) == 3 else [n, ref_shape[0]]
 
@@ -531,7 +534,7 @@ class TapeEngine:
 
     def __init__(self, architecture, loss_type='rep', lr_list=(5e-4, 2e-4), rep_weights=(0.0, -1.0), batch_size=64,
                  seed=0, device=None, dist_group=None, use_graph=False, sn_mode='default', weight_init='default',
-                 mix_threshold=None):
+                 mix_threshold=None, launch_mode=None):
         ops.require_device()
         initializers.check_mode(weight_init)
         if loss_type not in ops.LOSS:
@@ -566,10 +569,21 @@ class TapeEngine:
         self._static_z = torch.zeros(self.B, self.code_size, device=self.device)
         self._z_gen = torch.Generator(device=self.device)                # per-replica code sampler, see GanEngine
         self._z_gen.manual_seed((int(seed) * 1000003 + 7919 * self.rank + 12345) % (2 ** 63 - 1))
-        self._static_real = torch.zeros(_native(self.in_shape_ref, self.B), device=self.device)
         self._dis_in = torch.zeros(_native(self.in_shape_ref, 2 * self.B), device=self.device)
+        self._static_real = self._dis_in[:self.B]                        # the batch buffer IS the real half of D's input
+        # this engine's own library state (include/mmdgan_hip.h "Handles"): workspace, prezeroed mode, launch plan, events
+        self._handle = ops.Handle(device=self.device)
+        # how a step reaches the GPU: 'eager' = library calls from Python, 'plan' = the library records one eager step and
+        # re-issues it from ONE C call (engine.py); MMDGAN_LAUNCH_MODE overrides
+        self.launch_mode = launch_mode or os.environ.get('MMDGAN_LAUNCH_MODE') or 'eager'
+        if self.launch_mode == 'graph':
+            self.launch_mode = 'plan'                                    # (no hipGraph capture here; the plan is its equal)
+        assert self.launch_mode in ('eager', 'plan'), self.launch_mode
+        self._plan, self._plan_stream, self._baked_lr = None, None, (self.lr_d, self.lr_g)
+        self._out_buffer = None
         self._bufs = {}
         self._in_step = False                                            # transformed weights are valid inside step() only
+        self._sn_zeroed = False                                          # inside step(): the power iteration's targets are zeroed
         self._exchange_pending = False
         self._d_has_bn = bool(self.dis.bns)
         lib = ops.require_device()
@@ -623,14 +637,15 @@ class TapeEngine:
         # scratch, zeroed once per step (the backward pass runs with mmdgan_set_outputs_prezeroed(1))
         sizes = []
         for net in (self.gen, self.dis):
-            for k in net.kernels:
+            for k in net.kernels:                          # what the power iteration and the fix-up accumulate into
                 if k.sn:
-                    sizes.append((net.sn[k.scope], 'dot', 4))
+                    st = net.sn[k.scope]
+                    sizes.append((st, 'dot', 4))
+                    sizes += [(st, q, st[q].numel()) for q in ('dsigma', 'u', 'xb')]
             for i, p in enumerate(net.prims):
                 if p['kind'] == 'bn':
                     c = net.shapes[p['out']][0]
                     sizes.append((p, '_ws_bwd', max(lib.mmdgan_bn_workspace_bytes(c) // 4, 4)))
-                    sizes.append((p, '_ws_fwd', max(lib.mmdgan_bn_workspace_bytes(c) // 4, 4)))
                     if net is self.dis:                # the loss_gen pass through a D with batch norm: totals of its own
                         sizes += [(p, '_ws_bwd2', max(lib.mmdgan_bn_workspace_bytes(c) // 4, 4)), (p, '_gg2', c), (p, '_gb2', c)]
             for k in net.kernels:                          # weight gradients of the folded 4x4 kernels (atomics)
@@ -640,7 +655,11 @@ class TapeEngine:
         self._zero_scratch = torch.zeros(max(total, 4), device=self.device)
         off = 0
         for holder, key, n in sizes:
-            holder[key] = self._zero_scratch[off:off + n]
+            old = holder.get(key) if isinstance(holder, dict) else None
+            if torch.is_tensor(old):                       # (a tensor the net allocated for itself: same shape, new home)
+                holder[key] = self._zero_scratch[off:off + old.numel()].view(old.shape)
+            else:
+                holder[key] = self._zero_scratch[off:off + n]
             off += (n + 3) // 4 * 4
         for entry in self._folded.values():
             entry[1] = entry[1].view(entry[0].shape)
@@ -663,8 +682,10 @@ class TapeEngine:
 
     # ---- spectral norm (math_func.py:661-672), as engine.py:_sn_step -------------------------------------------
     def _sn_step(self, net, k, update=True):
-        """update=False: sigma / scale from the stored vector only (inference: no UPDATE_OPS)"""
+        """update=False: sigma / scale from the stored vector only (inference: no UPDATE_OPS).  Inside step() the chain's
+        accumulation targets (u, xb, dsigma) are zero on entry - the step's one scratch memset - and the launches may split"""
         st = net.sn[k.scope]
+        oz = self._sn_zeroed
         w, x = net.p(k.w_name), net.state[k.scope + '/SN/in_rand']
         sigma, scale, dsig, u, un, xb, xbn = st['sigma'], st['scale'], st['dsigma'], st['u'], st['un'], st['xb'], st['xbn']
         if k.op == 'd' or k.pim:
@@ -673,18 +694,18 @@ class TapeEngine:
             if 1 in w.shape:                                             # math_func.py:702-704
                 ops.sn_norm_scale(w.reshape(-1), k.act_k, sigma, scale, dsig.view(-1))
             elif k.use_u:
-                ops.gemm(x, w, out=u)
+                ops.gemm(x, w, out=u, out_zeroed=oz)
                 ops.sn_norm_scale(u.view(-1), k.act_k, sigma, scale, un.view(-1))
                 if update:
-                    ops.gemm(x, un, trans_a=True, out=dsig)
-                    ops.gemm(un, w, trans_b=True, out=xb)
+                    ops.gemm(x, un, trans_a=True, out=dsig, out_zeroed=oz)
+                    ops.gemm(un, w, trans_b=True, out=xb, out_zeroed=oz)
                     ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
             else:
-                ops.gemm(x, w, trans_b=True, out=u)
+                ops.gemm(x, w, trans_b=True, out=u, out_zeroed=oz)
                 ops.sn_norm_scale(u.view(-1), k.act_k, sigma, scale, un.view(-1))
                 if update:
-                    ops.gemm(un, x, trans_a=True, out=dsig)
-                    ops.gemm(un, w, out=xb)
+                    ops.gemm(un, x, trans_a=True, out=dsig, out_zeroed=oz)
+                    ops.gemm(un, w, out=xb, out_zeroed=oz)
                     ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
         else:
             h, wd = (k.in_ref if k.op == 'c' else k.out_ref)[1:]         # input of the conv ('tc': the layer's OUTPUT)
@@ -705,11 +726,21 @@ class TapeEngine:
         return scale
 
     # ---- forward ----------------------------------------------------------------------------------------------
-    def _forward(self, net, x, training, tag):
-        """runs the net's primitives; returns the value table (kept for the backward pass when training)"""
+    def _buf_of(self, key, shape):
+        ob = self._out_buffer
+        if ob is not None and key[:2] == ob[0] and key[2] == ob[1]:      # the net's last primitive writes where its reader reads
+            assert list(ob[2].shape) == list(shape)
+            return ob[2]
+        return self._buf(key, shape)
+
+    def _forward(self, net, x, training, tag, out_buffer=None):
+        """runs the net's primitives; returns the value table (kept for the backward pass when training).
+        out_buffer: where the net's output goes (instead of a buffer of the engine's own)"""
         n = x.shape[0]
         vals = {0: x}
         lib = ops.require_device()
+        last = max(i for i, p in enumerate(net.prims) if p['out'] == net.out_val)
+        self._out_buffer = ((tag, net.name), last, out_buffer) if (out_buffer is not None and net.prims[last]['kind'] != 'reshape') else None
         for i, p in enumerate(net.prims):
             kind, a = p['kind'], vals[p['ins'][0]]
             key = (tag, net.name, i)
@@ -720,7 +751,7 @@ class TapeEngine:
                 k = p['k']
                 scale = net.sn[k.scope]['scale'] if k.sn else None
                 bias = net.p(k.bias_name) if k.bias_name is not None else None
-                y = self._buf(key, out_shape)
+                y = self._buf_of(key, out_shape)
                 if kind == 'dense':
                     ops.gemm(a.reshape(n, -1), net.p(k.w_name), bias=bias, scale=scale, out=y)
                 else:
@@ -733,7 +764,7 @@ class TapeEngine:
                 w4 = self._folded[k.scope][0]
                 if not (training and self._in_step):                     # outside step(): compose on the spot
                     w4 = ops.compose_scaled_conv(net.p(k.w_name), k.fold)
-                y = self._buf(key, out_shape)
+                y = self._buf_of(key, out_shape)
                 if kind == 'convdown':
                     ops.conv2d_fwd(a, w4, 2, bias=bias, scale=scale, out=y,
                                    wino=self._wino_of(k, False, n) if (training and self._in_step) else None)
@@ -744,11 +775,11 @@ class TapeEngine:
                 k = p['k']
                 bias = net.p(k.bias_name) if k.bias_name is not None else None
                 scale = net.sn[k.scope]['scale'] if k.sn else None
-                y = self._buf(key, out_shape)
+                y = self._buf_of(key, out_shape)
                 ops.conv2d_dgrad(a, net.p(k.w_name), (out_shape[1], out_shape[2]), k.stride, bias=bias, scale=scale, out=y,
                                  wino=self._wino_of(k, True, n) if (training and self._in_step) else None)
             elif kind == 'bn':
-                y = self._buf(key, out_shape)
+                y = self._buf_of(key, out_shape)
                 c = out_shape[-1]
                 pre = p['prefix']
                 gamma, beta = net.p(pre + '/BN/gamma'), net.p(pre + '/BN/beta')
@@ -767,22 +798,25 @@ class TapeEngine:
                         x2.data_ptr(), x2.shape[0], c, gamma.data_ptr(), beta.data_ptr(), 1e-3, ops.act_id(p['act']),
                         mm.data_ptr(), mv.data_ptr(), y2.data_ptr(), ops._stream()), 'bn_fwd_infer')
             elif kind == 'act':
-                y = ops.act_fwd(a, p['act'], out=self._buf(key, out_shape))
+                y = ops.act_fwd(a, p['act'], out=self._buf_of(key, out_shape))
             elif kind == 'down':
-                y = ops.resample_down(a, p['f'], out=self._buf(key, out_shape))
+                y = ops.resample_down(a, p['f'], out=self._buf_of(key, out_shape))
             elif kind == 'up':
-                y = ops.resample_up(a, p['f'], out=self._buf(key, out_shape))
+                y = ops.resample_up(a, p['f'], out=self._buf_of(key, out_shape))
             elif kind == 'shuffle':
-                y = ops.periodic_shuffle(a, p['f'], p['to_big'], out=self._buf(key, out_shape))
+                y = ops.periodic_shuffle(a, p['f'], p['to_big'], out=self._buf_of(key, out_shape))
             elif kind in ('bilinear', 'bicubic'):
-                y = (ops.bilinear_resize if kind == 'bilinear' else ops.bicubic_resize)(a, out_shape[1:3], out=self._buf(key, out_shape))
+                y = (ops.bilinear_resize if kind == 'bilinear' else ops.bicubic_resize)(a, out_shape[1:3], out=self._buf_of(key, out_shape))
             elif kind == 'maxpool':
-                y = ops.max_pool(a, p['f'], out=self._buf(key, out_shape))
+                y = ops.max_pool(a, p['f'], out=self._buf_of(key, out_shape))
             elif kind == 'add':
-                y = ops.axpby(a, vals[p['ins'][1]], out=self._buf(key, out_shape))
+                y = ops.axpby(a, vals[p['ins'][1]], out=self._buf_of(key, out_shape))
             else:
                 raise AssertionError(kind)
             vals[p['out']] = y
+        if out_buffer is not None and self._out_buffer is None:
+            ops.copy(out_buffer, vals[net.out_val].reshape(out_buffer.shape))
+        self._out_buffer = None
         return vals
 
     # ---- backward ---------------------------------------------------------------------------------------------
@@ -1037,98 +1071,153 @@ class TapeEngine:
             mdist.allreduce_sum_(net.grads, self.dist_group)
             return
         comm = self._sn_stream
-        comm.wait_stream(torch.cuda.current_stream())
-        comm.wait_stream(self._wg_stream)
+        ops.stream_wait(self._sn_raw, ops._stream())
+        ops.stream_wait(self._sn_raw, self._wg_raw)
         with torch.cuda.stream(comm):
             mdist.allreduce_sum_(net.grads, self.dist_group)
         self._exchange_pending = True
 
-    def step(self, real_nhwc=None, z=None, uni=None):
+    def _dp_active(self):
+        return self.dist_group is not None and (self.world > 1 or self._dp_force)
+
+    def _step_body(self):
+        """one training step as library calls only (streams and dependencies included): what a launch plan records"""
         B = self.B
         lib = ops.require_device()
-        main = torch.cuda.current_stream()
+        main = ops._stream()
+        # everything the step accumulates into that is not a gradient arena (power-iteration targets, <G, W> scalars,
+        # batch-norm totals of the backward pass, folded-kernel gradients): one small launch, first thing
+        ops.memset_zero_multi([self._zero_scratch])
+        lib.mmdgan_set_outputs_prezeroed(1)
+        self._sn_zeroed = True
+        try:
+            if self._side:
+                # after the previous step's Adam: G's transformed weights first (its forward pass waits for them), then
+                # the zeroing of the gradient arenas, then D's
+                ops.stream_wait(self._wg_raw, main)
+                with torch.cuda.stream(self._wg_stream):
+                    self._transform_weights(self.gen)
+                    ops.event_record(_EV_GEN_READY, self._wg_raw)
+                    ops.memset_zero_multi([self.gen.grads, self.dis.grads])
+                    self._transform_weights(self.dis)
+                    ops.event_record(_EV_DIS_READY, self._wg_raw)
+                ops.stream_wait(self._sn_raw, main)
+                with torch.cuda.stream(self._sn_stream):                 # depend on the weights only; G's first
+                    for k in self.gen.kernels:
+                        if k.sn:
+                            self._sn_step(self.gen, k)
+                    if any(k.sn for k in self.gen.kernels):
+                        ops.event_record(_EV_GEN_SN_READY, self._sn_raw)
+                        ops.event_wait(_EV_GEN_SN_READY, main)
+                    for k in self.dis.kernels:
+                        if k.sn:
+                            self._sn_step(self.dis, k)
+                ops.event_wait(_EV_GEN_READY, main)
+            else:
+                ops.memset_zero_multi([self.gen.grads, self.dis.grads])
+                self._compose_weights(self.gen)
+                self._compose_weights(self.dis)
+                for net in (self.gen, self.dis):
+                    for k in net.kernels:
+                        if k.sn:
+                            self._sn_step(net, k)
+        finally:
+            # (the forward pass runs without it: its launches with few tiles split their reductions into outputs the
+            # library zeroes itself)
+            lib.mmdgan_set_outputs_prezeroed(0)
+            self._sn_zeroed = False
+        self._in_step = True
+        try:
+            # G's output goes straight into the fake half of D's input (my_sngan.py:278: D sees [real ; fake]); the real half
+            # IS the batch buffer
+            gvals = self._forward(self.gen, self._static_z, True, 'g', out_buffer=self._dis_in[B:])
+            if self._side:
+                ops.stream_wait(main, self._sn_raw)
+                ops.event_wait(_EV_DIS_READY, main)
+            dvals = self._forward(self.dis, self._dis_in, True, 'd')
+            self._last_vals = (gvals, dvals)                             # (the parity tests read activations from here)
+            scores = dvals[self.dis.out_val]                             # [2B, d]: s_x = [:B], s_gen = [B:]
+            self._loss.launch(scores, self.losses)
+            ds = self._loss.grads.view(4 * B, -1)   # [dLd/ds_x ; dLd/ds_gen ; dLg/ds_gen ; dLg/ds_x]
+            lib.mmdgan_set_outputs_prezeroed(1)     # gradient arenas and the scratch were zeroed at step start
+            if self._d_joint:
+                # loss_dis (2B rows) and loss_gen (the fake half again) through D together, 3B rows per launch
+                d_in = self._backward(self.dis, dvals, ds[:3 * B], 'bd', param_grads=True, need_input_grad=True, extra_rows=B)
+                self._allreduce(self.dis)
+            else:
+                self._backward(self.dis, dvals, ds[:2 * B], 'bd', param_grads=True)
+                self._allreduce(self.dis)
+                if self._d_has_bn:
+                    # batch statistics couple the rows: the REAL scores depend on the fake images too (through the batch
+                    # mean / variance), so loss_gen reaches G along dLg/ds_x as well - a full 2B-row pass with both halves
+                    # of the loss_gen score gradient, [dLg/ds_x ; dLg/ds_gen] in D's [real ; fake] row order
+                    dg = self._buf('dg_full', [2 * B, self.score_size])
+                    ops.copy(dg[:B], ds[3 * B:4 * B])
+                    ops.copy(dg[B:], ds[2 * B:3 * B])
+                    d_in = self._backward(self.dis, dvals, dg, 'bg', param_grads=False, need_input_grad=True)[B:]
+                else:
+                    d_in = self._backward(self.dis, dvals, ds[2 * B:3 * B], 'bg', rows=(B, 2 * B), param_grads=False,
+                                          need_input_grad=True)
+            self._backward(self.gen, gvals, d_in, 'gb', param_grads=True)
+            if self._side:
+                ops.stream_wait(main, self._wg_raw)
+        finally:
+            lib.mmdgan_set_outputs_prezeroed(0)
+            self._in_step = False
+        self._allreduce(self.gen)
+        if self._exchange_pending:
+            ops.stream_wait(main, self._sn_raw)
+            self._exchange_pending = False
+        gs = 1.0 / self.world
+        self.dis.opt.step(self.lr_d, grad_scale=gs)
+        self.gen.opt.step(self.lr_g, grad_scale=gs)
+
+    def step(self, real_nhwc=None, z=None, uni=None):
         if z is None:
             self._static_z.normal_(generator=self._z_gen)                # my_sngan.py:123-124
         else:
             self._static_z.copy_(z)
         self._loss.draw(self._z_gen, uni)                                # the *_mix coin (math_func.py:2079)
         if real_nhwc is not None:
-            self._static_real.copy_(real_nhwc)
-        if self._side:
-            # after the previous step's Adam: G's transformed weights first (its forward pass waits for them), then
-            # the zeroing of everything the backward pass accumulates into, then D's
-            self._wg_stream.wait_stream(main)
-            with torch.cuda.stream(self._wg_stream):
-                self._transform_weights(self.gen)
-                self._gen_ready.record(self._wg_stream)
-                self.gen.grads.zero_()
-                self.dis.grads.zero_()
-                self._zero_scratch.zero_()
-                self._transform_weights(self.dis)
-                self._dis_ready.record(self._wg_stream)
-            self._sn_stream.wait_stream(main)
-            with torch.cuda.stream(self._sn_stream):                     # depend on the weights only; G's first
-                for k in self.gen.kernels:
-                    if k.sn:
-                        self._sn_step(self.gen, k)
-                if any(k.sn for k in self.gen.kernels):
-                    self._gen_sn_ready.record(self._sn_stream)
-                    main.wait_event(self._gen_sn_ready)
-                for k in self.dis.kernels:
-                    if k.sn:
-                        self._sn_step(self.dis, k)
-            main.wait_event(self._gen_ready)
-        else:
-            self.gen.grads.zero_()
-            self.dis.grads.zero_()
-            self._zero_scratch.zero_()
-            self._compose_weights(self.gen)
-            self._compose_weights(self.dis)
-            for net in (self.gen, self.dis):
-                for k in net.kernels:
-                    if k.sn:
-                        self._sn_step(net, k)
-        self._in_step = True
-        gvals = self._forward(self.gen, self._static_z, True, 'g')
-        self._dis_in[:B].copy_(self._static_real)                        # my_sngan.py:278: D sees [real ; fake]
-        self._dis_in[B:].copy_(gvals[self.gen.out_val])
-        if self._side:
-            main.wait_stream(self._sn_stream)
-            main.wait_event(self._dis_ready)
-        dvals = self._forward(self.dis, self._dis_in, True, 'd')
-        self._last_vals = (gvals, dvals)                                 # (the parity tests read activations from here)
-        scores = dvals[self.dis.out_val]                                 # [2B, d]: s_x = [:B], s_gen = [B:]
-        self._loss.launch(scores, self.losses)
-        ds = self._loss.grads.view(4 * B, -1)       # [dLd/ds_x ; dLd/ds_gen ; dLg/ds_gen ; dLg/ds_x]
-        lib.mmdgan_set_outputs_prezeroed(1)         # gradient arenas and the scratch were zeroed at step start
-        try:
-            self._backward(self.dis, dvals, ds[:2 * B], 'bd', param_grads=True)
-            self._allreduce(self.dis)
-            if self._d_has_bn:
-                # batch statistics couple the rows: the REAL scores depend on the fake images too (through the batch
-                # mean / variance), so loss_gen reaches G along dLg/ds_x as well - a full 2B-row pass with both halves
-                # of the loss_gen score gradient, [dLg/ds_x ; dLg/ds_gen] in D's [real ; fake] row order
-                dg = self._buf('dg_full', [2 * B, self.score_size])
-                dg[:B].copy_(ds[3 * B:4 * B])
-                dg[B:].copy_(ds[2 * B:3 * B])
-                d_in = self._backward(self.dis, dvals, dg, 'bg', param_grads=False, need_input_grad=True)[B:]
+            self._static_real.copy_(real_nhwc)                           # (= the real half of D's input)
+        mode = self.launch_mode
+        if mode == 'plan' and self._dp_active():
+            mode = 'eager'                                               # torch.distributed collectives are not plan nodes
+        if (self.lr_d, self.lr_g) != self._baked_lr:                     # a recorded plan holds the learning rates by value
+            self._baked_lr = (self.lr_d, self.lr_g)
+            self._drop_plan()
+        with self._handle:                                               # this engine's workspace / prezeroed mode / plan / events
+            if mode == 'eager':
+                self._step_body()
             else:
-                d_in = self._backward(self.dis, dvals, ds[2 * B:3 * B], 'bg', rows=(B, 2 * B), param_grads=False,
-                                      need_input_grad=True)
-            self._backward(self.gen, gvals, d_in.contiguous(), 'gb', param_grads=True)
-            if self._side:
-                main.wait_stream(self._wg_stream)
-        finally:
-            lib.mmdgan_set_outputs_prezeroed(0)
-            self._in_step = False
-        self._allreduce(self.gen)
-        if self._exchange_pending:
-            main.wait_stream(self._sn_stream)
-            self._exchange_pending = False
-        gs = 1.0 / self.world
-        self.dis.opt.step(self.lr_d, grad_scale=gs)
-        self.gen.opt.step(self.lr_g, grad_scale=gs)
+                self._plan_step()
         self.global_step += 1
+
+    def _drop_plan(self):
+        if self._plan is not None:
+            with self._handle:
+                ops.require_device().mmdgan_plan_destroy(self._plan)
+            self._plan = None
+
+    def _plan_step(self):
+        """record the step once (an ordinary eager step that the library notes down), replay it from one C call afterwards"""
+        import ctypes
+        lib = ops.require_device()
+        main = ops._stream()
+        if self._plan is not None and self._plan_stream != main:
+            self._drop_plan()
+        if self._plan is None:
+            ops.check(lib.mmdgan_plan_begin(), 'plan_begin')
+            try:
+                self._step_body()
+            except Exception:
+                lib.mmdgan_plan_abort()
+                raise
+            pid = ctypes.c_int(-1)
+            ops.check(lib.mmdgan_plan_end(ctypes.byref(pid)), 'plan_end')
+            self._plan, self._plan_stream = pid.value, main
+            return
+        ops.check(lib.mmdgan_plan_replay(self._plan, 0), 'plan_replay')
 
     # ---- variables / checkpoints (reference names and layouts) -------------------------------------------------
     def _net_of(self, name):
