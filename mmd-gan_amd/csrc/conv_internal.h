@@ -69,6 +69,8 @@ void slab_reduce(const float *part, int nsplit, size_t n, float *dw, const float
                  const float *wdot = nullptr, float *dot = nullptr);
 
 // Winograd F(2x2,2x2) for 4x4 / stride-2 layers and their input-gradient (conv_wino2.hip); U = 36*C*K floats
+// out = epilogue(sum of nslabs partial results, `total` floats each): the second pass of a reduction-split Winograd launch
+int slab_epilogue(const float *slabs, int nslabs, long total, int Ko, const ConvEpilogue &ep, float *out, hipStream_t st);
 bool wino2_eligible(const ConvDims &d, bool dgrad);
 bool wino2_fwd_ok(const ConvDims &d);
 bool wino2_dgrad_ok(const ConvDims &d);

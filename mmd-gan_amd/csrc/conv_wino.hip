@@ -57,16 +57,17 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float *__restric
 // lane, 128 contiguous bytes per half-wave) are loaded from L2 straight into the MFMA operand registers,
 // each refilled for the next stage right after the MFMA that consumed it (measured on the D l3 shape:
 // staging U through LDS cost 10 of 60 us).
-// SPLIT: blockIdx.z takes a slice of the channel reduction and ADDS scale * (A^T M A) into a zeroed output with
-// atomics (the transform is linear); bias / activation follow in epilogue_pass_kernel.  For launches whose tile
-// count alone cannot fill the chip (D l7 forward at batch 128: 16 x 8 workgroups on 256 CUs).
+// SPLIT: blockIdx.z takes a slice of the channel reduction and writes its A^T M A (the transform is linear) into slab
+// blockIdx.z of `out` (= the library workspace then, slab_elems apart); slab_epilogue() sums the slabs and applies
+// scale / bias / activation.  For launches whose tile count alone cannot fill the chip (D l7 forward at batch 128:
+// 16 x 8 workgroups on 256 CUs).  No zeroing, no atomics: the same bits every run.
 #ifndef WINO_WAVES
 #define WINO_WAVES 2
 #endif
 template <int BN, bool SPLIT>
 __global__ __launch_bounds__(256, WINO_WAVES) void wino_kernel(int N, int H, int W, int Cr, int Ko, ConvEpilogue ep,
                                                       const float *__restrict__ x, const float *__restrict__ U,
-                                                      float *__restrict__ out, int stages_per_split) {
+                                                      float *__restrict__ out, int stages_per_split, long slab_elems) {
     using Cf = wino::Cfg<BN>;
     constexpr int BC = wino::BC, ROW = wino::ROW, FSV = wino::FSV, NCB = Cf::NCB, VF = wino::V_FLOATS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -226,9 +227,8 @@ __global__ __launch_bounds__(256, WINO_WAVES) void wino_kernel(int N, int H, int
                     if (a == 0) v = make_float4(z0.x + z1.x + z2.x, z0.y + z1.y + z2.y, z0.z + z1.z + z2.z, z0.w + z1.w + z2.w);
                     else v = make_float4(z1.x - z2.x - z3.x, z1.y - z2.y - z3.y, z1.z - z2.z - z3.z, z1.w - z2.w - z3.w);
                     const long o = ob + ((long)a * W + b) * Ko + ch;
-                    if (SPLIT) {
-                        atomicAdd(out + o, v.x * sc); atomicAdd(out + o + 1, v.y * sc);
-                        atomicAdd(out + o + 2, v.z * sc); atomicAdd(out + o + 3, v.w * sc);
+                    if (SPLIT) {                          // this part's plain sums into its slab; the epilogue follows the slab sum
+                        *reinterpret_cast<float4 *>(out + (long)blockIdx.z * slab_elems + o) = v;
                         continue;
                     }
                     v.x = v.x * sc + bv.x; v.y = v.y * sc + bv.y; v.z = v.z * sc + bv.z; v.w = v.w * sc + bv.w;
@@ -323,6 +323,7 @@ int wino_transform(const ConvDims &d, const float *w, bool flip, float *U, hipSt
 static int wino_launch(const ConvDims &d, const ConvEpilogue &ep, const float *in, const float *w, const float *U, float *out,
                        bool flip, hipStream_t st) {
     const int cr = flip ? d.K : d.C, ko = flip ? d.C : d.K;
+    const bool own_u = U != nullptr;
     if (!U) {
         float *ws = (float *)workspace_acquire(sizeof(float) * 16 * (size_t)cr * ko, st);
         if (!ws) { set_error("conv2d (winograd): no workspace for the transformed weights"); return MMDGAN_E_ARG; }
@@ -332,22 +333,28 @@ static int wino_launch(const ConvDims &d, const ConvEpilogue &ep, const float *i
     const long T = (long)d.N * (d.H / 2) * (d.W / 2);
     const long wgs = ((T + 31) / 32) * (ko / 64);
     const int nstages = cr / wino::BC;
+    // too few tiles for two workgroups per CU, weights transformed by the caller (the workspace is free then): split the
+    // channel reduction over workspace slabs, as the 4x4 stride-2 kernel does (conv_wino2.hip: wino2_ksplit).  Each part
+    // keeps >= 8 stages (64 channels, 256 MFMAs per wave).  Measured (CIFAR batch 64): D l7 forward (128 workgroups) 69.7 ->
+    // 52.4 us, its 3B-row input-gradient (192) 87.8 -> 75.7; ms per CIFAR / STL step with the split applied to grids below
+    // 0 / 129 / 193 / 257 / 385 workgroups: 2.045 / 2.014 / 1.999 / 1.999 / 1.974 and 3.909 / 3.915 / 3.902 / 3.912 / 3.887
+    // (here the 384-workgroup launch, D l5's 3B-row input-gradient, gains too - the 4x4 kernel's did not).
+    static long below = -1;
+    if (below < 0) { const char *e = getenv("MMDGAN_WINO_KSPLIT_BELOW"); below = e ? atol(e) : 385; }
     int split = 1;
-    if (wgs < 96) {                                      // far too few tiles for 256 CUs: split the channel reduction
-        split = (int)((512 + wgs - 1) / wgs);
-        if (split > nstages / 8) split = nstages / 8;    // >= 8 stages (256 MFMAs per wave) per workgroup
-        if (split < 1) split = 1;
-    }
-    if (split > 1) {
-        const int sps = (nstages + split - 1) / split;
-        split = (nstages + sps - 1) / sps;
-        const long total = (long)d.N * d.H * d.W * ko;
-        if (memset_async(out, 0, sizeof(float) * total, st) != hipSuccess) return check_launch("conv2d(winograd) memset");
+    if (own_u && d.N > 1 && wgs < below)
+        while (split < 8 && wgs * split < 512 && nstages % (2 * split) == 0 && nstages / (2 * split) >= 8) split *= 2;
+    const long total = (long)d.N * d.H * d.W * ko;
+    float *slabs = nullptr;
+    if (split > 1) slabs = (float *)workspace_acquire(sizeof(float) * (size_t)split * total, st);
+    if (slabs) {
         const dim3 grid((unsigned)((T + 31) / 32), ko / 64, split);
-        hipLaunchKernelGGL((wino_kernel<64, true>), grid, dim3(256), (wino::Cfg<64>::LDS_BYTES), st, d.N, d.H, d.W, cr, ko, ep, in,
-                           U, out, sps);
+        ConvEpilogue plain{};
+        plain.wrap_from = kNoWrap;
+        hipLaunchKernelGGL((wino_kernel<64, true>), grid, dim3(256), (wino::Cfg<64>::LDS_BYTES), st, d.N, d.H, d.W, cr, ko, plain, in,
+                           U, slabs, nstages / split, total);
         if (int rc = check_launch(flip ? "conv2d_dgrad(winograd split)" : "conv2d_fwd(winograd split)")) return rc;
-        return epilogue_pass(out, total, ko, ep, st);
+        return slab_epilogue(slabs, split, total, ko, ep, out, st);
     }
     // 32-channel column blocks (half the accumulators: 4 waves per SIMD instead of 2, twice the workgroups, but the
     // input transform is redone per column block) pay off at the grid sizes where 64 leaves CUs idle - measured:
@@ -355,11 +362,11 @@ static int wino_launch(const ConvDims &d, const ConvEpilogue &ep, const float *i
     if (wgs <= 128 || (wgs > 256 && wgs < 512)) {
         const dim3 grid((unsigned)((T + 31) / 32), ko / 32);
         hipLaunchKernelGGL((wino_kernel<32, false>), grid, dim3(256), (wino::Cfg<32>::LDS_BYTES), st, d.N, d.H, d.W, cr, ko, ep, in,
-                           U, out, nstages);
+                           U, out, nstages, 0L);
     } else {
         const dim3 grid((unsigned)((T + 31) / 32), ko / 64);
         hipLaunchKernelGGL((wino_kernel<64, false>), grid, dim3(256), (wino::Cfg<64>::LDS_BYTES), st, d.N, d.H, d.W, cr, ko, ep, in,
-                           U, out, nstages);
+                           U, out, nstages, 0L);
     }
     return check_launch(flip ? "conv2d_dgrad(winograd)" : "conv2d_fwd(winograd)");
 }

@@ -450,7 +450,7 @@ int wino2_transform(const ConvDims &d, const float *w, bool dgrad, float *U, hip
 }
 
 // the second half of a reduction-split launch: out = epilogue(sum of the ksplit partial results), float4 per thread
-__global__ __launch_bounds__(256) void wino2_slab_epilogue_kernel(const float4 *__restrict__ part, int ksplit, long n4, int Ko,
+__global__ __launch_bounds__(256) void slab_epilogue_kernel(const float4 *__restrict__ part, int ksplit, long n4, int Ko,
                                                                   ConvEpilogue ep, float4 *__restrict__ out) {
     const float sc = ep.scale ? ep.scale[0] : 1.f;
     const long stride = (long)gridDim.x * 256;
@@ -474,6 +474,15 @@ __global__ __launch_bounds__(256) void wino2_slab_epilogue_kernel(const float4 *
         }
         out[e] = v;
     }
+}
+
+int slab_epilogue(const float *slabs, int nslabs, long total, int Ko, const ConvEpilogue &ep, float *out, hipStream_t st) {
+    const long n4 = total / 4;
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(slab_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float4 *)slabs, nslabs, n4, Ko, ep,
+                       (float4 *)out);
+    return check_launch("conv slab epilogue");
 }
 
 // reduction parts a launch with pre-transformed weights is cut into: enough to reach two workgroups per CU, each part
@@ -546,11 +555,8 @@ static int wino2_launch(const ConvDims &d, const ConvEpilogue &ep, const float *
         ConvEpilogue plain{};
         plain.wrap_from = kNoWrap;
         hipLaunchKernelGGL(wino2_kernel, grid, dim3(256), wino2::LDS_BYTES, st, P, plain, in, U, slabs);
-        const long n4 = (long)(out_bytes / 16);
-        long blocks = (n4 + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(wino2_slab_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float4 *)slabs, P.ksplit, n4, P.Ko, ep,
-                           (float4 *)out);
+        if (int rc = check_launch(dgrad ? "conv2d_dgrad(winograd 2x2 split)" : "conv2d_fwd(winograd 2x2 split)")) return rc;
+        return slab_epilogue(slabs, P.ksplit, (long)(out_bytes / 4), P.Ko, ep, out, st);
     } else
         hipLaunchKernelGGL(wino2_kernel, grid, dim3(256), wino2::LDS_BYTES, st, P, ep, in, U, out);
     return check_launch(dgrad ? "conv2d_dgrad(winograd 2x2)" : "conv2d_fwd(winograd 2x2)");

@@ -449,7 +449,7 @@ def test_conv2d_winograd_stride2_path(ops, case):
         ops.require_device().mmdgan_set_workspace(None, 0)
 
 
-WINO_CASES = [(16, 16, 16, 128, 128, 3, 1), (32, 8, 8, 64, 128, 3, 1), (9, 12, 12, 32, 64, 3, 1), (130, 4, 4, 64, 64, 3, 1),
+WINO_CASES = [(16, 16, 16, 128, 128, 3, 1), (32, 8, 8, 64, 128, 3, 1), (24, 4, 4, 256, 128, 3, 1), (9, 12, 12, 32, 64, 3, 1), (130, 4, 4, 64, 64, 3, 1),
               (5, 14, 18, 40, 192, 3, 1), (9, 10, 12, 64, 64, 3, 1), (7, 6, 10, 32, 256, 3, 1), (67, 4, 4, 96, 128, 3, 1)]
 
 
@@ -496,6 +496,22 @@ def test_conv2d_winograd_path(ops, case):
             dx2 = ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s, scale=dev([0.5]), act='lrelu', dact_of=nhwc(yprev),
                                    dact_batch=2 * B)
             assert rel_err(to_nchw(dx2), 0.5 * gx.numpy() * mask) <= RTOL
+        # weights transformed by the caller + a workspace: a launch with few workgroups (every case here) cuts its channel
+        # reduction into parts (>= 64 channels each) over workspace slabs, a second pass sums them and applies the epilogue
+        if ops.wino_eligible(N, H, W, C, K, ksz, s, False):
+            uf = ops.wino_transform(dev(w), False)
+            ref = R._act(yt.detach() * float(sc) + torch.tensor(b, dtype=torch.float64).reshape(1, -1, 1, 1), 'lrelu').numpy()
+            y = ops.conv2d_fwd(nhwc(x), dev(w), s, bias=dev(b), scale=dev([sc]), act='lrelu', wino=uf)
+            assert rel_err(to_nchw(y), ref) <= RTOL
+            assert torch.equal(y, ops.conv2d_fwd(nhwc(x), dev(w), s, bias=dev(b), scale=dev([sc]), act='lrelu', wino=uf))
+        if ops.wino_eligible(N, H, W, C, K, ksz, s, True):
+            ub = ops.wino_transform(dev(w), True)
+            dx = ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s, wino=ub)
+            assert rel_err(to_nchw(dx), gx.numpy()) <= RTOL
+            if N % 3 == 0:
+                dx2 = ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s, scale=dev([0.5]), act='lrelu', dact_of=nhwc(yprev),
+                                       dact_batch=2 * B, wino=ub)
+                assert rel_err(to_nchw(dx2), 0.5 * gx.numpy() * mask) <= RTOL
     finally:
         ops.require_device().mmdgan_set_workspace(None, 0)
     # caller-side transform (no workspace): mmdgan_wino_transform + MMDGAN_ACT_FLAG_W_WINOGRAD
