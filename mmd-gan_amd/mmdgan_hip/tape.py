@@ -401,6 +401,13 @@ class _Net:
         st = self.sn[k.scope]
         return st['scale'] * g - (st['scale'] / st['sigma']) * st['dot'] * st['dsigma'].view(g.shape)
 
+    def effective_grads_flat(self):
+        """the whole gradient arena with every fix-up applied (tests / inspection)"""
+        out = self.grads.clone()
+        for name in self.arena.offsets:
+            self.arena.view(name, out).copy_(self.effective_grad(name))
+        return out
+
     def _creation_order(self):
         """kernels and BN ops in the order the primitives use them (= the reference's variable creation order)"""
         for p in self.prims:
@@ -663,6 +670,7 @@ class TapeEngine:
             off += (n + 3) // 4 * 4
         for entry in self._folded.values():
             entry[1] = entry[1].view(entry[0].shape)
+        self._grad_buckets = {id(net): self._make_buckets(net) for net in (self.gen, self.dis)}
         for net in (self.gen, self.dis):               # (the <G, W> scalars have moved: segments again)
             net.build_optimizer()
             # a single replica folds the spectral-norm fix-up into Adam's read of the gradient; data-parallel replicas apply
@@ -900,6 +908,7 @@ class TapeEngine:
                 scale = net.sn[k.scope]['scale'] if k.sn else None
                 if param_grads:
                     self._on_wg_stream(lambda: self._param_grads(net, p, a, first_rows(dy), w, scale))
+                    self._exchange(net, p)
                 # the input-gradient.  An activation in front of this primitive that nothing else reads: its derivative rides
                 # on the epilogue (dact_of = the activation's output), the gradient goes straight to the activation's input
                 q = producer.get(vin)
@@ -956,6 +965,8 @@ class TapeEngine:
                     a.data_ptr(), y.data_ptr(), dy.data_ptr(), a.numel() // c, c, net.p(pre + '/BN/gamma').data_ptr(),
                     mean.data_ptr(), invstd.data_ptr(), ops.act_id(p['act']), dx.data_ptr(), gg.data_ptr(), gb.data_ptr(),
                     ws.data_ptr(), ops._stream()), 'bn_bwd')
+                if param_grads:
+                    self._exchange(net, p)
                 if vin != 0 or need_input_grad:
                     give(vin, dx)
             elif kind == 'act':
@@ -1060,21 +1071,49 @@ class TapeEngine:
         vals = self._forward(self.dis, x_nhwc.contiguous(), False, 'score%d' % x_nhwc.shape[0])
         return vals[self.dis.out_val].clone()
 
-    def _allreduce(self, net):
-        """SUM all-reduce of one network's gradient arena as blocking collectives on the power-iteration stream (idle
-        from D's forward pass to the next step, on a hardware queue of its own - see engine.py:_allreduce): D's
-        exchange overlaps with the second pass through D and the whole of G's backward pass."""
-        if self.dist_group is None or (self.world == 1 and not self._dp_force):
+    def _make_buckets(self, net):
+        """the gradient arena of `net` cut into exchange buckets in BACKWARD order: [(lowest item index, start, end)]
+        (dist.layer_buckets; an item = one kernel with its bias, or one batch norm's gamma / beta, in creation order = arena
+        order = the reverse of the order the backward pass completes them in).  Every primitive that owns parameters
+        learns its item index (p['_item'])."""
+        from .dist import layer_buckets
+        target = int(float(os.environ.get('MMDGAN_DP_BUCKET_MB', '8')) * (1 << 20)) // 4
+        ranges = []
+        for p in net.prims:
+            if p['kind'] in ('dense', 'conv', 'tconv', 'upconv', 'convdown'):
+                names = [p['k'].w_name] + ([p['k'].bias_name] if p['k'].bias_name is not None else [])
+            elif p['kind'] == 'bn':
+                names = [p['prefix'] + '/BN/gamma', p['prefix'] + '/BN/beta']
+            else:
+                continue
+            lo = min(net.arena.offsets[n][0] for n in names)
+            hi = max(net.arena.offsets[n][0] + (net.arena.offsets[n][1] + 3) // 4 * 4 for n in names)
+            p['_item'] = len(ranges)
+            ranges.append((lo, hi))
+        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:])) and ranges[0][0] == 0, 'arena entries are not in creation order'
+        ranges[-1] = (ranges[-1][0], net.arena.size)
+        return layer_buckets(ranges, target)
+
+    def _exchange(self, net, p):
+        """called right after the parameter gradients of primitive `p` have been issued: if that completes an exchange
+        bucket, its SUM all-reduce starts now on the power-iteration stream (idle from D's forward pass to the next step, on
+        a hardware queue of its own - engine.py:_exchange) and travels underneath the backward kernels still to come; only
+        the last bucket of G is exposed.  Averaging is Adam's grad_scale = 1 / world."""
+        if not self._dp_active():
             return
+        bucket = next((b for b in self._grad_buckets[id(net)] if b[0] == p['_item']), None)
+        if bucket is None:
+            return
+        _, lo, hi = bucket
         from . import dist as mdist
         if not self._side:
-            mdist.allreduce_sum_(net.grads, self.dist_group)
+            mdist.allreduce_sum_(net.grads[lo:hi], self.dist_group)
             return
-        comm = self._sn_stream
-        ops.stream_wait(self._sn_raw, ops._stream())
+        # kernels' gradients are issued on the weight-gradient stream, batch-norm gradients on the main stream
         ops.stream_wait(self._sn_raw, self._wg_raw)
-        with torch.cuda.stream(comm):
-            mdist.allreduce_sum_(net.grads, self.dist_group)
+        ops.stream_wait(self._sn_raw, ops._stream())
+        with torch.cuda.stream(self._sn_stream):
+            mdist.allreduce_sum_(net.grads[lo:hi], self.dist_group)
         self._exchange_pending = True
 
     def _dp_active(self):
@@ -1143,10 +1182,8 @@ class TapeEngine:
             if self._d_joint:
                 # loss_dis (2B rows) and loss_gen (the fake half again) through D together, 3B rows per launch
                 d_in = self._backward(self.dis, dvals, ds[:3 * B], 'bd', param_grads=True, need_input_grad=True, extra_rows=B)
-                self._allreduce(self.dis)
             else:
                 self._backward(self.dis, dvals, ds[:2 * B], 'bd', param_grads=True)
-                self._allreduce(self.dis)
                 if self._d_has_bn:
                     # batch statistics couple the rows: the REAL scores depend on the fake images too (through the batch
                     # mean / variance), so loss_gen reaches G along dLg/ds_x as well - a full 2B-row pass with both halves
@@ -1164,7 +1201,6 @@ class TapeEngine:
         finally:
             lib.mmdgan_set_outputs_prezeroed(0)
             self._in_step = False
-        self._allreduce(self.gen)
         if self._exchange_pending:
             ops.stream_wait(main, self._sn_raw)
             self._exchange_pending = False

@@ -571,6 +571,8 @@ sys.path[:0] = [os.path.join(ROOT, 'mmd-gan_amd'), os.path.join(ROOT, 'tests'), 
 from mmdgan_hip.engine import GanEngine
 from mmdgan_hip import dist as mdist
 from test_step_gpu import mid_architecture
+if os.environ.get('DP2_ENGINE') == 'tape':                       # the primitive-op engine on the same architecture
+    from mmdgan_hip.tape import TapeEngine as GanEngine
 torch.cuda.set_device(0)
 rank = int(os.environ['RANK'])
 mdist.init_process_group(0, backend='gloo')                      # two replicas on ONE GPU: gloo carries CUDA tensors
@@ -639,16 +641,17 @@ for n, v in eng.get_variables().items():
     else:
         spread = max(spread, d)
 out['spread'], out['spread_sn'] = spread, spread_sn
-out['plan_segments'] = len(eng._plan_collectives) + 1 if mode == 'plan' else 0
+out['plan_segments'] = len(eng._plan_collectives) + 1 if (mode == 'plan' and hasattr(eng, '_plan_collectives')) else 0
 dist.barrier()
 dist.destroy_process_group()
 print('RESULT ' + json.dumps(out), flush=True)
 """
 
 
-@pytest.mark.parametrize('mode', ['eager', 'plan'])
+@pytest.mark.parametrize('mode', ['eager', 'plan', 'tape'])
 def test_data_parallel_step_equals_the_mean_gradient_step(mode):
-    """the ENGINE with world size 2 (two replicas on this one GPU, gloo carrying the CUDA tensors): after a step on two
+    """('tape': the primitive-op engine, eager issue - its buckets follow the primitives that own parameters)
+    the ENGINE with world size 2 (two replicas on this one GPU, gloo carrying the CUDA tensors): after a step on two
     different batches the gradient arenas hold the sum of what each replica computes alone, the variables moved by
     TF-Adam's step on the MEAN gradient, and both replicas stay identical over further steps.  Buckets are exchanged
     layer group by layer group during the backward pass; 'plan': the recorded step, cut into segments at the collectives."""
@@ -662,7 +665,7 @@ def test_data_parallel_step_equals_the_mean_gradient_step(mode):
     procs = []
     for rank in (0, 1):
         env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2',
-                   LOCAL_RANK='0', DP2_MODE=mode)
+                   LOCAL_RANK='0', DP2_MODE='eager' if mode == 'tape' else mode, DP2_ENGINE='tape' if mode == 'tape' else 'dcgan')
         procs.append(subprocess.Popen([sys.executable, '-c', 'ROOT = %r\n' % root + _DP2_CHILD], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     res = {}
