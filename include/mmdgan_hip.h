@@ -280,6 +280,29 @@ int mmdgan_sn_scale(const float *sigma, float act_k, float *scale_out, void *str
 int mmdgan_sn_wgrad_fixup(float *g_inout, const float *dsigma_dw, const float *dot, const float *sigma,
                           const float *scale, long n, void *stream);
 
+/* One power-iteration step of MANY kernels at once (csrc/sn_chain.hip): every stage of all the chains is one launch - eight
+ * per call for up to 8 kernels (more are processed in groups of 8) instead of five per kernel.  Per kernel, as the
+ * reference's SpectralNorm (math_func.py:661-672, 739-744; the 'tc' branch :520-528 swaps the two conv forms):
+ *     u = F(x);  sigma[0] = ||u||;  scale[0] = act_k / sigma[0];  un = u / (sigma + 1e-10)
+ *     update != 0 (a training step's UPDATE_OPS):  dsigma = d sigma / d W  (the kernel's own layout),
+ *                  xb = F^T(un);  xb_norm[0] = ||xb|| (if given);  x = xb / (||xb|| + 1e-10)   IN PLACE
+ * form 0: F = conv2d_fwd with kernel w [R,R,C,K] ('SAME'): x [1,H,W,C], u / un [1,P,Q,K]
+ * form 1: F = conv2d_dgrad: x [1,P,Q,K], u / un [1,H,W,C]                 (P, Q = ceil(H / stride), ceil(W / stride))
+ * form 2: dense, w [C,K]: u [1,K] = x [1,C] w        form 3: dense: u [1,C] = x [1,K] w^T
+ * (a conv kernel in 'sn_paper' mode is the dense form on its [R*R*C, K] view).  xb has x's shape.
+ * col: scratch of 2 * P*Q * R*R*C floats per convolution kernel (the patch matrices), unused for the dense forms.
+ * u, xb and dsigma are accumulated into: the entry zeroes them first unless mmdgan_set_outputs_prezeroed(1) says the
+ * caller did.  `layers` is a HOST array, read during the call. */
+typedef struct mmdgan_sn_layer {
+    const float *w;
+    float *x, *u, *un, *xb, *col, *dsigma, *sigma, *scale, *xb_norm;
+    float *norm_acc;     /* 4 floats (two doubles: the sums of squares of u and xb), 8-byte aligned; CONSECUTIVE over the layers of a call */
+    float act_k;
+    int form;
+    int H, W, C, K, R, stride;
+} mmdgan_sn_layer;
+int mmdgan_sn_power_iteration(const mmdgan_sn_layer *layers, int n_layers, int update, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Pairwise squared distances + Gaussian kernel + repulsive ('rep') / bounded ('rmb') MMD losses,
  * forward and backward in one launch (the B x B matrices never touch HBM).

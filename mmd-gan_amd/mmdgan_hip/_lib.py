@@ -64,6 +64,7 @@ SIGNATURES = {
     'mmdgan_sn_norm_scale': (_I, [_P, _L, _F, _P, _P, _P, _P]),
     'mmdgan_sn_scale': (_I, [_P, _F, _P, _P]),
     'mmdgan_sn_wgrad_fixup': (_I, [_P, _P, _P, _P, _P, _L, _P]),
+    'mmdgan_sn_power_iteration': (_I, [_P, _I, _I, _P]),
     'mmdgan_mmd_workspace_bytes': (ctypes.c_size_t, [_I, _I]),
     'mmdgan_mmd_loss': (_I, [_P, _P, _I, _I, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P]),
     'mmdgan_mmd_mix_workspace_bytes': (ctypes.c_size_t, [_I, _I]),

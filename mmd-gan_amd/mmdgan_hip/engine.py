@@ -421,6 +421,23 @@ def sn_power_iteration(net, s, b, update=True, out_zeroed=True):
     return scale
 
 
+def sn_chain_layer(net, s, b):
+    """the power iteration of layer `s` as ops.SnChains describes it (same tensors as sn_power_iteration), or None for a
+    kernel with a unit dimension (math_func.py:702-704: no iteration, sigma = ||w||)"""
+    w = net.p(s.scope + '/kernel/kernel')
+    if (s.op == 'd' or s.pim) and 1 in (int(np.prod(w.shape[:-1])), w.shape[-1]):
+        return None
+    L = dict(w=w, x=net.state[s.scope + '/kernel/SN/in_rand'], sigma=net.state[s.scope + '#sigma'],
+             scale=net.state[s.scope + '#scale'], dsigma=net.state[s.scope + '#dsigma'], u=b[s.scope + '#u'],
+             un=b[s.scope + '#un'], xb=b[s.scope + '#xb'], xb_norm=b[s.scope + '#xbnorm'], act_k=s.act_k)
+    if s.op == 'd' or s.pim:                             # ('sn_paper': the conv kernel as its [R*R*C, K] matrix)
+        L.update(form=2 if s.use_u else 3, C=int(np.prod(w.shape[:-1])), K=w.shape[-1])
+    else:
+        c, h, wd = s.in_shape_ref if s.op == 'c' else s.op_out_ref
+        L.update(form=0 if s.use_u else 1, H=h, W=wd, C=w.shape[2], K=w.shape[3], R=s.R, stride=s.stride)
+    return L
+
+
 class GanEngine:
     """G + D + loss + two TF-Adam optimisers; `step()` = one sess.run of graph_func.py:853."""
 
@@ -639,6 +656,15 @@ class GanEngine:
             if above.op == 'tc' and (below.bn or below.act == 'linear'):
                 self._zero_each_step.append(self.buf[below.scope + ('#dy' if below.bn else '#dz')])
         self._zeroed_ptrs = {t.data_ptr() for t in self._zero_each_step}
+        # the power iterations of a whole net as six launches (csrc/sn_chain.hip) instead of five per kernel;
+        # MMDGAN_SN_FUSED=0: one chain of launches per layer, dealt to the power-iteration streams
+        self._sn_fused = os.environ.get('MMDGAN_SN_FUSED', '1') != '0' and len(self._sn_streams) > 0
+        self._sn_chains = {}
+        if self._sn_fused:
+            for net in (self.gen, self.dis):
+                layers = [(s, sn_chain_layer(net, s, self.buf)) for s in net.specs if s.sn]
+                self._sn_chains[id(net)] = (ops.SnChains([L for _, L in layers if L is not None], dev),
+                                            [s for s, L in layers if L is None])
 
     # ---------------------------------------------------------------------------------------
     # spectral norm: one power-iteration step per D layer (math_func.py:661-672)
@@ -703,9 +729,11 @@ class GanEngine:
             scales = {s.scope: sn_power_iteration(self.gen, s, self.buf, update=False, out_zeroed=False)
                       for s in self.gen.specs if s.sn}
         x = z
+        waited = False
         for i, s in enumerate(self.gen.specs):
-            if s.sn and is_training:
-                ops.event_wait(_EV_SN_GEN0 + i, ops._stream())               # this layer's power iteration (_forward)
+            if s.sn and is_training and not (self._sn_fused and waited):
+                ops.event_wait(_EV_SN_GEN0 + (0 if self._sn_fused else i), ops._stream())   # this layer's power iteration (_forward)
+                waited = True
             x = self._layer_forward(self.gen, s, x, is_training, scales.get(s.scope))
             if s.out_reshape is not None:
                 x = x.view(_native_shape(s.out_shape_ref, x.shape[0]))
@@ -738,6 +766,18 @@ class GanEngine:
             ops.stream_wait(st, main)
         # (G's first: its forward pass is what the main stream runs next)
         for net, ev0 in ((self.gen, _EV_SN_GEN0), (self.dis, _EV_SN0)):
+            if self._sn_fused:
+                # every stage of all the net's chains as one launch, on the first power-iteration stream; one event for the net
+                chains, single = self._sn_chains[id(net)]
+                for s in net.specs:
+                    self._scales[s.scope] = net.state[s.scope + '#scale'] if s.sn else None
+                if any(s.sn for s in net.specs):
+                    with torch.cuda.stream(self._sn_streams[0]):
+                        chains.run(update=True)
+                        for s in single:
+                            self._sn_step(net, s)
+                        ops.event_record(ev0, self._sn_raw[0])
+                continue
             for i, s in enumerate(net.specs):
                 k = i % len(self._sn_streams)
                 with torch.cuda.stream(self._sn_streams[k]):
@@ -752,12 +792,14 @@ class GanEngine:
         if self._wino:
             ops.event_wait(_EV_WINO_DIS, main)                               # D's transformed weights of this step
         x = b['dis_in']
+        waited = False
         for i, s in enumerate(self.dis.specs):
-            if s.sn:
+            if s.sn and not (self._sn_fused and waited):
                 # a layer waits for ITS power iteration only, not for both chains (measured: no difference at CIFAR B=64, where
                 # the chains finish under G's forward pass; tried with it: D's real half as a separate half-batch pass on the
                 # parameter-gradient stream underneath G's forward pass - 3.05 instead of 2.33 ms per step, dropped)
-                ops.event_wait(_EV_SN0 + i, main)
+                ops.event_wait(_EV_SN0 + (0 if self._sn_fused else i), main)
+                waited = True
             scale = self._scales[s.scope]
             x = self._layer_forward(self.dis, s, x, True, scale)
             if s.out_reshape is not None:

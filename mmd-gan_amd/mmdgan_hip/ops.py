@@ -345,6 +345,41 @@ def sn_norm(v, normalise=True, out_norm=None, out_v=None):
     return norm, vn
 
 
+class SnLayer(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_void_p) for k in ('w', 'x', 'u', 'un', 'xb', 'col', 'dsigma', 'sigma', 'scale', 'xb_norm', 'norm_acc')] + \
+               [('act_k', ctypes.c_float), ('form', ctypes.c_int)] + [(k, ctypes.c_int) for k in ('H', 'W', 'C', 'K', 'R', 'stride')]
+
+
+class SnChains:
+    """mmdgan_sn_power_iteration: one power-iteration step of many kernels, every stage of all chains as one launch.
+    layers: dicts with the tensors w, x, u, un, xb, dsigma, sigma, scale, xb_norm (col is allocated here), act_k, form
+    (0 conv2d_fwd, 1 conv2d_dgrad, 2 x W, 3 x W^T) and the conv geometry H, W, C, K, R, stride (dense: C, K).
+    Pointers are taken once: the tensors stay where they are for the life of an engine."""
+
+    def __init__(self, layers, device):
+        self.keep = list(layers)
+        self.table = (SnLayer * max(1, len(self.keep)))()
+        self.cols = []
+        self.norm_acc = torch.zeros(4 * max(1, len(self.keep)), device=device, dtype=torch.float32)
+        for i, (t, L) in enumerate(zip(self.table, self.keep)):
+            t.norm_acc = self.norm_acc.data_ptr() + 16 * i
+            for k in ('w', 'x', 'u', 'un', 'xb', 'dsigma', 'sigma', 'scale', 'xb_norm'):
+                setattr(t, k, L[k].data_ptr() if L.get(k) is not None else None)
+            t.act_k, t.form = float(L['act_k']), int(L['form'])
+            for k in ('H', 'W', 'C', 'K', 'R', 'stride'):
+                setattr(t, k, int(L.get(k, 1)))
+            if t.form <= 1:
+                P, Q = out_hw(t.H, t.W, t.stride)
+                col = torch.empty(2 * P * Q * t.R * t.R * t.C, device=device, dtype=torch.float32)
+                self.cols.append(col)
+                t.col = col.data_ptr()
+
+    def run(self, update=True, stream=None):
+        if self.keep:
+            check(require_device().mmdgan_sn_power_iteration(ctypes.cast(self.table, ctypes.c_void_p), len(self.keep), int(bool(update)),
+                                                             _stream() if stream is None else stream), 'sn_power_iteration')
+
+
 def sn_norm_scale(v, act_k, out_norm, out_scale, out_v=None):
     """||v|| -> out_norm, act_k/||v|| -> out_scale, v/(||v||+1e-10) -> out_v, one launch"""
     lib = require_device()

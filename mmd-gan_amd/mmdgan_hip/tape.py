@@ -670,6 +670,14 @@ class TapeEngine:
             off += (n + 3) // 4 * 4
         for entry in self._folded.values():
             entry[1] = entry[1].view(entry[0].shape)
+        # the power iterations of a whole net as a few launches (csrc/sn_chain.hip: every stage of all chains at once, 8 kernels
+        # per group) instead of five per kernel; MMDGAN_SN_FUSED=0 for the per-kernel chains
+        self._sn_chains = {}
+        if os.environ.get('MMDGAN_SN_FUSED', '1') != '0':
+            for net in (self.gen, self.dis):
+                layers = [(k, self._sn_chain_layer(net, k)) for k in net.kernels if k.sn]
+                self._sn_chains[id(net)] = (ops.SnChains([L for _, L in layers if L is not None], self.device),
+                                            [k for k, L in layers if L is None])
         self._grad_buckets = {id(net): self._make_buckets(net) for net in (self.gen, self.dis)}
         for net in (self.gen, self.dis):               # (the <G, W> scalars have moved: segments again)
             net.build_optimizer()
@@ -687,6 +695,33 @@ class TapeEngine:
         elif zero:
             t.zero_()
         return t
+
+    def _sn_chain_layer(self, net, k):
+        """the power iteration of kernel `k` as ops.SnChains describes it (the tensors of _sn_step), or None for a kernel with a
+        unit dimension (math_func.py:702-704)"""
+        w, st = net.p(k.w_name), net.sn[k.scope]
+        if (k.op == 'd' or k.pim) and 1 in (int(np.prod(w.shape[:-1])), w.shape[-1]):
+            return None
+        L = dict(w=w, x=net.state[k.scope + '/SN/in_rand'], sigma=st['sigma'], scale=st['scale'], dsigma=st['dsigma'], u=st['u'],
+                 un=st['un'], xb=st['xb'], xb_norm=st['xbn'], act_k=k.act_k)
+        if k.op == 'd' or k.pim:
+            L.update(form=2 if k.use_u else 3, C=int(np.prod(w.shape[:-1])), K=w.shape[-1])
+        else:
+            h, wd = (k.in_ref if k.op == 'c' else k.out_ref)[1:]         # input of the conv ('tc': the layer's OUTPUT)
+            L.update(form=0 if k.use_u else 1, H=h, W=wd, C=w.shape[2], K=w.shape[3], R=k.R, stride=k.stride)
+        return L
+
+    def _sn_all(self, net):
+        """one power-iteration step of every spectrally normalised kernel of `net` (a training step's UPDATE_OPS)"""
+        fused = self._sn_chains.get(id(net))
+        if fused is None:
+            for k in net.kernels:
+                if k.sn:
+                    self._sn_step(net, k)
+            return
+        fused[0].run(update=True)
+        for k in fused[1]:
+            self._sn_step(net, k)
 
     # ---- spectral norm (math_func.py:661-672), as engine.py:_sn_step -------------------------------------------
     def _sn_step(self, net, k, update=True):
@@ -1142,24 +1177,18 @@ class TapeEngine:
                     ops.event_record(_EV_DIS_READY, self._wg_raw)
                 ops.stream_wait(self._sn_raw, main)
                 with torch.cuda.stream(self._sn_stream):                 # depend on the weights only; G's first
-                    for k in self.gen.kernels:
-                        if k.sn:
-                            self._sn_step(self.gen, k)
                     if any(k.sn for k in self.gen.kernels):
+                        self._sn_all(self.gen)
                         ops.event_record(_EV_GEN_SN_READY, self._sn_raw)
                         ops.event_wait(_EV_GEN_SN_READY, main)
-                    for k in self.dis.kernels:
-                        if k.sn:
-                            self._sn_step(self.dis, k)
+                    self._sn_all(self.dis)
                 ops.event_wait(_EV_GEN_READY, main)
             else:
                 ops.memset_zero_multi([self.gen.grads, self.dis.grads])
                 self._compose_weights(self.gen)
                 self._compose_weights(self.dis)
                 for net in (self.gen, self.dis):
-                    for k in net.kernels:
-                        if k.sn:
-                            self._sn_step(net, k)
+                    self._sn_all(net)
         finally:
             # (the forward pass runs without it: its launches with few tiles split their reductions into outputs the
             # library zeroes itself)

@@ -698,6 +698,87 @@ def test_sn_helpers_and_adam(ops):
     assert rel_err(dp[1].cpu().numpy(), params['b'].numpy()) <= 1e-6
 
 
+def test_power_iterations_of_many_kernels_in_six_launches(ops):
+    """mmdgan_sn_power_iteration (every stage of all chains as one launch) against the same chains issued per kernel
+    through the batch-1 conv / gemm entries: both conv forms (3x3, 4x4 stride 2, 3x3 stride 2 with its one-sided 'SAME'
+    padding, 1x1, channel counts that are no tile multiple), both dense forms, more kernels than one group holds (8);
+    with and without the update; in prezeroed mode and with the entry zeroing its own accumulators."""
+    rs = np.random.RandomState(31)
+    convs = [(0, 16, 16, 64, 128, 3, 1), (1, 16, 16, 64, 128, 4, 2), (0, 32, 32, 3, 64, 3, 1), (1, 8, 8, 128, 256, 3, 1),
+             (0, 8, 8, 24, 40, 4, 2), (1, 10, 6, 16, 32, 3, 2), (0, 6, 10, 32, 16, 3, 2), (0, 8, 8, 64, 96, 1, 1),
+             (1, 4, 4, 512, 512, 3, 1), (0, 4, 4, 256, 512, 4, 2)]
+    dense = [(2, 8192, 16), (3, 16, 8192), (2, 128, 1024), (3, 100, 37)]
+    layers, want = [], []
+    z = lambda *sh: torch.zeros(*sh, device='cuda')
+    for form, H, W, C, K, R, st in convs:
+        P, Q = -(-H // st), -(-W // st)
+        w = dev((rs.randn(R, R, C, K) * 0.1).astype(np.float32))
+        xin, uout = ([1, H, W, C], [1, P, Q, K]) if form == 0 else ([1, P, Q, K], [1, H, W, C])
+        x = dev(rs.randn(*xin).astype(np.float32))
+        x /= x.norm()
+        layers.append(dict(w=w, x=x.clone(), u=z(*uout), un=z(*uout), xb=z(*xin), dsigma=z(R, R, C, K), sigma=z(1), scale=z(1),
+                           xb_norm=z(1), act_k=1.7, form=form, H=H, W=W, C=C, K=K, R=R, stride=st))
+        if form == 0:
+            u = ops.conv2d_fwd(x, w, st)
+        else:
+            u = ops.conv2d_dgrad(x, w, (H, W), st)
+        sig = u.norm()
+        un = u / (sig + 1e-10)
+        if form == 0:
+            ds, xb = ops.conv2d_wgrad(x, un, R, st), ops.conv2d_dgrad(un, w, (H, W), st)
+        else:
+            ds, xb = ops.conv2d_wgrad(un, x, R, st), ops.conv2d_fwd(un, w, st)
+        want.append((u, sig, un, ds, xb, xb / (xb.norm() + 1e-10)))
+    for form, C, K in dense:
+        w = dev((rs.randn(C, K) * 0.1).astype(np.float32))
+        x = dev(rs.randn(1, C if form == 2 else K).astype(np.float32))
+        x /= x.norm()
+        nu = K if form == 2 else C
+        layers.append(dict(w=w, x=x.clone(), u=z(1, nu), un=z(1, nu), xb=z(*x.shape), dsigma=z(C, K), sigma=z(1), scale=z(1),
+                           xb_norm=z(1), act_k=0.9, form=form, C=C, K=K))
+        u = x @ w if form == 2 else x @ w.t()
+        sig = u.norm()
+        un = u / (sig + 1e-10)
+        ds, xb = (x.t() @ un, un @ w.t()) if form == 2 else (un.t() @ x, un @ w)
+        want.append((u, sig, un, ds, xb, xb / (xb.norm() + 1e-10)))
+    assert len(layers) > 8
+    x0 = [L['x'].clone() for L in layers]
+    chains = ops.SnChains(layers, 'cuda')
+
+    def check(update):
+        for L, (u, sig, un, ds, xb, xn), x_old in zip(layers, want, x0):
+            tag = (L['form'], tuple(L['w'].shape))
+            assert rel_err(L['u'].cpu().numpy(), u.cpu().numpy()) <= 1e-5, tag
+            assert abs(float(L['sigma']) - float(sig)) <= 1e-5 * float(sig), tag
+            assert abs(float(L['scale']) - L['act_k'] / float(sig)) <= 1e-5 * L['act_k'] / float(sig), tag
+            assert rel_err(L['un'].cpu().numpy(), un.cpu().numpy()) <= 1e-5, tag
+            if update:
+                assert rel_err(L['dsigma'].cpu().numpy(), ds.cpu().numpy()) <= 1e-5, tag
+                assert rel_err(L['xb'].cpu().numpy(), xb.cpu().numpy()) <= 1e-5, tag
+                assert rel_err(L['x'].cpu().numpy(), xn.cpu().numpy()) <= 1e-5, tag
+                assert abs(float(L['xb_norm']) - float(xb.norm())) <= 1e-5 * float(xb.norm()), tag
+            else:
+                assert torch.equal(L['x'], x_old), tag
+    for L in layers:                                     # garbage in the accumulators: the entry zeroes them itself
+        for k in ('u', 'xb', 'dsigma'):
+            L[k].fill_(float('nan'))
+    chains.run(update=False)
+    check(False)
+    chains.run(update=True)
+    check(True)
+    lib = ops.require_device()
+    for L, x_old in zip(layers, x0):                     # prezeroed mode: the caller zeroes, the entry accumulates
+        L['x'].copy_(x_old)
+        for k in ('u', 'xb', 'dsigma'):
+            L[k].zero_()
+    lib.mmdgan_set_outputs_prezeroed(1)
+    try:
+        chains.run(update=True)
+    finally:
+        lib.mmdgan_set_outputs_prezeroed(0)
+    check(True)
+
+
 def test_segmented_adam_folds_the_spectral_norm_fixup(ops):
     """mmdgan_adam_segments + mmdgan_conv2d_wgrad_sn: the gradient arena keeps the RAW gradient of a spectrally normalised
     kernel plus the scalar <G, W>; the optimiser reads  scale * G - (scale / sigma) * <G, W> * dsigma/dW  (SURVEY A.2).
