@@ -379,6 +379,12 @@ int mmdgan_adam_segments(float *params, const float *grads, float *adam_m, float
                          const mmdgan_adam_segment *segments_dev, int n_segments, const int *blocks_dev, long n_blocks,
                          float lr, float beta1, float beta2, float eps, int step, int *step_counter, float *lr_t_scratch,
                          float grad_scale, int apply_fixup, void *stream);
+/* The step-count half of either update on its own: advances the device counter (or takes `step`) and leaves the bias-corrected
+ * learning rate in lr_t_scratch[0].  It depends on no gradient, so a caller can issue it early, off the critical path, and
+ * then call mmdgan_adam_segments with step_counter = NULL and step = MMDGAN_ADAM_PREPARED (lr / betas of that call ignored
+ * for the learning rate: lr_t_scratch is used as it is). */
+#define MMDGAN_ADAM_PREPARED (-1)
+int mmdgan_adam_prepare(float lr, float beta1, float beta2, int step, int *step_counter, float *lr_t_scratch, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Elementwise pieces of the residual blocks (layer_func.py:1687-1842), NHWC fp32.

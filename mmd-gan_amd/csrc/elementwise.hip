@@ -367,13 +367,22 @@ extern "C" int mmdgan_adam_segments(float *params, const float *grads, float *ad
                                     float *lr_t_scratch, float grad_scale, int apply_fixup, void *stream) {
     MMDGAN_REQUIRE(params && grads && adam_m && adam_v && segments_dev && blocks_dev && lr_t_scratch && n_segments >= 1 &&
                    n_blocks >= 1, "adam_segments: bad arguments");
-    MMDGAN_REQUIRE(step_counter || step >= 1, "adam_segments: step must be >= 1 when no device counter is given");
+    MMDGAN_REQUIRE(step_counter || step >= 1 || step == MMDGAN_ADAM_PREPARED,
+                   "adam_segments: step must be >= 1 (or MMDGAN_ADAM_PREPARED) when no device counter is given");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, st, step_counter, step, lr, beta1, beta2, lr_t_scratch);
+    if (step_counter || step != MMDGAN_ADAM_PREPARED)
+        hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, st, step_counter, step, lr, beta1, beta2, lr_t_scratch);
     hipLaunchKernelGGL(adam_segments_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, params, grads, adam_m, adam_v,
                        reinterpret_cast<const AdamSegment *>(segments_dev), reinterpret_cast<const int2 *>(blocks_dev), lr_t_scratch,
                        beta1, beta2, eps, grad_scale, apply_fixup);
     return check_launch("adam_segments");
+}
+
+extern "C" int mmdgan_adam_prepare(float lr, float beta1, float beta2, int step, int *step_counter, float *lr_t_scratch,
+                                   void *stream) {
+    MMDGAN_REQUIRE(lr_t_scratch && (step_counter || step >= 1), "adam_prepare: bad arguments");
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_counter, step, lr, beta1, beta2, lr_t_scratch);
+    return check_launch("adam_prepare");
 }
 
 extern "C" int mmdgan_nchw_to_nhwc(const float *src, float *dst, int N, int C, int H, int W, void *stream) {

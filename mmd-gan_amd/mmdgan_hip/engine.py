@@ -1067,6 +1067,9 @@ class GanEngine:
                     ops.event_record(_EV_WINO_GEN, self._wg_raw)
                     ops.memset_zero_multi(list(arenas))
                     self._wino_jobs[1].run()
+                    # (the step counts and bias-corrected learning rates of both updates: no gradient needed, so here)
+                    self.dis.opt.prepare(self.lr_d)
+                    self.gen.opt.prepare(self.lr_g)
                     ops.event_record(_EV_WINO_DIS, self._wg_raw)
             # the small scratch buffers of the step (power-iteration scratch, batch-norm totals, split-K outputs): one launch
             ops.memset_zero_multi([t for t in self._zero_each_step if not any(t is a for a in arenas)])

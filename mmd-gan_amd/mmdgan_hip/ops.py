@@ -585,13 +585,23 @@ class AdamArena:
         self.lr_t = torch.zeros(1, dtype=torch.float32, device=dev)
 
     fold_fixup = True        # False: the caller applied sn_wgrad_fixup itself (data-parallel replicas, before their all-reduce)
+    prepared = False         # prepare() has run for the coming step()
+
+    def prepare(self, lr, step=None, beta1=0.5, beta2=0.999):
+        """the step count and the bias-corrected learning rate of the coming step() - no gradient needed, so a step can issue
+        it early, beside its forward pass, instead of in front of the update"""
+        check(require_device().mmdgan_adam_prepare(float(lr), float(beta1), float(beta2), int(step or 0),
+                                                   self.step_counter.data_ptr() if step is None else None,
+                                                   self.lr_t.data_ptr(), _stream()), 'adam_prepare')
+        self.prepared = True
 
     def step(self, lr, step=None, beta1=0.5, beta2=0.999, eps=1e-8, grad_scale=1.0):
         lib = require_device()
+        pre, self.prepared = self.prepared, False
         check(lib.mmdgan_adam_segments(_p(self.params), _p(self.grads), _p(self.m), _p(self.v), self.segs.data_ptr(),
                                        self.n_segs, self.blocks.data_ptr(), self.n_blocks, float(lr), float(beta1),
-                                       float(beta2), float(eps), int(step or 0),
-                                       self.step_counter.data_ptr() if step is None else None, self.lr_t.data_ptr(),
+                                       float(beta2), float(eps), -1 if pre else int(step or 0),
+                                       None if (pre or step is not None) else self.step_counter.data_ptr(), self.lr_t.data_ptr(),
                                        float(grad_scale), int(self.fold_fixup), _stream()), 'adam_segments')
 
 
