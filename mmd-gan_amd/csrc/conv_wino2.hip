@@ -52,6 +52,7 @@ struct Params {
     int ntb, nkb, nph;      // work items = tile blocks x column blocks x phases x reduction parts
     int ksplit, spp;        // the reduction of an output tile cut into ksplit parts of spp stages each: part k writes its partial
     unsigned slab_bytes;    // result (plain sums, no epilogue) into slab k of `out` (= the workspace then), slab_bytes apart
+    int contiguous;         // A/B: a workgroup's items as one contiguous run instead of round-robin over the XCD's workgroups
 };
 }  // namespace wino2
 
@@ -110,18 +111,30 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
     const int nm = fq == 0 ? 5 : 4;
     // ---- this workgroup's run of items: XCD x (speed assumption: workgroup b runs on XCD b % 8) gets a contiguous eighth of
     // the items, ordered (tile block, phase, column block) so that the re-reads of a patch by the other phases / column
-    // blocks hit that XCD's L2, and deals it in contiguous runs to its workgroups
+    // blocks hit that XCD's L2 ...
     const int nitems = P.ntb * P.nkb * P.nph * P.ksplit, nwg = gridDim.x;
-    int first, count;
+    // ... and deals them ROUND-ROBIN to its workgroups (workgroup j takes items j, j + wx, j + 2 wx, ...): at any time the XCD's
+    // workgroups are on neighbouring items, i.e. the four phases / the column blocks of one tile block run side by side and
+    // share its patches through the L2.  (Contiguous runs per workgroup put the phases of a tile block one after the other in
+    // ONE workgroup, 20 us apart, and the 4 MB L2 had turned over by then: 147 MB fetched per launch of the 3B-row D l2
+    // input-gradient against 77 MB algorithmic.)
+    int first, count, istep;
     {
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
         const int nx = min(8, nwg);                                   // XCDs in use
         const int wx = nwg / nx + (xcd < nwg % nx ? 1 : 0);           // workgroups on this XCD
         const int iq = nitems / nx, ir = nitems % nx;
         const int xfirst = xcd * iq + min(xcd, ir), xcount = iq + (xcd < ir ? 1 : 0);
-        const int q = xcount / wx, r = xcount % wx;
-        first = xfirst + j * q + min(j, r);
-        count = q + (j < r ? 1 : 0);
+        if (P.contiguous) {
+            const int q = xcount / wx, r = xcount % wx;
+            first = xfirst + j * q + min(j, r);
+            count = q + (j < r ? 1 : 0);
+            istep = 1;
+        } else {
+            first = xfirst + j;
+            count = j < xcount ? (xcount - j + wx - 1) / wx : 0;
+            istep = wx;
+        }
     }
     if (count <= 0) return;
     const unsigned T = (unsigned)P.N * P.TH * P.TW;
@@ -155,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
     unsigned xbase = 0, xmask = 0;                       // byte offset of patch pixel (0,0), channel 4 cq; bit 3u+v: pixel (u,v) exists
     const unsigned xrow = (unsigned)(P.pstep * P.IW * P.Cr * 4), xcol = (unsigned)(P.pstep * P.Cr * 4);
     auto enter_item = [&]() {                            // the load cursor has reached item l_it (< count)
-        const int item = first + l_it;
+        const int item = first + l_it * istep;
         const int tblk = item / per_tb, rem0 = item - tblk * per_tb;
         const int rem = rem0 / P.ksplit, chunk = rem0 - rem * P.ksplit;
         const int s0 = chunk * P.spp;                    // the item's first stage of the tile's reduction
@@ -229,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
     int b_it = 0, b_seg = 0, b_cs = 0, b_left = P.spp;
     unsigned b_off;
     auto b_item = [&]() {
-        const int item = first + b_it;
+        const int item = first + b_it * istep;
         const int tblk = item / per_tb, rem0 = item - tblk * per_tb;
         const int rem = rem0 / P.ksplit, chunk = rem0 - rem * P.ksplit;
         const int phase = rem / P.nkb, n0 = (rem - phase * P.nkb) * 64;
@@ -272,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
     int par = 0;
 
     for (int it = 0; it < count; ++it) {
-        const int item = first + it;
+        const int item = first + it * istep;
         const int c_tblk = item / per_tb, c_rem = (item - c_tblk * per_tb) / P.ksplit;
         const int c_phase = c_rem / P.nkb;
         const int n0 = (c_rem - c_phase * P.nkb) * 64;
@@ -535,6 +548,9 @@ static int wino2_launch(const ConvDims &d, const ConvEpilogue &ep, const float *
     if (P.ksplit > 1 && (size_t)P.ksplit * out_bytes < (1ul << 31)) slabs = (float *)workspace_acquire((size_t)P.ksplit * out_bytes, st);
     if (!slabs) P.ksplit = 1;
     P.spp = nstages / P.ksplit;
+    static int contig = -1;
+    if (contig < 0) { const char *e = getenv("MMDGAN_WINO2_CONTIGUOUS"); contig = e ? atoi(e) : 0; }
+    P.contiguous = contig;
     P.slab_bytes = (unsigned)out_bytes;
     const long nitems = (long)P.ntb * P.nkb * P.nph * P.ksplit;
     static int ncu = 0;
