@@ -238,8 +238,10 @@ template <int MODE, bool GRAD>
 __global__ __launch_bounds__(256) void compose_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int K) {
     const long total = (long)C * K;
     const long stride = (long)gridDim.x * 256;
-    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {     // o = c*K + k
-        const int c = (int)(o / K), k = (int)(o - (long)c * K);
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {
+        // neighbouring threads walk the 4x4 kernel's innermost dimension (16 of the 25 accesses per element are on that side):
+        // MODE 0 [4,4,C,K]: o = c*K + k;  MODE 1 [4,4,K,C]: o = k*C + c (the 9 accesses of W are strided there, and cached)
+        const int c = MODE == 0 ? (int)(o / K) : (int)(o % C), k = MODE == 0 ? (int)(o - (long)c * K) : (int)(o / C);
         const float s = MODE == 0 ? 0.25f : 1.f;
         // F[r][a] = 1 where tap a of W contributes to tap r of the 4-wide kernel
         //   MODE 0: r = a + i (i = 0,1);  MODE 1: flipped: r = 3 - (a + i)
