@@ -697,19 +697,13 @@ class GanEngine:
         if s.bn:
             gamma, beta = net.p(s.scope + '/BN/BN/gamma'), net.p(s.scope + '/BN/BN/beta')
             mm, mv = net.state[s.scope + '/BN/BN/moving_mean'], net.state[s.scope + '/BN/BN/moving_variance']
-            raw2d = tgt.view(-1, tgt.shape[-1])
-            lib = ops.require_device()
-            ws = self._bn_totals[s.scope][0]
-            if is_training:
-                ops.check(lib.mmdgan_bn_fwd_train(
-                    raw2d.data_ptr(), raw2d.shape[0], raw2d.shape[1], gamma.data_ptr(), beta.data_ptr(), 1e-3, 0.99,
-                    int(tgt.dim() == 4), ops.act_id(s.act), y.data_ptr(), b[s.scope + '#mean'].data_ptr(),
-                    b[s.scope + '#invstd'].data_ptr(), mm.data_ptr(), mv.data_ptr(), mm.data_ptr(), mv.data_ptr(),
-                    ws.data_ptr(), ops._stream()), 'bn_fwd_train')
+            raw2d, y2d = tgt.view(-1, tgt.shape[-1]), y.view(-1, tgt.shape[-1])
+            if is_training:                                  # moving statistics updated in place (UPDATE_OPS)
+                ops.bn_fwd_train(raw2d, gamma, beta, mm, mv, act=s.act, unbiased=tgt.dim() == 4, new_moving_mean=mm,
+                                 new_moving_var=mv, out=y2d, save_mean=b[s.scope + '#mean'], save_invstd=b[s.scope + '#invstd'],
+                                 workspace=self._bn_totals[s.scope][0])
             else:
-                ops.check(lib.mmdgan_bn_fwd_infer(
-                    raw2d.data_ptr(), raw2d.shape[0], raw2d.shape[1], gamma.data_ptr(), beta.data_ptr(), 1e-3,
-                    ops.act_id(s.act), mm.data_ptr(), mv.data_ptr(), y.data_ptr(), ops._stream()), 'bn_fwd_infer')
+                ops.bn_fwd_infer(raw2d, gamma, beta, mm, mv, act=s.act, out=y2d)
         return y
 
     def _wino_fwd_ok(self, net, s, n):
@@ -904,16 +898,11 @@ class GanEngine:
             scale = self._scales[s.scope]                                    # None unless the layer is spectrally normalised
             if s.bn:                                                         # dz is d/d(BN output after act)
                 raw, y = b[s.scope + '#raw'], b[s.scope + '#y']
-                lib = ops.require_device()
                 C = raw.shape[-1]
-                ws = self._bn_totals[s.scope][1]
                 draw = b[s.scope + '#dz']
-                ops.check(lib.mmdgan_bn_bwd(
-                    raw.data_ptr(), y.data_ptr(), dz.data_ptr(), raw.numel() // C, C,
-                    net.p(s.scope + '/BN/BN/gamma').data_ptr(), b[s.scope + '#mean'].data_ptr(),
-                    b[s.scope + '#invstd'].data_ptr(), ops.act_id(s.act), draw.data_ptr(),
-                    net.g(s.scope + '/BN/BN/gamma').data_ptr(), net.g(s.scope + '/BN/BN/beta').data_ptr(),
-                    ws.data_ptr(), ops._stream()), 'bn_bwd')
+                ops.bn_bwd(raw.view(-1, C), y.view(-1, C), dz.view(-1, C), net.p(s.scope + '/BN/BN/gamma'), b[s.scope + '#mean'],
+                           b[s.scope + '#invstd'], act=s.act, dgamma=net.g(s.scope + '/BN/BN/gamma'),
+                           dbeta=net.g(s.scope + '/BN/BN/beta'), out=draw.view(-1, C), workspace=self._bn_totals[s.scope][1])
                 dz = draw
             dz = dz.view(_native_shape(s.op_out_ref, B))
 

@@ -299,38 +299,40 @@ def _bn_workspace(C, device):
 
 
 def bn_fwd_train(x2d, gamma, beta, moving_mean, moving_var, act='linear', eps=1e-3, momentum=0.99, unbiased=True,
-                 new_moving_mean=None, new_moving_var=None):
-    """x2d [rows, C].  Returns (y, save_mean, save_invstd, new_moving_mean, new_moving_var)."""
+                 new_moving_mean=None, new_moving_var=None, out=None, save_mean=None, save_invstd=None, workspace=None):
+    """x2d [rows, C].  Returns (y, save_mean, save_invstd, new_moving_mean, new_moving_var).
+    out / save_mean / save_invstd / workspace: caller-owned buffers (an engine's per-step ones; `workspace` holds the
+    per-channel totals, mmdgan_bn_workspace_bytes(C)); new_moving_* may be the moving_* tensors themselves (in place)"""
     lib = require_device()
     rows, C = x2d.shape
-    y = torch.empty_like(x2d)
-    mean = torch.empty(C, device=x2d.device, dtype=torch.float32)
-    invstd = torch.empty_like(mean)
+    y = out if out is not None else torch.empty_like(x2d)
+    mean = save_mean if save_mean is not None else torch.empty(C, device=x2d.device, dtype=torch.float32)
+    invstd = save_invstd if save_invstd is not None else torch.empty_like(mean)
     nmm = new_moving_mean if new_moving_mean is not None else torch.empty_like(mean)
     nmv = new_moving_var if new_moving_var is not None else torch.empty_like(mean)
-    ws = _bn_workspace(C, x2d.device)
+    ws = workspace if workspace is not None else _bn_workspace(C, x2d.device)
     check(lib.mmdgan_bn_fwd_train(_p(x2d), rows, C, _p(gamma), _p(beta), eps, momentum, int(unbiased), act_id(act), _p(y),
                                   _p(mean), _p(invstd), _p(moving_mean), _p(moving_var), _p(nmm), _p(nmv),
                                   ws.data_ptr(), _stream()), 'bn_fwd_train')
     return y, mean, invstd, nmm, nmv
 
 
-def bn_fwd_infer(x2d, gamma, beta, moving_mean, moving_var, act='linear', eps=1e-3):
+def bn_fwd_infer(x2d, gamma, beta, moving_mean, moving_var, act='linear', eps=1e-3, out=None):
     lib = require_device()
     rows, C = x2d.shape
-    y = torch.empty_like(x2d)
+    y = out if out is not None else torch.empty_like(x2d)
     check(lib.mmdgan_bn_fwd_infer(_p(x2d), rows, C, _p(gamma), _p(beta), eps, act_id(act), _p(moving_mean),
                                   _p(moving_var), _p(y), _stream()), 'bn_fwd_infer')
     return y
 
 
-def bn_bwd(x2d, y2d, dy2d, gamma, save_mean, save_invstd, act='linear', dgamma=None, dbeta=None):
+def bn_bwd(x2d, y2d, dy2d, gamma, save_mean, save_invstd, act='linear', dgamma=None, dbeta=None, out=None, workspace=None):
     lib = require_device()
     rows, C = x2d.shape
-    dx = torch.empty_like(x2d)
+    dx = out if out is not None else torch.empty_like(x2d)
     dgamma = dgamma if dgamma is not None else torch.empty(C, device=x2d.device, dtype=torch.float32)
     dbeta = dbeta if dbeta is not None else torch.empty(C, device=x2d.device, dtype=torch.float32)
-    ws = _bn_workspace(C, x2d.device)
+    ws = workspace if workspace is not None else _bn_workspace(C, x2d.device)
     check(lib.mmdgan_bn_bwd(_p(x2d), _p(y2d), _p(dy2d), rows, C, _p(gamma), _p(save_mean), _p(save_invstd), act_id(act),
                             _p(dx), _p(dgamma), _p(dbeta), ws.data_ptr(), _stream()), 'bn_bwd')
     return dx, dgamma, dbeta

@@ -832,14 +832,10 @@ class TapeEngine:
                     mean, invstd = self._buf(key + ('mean',), [c]), self._buf(key + ('invstd',), [c])
                     ws = self._buf(key + ('ws',), [max(lib.mmdgan_bn_workspace_bytes(c) // 4, 4)])
                     p['_saved'] = (mean, invstd)
-                    ops.check(lib.mmdgan_bn_fwd_train(
-                        x2.data_ptr(), x2.shape[0], c, gamma.data_ptr(), beta.data_ptr(), 1e-3, 0.99, int(a.dim() == 4),
-                        ops.act_id(p['act']), y2.data_ptr(), mean.data_ptr(), invstd.data_ptr(), mm.data_ptr(),
-                        mv.data_ptr(), mm.data_ptr(), mv.data_ptr(), ws.data_ptr(), ops._stream()), 'bn_fwd_train')
+                    ops.bn_fwd_train(x2, gamma, beta, mm, mv, act=p['act'], unbiased=a.dim() == 4, new_moving_mean=mm,
+                                     new_moving_var=mv, out=y2, save_mean=mean, save_invstd=invstd, workspace=ws)
                 else:
-                    ops.check(lib.mmdgan_bn_fwd_infer(
-                        x2.data_ptr(), x2.shape[0], c, gamma.data_ptr(), beta.data_ptr(), 1e-3, ops.act_id(p['act']),
-                        mm.data_ptr(), mv.data_ptr(), y2.data_ptr(), ops._stream()), 'bn_fwd_infer')
+                    ops.bn_fwd_infer(x2, gamma, beta, mm, mv, act=p['act'], out=y2)
             elif kind == 'act':
                 y = ops.act_fwd(a, p['act'], out=self._buf_of(key, out_shape))
             elif kind == 'down':
@@ -996,10 +992,8 @@ class TapeEngine:
                     ws, gg, gb = p['_ws_bwd'], net.g(pre + '/BN/gamma'), net.g(pre + '/BN/beta')
                 else:                                                    # a second pass through the same op
                     ws, gg, gb = p['_ws_bwd2'], p['_gg2'], p['_gb2']
-                ops.check(lib.mmdgan_bn_bwd(
-                    a.data_ptr(), y.data_ptr(), dy.data_ptr(), a.numel() // c, c, net.p(pre + '/BN/gamma').data_ptr(),
-                    mean.data_ptr(), invstd.data_ptr(), ops.act_id(p['act']), dx.data_ptr(), gg.data_ptr(), gb.data_ptr(),
-                    ws.data_ptr(), ops._stream()), 'bn_bwd')
+                ops.bn_bwd(a.reshape(-1, c), y.reshape(-1, c), dy.reshape(-1, c), net.p(pre + '/BN/gamma'), mean, invstd,
+                           act=p['act'], dgamma=gg, dbeta=gb, out=dx.view(-1, c), workspace=ws)
                 if param_grads:
                     self._exchange(net, p)
                 if vin != 0 or need_input_grad:
