@@ -103,6 +103,13 @@ def load():
         raise HipLibraryError(
             'libmmdgan_hip.so is missing at %s - build it with `python mmd-gan_amd/build_ext.py` '
             '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+    # PyTorch-ROCm ships its own libamdhip64; the library links the system one.  Whichever is loaded FIRST becomes the
+    # process's HIP runtime for both (same SONAME) - and torch finds no device when that is not its own copy.  The engines
+    # use torch for device memory and streams, so torch's runtime has to be the one: import it before the library.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass                                     # a torch-free caller (a C / ctypes host): the system runtime is the only one
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)        # AttributeError if the .so lacks a declared symbol
