@@ -692,8 +692,8 @@ class TapeEngine:
         if t is None or list(t.shape) != list(shape):
             t = torch.zeros(list(shape), device=self.device)
             self._bufs[key] = t
-        elif zero:
-            t.zero_()
+        if zero:
+            ops.memset_zero(t)                           # (a library call - also on first use: a launch plan records THIS step)
         return t
 
     def _sn_chain_layer(self, net, k):

@@ -27,19 +27,22 @@ def close(got, ref, rtol, floor):
     return np.max(np.abs(got - ref)) <= rtol * np.max(np.abs(ref)) + floor
 
 
-@pytest.mark.parametrize('tag', ['res_rep', 'res_ps_rmb', 'res_bil_rep', 'res_bic_rep', 'res_max_rep'])
+@pytest.mark.parametrize('tag', ['res_rep', 'res_rep-plan', 'res_ps_rmb', 'res_bil_rep', 'res_bil_rep-plan', 'res_bic_rep', 'res_max_rep'])
 def test_res_step_matches_reference_golden(tag):
-    """'res_rep': res / res_i / res_v1 blocks with 'avg' and 'unpool' scaling and an identity layer, rep loss;
+    """('-plan': the same steps issued through the engine's recorded launch plan - step 0 records while it runs, steps 1
+    and 2 are replays from one C call)
+    'res_rep': res / res_i / res_v1 blocks with 'avg' and 'unpool' scaling and an identity layer, rep loss;
     'res_ps_rmb': blocks whose scaling is periodic shuffling, rmb loss; 'res_bil_rep' / 'res_bic_rep': bilinear / bicubic
     resizing (x2, /2, /3);
     'res_max_rep': max pooling, and scaling on plain (non-block) layers"""
     from mmdgan_hip.tape import TapeEngine
+    tag, launch_mode = (tag[:-len('-plan')], 'plan') if tag.endswith('-plan') else (tag, 'eager')
     fx = load(golden('step_tiny_%s.npz' % tag)[0])
     B = int(fx['B'])
     arch = {'res_rep': tiny_res_architecture, 'res_ps_rmb': tiny_res_ps_architecture,
             'res_bil_rep': tiny_res_bil_architecture, 'res_max_rep': tiny_res_max_architecture,
             'res_bic_rep': tiny_res_bic_architecture}[tag]()
-    eng = TapeEngine(arch, str(fx['loss_type']), tuple(fx['lr']), batch_size=B)
+    eng = TapeEngine(arch, str(fx['loss_type']), tuple(fx['lr']), batch_size=B, launch_mode=launch_mode)
     init = {k[len('init/'):]: v for k, v in fx.items() if k.startswith('init/')}
     assert sorted(init) == sorted(eng.variable_names())              # the reference's variable names, all of them
     eng.set_variables(init)
