@@ -277,7 +277,8 @@ def main():
     if want == 'auto':
         # untimed: a few steps each way, keep the fastest launch mode (data-parallel: eager or plan, the slowest rank's
         # time decides so that every rank makes the same choice)
-        for m in (('eager', 'plan') if (group is not None or tape) else ('eager', 'graph', 'plan')):
+        modes = ('eager', 'plan') if (group is not None or tape) else ('eager', 'graph', 'plan')
+        for m in modes + modes:                          # two passes, the better one counts: one host hiccup must not pick the mode
             eng.launch_mode = m
             for _ in range(5):
                 eng.step(real)
@@ -286,7 +287,8 @@ def main():
             for _ in range(25):
                 eng.step(real)
             torch.cuda.synchronize()
-            trial[m] = (time.perf_counter() - t0) / 25
+            trial[m] = min(trial.get(m, 1e9), (time.perf_counter() - t0) / 25)
+        for m in modes:
             if group is not None:
                 import torch.distributed as dist
                 t = torch.tensor([trial[m]], device='cuda', dtype=torch.float64)

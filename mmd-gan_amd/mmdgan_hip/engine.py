@@ -628,23 +628,22 @@ class GanEngine:
         # G w G^T is computed once per step on the parameter-gradient stream (idle during the forward pass)
         # instead of inside every conv call.  scope -> [forward tensor or None, input-gradient tensor or None]
         self._wino, self._wino_ok = {}, {}
-        if self._side_wgrad:
-            for net, nf, nb in ((self.dis, 2 * B, 3 * B), (self.gen, B, B)):
-                for s in net.specs:
-                    if s.op == 'c':                              # conv geometry: input = layer input
-                        c, h, w = s.in_shape_ref
-                        k = s.out
-                    elif s.op == 'tc':                           # the conv whose input-gradient the tc layer is
-                        k = s.in_shape_ref[0]
-                        c, h, w = s.out, s.in_shape_ref[1] * s.stride, s.in_shape_ref[2] * s.stride
-                    else:
-                        continue
-                    fw = ops.wino_eligible(nf, h, w, c, k, s.R, s.stride, False)
-                    bw = ops.wino_eligible(nb, h, w, c, k, s.R, s.stride, True)
-                    if fw or bw:
-                        lead = (16,) if s.R == 3 else (4, 9)     # F(2x2,3x3) / F(2x2,2x2) on 4 parity segments
-                        self._wino[s.scope] = [torch.empty(lead + (c, k), device=dev) if fw else None,
-                                               torch.empty(lead + (k, c), device=dev) if bw else None, net]
+        for net, nf, nb in ((self.dis, 2 * B, 3 * B), (self.gen, B, B)):
+            for s in net.specs:
+                if s.op == 'c':                              # conv geometry: input = layer input
+                    c, h, w = s.in_shape_ref
+                    k = s.out
+                elif s.op == 'tc':                           # the conv whose input-gradient the tc layer is
+                    k = s.in_shape_ref[0]
+                    c, h, w = s.out, s.in_shape_ref[1] * s.stride, s.in_shape_ref[2] * s.stride
+                else:
+                    continue
+                fw = ops.wino_eligible(nf, h, w, c, k, s.R, s.stride, False)
+                bw = ops.wino_eligible(nb, h, w, c, k, s.R, s.stride, True)
+                if fw or bw:
+                    lead = (16,) if s.R == 3 else (4, 9)     # F(2x2,3x3) / F(2x2,2x2) on 4 parity segments
+                    self._wino[s.scope] = [torch.empty(lead + (c, k), device=dev) if fw else None,
+                                           torch.empty(lead + (k, c), device=dev) if bw else None, net]
         self._wino_jobs = [ops.WinoTransforms([(net.p(scope + '/kernel/kernel'), u, dg) for scope, (uf, ub, net) in self._wino.items()
                                                if net is which for u, dg in ((uf, False), (ub, True)) if u is not None])
                            for which in (self.gen, self.dis)]
@@ -1060,6 +1059,11 @@ class GanEngine:
                     self.dis.opt.prepare(self.lr_d)
                     self.gen.opt.prepare(self.lr_g)
                     ops.event_record(_EV_WINO_DIS, self._wg_raw)
+            else:                                            # no side stream (MMDGAN_SIDE_WGRAD=0): the same work on the main one
+                self._wino_jobs[0].run()
+                self._wino_jobs[1].run()
+                ops.event_record(_EV_WINO_GEN, main)
+                ops.event_record(_EV_WINO_DIS, main)
             # the small scratch buffers of the step (power-iteration scratch, batch-norm totals, split-K outputs): one launch
             ops.memset_zero_multi([t for t in self._zero_each_step if not any(t is a for a in arenas)])
             self._in_step = True
