@@ -498,13 +498,28 @@ class GanEngine:
             self._dp_backend = 'capi' if (dist_group is not None and tdist.get_backend(dist_group) == 'nccl') else 'torch'
         assert self._dp_backend in ('torch', 'capi'), self._dp_backend
         if self._dp_backend == 'capi' and dist_group is not None:
+            import torch.distributed as tdist
+            err = None
             try:
                 self._init_capi_comm()
-            except Exception as err:                     # no RCCL to bind, or its rendezvous failed: say so and carry on
+                # self-check: a SUM all-reduce of ones through the library's communicator gives the world size everywhere
+                probe = torch.ones(1024, device=self.device)
+                ops.check(ops.require_device().mmdgan_allreduce_bucket(probe.data_ptr(), probe.numel(), ops._stream()),
+                          'allreduce_bucket')
+                torch.cuda.synchronize()
+                if not bool((probe == float(self.world)).all()):
+                    raise RuntimeError('self-check all-reduce returned %r, expected %d' % (probe[:2].tolist(), self.world))
+            except Exception as e:                       # no RCCL to bind, its rendezvous failed, or it does not add up
+                err = e
+            # every rank takes the SAME decision: one rank without the library path means none uses it
+            flag = torch.tensor([0 if err is not None else 1], dtype=torch.int32,
+                                device=self.device if tdist.get_backend(dist_group) == 'nccl' else 'cpu')
+            tdist.all_reduce(flag, op=tdist.ReduceOp.MIN, group=dist_group)
+            if int(flag.item()) == 0:
                 import sys
                 if dp_backend == 'capi' or os.environ.get('MMDGAN_DP_BACKEND') == 'capi':
-                    raise
-                sys.stderr.write('mmdgan: library-owned RCCL exchange unavailable (%s); using torch.distributed\n' % err)
+                    raise RuntimeError('library-owned RCCL exchange unavailable on some rank (this rank: %s)' % (err,))
+                sys.stderr.write('mmdgan: library-owned RCCL exchange unavailable (this rank: %s); using torch.distributed\n' % (err,))
                 self._dp_backend = 'torch'
         # the power iterations of different layers are independent of each other too: two chains.
         # weight / bias gradients of a layer depend only on dz of that layer, not on the dgrad chain that
