@@ -292,18 +292,21 @@ static bool wino_enabled() {       // MMDGAN_WINO=0 keeps the 3x3 layers on the 
 // activation pass cost what the extra workgroups gain (D l7 forward 98 vs 92 direct, 3B dgrad 139 vs 101
 // unsplit) - so it is only used below 96 workgroups.  MMDGAN_WINO_MIN_TILES overrides (the parity tests use small
 // problems, which is also what exercises the split path).
-static long wino_min_tiles() {
-    static long v = -1;
-    if (v < 0) { const char *e = getenv("MMDGAN_WINO_MIN_TILES"); v = e ? atol(e) : 512; }
-    return v;
+// Round 3: with weights transformed by the caller a small launch splits its channel reduction over workspace slabs
+// (wino_launch) and fills the chip whatever its tile count, so the line for THAT form is 128 tiles: the 512 -> 512 block of the
+// ResNet-SN discriminator at 4x4 (384 tiles at 3B rows) 118 -> ~45 us per input-gradient, the ResNet step 4.92 -> 4.81 ms.
+static long wino_min_tiles(bool caller_transformed = false) {
+    static long v = -2;
+    if (v == -2) { const char *e = getenv("MMDGAN_WINO_MIN_TILES"); v = e ? atol(e) : -1; }
+    return v >= 0 ? v : (caller_transformed ? 128 : 512);
 }
 
-static bool wino_shape_ok(const ConvDims &d, int cr, int ko) {
+static bool wino_shape_ok(const ConvDims &d, int cr, int ko, bool caller_transformed = false) {
     return wino_enabled() && d.R == 3 && d.stride == 1 && d.pad == 1 && d.H % 2 == 0 && d.W % 2 == 0 && cr % wino::BC == 0 &&
-           cr >= 32 && ko % 64 == 0 && (long)d.N * (d.H / 2) * (d.W / 2) >= wino_min_tiles();
+           cr >= 32 && ko % 64 == 0 && (long)d.N * (d.H / 2) * (d.W / 2) >= wino_min_tiles(caller_transformed);
 }
-// would the library run this geometry through Winograd (given transformed weights or a workspace for them)?
-bool wino_eligible(const ConvDims &d, bool dgrad) { return dgrad ? wino_shape_ok(d, d.K, d.C) : wino_shape_ok(d, d.C, d.K); }
+// would the library run this geometry through Winograd, given transformed weights?
+bool wino_eligible(const ConvDims &d, bool dgrad) { return dgrad ? wino_shape_ok(d, d.K, d.C, true) : wino_shape_ok(d, d.C, d.K, true); }
 // (without transformed weights the call transforms into the workspace: not for batch-1 launches, which run on concurrent chains)
 bool wino_fwd_ok(const ConvDims &d) { return d.N > 1 && wino_shape_ok(d, d.C, d.K) && workspace(sizeof(float) * 16 * (size_t)d.C * d.K) != nullptr; }
 bool wino_dgrad_ok(const ConvDims &d) { return d.N > 1 && wino_shape_ok(d, d.K, d.C) && workspace(sizeof(float) * 16 * (size_t)d.C * d.K) != nullptr; }
