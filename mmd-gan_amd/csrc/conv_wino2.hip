@@ -859,7 +859,12 @@ bool wino2_wgrad_ok(const ConvDims &d) {
     if ((!en && wino2_mode() < 2) || wino2_mode() == 0) return false;
     if (d.N == 1) return false;     // batch-1 = a power iteration's launch, on a chain concurrent with others: no workspace slabs
     // the batch-1 weight gradients of the power iteration (64 tiles) stay direct: 7.7 us against 7 + the 6 us reduction pass
-    if (wino2_mode() < 2 && (long)d.N * (d.P / 2) * (d.Q / 2) < 256) return false;
+    // (64-255 tiles with enough channel blocks for a full round of workgroups - the ResNet generator's first up-sampling
+    // block, 512 x 1024 channels at 128 tiles - run here as well; MMDGAN_WINO2_WGRAD_MIN_TILES)
+    static long min_tiles = -1;
+    if (min_tiles < 0) { const char *e = getenv("MMDGAN_WINO2_WGRAD_MIN_TILES"); min_tiles = e ? atol(e) : 256; }
+    const long tiles = (long)d.N * (d.P / 2) * (d.Q / 2), blocks = (long)(d.C / wino2w::BC) * (d.K / wino2w::BK) * 4;
+    if (wino2_mode() < 2 && tiles < min_tiles && !(tiles >= 64 && blocks >= 192 && min_tiles <= 256)) return false;
     return d.R == 4 && d.stride == 2 && d.pad == 1 && d.H % 4 == 0 && d.W % 4 == 0 && d.C % wino2w::BC == 0 && d.K % wino2w::BK == 0;
 }
 
