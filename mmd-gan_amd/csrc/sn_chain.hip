@@ -5,12 +5,14 @@
 // small launches, ~45 per step for a DCGAN discriminator - batch-1 convolutions of 70 MFLOP that each occupy a few CUs
 // for 8-15 us on two side streams.  The chains of different kernels do not depend on each other, so here every STAGE of
 // all of them is one launch:
-//     0  patches of x (im2col)                       | form 1: P = x W^T
+//     0  patches of x (im2col)                       | form 1: P = x W^T                  (+ the sums of squares zeroed)
 //     1  u = patches . W                             | form 1: u = fold(P)            (col2im, gather form)
-//     2  sigma, scale = act_k / sigma, y             (one workgroup per kernel, sums in double: elementwise.hip:sn_norm_kernel)
-//     3  dsigma = patches^T . y ,  P' = y W^T        | form 1: patches of y
-//     4  F^T(y) = fold(P')                           | form 1: dsigma = patches(y)^T . x ,  F^T(y) = patches(y) . W
-//     5  x <- F^T(y) / (||F^T(y)|| + eps)
+//     2  sum of squares of u                         (4096 elements per workgroup, double, one atomic each)
+//     3  sigma, scale = act_k / sigma, y = u / (sigma + eps)        (elementwise.hip:sn_norm_kernel's arithmetic)
+//     4  dsigma = patches^T . y ,  P' = y W^T        | form 1: patches of y
+//     5  F^T(y) = fold(P')                           | form 1: dsigma = patches(y)^T . x ,  F^T(y) = patches(y) . W
+//     6  sum of squares of F^T(y)
+//     7  x <- F^T(y) / (||F^T(y)|| + eps)
 // A batch-1 convolution IS a small matrix product on its patch matrix [P*Q, R*R*C] (a few MB at most), the HWIO kernel is
 // its [R*R*C, K] operand as it lies, and the weight gradient comes out in HWIO layout: one tiled fp32-MFMA product serves
 // every stage (operands addressed through two strides each, so transposes cost nothing; long reductions split over
