@@ -30,7 +30,7 @@ if [ "${2:-all}" = "probes" ]; then exit 0; fi
 # 5. whole-step MFMA busy: the SQ counters over every kernel of 8 eagerly issued single-stream steps
 MMDGAN_SIDE_WGRAD=0 MMDGAN_SN_STREAMS=1 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_step -o s -- $B --steps 5 --warmup 3 --repeats 1 --launch-mode eager --no-cpu-baseline > /dev/null 2> $OUT/pmc_step.err
 # 6. the ResNet-SN config: kernel stats of its bench command
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/resnet -o r -- $B --config lsun_resnet --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline > $OUT/bench_resnet_profiled.json 2> $OUT/bench_resnet.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/resnet -o r -- $B --config lsun_resnet --steps 10 --warmup 3 --repeats 1 --launch-mode eager --no-cpu-baseline > $OUT/bench_resnet_profiled.json 2> $OUT/bench_resnet.err
 ls $OUT
 cd $R
 BENCH_DGRAD_3B=1 python tools/bench_conv.py 64 > $OUT/conv_layers.txt 2>&1

@@ -116,8 +116,8 @@ summary('default', 'g', trial_steps(os.path.join(src, 'bench_default_profiled.js
 summary('single', 'e', 28, tag + '_kernel_stats_single_stream.txt',
         '# MMDGAN_SIDE_WGRAD=0 MMDGAN_SN_STREAMS=1 rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --launch-mode eager --no-cpu-baseline')
 if find('resnet', '_kernel_stats.csv'):
-    summary('resnet', 'r', 13, tag + '_resnet_kernel_stats.txt',
-            '# rocprofv3 --kernel-trace --stats -- python bench.py --config lsun_resnet --steps 10 --warmup 3 --no-cpu-baseline')
+    summary('resnet', 'r', 16, tag + '_resnet_kernel_stats.txt',      # 3 warm-up + 3 after the launch mode is set + 10 timed steps
+            '# rocprofv3 --kernel-trace --stats -- python bench.py --config lsun_resnet --steps 10 --warmup 3 --launch-mode eager --no-cpu-baseline')
 tl = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'step_timeline.py'), os.path.join(src, 'timeline')],
                     capture_output=True, text=True).stdout
 open(os.path.join(dst, tag + '_step_timeline.txt'), 'w').write(
