@@ -31,8 +31,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md (f32
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--config', default='cifar', choices=['cifar', 'stl', 'celeba', 'lsun_resnet'])
     ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: 64; 128 for celeba; 32 for lsun_resnet = 256 on 8 GPUs)')
     ap.add_argument('--loss', default='rep', choices=['rep', 'rmb'])
