@@ -426,6 +426,17 @@ int mmdgan_max_pool(const float *x, const float *dy, float *out, int N, int P, i
  * with w [3,3,C,K] the block's HWIO kernel.  grad = 1 is the adjoint: src = the gradient w.r.t. the 4x4 kernel (same
  * layout as dst above), dst [3,3,C,K] = the gradient w.r.t. w (overwritten). */
 int mmdgan_compose_scaled_conv(const float *src, float *dst, int C, int K, int mode, int grad, void *stream);
+/* The 'padding' and 'dilation' keys of a conv layer (layer_func.py:541-556, 912-916; math_func.py:172-193) as compositions
+ * around the 'SAME' kernels above, NHWC:
+ *   'VALID', kernel R, stride s, dilation d:  y = slice(conv_SAME_stride1(x)) with off = d * ((R-1)/2), step = s,
+ *        P = ceil((H - (R-1) d) / s);  backward: the adjoint scatter (every element of the large tensor written), then the
+ *        stride-1 input- / weight-gradient
+ *   dilation d (stride 1, odd R):  y = from_batch(conv_SAME(to_batch(x))) on the d*d phase images of ceil(H/d) x ceil(W/d)
+ * strided_slice: adjoint = 0: src [N,H,W,C] -> dst [N,P,Q,C]; adjoint = 1: src [N,P,Q,C] -> dst [N,H,W,C].
+ * space_batch: to_batch = 1: src [N,H,W,C] -> dst [N*d*d, ceil(H/d), ceil(W/d), C] (zeros beyond the image); 0: the reverse. */
+int mmdgan_strided_slice(const float *src, float *dst, int N, int H, int W, int C, int off, int step, int P, int Q,
+                         int adjoint, void *stream);
+int mmdgan_space_batch(const float *src, float *dst, int N, int H, int W, int C, int dilation, int to_batch, void *stream);
 int mmdgan_act_fwd(const float *x, float *y, long n, int act, void *stream);
 int mmdgan_act_bwd(const float *dy, const float *y, float *dx, long n, int act, int accumulate, void *stream);
 int mmdgan_axpby(const float *a, float alpha, const float *b, float beta, float *out, long n, void *stream);

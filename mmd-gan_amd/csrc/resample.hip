@@ -317,6 +317,62 @@ __global__ __launch_bounds__(256) void axpby_kernel(const float *__restrict__ a,
     for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < n; o += stride) out[o] = alpha * a[o] + beta * b[o];
 }
 
+// ---- the 'padding' / 'dilation' keys of a conv layer as compositions around the 'SAME' stride-1 kernels -------------------
+// strided slice: dst[n][p][q][c] = src[n][off + p*step][off + q*step][c]; adjoint = 1: src is the small tensor, dst the
+// large one - every element of dst is written (the slice's positions get their value, the others zero): no zeroing, no atomics
+__global__ __launch_bounds__(256) void strided_slice_kernel(const float *__restrict__ src, float *__restrict__ dst, int N, int H,
+                                                            int W, int C, int off, int step, int P, int Q, int adjoint) {
+    const long total = adjoint ? (long)N * H * W * C : (long)N * P * Q * C;
+    const long stride = (long)gridDim.x * 256;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {
+        const int c = (int)(o % C);
+        long t = o / C;
+        if (!adjoint) {
+            const int q = (int)(t % Q);
+            t /= Q;
+            const int p = (int)(t % P), n = (int)(t / P);
+            dst[o] = src[(((long)n * H + off + p * step) * W + off + q * step) * C + c];
+        } else {
+            const int w = (int)(t % W);
+            t /= W;
+            const int h = (int)(t % H), n = (int)(t / H);
+            const int hp = h - off, wq = w - off;
+            const bool hit = hp >= 0 && wq >= 0 && hp % step == 0 && wq % step == 0 && hp / step < P && wq / step < Q;
+            dst[o] = hit ? src[(((long)n * P + hp / step) * Q + wq / step) * C + c] : 0.f;
+        }
+    }
+}
+// space <-> batch for a dilated conv (dilation d, stride 1): image n splits into d*d phase images of ceil(H/d) x ceil(W/d)
+// (zero rows / columns where the size is no multiple of d - they act as the 'SAME' padding of the phase conv):
+//   to_batch:  dst[(n*d + ph)*d + pw][hq][wq][c] = src[n][hq*d + ph][wq*d + pw][c]  (0 beyond the image)
+//   from batch: dst[n][h][w][c] = src[(n*d + h%d)*d + w%d][h/d][w/d][c]             - each the other's adjoint
+__global__ __launch_bounds__(256) void space_batch_kernel(const float *__restrict__ src, float *__restrict__ dst, int N, int H,
+                                                          int W, int C, int d, int to_batch) {
+    const int Hd = (H + d - 1) / d, Wd = (W + d - 1) / d;
+    const long total = to_batch ? (long)N * d * d * Hd * Wd * C : (long)N * H * W * C;
+    const long stride = (long)gridDim.x * 256;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {
+        const int c = (int)(o % C);
+        long t = o / C;
+        if (to_batch) {
+            const int wq = (int)(t % Wd);
+            t /= Wd;
+            const int hq = (int)(t % Hd);
+            t /= Hd;
+            const int pw = (int)(t % d);
+            t /= d;
+            const int ph = (int)(t % d), n = (int)(t / d);
+            const int h = hq * d + ph, w = wq * d + pw;
+            dst[o] = (h < H && w < W) ? src[(((long)n * H + h) * W + w) * C + c] : 0.f;
+        } else {
+            const int w = (int)(t % W);
+            t /= W;
+            const int h = (int)(t % H), n = (int)(t / H);
+            dst[o] = src[((((long)n * d + h % d) * d + w % d) * Hd + h / d) * Wd * C + (long)(w / d) * C + c];
+        }
+    }
+}
+
 static inline int grid_of(long n) {
     long b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -353,6 +409,26 @@ extern "C" int mmdgan_resample_up(const float *x, float *y, int N, int P, int Q,
         hipLaunchKernelGGL(resample_up_kernel<1>, dim3(grid_of(total)), dim3(256), 0, st, x, y, total, P, Q, C, factor, scale, accumulate);
     }
     return check_launch("resample_up");
+}
+
+extern "C" int mmdgan_strided_slice(const float *src, float *dst, int N, int H, int W, int C, int off, int step, int P, int Q,
+                                    int adjoint, void *stream) {
+    MMDGAN_REQUIRE(src && dst && N >= 1 && H >= 1 && W >= 1 && C >= 1 && off >= 0 && step >= 1 && P >= 1 && Q >= 1 &&
+                   off + (P - 1) * step < H && off + (Q - 1) * step < W, "strided_slice: bad arguments");
+    const long total = adjoint ? (long)N * H * W * C : (long)N * P * Q * C;
+    hipLaunchKernelGGL(strided_slice_kernel, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, src, dst, N, H, W, C, off, step,
+                       P, Q, adjoint);
+    return check_launch("strided_slice");
+}
+
+extern "C" int mmdgan_space_batch(const float *src, float *dst, int N, int H, int W, int C, int dilation, int to_batch,
+                                  void *stream) {
+    MMDGAN_REQUIRE(src && dst && N >= 1 && H >= 1 && W >= 1 && C >= 1 && dilation >= 1, "space_batch: bad arguments");
+    const int Hd = (H + dilation - 1) / dilation, Wd = (W + dilation - 1) / dilation;
+    const long total = to_batch ? (long)N * dilation * dilation * Hd * Wd * C : (long)N * H * W * C;
+    hipLaunchKernelGGL(space_batch_kernel, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, src, dst, N, H, W, C, dilation,
+                       to_batch);
+    return check_launch("space_batch");
 }
 
 extern "C" int mmdgan_act_fwd(const float *x, float *y, long n, int act, void *stream) {

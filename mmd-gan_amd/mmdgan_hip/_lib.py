@@ -81,6 +81,8 @@ SIGNATURES = {
     'mmdgan_bicubic_resize': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'mmdgan_max_pool': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'mmdgan_compose_scaled_conv': (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    'mmdgan_strided_slice': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'mmdgan_space_batch': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'mmdgan_act_fwd': (_I, [_P, _P, _L, _I, _P]),
     'mmdgan_act_bwd': (_I, [_P, _P, _P, _L, _I, _I, _P]),
     'mmdgan_axpby': (_I, [_P, _F, _P, _F, _P, _L, _P]),

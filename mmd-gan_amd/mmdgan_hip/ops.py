@@ -753,6 +753,39 @@ def act_fwd(x, act, out=None):
     return out
 
 
+def strided_slice(x, off, step, out_hw, out=None, adjoint_hw=None):
+    """x [N,H,W,C] -> [N,P,Q,C] = x[:, off + p*step, off + q*step]; adjoint_hw=(H, W): x is [N,P,Q,C] and the result the
+    [N,H,W,C] tensor with x at those positions and zeros elsewhere (every element written)"""
+    lib = require_device()
+    if adjoint_hw is None:
+        n, h, w, c = x.shape
+        p, q = out_hw
+        out = out if out is not None else torch.empty((n, p, q, c), device=x.device, dtype=torch.float32)
+        check(lib.mmdgan_strided_slice(_p(x), _p(out), n, h, w, c, int(off), int(step), p, q, 0, _stream()), 'strided_slice')
+    else:
+        n, p, q, c = x.shape
+        h, w = adjoint_hw
+        out = out if out is not None else torch.empty((n, h, w, c), device=x.device, dtype=torch.float32)
+        check(lib.mmdgan_strided_slice(_p(x), _p(out), n, h, w, c, int(off), int(step), p, q, 1, _stream()), 'strided_slice')
+    return out
+
+
+def space_batch(x, d, hw=None, out=None):
+    """hw=None: x [N,H,W,C] -> the d*d phase images [N*d*d, ceil(H/d), ceil(W/d), C] (zeros beyond the image);
+    hw=(H, W): the reverse, x [N*d*d, ceil(H/d), ceil(W/d), C] -> [N,H,W,C]"""
+    lib = require_device()
+    if hw is None:
+        n, h, w, c = x.shape
+        out = out if out is not None else torch.empty((n * d * d, -(-h // d), -(-w // d), c), device=x.device, dtype=torch.float32)
+        check(lib.mmdgan_space_batch(_p(x), _p(out), n, h, w, c, int(d), 1, _stream()), 'space_batch')
+    else:
+        h, w = hw
+        n, c = x.shape[0] // (d * d), x.shape[3]
+        out = out if out is not None else torch.empty((n, h, w, c), device=x.device, dtype=torch.float32)
+        check(lib.mmdgan_space_batch(_p(x), _p(out), n, h, w, c, int(d), 0, _stream()), 'space_batch')
+    return out
+
+
 def act_bwd(dy, y, act, out=None, accumulate=False):
     """dx (+)= dy * act'(.), the derivative taken from the activation's output y"""
     lib = require_device()

@@ -29,9 +29,13 @@ _PIM = ('sn_paper', 'PIM', 'pim')
 
 
 def needs_primitive_ops(designs):
-    """a net the hand-scheduled chain does not express: residual blocks, identity layers, scaling ops, an input reshape"""
+    """a net the hand-scheduled chain does not express: residual blocks, identity layers, scaling ops, an input reshape,
+    'VALID' padding, dilation"""
+    def plain(v, default):
+        return all(x == default for x in v) if isinstance(v, (list, tuple)) else v == default
     return any(d.get('type', 'default') in RES_TYPES or d.get('op') == 'i' or d.get('scale') is not None
-               or d.get('in_reshape') is not None for d in designs)
+               or d.get('in_reshape') is not None or not plain(d.get('dilation', 1), 1) or not plain(d.get('padding', 'SAME'), 'SAME')
+               for d in designs)
 
 
 def has_residual_blocks(architecture):
@@ -59,6 +63,7 @@ class _Kernel:
         self.out = kernel_shape[-1] if out is None else out           # a tc kernel is [R, R, out, in]
         self.sn, self.act_k, self.pim = w_nm == 's', act_k, False
         self.fold = None                                                 # 'unpool' / 'avg': scaling folded into this conv
+        self.dil, self.valid = 1, False                                  # the layer's 'dilation' / 'padding' keys (_conv)
         self.row_perm = self.col_perm = None                             # dense kernels at an NCHW <-> NHWC seam
         if w_nm not in (None, 's'):
             raise NotImplementedError('{}: {} method not implemented'.format(scope, w_nm))       # layer_func.py:824
@@ -134,8 +139,32 @@ class _Net:
         if ref_hw is not None:                           # a 1x1 conv moved across its block's scaling op: the kernel keeps
             h, w = ref_hw                                # the reference's geometry (spectral norm), the launch runs on x
         R, stride, out = _pick(d['kernel'], index), _pick(d['strides'], index), _pick(d['out'], index)
-        if _pick(d['dilation'], index) != 1 or _pick(d['padding'], index) != 'SAME':
-            raise NotImplementedError('{}: dilation / VALID are not built'.format(scope))
+        dil, padding = _pick(d['dilation'], index), _pick(d['padding'], index)
+        if stride > 1 and dil > 1:                                       # layer_func.py:546-549
+            dil = 1
+        if padding not in ('SAME', 'same', 'VALID', 'valid'):
+            raise NotImplementedError('{}: padding {} is not known'.format(scope, padding))
+        valid = padding in ('VALID', 'valid')
+        if dil != 1 or valid:
+            # the 'dilation' / 'padding' keys (layer_func.py:541-556, 912-916; shapes math_func.py:172-193): compositions around the
+            # 'SAME' kernels (TapeEngine._gconv_*; include/mmdgan_hip.h: mmdgan_strided_slice, mmdgan_space_batch)
+            if fold is not None or ref_hw is not None:
+                raise NotImplementedError('{}: dilation / VALID inside a block with scaling are not built'.format(scope))
+            if dil > 1 and R % 2 == 0:
+                raise NotImplementedError('{}: dilation on an even kernel is not built'.format(scope))
+            ext = (R - 1) * dil
+            if valid and (h <= ext or w <= ext):
+                raise AssertionError('{}: a {}x{} input is smaller than the dilated {}x{} kernel'.format(scope, h, w, ext + 1, ext + 1))
+            out_ref = [out, -(-(h - ext) // stride), -(-(w - ext) // stride)] if valid else [out, -(-h // stride), -(-w // stride)]
+            k = _Kernel('{}/{}'.format(scope, opname), 'c', [R, R, c, out], [c, h, w], out_ref, _pick(d['act'], index),
+                        _pick(d['w_nm'], index), _pick(d['act_k'], index), bias_name, stride, self.sn_mode)
+            k.dil, k.valid = dil, valid
+            if k.sn and not k.pim and dil > 1:
+                # math_func.py:613-616, 630-634: tf.nn.atrous_conv2d(_transpose), NHWC-only ops on the NCHW tensors of the reference's
+                # default data format - not a defined computation
+                raise NotImplementedError('{}: spectral norm (default mode) on a dilated kernel'.format(scope))
+            self.kernels.append(k)
+            return self._emit('gconv', [x], out_ref, k=k)
         out_ref = [out, -(-h // stride), -(-w // stride)]
         k = _Kernel('{}/{}'.format(scope, opname), 'c', [R, R, c, out], [c, h, w], out_ref, _pick(d['act'], index),
                     _pick(d['w_nm'], index), _pick(d['act_k'], index), bias_name, stride, self.sn_mode)
@@ -411,7 +440,7 @@ class _Net:
     def _creation_order(self):
         """kernels and BN ops in the order the primitives use them (= the reference's variable creation order)"""
         for p in self.prims:
-            if p['kind'] in ('dense', 'conv', 'tconv', 'upconv', 'convdown'):
+            if p['kind'] in ('dense', 'conv', 'gconv', 'tconv', 'upconv', 'convdown'):
                 yield p['k']
             elif p['kind'] == 'bn':
                 yield (p['prefix'], self.shapes[p['out']][0])
@@ -618,7 +647,7 @@ class TapeEngine:
                     cin, cout = k.kernel_shape[2], k.out
                     shape = (4, 4, cin, cout) if k.fold == 'avg' else (4, 4, cout, cin)
                     self._folded[k.scope] = [torch.zeros(shape, device=self.device), None]
-                if k.op not in ('c', 'tc') or not self._side:
+                if k.op not in ('c', 'tc') or not self._side or k.dil != 1 or k.valid:
                     continue
                 R, stride = (4, 2) if k.fold is not None else (k.R, k.stride)
                 as_conv = k.op == 'c' and k.fold != 'unpool'
@@ -702,6 +731,8 @@ class TapeEngine:
         w, st = net.p(k.w_name), net.sn[k.scope]
         if (k.op == 'd' or k.pim) and 1 in (int(np.prod(w.shape[:-1])), w.shape[-1]):
             return None
+        if not (k.op == 'd' or k.pim) and (k.dil != 1 or k.valid):      # a composition: its own chain of launches (_sn_step)
+            return None
         L = dict(w=w, x=net.state[k.scope + '/SN/in_rand'], sigma=st['sigma'], scale=st['scale'], dsigma=st['dsigma'], u=st['u'],
                  un=st['un'], xb=st['xb'], xb_norm=st['xbn'], act_k=k.act_k)
         if k.op == 'd' or k.pim:
@@ -722,6 +753,61 @@ class TapeEngine:
         fused[0].run(update=True)
         for k in fused[1]:
             self._sn_step(net, k)
+
+    # ---- conv layers with 'padding': 'VALID' and / or 'dilation' > 1 (layer_func.py:541-556, 912-916) ------------------
+    # compositions around the 'SAME' kernels: dilation d (stride 1) = the 'SAME' conv of each of the d*d phase images (space <->
+    # batch, zero rows where the size is no multiple of d); 'VALID' = the stride-1 'SAME' result sampled at off + p * stride
+    # with off = d * ((R - 1) // 2); the gradients take the adjoint ops.  key: buffer key prefix of the caller.
+    def _gconv_slice(self, k):
+        return k.dil * ((k.R - 1) // 2), k.stride, (k.out_ref[1], k.out_ref[2])
+
+    def _gconv_fwd(self, k, a, w, key, bias=None, scale=None, out=None):
+        n, h, wd = a.shape[0], a.shape[1], a.shape[2]
+        d, K = k.dil, w.shape[3]
+        s_eff = 1 if k.valid else k.stride
+        xin = ops.space_batch(a, d, out=self._buf(key + ('xb',), [n * d * d, -(-h // d), -(-wd // d), a.shape[3]])) if d > 1 else a
+        hf, wf = -(-xin.shape[1] // s_eff), -(-xin.shape[2] // s_eff)
+        last = d == 1 and not k.valid
+        full = out if last else self._buf(key + ('full',), [xin.shape[0], hf, wf, K])
+        if n == 1 and self._sn_zeroed:                   # a batch-1 launch may split into an output it expects zeroed
+            ops.memset_zero(full)
+        ops.conv2d_fwd(xin, w, s_eff, bias=bias, scale=scale, out=full)
+        if d > 1:
+            full = ops.space_batch(full, d, hw=(h, wd), out=out if not k.valid else self._buf(key + ('unb',), [n, h, wd, K]))
+        if k.valid:
+            off, step, (P, Q) = self._gconv_slice(k)
+            full = ops.strided_slice(full, off, step, (P, Q), out=out)
+        return full
+
+    def _gconv_dy(self, k, dy, in_hw, key):
+        """the output gradient as the kernel launches see it: un-sliced ('VALID'), split into phase images (dilation)"""
+        h, wd = in_hw
+        if k.valid:
+            off, step, _ = self._gconv_slice(k)
+            dy = ops.strided_slice(dy, off, step, None, adjoint_hw=(h, wd), out=self._buf(key + ('dyf',), [dy.shape[0], h, wd, dy.shape[3]]))
+        if k.dil > 1:
+            d = k.dil
+            dy = ops.space_batch(dy, d, out=self._buf(key + ('dyb',), [dy.shape[0] * d * d, -(-h // d), -(-wd // d), dy.shape[3]]))
+        return dy
+
+    def _gconv_dgrad(self, k, dy, w, in_hw, key, scale=None, out=None, dy_ready=None):
+        h, wd = in_hw
+        n, d, C = dy.shape[0], k.dil, w.shape[2]
+        s_eff = 1 if k.valid else k.stride
+        dyk = dy_ready if dy_ready is not None else self._gconv_dy(k, dy, in_hw, key)
+        hd, wdd = -(-h // d), -(-wd // d)
+        dxb = out if d == 1 else self._buf(key + ('dxb',), [n * d * d, hd, wdd, C])
+        if n == 1 and self._sn_zeroed:
+            ops.memset_zero(dxb)
+        ops.conv2d_dgrad(dyk, w, (hd, wdd), s_eff, scale=scale, out=dxb)
+        return ops.space_batch(dxb, d, hw=(h, wd), out=out) if d > 1 else dxb
+
+    def _gconv_wgrad(self, k, a, dy, key, out, dbias=None, w=None, dot=None, dy_ready=None):
+        h, wd, d = a.shape[1], a.shape[2], k.dil
+        s_eff = 1 if k.valid else k.stride
+        dyk = dy_ready if dy_ready is not None else self._gconv_dy(k, dy, (h, wd), key)
+        xin = ops.space_batch(a, d, out=self._buf(key + ('xbw',), [a.shape[0] * d * d, -(-h // d), -(-wd // d), a.shape[3]])) if d > 1 else a
+        ops.conv2d_wgrad(xin, dyk, k.R, s_eff, out=out, dbias=dbias, w=w, dot=dot)
 
     # ---- spectral norm (math_func.py:661-672), as engine.py:_sn_step -------------------------------------------
     def _sn_step(self, net, k, update=True):
@@ -749,6 +835,23 @@ class TapeEngine:
                 if update:
                     ops.gemm(un, x, trans_a=True, out=dsig, out_zeroed=oz)
                     ops.gemm(un, w, out=xb, out_zeroed=oz)
+                    ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
+        elif k.dil != 1 or k.valid:                                      # a 'VALID' conv (dilated ones are refused at lowering)
+            h, wd = k.in_ref[1:]
+            key = ('sn', k.scope)
+            if k.use_u:
+                self._gconv_fwd(k, x, w, key + ('f',), out=u)
+                ops.sn_norm_scale(u.view(-1), k.act_k, sigma, scale, un.view(-1))
+                if update:
+                    self._gconv_wgrad(k, x, un, key + ('w',), out=dsig)
+                    self._gconv_dgrad(k, un, w, (h, wd), key + ('b',), out=xb)
+                    ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
+            else:
+                self._gconv_dgrad(k, x, w, (h, wd), key + ('f',), out=u)
+                ops.sn_norm_scale(u.view(-1), k.act_k, sigma, scale, un.view(-1))
+                if update:
+                    self._gconv_wgrad(k, un, x, key + ('w',), out=dsig)
+                    self._gconv_fwd(k, un, w, key + ('b',), out=xb)
                     ops.sn_norm(xb.view(-1), True, out_norm=xbn, out_v=x.view(-1))
         else:
             h, wd = (k.in_ref if k.op == 'c' else k.out_ref)[1:]         # input of the conv ('tc': the layer's OUTPUT)
@@ -800,6 +903,11 @@ class TapeEngine:
                 else:
                     ops.conv2d_fwd(a, net.p(k.w_name), k.stride, bias=bias, scale=scale, out=y,
                                    wino=self._wino_of(k, False, n) if (training and self._in_step) else None)
+            elif kind == 'gconv':                                        # 'VALID' padding and / or dilation: a composition
+                k = p['k']
+                scale = net.sn[k.scope]['scale'] if k.sn else None
+                bias = net.p(k.bias_name) if k.bias_name is not None else None
+                y = self._gconv_fwd(k, a, net.p(k.w_name), key, bias=bias, scale=scale, out=self._buf_of(key, out_shape))
             elif kind in ('upconv', 'convdown'):                         # a conv with its block's scaling op folded in
                 k = p['k']
                 scale = net.sn[k.scope]['scale'] if k.sn else None
@@ -859,7 +967,7 @@ class TapeEngine:
         return vals
 
     # ---- backward ---------------------------------------------------------------------------------------------
-    _ROW_WISE = ('reshape', 'dense', 'conv', 'upconv', 'convdown', 'tconv', 'act', 'down', 'up', 'shuffle', 'add')
+    _ROW_WISE = ('reshape', 'dense', 'conv', 'gconv', 'upconv', 'convdown', 'tconv', 'act', 'down', 'up', 'shuffle', 'add')
 
     def _graph_of(self, net):
         """value id -> the primitive that produces it, value id -> number of consumers (the net's output counts as one)"""
@@ -929,11 +1037,11 @@ class TapeEngine:
                 continue
             kind, dy = p['kind'], grads.pop(p['out'])
             vin = p['ins'][0]
-            if vin == 0 and not need_input_grad and kind not in ('dense', 'conv', 'tconv', 'upconv', 'convdown', 'bn'):
+            if vin == 0 and not need_input_grad and kind not in ('dense', 'conv', 'gconv', 'tconv', 'upconv', 'convdown', 'bn'):
                 continue
             key = (tag, net.name, i, 'd')
             a = sl(vals[vin])
-            if kind in ('dense', 'conv', 'upconv', 'convdown', 'tconv'):
+            if kind in ('dense', 'conv', 'gconv', 'upconv', 'convdown', 'tconv'):
                 k = p['k']
                 w = net.p(k.w_name)
                 scale = net.sn[k.scope]['scale'] if k.sn else None
@@ -943,7 +1051,7 @@ class TapeEngine:
                 # the input-gradient.  An activation in front of this primitive that nothing else reads: its derivative rides
                 # on the epilogue (dact_of = the activation's output), the gradient goes straight to the activation's input
                 q = producer.get(vin)
-                fuse = q is not None and q['kind'] == 'act' and uses.get(vin, 0) == 1 and vin not in grads
+                fuse = q is not None and q['kind'] == 'act' and uses.get(vin, 0) == 1 and vin not in grads and kind != 'gconv'
                 tgt = q['ins'][0] if fuse else vin
                 if tgt == 0 and not need_input_grad:
                     continue
@@ -966,6 +1074,8 @@ class TapeEngine:
                 elif kind == 'conv':
                     ops.conv2d_dgrad(dyx, w, (in_shape[1], in_shape[2]), k.stride, scale=scale, act=act, dact_of=dact,
                                      dact_batch=dact_batch, out=dx, wino=self._wino_of(k, True, nx))
+                elif kind == 'gconv':                        # 'VALID' / dilated: the adjoint composition
+                    self._gconv_dgrad(k, dyx, w, (in_shape[1], in_shape[2]), key + ('x',), scale=scale, out=dx)
                 elif kind == 'convdown':
                     ops.conv2d_dgrad(dyx, self._folded[k.scope][0], (in_shape[1], in_shape[2]), 2, scale=scale, act=act,
                                      dact_of=dact, dact_batch=dact_batch, out=dx, wino=self._wino_of(k, True, nx))
@@ -1041,6 +1151,9 @@ class TapeEngine:
         elif kind == 'conv':                                             # (<G, W> rides on the weight-gradient launch)
             ops.conv2d_wgrad(a, dy, k.R, k.stride, out=gw, dbias=gb, w=w if k.sn else None, dot=dot)
             dot_done = True
+        elif kind == 'gconv':                                            # 'VALID' / dilated
+            self._gconv_wgrad(k, a, dy, ('pg', net.name, k.scope), out=gw, dbias=gb, w=w if k.sn else None, dot=dot)
+            dot_done = True
         elif kind == 'tconv':                                            # W[R,R,out,in]: roles swapped
             if gb is not None:
                 ops.colsum(dy.reshape(-1, dy.shape[-1]), out=gb)
@@ -1109,7 +1222,7 @@ class TapeEngine:
         target = int(float(os.environ.get('MMDGAN_DP_BUCKET_MB', '8')) * (1 << 20)) // 4
         ranges = []
         for p in net.prims:
-            if p['kind'] in ('dense', 'conv', 'tconv', 'upconv', 'convdown'):
+            if p['kind'] in ('dense', 'conv', 'gconv', 'tconv', 'upconv', 'convdown'):
                 names = [p['k'].w_name] + ([p['k'].bias_name] if p['k'].bias_name is not None else [])
             elif p['kind'] == 'bn':
                 names = [p['prefix'] + '/BN/gamma', p['prefix'] + '/BN/beta']

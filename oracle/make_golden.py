@@ -302,9 +302,22 @@ def run_net_case(designs, net_name, input_shape, batch, seed, n_steps=2):
     return out
 
 
-def make_layers():
+def make_layers(only=None):
     ak = float(np.power(64.0, 0.125))
     cases = {
+        # the 'padding' and 'dilation' keys of the layer dict (layer_func.py:541-556, 912-916; math_func.py:172-193): 'VALID'
+        # convs with and without spectral norm (k3 s1, k4 s2, k3 s2), dilated k3 convs ('SAME' and 'VALID'; no spectral norm:
+        # the reference's SpectralNorm sends dilated kernels through NHWC-only atrous ops), dilation ignored at stride 2 ('SAME'
+        # only: with 'VALID' the reference's shape inference counts the ignored dilation and trips its own output check)
+        'dis_valid_dil': ([{'name': 'l1_v', 'out': 8, 'act': 'lrelu', 'act_k': ak, 'w_nm': 's', 'padding': 'VALID'},
+                           {'name': 'l2_dil', 'out': 16, 'act': 'lrelu', 'dilation': 2},
+                           {'name': 'l3_vs2', 'out': 16, 'act': 'lrelu', 'act_k': ak, 'w_nm': 's', 'kernel': 4, 'strides': 2,
+                            'padding': 'VALID'},
+                           {'name': 'l4_dilv', 'out': 24, 'act': 'relu', 'dilation': 2, 'padding': 'VALID'},
+                           {'name': 'l5_s2d', 'out': 32, 'act': 'lrelu', 'strides': 2, 'dilation': 2,
+                            'out_reshape': [4 * 5 * 32]},
+                           {'name': 'l6_s', 'out': 16, 'op': 'd', 'act_k': ak, 'bias': 'b', 'w_nm': 's'}],
+                          'dis', [3, 26, 30], 6),
         # D-style SN conv layers: k3s1 (use_u) and k4s2 (not use_u), + dense SN head with C,H,W flatten
         'dis_small': ([{'name': 'l1_f32', 'out': 8, 'act': 'lrelu', 'act_k': ak, 'w_nm': 's'},
                        {'name': 'l2_ds', 'out': 16, 'act': 'lrelu', 'act_k': ak, 'w_nm': 's', 'kernel': 4, 'strides': 2},
@@ -332,6 +345,8 @@ def make_layers():
                     'dis', [5, 12, 12], 3),
     }
     for name, (designs, net_name, in_shape, batch) in cases.items():
+        if only is not None and name not in only:
+            continue
         fx = run_net_case(designs, net_name, in_shape, batch, seed=zlib.crc32(name.encode()) % 1000)
         fx['designs_repr'] = np.asarray(repr(designs))
         fx['input_shape'] = np.asarray(in_shape)
@@ -696,6 +711,11 @@ if __name__ == '__main__':
         make_step('rep', arch_fn=tiny_gsn_architecture, tag='gsn_rep')
         make_step('rmb', sn_mode='sn_paper', arch_fn=tiny_gsn_architecture, tag='gsn_rmb_pim')
         make_step_warm('rep', arch_fn=tiny_gsn_architecture, tag='gsn_rep', data_seed=int(os.environ.get('GSN_SEED', '99')))
+        sys.exit(0)
+    if '--only-valid' in sys.argv:
+        torch.manual_seed(0)
+        torch.set_num_threads(4)
+        make_layers(only=('dis_valid_dil',))
         sys.exit(0)
     if '--only-bic' in sys.argv:
         torch.manual_seed(0)

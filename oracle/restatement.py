@@ -237,6 +237,22 @@ def _same_out(size, stride):
     return -(-size // stride)          # math_func.py:172-193 ('SAME')
 
 
+def _conv_geometry(d):
+    """(stride, dilation, padding) of a conv design as the reference applies them: dilation is ignored when the stride is
+    above 1 (layer_func.py:546-549)"""
+    stride, dil = d['strides'], d.get('dilation', 1)
+    if stride > 1 and dil > 1:
+        dil = 1
+    return stride, dil, d.get('padding', 'SAME')
+
+
+def _conv_out(size, kernel, stride, dil, padding):
+    """spatial_shape_after_conv, math_func.py:172-193"""
+    if padding in ('same', 'SAME'):
+        return -(-size // stride)
+    return -(-(size - (kernel - 1) * dil) // stride)
+
+
 def build_net(designs, input_shape, net_name, sn_mode='default'):
     """Net + Routine.add_input_layers/seq_links shape inference (layer_func.py:2118,2221,2349).
 
@@ -274,8 +290,11 @@ def build_net(designs, input_shape, net_name, sn_mode='default'):
         elif d['op'] == 'c':                                 # layer_func.py:579-589
             c, h, w = shape
             s['kernel_shape'] = [d['kernel'], d['kernel'], c, d['out']]
-            out = [d['out'], _same_out(h, d['strides']), _same_out(w, d['strides'])]
+            st_, dil_, pad_ = _conv_geometry(d)
+            out = [d['out'], _conv_out(h, d['kernel'], st_, dil_, pad_), _conv_out(w, d['kernel'], st_, dil_, pad_)]
         else:                                                # 'tc', layer_func.py:590-600
+            if d.get('dilation', 1) != 1 or d.get('padding', 'SAME') != 'SAME':
+                raise NotImplementedError('{}: dilation / VALID on a transposed conv are not restated'.format(s['scope']))
             c, h, w = shape
             s['kernel_shape'] = [d['kernel'], d['kernel'], d['out'], c]
             out = [d['out'], h * d['strides'], w * d['strides']]
@@ -392,23 +411,27 @@ def trainable_names(params):
 # ---------------------------------------------------------------------------
 # linear operators (layer_func.py:909-928; SURVEY A.4 semantics)
 # ---------------------------------------------------------------------------
-def conv2d_same(x, w_hwio, stride):
-    """tf.nn.conv2d(x, W[k,k,Cin,Cout], 'SAME', NCHW): cross-correlation, pad_before = total//2."""
-    k = w_hwio.shape[0]
+def conv2d_same(x, w_hwio, stride, dilation=1, padding='SAME'):
+    """tf.nn.conv2d(x, W[k,k,Cin,Cout], padding, NCHW, dilations): cross-correlation; 'SAME': pad_before = total//2 on the
+    dilated extent (k - 1) * dilation + 1; 'VALID': no padding (layer_func.py:912-916)."""
+    k = (w_hwio.shape[0] - 1) * dilation + 1
+    if padding in ('same', 'SAME'):
+        def pads(size):
+            total = max((_same_out(size, stride) - 1) * stride + k - size, 0)
+            return total // 2, total - total // 2
+        (pt, pb), (pl, pr) = pads(x.shape[2]), pads(x.shape[3])
+        x = F.pad(x, (pl, pr, pt, pb))
+    return F.conv2d(x, w_hwio.permute(3, 2, 0, 1), stride=stride, dilation=dilation)
 
-    def pads(size):
-        total = max((_same_out(size, stride) - 1) * stride + k - size, 0)
-        return total // 2, total - total // 2
-    (pt, pb), (pl, pr) = pads(x.shape[2]), pads(x.shape[3])
-    return F.conv2d(F.pad(x, (pl, pr, pt, pb)), w_hwio.permute(3, 2, 0, 1), stride=stride)
 
-
-def conv2d_transpose_same(v, w, out_hw, stride):
-    """tf.nn.conv2d_transpose(v, W[k,k,Cout,Cin], 'SAME'): the input-gradient of conv2d_same."""
+def conv2d_transpose_same(v, w, out_hw, stride, padding='SAME'):
+    """tf.nn.conv2d_transpose(v, W[k,k,Cout,Cin], padding): the input-gradient of conv2d_same (dilation 1)."""
     k = w.shape[0]
     oh, ow = out_hw
 
     def pads(size):
+        if padding not in ('same', 'SAME'):
+            return 0, 0
         total = max((_same_out(size, stride) - 1) * stride + k - size, 0)
         return total // 2, total - total // 2
     (pt, pb), (pl, pr) = pads(oh), pads(ow)
@@ -439,10 +462,14 @@ def sn_power_iteration(w, x, spec):
         else:
             fwd, bwd = (lambda t: t @ w.t()), (lambda t: t @ w)
     else:
-        stride = d['strides']
+        stride, dil, padding = _conv_geometry(d)
+        if dil > 1:
+            # math_func.py:613-616, 630-634: tf.nn.atrous_conv2d(_transpose) - NHWC-only ops fed the NCHW tensors of the
+            # reference's default data format: not a defined computation, not restated
+            raise NotImplementedError('{}: spectral norm on a dilated kernel'.format(spec['scope']))
         in_hw = spec.get('in_shape_scaled', spec['in_shape'])[1:] if d['op'] == 'c' else spec['op_out_shape'][1:]
-        conv = lambda t: conv2d_same(t, w, stride)                       # math_func.py:604-619
-        conv_t = lambda t: conv2d_transpose_same(t, w, in_hw, stride)    # math_func.py:621-637
+        conv = lambda t: conv2d_same(t, w, stride, 1, padding)                    # math_func.py:604-619
+        conv_t = lambda t: conv2d_transpose_same(t, w, in_hw, stride, padding)    # math_func.py:621-637
         fwd, bwd = (conv, conv_t) if spec['use_u'] else (conv_t, conv)   # math_func.py:527-528
     u = fwd(x)
     sigma = _l2(u)
@@ -572,7 +599,7 @@ def net_forward(specs, params, x, is_training=True, collect=None, masks=None):
         if d['op'] == 'd':
             x = x @ w
         elif d['op'] == 'c':
-            x = conv2d_same(x, w, d['strides'])
+            x = conv2d_same(x, w, *_conv_geometry(d))
         else:
             x = conv2d_transpose_same(x, w, s['op_out_shape'][1:], d['strides'])
         if d['bias'] is not None:                             # layer_func.py:946-950

@@ -392,30 +392,39 @@ def _same_pad(size, k, s):
     return total // 2, total - total // 2
 
 
+def _dilation_hw(dilations, data_format):
+    if dilations is None:
+        return 1, 1
+    assert data_format in ('NCHW', 'channels_first')
+    return int(dilations[2]), int(dilations[3])
+
+
 def _conv2d(x, kernel, strides, padding, use_cudnn_on_gpu=True, data_format='NHWC', dilations=None, name=None):
+    """tf.nn.conv2d, NCHW: 'SAME' (pad_before = total // 2 on the dilated extent) or 'VALID'; dilations [1,1,d,d]"""
     sh, sw = _stride_hw(strides, data_format)
-    assert dilations is None or all(int(d) == 1 for d in dilations)
-    assert padding == 'SAME'
-    k = kernel.shape[0]
-    pt, pb = _same_pad(x.shape[2], k, sh)
-    pl, pr = _same_pad(x.shape[3], k, sw)
-    xp = F.pad(x, (pl, pr, pt, pb))
-    return F.conv2d(xp, kernel.permute(3, 2, 0, 1), stride=(sh, sw))
+    dh, dw = _dilation_hw(dilations, data_format)
+    assert padding in ('SAME', 'VALID'), padding
+    kh, kw = (kernel.shape[0] - 1) * dh + 1, (kernel.shape[1] - 1) * dw + 1       # dilated extents
+    if padding == 'SAME':
+        pt, pb = _same_pad(x.shape[2], kh, sh)
+        pl, pr = _same_pad(x.shape[3], kw, sw)
+        x = F.pad(x, (pl, pr, pt, pb))
+    return F.conv2d(x, kernel.permute(3, 2, 0, 1), stride=(sh, sw), dilation=(dh, dw))
 
 
 def _conv2d_transpose(value, kernel, output_shape, strides, padding='SAME', data_format='NHWC', name=None):
     """gradient of _conv2d w.r.t. its input; kernel is [k,k,out_channels,in_channels]."""
     sh, sw = _stride_hw(strides, data_format)
-    assert padding == 'SAME'
+    assert padding in ('SAME', 'VALID'), padding
     k = kernel.shape[0]
     oh, ow = int(output_shape[2]), int(output_shape[3])
-    pt, pb = _same_pad(oh, k, sh)
-    pl, pr = _same_pad(ow, k, sw)
+    pt, pb = _same_pad(oh, k, sh) if padding == 'SAME' else (0, 0)
+    pl, pr = _same_pad(ow, k, sw) if padding == 'SAME' else (0, 0)
     full = F.conv_transpose2d(value, kernel.permute(3, 2, 0, 1), stride=(sh, sw))
-    # full spatial size is (in-1)*s+k; the conv's padded input was oh+pt+pb
+    # full spatial size is (in-1)*s+k; the conv's padded input was oh+pt+pb (VALID: rows the conv never read get zeros)
     fh, fw = full.shape[2], full.shape[3]
     if fh < oh + pt + pb or fw < ow + pl + pr:
-        full = F.pad(full, (0, ow + pl + pr - fw, 0, oh + pt + pb - fh))
+        full = F.pad(full, (0, max(ow + pl + pr - fw, 0), 0, max(oh + pt + pb - fh, 0)))
     return full[:, :, pt:pt + oh, pl:pl + ow]
 
 

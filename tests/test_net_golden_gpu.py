@@ -14,7 +14,7 @@ from helpers import RTOL, designs_of, golden, load, rel_err
 
 pytestmark = pytest.mark.gpu
 
-CASES = ['dis_small', 'gen_small', 'gen_stl_head', 'dis_odd']
+CASES = ['dis_small', 'gen_small', 'gen_stl_head', 'dis_odd', 'dis_valid_dil']
 
 
 def _to_dev(a):

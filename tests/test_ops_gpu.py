@@ -990,6 +990,49 @@ def test_act_and_axpby(ops, act):
     assert rel_err(a.cpu().numpy(), x + dy) <= 1e-6
 
 
+def test_slice_and_space_batch_compose_valid_and_dilated_convs(ops):
+    """mmdgan_strided_slice / mmdgan_space_batch (the 'padding': 'VALID' and 'dilation' keys of a conv layer as compositions
+    around the 'SAME' kernels): the ops and their adjoints against indexing, and the composed convs against the oracle's
+    conv with padding / dilation (layer_func.py:912-916)"""
+    rs = np.random.RandomState(5)
+    x = dev(rs.randn(3, 11, 14, 5).astype(np.float32))
+    for off, step in ((1, 1), (1, 2), (0, 3), (2, 2)):
+        P, Q = -(-(11 - 2 * off) // step), -(-(14 - 2 * off) // step)
+        want = x[:, off:off + (P - 1) * step + 1:step, off:off + (Q - 1) * step + 1:step]
+        got = ops.strided_slice(x, off, step, (P, Q))
+        assert torch.equal(got, want.contiguous())
+        g = dev(rs.randn(3, P, Q, 5).astype(np.float32))
+        back = ops.strided_slice(g, off, step, None, adjoint_hw=(11, 14), out=torch.full((3, 11, 14, 5), float('nan'), device='cuda'))
+        ref = torch.zeros(3, 11, 14, 5, device='cuda')
+        ref[:, off:off + (P - 1) * step + 1:step, off:off + (Q - 1) * step + 1:step] = g
+        assert torch.equal(back, ref)
+    for d in (2, 3):
+        xb = ops.space_batch(x, d)
+        Hd, Wd = -(-11 // d), -(-14 // d)
+        assert xb.shape == (3 * d * d, Hd, Wd, 5)
+        pad = torch.zeros(3, Hd * d, Wd * d, 5, device='cuda')
+        pad[:, :11, :14] = x
+        want = pad.view(3, Hd, d, Wd, d, 5).permute(0, 2, 4, 1, 3, 5).reshape(3 * d * d, Hd, Wd, 5)
+        assert torch.equal(xb, want)
+        assert torch.equal(ops.space_batch(xb, d, hw=(11, 14)), x)
+    # composed convs: N, H, W, C, K, R, stride, dilation, padding
+    for N, H, W, C, K, Rk, st, dl, pad in ((4, 12, 10, 16, 32, 3, 1, 1, 'VALID'), (4, 13, 12, 16, 32, 4, 2, 1, 'VALID'),
+                                           (3, 12, 9, 16, 32, 3, 1, 2, 'SAME'), (3, 14, 13, 16, 32, 3, 1, 3, 'VALID'),
+                                           (2, 9, 9, 8, 8, 3, 2, 1, 'VALID')):
+        xx = rs.randn(N, C, H, W).astype(np.float32)
+        w = (rs.randn(Rk, Rk, C, K) * 0.1).astype(np.float32)
+        ref = R.conv2d_same(torch.tensor(xx, dtype=torch.float64), torch.tensor(w, dtype=torch.float64), st, dl, pad).numpy()
+        xin = nhwc(xx)
+        if dl > 1:
+            xin = ops.space_batch(xin, dl)
+        full = ops.conv2d_fwd(xin, dev(w), 1 if pad == 'VALID' else st)
+        if dl > 1:
+            full = ops.space_batch(full, dl, hw=(H, W))
+        if pad == 'VALID':
+            full = ops.strided_slice(full, dl * ((Rk - 1) // 2), st, ref.shape[2:])
+        assert rel_err(to_nchw(full), ref) <= RTOL, (N, H, W, Rk, st, dl, pad)
+
+
 def test_memset_zero_multi(ops):
     """several scratch buffers zeroed by one launch; odd sizes / alignments take the plain-memset route"""
     ts = [torch.randn(n, device='cuda') for n in (4, 1024, 100000, 12, 7, 0, 524288)]

@@ -192,6 +192,77 @@ def test_res_step_matches_oracle_on_mfma_sized_blocks(loss_type, sn_mode):
                 assert np.linalg.norm(du - dr) <= 0.1 * np.linalg.norm(dr) + 1e-12, (step, n)
 
 
+def valid_dil_architecture():
+    """the 'padding' / 'dilation' keys of the layer dict in a full G + D pair (MFMA-sized channel counts): 'VALID' convs with
+    spectral norm (k3 s1, k4 s2), dilated convs ('SAME' and 'VALID', no spectral norm - see tape._Net._conv), in G a dilated conv
+    behind the transposed ones"""
+    ak = float(np.power(64.0, 0.125))
+    return {'input': [(3, 32, 32)], 'code': [(32, 'linear')],
+            'generator': [{'name': 'l1', 'out': 64 * 8 * 8, 'op': 'd', 'out_reshape': [64, 8, 8]},
+                          {'name': 'l2_up', 'out': 64, 'op': 'tc', 'act': 'relu', 'act_nm': 'bn', 'kernel': 4, 'strides': 2},
+                          {'name': 'l3_up', 'out': 32, 'op': 'tc', 'act': 'relu', 'act_nm': 'bn', 'kernel': 4, 'strides': 2},
+                          {'name': 'l4_dil', 'out': 32, 'act': 'relu', 'dilation': 2},
+                          {'name': 'l5_t', 'out': 3, 'act': 'tanh'}],
+            'discriminator': [{'name': 'l1_v', 'out': 64, 'act': 'lrelu', 'act_k': ak, 'w_nm': 's', 'padding': 'VALID'},           # 30
+                              {'name': 'l2_vs2', 'out': 64, 'act': 'lrelu', 'act_k': ak, 'w_nm': 's', 'kernel': 4, 'strides': 2,
+                               'padding': 'VALID'},                                                                                  # 14
+                              {'name': 'l3_dil', 'out': 64, 'act': 'lrelu', 'dilation': 3},                                         # 14
+                              {'name': 'l4_dilv', 'out': 128, 'act': 'lrelu', 'dilation': 2, 'padding': 'VALID'},                   # 10
+                              {'name': 'l5_ds', 'out': 128, 'act': 'lrelu', 'act_k': ak, 'w_nm': 's', 'kernel': 4, 'strides': 2,
+                               'out_reshape': [5 * 5 * 128]},
+                              {'name': 'l6_s', 'out': 16, 'op': 'd', 'act_k': ak, 'bias': 'b', 'w_nm': 's'}]}
+
+
+@pytest.mark.parametrize('launch_mode', ['eager', 'plan'])
+def test_step_with_valid_padding_and_dilation_matches_oracle(launch_mode):
+    """three teacher-forced G + D steps of a pair whose layer dicts use 'padding': 'VALID' and 'dilation' (SNGan routes those to
+    the primitive-op engine) against the fp64 oracle: losses, sigma of the 'VALID' kernels, every gradient, the update -
+    D's joint 3B-row backward pass and (plan) the recorded launch plan run through the compositions"""
+    from mmdgan_hip.tape import TapeEngine, needs_tape_engine
+    arch, B = valid_dil_architecture(), 8
+    assert needs_tape_engine(arch)
+    eng = TapeEngine(arch, 'rep', (5e-4, 2e-4), batch_size=B, seed=5, launch_mode=launch_mode)
+    assert eng._d_joint
+    ora = R.OracleGan(arch, 'rep', (5e-4, 2e-4), dtype=torch.float64, params=eng.get_variables())
+    rs = np.random.RandomState(7)
+    last_bias = 'dis/l6_s/bias/bias'
+    for step in range(3):
+        z = rs.randn(B, 32).astype(np.float32)
+        real = rs.uniform(-1, 1, (B, 3, 32, 32)).astype(np.float32)
+        prev_vars = {k: v.numpy().copy() for k, v in ora.params.items()}
+        eng.set_variables(prev_vars)
+        zt, rt = torch.tensor(z, dtype=torch.float64), torch.tensor(real, dtype=torch.float64)
+        col = {}
+        lg, ld, stats, upd, gd, gg, aux = ora.grads(zt, rt, collect=col)
+        ora.step(zt, rt)
+        eng.step(nhwc(real), torch.as_tensor(z).cuda())
+        losses = eng.losses.cpu().numpy().astype(np.float64)
+        escale = float(max(losses[2:5]))
+        assert abs(losses[0] - float(lg)) <= RTOL * abs(float(lg)) + 1e-5 * escale, (step, losses[0], float(lg))
+        assert abs(losses[1] - float(ld)) <= RTOL * abs(float(ld)) + 1e-5 * escale, (step, losses[1], float(ld))
+        sig = eng.sigmas()
+        for scope in ('dis/l1_v', 'dis/l2_vs2', 'dis/l5_ds', 'dis/l6_s'):
+            ref = float(col[scope + '/sigma'])
+            assert abs(sig[scope] - ref) <= RTOL * ref, (step, scope, sig[scope], ref)
+        if step == 0:
+            continue                                     # un-normalised SN start vectors: step-0 gradients are rounding noise
+        grads = eng.get_variables(grad=True)
+        ref_g = dict(gd)
+        ref_g.update(gg)
+        assert_grads_within_fp32_floor(grads, {n: g.numpy() for n, g in ref_g.items()},
+                                       fp32_floor(arch, 'rep', (5e-4, 2e-4), prev_vars, z, real, eng), skip=(last_bias,),
+                                       what=(launch_mode, step))
+        for n, v in eng.get_variables().items():
+            if n == last_bias:
+                continue
+            ref = ora.params[n].numpy()
+            if n.endswith('in_rand') or '/moving_' in n:
+                assert close(v, ref, RTOL, 0.0), (step, n)
+            else:
+                du, dr = v.astype(np.float64) - prev_vars[n], ref - prev_vars[n]
+                assert np.linalg.norm(du - dr) <= 0.1 * np.linalg.norm(dr) + 1e-12, (step, n)
+
+
 def test_step_on_the_shipped_resnet_architecture():
     """BASELINE.json config 5: the FULL-WIDTH LSUN 64x64 ResNet-SN dict of configs.lsun_resnet() (1024-channel blocks,
     the bench workload) at batch 4 - two teacher-forced steps against the fp64 oracle, as
