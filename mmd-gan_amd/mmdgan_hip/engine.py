@@ -74,7 +74,8 @@ class LayerSpec:
         if d['w_nm'] not in (None, 's'):
             raise NotImplementedError('{}: {} method not implemented'.format(self.scope, d['w_nm']))  # :824
         if d['in_reshape'] is not None or d['scale'] is not None or d['dilation'] != 1 or d['padding'] != 'SAME':
-            raise NotImplementedError('{}: in_reshape / scale / dilation / VALID are outside the hot path'.format(self.scope))
+            raise NotImplementedError('{}: in_reshape / scale / dilation / VALID are not on this engine\'s schedule; use '
+                                      'mmdgan_hip.tape.TapeEngine (SNGan.init_net does)'.format(self.scope))
         self.op, self.act, self.name = d['op'], d['act'], d['name']
         self.bn = d['act_nm'] in ('bn', 'BN')
         self.has_bias = d['bias'] is not None
