@@ -35,7 +35,8 @@ def parse():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--config', default='cifar', choices=['cifar', 'stl', 'celeba', 'lsun_resnet'])
     ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: 64; 128 for celeba; 32 for lsun_resnet = 256 on 8 GPUs)')
-    ap.add_argument('--loss', default='rep', choices=['rep', 'rmb'])
+    ap.add_argument('--loss', default=None, choices=['rep', 'rmb'],
+                    help="default: the loss BASELINE.json names for the config ('rmb' for stl, 'rep' otherwise)")
     ap.add_argument('--launch-mode', default='auto', choices=['auto', 'eager', 'graph', 'plan'],
                     help="how a step reaches the GPU (mmdgan_hip/engine.py): 'eager' ~200 library calls from Python, 'graph' "
                          "one captured hipGraph, 'plan' the library's recorded launch plan replayed from one C call; "
@@ -54,7 +55,10 @@ def parse():
     ap.add_argument('--probe-warm', type=int, default=400, help='untimed launches before the timed ones of --probe-only')
     ap.add_argument('--engine', default='auto', choices=['auto', 'tape'],
                     help="'tape': run a DCGAN config on the primitive-op engine too (it is what residual-block configs use)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.loss is None:
+        args.loss = 'rmb' if args.config == 'stl' else 'rep'
+    return args
 
 
 def dominant_kernel_probe(eng, reps=20, warm=3):
