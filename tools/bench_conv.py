@@ -1,5 +1,10 @@
 #!/usr/bin/env python3
-"""per-layer conv kernel timings (HIP events) for the CIFAR B=64 step: TFLOP/s per launch."""
+"""per-layer conv kernel timings (HIP events) for the CIFAR B=64 step: TFLOP/s per launch.
+
+The layers are launched the way the engine launches them: with the Winograd-transformed weights handed in (`wino=`, made
+once per step by mmdgan_wino_transform_multi, so the transform is not part of a layer's time and the launches with few
+tile blocks may split their reduction over workspace slabs).  BENCH_OWN_TRANSFORM=1: the library transforms the weights
+inside every call (what a caller without the transformed tensors gets; rounds 1-2 measured this)."""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -33,14 +38,18 @@ for name, N, H, W, C, K, R, s in LAYERS:
     dy = torch.randn(N, P, Q, K, device='cuda'); y = torch.empty(N, P, Q, K, device='cuda')
     dx = torch.empty_like(x); dw = torch.empty_like(w); bias = torch.zeros(K, device='cuda')
     fl = 2.0 * N * P * Q * K * R * R * C
+    uf = ud = None
+    if not os.environ.get('BENCH_OWN_TRANSFORM'):
+        uf = ops.wino_transform(w, False) if ops.wino_eligible(N, H, W, C, K, R, s, False) else None
+        ud = ops.wino_transform(w, True) if ops.wino_eligible(N, H, W, C, K, R, s, True) else None
     if os.environ.get('BENCH_DGRAD_3B') and name.startswith('D l') and 'thin' not in name and '(B)' not in name:
         # the step's D backward: 3B rows (loss_dis rows 2B + loss_gen rows B), dact wraps to the last B images
         n3 = N + N // 2
         dy3 = torch.randn(n3, P, Q, K, device='cuda'); dx3 = torch.empty(n3, H, W, C, device='cuda')
-        t3 = timeit(lambda: ops.conv2d_dgrad(dy3, w, (H, W), s, act='lrelu', dact_of=x, dact_batch=N, out=dx3))
+        t3 = timeit(lambda: ops.conv2d_dgrad(dy3, w, (H, W), s, act='lrelu', dact_of=x, dact_batch=N, out=dx3, wino=ud))
         print('%-10s dgrad 3B rows: %7.1f us (%5.1f TF)' % (name, t3 * 1e3, 1.5 * fl / t3 / 1e9))
-    t = [timeit(lambda: ops.conv2d_fwd(x, w, s, bias=bias, act='lrelu', out=y)),
-         timeit(lambda: ops.conv2d_dgrad(dy, w, (H, W), s, act='lrelu', dact_of=x, out=dx)),
+    t = [timeit(lambda: ops.conv2d_fwd(x, w, s, bias=bias, act='lrelu', out=y, wino=uf)),
+         timeit(lambda: ops.conv2d_dgrad(dy, w, (H, W), s, act='lrelu', dact_of=x, out=dx, wino=ud)),
          timeit(lambda: ops.conv2d_wgrad(x, dy, R, s, out=dw))]
     for i in range(3): tot[i] += t[i]
     print('%-10s %8.2f | %7.1f (%5.1f) | %7.1f (%5.1f) | %7.1f (%5.1f)' % (

@@ -34,6 +34,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/resnet -o r -- $B -
 ls $OUT
 cd $R
 BENCH_DGRAD_3B=1 python tools/bench_conv.py 64 > $OUT/conv_layers.txt 2>&1
+BENCH_OWN_TRANSFORM=1 BENCH_DGRAD_3B=1 python tools/bench_conv.py 64 > $OUT/conv_layers_own_transform.txt 2>&1
 MMDGAN_WINO=0 BENCH_DGRAD_3B=1 python tools/bench_conv.py 64 'D l' > $OUT/conv_layers_direct.txt 2>&1
 python tools/wino_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/winograd_kernels.txt
 MMDGAN_WINO2=0 MMDGAN_WINO=0 python tools/wino_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/winograd_kernels_direct.txt

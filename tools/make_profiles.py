@@ -228,7 +228,7 @@ if f:
     json.dump(out, open(os.path.join(dst, tag + '_whole_step_mfma_busy.json'), 'w'), indent=1)
     print('whole-step MFMA busy', out['mfma_busy_frac_whole_step'], out['serialised']['mfma_busy_frac'], steps)
 
-for name in ('conv_layers.txt', 'conv_layers_direct.txt', 'winograd_kernels.txt', 'winograd_kernels_direct.txt', 'step_clock.txt',
+for name in ('conv_layers.txt', 'conv_layers_own_transform.txt', 'conv_layers_direct.txt', 'winograd_kernels.txt', 'winograd_kernels_direct.txt', 'step_clock.txt',
              'pairwise_kernel_sweep.txt', 'launch_modes.txt', 'bench.json', 'bench_stl.json', 'bench_celeba.json',
              'bench_lsun_resnet.json', 'bench_dp_one_rank.json', 'bench_default_profiled.json'):
     p = os.path.join(src, name)
