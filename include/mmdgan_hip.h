@@ -385,6 +385,15 @@ int mmdgan_adam_segments(float *params, const float *grads, float *adam_m, float
  * for the learning rate: lr_t_scratch is used as it is). */
 #define MMDGAN_ADAM_PREPARED (-1)
 int mmdgan_adam_prepare(float lr, float beta1, float beta2, int step, int *step_counter, float *lr_t_scratch, void *stream);
+/* ... of several updates (G's and D's: graph_func.py:851-874 runs both optimisers in one sess.run) as ONE launch; the table
+ * (host memory, n <= 8) travels by value. */
+typedef struct {
+    float lr, beta1, beta2;
+    int step;                  /* used when step_counter is NULL */
+    int *step_counter;
+    float *lr_t_scratch;
+} mmdgan_adam_prepare_job;
+int mmdgan_adam_prepare_multi(const mmdgan_adam_prepare_job *jobs, int n, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Elementwise pieces of the residual blocks (layer_func.py:1687-1842), NHWC fp32.

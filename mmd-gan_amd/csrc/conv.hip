@@ -136,16 +136,22 @@ static int wgrad_impl(const mmdgan_conv_geom *g, const float *x, const float *dy
         return rcw;
     }
     int rc = 1;
+    bool dot_done = false;
     if (!force_direct() && igemm_wgrad_ok(d)) rc = igemm_wgrad(d, x, dy, dw, dbias, (hipStream_t)stream);   // sums dy on the way
     else {
-        if (!force_direct() && !force_valu_thin() && thinm_wgrad_ok(d)) rc = thinm_wgrad(d, x, dy, dw, (hipStream_t)stream);
+        if (!force_direct() && !force_valu_thin() && thinm_wgrad_ok(d) && d.N > 1) {
+            // (its reduction pass forms <dw, w> where it has the finished dw)
+            if (wdot && zero_output(dot, sizeof(float), (hipStream_t)stream) != hipSuccess) return check_launch("conv2d_wgrad memset");
+            rc = thinm_wgrad(d, x, dy, dw, (hipStream_t)stream, wdot, dot);
+            dot_done = rc == 0;
+        }
         if (rc > 0) {                                              // 1: no workspace registered -> VALU kernel
             if (!force_direct() && thin_wgrad_ok(d)) rc = thin_wgrad(d, x, dy, dw, (hipStream_t)stream);
             else rc = direct_wgrad(d, x, dy, dw, (hipStream_t)stream);
         }
         if (rc == 0 && dbias) rc = mmdgan_colsum(dy, (long)d.N * d.P * d.Q, d.K, dbias, stream);
     }
-    if (rc == 0 && wdot) rc = mmdgan_dot(dw, wdot, nw, dot, stream);
+    if (rc == 0 && wdot && !dot_done) rc = mmdgan_dot(dw, wdot, nw, dot, stream);
     return rc;
 }
 

@@ -36,7 +36,8 @@ int thin_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const fl
 int thin_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, float *dx, hipStream_t st);
 int thin_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st);
 
-int thin_wgrad_reduce(const float *partials, int nblocks, long nout, float *dw, hipStream_t st);
+int thin_wgrad_reduce(const float *partials, int nblocks, long nout, float *dw, hipStream_t st, const float *wdot = nullptr,
+                      float *dot = nullptr);   // dot (zero on entry) += <dw, wdot>
 
 // MFMA versions of the same thin layers for 3x3 / stride 1 (conv_thin_mfma.hip)
 bool thinm_fwd_n2w_ok(const ConvDims &d);
@@ -46,7 +47,8 @@ bool thinm_dgrad_w2n_ok(const ConvDims &d);
 bool thinm_wgrad_ok(const ConvDims &d);
 int thinm_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, float *y, hipStream_t st);
 int thinm_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, float *dx, hipStream_t st);
-int thinm_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st);   // 1 = no workspace
+int thinm_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st, const float *wdot = nullptr,
+                float *dot = nullptr);   // 1 = no workspace; dot (zero on entry) += <dw, wdot> in the reduction pass
 
 // Winograd F(2x2,3x3) for 3x3 / stride-1 layers (conv_wino.hip); needs the library workspace for G g G^T
 bool wino_fwd_ok(const ConvDims &d);

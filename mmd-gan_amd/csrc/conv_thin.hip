@@ -246,8 +246,11 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(ConvDims d, const float
 
 // dw[o] = sum_b partials[b][o]: 64 outputs per block (coalesced across lanes), the 4 waves split the
 // partial blocks, 8 independent loads in flight per lane, LDS combine - no dependent load chain.
+// wdot / dot (optional): dot[0] += <dw, wdot> over this block's 64 outputs (dot is zero on entry) - the scalar of the
+// spectral-norm fix-up, formed where the finished dw is in registers (one atomic per block, 27 for a 3x3x3x64 kernel)
 __global__ __launch_bounds__(256) void thin_wgrad_reduce_kernel(const float *__restrict__ partials, int nblocks, long nout,
-                                                                float *__restrict__ dw) {
+                                                                float *__restrict__ dw, const float *__restrict__ wdot,
+                                                                float *__restrict__ dot) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long o = (long)blockIdx.x * 64 + lane;
@@ -265,7 +268,17 @@ __global__ __launch_bounds__(256) void thin_wgrad_reduce_kernel(const float *__r
     }
     red[wave][lane] = acc;
     __syncthreads();
-    if (wave == 0 && o < nout) dw[o] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    if (wave != 0) return;
+    double part = 0;
+    if (o < nout) {
+        const float v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        dw[o] = v;
+        if (wdot) part = (double)v * (double)wdot[o];
+    }
+    if (wdot) {
+        part = wave_sum(part);
+        if (lane == 0) atomicAdd(dot, (float)part);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -326,12 +339,13 @@ int thin_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hi
     else hipLaunchKernelGGL(thin_wgrad_kernel<false>, dim3(xblocks, ychunks), dim3(256), 0, st, d, x, dy, dw, rpb, partials);
     if (partials)
         hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3((unsigned)((nout + 63) / 64)), dim3(256), 0, st, partials, xblocks,
-                           nout, dw);
+                           nout, dw, (const float *)nullptr, (float *)nullptr);
     return check_launch("conv2d_wgrad(thin)");
 }
 
-int thin_wgrad_reduce(const float *partials, int nblocks, long nout, float *dw, hipStream_t st) {
-    hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3((unsigned)((nout + 63) / 64)), dim3(256), 0, st, partials, nblocks, nout, dw);
+int thin_wgrad_reduce(const float *partials, int nblocks, long nout, float *dw, hipStream_t st, const float *wdot, float *dot) {
+    hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3((unsigned)((nout + 63) / 64)), dim3(256), 0, st, partials, nblocks, nout, dw,
+                       wdot, dot);
     return check_launch("conv2d_wgrad(thin reduce)");
 }
 

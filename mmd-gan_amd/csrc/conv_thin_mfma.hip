@@ -405,7 +405,7 @@ int thinm_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, cons
 
 // needs the library workspace for the per-workgroup partial sums; returns 1 if it is not available
 // (the caller then falls back to the VALU kernel)
-int thinm_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st) {
+int thinm_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st, const float *wdot, float *dot) {
     const long nout = (long)d.R * d.R * d.C * d.K;
     const int nrows = d.N * d.H;
     int blocks = (nrows + 3) / 4;
@@ -423,7 +423,7 @@ int thinm_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, h
         if (d.C == 32) hipLaunchKernelGGL((thinm_wgrad_kernel<true, 1>), dim3(blocks), dim3(256), 0, st, d, dy, x, partials, rpw);
         else hipLaunchKernelGGL((thinm_wgrad_kernel<true, 2>), dim3(blocks), dim3(256), 0, st, d, dy, x, partials, rpw);
     }
-    return thin_wgrad_reduce(partials, blocks, nout, dw, st);
+    return thin_wgrad_reduce(partials, blocks, nout, dw, st, wdot, dot);
 }
 
 }  // namespace mmdgan

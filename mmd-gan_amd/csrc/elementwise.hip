@@ -385,6 +385,31 @@ extern "C" int mmdgan_adam_prepare(float lr, float beta1, float beta2, int step,
     return check_launch("adam_prepare");
 }
 
+namespace {
+struct AdamPrepareTable { mmdgan_adam_prepare_job job[8]; };
+__global__ void adam_prepare_multi_kernel(AdamPrepareTable t, int n) {
+    const int i = threadIdx.x;
+    if (i >= n) return;
+    // (the by-value table, indexed where it lies: a dynamic index into the argument copy would go through scratch)
+    const mmdgan_adam_prepare_job *jobs = (const mmdgan_adam_prepare_job *)__builtin_amdgcn_kernarg_segment_ptr();
+    const mmdgan_adam_prepare_job j = jobs[i];
+    int step = j.step;
+    if (j.step_counter) { step = j.step_counter[0] + 1; j.step_counter[0] = step; }
+    j.lr_t_scratch[0] = (float)((double)j.lr * sqrt(1.0 - pow((double)j.beta2, (double)step)) / (1.0 - pow((double)j.beta1, (double)step)));
+}
+}  // namespace
+
+extern "C" int mmdgan_adam_prepare_multi(const mmdgan_adam_prepare_job *jobs, int n, void *stream) {
+    MMDGAN_REQUIRE(jobs && n >= 1 && n <= 8, "adam_prepare_multi: 1..8 jobs");
+    AdamPrepareTable t{};
+    for (int i = 0; i < n; ++i) {
+        MMDGAN_REQUIRE(jobs[i].lr_t_scratch && (jobs[i].step_counter || jobs[i].step >= 1), "adam_prepare_multi: bad job %d", i);
+        t.job[i] = jobs[i];
+    }
+    hipLaunchKernelGGL(adam_prepare_multi_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t, n);
+    return check_launch("adam_prepare_multi");
+}
+
 extern "C" int mmdgan_nchw_to_nhwc(const float *src, float *dst, int N, int C, int H, int W, void *stream) {
     MMDGAN_REQUIRE(src && dst && N >= 1 && C >= 1 && H >= 1 && W >= 1, "nchw_to_nhwc: bad arguments");
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long)N * C * H * W)), dim3(256), 0, (hipStream_t)stream, src,

@@ -72,6 +72,7 @@ SIGNATURES = {
     'mmdgan_adam_multi': (_I, [_P, _P, _I, _L, _F, _F, _F, _F, _I, _P, _P, _F, _P]),
     'mmdgan_adam_segments': (_I, [_P, _P, _P, _P, _P, _I, _P, _L, _F, _F, _F, _F, _I, _P, _P, _F, _I, _P]),
     'mmdgan_adam_prepare': (_I, [_F, _F, _F, _I, _P, _P, _P]),
+    'mmdgan_adam_prepare_multi': (_I, [_P, _I, _P]),
     'mmdgan_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'mmdgan_nhwc_to_nchw': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'mmdgan_resample_down': (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),

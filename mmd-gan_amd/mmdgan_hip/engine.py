@@ -1072,8 +1072,7 @@ class GanEngine:
                     ops.memset_zero_multi(list(arenas))
                     self._wino_jobs[1].run()
                     # (the step counts and bias-corrected learning rates of both updates: no gradient needed, so here)
-                    self.dis.opt.prepare(self.lr_d)
-                    self.gen.opt.prepare(self.lr_g)
+                    ops.adam_prepare_multi([(self.dis.opt, self.lr_d), (self.gen.opt, self.lr_g)])
                     ops.event_record(_EV_WINO_DIS, self._wg_raw)
             else:                                            # no side stream (MMDGAN_SIDE_WGRAD=0): the same work on the main one
                 self._wino_jobs[0].run()

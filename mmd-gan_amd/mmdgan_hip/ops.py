@@ -607,6 +607,23 @@ class AdamArena:
                                        float(grad_scale), int(self.fold_fixup), _stream()), 'adam_segments')
 
 
+class AdamPrepareJob(ctypes.Structure):
+    _fields_ = [('lr', ctypes.c_float), ('beta1', ctypes.c_float), ('beta2', ctypes.c_float), ('step', ctypes.c_int),
+                ('step_counter', ctypes.c_void_p), ('lr_t_scratch', ctypes.c_void_p)]
+
+
+def adam_prepare_multi(jobs, beta1=0.5, beta2=0.999):
+    """AdamArena.prepare() of several arenas - jobs: [(arena, lr)] - as one launch (mmdgan_adam_prepare_multi)"""
+    table = (AdamPrepareJob * len(jobs))()
+    for t, (arena, lr) in zip(table, jobs):
+        t.lr, t.beta1, t.beta2, t.step = float(lr), float(beta1), float(beta2), 0
+        t.step_counter, t.lr_t_scratch = arena.step_counter.data_ptr(), arena.lr_t.data_ptr()
+    check(require_device().mmdgan_adam_prepare_multi(ctypes.cast(table, ctypes.c_void_p), len(jobs), _stream()),
+          'adam_prepare_multi')
+    for arena, _ in jobs:
+        arena.prepared = True
+
+
 def nchw_to_nhwc(x):
     lib = require_device()
     N, C, H, W = x.shape

@@ -789,7 +789,8 @@ def test_segmented_adam_folds_the_spectral_norm_fixup(ops):
     rs = np.random.RandomState(21)
     ops.set_workspace()
     try:
-        for (N, H, C, K, R_, s) in ((16, 16, 64, 128, 3, 1), (16, 16, 64, 128, 4, 2), (4, 8, 24, 40, 3, 1)):
+        # (the last one: D's first layer - the thin MFMA kernel, whose partial-sum reduction forms <dw, w> itself)
+        for (N, H, C, K, R_, s) in ((16, 16, 64, 128, 3, 1), (16, 16, 64, 128, 4, 2), (4, 8, 24, 40, 3, 1), (16, 32, 3, 64, 3, 1)):
             P = H // s
             x = dev(rs.randn(N, H, H, C).astype(np.float32))
             dy = dev(rs.randn(N, P, P, K).astype(np.float32))
@@ -830,6 +831,22 @@ def test_segmented_adam_folds_the_spectral_norm_fixup(ops):
     for lo, hi in ((4209, 4212), (4215, 4217), (total - 5, total)):
         assert np.array_equal(got[lo:hi], p0[lo:hi])
     assert int(opt_dev.step_counter.item()) == 3
+    # the step counts / learning rates of two arenas prepared by ONE launch (mmdgan_adam_prepare_multi), ahead of the updates:
+    # the same parameters as two arenas that prepare inside their own step()
+    pa, pb = [[dev(p0) for _ in range(2)] for _ in range(2)]
+    za = [[torch.zeros(total, device='cuda') for _ in range(4)] for _ in range(2)]
+    early = [ops.AdamArena(pa[i], g, za[i][0], za[i][1], segs) for i in range(2)]
+    late = [ops.AdamArena(pb[i], g, za[i][2], za[i][3], segs) for i in range(2)]
+    for _ in range(2):
+        ops.adam_prepare_multi([(early[0], 5e-4), (early[1], 2e-4)])
+        assert early[0].prepared and early[1].prepared
+        for i, lr in enumerate((5e-4, 2e-4)):
+            early[i].step(lr)
+            late[i].step(lr)
+            assert not early[i].prepared
+    for i in range(2):
+        assert int(early[i].step_counter.item()) == 2
+        assert torch.equal(pa[i], pb[i]) and torch.equal(early[i].lr_t, late[i].lr_t)
     # fold_fixup = False (data-parallel replicas fix up before their all-reduce): every segment is read plainly
     p2 = dev(p0)
     plain = ops.AdamArena(p2, g, torch.zeros_like(m), torch.zeros_like(v), segs)
