@@ -609,8 +609,22 @@ __global__ __launch_bounds__(winos::NT) void wino_wgrad_slab_kernel(int N, int H
     const int TH = H >> 1, TW = W >> 1;
     const long T = (long)N * TH * TW;
     const int nst_all = (int)((T + BT - 1) / BT);
-    const int c0 = blockIdx.x * BC, n0 = blockIdx.y * BK;
-    const int s0 = blockIdx.z * stages_per_split, s1 = min(nst_all, s0 + stages_per_split);
+    // The workgroups of one pixel range (same blockIdx.z, different channel / column blocks) read the same x and dY
+    // stages: walk the grid so that they sit on ONE XCD, next to each other in its dispatch order (hardware deals
+    // linear workgroup ids round-robin over the 8 XCDs), and the second reader is served by that XCD's L2.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const int per = gridDim.x * gridDim.y, n = per * gridDim.z;
+        if ((n & 7) == 0) {
+            const int id = bx + gridDim.x * (by + gridDim.y * bz);
+            const int v = (id & 7) * (n >> 3) + (id >> 3);
+            bx = v % gridDim.x;
+            by = (v / gridDim.x) % gridDim.y;
+            bz = v / per;
+        }
+    }
+    const int c0 = bx * BC, n0 = by * BK;
+    const int s0 = bz * stages_per_split, s1 = min(nst_all, s0 + stages_per_split);
     if (s0 >= s1) return;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (long)N * H * W * C * 4);
     const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, (long)N * H * W * K * 4);
@@ -658,7 +672,7 @@ __global__ __launch_bounds__(winos::NT) void wino_wgrad_slab_kernel(int N, int H
     };
     // ---- producer of the dY stage tile: item = (tile, pixel of its 2x2, channel quad of the 128), all threads
     const unsigned dyrow = (unsigned)(W * K * 4), dypix = (unsigned)(K * 4);
-    const bool dosum = DBIAS && blockIdx.x == 0;
+    const bool dosum = DBIAS && bx == 0;
     float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 rdyv[DYV];
     auto dyload = [&](int stage) {            // needs dyoff[stage], written at least one barrier ago
@@ -734,7 +748,7 @@ __global__ __launch_bounds__(winos::NT) void wino_wgrad_slab_kernel(int N, int H
             float t = 0.f;
 #pragma unroll
             for (int q = 0; q < NT / 32; ++q) t += smem[q * BK + tid];
-            dbpart[(long)blockIdx.z * K + n0 + tid] = t;
+            dbpart[(long)bz * K + n0 + tid] = t;
         }
         __syncthreads();
     }
@@ -758,7 +772,7 @@ __global__ __launch_bounds__(winos::NT) void wino_wgrad_slab_kernel(int N, int H
     }
     __syncthreads();
     const long CK = (long)C * K;
-    float *dst0 = part + (long)blockIdx.z * 9 * CK + (long)(c0 + 4 * kh) * K + n0 + wk * 32 + l31;
+    float *dst0 = part + (long)bz * 9 * CK + (long)(c0 + 4 * kh) * K + n0 + wk * 32 + l31;
     const float *theirs = ex + ((wv ^ 4) * 48) * 64 + lane;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
