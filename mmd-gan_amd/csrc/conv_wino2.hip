@@ -846,7 +846,12 @@ void slab_reduce(const float *part, int nsplit, size_t n, float *dw, const float
                  const float *wdot, float *dot) {
     const long n4 = (long)(n / 4), k4 = k / 4;
     long blocks = (n4 + k4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    // at most 512 workgroups: this pass runs on the weight-gradient stream beside the main stream's launches, and more of its
+    // small workgroups cost those launches more than they save here (CIFAR step, cap 2048 / 1024 / 512 / 256 / 128: 1.931 / 1.919 /
+    // 1.910 / 1.922 / 1.966 ms; CelebA flat down to 512); MMDGAN_SLAB_REDUCE_BLOCKS
+    static long cap = -1;
+    if (cap < 0) { const char *e = getenv("MMDGAN_SLAB_REDUCE_BLOCKS"); cap = e && atol(e) > 0 ? atol(e) : 512; }
+    if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float4 *)part, nsplit, n4, (float4 *)dw,
                        (const float4 *)dbpart, k4, (float4 *)dbias, (const float4 *)wdot, dot);
 }
