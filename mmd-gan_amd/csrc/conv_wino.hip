@@ -820,7 +820,7 @@ int wino_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, fl
     if (wino_wgrad_slab_ok(d)) {
         const int nst = (int)((T + winos::BT - 1) / winos::BT);
         const long base = (long)(d.C / winos::BC) * (d.K / winos::BK);
-        int split = (int)(256 / base);                                  // one 8-wave workgroup per CU, one round
+        int split = (int)(wgrad_cus() / base);                                  // one 8-wave workgroup per CU, one round
         if (split > nst / 2) split = nst / 2;                           // >= 2 stages (128 MFMAs per wave) per workgroup
         if (split < 1) split = 1;
         const int sps = (nst + split - 1) / split;

@@ -881,7 +881,7 @@ int wino2_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, f
     const long T = (long)d.N * (d.P / 2) * (d.Q / 2);
     const int nst = (int)((T + wino2w::BT - 1) / wino2w::BT);
     const long base = (long)(d.C / wino2w::BC) * (d.K / wino2w::BK) * 4;
-    int split = (int)(256 / base);                                  // one 8-wave workgroup per CU (140 KB of LDS), one round
+    int split = (int)(wgrad_cus() / base);                                  // one 8-wave workgroup per CU (140 KB of LDS), one round
     if (split > nst / 2) split = nst / 2;                           // >= 2 stages (144 MFMAs per wave) per workgroup
     if (split < 1) split = 1;
     const int sps = (nst + split - 1) / split;
