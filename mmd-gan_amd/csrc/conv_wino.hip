@@ -615,13 +615,11 @@ __global__ __launch_bounds__(winos::NT) void wino_wgrad_slab_kernel(int N, int H
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     {
         const int per = gridDim.x * gridDim.y, n = per * gridDim.z;
-        if ((n & 7) == 0) {
-            const int id = bx + gridDim.x * (by + gridDim.y * bz);
-            const int v = (id & 7) * (n >> 3) + (id >> 3);
-            bx = v % gridDim.x;
-            by = (v / gridDim.x) % gridDim.y;
-            bz = v / per;
-        }
+        const int id = bx + gridDim.x * (by + gridDim.y * bz), xcd = id & 7;
+        const int v = xcd * (n >> 3) + min(xcd, n & 7) + (id >> 3);     // XCD j holds ids j, j + 8, ...: n/8 of them, one more if j < n%8
+        bx = v % gridDim.x;
+        by = (v / gridDim.x) % gridDim.y;
+        bz = v / per;
     }
     const int c0 = bx * BC, n0 = by * BK;
     const int s0 = bz * stages_per_split, s1 = min(nst_all, s0 + stages_per_split);

@@ -1,6 +1,8 @@
 #!/bin/bash
 # run on the GPU box (through gpurun): collects the rocprofv3 evidence for profiles/.
 #   tools/collect_profiles.sh <tag>      -> gpurun_out/<tag>/...     then, here: python tools/make_profiles.py <tag>
+#   tools/collect_profiles.sh <tag> benches   only the bench lines: run it after make_profiles.py has written the
+#                                             r03_dominant_kernel_*.json of the same build (bench.py takes `traffic` from them)
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-r03}
@@ -8,6 +10,13 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py"
+benches() {
+cd $R
+MMDGAN_DP_FORCE=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 1 --no-cpu-baseline > $OUT/bench_dp_one_rank.json 2> /dev/null
+for c in stl celeba lsun_resnet; do python bench.py --config $c --steps 20 --warmup 5 > $OUT/bench_$c.json 2>/dev/null; done
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
+}
+if [ "${2:-all}" = "benches" ]; then benches; exit 0; fi
 if [ "${2:-all}" != "probes" ]; then
 # 1. the default bench command (launch mode chosen during warm-up; 4 streams): kernel trace + stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/default -o g -- $B --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline > $OUT/bench_default_profiled.json 2> $OUT/bench_default.err
@@ -42,6 +51,4 @@ MMDGAN_WINO2=0 MMDGAN_WINO=0 python tools/wino_bench.py 2>&1 | grep -v amdgpu.id
 python tools/bench_mmd.py 2>&1 | grep -v amdgpu.ids > $OUT/pairwise_kernel_sweep.txt
 python tools/issue_time.py > $OUT/launch_modes.txt 2>&1
 python tools/issue_time.py celeba >> $OUT/launch_modes.txt 2>&1
-MMDGAN_DP_FORCE=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 1 --no-cpu-baseline > $OUT/bench_dp_one_rank.json 2> /dev/null
-for c in stl celeba lsun_resnet; do python bench.py --config $c --steps 20 --warmup 5 > $OUT/bench_$c.json 2>/dev/null; done
-python bench.py > $OUT/bench.json 2> $OUT/bench.err
+benches
