@@ -149,10 +149,13 @@ def committed_profile(key, per_config=True):
     return d
 
 
-def loss_rel_err(eng, arch, lr, loss, B):
+def loss_rel_err(eng, arch, lr, loss, B, when):
     """the second half of BASELINE.json's metric ("MMD-loss rel-err vs ref"): one more step of the timed engine on a known
     batch, against the CPU oracle (the checker, fp64) started from the engine's variables before that step - the losses
-    of the HIP path relative to the reference algorithm on identical inputs, at the bench configuration itself."""
+    of the HIP path relative to the reference algorithm on identical inputs, at the bench configuration itself.
+    An MMD loss is a difference of kernel means (e_kxx + e_kyy - 2 e_kxy): `conditioning` = |loss_gen| / (e_kxx + e_kyy +
+    2 e_kxy) says how much of the means cancels at this point of the training, i.e. by how much the relative error of the
+    loss exceeds that of the means (`kernel_means`), which is what fp32 arithmetic bounds."""
     from oracle import restatement as R
     ora = R.OracleGan(arch, loss, tuple(lr), dtype=torch.float64, params=eng.get_variables())
     rs = np.random.RandomState(4321)
@@ -163,9 +166,13 @@ def loss_rel_err(eng, arch, lr, loss, B):
         lg, ld, stats, _, _ = ora.forward_losses(torch.tensor(z, dtype=torch.float64), torch.tensor(real, dtype=torch.float64))
     eng.step(torch.as_tensor(np.ascontiguousarray(real.transpose(0, 2, 3, 1))).cuda(), torch.as_tensor(z).cuda())
     got = eng.losses.cpu().numpy().astype(np.float64)
-    return {'loss_gen': abs(got[0] - float(lg)) / abs(float(lg)), 'loss_dis': abs(got[1] - float(ld)) / abs(float(ld)),
-            'values': {'loss_gen': [float(got[0]), float(lg)], 'loss_dis': [float(got[1]), float(ld)]},
-            'vs': 'oracle/restatement.py in fp64 from the engine\'s variables, same z and batch (B=%d)' % B, 'bar': 1e-4}
+    out = {'loss_gen': abs(got[0] - float(lg)) / abs(float(lg)), 'loss_dis': abs(got[1] - float(ld)) / abs(float(ld)),
+           'values': {'loss_gen': [float(got[0]), float(lg)], 'loss_dis': [float(got[1]), float(ld)]}, 'when': when}
+    if all(k in stats for k in ('kxx', 'kxy', 'kyy')) and got.shape[0] >= 5:
+        means = {k: float(stats[k]) for k in ('kxx', 'kxy', 'kyy')}
+        out['kernel_means'] = {k: abs(got[2 + i] - means[k]) / abs(means[k]) for i, k in enumerate(('kxx', 'kxy', 'kyy'))}
+        out['conditioning'] = abs(float(lg)) / (means['kxx'] + means['kyy'] + 2 * means['kxy'])
+    return out
 
 
 def cpu_model():
@@ -270,7 +277,15 @@ def main():
         probe = (dominant_kernel_probe_tape if tape else dominant_kernel_probe)(eng, reps=args.probe_reps, warm=args.probe_warm)
         print(json.dumps({'dominant_kernel': probe, 'reps': args.probe_reps, 'warm': args.probe_warm}))
         return
-    for _ in range(args.warmup):
+    # MMD-loss rel-err vs ref, untimed: at the engine's 5th step from its seeded initial variables (at the initial variables
+    # themselves D's scores are ~1e-5 and both losses are exactly 0 on both sides; a few steps in they are O(0.1) and neither
+    # degenerate nor cancelling), and once more after the whole run
+    rel_err, early = None, min(4, args.warmup)
+    for _ in range(early):
+        eng.step(real)
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        rel_err = loss_rel_err(eng, arch, lr, args.loss, B, 'step %d from the seeded initial variables' % (early + 1))
+    for _ in range(args.warmup - early):
         eng.step(real)
     barrier()
     want = 'eager' if args.no_graph else 'graph' if args.graph else args.launch_mode
@@ -395,7 +410,9 @@ def main():
             out['roofline']['whole_step']['mfma_busy_source'] = busy['_file']
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(arch, lr, args.loss, B, 1 if tape else args.cpu_steps)
-            out['mmd_loss_rel_err'] = loss_rel_err(eng, arch, lr, args.loss, B)
+            rel_err['after_the_timed_steps'] = loss_rel_err(eng, arch, lr, args.loss, B, 'after every step of this run (%d-odd steps on one synthetic batch)' % (args.warmup + args.repeats * args.steps))
+            rel_err.update({'vs': 'oracle/restatement.py in fp64 from the engine\'s variables, same z and batch (B=%d)' % B, 'bar': 1e-4})
+            out['mmd_loss_rel_err'] = rel_err
         print(json.dumps(out))
     if group is not None:
         import torch.distributed as dist
