@@ -187,10 +187,13 @@ def cpu_model():
     return platform.processor() or 'unknown'
 
 
-def cpu_baseline(arch, lr, loss, B, steps):
-    """the oracle restatement (fp32 torch-CPU) of the same step on the host cores, with all of torch's threads and with
-    one ("N = all host cores and N = 1, core count and CPU model printed"): a reported baseline, not the
-    optimisation target."""
+def cpu_baseline(arch, lr, loss, B, steps, budget_s=45.0):
+    """the oracle restatement (fp32 torch-CPU) of the same step on the host cores ("N = all host cores and
+    N = 1, core count and CPU model printed"): a reported baseline, not the optimisation target.  A batch of 64 32x32
+    images does not scale over torch-CPU's thread pool (128 threads measured SLOWER than one), so "all cores" alone is
+    not a baseline: the step is timed at threads in {1, 8, 16, 32, 64, all} - one un-warmed step each, cheapest first,
+    while the sample stays bounded (`budget_s`) - and `value` is the BEST of them over `steps` warmed steps, with the
+    count that gave it in `cores`; every count's rate is listed in `thread_sweep`."""
     from oracle import restatement as R
     threads = torch.get_num_threads()
     rs = np.random.RandomState(1234)
@@ -211,19 +214,48 @@ def cpu_baseline(arch, lr, loss, B, steps):
             torch.set_num_threads(threads)
     what = 'G+D steps of the same %dx%d B=%d workload, oracle/restatement.py fp32 on torch-CPU' % (
         arch['input'][0][1], arch['input'][0][2], B)
-    dt = timed(threads, steps, 1)
-    out = {'value': B * steps / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port', 'cpu_model': cpu_model(),
-           'host_cpus': os.cpu_count(), 'sample': '%d %s, %d threads (%.1f s)' % (steps, what, threads, dt)}
-    # one thread: ONE step, no warm-up (the first step of this restatement is ~10 % slower than the second), and only while
-    # that stays a bounded sample - a batch of 64 32x32 images scales poorly over threads (measured: one thread is 2-4x slower
-    # than 128), so the bound is 8x the all-thread step time <= 60 s
-    if dt / steps * 8.0 <= 60.0:
-        dt1 = timed(1, 1, 0)
-        out['single_thread'] = {'value': B / dt1, 'unit': 'images/sec', 'cores': 1,
-                                'sample': '1 %s, 1 thread, no warm-up (%.1f s)' % (what, dt1)}
-    else:
-        out['single_thread'] = None
-    return out
+    t_start = time.perf_counter()
+    counts = sorted({n for n in (1, 8, 16, 32, 64, threads) if n <= threads}, key=lambda n: (n == 1, -n))   # one thread last: the slowest
+    sweep, last = {}, 0.0
+    for n in counts:
+        if time.perf_counter() - t_start + 1.5 * last > budget_s and sweep:
+            sweep[n] = None                              # not run: the sample would leave its bound
+            continue
+        last = timed(n, 1, 0)
+        sweep[n] = B / last
+    best = max((n for n in sweep if sweep[n]), key=lambda n: sweep[n])
+    dt = timed(best, steps, 1)
+    sweep[best] = max(sweep[best], B * steps / dt)
+    return {'value': B * steps / dt, 'unit': 'images/sec', 'cores': best, 'kind': 'port', 'cpu_model': cpu_model(),
+            'host_cpus': os.cpu_count(), 'torch_threads_default': threads,
+            'sample': '%d %s, %d threads = the best of the sweep (%.1f s); sweep = one un-warmed step per thread count'
+                      % (steps, what, best, dt),
+            'thread_sweep': {str(n): (None if v is None else round(v, 2)) for n, v in sorted(sweep.items())},
+            'all_threads': None if sweep.get(threads) is None else {'value': sweep[threads], 'cores': threads},
+            'single_thread': None if sweep.get(1) is None else {'value': sweep[1], 'unit': 'images/sec', 'cores': 1,
+                                                                 'sample': '1 %s, 1 thread, no warm-up' % what}}
+
+
+def kernel_set_check(eng, config, loss, B):
+    """do the kernels of THIS run's step equal the ones the parity tests ran (tests/test_production_gpu.py)?  One step
+    is recorded as a launch plan and its kernel list (mmdgan_plan_describe) compared with the committed
+    tests/golden/production_kernels.json - the list those tests assert, under the same default environment."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import shipped_step
+    expected = shipped_step.expected_kernels(config, loss, B)
+    keep = eng.launch_mode
+    try:
+        eng.launch_mode = 'plan'
+        for _ in range(2):
+            eng.step()
+        got = shipped_step.kernel_multiset(eng.plan_kernels())
+    finally:
+        eng.launch_mode = keep
+    env = sorted(k for k in os.environ if k.startswith('MMDGAN_'))
+    diff = None if expected is None else sorted(k for k in set(got) | set(expected) if got.get(k) != expected.get(k))
+    return {'launches_per_step': sum(got.values()), 'distinct': len(got), 'fixture': 'tests/golden/production_kernels.json',
+            'case': shipped_step.case_key(config, loss, B), 'equals_tested_set': None if expected is None else not diff,
+            'differs_in': diff[:8] if diff else None, 'mmdgan_env': env}
 
 
 def main():
@@ -412,8 +444,24 @@ def main():
             out['cpu_baseline'] = cpu_baseline(arch, lr, args.loss, B, 1 if tape else args.cpu_steps)
             rel_err['after_the_timed_steps'] = loss_rel_err(eng, arch, lr, args.loss, B, 'after every step of this run (%d-odd steps on one synthetic batch)' % (args.warmup + args.repeats * args.steps))
             rel_err.update({'vs': 'oracle/restatement.py in fp64 from the engine\'s variables, same z and batch (B=%d)' % B, 'bar': 1e-4})
+            # the bar, applied to BOTH points.  At step 5 the losses themselves are held to 1e-4.  After the run the criterion is
+            # the one fp32 arithmetic can meet wherever the training went: every kernel mean within 1e-4, and the loss within
+            # 1e-4 / conditioning (a loss that is `conditioning` of the means it is the difference of carries their error
+            # divided by it)
+            post = rel_err['after_the_timed_steps']
+            rel_err['pass'] = bool(rel_err['loss_gen'] <= 1e-4 and rel_err['loss_dis'] <= 1e-4)
+            if 'kernel_means' in post:
+                cond = max(min(post['conditioning'], 1.0), 1e-12)
+                post['pass'] = bool(max(post['kernel_means'].values()) <= 1e-4 and post['loss_gen'] <= 1e-4 / cond)
+            else:
+                post['pass'] = bool(post['loss_gen'] <= 1e-4 and post['loss_dis'] <= 1e-4)
             out['mmd_loss_rel_err'] = rel_err
+            gate_failed = not (rel_err['pass'] and post['pass'])
+        if world == 1 and hasattr(eng, 'plan_kernels'):
+            out['config']['kernel_set'] = kernel_set_check(eng, args.config, args.loss, B)
         print(json.dumps(out))
+        if world == 1 and not args.no_cpu_baseline and gate_failed:
+            sys.exit('bench.py: mmd_loss_rel_err is above its bar (see the JSON line): %r' % (rel_err,))
     if group is not None:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -128,6 +128,11 @@ int mmdgan_plan_end(int *plan_id);
 int mmdgan_plan_abort(void);                   /* drop a recording in progress (an entry failed) */
 int mmdgan_plan_segments(int plan_id);         /* < 0: no such plan */
 long mmdgan_plan_nodes(int plan_id);           /* recorded launches / memsets / dependencies; < 0: no such plan */
+/* the kernel launches of a plan in issue order, one text line each: "<demangled kernel>\t<workgroups>\t<threads per
+ * workgroup>\t<stream number, by first use>\n" - which kernels a recorded step consists of (the reference's step is one fixed
+ * graph, graph_func.py:851-854: tests and the bench compare this list with a committed one).  Writes at most cap-1 bytes
+ * plus a terminator into buf (buf may be NULL); returns the size a complete listing needs, < 0: no such plan. */
+long mmdgan_plan_describe(int plan_id, char *buf, size_t cap);
 int mmdgan_plan_replay(int plan_id, int segment);
 int mmdgan_plan_destroy(int plan_id);
 int mmdgan_stream_wait(void *waiting_stream, void *signalling_stream);

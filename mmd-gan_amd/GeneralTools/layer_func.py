@@ -91,7 +91,9 @@ class Routine(object):
                 '{}: the input shape {} does not match existed shape {}.'.format(self.net.net_name, list(x.shape[1:]),
                                                                                 self.net.in_shape_ref)
             y = self.net.lowered(ops.nchw_to_nhwc(x.contiguous()) if x.dim() == 4 else x.contiguous(), is_training)
-            return {'x': ops.nhwc_to_nchw(y.contiguous()) if y.dim() == 4 else y}
+            # a 2-D result is the lowered net's cached buffer (keyed by batch size): the next call with that batch size would
+            # overwrite what this one returned - s_x = D(x)['x']; s_gen = D(G(z))['x'] - so it leaves as a copy
+            return {'x': ops.nhwc_to_nchw(y.contiguous()) if y.dim() == 4 else y.clone()}
         specs = net.specs
         assert list(x.shape[1:]) == specs[0].in_shape_ref, \
             '{}: the input shape {} does not match existed shape {}.'.format(specs[0].scope, list(x.shape[1:]),

@@ -31,6 +31,7 @@ bool outputs_prezeroed();         // mmdgan_set_outputs_prezeroed of the current
 // sequence is static can then be replayed from one C call without its ~200 host-side entry calls.
 bool plan_recording();
 void plan_push(std::function<void()> &&node);
+void plan_note_kernel(const void *host_fn, dim3 grid, dim3 block, hipStream_t st);   // what mmdgan_plan_describe lists
 void plan_note_collective();      // the plan being recorded holds a collective of the library's current communicator
 hipError_t memset_async(void *p, int value, size_t bytes, hipStream_t st);
 inline hipError_t zero_output(void *p, size_t bytes, hipStream_t st) {
@@ -42,10 +43,12 @@ inline void launch_k(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shm
     // convert to the kernel's own parameter types first: a recorded node must hold exactly what the kernel receives
     std::tuple<std::decay_t<KArgs>...> pack{static_cast<std::decay_t<KArgs>>(args)...};
     std::apply([&](auto &...a) { kernel<<<grid, block, shmem, st>>>(a...); }, pack);
-    if (plan_recording())
+    if (plan_recording()) {
+        plan_note_kernel((const void *)kernel, grid, block, st);
         plan_push([kernel, grid, block, shmem, st, pack]() mutable {
             std::apply([&](auto &...a) { kernel<<<grid, block, shmem, st>>>(a...); }, pack);
         });
+    }
 }
 
 inline int check_launch(const char *what) {

@@ -1,8 +1,11 @@
 // error state, version, device probe, handles (workspace / prezeroed mode / launch plans / events)
 #include "common.h"
 
+#include <cxxabi.h>
+
 #include <memory>
 #include <mutex>
+#include <string>
 #include <vector>
 
 namespace mmdgan {
@@ -20,6 +23,8 @@ struct Plan {
     std::vector<std::function<void()>> nodes;
     std::vector<size_t> segment_end;          // node count at the end of each closed segment
     std::vector<hipEvent_t> events;           // one per recorded stream_wait node (re-used on every replay), freed with the plan
+    struct KernelNote { const void *fn; unsigned grid, block; hipStream_t st; };
+    std::vector<KernelNote> kernels;          // every kernel launch of the plan in issue order (mmdgan_plan_describe)
     unsigned comm_generation = 0;             // of the library's communicator when a collective was recorded (0: none recorded)
     ~Plan() {
         for (hipEvent_t e : events)
@@ -83,6 +88,9 @@ void *workspace_acquire(size_t need, hipStream_t st) {
 }
 bool plan_recording() { return cur().recording != nullptr; }
 void plan_push(std::function<void()> &&node) { cur().recording->nodes.emplace_back(std::move(node)); }
+void plan_note_kernel(const void *fn, dim3 grid, dim3 block, hipStream_t st) {
+    cur().recording->kernels.push_back({fn, grid.x * grid.y * grid.z, block.x * block.y * block.z, st});
+}
 void plan_note_collective() { cur().recording->comm_generation = comm_generation(); }
 
 hipError_t memset_async(void *p, int value, size_t bytes, hipStream_t st) {
@@ -274,6 +282,33 @@ extern "C" long mmdgan_plan_nodes(int plan_id) {
     mmdgan_handle &h = cur();
     if (plan_id < 0 || plan_id >= (int)h.plans.size() || !h.plans[plan_id]) return MMDGAN_E_ARG;
     return (long)h.plans[plan_id]->nodes.size();
+}
+extern "C" long mmdgan_plan_describe(int plan_id, char *buf, size_t cap) {
+    mmdgan_handle &h = cur();
+    if (plan_id < 0 || plan_id >= (int)h.plans.size() || !h.plans[plan_id]) return MMDGAN_E_ARG;
+    Plan &p = *h.plans[plan_id];
+    std::vector<hipStream_t> streams;                     // streams numbered in order of first use
+    std::string out;
+    for (const Plan::KernelNote &k : p.kernels) {
+        size_t si = 0;
+        while (si < streams.size() && streams[si] != k.st) ++si;
+        if (si == streams.size()) streams.push_back(k.st);
+        const char *mangled = hipKernelNameRefByPtr(k.fn, k.st);
+        (void)hipGetLastError();
+        int status = 1;
+        char *dem = mangled ? abi::__cxa_demangle(mangled, nullptr, nullptr, &status) : nullptr;
+        out += (status == 0 && dem) ? dem : (mangled ? mangled : "?");
+        if (dem) free(dem);
+        char tail[64];
+        snprintf(tail, sizeof(tail), "\t%u\t%u\t%zu\n", k.grid, k.block, si);
+        out += tail;
+    }
+    if (buf && cap > 0) {
+        const size_t n = out.size() < cap - 1 ? out.size() : cap - 1;
+        memcpy(buf, out.data(), n);
+        buf[n] = 0;
+    }
+    return (long)out.size() + 1;
 }
 extern "C" int mmdgan_plan_replay(int plan_id, int segment) {
     mmdgan_handle &h = cur();

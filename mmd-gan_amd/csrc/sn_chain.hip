@@ -220,9 +220,15 @@ __global__ __launch_bounds__(256) void sn_phase_kernel(SnPhase ph_by_value) {
 namespace {
 struct PhaseBuilder {
     SnPhase ph[8];
+    SnOp spill;                                            // where an operation beyond kSnOpsMax lands (then `overflow`)
+    bool overflow = false;
     PhaseBuilder() { std::memset(ph, 0, sizeof(ph)); }
     SnOp &add(int p, int kind, unsigned nblocks) {
         SnPhase &s = ph[p];
+        if (s.n >= kSnOpsMax) {                            // the by-value kernel argument holds kSnOpsMax operations per stage
+            overflow = true;
+            return spill;
+        }
         SnOp &o = s.ops[s.n];
         o.kind = kind;
         o.first_block = s.n ? s.ops[s.n - 1].first_block + s.ops[s.n - 1].nblocks : 0;
@@ -273,6 +279,9 @@ extern "C" int mmdgan_sn_power_iteration(const mmdgan_sn_layer *layers, int n_la
     MMDGAN_REQUIRE(layers || n_layers == 0, "sn_power_iteration: null layer list");
     MMDGAN_REQUIRE(n_layers >= 0, "sn_power_iteration: negative layer count");
     hipStream_t st = (hipStream_t)stream;
+    // a group is kSnOpsMax / 2 kernels: a kernel adds at most TWO operations to a stage (the two products of stages 4 / 5),
+    // stage 0 holds the group's zeroing operation plus at most one per kernel - PhaseBuilder::add checks it anyway
+    static_assert(kSnOpsMax % 2 == 0 && kSnOpsMax / 2 + 1 <= kSnOpsMax, "group size against the operation table");
     for (int i0 = 0; i0 < n_layers; i0 += kSnOpsMax / 2) {
         const int n = n_layers - i0 < kSnOpsMax / 2 ? n_layers - i0 : kSnOpsMax / 2;
         PhaseBuilder pb;
@@ -359,6 +368,7 @@ extern "C" int mmdgan_sn_power_iteration(const mmdgan_sn_layer *layers, int n_la
                 break;
             }
         }
+        MMDGAN_REQUIRE(!pb.overflow, "sn_power_iteration: more than %d operations in one stage of a group", kSnOpsMax);
         for (int p = 0; p < 8; ++p) {
             const SnPhase &s = pb.ph[p];
             if (!s.n) continue;

@@ -31,6 +31,7 @@ SIGNATURES = {
     'mmdgan_plan_abort': (_I, []),
     'mmdgan_plan_segments': (_I, [_I]),
     'mmdgan_plan_nodes': (_L, [_I]),
+    'mmdgan_plan_describe': (_L, [_I, ctypes.c_char_p, ctypes.c_size_t]),
     'mmdgan_plan_replay': (_I, [_I, _I]),
     'mmdgan_plan_destroy': (_I, [_I]),
     'mmdgan_stream_wait': (_I, [_P, _P]),

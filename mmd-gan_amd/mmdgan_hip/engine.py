@@ -1229,23 +1229,48 @@ class GanEngine:
         return OrderedDict((s.scope, float(net.state[s.scope + '#sigma'].item()))
                            for net in (self.dis, self.gen) for s in net.specs if s.sn)
 
+    def get_adam_state(self):
+        """(m, v, t): the Adam moments by variable name in the reference's layouts, and the step count - what set_adam_state takes"""
+        m, v = OrderedDict(), OrderedDict()
+        for net in (self.gen, self.dis):
+            for k in net.variable_names(trainable_only=True):
+                m[k] = net._to_ref(k, net.arena.view(k, net.adam_m).detach().cpu().numpy())
+                v[k] = net._to_ref(k, net.arena.view(k, net.adam_v).detach().cpu().numpy())
+        return m, v, int(self.dis.opt.step_counter.item())
+
     def state_dict(self):
-        sd = {'global_step': self.global_step, 'variables': self.get_variables(), 'loss_state': self._loss.state_dict()}
-        for tag, net in (('gen', self.gen), ('dis', self.dis)):
-            sd[tag + '/adam_m'] = net.adam_m.cpu()
-            sd[tag + '/adam_v'] = net.adam_v.cpu()
-            sd[tag + '/adam_t'] = int(net.opt.step_counter.item())
-        return sd
+        """format 2: the Adam moments travel BY VARIABLE NAME in the reference's layouts, like the variables - a checkpoint
+        does not depend on how the engine lays its arenas out (format 1 stored the flat arenas, which the `#sn_dot` scratch
+        entry at their head shifted)"""
+        m, v, t = self.get_adam_state()
+        return {'format': 2, 'global_step': self.global_step, 'variables': self.get_variables(),
+                'loss_state': self._loss.state_dict(), 'adam_m': m, 'adam_v': v, 'adam_t': t}
 
     def load_state_dict(self, sd):
         self.set_variables(sd['variables'])
         self.global_step = int(sd['global_step'])
         self._loss.load_state_dict(sd.get('loss_state', {}))
-        for tag, net in (('gen', self.gen), ('dis', self.dis)):
-            net.adam_m.copy_(sd[tag + '/adam_m'])
-            net.adam_v.copy_(sd[tag + '/adam_v'])
-            net.opt.step_counter.fill_(int(sd[tag + '/adam_t']))
+        if sd.get('format', 1) >= 2:
+            self.set_adam_state(sd['adam_m'], sd['adam_v'], sd['adam_t'])
+        else:                                            # format 1: flat arenas of the layout that wrote them
+            for tag, net in (('gen', self.gen), ('dis', self.dis)):
+                if sd[tag + '/adam_m'].numel() != net.adam_m.numel():
+                    raise ValueError('checkpoint format 1 holds the Adam moments of %s as a flat arena of %d floats, this build\'s '
+                                     'arena has %d: re-save it with the build that wrote it' %
+                                     (tag, sd[tag + '/adam_m'].numel(), net.adam_m.numel()))
+                net.adam_m.copy_(sd[tag + '/adam_m'])
+                net.adam_v.copy_(sd[tag + '/adam_v'])
+                net.opt.step_counter.fill_(int(sd[tag + '/adam_t']))
         self._drop_recordings()
+
+    def plan_kernels(self):
+        """the kernel launches of the recorded step, in issue order: [(kernel, workgroups, threads, stream number)] -
+        launch_mode 'plan', after the first step (ops.plan_kernels).  The reference's step is one fixed graph
+        (graph_func.py:851-854); this is the build's: tests and bench.py compare it with tests/golden/production_kernels.json"""
+        if self._plan is None:
+            raise RuntimeError('no recorded plan: launch_mode must be "plan" and one step must have run')
+        with self._handle:
+            return ops.plan_kernels(self._plan)
 
     def _drop_recordings(self):
         """forget the captured graph and the recorded plan (both are re-made by the next step)"""

@@ -88,6 +88,41 @@ class Handle:
             pass
 
 
+def plan_kernels(plan_id):
+    """the kernel launches of a recorded plan of the CURRENT handle, in issue order: [(kernel, workgroups, threads, stream
+    number)] with the kernel's demangled name cut before its parameter list (mmdgan_plan_describe)"""
+    lib = require_device()
+    need = lib.mmdgan_plan_describe(int(plan_id), None, 0)
+    if need < 0:
+        raise ValueError('no plan %r on the current handle' % (plan_id,))
+    buf = ctypes.create_string_buffer(int(need))
+    lib.mmdgan_plan_describe(int(plan_id), buf, need)
+    out = []
+    for line in buf.value.decode().splitlines():
+        name, grid, block, st = line.rsplit('\t', 3)
+        out.append((kernel_base_name(name), int(grid), int(block), int(st)))
+    return out
+
+
+def kernel_base_name(demangled):
+    """'void mmdgan::wino_kernel<64, true>(mmdgan::WinoArgs)' -> 'wino_kernel<64, true>': the part before the parameter
+    list (the first '(' outside template brackets), without return type and namespace"""
+    demangled = demangled.replace('(anonymous namespace)::', '')
+    depth, end = 0, len(demangled)
+    for i, ch in enumerate(demangled):
+        if ch == '<':
+            depth += 1
+        elif ch == '>':
+            depth -= 1
+        elif ch == '(' and depth == 0:
+            end = i
+            break
+    head = demangled[:end].strip()
+    cut = head.find('<') if '<' in head else len(head)
+    start = max(head.rfind(' ', 0, cut), head.rfind('::', 0, cut) + 1) + 1
+    return head[start:]
+
+
 def stream_wait(waiting, signalling):
     """raw hipStream_t handles (ints): work issued later on `waiting` starts after what `signalling` holds now"""
     check(require_device().mmdgan_stream_wait(waiting, signalling), 'stream_wait')

@@ -1365,6 +1365,13 @@ class TapeEngine:
                 self._plan_step()
         self.global_step += 1
 
+    def plan_kernels(self):
+        """the kernel launches of the recorded step in issue order (GanEngine.plan_kernels)"""
+        if self._plan is None:
+            raise RuntimeError('no recorded plan: launch_mode must be "plan" and one step must have run')
+        with self._handle:
+            return ops.plan_kernels(self._plan)
+
     def _drop_plan(self):
         if self._plan is not None:
             with self._handle:
@@ -1427,18 +1434,32 @@ class TapeEngine:
                     out[scope] = float(net.sn[k.scope]['sigma'].item())
         return out
 
+    def get_adam_state(self):
+        """(m, v, t): Adam moments by variable name in the reference's layouts and the step count (what set_adam_state takes)"""
+        m, v = OrderedDict(), OrderedDict()
+        for net in (self.gen, self.dis):
+            for k in net.variable_names(trainable_only=True):
+                m[k] = net.to_ref(k, net.arena.view(k, net.adam_m).detach().cpu().numpy())
+                v[k] = net.to_ref(k, net.arena.view(k, net.adam_v).detach().cpu().numpy())
+        return m, v, int(self.dis.opt.step_counter.item())
+
     def state_dict(self):
-        sd = {'global_step': self.global_step, 'variables': self.get_variables(), 'loss_state': self._loss.state_dict()}
-        for tag, net in (('gen', self.gen), ('dis', self.dis)):
-            sd[tag + '/adam_m'], sd[tag + '/adam_v'] = net.adam_m.cpu(), net.adam_v.cpu()
-            sd[tag + '/adam_t'] = int(net.opt.step_counter.item())
-        return sd
+        """format 2 (GanEngine.state_dict): Adam moments by variable name, independent of the arena layout"""
+        m, v, t = self.get_adam_state()
+        return {'format': 2, 'global_step': self.global_step, 'variables': self.get_variables(),
+                'loss_state': self._loss.state_dict(), 'adam_m': m, 'adam_v': v, 'adam_t': t}
 
     def load_state_dict(self, sd):
         self.set_variables(sd['variables'])
         self.global_step = int(sd['global_step'])
         self._loss.load_state_dict(sd.get('loss_state', {}))
-        for tag, net in (('gen', self.gen), ('dis', self.dis)):
-            net.adam_m.copy_(sd[tag + '/adam_m'])
-            net.adam_v.copy_(sd[tag + '/adam_v'])
-            net.opt.step_counter.fill_(int(sd[tag + '/adam_t']))
+        if sd.get('format', 1) >= 2:
+            self.set_adam_state(sd['adam_m'], sd['adam_v'], sd['adam_t'])
+        else:                                            # format 1: the flat arenas of the layout that wrote them
+            for tag, net in (('gen', self.gen), ('dis', self.dis)):
+                if sd[tag + '/adam_m'].numel() != net.adam_m.numel():
+                    raise ValueError('checkpoint format 1 holds the Adam moments of %s as a flat arena of another layout' % tag)
+                net.adam_m.copy_(sd[tag + '/adam_m'])
+                net.adam_v.copy_(sd[tag + '/adam_v'])
+                net.opt.step_counter.fill_(int(sd[tag + '/adam_t']))
+        self._drop_plan()

@@ -57,3 +57,16 @@ def pytest_sessionstart(session):
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
         mod.build(verbose=False)
+
+
+def pytest_terminal_summary(terminalreporter):
+    """how often a step test fell back to the comparison under the engine's own sign decisions (helpers.note_knife_edge_retry):
+    printed in every gpu session's log, zero included, so the frequency of that path is on record"""
+    try:
+        import helpers
+    except ImportError:
+        return
+    n = len(helpers.KNIFE_EDGE_RETRIES)
+    terminalreporter.write_line('knife-edge retries (fallback to the engine\'s sign decisions): %d' % n)
+    for what in helpers.KNIFE_EDGE_RETRIES:
+        terminalreporter.write_line('  knife-edge retry: ' + what)

@@ -103,13 +103,40 @@ def engine_masks(eng):
 
 
 GRAD_BAR = 5e-4
+GRAD_MAXABS_BAR = 2e-3
+
+# every time a test falls back to the comparison "under the engine's own sign decisions" (a relu / lrelu output within fp32
+# resolution of zero decided the other way in this run) it is counted here; tests/conftest.py prints the tally at the end
+# of the session, so a log shows how often the fallback fired and for which test
+KNIFE_EDGE_RETRIES = []
+
+
+class KnifeEdgeRetry(UserWarning):
+    pass
+
+
+def note_knife_edge_retry(what):
+    import warnings
+    KNIFE_EDGE_RETRIES.append(str(what))
+    warnings.warn('%s: knife-edge activation decided the other way in this run; compared under the engine\'s sign decisions'
+                  % (what,), KnifeEdgeRetry)
+
+
+def max_err(got, ref, gscale=0.0):
+    """max|got - ref| / (max|ref| + 1e-6 * gscale): the ENTRY-wise companion of l2_err - a localised fault (one wrong border
+    row, one bad tile, one phase of a composed convolution) that an L2 norm over a whole kernel dilutes shows up here"""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-6 * gscale))
 
 
 def assert_grads_within_fp32_floor(grads, ref64, floor32, skip=(), what=''):
-    """THE rule for gradients of a step against the fp64 oracle (one rule, every step test): each tensor within 5e-4 in L2,
-    or within twice what an fp32 evaluation of the oracle itself loses against its fp64 evaluation on the same step.
+    """THE rule for gradients of a step against the fp64 oracle (one rule, every step test): each tensor within 5e-4 in L2
+    AND every entry within 2e-3 of the tensor's largest - or within twice what an fp32 evaluation of the oracle itself
+    loses against its fp64 evaluation on the same step (same two measures), plus those bars.
     grads / ref64: name -> array; floor32: a callable returning name -> array (the fp32 oracle's gradients; evaluated
-    lazily, once, only when some tensor is above the plain bar) or a dict."""
+    lazily, once, only when some tensor is above the plain bars) or a dict.  skip: variables whose gradient is ZERO
+    analytically (the last D bias: the loss sees score differences only) - what any implementation holds there is rounding
+    noise, so instead of comparing noise with noise they are held to 1e-4 of their net's gradient scale."""
     cache = {}
 
     def f32():
@@ -123,13 +150,16 @@ def assert_grads_within_fp32_floor(grads, ref64, floor32, skip=(), what=''):
         gscale = max(float(np.abs(np.asarray(ref64[n])).max()) for n in names)
         for n in names:
             if n in skip:
+                assert float(np.abs(np.asarray(grads[n])).max()) <= 1e-4 * gscale, (what, n, 'analytically zero gradient', gscale)
                 continue
             r = np.asarray(ref64[n], np.float64)
-            err = l2_err(grads[n], r, gscale)
-            if err <= GRAD_BAR:
+            err, emax = l2_err(grads[n], r, gscale), max_err(grads[n], r, gscale)
+            if err <= GRAD_BAR and emax <= GRAD_MAXABS_BAR:
                 continue
-            fl = l2_err(np.asarray(f32()[n], np.float64), r, gscale)
-            assert err <= 2.0 * fl + GRAD_BAR, (what, n, err, fl)
+            f = np.asarray(f32()[n], np.float64)
+            fl, flmax = l2_err(f, r, gscale), max_err(f, r, gscale)
+            assert err <= 2.0 * fl + GRAD_BAR, (what, n, 'L2', err, fl)
+            assert emax <= 2.0 * flmax + GRAD_MAXABS_BAR, (what, n, 'max-abs', emax, flmax)
 
 
 def fp32_floor(arch, loss_type, lr, prev_vars, z, real, eng, uni=None, mix_state=None, **kw):

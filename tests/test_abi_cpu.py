@@ -63,6 +63,7 @@ def test_handles_and_plan_bookkeeping_without_a_device():
     pid = ctypes.c_int(-1)
     assert lib.mmdgan_plan_end(ctypes.byref(pid)) == 0 and pid.value == 0
     assert lib.mmdgan_plan_segments(0) == 2 and lib.mmdgan_plan_nodes(0) == 2
+    assert lib.mmdgan_plan_describe(0, None, 0) == 1        # no kernel launch in it: an empty listing (terminator only)
     # the other handle knows nothing of it
     assert lib.mmdgan_make_current(h2) == 0
     assert lib.mmdgan_plan_segments(0) < 0

@@ -135,6 +135,32 @@ def test_routine_runs_residual_block_designs(which):
                 assert np.array_equal(net.network.get_variable(k), params[k].float().numpy()), k
 
 
+def test_routine_results_of_two_calls_do_not_alias():
+    """s_x = D(x)['x']; s_gen = D(G(z))['x'] - the reference's usage (my_sngan.py:278-279 on split halves): the first
+    result must still hold D(x) after the second call with the same batch size.  The primitive-op path (residual blocks)
+    returned its cached [batch, d] buffer un-copied; both paths are checked."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
+    from tiny_arch import tiny_architecture, tiny_res_architecture
+    from GeneralTools.layer_func import Net, Routine
+    for arch in (tiny_res_architecture(), tiny_architecture()):
+        in_ref = list(arch['input'][0])
+        net = Net(arch['discriminator'], net_name='dis', data_format='channels_first', num_class=0)
+        r = Routine(net)
+        r.add_input_layers([6] + in_ref, [0])
+        r.seq_links(list(range(net.num_layers)))
+        r.add_output_layers([net.num_layers - 1])
+        rs = np.random.RandomState(4)
+        xa = torch.as_tensor(rs.randn(6, *in_ref).astype(np.float32)).cuda()
+        xb = torch.as_tensor(rs.randn(6, *in_ref).astype(np.float32)).cuda()
+        r({'x': xa}, is_training=True)                   # creates the variables, normalises the power-iteration vectors
+        s_a = r({'x': xa}, is_training=False)['x']
+        keep = s_a.clone()
+        s_b = r({'x': xb}, is_training=False)['x']
+        assert s_a.data_ptr() != s_b.data_ptr()
+        assert torch.equal(s_a, keep) and not torch.equal(s_a, s_b)
+
+
 def test_eval_sampling_writes_the_reference_sprite_from_inference_mode_images(tmp_path):
     """my_sngan.py:499-581 after a few training steps (BN moving statistics away from their initial values): the
     images are G(code) with the MOVING statistics, checked against the oracle run with the engine's

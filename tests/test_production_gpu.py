@@ -1,0 +1,58 @@
+"""The step parity tests UNDER THE PRODUCTION KERNEL SELECTION, at the per-GPU batch of every BASELINE.json config.
+
+tests/conftest.py lowers the Winograd thresholds so that the small parity cases reach those kernels; the library caches
+such switches on first use, so this process cannot return to the defaults.  Each case below therefore runs
+tests/shipped_step.py in a SUBPROCESS whose environment holds no MMDGAN_* variable - exactly what `python bench.py`
+runs with - and checks, beside parity (images, scores, losses, every gradient against the fp64 oracle), that the
+recorded step consists of the kernels committed in tests/golden/production_kernels.json.  bench.py compares its own
+recorded step with the same file (`config.kernel_set`), so the kernels measured are the kernels tested.  The
+reference's counterpart is its one fixed graph per config (graph_func.py:851-854).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import shipped_step
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# (config, loss, per-GPU batch): BASELINE.json configs 2-5 (configs[0] is the reference's own CPU case)
+CASES = [('cifar', 'rep', 64), ('stl', 'rmb', 64), ('celeba', 'rep', 128), ('lsun_resnet', 'rep', 32)]
+
+
+def run_in_default_env(config, loss, B, mode='plan', timeout=1500):
+    env = {k: v for k, v in os.environ.items() if not k.startswith('MMDGAN_')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'shipped_step.py'), config, loss, str(B), mode],
+                       env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, 'shipped_step.py %s %s %d failed:\n%s\n%s' % (config, loss, B, r.stdout[-2000:], r.stderr[-4000:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize('config,loss,B', CASES)
+def test_step_under_the_production_kernel_selection(config, loss, B):
+    """one teacher-forced step from a warmed state through the recorded launch plan (the way bench.py issues the step),
+    no MMDGAN_* switch set: images / scores / losses at 1e-4, every gradient by the one gradient rule (helpers.py) at the
+    config's own batch - CelebA at 128 and the ResNet-SN at 32 included - and the step's kernel list equal to the
+    committed one."""
+    out = run_in_default_env(config, loss, B)
+    assert out['env'] == [], out['env']
+    assert out['grad_tensors'] >= 20
+    expected = shipped_step.expected_kernels(config, loss, B)
+    assert expected is not None, ('no committed kernel list for %s: run tools/record_production_kernels.py on the GPU box'
+                                  % shipped_step.case_key(config, loss, B))
+    assert out['kernels'] == expected, {k: (out['kernels'].get(k), expected.get(k))
+                                        for k in set(out['kernels']) | set(expected) if out['kernels'].get(k) != expected.get(k)}
+
+
+def test_this_process_does_not_run_the_production_selection():
+    """the reason for the subprocess: under tests/conftest.py's thresholds the SAME config takes other kernels (every
+    3x3 / 4x4 layer through the Winograd ones, whatever its grid) - if this ever stops being true the subprocess cases
+    above are redundant, not wrong"""
+    assert os.environ.get('MMDGAN_WINO_MIN_TILES') == '32' and os.environ.get('MMDGAN_WINO2') == '2'
+    out = shipped_step.run('cifar', 'rep', 8, 'plan', warm=2, check_grads=False)
+    assert out['env'] != [] and out['launches'] > 50

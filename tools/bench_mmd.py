@@ -7,7 +7,20 @@ from mmdgan_hip import ops
 d = 16
 print('# mmdgan_mmd_loss, d = 16, fp32; forward+backward in one launch ("fwd" = need_grads False)')
 print('# algorithmic bytes: read 2*B*d*4, write 8 scalars (+ 4*B*d*4 gradients); pairs = 4*B^2 distance/kernel evaluations')
-print('%6s %5s %10s %12s %14s %12s' % ('B', 'loss', 'us', 'alg. GB/s', '% of 8 TB/s', 'Gpair/s'))
+# What bounds it at large B is neither HBM nor a matrix pipe but VALU issue (and the LDS port feeding it).  Instruction model of
+# csrc/mmd.hip per (i, j) lane-iteration = 4 distance / kernel evaluations ("pairs"), d = 16, counted in fp32 VALU issue slots
+# (a transcendental v_exp_f32 is quarter rate = 4 slots, expf = scale + v_exp):
+#   forward : 6 dot products x 16 fma = 96, distances / clamps / sums ~ 24, 4 expf x 5 = 20         -> 140 slots = 35 per pair
+#   backward: 16 x (4 sub + 8 fma) = 192, 8 coefficients ~ 24                                        -> +216     = +54 per pair
+#   rmb     : two more expf on the bounded blocks + 4 compares                                        -> +14      = +3.5 per pair
+#   mmd_g   : five Gaussians per evaluation: 4 x 4 more expf + 4 x 8 fma                              -> +112     = +28 per pair
+# VALU issue peak: 256 CU x 4 SIMD x 32 lanes / clk x 2.4 GHz = 78.6 T lane-slots/s (the 157.3 TFLOP/s fp32 vector peak / 2).
+# LDS: the 32 ds_read_b32 of x_j / y_j per tile and wave (row stride d + 1: conflict-free) take 2 clk each on the CU's one
+# 128 B/clk port, 4 waves -> 256 clk per tile against ~280 clk of VALU issue per SIMD: the two limits are about equal, so the
+# kernel cannot pass ~50 % of the VALU-issue column below without keeping x_j / y_j in registers across the four rows.
+VALU_PEAK = 78.6e12
+SLOTS = {'rep': (35.0, 54.0), 'rmb': (38.5, 54.0), 'mmd_g': (63.0, 54.0)}
+print('%6s %5s %10s %12s %14s %12s %16s' % ('B', 'loss', 'us', 'alg. GB/s', '% of 8 TB/s', 'Gpair/s', '% of VALU issue'))
 for loss in ('rep', 'rmb', 'mmd_g'):
     for B in (64, 128, 256, 1024, 4096, 16384):
         g = torch.Generator(device='cuda').manual_seed(B)
@@ -24,5 +37,7 @@ for loss in ('rep', 'rmb', 'mmd_g'):
             e1.record(); torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / reps * 1e3
             nbytes = 2 * B * d * 4 + 32 + (4 * B * d * 4 if grads else 0)
-            print('%6d %5s %10.1f %12.3f %14.4f %12.1f  %s' % (B, loss, us, nbytes / us / 1e3, nbytes / us / 1e3 / 80, 4.0 * B * B / us / 1e3,
-                                                             'fwd+bwd' if grads else 'fwd'))
+            slots = SLOTS[loss][0] + (SLOTS[loss][1] if grads else 0.0)
+            print('%6d %5s %10.1f %12.3f %14.4f %12.1f %16.1f  %s' % (B, loss, us, nbytes / us / 1e3, nbytes / us / 1e3 / 80, 4.0 * B * B / us / 1e3,
+                                                                     100.0 * 4.0 * B * B * slots / (us * 1e-6) / VALU_PEAK,
+                                                                     'fwd+bwd' if grads else 'fwd'))
