@@ -151,8 +151,9 @@ class Agent(object):
             # tensors and plain containers only: a checkpoint file is data, never code (weights_only=True refuses
             # anything that would need unpickling arbitrary objects)
             sd = torch.load(path, map_location='cpu', weights_only=True)
-            if 'variables' in sd:
-                sd['variables'] = {k: v.numpy() for k, v in sd['variables'].items()}
+            for key in ('variables', 'adam_m', 'adam_v'):           # name -> tensor on disk, name -> numpy for the engine
+                if isinstance(sd.get(key), dict):
+                    sd[key] = {k: v.numpy() for k, v in sd[key].items()}
             engine.load_state_dict(sd)
             FLAGS.print('Model reloaded from {}'.format(path))
             return True
@@ -164,8 +165,9 @@ class Agent(object):
             return None
         path = '{}-{}'.format(self.save_path, engine.global_step)
         sd = engine.state_dict()
-        if 'variables' in sd:                                    # numpy arrays -> tensors: loadable with weights_only=True
-            sd['variables'] = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd['variables'].items()}
+        for key in ('variables', 'adam_m', 'adam_v'):            # numpy arrays -> tensors: loadable with weights_only=True
+            if isinstance(sd.get(key), dict):
+                sd[key] = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd[key].items()}
         torch.save(sd, path)
         files = sorted(glob.glob(self.save_path + '-*'), key=lambda f: int(f.rsplit('-', 1)[1]))
         for old in files[:-2]:                                   # Saver(max_to_keep=2), graph_func.py:708-717

@@ -86,6 +86,18 @@ void *workspace_acquire(size_t need, hipStream_t st) {
           : !h.ws_slot[0].used ? 0 : !h.ws_slot[1].used ? 1 : 0;
     return take(i) ? (char *)h.ws + (size_t)i * half : nullptr;
 }
+// Flags of every dependency event.  The events order kernels of ONE device across its streams and are never inspected by the
+// host, so the marker they put into the producing queue needs no system-scope release (a write-back towards the host that the
+// step pays at every cross-stream edge): hipEventReleaseToDevice.  MMDGAN_EVENT_FLAGS=<hex> overrides (2 = the plain
+// hipEventDisableTiming of the earlier rounds).
+unsigned event_flags() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("MMDGAN_EVENT_FLAGS");
+        v = e ? (int)strtoul(e, nullptr, 16) : (int)(hipEventDisableTiming);
+    }
+    return (unsigned)v;
+}
 bool plan_recording() { return cur().recording != nullptr; }
 void plan_push(std::function<void()> &&node) { cur().recording->nodes.emplace_back(std::move(node)); }
 void plan_note_kernel(const void *fn, dim3 grid, dim3 block, hipStream_t st) {
@@ -152,12 +164,12 @@ extern "C" int mmdgan_stream_wait(void *waiting_stream, void *signalling_stream)
     mmdgan_handle &h = cur();
     hipEvent_t ev = nullptr;
     if (plan_recording()) {                    // the node keeps an event of its own
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return check_launch("stream_wait event");
+        if (hipEventCreateWithFlags(&ev, event_flags()) != hipSuccess) return check_launch("stream_wait event");
         h.recording->events.push_back(ev);
     } else {                                   // a wait captures the event's state when it is issued: re-use is safe
         constexpr size_t kPool = 64;
         if (h.pool.size() < kPool) {
-            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return check_launch("stream_wait event");
+            if (hipEventCreateWithFlags(&ev, event_flags()) != hipSuccess) return check_launch("stream_wait event");
             h.pool.push_back(ev);
         } else {
             ev = h.pool[h.pool_next++ % kPool];
@@ -173,7 +185,7 @@ extern "C" int mmdgan_event_record(int slot, void *stream) {
     MMDGAN_REQUIRE(slot >= 0 && slot < 64, "event_record: slot %d outside [0,64)", slot);
     std::vector<hipEvent_t> &t = cur().slots;
     if ((int)t.size() <= slot) t.resize(slot + 1, nullptr);
-    if (!t[slot] && hipEventCreateWithFlags(&t[slot], hipEventDisableTiming) != hipSuccess) return check_launch("event_record");
+    if (!t[slot] && hipEventCreateWithFlags(&t[slot], event_flags()) != hipSuccess) return check_launch("event_record");
     hipEvent_t ev = t[slot];
     hipStream_t s = (hipStream_t)stream;
     if (hipEventRecord(ev, s) != hipSuccess) return check_launch("event_record");

@@ -103,3 +103,60 @@ def shard_of(n_items, rank, world):
     base, rem = divmod(n_items, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init_library_comm(group, world, rank, device):
+    """one RCCL communicator INSIDE the library for this process (mmdgan_comm_init): rank 0's unique id travels over
+    `group`.  A communicator of the right size made by an earlier engine of this process is kept."""
+    import ctypes
+    from . import ops
+    lib = ops.require_device()
+    if lib.mmdgan_comm_size() == world:
+        return
+    ident = (ctypes.c_char * 128)()
+    if rank == 0:
+        ops.check(lib.mmdgan_comm_unique_id(ident), 'comm_unique_id')
+    dev = device if tdist.get_backend(group) == 'nccl' else torch.device('cpu')
+    t = torch.tensor(list(bytes(ident)), dtype=torch.uint8, device=dev)
+    tdist.broadcast(t, src=0, group=group)
+    ops.check(lib.mmdgan_comm_init(bytes(t.cpu().tolist()), world, rank), 'comm_init')
+
+
+def choose_dp_backend(group, device, requested=None):
+    """who carries an engine's gradient exchange: 'capi' = the library's own RCCL communicator (mmdgan_allreduce_bucket:
+    the collectives are launch-plan nodes like any kernel, so a data-parallel step replays from one C call, and nothing
+    depends on which stream ProcessGroupNCCL picks) or 'torch' = torch.distributed on `group`.
+    requested: 'capi' / 'torch' / None (then MMDGAN_DP_BACKEND, then: 'capi' under an nccl (= RCCL) group, 'torch' under any
+    other backend - gloo in the tests).  'capi' is verified before it is chosen - the communicator is made and a SUM
+    all-reduce of ones must give the world size - and EVERY rank takes the same decision: one rank without the library path
+    means none uses it (an explicit request then raises instead of falling back)."""
+    import os
+    import sys
+    from . import ops
+    explicit = requested or os.environ.get('MMDGAN_DP_BACKEND')
+    backend = explicit
+    if backend is None:
+        backend = 'capi' if (group is not None and tdist.get_backend(group) == 'nccl') else 'torch'
+    assert backend in ('torch', 'capi'), backend
+    if backend != 'capi' or group is None:
+        return backend
+    world, rank = tdist.get_world_size(group), tdist.get_rank(group)
+    err = None
+    try:
+        init_library_comm(group, world, rank, device)
+        probe = torch.ones(1024, device=device)
+        ops.check(ops.require_device().mmdgan_allreduce_bucket(probe.data_ptr(), probe.numel(), ops._stream()), 'allreduce_bucket')
+        torch.cuda.synchronize()
+        if not bool((probe == float(world)).all()):
+            raise RuntimeError('self-check all-reduce returned %r, expected %d' % (probe[:2].tolist(), world))
+    except Exception as e:                           # no RCCL to bind, its rendezvous failed, or it does not add up
+        err = e
+    flag = torch.tensor([0 if err is not None else 1], dtype=torch.int32,
+                        device=device if tdist.get_backend(group) == 'nccl' else 'cpu')
+    tdist.all_reduce(flag, op=tdist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 0:
+        if explicit == 'capi':
+            raise RuntimeError('library-owned RCCL exchange unavailable on some rank (this rank: %s)' % (err,))
+        sys.stderr.write('mmdgan: library-owned RCCL exchange unavailable (this rank: %s); using torch.distributed\n' % (err,))
+        return 'torch'
+    return 'capi'

@@ -493,35 +493,8 @@ class GanEngine:
         # collectives are plan nodes like any launch - a data-parallel step then replays from one C call
         # Default: 'capi' under an nccl (= RCCL) group - it depends on nothing ProcessGroupNCCL does with streams and the
         # whole data-parallel step replays from one C call; 'torch' for any other backend (gloo in the tests)
-        self._dp_backend = dp_backend or os.environ.get('MMDGAN_DP_BACKEND')
-        if self._dp_backend is None:
-            import torch.distributed as tdist
-            self._dp_backend = 'capi' if (dist_group is not None and tdist.get_backend(dist_group) == 'nccl') else 'torch'
-        assert self._dp_backend in ('torch', 'capi'), self._dp_backend
-        if self._dp_backend == 'capi' and dist_group is not None:
-            import torch.distributed as tdist
-            err = None
-            try:
-                self._init_capi_comm()
-                # self-check: a SUM all-reduce of ones through the library's communicator gives the world size everywhere
-                probe = torch.ones(1024, device=self.device)
-                ops.check(ops.require_device().mmdgan_allreduce_bucket(probe.data_ptr(), probe.numel(), ops._stream()),
-                          'allreduce_bucket')
-                torch.cuda.synchronize()
-                if not bool((probe == float(self.world)).all()):
-                    raise RuntimeError('self-check all-reduce returned %r, expected %d' % (probe[:2].tolist(), self.world))
-            except Exception as e:                       # no RCCL to bind, its rendezvous failed, or it does not add up
-                err = e
-            # every rank takes the SAME decision: one rank without the library path means none uses it
-            flag = torch.tensor([0 if err is not None else 1], dtype=torch.int32,
-                                device=self.device if tdist.get_backend(dist_group) == 'nccl' else 'cpu')
-            tdist.all_reduce(flag, op=tdist.ReduceOp.MIN, group=dist_group)
-            if int(flag.item()) == 0:
-                import sys
-                if dp_backend == 'capi' or os.environ.get('MMDGAN_DP_BACKEND') == 'capi':
-                    raise RuntimeError('library-owned RCCL exchange unavailable on some rank (this rank: %s)' % (err,))
-                sys.stderr.write('mmdgan: library-owned RCCL exchange unavailable (this rank: %s); using torch.distributed\n' % (err,))
-                self._dp_backend = 'torch'
+        from . import dist as mdist
+        self._dp_backend = mdist.choose_dp_backend(dist_group, self.device, dp_backend)      # verified, same on every rank
         # the power iterations of different layers are independent of each other too: two chains.
         # weight / bias gradients of a layer depend only on dz of that layer, not on the dgrad chain that
         # continues below it: they go to another stream so their blocks fill the tail of the dgrad
@@ -537,6 +510,9 @@ class GanEngine:
         self._gen_tail_on_main = int(os.environ.get('MMDGAN_GEN_TAIL_MAIN', '2')) if os.environ.get('MMDGAN_SIDE_WGRAD', '1') != '0' else 0
         self._early_d_adam = os.environ.get('MMDGAN_EARLY_D_ADAM', '1') != '0'
         self._side_wgrad = os.environ.get('MMDGAN_SIDE_WGRAD', '1') != '0'
+        # round 4: dependencies that put a marker / barrier packet into the MAIN queue (~6 us of idle queue each) moved off it
+        # where another ordering already covers them (MMDGAN_QUEUE_OPT=0: the round-3 placement)
+        self._queue_opt = os.environ.get('MMDGAN_QUEUE_OPT', '1') != '0' and self._side_wgrad
         if ops._workspace is None:
             ops.set_workspace(device=self.device)                        # the default handle's (eval paths, stand-alone ops)
         # this engine's own library state (include/mmdgan_hip.h "Handles"): workspace, prezeroed mode, launch plan
@@ -743,6 +719,8 @@ class GanEngine:
             if s.sn and is_training and not (self._sn_fused and waited):
                 ops.event_wait(_EV_SN_GEN0 + (0 if self._sn_fused else i), ops._stream())   # this layer's power iteration (_forward)
                 waited = True
+            if is_training and getattr(self, '_gen_wino_wait', None) == i:
+                ops.event_wait(_EV_WINO_GEN, ops._stream())
             x = self._layer_forward(self.gen, s, x, is_training, scales.get(s.scope))
             if s.out_reshape is not None:
                 x = x.view(_native_shape(s.out_shape_ref, x.shape[0]))
@@ -795,8 +773,16 @@ class GanEngine:
                         ops.event_record(ev0 + i, self._sn_raw[k])
         if real.data_ptr() != b['dis_in'].data_ptr():
             ops.copy(b['dis_in'][:B], real)                                  # my_sngan.py:278: D sees [real ; fake]
-        if any(net is self.gen for _, _, net in self._wino.values()):
-            ops.event_wait(_EV_WINO_GEN, main)
+        gen_wino = any(net is self.gen for _, _, net in self._wino.values())
+        # G's transformed weights: waited for where the first layer that reads them starts (a dense first layer runs beside the
+        # transform, which itself waits for the previous step's Adam)
+        self._gen_wino_wait = None
+        if gen_wino:
+            first = next(i for i, s in enumerate(self.gen.specs) if s.scope in self._wino)
+            if self._queue_opt and first > 0:
+                self._gen_wino_wait = first
+            else:
+                ops.event_wait(_EV_WINO_GEN, main)
         self.generate(z, is_training=True)                                   # writes dis_in[B:]
         if self._wino:
             ops.event_wait(_EV_WINO_DIS, main)                               # D's transformed weights of this step
@@ -813,8 +799,11 @@ class GanEngine:
             x = self._layer_forward(self.dis, s, x, True, scale)
             if s.out_reshape is not None:
                 x = x.view(_native_shape(s.out_shape_ref, x.shape[0]))
-        for st in self._sn_raw:
-            ops.stream_wait(main, st)                                        # the chains' tails (x <- normalised F^T(y))
+        if not self._queue_opt:
+            for st in self._sn_raw:
+                ops.stream_wait(main, st)                                    # the chains' tails (x <- normalised F^T(y))
+        # (_queue_opt: nothing before the parameter gradients reads what the chains' tails write - the updated vectors,
+        # dsigma/dW - so the weight-gradient stream joins them instead, at the start of the backward pass: _backward_dis)
         scores = x                                                           # [2B, d]; s_x = [:B], s_gen = [B:]
         self._loss.launch(scores, self.losses)
         return scores
@@ -830,6 +819,12 @@ class GanEngine:
         # its first 3B rows are the score gradient of the 3B-row backward pass
         specs = net.specs
         dz = b['mmd_grads'].view(4 * B, -1)[:3 * B]
+        if self._queue_opt:
+            # the power-iteration chains' tails: their readers are the gradient fix-ups and Adam, all of which run on the
+            # weight-gradient stream or behind it (the main stream joins that stream before its own Adam; the exchange stream
+            # IS the first power-iteration stream)
+            for st in (self._sn_raw[:1] if self._sn_fused else self._sn_raw):
+                ops.stream_wait(self._wg_raw, st)
         for li in range(len(specs) - 1, -1, -1):
             s = specs[li]
             x_in = b['dis_in'] if li == 0 else b[specs[li - 1].scope + '#y']
@@ -1028,22 +1023,6 @@ class GanEngine:
         with torch.cuda.stream(self._comm_stream):
             mdist.allreduce_sum_(net.grads[lo:hi], self.dist_group)
 
-    def _init_capi_comm(self):
-        """one RCCL communicator inside the library for this process: rank 0's unique id travels over `dist_group`"""
-        import ctypes
-        import torch.distributed as tdist
-        lib = ops.require_device()
-        if lib.mmdgan_comm_size() == self.world:
-            return                                       # an earlier engine of this process made it
-        ident = (ctypes.c_char * 128)()
-        if self.rank == 0:
-            ops.check(lib.mmdgan_comm_unique_id(ident), 'comm_unique_id')
-        dev = self.device if tdist.get_backend(self.dist_group) == 'nccl' else torch.device('cpu')
-        t = torch.tensor(list(bytes(ident)), dtype=torch.uint8, device=dev)
-        tdist.broadcast(t, src=0, group=self.dist_group)
-        raw = bytes(t.cpu().tolist())
-        ops.check(lib.mmdgan_comm_init(raw, self.world, self.rank), 'comm_init')
-
     def _update(self):
         gs = 1.0 / self.world
         main = ops._stream()
@@ -1084,7 +1063,9 @@ class GanEngine:
             self._in_step = True
             self._d_updated_early = False
             self._forward(z, real)
-            if arenas:
+            if arenas and not (self._queue_opt and self._wino):
+                # (with transformed weights in the step the main stream has already waited for _EV_WINO_DIS, recorded behind
+                # everything the weight-gradient stream does at step start)
                 ops.stream_wait(main, self._wg_raw)
             dz = self._backward_dis()
             if self._early_d_adam and not self._dp_active() and self._side_wgrad:

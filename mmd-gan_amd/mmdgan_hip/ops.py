@@ -119,7 +119,8 @@ def kernel_base_name(demangled):
             break
     head = demangled[:end].strip()
     cut = head.find('<') if '<' in head else len(head)
-    start = max(head.rfind(' ', 0, cut), head.rfind('::', 0, cut) + 1) + 1
+    sp, ns = head.rfind(' ', 0, cut), head.rfind('::', 0, cut)
+    start = max(sp + 1, ns + 2 if ns >= 0 else 0)
     return head[start:]
 
 

@@ -570,7 +570,7 @@ class TapeEngine:
 
     def __init__(self, architecture, loss_type='rep', lr_list=(5e-4, 2e-4), rep_weights=(0.0, -1.0), batch_size=64,
                  seed=0, device=None, dist_group=None, use_graph=False, sn_mode='default', weight_init='default',
-                 mix_threshold=None, launch_mode=None):
+                 mix_threshold=None, launch_mode=None, dp_backend=None):
         ops.require_device()
         initializers.check_mode(weight_init)
         if loss_type not in ops.LOSS:
@@ -598,6 +598,10 @@ class TapeEngine:
             self.world = tdist.get_world_size(dist_group)
             self.rank = tdist.get_rank(dist_group)
         self._dp_force = os.environ.get('MMDGAN_DP_FORCE') == '1'
+        # who carries the gradient exchange (dist.choose_dp_backend, as GanEngine): the library's own RCCL communicator under
+        # an nccl group - its collectives are plan nodes, so a data-parallel step replays from one C call - else torch.distributed
+        from . import dist as mdist
+        self._dp_backend = mdist.choose_dp_backend(dist_group, self.device, dp_backend)
         self.use_graph = False                                           # eager issue only
         if ops._workspace is None:
             ops.set_workspace(device=self.device)
@@ -1248,15 +1252,24 @@ class TapeEngine:
             return
         _, lo, hi = bucket
         from . import dist as mdist
+        capi = self._dp_backend == 'capi'
+
+        def collective(stream_raw):
+            if capi:                                     # a library call: recorded by a launch plan like any kernel
+                ops.check(ops.require_device().mmdgan_allreduce_bucket(net.grads.data_ptr() + 4 * lo, hi - lo, stream_raw),
+                          'allreduce_bucket')
+            else:
+                mdist.allreduce_sum_(net.grads[lo:hi], self.dist_group)
         if not self._side:
-            mdist.allreduce_sum_(net.grads[lo:hi], self.dist_group)
+            collective(ops._stream())
             return
         # kernels' gradients are issued on the weight-gradient stream, batch-norm gradients on the main stream
         ops.stream_wait(self._sn_raw, self._wg_raw)
         ops.stream_wait(self._sn_raw, ops._stream())
         with torch.cuda.stream(self._sn_stream):
-            mdist.allreduce_sum_(net.grads[lo:hi], self.dist_group)
+            collective(self._sn_raw)
         self._exchange_pending = True
+        self.exchanged_buckets = getattr(self, 'exchanged_buckets', 0) + 1
 
     def _dp_active(self):
         return self.dist_group is not None and (self.world > 1 or self._dp_force)
@@ -1353,7 +1366,7 @@ class TapeEngine:
         if real_nhwc is not None:
             self._static_real.copy_(real_nhwc)                           # (= the real half of D's input)
         mode = self.launch_mode
-        if mode == 'plan' and self._dp_active():
+        if mode == 'plan' and self._dp_active() and self._dp_backend != 'capi':
             mode = 'eager'                                               # torch.distributed collectives are not plan nodes
         if (self.lr_d, self.lr_g) != self._baked_lr:                     # a recorded plan holds the learning rates by value
             self._baked_lr = (self.lr_d, self.lr_g)
