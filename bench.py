@@ -321,8 +321,9 @@ def main():
         eng.step(real)
     barrier()
     want = 'eager' if args.no_graph else 'graph' if args.graph else args.launch_mode
-    if tape and (want == 'graph' or group is not None):
-        want = 'eager'                                   # the primitive-op engine: no hipGraph capture; eager under data parallelism
+    if tape and (want == 'graph' or (group is not None and getattr(eng, '_dp_backend', 'torch') != 'capi')):
+        want = 'eager'                                   # the primitive-op engine: no hipGraph capture; under data parallelism a plan
+        #                                                  needs the library-owned exchange (collectives as plan nodes)
     elif group is not None and want == 'graph':
         want = 'eager'                                   # collectives between the launches: no hipGraph
     trial = {}
@@ -377,6 +378,26 @@ def main():
     dt, ev_ms = regions[order[(len(order) - 1) // 2]]                     # the median region (lower middle for an even count)
     losses = eng.losses.cpu().numpy()
     assert np.all(np.isfinite(losses)), 'Model diverged with loss = NaN'               # graph_func.py:856
+    # data parallel: how long the LAST exchange bucket (G's first layer - the only one no backward kernel is left to hide)
+    # takes, and how much of it the main stream actually waits for; untimed eager steps after the timed regions
+    exchange = None
+    if group is not None and hasattr(eng, 'exchange_probe'):
+        keep = eng.launch_mode
+        eng.launch_mode, eng.exchange_probe = 'eager', {}
+        took, exposed = [], []
+        for _ in range(12):
+            eng.step(real)
+            torch.cuda.synchronize()
+            pr = eng.exchange_probe
+            if all(k in pr for k in ('start', 'end', 'main_ready')):
+                took.append(pr['start'].elapsed_time(pr['end']))
+                exposed.append(max(0.0, pr['main_ready'].elapsed_time(pr['end'])))
+        if took:
+            exchange = {'last_bucket_bytes': eng.exchange_probe.get('bucket_bytes'), 'last_bucket_ms': float(np.median(took[2:])),
+                        'exposed_ms': float(np.median(exposed[2:])), 'buckets_per_step': sum(len(b) for b in eng._grad_buckets.values()),
+                        'note': 'eager steps after the timed regions; exposed = end of the last bucket minus the point where the '
+                                'main stream has only Adam left'}
+        eng.launch_mode, eng.exchange_probe = keep, None
 
     if rank == 0:
         fg, fd = configs.flops_per_image(arch)
@@ -396,6 +417,7 @@ def main():
                                       B, args.loss, lr[0], lr[1]),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world, 'launch_mode': mode,
                        'dp_backend': getattr(eng, '_dp_backend', None) if group is not None else None,
+                       'exchange': exchange,
                        'launch_mode_trial_ms': {k: round(v * 1e3, 4) for k, v in trial.items()} or None},
             'loss_gen': float(losses[0]), 'loss_dis': float(losses[1]),
         }

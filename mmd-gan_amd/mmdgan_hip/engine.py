@@ -488,6 +488,9 @@ class GanEngine:
         self._z_gen = torch.Generator(device=self.device)
         self._z_gen.manual_seed((int(seed) * 1000003 + 7919 * self.rank + 12345) % (2 ** 63 - 1))
         self._recording, self._d_updated_early = False, False
+        # set to {} by a caller (bench.py under data parallelism): eager steps then leave three events in it - start / end of
+        # G's last exchange bucket on the exchange stream and the point where the main stream starts waiting for it
+        self.exchange_probe = None
         # who carries the gradient exchange: 'torch' = torch.distributed on `dist_group` (RCCL through ProcessGroupNCCL; gloo in
         # the tests); 'capi' = the library's own RCCL communicator (mmdgan_comm_init / mmdgan_allreduce_bucket), whose
         # collectives are plan nodes like any launch - a data-parallel step then replays from one C call
@@ -1003,8 +1006,16 @@ class GanEngine:
         if self._recording and self._dp_backend != 'capi':
             lib.mmdgan_plan_mark()                       # the collective is not the library's: a segment boundary
             self._plan_collectives.append((net, lo, hi))
-        self._issue_collective(net, lo, hi)
         last = bucket is self._grad_buckets[id(net)][-1]
+        probe = self.exchange_probe if (last and net is self.gen and not self._recording) else None
+        if probe is not None:                            # tools/scale.sh: how long G's last bucket takes and how much of it is exposed
+            probe['bucket_bytes'] = 4 * (hi - lo)
+            probe['start'] = torch.cuda.Event(enable_timing=True)
+            probe['start'].record(self._comm_stream)
+        self._issue_collective(net, lo, hi)
+        if probe is not None:
+            probe['end'] = torch.cuda.Event(enable_timing=True)
+            probe['end'].record(self._comm_stream)
         if last and net is self.dis and self._early_d_adam:
             # D's exchange is complete and nothing in G's backward pass reads D's weights: its Adam runs on the exchange
             # stream, beside G's backward pass, instead of at the tail of the step - behind everything the main stream
@@ -1027,6 +1038,9 @@ class GanEngine:
         gs = 1.0 / self.world
         main = ops._stream()
         if self._dp_active():
+            if self.exchange_probe is not None and not self._recording:
+                self.exchange_probe['main_ready'] = torch.cuda.Event(enable_timing=True)
+                self.exchange_probe['main_ready'].record()       # the main stream has nothing left but Adam
             ops.stream_wait(main, self._comm_raw)        # all buckets (and D's early Adam) have landed
         if not self._d_updated_early:
             self.dis.opt.step(self.lr_d, grad_scale=gs)

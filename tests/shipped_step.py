@@ -116,9 +116,13 @@ def run(config, loss, B, mode='plan', warm=3, check_grads=True, seed=5):
             gscale = max(float(np.abs(ref_g[n]).max()) for n in grads if n.startswith(net))   # which only score differences matter)
             zero |= {n for n in grads if n.startswith(net) and np.abs(ref_g[n]).max() <= 1e-9 * gscale}
         assert len(zero) <= 10, zero
+        gs = {net: max(float(np.abs(ref_g[n]).max()) for n in grads if n.startswith(net)) for net in ('gen', 'dis')}
+        if os.environ.get('SHIPPED_STEP_REPORT'):        # debugging aid: every tensor's error instead of the first failure
+            out['per_tensor'] = {n: [l2_err(grads[n], ref_g[n], gs[n[:3]]), max_err(grads[n], ref_g[n], gs[n[:3]])]
+                                 for n in grads if n not in zero}
+            return out
         assert_grads_within_fp32_floor(grads, ref_g, fp32_floor(arch, loss, lr, prev_vars, z, real, eng), skip=zero,
                                        what=(config, loss, B, mode))
-        gs = {net: max(float(np.abs(ref_g[n]).max()) for n in grads if n.startswith(net)) for net in ('gen', 'dis')}
         out['grad_err_l2_max'] = max(l2_err(grads[n], ref_g[n], gs[n[:3]]) for n in grads if n not in zero)
         out['grad_err_maxabs_max'] = max(max_err(grads[n], ref_g[n], gs[n[:3]]) for n in grads if n not in zero)
         out['grad_tensors'] = len(grads) - len(zero)
