@@ -37,7 +37,8 @@ constexpr int V_FLOATS = 9 * FSV;
 constexpr int MS_FLOATS = 9 * 32 * 32;       // epilogue exchange buffer (one column block at a time), Ms[f][tile][k 32]
 static_assert(MS_FLOATS <= V_FLOATS, "the epilogue buffer is the V buffer the last stage released");
 constexpr int SMEM_FLOATS = 2 * V_FLOATS;
-constexpr size_t LDS_BYTES = sizeof(float) * SMEM_FLOATS + sizeof(unsigned) * 64 + sizeof(int) * 4;
+constexpr int OB_SLOTS = 4;             // items whose output offsets are live at once: the load cursor runs up to TWO items ahead (2-stage items)
+constexpr size_t LDS_BYTES = sizeof(float) * SMEM_FLOATS + sizeof(unsigned) * 32 * OB_SLOTS + sizeof(int) * 4;
 constexpr int NM = 5;                   // frequencies per wave (the waves with the odd frequencies use 4)
 
 struct Params {
@@ -92,8 +93,14 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
                                                        const float *__restrict__ U, float *__restrict__ out) {
     using namespace wino2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    unsigned *obase = reinterpret_cast<unsigned *>(smem + SMEM_FLOATS);  // [item parity][tile]: output byte offset of the tile
-    int *wgctl = reinterpret_cast<int *>(obase + 64);
+    // [item % OB_SLOTS][tile]: output byte offset of the tile.  A ring of FOUR items, not two: the load cursor is two STAGES
+    // ahead of the multiply, which for items of two stages (64 reduction channels, e.g. the 64 -> 64 first block of the
+    // ResNet-SN discriminator) is a whole item - finishing item i+1's loads during item i's last stage it enters item i+2
+    // BEFORE item i's epilogue has read its offsets.  (With two slots that epilogue stored item i's tiles at item i+2's
+    // addresses: wrong input-gradients whenever a workgroup walked three or more such items - found by the parity test at
+    // the ResNet config's own batch, tests/test_production_gpu.py.)
+    unsigned *obase = reinterpret_cast<unsigned *>(smem + SMEM_FLOATS);
+    int *wgctl = reinterpret_cast<int *>(obase + 32 * OB_SLOTS);
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     // wave-uniform by construction, but hipcc only knows once it sits in an SGPR: without this every B load with a
     // wave-dependent scalar offset became a waterfall loop and every `m < nm` an exec-mask branch (2x slower)
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
         tn = (int)(q1 / (unsigned)P.TH);
         ty = (int)(q1 - (unsigned)tn * P.TH);
         if (cq == 0)             // byte offset of this tile's output pixel (a=0, b=0), channel 0 (kOOB: no such tile)
-            obase[(l_it & 1) * 32 + pt] =
+            obase[(l_it & (OB_SLOTS - 1)) * 32 + pt] =
                 tile_ok ? (unsigned)((((long)tn * P.OH + ty * P.otile + P.o0r[l_phase]) * P.OW + tx * P.otile + P.o0c[l_phase]) * P.Ko * 4) +
                               (unsigned)chunk * P.slab_bytes : kOOB;
     };
@@ -289,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
         const int c_tblk = item / per_tb, c_rem = (item - c_tblk * per_tb) / P.ksplit;
         const int c_phase = c_rem / P.nkb;
         const int n0 = (c_rem - c_phase * P.nkb) * 64;
-        const unsigned *ob_it = obase + (it & 1) * 32;
+        const unsigned *ob_it = obase + (it & (OB_SLOTS - 1)) * 32;
         const bool last_item = it + 1 == count;
         f32x16 acc[NM];
 #pragma unroll

@@ -337,6 +337,11 @@ FULL_SIZE = [
     (64, 32, 32, 64, 128, 4, 2),                                  # G l4_up as the conv it is the input-gradient of
     (256, 64, 64, 64, 128, 4, 2),                                 # CelebA D l2 at batch 2B = 256: 268 MB of activations
     (64, 64, 64, 128, 128, 3, 1),                                 # the ResNet-SN config's largest 3x3
+    # the ResNet-SN discriminator's first block at its bench batch 32 (3B = 96 rows): 64 -> 64 channels, the 4x4 stride-2
+    # kernel its folded avg-pool makes.  Its input-gradient has a 64-channel reduction = work items of TWO pipeline stages in
+    # the F(2x2,2x2) kernel, and each workgroup walks six of them: the launch that stored tiles at another item's addresses
+    # (csrc/conv_wino2.hip, OB_SLOTS) - wrong by 100 % in L2, and caught by this identity
+    (96, 64, 64, 64, 64, 4, 2), (64, 64, 64, 64, 64, 4, 2),
 ]
 
 
