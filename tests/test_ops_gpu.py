@@ -375,6 +375,84 @@ def test_conv_full_size_adjointness_and_linearity(ops, case):
         assert float((alone[0] - y[i]).abs().max()) <= 1e-4 * float(y[i].abs().max())
 
 
+def _config_conv_shapes():
+    """every convolution geometry of every BASELINE.json config at its per-GPU bench batch, with the batch sizes its launches
+    run at: (config, N, H, W, C, K, R, stride).  DCGAN dicts: D layers at 2B (forward, weight gradient) and 3B (the joint
+    input-gradient pass) rows, G's transposed layers as the conv they are the input-gradient of, at B rows.  ResNet-SN: the
+    primitive-op engine's kernels (a block's scaling op folded into its 3x3 conv makes a 4x4 stride-2 geometry)."""
+    import configs
+    out = []
+    for name, B in (('cifar', 64), ('stl', 64), ('celeba', 128)):
+        arch, _ = configs.CONFIGS[name]()
+        c, h, _w = arch['input'][0]
+        for d in arch['discriminator']:
+            if d.get('op', 'c') != 'c':
+                continue
+            R, s, k = d.get('kernel', 3), d.get('strides', 1), d['out']
+            out += [(name, n, h, h, c, k, R, s) for n in (2 * B, 3 * B)]
+            c, h = k, -(-h // s)
+        c, h = None, None
+        for d in arch['generator']:
+            if d.get('op', 'c') == 'd':
+                c, h = d['out_reshape'][0], d['out_reshape'][1]
+            elif d.get('op') == 'tc':                    # conv geometry: input = the layer's output
+                out.append((name, B, h * d['strides'], h * d['strides'], d['out'], c, d['kernel'], d['strides']))
+                c, h = d['out'], h * d['strides']
+            else:
+                out.append((name, B, h, h, c, d['out'], d.get('kernel', 3), d.get('strides', 1)))
+                c = d['out']
+    from mmdgan_hip.tape import _Net
+    arch, _ = configs.lsun_resnet()
+    B = 32
+    for net_name, designs, in_ref, batches in (('gen', arch['generator'], [arch['code'][0][0]], (B,)),
+                                               ('dis', arch['discriminator'], list(arch['input'][0]), (2 * B, 3 * B))):
+        net = _Net(designs, in_ref, net_name, torch.device('cuda'), np.random.RandomState(0), 'default')
+        for k in net.kernels:
+            if k.op not in ('c', 'tc'):
+                continue
+            R, s = (4, 2) if k.fold is not None else (k.R, k.stride)
+            if k.op == 'c' and k.fold != 'unpool':
+                c, h, kk = k.in_ref[0], k.in_ref[1], k.out
+            else:                                        # transposed form: the conv whose input is the layer's output
+                c, h, kk = k.out, k.out_ref[1], k.in_ref[0]
+            out += [('lsun_resnet', n, h, h, c, kk, R, s) for n in batches]
+    return sorted(set(out))
+
+
+def test_conv_shapes_of_every_config_at_their_bench_batch(ops):
+    """the adjointness identity  <conv(x, w), dy> = <x, dgrad(dy, w)> = <w, wgrad(x, dy)>  on EVERY convolution geometry of
+    every BASELINE.json config at the batch sizes its launches run at (2B / 3B rows in D, B in G), with the weights handed over
+    transformed wherever the library's selection takes a Winograd kernel - i.e. each launch as the engines issue it, under
+    whatever kernel selection this process runs (tests/test_production_gpu.py repeats the step itself under the production
+    one).  Three kernels computing one bilinear form disagree when any of them mis-addresses a tile, whatever the size."""
+    shapes = _config_conv_shapes()
+    assert len(shapes) >= 60
+    bad = []
+    ops.set_workspace(128 << 20)                         # what an engine's handle registers (slab / partial-sum paths need it)
+    for (cfg, N, H, W, C, K, R, s) in shapes:
+        g = torch.Generator(device='cuda').manual_seed(N * 7 + C + K)
+        P, Q = -(-H // s), -(-W // s)
+        x = torch.empty(N, H, W, C, device='cuda').uniform_(-1, 1, generator=g)
+        w = torch.randn(R, R, C, K, device='cuda', generator=g) / float(np.sqrt(R * R * C))
+        dy = torch.randn(N, P, Q, K, device='cuda', generator=g)
+        wino_ok = R in (3, 4)
+        uf = ops.wino_transform(w, False) if wino_ok and ops.wino_eligible(N, H, W, C, K, R, s, False) else None
+        ud = ops.wino_transform(w, True) if wino_ok and ops.wino_eligible(N, H, W, C, K, R, s, True) else None
+        y = ops.conv2d_fwd(x, w, s, wino=uf)
+        dx = ops.conv2d_dgrad(dy, w, (H, W), s, wino=ud)
+        dw = ops.conv2d_wgrad(x, dy, R, s)
+
+        def dot(a, b):
+            return float((a.double() * b.double()).sum())
+        form, scale = dot(y, dy), float(y.double().norm() * dy.double().norm())
+        e1, e2 = abs(dot(x, dx) - form) / scale, abs(dot(w, dw) - form) / scale
+        if not (e1 <= 1e-6 and e2 <= 1e-6):
+            bad.append(((cfg, N, H, W, C, K, R, s), e1, e2))
+        del x, w, dy, y, dx, dw
+    ops.require_device().mmdgan_set_workspace(None, 0)
+    assert not bad, bad
+
+
 WINO2_CASES = [(16, 16, 16, 64, 128, 4, 2), (30, 12, 12, 32, 64, 4, 2), (6, 8, 16, 64, 64, 4, 2), (9, 4, 4, 128, 64, 4, 2),
                (33, 8, 8, 96, 192, 4, 2), (5, 12, 8, 64, 128, 4, 2), (9, 4, 4, 128, 256, 4, 2), (70, 8, 8, 64, 128, 4, 2)]
 
