@@ -43,4 +43,8 @@ __device__ __forceinline__ void bufst4(__amdgpu_buffer_rsrc_t r, unsigned byte_o
     __builtin_amdgcn_raw_buffer_store_b128(d, r, byte_off, 0, 0);
 }
 
+__device__ __forceinline__ void bufst1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, byte_off, 0, 0);
+}
+
 }  // namespace mmdgan
