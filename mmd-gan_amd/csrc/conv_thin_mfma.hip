@@ -17,6 +17,13 @@
 //        library workspace and are combined in fixed order (deterministic).
 //
 // All three are then HBM-bound on the wide tensor (33.5 MB for D l1 at batch 128).
+// Round 4, measured and NOT kept (tools/bench_conv.py, CIFAR batch 64, us): n2w with the operands swapped - MFMA rows = pixels,
+// so a lane owns one channel and every accumulator register leaves as two whole 128-byte lines, no LDS transpose, no address
+// arithmetic - D l1 forward 20.7 -> 22.6, G l5 input-gradient 15.0 -> 20.8: 32 dword stores per tile instead of 8 float4
+// stores cost more in the vector-memory instruction path than the LDS round trip and its ~200 VALU instructions saved;
+// w2n with eight waves per band (one tile each) instead of four waves of two: G l5 forward 15.6 -> 18.3, D l1
+// input-gradient 19.0 -> 21.9; more n2w workgroups (768 / 1024 instead of 512): unchanged.  The whole step did not move in
+// any of the three (1.891-1.896 ms).
 // Layout of v_mfma_f32_32x32x2_f32 (wave64): A lane l -> row l%32, k = l/32; B lane l -> col l%32,
 // k = l/32; D register r of lane l -> row (r&3) + 8*(r>>2) + 4*(l/32), col l%32.
 #include "conv_internal.h"
@@ -61,7 +68,7 @@ static PatchTab make_patch_tab(const ConvDims &d, int Cn) {
 // n2w.  FLIP = false: forward (in = x [N,H,W,Cn=C], Wm[j][ch] = w[j*K + ch]);
 //       FLIP = true : input-gradient (in = dy [N,H,W,Cn=K], Wm[(tap,k)][c] = w[(tap*C + c)*K + k])
 template <bool FLIP, int WB>
-__global__ __launch_bounds__(256, (WB <= 2 ? 3 : 1)) void thinm_n2w_kernel(ConvDims d, ConvEpilogue ep, const float *__restrict__ in,
+__global__ __launch_bounds__(256) void thinm_n2w_kernel(ConvDims d, ConvEpilogue ep, const float *__restrict__ in,
                                                         const float *__restrict__ w, float *__restrict__ out,
                                                         int ntiles, PatchTab tab) {
     constexpr int Wd = WB * 32;
@@ -85,13 +92,6 @@ __global__ __launch_bounds__(256, (WB <= 2 ? 3 : 1)) void thinm_n2w_kernel(ConvD
     }
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(in, M * Cn * 4);
     const float sc = ep.scale ? ep.scale[0] : 1.f;
-    // output and activation-derivative operand through buffer resources with 32-bit byte offsets: a pixel beyond the ragged end
-    // carries offset kOOB - its load returns 0, its store is dropped, no branch
-    const __amdgpu_buffer_rsrc_t ro = make_rsrc(out, M * Wd * 4);
-    const bool wraps = ep.wrap_from < 0x20000000L;       // the operand tensor holds fewer images than the output (ConvEpilogue)
-    const unsigned wrap_from = wraps ? (unsigned)(ep.wrap_from * 4) : 0xffffffffu, wrap_sub = (unsigned)(ep.wrap_sub * 4);
-    const __amdgpu_buffer_rsrc_t rd = make_rsrc(ep.dact ? ep.dact : in, ep.dact ? (wraps ? ep.wrap_from * 4 : M * Wd * 4) : 0);
-    auto dact_off = [&](unsigned o) { return (o >= wrap_from ? o - wrap_sub : o) | (o & kOOB); };
     // the patch gather of tile t+1 is in flight while tile t is multiplied and stored: a wave walks several tiles
     // (launch_n2w sizes the grid for ~4), so the weight prologue and the gather latency are paid once, not per tile
     auto gather = [&](int tile, float (&bq)[kJP]) {
@@ -117,6 +117,8 @@ __global__ __launch_bounds__(256, (WB <= 2 ? 3 : 1)) void thinm_n2w_kernel(ConvD
     float bnext[kJP];
     gather(blockIdx.x * 4 + wave, bnext);
     for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += tstep) {
+        const long m = (long)tile * 32 + l31;
+        const bool ok = m < M;
         float b[kJP];
 #pragma unroll
         for (int jp = 0; jp < kJP; ++jp) b[jp] = bnext[jp];
@@ -126,32 +128,79 @@ __global__ __launch_bounds__(256, (WB <= 2 ? 3 : 1)) void thinm_n2w_kernel(ConvD
         for (int wb = 0; wb < WB; ++wb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[wb][r] = 0.f;
-        // MFMA rows = PIXELS (the patch is the A operand), columns = wide channels (the weights are B): D register r of lane
-        // l is then pixel (r & 3) + 8 (r >> 2) + 4 kh of the tile, channel wb * 32 + l31 - a lane owns ONE channel, and the
-        // 32 lanes of a half-wave hold 32 consecutive channels of one pixel: every store instruction writes two whole
-        // 128-byte lines, straight from the accumulators.  (Round 2 had the operands the other way round - lane = pixel -
-        // and needed a transpose through a wave-private LDS slab plus ~200 VALU instructions per tile to get line-sized
-        // stores; this form has no LDS, no address arithmetic - the 16 pixel rows are immediate offsets - and bias / scale
-        // are per-lane constants.)
 #pragma unroll
         for (int jp = 0; jp < kJP; ++jp)
 #pragma unroll
-            for (int wb = 0; wb < WB; ++wb) acc[wb] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[jp], a[wb][jp], acc[wb], 0, 0, 0);
-        const long m0 = (long)tile * 32;
-        const unsigned obase = (unsigned)(((m0 + 4 * kh) * Wd + l31) * 4);        // (every tensor is < 2 GiB)
+            for (int wb = 0; wb < WB; ++wb) acc[wb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[wb][jp], b[jp], acc[wb], 0, 0, 0);
+        if constexpr (WB <= 2) {
+            // The wide tensor is what this kernel moves (33.5 MB for D l1 at batch 128): its stores decide the time.
+            // A lane holds one PIXEL's channel quads, so direct stores put 16 bytes at a 256-byte stride per lane - every
+            // 128-byte line is written by four different instructions (18 % of the HBM rate, profiles/r01_conv_layers.txt).
+            // Transposed through a wave-private LDS slab [32 pixels][Wd + 4] the same data leaves as whole pixel rows:
+            // lane L stores the float4 of channel quad L % (Wd/4) of pixel L / (Wd/4) - 1 KB contiguous per instruction.
+            constexpr int LDP = Wd + 4;                    // +4 floats: the 16 pixel rows of a b128 phase cover all 64 banks
+            __shared__ __attribute__((aligned(16))) float slab[4][32 * LDP];
+            float *sl = slab[wave];
 #pragma unroll
-        for (int wb = 0; wb < WB; ++wb) {
-            const float bv = ep.bias ? ep.bias[wb * 32 + l31] : 0.f;
+            for (int wb = 0; wb < WB; ++wb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int px = (r & 3) + 8 * (r >> 2);                           // + 4 kh: in obase
-                const unsigned o = (m0 + px + 4 * kh < M) ? obase + (unsigned)((px * Wd + wb * 32) * 4) : kOOB;
-                float v = acc[wb][r] * sc + bv;
-                if (ep.dact) v *= act_bwd_from_out(bufld1(rd, dact_off(o)), ep.act);
-                else v = act_fwd(v, ep.act);
-                bufst1(ro, o, v);
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4 *>(sl + l31 * LDP + wb * 32 + 8 * g + 4 * kh) =
+                        make_float4(acc[wb][4 * g], acc[wb][4 * g + 1], acc[wb][4 * g + 2], acc[wb][4 * g + 3]);
+            __builtin_amdgcn_wave_barrier();               // same wave, in-order LDS queue: a scheduling fence is enough
+            asm volatile("" ::: "memory");
+            constexpr int QP = Wd / 4, PPI = 64 / QP;      // lanes per pixel row, pixels per store instruction
+            const int cq = lane % QP, pp = lane / QP, ch = 4 * cq;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ep.bias) bv = *reinterpret_cast<const float4 *>(ep.bias + ch);
+            const long m0 = (long)tile * 32;
+#pragma unroll
+            for (int it = 0; it < 32 / PPI; ++it) {
+                const int px = it * PPI + pp;
+                const long mo = m0 + px;
+                float4 v = *reinterpret_cast<const float4 *>(sl + px * LDP + ch);
+                if (mo < M) {
+                    const long o = mo * Wd + ch;
+                    v.x = v.x * sc + bv.x; v.y = v.y * sc + bv.y; v.z = v.z * sc + bv.z; v.w = v.w * sc + bv.w;
+                    if (ep.dact) {
+                        const float4 y = *reinterpret_cast<const float4 *>(ep.dact + ep.dact_index(o));
+                        v.x *= act_bwd_from_out(y.x, ep.act); v.y *= act_bwd_from_out(y.y, ep.act);
+                        v.z *= act_bwd_from_out(y.z, ep.act); v.w *= act_bwd_from_out(y.w, ep.act);
+                    } else {
+                        v.x = act_fwd(v.x, ep.act); v.y = act_fwd(v.y, ep.act);
+                        v.z = act_fwd(v.z, ep.act); v.w = act_fwd(v.w, ep.act);
+                    }
+                    *reinterpret_cast<float4 *>(out + o) = v;
+                }
             }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+            continue;
         }
+        if (!ok) continue;
+        // (128 wide channels: the slab would not fit the default LDS cap) lane = one pixel; registers 4g..4g+3 are 4
+        // consecutive channels -> float4 stores
+#pragma unroll
+        for (int wb = 0; wb < WB; ++wb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = wb * 32 + 8 * g + 4 * kh;
+                const long o = m * Wd + ch;
+                float4 v = make_float4(acc[wb][4 * g] * sc, acc[wb][4 * g + 1] * sc, acc[wb][4 * g + 2] * sc, acc[wb][4 * g + 3] * sc);
+                if (ep.bias) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(ep.bias + ch);
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                }
+                if (ep.dact) {
+                    const float4 y = *reinterpret_cast<const float4 *>(ep.dact + ep.dact_index(o));
+                    v.x *= act_bwd_from_out(y.x, ep.act); v.y *= act_bwd_from_out(y.y, ep.act);
+                    v.z *= act_bwd_from_out(y.z, ep.act); v.w *= act_bwd_from_out(y.w, ep.act);
+                } else {
+                    v.x = act_fwd(v.x, ep.act); v.y = act_fwd(v.y, ep.act);
+                    v.z = act_fwd(v.z, ep.act); v.w = act_fwd(v.w, ep.act);
+                }
+                *reinterpret_cast<float4 *>(out + o) = v;
+            }
     }
 }
 
@@ -159,11 +208,8 @@ __global__ __launch_bounds__(256, (WB <= 2 ? 3 : 1)) void thinm_n2w_kernel(ConvD
 // w2n.  FLIP = false: forward (in = x [N,H,W,CW=C], out = y [N,H,W,Cn=K], Wm[c][(tap,k)] = w[(tap*C + c)*K + k]);
 //       FLIP = true : input-gradient (in = dy [N,H,W,CW=K], out = dx [N,H,W,Cn=C], Wm[k][(tap,c)] = w[(tap*C + c)*K + k])
 // One workgroup = one band of RB output rows of one image; T covers the band plus R-1 halo rows.
-// EIGHT waves per workgroup, one 32-pixel tile of T each (a band of 6 + 2 halo rows of a 32-wide image is 8 tiles): the whole
-// layer is only ~8 tiles per CU, so what bounds it is the one load -> MFMA -> LDS -> gather chain a wave walks; with four
-// waves of two tiles that chain ran twice back to back on every SIMD
 template <bool FLIP, int CW>
-__global__ __launch_bounds__(512) void thinm_w2n_kernel(ConvDims d, ConvEpilogue ep, const float *__restrict__ in,
+__global__ __launch_bounds__(256) void thinm_w2n_kernel(ConvDims d, ConvEpilogue ep, const float *__restrict__ in,
                                                         const float *__restrict__ w, float *__restrict__ out, int RB,
                                                         int bands, int ldp) {
     extern __shared__ __attribute__((aligned(16))) float T[];       // [J][ldp]
@@ -189,8 +235,8 @@ __global__ __launch_bounds__(512) void thinm_w2n_kernel(ConvDims d, ConvEpilogue
         }
     }
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(in, (long)d.N * IH * IW * CW * 4);
-    const int ntile = (tpix + 31) / 32, nwaves = blockDim.x >> 6;
-    for (int tile = wave; tile < ntile; tile += nwaves) {
+    const int ntile = (tpix + 31) / 32;
+    for (int tile = wave; tile < ntile; tile += 4) {
         const int pl = tile * 32 + l31;
         const int row = tr0 + pl / IW, col = pl % IW;
         const bool ok = pl < tpix && row >= 0 && row < IH;
@@ -217,7 +263,7 @@ __global__ __launch_bounds__(512) void thinm_w2n_kernel(ConvDims d, ConvEpilogue
     __syncthreads();
     const float sc = ep.scale ? ep.scale[0] : 1.f;
     const int npo = rows_out * IW;
-    for (int idx = threadIdx.x; idx < npo * Cn; idx += blockDim.x) {
+    for (int idx = threadIdx.x; idx < npo * Cn; idx += 256) {
         const int cn = idx / npo, px = idx - cn * npo;
         const int ro = px / IW, wo = px - ro * IW;
         float v = 0.f;
@@ -343,14 +389,12 @@ static void launch_w2n(const ConvDims &d, const ConvEpilogue &ep, const float *i
     const int ldp = (RB + d.R - 1) * d.W;
     const size_t lds = sizeof(float) * (size_t)d.R * d.R * narrow * ldp;
     const dim3 grid(d.N * bands);
-    static int nt = -1;                  // MMDGAN_W2N_THREADS: tuning aid (256 = the four-wave form of rounds 2-3)
-    if (nt < 0) { const char *e = getenv("MMDGAN_W2N_THREADS"); nt = e && (atoi(e) == 256 || atoi(e) == 512) ? atoi(e) : 512; }
     if (wide == 32) {
-        hipLaunchKernelGGL((thinm_w2n_kernel<FLIP, 32>), grid, dim3(nt), lds, st, d, ep, in, w, out, RB, bands, ldp);
+        hipLaunchKernelGGL((thinm_w2n_kernel<FLIP, 32>), grid, dim3(256), lds, st, d, ep, in, w, out, RB, bands, ldp);
     } else if (wide == 64) {
-        hipLaunchKernelGGL((thinm_w2n_kernel<FLIP, 64>), grid, dim3(nt), lds, st, d, ep, in, w, out, RB, bands, ldp);
+        hipLaunchKernelGGL((thinm_w2n_kernel<FLIP, 64>), grid, dim3(256), lds, st, d, ep, in, w, out, RB, bands, ldp);
     } else {
-        hipLaunchKernelGGL((thinm_w2n_kernel<FLIP, 128>), grid, dim3(nt), lds, st, d, ep, in, w, out, RB, bands, ldp);
+        hipLaunchKernelGGL((thinm_w2n_kernel<FLIP, 128>), grid, dim3(256), lds, st, d, ep, in, w, out, RB, bands, ldp);
     }
 }
 
