@@ -191,6 +191,17 @@ int mmdgan_conv2d_fwd(const mmdgan_conv_geom *g, const float *x, const float *w,
 int mmdgan_conv2d_dgrad(const mmdgan_conv_geom *g, const float *dy, const float *w, const float *bias,
                         const float *scale, int act, const float *dact_of, int dact_batch, float *dx, void *stream);
 
+/* The same two entries with a tensor added LAST - out = epilogue(conv) + addend, addend of the output's shape (16-byte aligned;
+ * it may be the output buffer itself).  A residual block's branch sum  x + f(x)  (layer_func.py:1842) and the fan-in of the two
+ * gradients that meet at a block's input ride on the launch that produces the second term instead of a pass of their own.
+ * Kernels with an epilogue for it apply it in their stores (implicit GEMM, F(2x2,3x3), the slab pass of every split launch,
+ * thin, direct); for the others the entry appends an axpby pass - the same result from every kernel.
+ * Not with MMDGAN_ACT_FLAG_OUT_ZEROED (a split launch zeroes and accumulates into its output). */
+int mmdgan_conv2d_fwd_add(const mmdgan_conv_geom *g, const float *x, const float *w, const float *bias, const float *scale,
+                          int act, const float *dact_of, int dact_batch, const float *addend, float *y, void *stream);
+int mmdgan_conv2d_dgrad_add(const mmdgan_conv_geom *g, const float *dy, const float *w, const float *bias, const float *scale,
+                            int act, const float *dact_of, int dact_batch, const float *addend, float *dx, void *stream);
+
 /* dw[R,R,C,K] = sum over pixels x (x) dy                   autodiff of conv2d / conv2d_transpose
  * dw is overwritten.  With a workspace registered the 3x3 / stride-1 (C % 32, K % 128) and 4x4 / stride-2 (C % 64,
  * K % 128) layers run in the Winograd domain with slab partial sums: no atomics, bit-reproducible. */

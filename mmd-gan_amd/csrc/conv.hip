@@ -29,7 +29,11 @@ bool force_valu_thin() {
     return v == 1;
 }
 inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }    // also true for nullptr
+thread_local bool t_addend_applied = false;
 }  // namespace
+namespace mmdgan {
+void addend_applied() { t_addend_applied = true; }
+}
 
 namespace {
 // dact_batch: number of images dact_of holds (0 = as many as the output); the trailing
@@ -45,9 +49,36 @@ int make_wrap(int N, int dact_batch, long per_image, const char *what, long *fro
 }
 }  // namespace
 
+static int conv2d_fwd_impl(const mmdgan_conv_geom *g, const float *x, const float *w, const float *bias, const float *scale,
+                           int act, const float *dact_of, int dact_batch, const float *addend, float *y, void *stream);
+static int conv2d_dgrad_impl(const mmdgan_conv_geom *g, const float *dy, const float *w, const float *bias, const float *scale,
+                             int act, const float *dact_of, int dact_batch, const float *addend, float *dx, void *stream);
+// out = conv(...) + addend: the kernel's own epilogue where it has one for it, an axpby pass behind it otherwise
+template <class F>
+static int with_addend(const float *addend, float *out, long n, void *stream, F &&launch) {
+    t_addend_applied = false;
+    if (int rc = launch()) return rc;
+    if (addend && !t_addend_applied) return mmdgan_axpby(out, 1.f, addend, 1.f, out, n, stream);
+    return MMDGAN_OK;
+}
+
 extern "C" int mmdgan_conv2d_fwd(const mmdgan_conv_geom *g, const float *x, const float *w, const float *bias,
                                  const float *scale, int act, const float *dact_of, int dact_batch, float *y,
                                  void *stream) {
+    return conv2d_fwd_impl(g, x, w, bias, scale, act, dact_of, dact_batch, nullptr, y, stream);
+}
+extern "C" int mmdgan_conv2d_fwd_add(const mmdgan_conv_geom *g, const float *x, const float *w, const float *bias,
+                                     const float *scale, int act, const float *dact_of, int dact_batch, const float *addend,
+                                     float *y, void *stream) {
+    if (int rc = validate(g, "conv2d_fwd_add")) return rc;
+    MMDGAN_REQUIRE(addend && al16(addend), "conv2d_fwd_add: the addend must be a 16-byte aligned tensor of the output's shape");
+    MMDGAN_REQUIRE(!(act & MMDGAN_ACT_FLAG_OUT_ZEROED), "conv2d_fwd_add: not with MMDGAN_ACT_FLAG_OUT_ZEROED (split accumulation)");
+    const ConvDims d = conv_dims(*g);
+    return with_addend(addend, y, (long)d.N * d.P * d.Q * d.K, stream,
+                       [&]() { return conv2d_fwd_impl(g, x, w, bias, scale, act, dact_of, dact_batch, addend, y, stream); });
+}
+static int conv2d_fwd_impl(const mmdgan_conv_geom *g, const float *x, const float *w, const float *bias, const float *scale,
+                           int act, const float *dact_of, int dact_batch, const float *addend, float *y, void *stream) {
     if (int rc = validate(g, "conv2d_fwd")) return rc;
     MMDGAN_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
     const bool out_zeroed = (act & MMDGAN_ACT_FLAG_OUT_ZEROED) != 0, w_wino = (act & MMDGAN_ACT_FLAG_W_WINOGRAD) != 0;
@@ -56,7 +87,7 @@ extern "C" int mmdgan_conv2d_fwd(const mmdgan_conv_geom *g, const float *x, cons
     const ConvDims d = conv_dims(*g);
     long wf, ws;
     if (int rc = make_wrap(d.N, dact_of ? dact_batch : 0, (long)d.P * d.Q * d.K, "conv2d_fwd", &wf, &ws)) return rc;
-    const ConvEpilogue ep{bias, scale, dact_of, act, wf, ws, out_zeroed};
+    const ConvEpilogue ep{bias, scale, dact_of, act, wf, ws, out_zeroed, addend};
     if (w_wino) {
         MMDGAN_REQUIRE(wino_eligible(d, false) || wino2_eligible(d, false),
                        "conv2d_fwd: MMDGAN_ACT_FLAG_W_WINOGRAD on a geometry mmdgan_wino_eligible() rejects");
@@ -75,6 +106,19 @@ extern "C" int mmdgan_conv2d_fwd(const mmdgan_conv_geom *g, const float *x, cons
 extern "C" int mmdgan_conv2d_dgrad(const mmdgan_conv_geom *g, const float *dy, const float *w, const float *bias,
                                    const float *scale, int act, const float *dact_of, int dact_batch, float *dx,
                                    void *stream) {
+    return conv2d_dgrad_impl(g, dy, w, bias, scale, act, dact_of, dact_batch, nullptr, dx, stream);
+}
+extern "C" int mmdgan_conv2d_dgrad_add(const mmdgan_conv_geom *g, const float *dy, const float *w, const float *bias,
+                                       const float *scale, int act, const float *dact_of, int dact_batch, const float *addend,
+                                       float *dx, void *stream) {
+    if (int rc = validate(g, "conv2d_dgrad_add")) return rc;
+    MMDGAN_REQUIRE(addend && al16(addend), "conv2d_dgrad_add: the addend must be a 16-byte aligned tensor of the output's shape");
+    MMDGAN_REQUIRE(!(act & MMDGAN_ACT_FLAG_OUT_ZEROED), "conv2d_dgrad_add: not with MMDGAN_ACT_FLAG_OUT_ZEROED (split accumulation)");
+    return with_addend(addend, dx, (long)g->N * g->H * g->W * g->C, stream,
+                       [&]() { return conv2d_dgrad_impl(g, dy, w, bias, scale, act, dact_of, dact_batch, addend, dx, stream); });
+}
+static int conv2d_dgrad_impl(const mmdgan_conv_geom *g, const float *dy, const float *w, const float *bias, const float *scale,
+                             int act, const float *dact_of, int dact_batch, const float *addend, float *dx, void *stream) {
     if (int rc = validate(g, "conv2d_dgrad")) return rc;
     MMDGAN_REQUIRE(dy && w && dx, "conv2d_dgrad: null pointer");
     const bool out_zeroed = (act & MMDGAN_ACT_FLAG_OUT_ZEROED) != 0, w_wino = (act & MMDGAN_ACT_FLAG_W_WINOGRAD) != 0;
@@ -83,7 +127,7 @@ extern "C" int mmdgan_conv2d_dgrad(const mmdgan_conv_geom *g, const float *dy, c
     const ConvDims d = conv_dims(*g);
     long wf, ws;
     if (int rc = make_wrap(d.N, dact_of ? dact_batch : 0, (long)d.H * d.W * d.C, "conv2d_dgrad", &wf, &ws)) return rc;
-    const ConvEpilogue ep{bias, scale, dact_of, act, wf, ws, out_zeroed};
+    const ConvEpilogue ep{bias, scale, dact_of, act, wf, ws, out_zeroed, addend};
     if (w_wino) {
         MMDGAN_REQUIRE(wino_eligible(d, true) || wino2_eligible(d, true),
                        "conv2d_dgrad: MMDGAN_ACT_FLAG_W_WINOGRAD on a geometry mmdgan_wino_eligible() rejects");

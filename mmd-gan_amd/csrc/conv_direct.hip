@@ -100,6 +100,7 @@ int direct_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const 
     long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(direct_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d, ep, x, w, y);
+    addend_applied();                                   // ConvEpilogue::apply
     return check_launch("conv2d_fwd(direct)");
 }
 int direct_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, float *dx, hipStream_t st) {
@@ -107,6 +108,7 @@ int direct_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, con
     long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(direct_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d, ep, dy, w, dx);
+    addend_applied();
     return check_launch("conv2d_dgrad(direct)");
 }
 int direct_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st) {

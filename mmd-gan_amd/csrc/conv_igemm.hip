@@ -255,7 +255,7 @@ __device__ __forceinline__ void epilogue_store(float *smem, f32x16 (&acc)[TileCf
                             v.z = act_fwd(v.z, ep.act); v.w = act_fwd(v.w, ep.act);
                         }
                     }
-                    *reinterpret_cast<float4 *>(out + o) = v;
+                    *reinterpret_cast<float4 *>(out + o) = raw ? v : ep.add4(v, o);
                 }
             }
         }
@@ -648,7 +648,8 @@ int igemm_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const f
     const int nstages = d.R * d.R * d.C / BK;
     const long tiles = ((M + bm - 1) / bm) * (d.K / bn);
     // with caller-side zeroing only the batch-1 (spectral-norm power iteration) launches may split
-    const bool may_split = ep.act == MMDGAN_ACT_LINEAR && !ep.dact && (!outputs_prezeroed() || d.N == 1 || ep.out_zeroed);
+    // (an addend rides on the plain store of an unsplit launch only: a split one zeroes and accumulates into the output)
+    const bool may_split = ep.act == MMDGAN_ACT_LINEAR && !ep.dact && !ep.addend && (!outputs_prezeroed() || d.N == 1 || ep.out_zeroed);
     int split = pick_split(tiles, nstages, may_split);
     int sps = (nstages + split - 1) / split;
     split = (nstages + sps - 1) / sps;
@@ -662,6 +663,7 @@ int igemm_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const f
         else hipLaunchKernelGGL((igemm_fwd_kernel<64, 64, false, 2>), grid, dim3(512), (smem_bytes<64, 64>()), st, d, ep, x, w, y, sps);
     }
     else { if (split > 1) hipLaunchKernelGGL((igemm_fwd_kernel<64, 64, true>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, ep, x, w, y, sps); else hipLaunchKernelGGL((igemm_fwd_kernel<64, 64, false>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, ep, x, w, y, sps); }
+    if (split == 1) addend_applied();
     return check_launch("conv2d_fwd(igemm)");
 }
 
@@ -676,7 +678,8 @@ int igemm_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, cons
     const long tiles = ((M + bm - 1) / bm) * (d.C / bn) * s * s;
     const int TT = d.R / s;
     const int nstages = TT * TT * d.K / BK;
-    const bool may_split = ep.act == MMDGAN_ACT_LINEAR && !ep.dact && (!outputs_prezeroed() || d.N == 1 || ep.out_zeroed);
+    // (an addend rides on the plain store of an unsplit launch only: a split one zeroes and accumulates into the output)
+    const bool may_split = ep.act == MMDGAN_ACT_LINEAR && !ep.dact && !ep.addend && (!outputs_prezeroed() || d.N == 1 || ep.out_zeroed);
     int split = pick_split(tiles, nstages, may_split);
     int sps = (nstages + split - 1) / split;
     split = (nstages + sps - 1) / sps;
@@ -691,6 +694,7 @@ int igemm_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, cons
         else hipLaunchKernelGGL((igemm_dgrad_kernel<64, 64, false, 2>), grid, dim3(512), (smem_bytes<64, 64>()), st, d, ep, dy, w, dx, split, sps);
     }
     else { if (split > 1) hipLaunchKernelGGL((igemm_dgrad_kernel<64, 64, true>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, ep, dy, w, dx, split, sps); else hipLaunchKernelGGL((igemm_dgrad_kernel<64, 64, false>), grid, dim3(256), (smem_bytes<64, 64>()), st, d, ep, dy, w, dx, split, sps); }
+    if (split == 1) addend_applied();
     return check_launch("conv2d_dgrad(igemm)");
 }
 

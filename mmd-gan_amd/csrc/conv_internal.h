@@ -14,12 +14,27 @@ struct ConvEpilogue {
     int act;
     long wrap_from, wrap_sub;
     bool out_zeroed;          // host-side hint only (MMDGAN_ACT_FLAG_OUT_ZEROED)
+    // added LAST, after the activation / its derivative: out = epilogue(v) + addend[o] (same shape as the output; may BE the
+    // output buffer).  A residual block's branch sum (layer_func.py:1842) and the fan-in of two gradients at a block's
+    // input ride on the launch that produces the second term instead of a pass of their own (mmdgan_conv2d_*_add).
+    // A launcher that applies it in its kernel says so with addend_applied(); for any other the entry point adds it
+    // with an axpby pass afterwards - every kernel gives the same result, the native ones save the pass.
+    const float *addend = nullptr;
     __device__ __forceinline__ long dact_index(long o) const { return o >= wrap_from ? o - wrap_sub : o; }
     __device__ __forceinline__ float apply(float v, int ch, long o) const {
         if (bias) v += bias[ch];
-        return dact ? v * act_bwd_from_out(dact[dact_index(o)], act) : act_fwd(v, act);
+        v = dact ? v * act_bwd_from_out(dact[dact_index(o)], act) : act_fwd(v, act);
+        return addend ? v + addend[o] : v;
+    }
+    __device__ __forceinline__ float4 add4(float4 v, long o) const {      // o: element offset of v.x (16-byte aligned)
+        if (addend) {
+            const float4 a = *reinterpret_cast<const float4 *>(addend + o);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        return v;
     }
 };
+void addend_applied();        // conv.hip: the launch just issued applies ep.addend itself (thread-local note for the entry point)
 constexpr long kNoWrap = 0x7fffffffffffffffL;
 
 int direct_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, float *y, hipStream_t st);

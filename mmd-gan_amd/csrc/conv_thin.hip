@@ -307,6 +307,7 @@ int thin_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const fl
         const size_t lds = sizeof(float) * d.R * d.R * d.K * d.C;
         hipLaunchKernelGGL(thin_out_kernel<false>, dim3(blocks_for(work, 128, 4096)), dim3(128), lds, st, d, ep, x, w, y);
     }
+    addend_applied();                                   // ConvEpilogue::apply in both kernels
     return check_launch("conv2d_fwd(thin)");
 }
 int thin_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, float *dx, hipStream_t st) {
@@ -319,6 +320,7 @@ int thin_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const
         const size_t lds = sizeof(float) * d.R * d.R * d.K * d.C;
         hipLaunchKernelGGL(thin_out_kernel<true>, dim3(blocks_for(work, 128, 4096)), dim3(128), lds, st, d, ep, dy, w, dx);
     }
+    addend_applied();
     return check_launch("conv2d_dgrad(thin)");
 }
 int thin_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hipStream_t st) {

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void thinm_n2w_kernel(ConvDims d, ConvEpilogue
                         v.x = act_fwd(v.x, ep.act); v.y = act_fwd(v.y, ep.act);
                         v.z = act_fwd(v.z, ep.act); v.w = act_fwd(v.w, ep.act);
                     }
-                    *reinterpret_cast<float4 *>(out + o) = v;
+                    *reinterpret_cast<float4 *>(out + o) = ep.add4(v, o);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void thinm_n2w_kernel(ConvDims d, ConvEpilogue
                     v.x = act_fwd(v.x, ep.act); v.y = act_fwd(v.y, ep.act);
                     v.z = act_fwd(v.z, ep.act); v.w = act_fwd(v.w, ep.act);
                 }
-                *reinterpret_cast<float4 *>(out + o) = v;
+                *reinterpret_cast<float4 *>(out + o) = ep.add4(v, o);
             }
     }
 }
@@ -401,12 +401,14 @@ static void launch_w2n(const ConvDims &d, const ConvEpilogue &ep, const float *i
 int thinm_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, float *y, hipStream_t st) {
     if (thinm_fwd_n2w_ok(d)) launch_n2w<false>(d, ep, x, w, y, d.K, st);
     else launch_w2n<false>(d, ep, x, w, y, d.C, d.K, st);
+    addend_applied();                                   // n2w: add4 at its stores; w2n: ConvEpilogue::apply
     return check_launch("conv2d_fwd(thin mfma)");
 }
 
 int thinm_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, float *dx, hipStream_t st) {
     if (thinm_dgrad_n2w_ok(d)) launch_n2w<true>(d, ep, dy, w, dx, d.C, st);
     else launch_w2n<true>(d, ep, dy, w, dx, d.K, d.C, st);
+    addend_applied();
     return check_launch("conv2d_dgrad(thin mfma)");
 }
 

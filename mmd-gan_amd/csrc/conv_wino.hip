@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256, WINO_WAVES) void wino_kernel(int N, int H, int
                         v.x = act_fwd(v.x, ep.act); v.y = act_fwd(v.y, ep.act);
                         v.z = act_fwd(v.z, ep.act); v.w = act_fwd(v.w, ep.act);
                     }
-                    *reinterpret_cast<float4 *>(out + o) = v;
+                    *reinterpret_cast<float4 *>(out + o) = ep.add4(v, o);
                 }
             }
         }
@@ -371,6 +371,7 @@ static int wino_launch(const ConvDims &d, const ConvEpilogue &ep, const float *i
         hipLaunchKernelGGL((wino_kernel<64, false>), grid, dim3(256), (wino::Cfg<64>::LDS_BYTES), st, d.N, d.H, d.W, cr, ko, ep, in,
                            U, out, nstages, 0L);
     }
+    addend_applied();                                   // in the kernel's stores (the split form above: in slab_epilogue)
     return check_launch(flip ? "conv2d_dgrad(winograd)" : "conv2d_fwd(winograd)");
 }
 

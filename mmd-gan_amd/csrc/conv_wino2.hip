@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void slab_epilogue_kernel(const float4 *__rest
             v.x = act_fwd(v.x, ep.act); v.y = act_fwd(v.y, ep.act);
             v.z = act_fwd(v.z, ep.act); v.w = act_fwd(v.w, ep.act);
         }
-        out[e] = v;
+        out[e] = ep.add4(v, e * 4);
     }
 }
 
@@ -502,6 +502,7 @@ int slab_epilogue(const float *slabs, int nslabs, long total, int Ko, const Conv
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(slab_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float4 *)slabs, nslabs, n4, Ko, ep,
                        (float4 *)out);
+    addend_applied();
     return check_launch("conv slab epilogue");
 }
 

@@ -47,6 +47,8 @@ SIGNATURES = {
     'mmdgan_allreduce_bucket': (_I, [_P, ctypes.c_size_t, _P]),
     'mmdgan_conv2d_fwd': (_I, [_G, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     'mmdgan_conv2d_dgrad': (_I, [_G, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
+    'mmdgan_conv2d_fwd_add': (_I, [_G, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P]),
+    'mmdgan_conv2d_dgrad_add': (_I, [_G, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P]),
     'mmdgan_conv2d_wgrad': (_I, [_G, _P, _P, _P, _P]),
     'mmdgan_conv2d_wgrad_bias': (_I, [_G, _P, _P, _P, _P, _P]),
     'mmdgan_conv2d_wgrad_sn': (_I, [_G, _P, _P, _P, _P, _P, _P, _P]),

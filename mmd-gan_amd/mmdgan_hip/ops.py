@@ -194,9 +194,10 @@ def out_hw(H, W, stride):
 
 # ------------------------------------------------------------------------------------------------
 def conv2d_fwd(x, w, stride, bias=None, scale=None, act='linear', dact_of=None, out=None, dact_batch=0,
-               out_zeroed=False, wino=None):
+               out_zeroed=False, wino=None, addend=None):
     """x [N,H,W,C], w [R,R,C,K] -> y [N,P,Q,K] = act(scale*conv(x,w)+bias) (layer_func.py:913-916)
-    wino: the tensor wino_transform(w, ...) made from w (the library then skips its own transform)"""
+    wino: the tensor wino_transform(w, ...) made from w (the library then skips its own transform)
+    addend: a tensor of y's shape added last (mmdgan_conv2d_fwd_add; may be `out` itself)"""
     lib = require_device()
     N, H, W, C = x.shape
     R, K = w.shape[0], w.shape[3]
@@ -204,15 +205,20 @@ def conv2d_fwd(x, w, stride, bias=None, scale=None, act='linear', dact_of=None, 
     P, Q = out_hw(H, W, stride)
     y = out if out is not None else torch.empty((N, P, Q, K), device=x.device, dtype=torch.float32)
     g = geom(N, H, W, C, K, R, stride)
-    check(lib.mmdgan_conv2d_fwd(ctypes.byref(g), _p(x), _p(w if wino is None else wino), _p(bias), _p(scale),
-                                act_id(act) | (0x100 if out_zeroed else 0) | (0 if wino is None else 0x200),
+    flags = act_id(act) | (0x100 if out_zeroed else 0) | (0 if wino is None else 0x200)
+    if addend is not None:
+        assert tuple(addend.shape) == tuple(y.shape) and addend.is_contiguous()
+        check(lib.mmdgan_conv2d_fwd_add(ctypes.byref(g), _p(x), _p(w if wino is None else wino), _p(bias), _p(scale), flags,
+                                        _p(dact_of), int(dact_batch), _p(addend), _p(y), _stream()), 'conv2d_fwd_add')
+        return y
+    check(lib.mmdgan_conv2d_fwd(ctypes.byref(g), _p(x), _p(w if wino is None else wino), _p(bias), _p(scale), flags,
                                 _p(dact_of), int(dact_batch),
                                 _p(y), _stream()), 'conv2d_fwd')
     return y
 
 
 def conv2d_dgrad(dy, w, in_hw, stride, bias=None, scale=None, act='linear', dact_of=None, out=None, dact_batch=0,
-                 wino=None, out_zeroed=False):
+                 wino=None, out_zeroed=False, addend=None):
     """dy [N,P,Q,K], w [R,R,C,K] -> dx [N,H,W,C]; forward form = tf.nn.conv2d_transpose (layer_func.py:926)
     out_zeroed: `out` is zero on entry - a launch with a linear epilogue may split its reduction over workgroups"""
     lib = require_device()
@@ -223,8 +229,13 @@ def conv2d_dgrad(dy, w, in_hw, stride, bias=None, scale=None, act='linear', dact
     assert out_hw(H, W, stride) == (P, Q)
     dx = out if out is not None else torch.empty((N, H, W, C), device=dy.device, dtype=torch.float32)
     g = geom(N, H, W, C, K, R, stride)
-    check(lib.mmdgan_conv2d_dgrad(ctypes.byref(g), _p(dy), _p(w if wino is None else wino), _p(bias), _p(scale),
-                                  act_id(act) | (0x100 if out_zeroed else 0) | (0 if wino is None else 0x200), _p(dact_of),
+    flags = act_id(act) | (0x100 if out_zeroed else 0) | (0 if wino is None else 0x200)
+    if addend is not None:                               # added last (mmdgan_conv2d_dgrad_add; may be `out` itself)
+        assert tuple(addend.shape) == tuple(dx.shape) and addend.is_contiguous()
+        check(lib.mmdgan_conv2d_dgrad_add(ctypes.byref(g), _p(dy), _p(w if wino is None else wino), _p(bias), _p(scale), flags,
+                                          _p(dact_of), int(dact_batch), _p(addend), _p(dx), _stream()), 'conv2d_dgrad_add')
+        return dx
+    check(lib.mmdgan_conv2d_dgrad(ctypes.byref(g), _p(dy), _p(w if wino is None else wino), _p(bias), _p(scale), flags, _p(dact_of),
                                   int(dact_batch), _p(dx), _stream()), 'conv2d_dgrad')
     return dx
 

@@ -548,6 +548,7 @@ class NetForward:
         run = TapeEngine.__new__(TapeEngine)
         run.device, run._bufs, run._wino, run._in_step, run._sn_zeroed = self.device, {}, {}, False, False
         run._folded = {k.scope: [None, None] for k in self.net.kernels}
+        run._graphs, run._fusions, run._out_buffer = {}, {}, None
         self._run = run
 
     def __call__(self, x_nhwc, is_training=False):
@@ -625,6 +626,7 @@ class TapeEngine:
         self._in_step = False                                            # transformed weights are valid inside step() only
         self._sn_zeroed = False                                          # inside step(): the power iteration's targets are zeroed
         self._exchange_pending = False
+        self._fuse_fanin = os.environ.get('MMDGAN_TAPE_FUSE_ADD', '1') != '0'
         self._d_has_bn = bool(self.dis.bns)
         lib = ops.require_device()
         # side streams on hardware queues of their own (streams.py): the power iterations run under G's forward pass,
@@ -634,7 +636,7 @@ class TapeEngine:
             from .streams import distinct_queue_streams
             self._wg_stream, self._sn_stream = distinct_queue_streams(2, self.device)
             self._wg_raw, self._sn_raw = self._wg_stream.cuda_stream, self._sn_stream.cuda_stream
-        self._graphs = {}
+        self._graphs, self._fusions = {}, {}
         # D without batch norm: its rows are independent, so loss_dis (2B rows) and loss_gen (the fake half again, B rows) go
         # back through it TOGETHER as 3B rows (one launch per primitive instead of two passes) - _backward(extra_rows=B)
         self._d_joint = (not self._d_has_bn and all(p['kind'] in self._ROW_WISE for p in self.dis.prims)
@@ -891,10 +893,12 @@ class TapeEngine:
         lib = ops.require_device()
         last = max(i for i, p in enumerate(net.prims) if p['out'] == net.out_val)
         self._out_buffer = ((tag, net.name), last, out_buffer) if (out_buffer is not None and net.prims[last]['kind'] != 'reshape') else None
+        fused_addend, fused_add = self._add_fusions(net)
         for i, p in enumerate(net.prims):
             kind, a = p['kind'], vals[p['ins'][0]]
             key = (tag, net.name, i)
             out_shape = _native(net.shapes[p['out']], n)
+            addend = vals[fused_addend[i]] if i in fused_addend else None     # a branch sum riding on this launch
             if kind == 'reshape':
                 y = a.reshape(out_shape)
             elif kind in ('dense', 'conv'):
@@ -905,7 +909,7 @@ class TapeEngine:
                 if kind == 'dense':
                     ops.gemm(a.reshape(n, -1), net.p(k.w_name), bias=bias, scale=scale, out=y)
                 else:
-                    ops.conv2d_fwd(a, net.p(k.w_name), k.stride, bias=bias, scale=scale, out=y,
+                    ops.conv2d_fwd(a, net.p(k.w_name), k.stride, bias=bias, scale=scale, out=y, addend=addend,
                                    wino=self._wino_of(k, False, n) if (training and self._in_step) else None)
             elif kind == 'gconv':                                        # 'VALID' padding and / or dilation: a composition
                 k = p['k']
@@ -921,10 +925,10 @@ class TapeEngine:
                     w4 = ops.compose_scaled_conv(net.p(k.w_name), k.fold)
                 y = self._buf_of(key, out_shape)
                 if kind == 'convdown':
-                    ops.conv2d_fwd(a, w4, 2, bias=bias, scale=scale, out=y,
+                    ops.conv2d_fwd(a, w4, 2, bias=bias, scale=scale, out=y, addend=addend,
                                    wino=self._wino_of(k, False, n) if (training and self._in_step) else None)
                 else:
-                    ops.conv2d_dgrad(a, w4, (out_shape[1], out_shape[2]), 2, bias=bias, scale=scale, out=y,
+                    ops.conv2d_dgrad(a, w4, (out_shape[1], out_shape[2]), 2, bias=bias, scale=scale, out=y, addend=addend,
                                      wino=self._wino_of(k, True, n) if (training and self._in_step) else None)
             elif kind == 'tconv':                                        # y = the input-gradient of a conv with kernel w
                 k = p['k']
@@ -932,7 +936,7 @@ class TapeEngine:
                 scale = net.sn[k.scope]['scale'] if k.sn else None
                 y = self._buf_of(key, out_shape)
                 ops.conv2d_dgrad(a, net.p(k.w_name), (out_shape[1], out_shape[2]), k.stride, bias=bias, scale=scale, out=y,
-                                 wino=self._wino_of(k, True, n) if (training and self._in_step) else None)
+                                 addend=addend, wino=self._wino_of(k, True, n) if (training and self._in_step) else None)
             elif kind == 'bn':
                 y = self._buf_of(key, out_shape)
                 c = out_shape[-1]
@@ -953,7 +957,10 @@ class TapeEngine:
             elif kind == 'down':
                 y = ops.resample_down(a, p['f'], out=self._buf_of(key, out_shape))
             elif kind == 'up':
-                y = ops.resample_up(a, p['f'], out=self._buf_of(key, out_shape))
+                if addend is not None:                                   # += into the other term of the sum that follows
+                    y = ops.resample_up(a, p['f'], out=addend, accumulate=True)
+                else:
+                    y = ops.resample_up(a, p['f'], out=self._buf_of(key, out_shape))
             elif kind == 'shuffle':
                 y = ops.periodic_shuffle(a, p['f'], p['to_big'], out=self._buf_of(key, out_shape))
             elif kind in ('bilinear', 'bicubic'):
@@ -961,7 +968,10 @@ class TapeEngine:
             elif kind == 'maxpool':
                 y = ops.max_pool(a, p['f'], out=self._buf_of(key, out_shape))
             elif kind == 'add':
-                y = ops.axpby(a, vals[p['ins'][1]], out=self._buf_of(key, out_shape))
+                if i in fused_add:                                       # the sum was formed by the launch of its second term
+                    y = vals[fused_add[i]]
+                else:
+                    y = ops.axpby(a, vals[p['ins'][1]], out=self._buf_of(key, out_shape))
             else:
                 raise AssertionError(kind)
             vals[p['out']] = y
@@ -985,6 +995,38 @@ class TapeEngine:
             uses[net.out_val] = uses.get(net.out_val, 0) + 1
             g = self._graphs[id(net)] = (producer, uses)
         return g
+
+    def _add_fusions(self, net):
+        """which branch sums (layer_func.py:1842) ride on the launch that produces their second term instead of an axpby pass:
+        ({index of a conv-like / 'up' primitive: the value it adds in its epilogue}, {index of an 'add' primitive: the value
+        whose buffer then already holds the sum}).  A term qualifies when nothing else reads it and the other term exists
+        before its producer runs: the 1x1 shortcut conv of a down-sampling block (its epilogue adds the branch), the
+        'unpool' of an up-sampling block's shortcut (accumulated into the branch's buffer), the last conv of a block with
+        an identity shortcut (adds the block input).  MMDGAN_TAPE_FUSE_ADD=0: every sum as its own pass."""
+        f = self._fusions.get(id(net))
+        if f is None:
+            producer, uses = self._graph_of(net)
+            where = {p['out']: i for i, p in enumerate(net.prims)}
+            addend, alias = {}, {}
+            if os.environ.get('MMDGAN_TAPE_FUSE_ADD', '1') != '0':
+                for i, p in enumerate(net.prims):
+                    if p['kind'] != 'add' or p['out'] == net.out_val:
+                        continue
+                    a, b = p['ins']
+                    for term, other in ((b, a), (a, b)):
+                        q = producer.get(term)
+                        if q is None or uses.get(term, 0) != 1 or where[term] in addend:
+                            continue
+                        if where.get(other, -1) > where[term]:
+                            continue                     # the other term does not exist yet when `term` is produced
+                        if q['kind'] in ('conv', 'convdown', 'upconv', 'tconv'):
+                            addend[where[term]], alias[i] = other, term
+                            break
+                        if q['kind'] == 'up' and uses.get(other, 0) == 1 and other != 0:
+                            addend[where[term]], alias[i] = other, other      # accumulated INTO the other term's buffer
+                            break
+            f = self._fusions[id(net)] = (addend, alias)
+        return f
 
     def _sn_grad_tail(self, net, k, gw, w, scale, dot_done):
         """the spectral-norm fix-up of a kernel's gradient: <G, W> next to the RAW gradient; the fix-up itself
@@ -1071,23 +1113,29 @@ class TapeEngine:
                 nx = dyx.shape[0]
                 in_shape = [nx] + list(a.shape[1:])
                 dx = self._buf(key, in_shape)
+                # fan-in: the value this gradient goes to already holds one from another consumer (a block's input: shortcut
+                # and branch) - the sum rides on this launch's epilogue (give() would spend an axpby pass on it)
+                fan = None
+                if (self._fuse_fanin and tgt != 0 and kind in ('conv', 'convdown', 'upconv', 'tconv') and tgt in grads
+                        and list(grads[tgt].shape) == in_shape and grads[tgt].is_contiguous()):
+                    fan = grads.pop(tgt)
                 if kind == 'dense':
                     ops.gemm(dyx.reshape(nx, -1), w, trans_b=True, scale=scale, act=act,
                              dact_of=dact.reshape(dact.shape[0], -1) if dact is not None else None, dact_rows=dact_batch,
                              out=dx.view(nx, -1))
                 elif kind == 'conv':
                     ops.conv2d_dgrad(dyx, w, (in_shape[1], in_shape[2]), k.stride, scale=scale, act=act, dact_of=dact,
-                                     dact_batch=dact_batch, out=dx, wino=self._wino_of(k, True, nx))
+                                     dact_batch=dact_batch, out=dx, addend=fan, wino=self._wino_of(k, True, nx))
                 elif kind == 'gconv':                        # 'VALID' / dilated: the adjoint composition
                     self._gconv_dgrad(k, dyx, w, (in_shape[1], in_shape[2]), key + ('x',), scale=scale, out=dx)
                 elif kind == 'convdown':
                     ops.conv2d_dgrad(dyx, self._folded[k.scope][0], (in_shape[1], in_shape[2]), 2, scale=scale, act=act,
-                                     dact_of=dact, dact_batch=dact_batch, out=dx, wino=self._wino_of(k, True, nx))
+                                     dact_of=dact, dact_batch=dact_batch, out=dx, addend=fan, wino=self._wino_of(k, True, nx))
                 elif kind == 'upconv':
                     ops.conv2d_fwd(dyx, self._folded[k.scope][0], 2, scale=scale, act=act, dact_of=dact,
-                                   dact_batch=dact_batch, out=dx, wino=self._wino_of(k, False, nx))
+                                   dact_batch=dact_batch, out=dx, addend=fan, wino=self._wino_of(k, False, nx))
                 else:                                        # tconv: d/dx of dgrad(x, W) = conv(dy, W)
-                    ops.conv2d_fwd(dyx, w, k.stride, scale=scale, act=act, dact_of=dact, dact_batch=dact_batch, out=dx,
+                    ops.conv2d_fwd(dyx, w, k.stride, scale=scale, act=act, dact_of=dact, dact_batch=dact_batch, out=dx, addend=fan,
                                    wino=self._wino_of(k, False, nx))
                 give(tgt, dx)
                 continue
