@@ -453,6 +453,61 @@ def test_conv_shapes_of_every_config_at_their_bench_batch(ops):
     assert not bad, bad
 
 
+ADD_CASES = [
+    # N, H, W, C, K, R, stride                          which kernel takes it under the test thresholds
+    (16, 16, 16, 64, 128, 3, 1),                          # F(2x2,3x3), unsplit: in the kernel's stores
+    (4, 8, 8, 128, 128, 3, 1),                            # F(2x2,3x3) with the reduction split over slabs: in the slab pass
+    (16, 16, 16, 64, 128, 4, 2),                          # F(2x2,2x2): the entry's axpby pass (unsplit) / the slab pass
+    (8, 16, 16, 64, 64, 1, 1),                            # 1x1 shortcut conv: implicit GEMM
+    (8, 16, 16, 3, 64, 1, 1), (8, 32, 32, 3, 64, 3, 1),   # thin input: direct / thin kernels
+    (5, 9, 7, 5, 6, 3, 1),                                # generic direct kernel
+]
+
+
+@pytest.mark.parametrize('case', ADD_CASES, ids=[str(c) for c in ADD_CASES])
+def test_conv_with_an_addend_equals_conv_plus_addend(ops, case):
+    """mmdgan_conv2d_fwd_add / _dgrad_add: out = epilogue(conv) + addend, whichever kernel the geometry takes (its own
+    epilogue or the entry's axpby pass), with an activation / activation derivative in front of the sum, with transformed
+    weights handed in, and IN PLACE (the addend is the output buffer) - against the same launch without the addend."""
+    N, H, W, C, K, R, s = case
+    g = torch.Generator(device='cuda').manual_seed(N + C + K)
+    P, Q = -(-H // s), -(-W // s)
+    x = torch.empty(N, H, W, C, device='cuda').uniform_(-1, 1, generator=g)
+    w = torch.randn(R, R, C, K, device='cuda', generator=g) / float(np.sqrt(R * R * C))
+    b = torch.randn(K, device='cuda', generator=g) * 0.1
+    dy = torch.randn(N, P, Q, K, device='cuda', generator=g)
+    ay = torch.randn(N, P, Q, K, device='cuda', generator=g)
+    ax = torch.randn(N, H, W, C, device='cuda', generator=g)
+    sc = torch.tensor([0.37], device='cuda')
+    ops.set_workspace(128 << 20)
+    try:
+        for wino in (False, True):
+            ok = wino and R in (3, 4)
+            uf = ops.wino_transform(w, False) if ok and ops.wino_eligible(N, H, W, C, K, R, s, False) else None
+            ud = ops.wino_transform(w, True) if ok and ops.wino_eligible(N, H, W, C, K, R, s, True) else None
+            if wino and uf is None and ud is None:
+                continue
+            y0 = ops.conv2d_fwd(x, w, s, bias=b, scale=sc, act='lrelu', wino=uf)
+            y1 = ops.conv2d_fwd(x, w, s, bias=b, scale=sc, act='lrelu', wino=uf, addend=ay)
+            assert torch.allclose(y1, y0 + ay, rtol=1e-6, atol=1e-6), ('fwd', wino)
+            buf = ay.clone()
+            ops.conv2d_fwd(x, w, s, bias=b, scale=sc, act='lrelu', wino=uf, addend=buf, out=buf)      # in place
+            assert torch.equal(buf, y1), ('fwd in place', wino)
+            d0 = ops.conv2d_dgrad(dy, w, (H, W), s, scale=sc, act='lrelu', dact_of=x, wino=ud)
+            d1 = ops.conv2d_dgrad(dy, w, (H, W), s, scale=sc, act='lrelu', dact_of=x, wino=ud, addend=ax)
+            assert torch.allclose(d1, d0 + ax, rtol=1e-6, atol=1e-6), ('dgrad', wino)
+            buf = ax.clone()
+            ops.conv2d_dgrad(dy, w, (H, W), s, scale=sc, act='lrelu', dact_of=x, wino=ud, addend=buf, out=buf)
+            assert torch.equal(buf, d1), ('dgrad in place', wino)
+    finally:
+        ops.require_device().mmdgan_set_workspace(None, 0)
+    lib = ops.require_device()
+    import ctypes
+    gm = ops.geom(N, H, W, C, K, R, s)
+    rc = lib.mmdgan_conv2d_fwd_add(ctypes.byref(gm), x.data_ptr(), w.data_ptr(), None, None, 0, None, 0, None, y0.data_ptr(), None)
+    assert rc == -1 and b'addend' in lib.mmdgan_last_error()
+
+
 WINO2_CASES = [(16, 16, 16, 64, 128, 4, 2), (30, 12, 12, 32, 64, 4, 2), (6, 8, 16, 64, 64, 4, 2), (9, 4, 4, 128, 64, 4, 2),
                (33, 8, 8, 96, 192, 4, 2), (5, 12, 8, 64, 128, 4, 2), (9, 4, 4, 128, 256, 4, 2), (70, 8, 8, 64, 128, 4, 2)]
 
