@@ -191,8 +191,8 @@ int mmdgan_conv2d_fwd(const mmdgan_conv_geom *g, const float *x, const float *w,
 int mmdgan_conv2d_dgrad(const mmdgan_conv_geom *g, const float *dy, const float *w, const float *bias,
                         const float *scale, int act, const float *dact_of, int dact_batch, float *dx, void *stream);
 
-/* The same two entries with a tensor added LAST - out = epilogue(conv) + addend, addend of the output's shape (16-byte aligned;
- * it may be the output buffer itself).  A residual block's branch sum  x + f(x)  (layer_func.py:1842) and the fan-in of the two
+/* The same two entries with a tensor added LAST - out = epilogue(conv) + addend, addend of the output's shape (16-byte aligned,
+ * not the output buffer: a kernel without an epilogue for it gets an axpby pass behind it).  A residual block's branch sum  x + f(x)  (layer_func.py:1842) and the fan-in of the two
  * gradients that meet at a block's input ride on the launch that produces the second term instead of a pass of their own.
  * Kernels with an epilogue for it apply it in their stores (implicit GEMM, F(2x2,3x3), the slab pass of every split launch,
  * thin, direct); for the others the entry appends an axpby pass - the same result from every kernel.

@@ -71,7 +71,7 @@ extern "C" int mmdgan_conv2d_fwd_add(const mmdgan_conv_geom *g, const float *x, 
                                      const float *scale, int act, const float *dact_of, int dact_batch, const float *addend,
                                      float *y, void *stream) {
     if (int rc = validate(g, "conv2d_fwd_add")) return rc;
-    MMDGAN_REQUIRE(addend && al16(addend), "conv2d_fwd_add: the addend must be a 16-byte aligned tensor of the output's shape");
+    MMDGAN_REQUIRE(addend && al16(addend) && addend != y, "conv2d_fwd_add: the addend must be a 16-byte aligned tensor of the output's shape, not the output itself");
     MMDGAN_REQUIRE(!(act & MMDGAN_ACT_FLAG_OUT_ZEROED), "conv2d_fwd_add: not with MMDGAN_ACT_FLAG_OUT_ZEROED (split accumulation)");
     const ConvDims d = conv_dims(*g);
     return with_addend(addend, y, (long)d.N * d.P * d.Q * d.K, stream,
@@ -112,7 +112,7 @@ extern "C" int mmdgan_conv2d_dgrad_add(const mmdgan_conv_geom *g, const float *d
                                        const float *scale, int act, const float *dact_of, int dact_batch, const float *addend,
                                        float *dx, void *stream) {
     if (int rc = validate(g, "conv2d_dgrad_add")) return rc;
-    MMDGAN_REQUIRE(addend && al16(addend), "conv2d_dgrad_add: the addend must be a 16-byte aligned tensor of the output's shape");
+    MMDGAN_REQUIRE(addend && al16(addend) && addend != dx, "conv2d_dgrad_add: the addend must be a 16-byte aligned tensor of the output's shape, not the output itself");
     MMDGAN_REQUIRE(!(act & MMDGAN_ACT_FLAG_OUT_ZEROED), "conv2d_dgrad_add: not with MMDGAN_ACT_FLAG_OUT_ZEROED (split accumulation)");
     return with_addend(addend, dx, (long)g->N * g->H * g->W * g->C, stream,
                        [&]() { return conv2d_dgrad_impl(g, dy, w, bias, scale, act, dact_of, dact_batch, addend, dx, stream); });

@@ -14,8 +14,7 @@ struct ConvEpilogue {
     int act;
     long wrap_from, wrap_sub;
     bool out_zeroed;          // host-side hint only (MMDGAN_ACT_FLAG_OUT_ZEROED)
-    // added LAST, after the activation / its derivative: out = epilogue(v) + addend[o] (same shape as the output; may BE the
-    // output buffer).  A residual block's branch sum (layer_func.py:1842) and the fan-in of two gradients at a block's
+    // added LAST, after the activation / its derivative: out = epilogue(v) + addend[o] (same shape as the output, another buffer).  A residual block's branch sum (layer_func.py:1842) and the fan-in of two gradients at a block's
     // input ride on the launch that produces the second term instead of a pass of their own (mmdgan_conv2d_*_add).
     // A launcher that applies it in its kernel says so with addend_applied(); for any other the entry point adds it
     // with an axpby pass afterwards - every kernel gives the same result, the native ones save the pass.

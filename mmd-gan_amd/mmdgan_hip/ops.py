@@ -197,7 +197,7 @@ def conv2d_fwd(x, w, stride, bias=None, scale=None, act='linear', dact_of=None, 
                out_zeroed=False, wino=None, addend=None):
     """x [N,H,W,C], w [R,R,C,K] -> y [N,P,Q,K] = act(scale*conv(x,w)+bias) (layer_func.py:913-916)
     wino: the tensor wino_transform(w, ...) made from w (the library then skips its own transform)
-    addend: a tensor of y's shape added last (mmdgan_conv2d_fwd_add; may be `out` itself)"""
+    addend: another tensor of y's shape, added last (mmdgan_conv2d_fwd_add)"""
     lib = require_device()
     N, H, W, C = x.shape
     R, K = w.shape[0], w.shape[3]
@@ -230,7 +230,7 @@ def conv2d_dgrad(dy, w, in_hw, stride, bias=None, scale=None, act='linear', dact
     dx = out if out is not None else torch.empty((N, H, W, C), device=dy.device, dtype=torch.float32)
     g = geom(N, H, W, C, K, R, stride)
     flags = act_id(act) | (0x100 if out_zeroed else 0) | (0 if wino is None else 0x200)
-    if addend is not None:                               # added last (mmdgan_conv2d_dgrad_add; may be `out` itself)
+    if addend is not None:                               # another tensor of dx's shape, added last (mmdgan_conv2d_dgrad_add)
         assert tuple(addend.shape) == tuple(dx.shape) and addend.is_contiguous()
         check(lib.mmdgan_conv2d_dgrad_add(ctypes.byref(g), _p(dy), _p(w if wino is None else wino), _p(bias), _p(scale), flags,
                                           _p(dact_of), int(dact_batch), _p(addend), _p(dx), _stream()), 'conv2d_dgrad_add')
