@@ -375,14 +375,16 @@ def test_conv_full_size_adjointness_and_linearity(ops, case):
         assert float((alone[0] - y[i]).abs().max()) <= 1e-4 * float(y[i].abs().max())
 
 
-def _config_conv_shapes():
+def _config_conv_shapes(batches=None):
     """every convolution geometry of every BASELINE.json config at its per-GPU bench batch, with the batch sizes its launches
     run at: (config, N, H, W, C, K, R, stride).  DCGAN dicts: D layers at 2B (forward, weight gradient) and 3B (the joint
     input-gradient pass) rows, G's transposed layers as the conv they are the input-gradient of, at B rows.  ResNet-SN: the
     primitive-op engine's kernels (a block's scaling op folded into its 3x3 conv makes a 4x4 stride-2 geometry)."""
     import configs
     out = []
-    for name, B in (('cifar', 64), ('stl', 64), ('celeba', 128)):
+    batches = batches or {'cifar': 64, 'stl': 64, 'celeba': 128, 'lsun_resnet': 32}
+    for name in ('cifar', 'stl', 'celeba'):
+        B = batches[name]
         arch, _ = configs.CONFIGS[name]()
         c, h, _w = arch['input'][0]
         for d in arch['discriminator']:
@@ -403,7 +405,7 @@ def _config_conv_shapes():
                 c = d['out']
     from mmdgan_hip.tape import _Net
     arch, _ = configs.lsun_resnet()
-    B = 32
+    B = batches['lsun_resnet']
     for net_name, designs, in_ref, batches in (('gen', arch['generator'], [arch['code'][0][0]], (B,)),
                                                ('dis', arch['discriminator'], list(arch['input'][0]), (2 * B, 3 * B))):
         net = _Net(designs, in_ref, net_name, torch.device('cuda'), np.random.RandomState(0), 'default')
@@ -419,13 +421,16 @@ def _config_conv_shapes():
     return sorted(set(out))
 
 
-def test_conv_shapes_of_every_config_at_their_bench_batch(ops):
-    """the adjointness identity  <conv(x, w), dy> = <x, dgrad(dy, w)> = <w, wgrad(x, dy)>  on EVERY convolution geometry of
+@pytest.mark.parametrize('which', ['bench', 'ragged'])
+def test_conv_shapes_of_every_config_at_their_bench_batch(ops, which):
+    """('ragged': the same geometries at batch sizes that are no multiple of anything - 24 / 24 / 40 / 12 per GPU - so tile
+    blocks end ragged and the persistent kernels' work-item counts per workgroup differ from the bench's.)
+    the adjointness identity  <conv(x, w), dy> = <x, dgrad(dy, w)> = <w, wgrad(x, dy)>  on EVERY convolution geometry of
     every BASELINE.json config at the batch sizes its launches run at (2B / 3B rows in D, B in G), with the weights handed over
     transformed wherever the library's selection takes a Winograd kernel - i.e. each launch as the engines issue it, under
     whatever kernel selection this process runs (tests/test_production_gpu.py repeats the step itself under the production
     one).  Three kernels computing one bilinear form disagree when any of them mis-addresses a tile, whatever the size."""
-    shapes = _config_conv_shapes()
+    shapes = _config_conv_shapes(None if which == 'bench' else {'cifar': 24, 'stl': 24, 'celeba': 40, 'lsun_resnet': 12})
     assert len(shapes) >= 60
     bad = []
     ops.set_workspace(128 << 20)                         # what an engine's handle registers (slab / partial-sum paths need it)
