@@ -746,7 +746,10 @@ def test_dact_batch_wrap(ops):
                                          (256, 16, 18432, False, False), (16, 16, 1024, False, False), (48, 16, 4608, False, False),
                                          (128, 16, 8192 + 128, False, False), (120, 16, 8192, False, False),
                                          (128, 8192, 128, False, False), (32, 1024, 64, False, False), (96, 2048, 256, False, False),
-                                         (64, 4160, 100, False, False)])
+                                         (64, 4160, 100, False, False),
+                                         # the whole-K-at-once kernel of the short reductions (K <= 128), every operand form, ragged edges
+                                         (70, 1000, 100, True, True), (64, 8192, 128, False, True), (130, 1090, 128, True, False),
+                                         (64, 2049, 7, False, False)])
 def test_gemm(ops, M, N, K, ta, tb):
     rs = np.random.RandomState(M + N + K)
     a = rs.randn(*((K, M) if ta else (M, K))).astype(np.float32)
@@ -759,6 +762,13 @@ def test_gemm(ops, M, N, K, ta, tb):
     assert rel_err(c.cpu().numpy(), ref) <= RTOL
     c2 = ops.gemm(dev(a), dev(b), ta, tb, bias=dev(bias), scale=dev([0.7]), act='relu')
     assert rel_err(c2.cpu().numpy(), np.maximum(ref, 0)) <= RTOL
+    # backward form: (scale * A B + bias) * lrelu'(y), y holding fewer rows than the output (the 3B-row wrap)
+    if M % 3 == 0 or M >= 64:
+        rows = (2 * M) // 3 if M % 3 == 0 else M
+        y = rs.randn(rows, N).astype(np.float32)
+        full = np.concatenate([y, y[rows - (M - rows):]], 0) if rows < M else y
+        c3 = ops.gemm(dev(a), dev(b), ta, tb, bias=dev(bias), scale=dev([0.7]), act='lrelu', dact_of=dev(y), dact_rows=rows if rows < M else 0)
+        assert rel_err(c3.cpu().numpy(), ref * np.where(full > 0, 1.0, 0.1)) <= RTOL
 
 
 def test_colsum_dot_layout(ops):
