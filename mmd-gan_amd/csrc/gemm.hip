@@ -3,6 +3,8 @@
 // (G l1: [B,128]x[128,8192]; D l8: [2B,8192]x[8192,16]) - under 0.1 % of the step's FLOPs and
 // bound by streaming the weight matrix once, so this is an LDS-tiled fp32 VALU kernel with
 // split-K for the K >> M*N shapes rather than an MFMA kernel.
+// (Round 4, measured and not kept: a variant for the short reductions - G l1's [B,128] x [128,8192] and its weight gradient -
+// that fetches a workgroup's whole K extent at once instead of walking 16-deep steps: the CIFAR step 1.907 vs 1.896 ms.)
 //   C[M,N] = act(scale * op(A) op(B) + bias)           (or * act'(dact_of) in backward form)
 #include <stdint.h>
 
@@ -107,69 +109,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 }
 
-// Short reductions (K <= 128: the generator's first layer, z [B,128] x W [128,8192], layer_func.py:909-911, and its weight
-// gradient z^T dz with K = B) are launch-to-launch latency, not work: 134 MFLOP on 4 MB of weights.  The tiled kernel above
-// walks K in 16-deep steps, each step's loads one HBM round trip behind the previous one's (21 us for G l1 at batch 64).
-// Here a workgroup fetches its WHOLE K extent of both operands at once - every load of the launch is in flight together -
-// parks it in LDS behind one barrier and multiplies.  Same tiles, same epilogue, same sums in the same order.
-__global__ __launch_bounds__(256) void gemm_shortk_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) float sk_smem[];
-    float (*As)[GT + 4] = reinterpret_cast<float (*)[GT + 4]>(sk_smem);
-    float (*Bs)[GT + 4] = reinterpret_cast<float (*)[GT + 4]>(sk_smem + (size_t)g.K * (GT + 4));
-    const int tid = threadIdx.x;
-    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
-    const int tm = (tid >> 4) * 4, tn = (tid & 15) * 4;
-    const int per = (g.K * GT + 255) / 256;                // elements of each operand per thread (K <= 128: <= 32)
-    for (int e = 0; e < per; ++e) {
-        const int idx = tid + e * 256;
-        if (idx >= g.K * GT) break;
-        {
-            int m, k;
-            if (g.transA) { m = idx & 63; k = idx >> 6; } else { k = idx % g.K; m = idx / g.K; }
-            const int gm = m0 + m;
-            As[k][m] = gm < g.M ? (g.transA ? g.A[(size_t)k * g.lda + gm] : g.A[(size_t)gm * g.lda + k]) : 0.f;
-        }
-        {
-            int n, k;
-            if (g.transB) { k = idx % g.K; n = idx / g.K; } else { n = idx & 63; k = idx >> 6; }
-            const int gn = n0 + n;
-            Bs[k][n] = gn < g.N ? (g.transB ? g.B[(size_t)gn * g.ldb + k] : g.B[(size_t)k * g.ldb + gn]) : 0.f;
-        }
-    }
-    __syncthreads();
-    float acc[4][4] = {};
-    for (int k = 0; k < g.K; ++k) {
-        const float4 a = *reinterpret_cast<const float4 *>(&As[k][tm]);
-        const float4 b = *reinterpret_cast<const float4 *>(&Bs[k][tn]);
-        const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
-    }
-    const float sc = g.scale ? g.scale[0] : 1.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int gm = m0 + tm + i;
-        if (gm >= g.M) continue;
-        const int gn = n0 + tn;
-        const size_t o = (size_t)gm * g.ldc + gn;
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v[j] = acc[i][j] * sc;
-            if (gn + j < g.N) {
-                if (g.bias) v[j] += g.bias[gn + j];
-                v[j] = g.dact ? v[j] * act_bwd_from_out(g.dact[o + j >= (size_t)g.wrap_from ? o + j - g.wrap_sub : o + j], g.act) : act_fwd(v[j], g.act);
-            }
-        }
-        if (gn + 3 < g.N && (g.ldc & 3) == 0 && ((uintptr_t)g.C & 15) == 0) *reinterpret_cast<float4 *>(g.C + o) = make_float4(v[0], v[1], v[2], v[3]);
-        else
-            for (int j = 0; j < 4; ++j)
-                if (gn + j < g.N) g.C[o + j] = v[j];
-    }
-}
-
 // The discriminator's head (D l8: [2B, 8192] x [8192, 16], layer_func.py:909-911) is a skinny-N product on the step's critical
 // path between D's forward and backward passes: the tiled kernel above spends 23 us on it (a 64-wide N tile for 16 columns,
 // 262 k atomics).  Here: v_mfma_f32_16x16x4_f32, one wave = 16 rows x 16 columns x a slice of K; a lane loads 16 bytes of its
@@ -259,21 +198,6 @@ extern "C" int mmdgan_gemm(int transA, int transB, int M, int N, int K, const fl
     }
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.transA = transA; g.transB = transB; g.act = act;
     const int tiles = ((M + GT - 1) / GT) * ((N + GT - 1) / GT);
-    {
-        static int shortk = -1;              // MMDGAN_GEMM_SHORTK=0: the tiled kernel for these too (A/B)
-        if (shortk < 0) { const char *e = getenv("MMDGAN_GEMM_SHORTK"); shortk = (e && e[0] == '0') ? 0 : 1; }
-        if (shortk && K <= 128 && tiles >= 16) {
-            g.ksplit = 1; g.kchunk = K;
-            const size_t lds = sizeof(float) * 2 * (size_t)K * (GT + 4);
-            static bool cap_raised = false;
-            if (!cap_raised) {
-                (void)hipFuncSetAttribute((const void *)gemm_shortk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * 2 * 128 * (GT + 4)));
-                cap_raised = true;
-            }
-            hipLaunchKernelGGL(gemm_shortk_kernel, dim3((N + GT - 1) / GT, (M + GT - 1) / GT), dim3(256), lds, st, g);
-            return check_launch("gemm");
-        }
-    }
     int ksplit = 1;
     if (act == MMDGAN_ACT_LINEAR && !dact_of && tiles < 128 && K >= 512 && ldc == N &&
         (!outputs_prezeroed() || out_zeroed)) {

@@ -747,7 +747,7 @@ def test_dact_batch_wrap(ops):
                                          (128, 16, 8192 + 128, False, False), (120, 16, 8192, False, False),
                                          (128, 8192, 128, False, False), (32, 1024, 64, False, False), (96, 2048, 256, False, False),
                                          (64, 4160, 100, False, False),
-                                         # the whole-K-at-once kernel of the short reductions (K <= 128), every operand form, ragged edges
+                                         # short reductions (K <= 128), every operand form, ragged edges
                                          (70, 1000, 100, True, True), (64, 8192, 128, False, True), (130, 1090, 128, True, False),
                                          (64, 2049, 7, False, False)])
 def test_gemm(ops, M, N, K, ta, tb):

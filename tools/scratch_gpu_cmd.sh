@@ -1,5 +1,4 @@
 mkdir -p gpurun_out
-python tools/record_production_kernels.py > gpurun_out/record.log 2>&1; cp gpurun_out/production_kernels.json tests/golden/
-(time python -m pytest tests -m gpu -q --durations=8) > gpurun_out/pytest_gpu.log 2>&1; tail -25 gpurun_out/pytest_gpu.log
-python bench.py > gpurun_out/bench_b.json 2> gpurun_out/bench_b.err; python -c "
-import json; d=json.load(open('gpurun_out/bench_b.json')); print(d['ms_per_step'], d['value'], d['config']['launch_mode'], d['config']['kernel_set'], d['roofline']['frac'], d['cpu_baseline']['thread_sweep'])"
+python -m pytest tests/test_ops_gpu.py -q -m gpu -k "gemm" 2>&1 | tail -4
+python -m pytest tests/test_step_gpu.py -q -m gpu -k "golden or warm_start or shipped" -x 2>&1 | tail -4
+python tools/ab_env.py MMDGAN_GEMM_SHORTK=0 base 2>&1 | tee gpurun_out/ab_shortk.txt

@@ -23,9 +23,16 @@ ends = []
 for a, b in zip(loss[:-1], loss[1:]):
     cand = [i for i in adams if a < i < b]
     ends.append(max(cand, key=lambda i: rows[i]['e']))
-lo, hi = ends[-2], ends[-1]                  # the last complete step: after the Adam of step n-1 up to the Adam of step n
-t_lo = rows[lo]['e']
-step = [r for r in rows if r['s'] >= t_lo and r['e'] <= rows[hi]['e'] and r is not rows[lo]]
+# the last complete ORDINARY step: after the Adam of step n-1 up to the Adam of step n.  (bench.py's untimed extras at the end
+# of a run - the dominant-kernel probe's launches, the loss check - fall between two steps too: a candidate must have the
+# launch count most steps have)
+def between(lo, hi):
+    t_lo = rows[lo]['e']
+    return [r for r in rows if r['s'] >= t_lo and r['e'] <= rows[hi]['e'] and r is not rows[lo]]
+cands = [(lo, hi, len(between(lo, hi))) for lo, hi in zip(ends[:-1], ends[1:])]
+usual = collections.Counter(c[2] for c in cands).most_common(1)[0][0]
+lo, hi = [(a, b) for a, b, n in cands if n == usual][-1]
+step = between(lo, hi)
 t0 = min(r['s'] for r in step)
 span = (rows[hi]['e'] - t0) / 1e3
 busy = sum(r['e'] - r['s'] for r in step) / 1e3
