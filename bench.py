@@ -481,6 +481,11 @@ def main():
             gate_failed = not (rel_err['pass'] and post['pass'])
         if world == 1 and hasattr(eng, 'plan_kernels'):
             out['config']['kernel_set'] = kernel_set_check(eng, args.config, args.loss, B)
+        # the switches this line was measured under: the library's kernel selection (csrc/tuning.h) and the host side's schedule
+        # (mmdgan_hip/settings.py) - only what is OFF its default; both empty = the configuration the parity tests pin
+        from mmdgan_hip import ops as _ops, settings as _settings
+        out['config']['switches'] = {'library': {k: v for k, (v, dflt) in _ops.tuning().items() if not dflt},
+                                     'host': _settings.describe(), 'unknown': _settings.unknown()}
         print(json.dumps(out))
         if world == 1 and not args.no_cpu_baseline and gate_failed:
             sys.exit('bench.py: mmd_loss_rel_err is above its bar (see the JSON line): %r' % (rel_err,))

@@ -67,6 +67,11 @@ extern "C" {
 
 const char *mmdgan_last_error(void);
 int mmdgan_version(void);
+/* Which kernel a convolution call takes is decided by the geometry and by a handful of process-wide switches (environment
+ * variables MMDGAN_*, read once: csrc/tuning.h lists them with their defaults - the defaults are the configuration the
+ * bench runs and tests/test_production_gpu.py pins).  This writes "name=value ..." of all of them, a '*' behind every value
+ * that is off its default, so a log can state the selection it ran under.  Returns the size a full listing needs. */
+long mmdgan_tuning_describe(char *buf, size_t cap);
 /* 1 if a gfx950 device is visible to this process, 0 otherwise (never an error) */
 int mmdgan_device_ok(void);
 /* ------------------------------------------------------------------------------------------------

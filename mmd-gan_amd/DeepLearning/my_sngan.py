@@ -59,10 +59,9 @@ class SNGan(object):
                                     batch_size=batch_size, seed=seed, dist_group=self.dist_group,
                                     sn_mode=FLAGS.SPECTRAL_NORM_MODE,                # layer_func.py:802-814
                                     weight_init=FLAGS.WEIGHT_INITIALIZER,           # layer_func.py:27-64
-                                    # eager issue measured faster than replaying the 3-branch hipGraph when the
-                                    # host keeps up (2.35 vs 2.69 ms/step, bench.py tries both); MMDGAN_HIP_GRAPH=1
-                                    # for hosts that do not
-                                    use_graph=self.dist_group is None and os.environ.get('MMDGAN_HIP_GRAPH') == '1')
+                                    # (how a step reaches the GPU - eager issue, one hipGraph, the library's launch
+                                    # plan - is the engine's `launch_mode`; MMDGAN_LAUNCH_MODE, mmdgan_hip/settings.py)
+                                    )
             if self.dist_group is not None:
                 # data-parallel replicas must start from the same variables, Adam moments, SN vectors and BN statistics
                 from mmdgan_hip import dist as mdist

@@ -17,17 +17,9 @@ int validate(const mmdgan_conv_geom *g, const char *what) {
     return MMDGAN_OK;
 }
 // MMDGAN_FORCE_DIRECT=1 routes everything to the direct kernels (A/B debugging aid)
-bool force_direct() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("MMDGAN_FORCE_DIRECT"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1;
-}
+bool force_direct() { return tuning().force_direct != 0; }
 // MMDGAN_THIN_VALU=1 keeps the thin first/last layers on the VALU kernels (A/B against the MFMA ones)
-bool force_valu_thin() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("MMDGAN_THIN_VALU"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1;
-}
+bool force_valu_thin() { return tuning().thin_valu != 0; }
 inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }    // also true for nullptr
 thread_local bool t_addend_applied = false;
 }  // namespace

@@ -609,32 +609,20 @@ bool igemm_fwd_ok(const ConvDims &d) { return d.C % BK == 0 && d.K % 64 == 0 && 
 bool igemm_dgrad_ok(const ConvDims &d) { return d.K % BK == 0 && d.C % 64 == 0 && d.R % d.stride == 0 && d.R / d.stride <= 5; }
 bool igemm_wgrad_ok(const ConvDims &d) { return d.C % 64 == 0 && d.K % 64 == 0; }
 
-static int forced_tile() {       // MMDGAN_TILE=0|1|2 forces 128x128 | 128x64 | 64x64 where legal (tuning aid)
-    static int v = -2;
-    if (v == -2) { const char *e = getenv("MMDGAN_TILE"); v = e ? atoi(e) : -1; }
-    return v;
-}
-
 static void pick_tile(long M, int N, int &bm, int &bn) {
-    const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
-    const int f = forced_tile();
-    if (f >= 0 && f <= 2 && N % cand[f][1] == 0) { bm = cand[f][0]; bn = cand[f][1]; return; }
-    // measured on every layer shape of the step (tools/bench_conv.py with MMDGAN_TILE=0|1|2): the 64x64
+    // measured on every layer shape of the step (round 1, each tile forced in turn): the 64x64
     // tile at 4 workgroups per CU beats 128x64 / 128x128 at 1-2 per CU by 3-12 % whenever it gives no
     // more than a few rounds of workgroups - four independent barrier domains per CU hide each other's
     // stalls better than one large tile reuses LDS traffic.  Larger tiles only for very large grids.
     const long t64 = ((M + 63) / 64) * (N / 64);
-    if (t64 <= 16 * 1024 || N % 128) { bm = 64; bn = 64; (void)cand; return; }
+    if (t64 <= 16 * 1024 || N % 128) { bm = 64; bn = 64; return; }
     if (t64 <= 64 * 1024) { bm = 128; bn = 64; return; }
     bm = 128; bn = 128;
 }
 
 static int pick_split(long tiles, int nstages, bool allowed) {
-    static int forced = -2;                      // MMDGAN_FWD_SPLIT=n forces the reduction split of forward / input-gradient launches (tuning aid)
-    if (forced == -2) { const char *e = getenv("MMDGAN_FWD_SPLIT"); forced = e ? atoi(e) : -1; }
     if (!allowed || tiles >= kTargetBlocks / 2) return 1;
     int s = (int)(kTargetBlocks / tiles);
-    if (forced > 0) s = forced;
     const int maxs = nstages / 4;                // keep >= 4 stages (128 deep) per split
     if (s > maxs) s = maxs;
     return s < 1 ? 1 : s;
@@ -722,11 +710,6 @@ int igemm_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, f
             if (sp > 1) eff *= 0.98 - 0.004 * sp;          // atomics + zeroing are not free
             if (eff > best + 1e-9) { best = eff; split = sp; }
         }
-    }
-    {
-        static int forced = -2;              // MMDGAN_WGRAD_SPLIT=n forces the pixel-reduction split (tuning aid)
-        if (forced == -2) { const char *e = getenv("MMDGAN_WGRAD_SPLIT"); forced = e ? atoi(e) : -1; }
-        if (forced > 0) split = forced;
     }
     int sps = (nstages + split - 1) / split;
     split = (nstages + sps - 1) / sps;

@@ -1,6 +1,7 @@
 // internal declarations shared by the convolution translation units
 #pragma once
 #include "common.h"
+#include "tuning.h"
 
 namespace mmdgan {
 
@@ -55,11 +56,7 @@ int thin_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, hi
 // finds every CU held by a 60 us workgroup waits for it; with an eighth of the CUs left over the step is no slower where it
 // does not matter and a little faster where it does (CIFAR 256 / 224 / 192 / 160 / 128: 1.923 / 1.914 / 1.912 / 1.950 /
 // 1.931 ms; CelebA 13.57 / 13.55 / 13.57 / 13.94 / 13.81).  MMDGAN_WGRAD_CUS.
-inline int wgrad_cus() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("MMDGAN_WGRAD_CUS"); v = e && atoi(e) > 0 ? atoi(e) : 224; }
-    return v;
-}
+inline int wgrad_cus() { return tuning().wgrad_cus; }
 int thin_wgrad_reduce(const float *partials, int nblocks, long nout, float *dw, hipStream_t st, const float *wdot = nullptr,
                       float *dot = nullptr);   // dot (zero on entry) += <dw, wdot>
 

@@ -368,9 +368,7 @@ static void launch_n2w(const ConvDims &d, const ConvEpilogue &ep, const float *i
     const long M = (long)d.N * d.H * d.W;
     const int ntiles = (int)((M + 31) / 32);
     int blocks = (ntiles + 3) / 4;
-    static int cap = -1;                 // MMDGAN_N2W_BLOCKS: tuning aid
-    if (cap < 0) { const char *e = getenv("MMDGAN_N2W_BLOCKS"); cap = e ? atoi(e) : 512; }
-    if (blocks > cap) blocks = cap;
+    if (blocks > 512) blocks = 512;      // two workgroups per CU, each wave walks its tiles (768 / 1024: measured the same)
     const PatchTab tab = make_patch_tab<FLIP>(d, FLIP ? d.K : d.C);
     if (wide == 32) hipLaunchKernelGGL((thinm_n2w_kernel<FLIP, 1>), dim3(blocks), dim3(256), 0, st, d, ep, in, w, out, ntiles, tab);
     else if (wide == 64) hipLaunchKernelGGL((thinm_n2w_kernel<FLIP, 2>), dim3(blocks), dim3(256), 0, st, d, ep, in, w, out, ntiles, tab);

@@ -280,11 +280,7 @@ int epilogue_pass(float *y, long total, int Ko, const ConvEpilogue &ep, hipStrea
 }
 
 // ------------------------------------------------------------------------------------------------
-static bool wino_enabled() {       // MMDGAN_WINO=0 keeps the 3x3 layers on the direct implicit-GEMM kernels
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("MMDGAN_WINO"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v == 1;
-}
+static bool wino_enabled() { return tuning().wino != 0; }      // MMDGAN_WINO=0: the 3x3 layers on the implicit-GEMM kernels
 
 // below ~512 tiles the grid no longer fills the chip and the direct kernel wins (measured: D l7 forward at batch
 // 128 = 512 tiles: 68 us with 32-channel column blocks vs 92 direct; 768 tiles: 98 vs 160 us).  Splitting the
@@ -296,8 +292,7 @@ static bool wino_enabled() {       // MMDGAN_WINO=0 keeps the 3x3 layers on the 
 // (wino_launch) and fills the chip whatever its tile count, so the line for THAT form is 128 tiles: the 512 -> 512 block of the
 // ResNet-SN discriminator at 4x4 (384 tiles at 3B rows) 118 -> ~45 us per input-gradient, the ResNet step 4.92 -> 4.81 ms.
 static long wino_min_tiles(bool caller_transformed = false) {
-    static long v = -2;
-    if (v == -2) { const char *e = getenv("MMDGAN_WINO_MIN_TILES"); v = e ? atol(e) : -1; }
+    const long v = tuning().wino_min_tiles;
     return v >= 0 ? v : (caller_transformed ? 128 : 512);
 }
 
@@ -342,8 +337,7 @@ static int wino_launch(const ConvDims &d, const ConvEpilogue &ep, const float *i
     // 52.4 us, its 3B-row input-gradient (192) 87.8 -> 75.7; ms per CIFAR / STL step with the split applied to grids below
     // 0 / 129 / 193 / 257 / 385 workgroups: 2.045 / 2.014 / 1.999 / 1.999 / 1.974 and 3.909 / 3.915 / 3.902 / 3.912 / 3.887
     // (here the 384-workgroup launch, D l5's 3B-row input-gradient, gains too - the 4x4 kernel's did not).
-    static long below = -1;
-    if (below < 0) { const char *e = getenv("MMDGAN_WINO_KSPLIT_BELOW"); below = e ? atol(e) : 385; }
+    const long below = tuning().wino_ksplit_below;
     int split = 1;
     if (own_u && d.N > 1 && wgs < below)
         while (split < 8 && wgs * split < 512 && nstages % (2 * split) == 0 && nstages / (2 * split) >= 8) split *= 2;
@@ -798,15 +792,11 @@ __global__ __launch_bounds__(winos::NT) void wino_wgrad_slab_kernel(int N, int H
 }
 
 bool wino_wgrad_slab_ok(const ConvDims &d) {
-    static int en = -1;
-    if (en < 0) { const char *e = getenv("MMDGAN_WINO_WGRAD_SLAB"); en = (e && e[0] == '0') ? 0 : 1; }
-    return en && d.C % winos::BC == 0 && d.K % winos::BK == 0;
+    return tuning().wino_wgrad_slab && d.C % winos::BC == 0 && d.K % winos::BK == 0;
 }
 
 bool wino_wgrad_ok(const ConvDims &d) {
-    static int en = -1;
-    if (en < 0) { const char *e = getenv("MMDGAN_WINO_WGRAD"); en = (e && e[0] == '0') ? 0 : 1; }
-    return en && d.N > 1 && wino_enabled() && d.R == 3 && d.stride == 1 && d.pad == 1 && d.H % 2 == 0 && d.W % 2 == 0 && d.C % 32 == 0 &&
+    return tuning().wino_wgrad && d.N > 1 && wino_enabled() && d.R == 3 && d.stride == 1 && d.pad == 1 && d.H % 2 == 0 && d.W % 2 == 0 && d.C % 32 == 0 &&
            d.K % 64 == 0 && (long)d.N * (d.H / 2) * (d.W / 2) >= (wino_min_tiles() < 256 ? wino_min_tiles() : 256);   // 79 vs 89 us at 512 tiles (D l7)
 }
 

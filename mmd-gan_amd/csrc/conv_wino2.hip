@@ -21,9 +21,6 @@
 #include "bufload.h"
 #include "wino_weight.h"
 
-#ifndef W2W_DEFAULT
-#define W2W_DEFAULT 1
-#endif
 
 namespace mmdgan {
 
@@ -430,19 +427,11 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
 // 100 vs 120 (768); D l6 3B dgrad 109 vs 113 (384); it loses below that (D l6 forward, 128 workgroups: 128 vs 84;
 // G's top layers at batch 64).  Default (MMDGAN_WINO2=1): forward with >= 256 workgroups, input-gradient with
 // >= 384; =0 never; =2 every eligible shape (what the parity tests run).
-static int wino2_mode() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("MMDGAN_WINO2"); v = e ? atoi(e) : 1; }
-    return v;
-}
+static int wino2_mode() { return tuning().wino2; }
 
 // d describes the CONV (4x4, stride 2, pad 1): x [N,H,W,C] -> y [N,P,Q,K]
 static int wino2_ksplit(long base_items, int nstages);
-static bool wino2_split_enabled() {            // MMDGAN_WINO2_KSPLIT=0: no reduction split (A/B)
-    static int en = -1;
-    if (en < 0) { const char *e = getenv("MMDGAN_WINO2_KSPLIT"); en = e ? atoi(e) : 1; }
-    return en != 0;
-}
+static bool wino2_split_enabled() { return tuning().wino2_ksplit != 0; }       // MMDGAN_WINO2_KSPLIT=0: no reduction split
 static bool wino2_shape_ok(const ConvDims &d, bool dgrad, bool split_ok = false) {
     const int mode = wino2_mode();
     if (mode == 0 || d.R != 4 || d.stride != 2 || d.pad != 1 || d.H % 4 || d.W % 4) return false;
@@ -515,9 +504,7 @@ int slab_epilogue(const float *slabs, int nslabs, long total, int Ko, const Conv
 // split gains: ms per CIFAR / STL step with the split applied below 0 / 129 / 257 / 385 / 512 items:
 // 2.061 / 2.057 / 2.034 / 2.071 / 2.084 and 4.027 / 4.050 / 3.969 / 3.932 / 3.939 (STL's 288-item launches sit in between).
 static int wino2_ksplit(long base_items, int nstages) {
-    static long below = -1;
-    if (below < 0) { const char *e = getenv("MMDGAN_WINO2_KSPLIT_BELOW"); below = e ? atol(e) : 384; }
-    if (base_items >= below) return 1;
+    if (base_items >= tuning().wino2_ksplit_below) return 1;
     int k = 1;
     while (k < 8 && base_items * k < 512 && nstages % (2 * k) == 0 && nstages / (2 * k) >= 4) k *= 2;
     return k;
@@ -556,9 +543,7 @@ static int wino2_launch(const ConvDims &d, const ConvEpilogue &ep, const float *
     if (P.ksplit > 1 && (size_t)P.ksplit * out_bytes < (1ul << 31)) slabs = (float *)workspace_acquire((size_t)P.ksplit * out_bytes, st);
     if (!slabs) P.ksplit = 1;
     P.spp = nstages / P.ksplit;
-    static int contig = -1;
-    if (contig < 0) { const char *e = getenv("MMDGAN_WINO2_CONTIGUOUS"); contig = e ? atoi(e) : 0; }
-    P.contiguous = contig;
+    P.contiguous = 0;                                   // (contiguous runs per workgroup re-fetch a tile block's patches: 1.55x the bytes)
     P.slab_bytes = (unsigned)out_bytes;
     const long nitems = (long)P.ntb * P.nkb * P.nph * P.ksplit;
     static int ncu = 0;
@@ -856,10 +841,8 @@ void slab_reduce(const float *part, int nsplit, size_t n, float *dw, const float
     long blocks = (n4 + k4 + 255) / 256;
     // at most 512 workgroups: this pass runs on the weight-gradient stream beside the main stream's launches, and more of its
     // small workgroups cost those launches more than they save here (CIFAR step, cap 2048 / 1024 / 512 / 256 / 128: 1.931 / 1.919 /
-    // 1.910 / 1.922 / 1.966 ms; CelebA flat down to 512); MMDGAN_SLAB_REDUCE_BLOCKS
-    static long cap = -1;
-    if (cap < 0) { const char *e = getenv("MMDGAN_SLAB_REDUCE_BLOCKS"); cap = e && atol(e) > 0 ? atol(e) : 512; }
-    if (blocks > cap) blocks = cap;
+    // 1.910 / 1.922 / 1.966 ms; CelebA flat down to 512)
+    if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float4 *)part, nsplit, n4, (float4 *)dw,
                        (const float4 *)dbpart, k4, (float4 *)dbias, (const float4 *)wdot, dot);
 }
@@ -867,15 +850,13 @@ void slab_reduce(const float *part, int nsplit, size_t n, float *dw, const float
 // MMDGAN_WINO2_WGRAD=0 keeps the stride-2 weight gradients on the direct implicit-GEMM kernel, =1 uses this one;
 // MMDGAN_WINO2=2 (the parity tests) always.
 bool wino2_wgrad_ok(const ConvDims &d) {
-    static int en = -1;
-    if (en < 0) { const char *e = getenv("MMDGAN_WINO2_WGRAD"); en = e ? atoi(e) : W2W_DEFAULT; }
+    const int en = tuning().wino2_wgrad;
     if ((!en && wino2_mode() < 2) || wino2_mode() == 0) return false;
     if (d.N == 1) return false;     // batch-1 = a power iteration's launch, on a chain concurrent with others: no workspace slabs
     // the batch-1 weight gradients of the power iteration (64 tiles) stay direct: 7.7 us against 7 + the 6 us reduction pass
     // (64-255 tiles with enough channel blocks for a full round of workgroups - the ResNet generator's first up-sampling
     // block, 512 x 1024 channels at 128 tiles - run here as well; MMDGAN_WINO2_WGRAD_MIN_TILES)
-    static long min_tiles = -1;
-    if (min_tiles < 0) { const char *e = getenv("MMDGAN_WINO2_WGRAD_MIN_TILES"); min_tiles = e ? atol(e) : 256; }
+    const long min_tiles = tuning().wino2_wgrad_min_tiles;
     const long tiles = (long)d.N * (d.P / 2) * (d.Q / 2), blocks = (long)(d.C / wino2w::BC) * (d.K / wino2w::BK) * 4;
     if (wino2_mode() < 2 && tiles < min_tiles && !(tiles >= 64 && blocks >= 192 && min_tiles <= 256)) return false;
     return d.R == 4 && d.stride == 2 && d.pad == 1 && d.H % 4 == 0 && d.W % 4 == 0 && d.C % wino2w::BC == 0 && d.K % wino2w::BK == 0;

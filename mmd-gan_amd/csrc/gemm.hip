@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #include "common.h"
+#include "tuning.h"
 
 namespace mmdgan {
 
@@ -181,9 +182,7 @@ extern "C" int mmdgan_gemm(int transA, int transB, int M, int N, int K, const fl
     }
     if (!transA && !transB && N == 16 && M % 16 == 0 && K % 256 == 0 && K >= 1024 && act == MMDGAN_ACT_LINEAR && !dact_of &&
         lda % 4 == 0 && ((uintptr_t)A & 15) == 0 && ldc == N && (!outputs_prezeroed() || out_zeroed)) {
-        static int en = -1;
-        if (en < 0) { const char *e = getenv("MMDGAN_GEMM_SKINNY"); en = (e && e[0] == '0') ? 0 : 1; }
-        if (en) {
+        if (tuning().gemm_skinny) {
             // ~512 waves: K split so that every wave keeps >= 64 of K (4 blocks of loads in flight)
             int ksplit = 128 / (M / 16);
             if (ksplit < 1) ksplit = 1;
@@ -202,9 +201,6 @@ extern "C" int mmdgan_gemm(int transA, int transB, int M, int N, int K, const fl
     if (act == MMDGAN_ACT_LINEAR && !dact_of && tiles < 128 && K >= 512 && ldc == N &&
         (!outputs_prezeroed() || out_zeroed)) {
         ksplit = 512 / tiles;
-        static int cap = -1;                   // MMDGAN_GEMM_KSPLIT: upper bound of the K split (tuning aid)
-        if (cap < 0) { const char *e = getenv("MMDGAN_GEMM_KSPLIT"); cap = e ? atoi(e) : 0; }
-        if (cap > 0 && ksplit > cap) ksplit = cap;
         const int maxs = K / 64;
         if (ksplit > maxs) ksplit = maxs;
         if (ksplit < 1) ksplit = 1;

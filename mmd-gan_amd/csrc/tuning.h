@@ -1,0 +1,60 @@
+// Every switch that changes WHICH KERNEL (or which split of it) a library call takes, in ONE place: read from the
+// environment once per process, listed with its default, and reportable (mmdgan_tuning_describe) - so a test log or a
+// bench line can say under which selection it ran instead of that being hidden process state.  The reference has no
+// counterpart (one fixed TF graph, graph_func.py:851-854); the defaults below ARE the build's fixed graph, and
+// tests/test_production_gpu.py + tests/golden/production_kernels.json pin the kernels they select.
+// Anything that was an experiment's A/B lever and lost (tile forcing, split forcing, block caps, event flags, contiguous
+// item runs, ...) is gone: its measurement is in DESIGN.md, not in the library's surface.
+#pragma once
+#include <stdlib.h>
+
+namespace mmdgan {
+
+struct Tuning {
+    int force_direct;            // MMDGAN_FORCE_DIRECT=1        every conv on the generic direct kernels (debugging reference)
+    int thin_valu;               // MMDGAN_THIN_VALU=1           thin first / last layers on the VALU kernels, not the MFMA ones
+    int wino;                    // MMDGAN_WINO=0                no F(2x2,3x3) kernels (3x3 layers on the implicit GEMM)
+    long wino_min_tiles;         // MMDGAN_WINO_MIN_TILES=n      F(2x2,3x3) from n tiles on (default -1: 512, or 128 with caller-transformed weights)
+    long wino_ksplit_below;      // MMDGAN_WINO_KSPLIT_BELOW=n   its reduction split over workspace slabs for grids below n workgroups (385)
+    int wino_wgrad;              // MMDGAN_WINO_WGRAD=0          3x3 weight gradients on the implicit GEMM
+    int wino_wgrad_slab;         // MMDGAN_WINO_WGRAD_SLAB=0     ... on the atomics form of the Winograd-domain kernel, not the slab form
+    int wino2;                   // MMDGAN_WINO2=0|1|2           F(2x2,2x2) for 4x4 stride-2: never | from 256 / 384 workgroups (default) | every eligible shape
+    int wino2_ksplit;            // MMDGAN_WINO2_KSPLIT=0        no reduction split of its small launches
+    long wino2_ksplit_below;     // MMDGAN_WINO2_KSPLIT_BELOW=n  split grids below n work items (384)
+    int wino2_wgrad;             // MMDGAN_WINO2_WGRAD=0         4x4 stride-2 weight gradients on the implicit GEMM
+    long wino2_wgrad_min_tiles;  // MMDGAN_WINO2_WGRAD_MIN_TILES=n   ... from n tiles on (256)
+    int wgrad_cus;               // MMDGAN_WGRAD_CUS=n           workgroups (= CUs) the one-round weight-gradient kernels size their grid for (224)
+    int gemm_skinny;             // MMDGAN_GEMM_SKINNY=0         D's head product on the tiled kernel, not the skinny-N MFMA one
+};
+
+inline const Tuning &tuning_defaults() {
+    static const Tuning d = {0, 0, 1, -1, 385, 1, 1, 1, 1, 384, 1, 256, 224, 1};
+    return d;
+}
+
+inline const Tuning &tuning() {
+    static const Tuning t = [] {
+        Tuning v = tuning_defaults();
+        auto geti = [](const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; };
+        auto getl = [](const char *name, long dflt) { const char *e = getenv(name); return e && *e ? atol(e) : dflt; };
+        v.force_direct = geti("MMDGAN_FORCE_DIRECT", v.force_direct) == 1;
+        v.thin_valu = geti("MMDGAN_THIN_VALU", v.thin_valu) == 1;
+        v.wino = geti("MMDGAN_WINO", v.wino) != 0;
+        v.wino_min_tiles = getl("MMDGAN_WINO_MIN_TILES", v.wino_min_tiles);
+        v.wino_ksplit_below = getl("MMDGAN_WINO_KSPLIT_BELOW", v.wino_ksplit_below);
+        v.wino_wgrad = geti("MMDGAN_WINO_WGRAD", v.wino_wgrad) != 0;
+        v.wino_wgrad_slab = geti("MMDGAN_WINO_WGRAD_SLAB", v.wino_wgrad_slab) != 0;
+        v.wino2 = geti("MMDGAN_WINO2", v.wino2);
+        v.wino2_ksplit = geti("MMDGAN_WINO2_KSPLIT", v.wino2_ksplit) != 0;
+        v.wino2_ksplit_below = getl("MMDGAN_WINO2_KSPLIT_BELOW", v.wino2_ksplit_below);
+        v.wino2_wgrad = geti("MMDGAN_WINO2_WGRAD", v.wino2_wgrad) != 0;
+        v.wino2_wgrad_min_tiles = getl("MMDGAN_WINO2_WGRAD_MIN_TILES", v.wino2_wgrad_min_tiles);
+        const int cus = geti("MMDGAN_WGRAD_CUS", v.wgrad_cus);
+        v.wgrad_cus = cus > 0 ? cus : v.wgrad_cus;
+        v.gemm_skinny = geti("MMDGAN_GEMM_SKINNY", v.gemm_skinny) != 0;
+        return v;
+    }();
+    return t;
+}
+
+}  // namespace mmdgan

@@ -20,6 +20,7 @@ SIGNATURES = {
     'mmdgan_last_error': (ctypes.c_char_p, []),
     'mmdgan_version': (_I, []),
     'mmdgan_device_ok': (_I, []),
+    'mmdgan_tuning_describe': (_L, [ctypes.c_char_p, ctypes.c_size_t]),
     'mmdgan_create': (_I, [ctypes.POINTER(ctypes.c_void_p)]),
     'mmdgan_destroy': (_I, [_P]),
     'mmdgan_make_current': (_I, [_P]),

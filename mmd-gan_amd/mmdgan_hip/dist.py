@@ -133,7 +133,8 @@ def choose_dp_backend(group, device, requested=None):
     import os
     import sys
     from . import ops
-    explicit = requested or os.environ.get('MMDGAN_DP_BACKEND')
+    from . import settings
+    explicit = requested or settings.get('MMDGAN_DP_BACKEND')
     backend = explicit
     if backend is None:
         backend = 'capi' if (group is not None and tdist.get_backend(group) == 'nccl') else 'torch'

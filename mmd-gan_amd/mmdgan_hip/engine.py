@@ -31,7 +31,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from . import initializers, ops
+from . import initializers, ops, settings
 
 # named event slots (mmdgan_event_record / _wait)
 _EV_WINO_GEN = 0                      # G's Winograd weights are ready
@@ -477,7 +477,7 @@ class GanEngine:
         self.score_size = self.dis.specs[-1].out
         self.global_step = 0
         self.dist_group = dist_group
-        self._dp_force = os.environ.get('MMDGAN_DP_FORCE') == '1'
+        self._dp_force = settings.on('MMDGAN_DP_FORCE')
         self.world, self.rank = 1, 0
         if dist_group is not None:
             import torch.distributed as tdist
@@ -504,18 +504,18 @@ class GanEngine:
         # launches (each launch alone leaves CUs idle while its last wave of tiles drains).
         # All of them must sit on hardware queues of their own (streams.py: 2.43 vs 2.55 / 2.89 ms per step)
         from .streams import distinct_queue_streams
-        n_sn = int(os.environ.get('MMDGAN_SN_STREAMS', '2'))
+        n_sn = int(settings.get('MMDGAN_SN_STREAMS'))
         side = distinct_queue_streams(n_sn + 1, self.device)
         self._wg_stream, self._sn_streams = side[0], side[1:]
         self._comm_stream = side[1] if len(side) > 1 else side[0]      # gradient exchange, see _exchange
         self._wg_raw, self._comm_raw = self._wg_stream.cuda_stream, self._comm_stream.cuda_stream
         self._sn_raw = [st.cuda_stream for st in self._sn_streams]
-        self._gen_tail_on_main = int(os.environ.get('MMDGAN_GEN_TAIL_MAIN', '2')) if os.environ.get('MMDGAN_SIDE_WGRAD', '1') != '0' else 0
-        self._early_d_adam = os.environ.get('MMDGAN_EARLY_D_ADAM', '1') != '0'
-        self._side_wgrad = os.environ.get('MMDGAN_SIDE_WGRAD', '1') != '0'
+        self._gen_tail_on_main = int(settings.get('MMDGAN_GEN_TAIL_MAIN')) if settings.on('MMDGAN_SIDE_WGRAD') else 0
+        self._early_d_adam = settings.on('MMDGAN_EARLY_D_ADAM')
+        self._side_wgrad = settings.on('MMDGAN_SIDE_WGRAD')
         # round 4: dependencies that put a marker / barrier packet into the MAIN queue (~6 us of idle queue each) moved off it
         # where another ordering already covers them (MMDGAN_QUEUE_OPT=0: the round-3 placement)
-        self._queue_opt = os.environ.get('MMDGAN_QUEUE_OPT', '1') != '0' and self._side_wgrad
+        self._queue_opt = settings.on('MMDGAN_QUEUE_OPT') and self._side_wgrad
         if ops._workspace is None:
             ops.set_workspace(device=self.device)                        # the default handle's (eval paths, stand-alone ops)
         # this engine's own library state (include/mmdgan_hip.h "Handles"): workspace, prezeroed mode, launch plan
@@ -528,7 +528,7 @@ class GanEngine:
         # (few host microseconds, but its branches overlap less: 2.69 vs 2.35 ms per CIFAR step); 'plan': the library
         # records one eager step and re-issues it from ONE C call (mmdgan_plan_replay) - the eager step's streams and
         # overlap with the graph's host cost.  MMDGAN_LAUNCH_MODE overrides; use_graph=True is the old spelling of 'graph'
-        self.launch_mode = launch_mode or os.environ.get('MMDGAN_LAUNCH_MODE') or ('graph' if use_graph else 'eager')
+        self.launch_mode = launch_mode or settings.get('MMDGAN_LAUNCH_MODE') or ('graph' if use_graph else 'eager')
         assert self.launch_mode in ('eager', 'graph', 'plan'), self.launch_mode
         self._graph, self._plan, self._plan_stream, self._plan_collectives = None, None, None, []
         self._baked_lr = (self.lr_d, self.lr_g)
@@ -558,7 +558,7 @@ class GanEngine:
         last one travel underneath the rest of the backward pass.  Layers are contiguous in the arena (forward order);
         a bucket closes once it holds MMDGAN_DP_BUCKET_MB (default 8) - xGMI rings are latency-bound below a few MB."""
         from .dist import layer_buckets
-        target = int(float(os.environ.get('MMDGAN_DP_BUCKET_MB', '8')) * (1 << 20)) // 4
+        target = int(float(settings.get('MMDGAN_DP_BUCKET_MB')) * (1 << 20)) // 4
         first = {}                                   # layer index -> (start, end) float offsets of its entries
         for name, (o, size, _) in net.arena.offsets.items():
             # (the <G, W> scalars at the head of the arena are complete with layer 0's gradients: they travel with the last bucket)
@@ -652,7 +652,7 @@ class GanEngine:
         self._zeroed_ptrs = {t.data_ptr() for t in self._zero_each_step}
         # the power iterations of a whole net as six launches (csrc/sn_chain.hip) instead of five per kernel;
         # MMDGAN_SN_FUSED=0: one chain of launches per layer, dealt to the power-iteration streams
-        self._sn_fused = os.environ.get('MMDGAN_SN_FUSED', '1') != '0' and len(self._sn_streams) > 0
+        self._sn_fused = settings.on('MMDGAN_SN_FUSED') and len(self._sn_streams) > 0
         self._sn_chains = {}
         if self._sn_fused:
             for net in (self.gen, self.dis):

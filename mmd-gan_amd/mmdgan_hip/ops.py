@@ -88,6 +88,20 @@ class Handle:
             pass
 
 
+def tuning():
+    """the library's kernel-selection switches of this process as {name: (value, is_default)} (mmdgan_tuning_describe)"""
+    from . import _lib
+    lib = _lib.load()                                    # (host logic: needs no device)
+    need = lib.mmdgan_tuning_describe(None, 0)
+    buf = ctypes.create_string_buffer(int(need))
+    lib.mmdgan_tuning_describe(buf, need)
+    out = {}
+    for item in buf.value.decode().split():
+        name, val = item.split('=')
+        out[name] = (int(val.rstrip('*')), not val.endswith('*'))
+    return out
+
+
 def plan_kernels(plan_id):
     """the kernel launches of a recorded plan of the CURRENT handle, in issue order: [(kernel, workgroups, threads, stream
     number)] with the kernel's demangled name cut before its parameter list (mmdgan_plan_describe)"""
@@ -165,8 +179,7 @@ def _p(t):
     return t.data_ptr()
 
 
-import os as _os
-_raw_stream = None if _os.environ.get('MMDGAN_SLOW_STREAM') else getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
 
 def _stream():

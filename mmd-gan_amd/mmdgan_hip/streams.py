@@ -48,12 +48,9 @@ def shares_queue(a, b, ms=0.3):
 
 def distinct_queue_streams(n, device, avoid=(), max_candidates=24):
     """n streams that share a hardware queue neither with the current stream, nor with `avoid`, nor with each other.
-    Falls back to untested streams when the runtime has too few queues (GPU_MAX_HW_QUEUES < n + 1) or when
-    MMDGAN_STREAM_PROBE=0."""
+    Falls back to untested streams when the runtime has too few queues (GPU_MAX_HW_QUEUES < n + 1)."""
     if n <= 0:
         return []
-    if os.environ.get('MMDGAN_STREAM_PROBE', '1') == '0':
-        return [torch.cuda.Stream(device=device) for _ in range(n)]
     with torch.cuda.device(device):
         taken = [torch.cuda.current_stream(device)] + list(avoid)
         chosen, rejected = [], []

@@ -18,7 +18,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from . import initializers, ops
+from . import initializers, ops, settings
 from .engine import _Arena, _chw_perm, _trunc_normal
 
 _TEMPLATE = {'name': None, 'type': 'default', 'op': 'c', 'out': None, 'bias': 'b', 'act': 'linear', 'act_nm': None,
@@ -105,7 +105,7 @@ class _Net:
         self.weight_init = initializers.check_mode(weight_init)          # FLAGS.WEIGHT_INITIALIZER
         # fold a block's 'unpool' x2 / 'avg' /2 into the 3x3 conv next to it (one 4x4 stride-2 launch: 4 taps per pixel
         # instead of 9, no up-sampled tensor in HBM; ResNet-SN config 7.32 -> 6.57 ms per step); MMDGAN_TAPE_COMPOSE=0: two ops
-        self.compose = os.environ.get('MMDGAN_TAPE_COMPOSE', '1') != '0'
+        self.compose = settings.on('MMDGAN_TAPE_COMPOSE')
         self.prims, self.kernels, self.bns = [], [], []
         self._bn_perm = {}                                               # BN prefix -> feature permutation (see _allocate)
         self._nval = 1                                                   # value 0 is the net input
@@ -598,7 +598,7 @@ class TapeEngine:
             import torch.distributed as tdist
             self.world = tdist.get_world_size(dist_group)
             self.rank = tdist.get_rank(dist_group)
-        self._dp_force = os.environ.get('MMDGAN_DP_FORCE') == '1'
+        self._dp_force = settings.on('MMDGAN_DP_FORCE')
         # who carries the gradient exchange (dist.choose_dp_backend, as GanEngine): the library's own RCCL communicator under
         # an nccl group - its collectives are plan nodes, so a data-parallel step replays from one C call - else torch.distributed
         from . import dist as mdist
@@ -616,7 +616,7 @@ class TapeEngine:
         self._handle = ops.Handle(device=self.device)
         # how a step reaches the GPU: 'eager' = library calls from Python, 'plan' = the library records one eager step and
         # re-issues it from ONE C call (engine.py); MMDGAN_LAUNCH_MODE overrides
-        self.launch_mode = launch_mode or os.environ.get('MMDGAN_LAUNCH_MODE') or 'eager'
+        self.launch_mode = launch_mode or settings.get('MMDGAN_LAUNCH_MODE') or 'eager'
         if self.launch_mode == 'graph':
             self.launch_mode = 'plan'                                    # (no hipGraph capture here; the plan is its equal)
         assert self.launch_mode in ('eager', 'plan'), self.launch_mode
@@ -626,12 +626,12 @@ class TapeEngine:
         self._in_step = False                                            # transformed weights are valid inside step() only
         self._sn_zeroed = False                                          # inside step(): the power iteration's targets are zeroed
         self._exchange_pending = False
-        self._fuse_fanin = os.environ.get('MMDGAN_TAPE_FUSE_ADD', '1') != '0'
+        self._fuse_fanin = settings.on('MMDGAN_TAPE_FUSE_ADD')
         self._d_has_bn = bool(self.dis.bns)
         lib = ops.require_device()
         # side streams on hardware queues of their own (streams.py): the power iterations run under G's forward pass,
         # weight / bias gradients beside the input-gradient chain; MMDGAN_TAPE_STREAMS=0 keeps everything on one stream
-        self._side = os.environ.get('MMDGAN_TAPE_STREAMS', '1') != '0'
+        self._side = settings.on('MMDGAN_TAPE_STREAMS')
         if self._side:
             from .streams import distinct_queue_streams
             self._wg_stream, self._sn_stream = distinct_queue_streams(2, self.device)
@@ -640,7 +640,7 @@ class TapeEngine:
         # D without batch norm: its rows are independent, so loss_dis (2B rows) and loss_gen (the fake half again, B rows) go
         # back through it TOGETHER as 3B rows (one launch per primitive instead of two passes) - _backward(extra_rows=B)
         self._d_joint = (not self._d_has_bn and all(p['kind'] in self._ROW_WISE for p in self.dis.prims)
-                         and os.environ.get('MMDGAN_TAPE_JOINT', '1') != '0')
+                         and settings.on('MMDGAN_TAPE_JOINT'))
         # Winograd-eligible convolutions get their weights transformed once per step, off the critical path, instead
         # of inside every call (forward, and up to two input-gradient passes) - which also keeps the library's
         # shared workspace out of every launch of the main stream.  kernel scope -> {(dgrad, batch): tensor}
@@ -708,7 +708,7 @@ class TapeEngine:
         # the power iterations of a whole net as a few launches (csrc/sn_chain.hip: every stage of all chains at once, 8 kernels
         # per group) instead of five per kernel; MMDGAN_SN_FUSED=0 for the per-kernel chains
         self._sn_chains = {}
-        if os.environ.get('MMDGAN_SN_FUSED', '1') != '0':
+        if settings.on('MMDGAN_SN_FUSED'):
             for net in (self.gen, self.dis):
                 layers = [(k, self._sn_chain_layer(net, k)) for k in net.kernels if k.sn]
                 self._sn_chains[id(net)] = (ops.SnChains([L for _, L in layers if L is not None], self.device),
@@ -1008,7 +1008,7 @@ class TapeEngine:
             producer, uses = self._graph_of(net)
             where = {p['out']: i for i, p in enumerate(net.prims)}
             addend, alias = {}, {}
-            if os.environ.get('MMDGAN_TAPE_FUSE_ADD', '1') != '0':
+            if settings.on('MMDGAN_TAPE_FUSE_ADD'):
                 for i, p in enumerate(net.prims):
                     if p['kind'] != 'add' or p['out'] == net.out_val:
                         continue
@@ -1271,7 +1271,7 @@ class TapeEngine:
         order = the reverse of the order the backward pass completes them in).  Every primitive that owns parameters
         learns its item index (p['_item'])."""
         from .dist import layer_buckets
-        target = int(float(os.environ.get('MMDGAN_DP_BUCKET_MB', '8')) * (1 << 20)) // 4
+        target = int(float(settings.get('MMDGAN_DP_BUCKET_MB')) * (1 << 20)) // 4
         ranges = []
         for p in net.prims:
             if p['kind'] in ('dense', 'conv', 'gconv', 'tconv', 'upconv', 'convdown'):

@@ -47,6 +47,31 @@ def test_argument_errors_do_not_need_a_device():
     assert lib.mmdgan_mmd_loss(1, 1, 8, 16, 7, 0.0, -1.0, 0.25, 4.0, 1, None, None, None, 1, None) == -1
 
 
+def test_kernel_selection_switches_are_listed_in_one_place(monkeypatch):
+    """the library reports its kernel-selection switches (csrc/tuning.h) and which of them are off their default; the host
+    side's switches live in mmdgan_hip/settings.py.  tests/conftest.py sets two of the library's for this process."""
+    from mmdgan_hip import ops, settings
+    t = ops.tuning()
+    assert set(t) == {'force_direct', 'thin_valu', 'wino', 'wino_min_tiles', 'wino_ksplit_below', 'wino_wgrad', 'wino_wgrad_slab',
+                      'wino2', 'wino2_ksplit', 'wino2_ksplit_below', 'wino2_wgrad', 'wino2_wgrad_min_tiles', 'wgrad_cus', 'gemm_skinny'}
+    assert t['wino_min_tiles'] == (32, False) and t['wino2'] == (2, False)          # conftest's thresholds
+    assert t['wgrad_cus'] == (224, True) and t['wino'] == (1, True)
+    assert settings.describe() == {} or all(k.startswith('MMDGAN_') for k in settings.describe())
+    monkeypatch.setenv('MMDGAN_SN_STREAMS', '1')
+    monkeypatch.setenv('MMDGAN_NO_SUCH_SWITCH', '1')
+    assert settings.describe().get('MMDGAN_SN_STREAMS') == '1' and settings.get('MMDGAN_SN_STREAMS') == '1'
+    assert 'MMDGAN_NO_SUCH_SWITCH' in settings.unknown() and 'MMDGAN_WINO2' not in settings.unknown()
+    # no other place reads the environment for a switch: the sources hold no getenv / os.environ beside these two files
+    import glob
+    root = os.path.join(os.path.dirname(__file__), '..', 'mmd-gan_amd')
+    for path in glob.glob(os.path.join(root, 'csrc', '*')):
+        if not path.endswith('tuning.h'):
+            assert 'getenv(' not in open(path).read(), path
+    for path in glob.glob(os.path.join(root, 'mmdgan_hip', '*.py')) + glob.glob(os.path.join(root, '*', '*.py')):
+        if not path.endswith(('settings.py', 'dist.py', '_lib.py')):
+            assert "environ.get('MMDGAN_" not in open(path).read(), path
+
+
 def test_handles_and_plan_bookkeeping_without_a_device():
     """handles own what used to be process-global state; a plan's segment bookkeeping is host logic"""
     import ctypes
