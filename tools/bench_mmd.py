@@ -19,6 +19,9 @@ print('# algorithmic bytes: read 2*B*d*4, write 8 scalars (+ 4*B*d*4 gradients);
 # 128 B/clk port, 4 waves -> 256 clk per tile against ~280 clk of VALU issue per SIMD: the two limits are about equal, so the
 # kernel cannot pass ~50 % of the VALU-issue column below without keeping x_j / y_j in registers across the four rows.
 VALU_PEAK = 78.6e12
+print('# VALU-issue column: fp32 VALU issue slots per pair evaluation (d = 16; v_exp_f32 quarter rate): rep forward 35, + backward 54;')
+print('# rmb + 3.5, mmd_g (five Gaussians) + 28; against 78.6 T lane-slots/s (256 CU x 4 SIMD x 32 lanes x 2.4 GHz).  The LDS port')
+print('# (32 ds_read_b32 of x_j / y_j per tile and wave) caps the kernel near 50 % of that column; below B ~ 1024 it is launch latency.')
 SLOTS = {'rep': (35.0, 54.0), 'rmb': (38.5, 54.0), 'mmd_g': (63.0, 54.0)}
 print('%6s %5s %10s %12s %14s %12s %16s' % ('B', 'loss', 'us', 'alg. GB/s', '% of 8 TB/s', 'Gpair/s', '% of VALU issue'))
 for loss in ('rep', 'rmb', 'mmd_g'):

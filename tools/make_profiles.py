@@ -53,7 +53,7 @@ def bench_line(path):
 def trial_steps(path, steps, warmup):
     """steps in a profiled default run: warm-up + launch-mode trial (3 modes x 30) + 3 + timed"""
     b = bench_line(path)
-    n = steps + warmup + 3
+    n = steps + warmup + 3 + 2               # (+ 2: the kernel-set check at the end of a run records and replays one step)
     if b and b['config'].get('launch_mode_trial_ms'):
         n += len(b['config']['launch_mode_trial_ms']) * 30
     return n
@@ -113,10 +113,11 @@ summary('default', 'g', trial_steps(os.path.join(src, 'bench_default_profiled.js
         '# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline   (the default command:\n'
         '# 4 streams, launch-mode trial during warm-up included in the trace; kernel durations include overlap between\n'
         '# streams: use the single-stream file for per-kernel cost)')
-summary('single', 'e', 28, tag + '_kernel_stats_single_stream.txt',
-        '# MMDGAN_SIDE_WGRAD=0 MMDGAN_SN_STREAMS=1 rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --launch-mode eager --no-cpu-baseline')
+summary('single', 'e', 30, tag + '_kernel_stats_single_stream.txt',      # 5 warm-up + 3 + 20 timed + 2 of the kernel-set check
+        '# MMDGAN_SIDE_WGRAD=0 MMDGAN_SN_STREAMS=1 rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --launch-mode eager --no-cpu-baseline\n'
+        '# (the wino2_kernel row also holds the 23 launches of the run\'s dominant-kernel probe: 0.06 ms/step of its total)')
 if find('resnet', '_kernel_stats.csv'):
-    summary('resnet', 'r', 16, tag + '_resnet_kernel_stats.txt',      # 3 warm-up + 3 after the launch mode is set + 10 timed steps
+    summary('resnet', 'r', 18, tag + '_resnet_kernel_stats.txt',      # 3 warm-up + 3 after the launch mode is set + 10 timed steps + 2 of the kernel-set check
             '# rocprofv3 --kernel-trace --stats -- python bench.py --config lsun_resnet --steps 10 --warmup 3 --launch-mode eager --no-cpu-baseline')
 tl = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'step_timeline.py'), os.path.join(src, 'timeline')],
                     capture_output=True, text=True).stdout
@@ -234,4 +235,7 @@ for name in ('conv_layers.txt', 'conv_layers_own_transform.txt', 'conv_layers_di
     p = os.path.join(src, name)
     if os.path.exists(p):
         with open(p) as f, open(os.path.join(dst, 'bench_' + tag + '.json' if name == 'bench.json' else tag + '_' + name), 'w') as g:
-            g.write('\n'.join(ln for ln in f.read().splitlines() if 'amdgpu.ids' not in ln) + '\n')
+            lines = [ln for ln in f.read().splitlines() if 'amdgpu.ids' not in ln]
+            if name.startswith('bench') and name.endswith('.json'):      # the JSON line only (RCCL prints a banner to stdout)
+                lines = [ln for ln in lines if ln.startswith('{')][-1:]
+            g.write('\n'.join(lines) + '\n')
