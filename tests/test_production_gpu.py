@@ -49,6 +49,14 @@ def test_step_under_the_production_kernel_selection(config, loss, B):
                                         for k in set(out['kernels']) | set(expected) if out['kernels'].get(k) != expected.get(k)}
 
 
+def test_eager_issue_under_the_production_kernel_selection():
+    """bench.py keeps the faster of eager issue and plan replay (it is usually eager by a hair): the same CIFAR step issued
+    eagerly, in the same clean environment, against the oracle.  (Both modes issue the same kernels - a plan IS a recorded
+    eager step - so the kernel list is the plan case's.)"""
+    out = run_in_default_env('cifar', 'rep', 64, mode='eager')
+    assert out['env'] == [] and out['grad_tensors'] >= 20 and 'kernels' not in out
+
+
 def test_this_process_does_not_run_the_production_selection():
     """the reason for the subprocess: under tests/conftest.py's thresholds the SAME config takes other kernels (every
     3x3 / 4x4 layer through the Winograd ones, whatever its grid) - if this ever stops being true the subprocess cases
