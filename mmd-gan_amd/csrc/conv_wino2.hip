@@ -111,6 +111,12 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
     __syncthreads();
     const int second = __builtin_amdgcn_readfirstlane(wgctl[0]), pos0 = __builtin_amdgcn_readfirstlane(wgctl[1]);
     const int wrole = (wave + pos0 + 2 * second) & 3;
+    // Static priority for the SECOND workgroup of the CU: its wave is the younger one on every SIMD and loses the VALU / MFMA
+    // arbitration against the first workgroup's on every segment (MI355X_MICROARCH.md, "two waves per SIMD", item 4).  One
+    // s_setprio for the whole kernel, no per-segment flips.  Round 4, the 3B-row D l2 launch, 100 launches each, twice: none
+    // 80.87 / 80.80 us, second workgroup 80.57 / 80.61, first workgroup 80.87 / 81.02, the five-accumulator waves 83.18 / 83.06;
+    // CIFAR step 1.899 / 1.902 -> 1.883 / 1.899 ms.
+    if (second) __builtin_amdgcn_s_setprio(1);
     const int cb = wrole & 1, fq = wrole >> 1;           // this wave: column block cb, frequencies fq + 2m
     const int nm = fq == 0 ? 5 : 4;
     // ---- this workgroup's run of items: XCD x (speed assumption: workgroup b runs on XCD b % 8) gets a contiguous eighth of
