@@ -333,14 +333,14 @@ def main():
         modes = ('eager', 'plan') if (group is not None or tape) else ('eager', 'graph', 'plan')
         for m in modes + modes:                          # two passes, the better one counts: one host hiccup must not pick the mode
             eng.launch_mode = m
-            for _ in range(5):
+            for _ in range(10):
                 eng.step(real)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(25):
-                eng.step(real)
+            for _ in range(60):                          # (25 steps under-measured the replay modes: a fixed ~1 ms start-up
+                eng.step(real)                           # per timed block - the same sequence at 100 steps: plan = eager)
             torch.cuda.synchronize()
-            trial[m] = min(trial.get(m, 1e9), (time.perf_counter() - t0) / 25)
+            trial[m] = min(trial.get(m, 1e9), (time.perf_counter() - t0) / 60)
         for m in modes:
             if group is not None:
                 import torch.distributed as dist

@@ -11,9 +11,9 @@ arch, lr = configs.CONFIGS[config]()
 eng = GanEngine(arch, 'rep', lr, batch_size=B, seed=0)
 c, h, w = arch['input'][0]
 real = torch.empty(B, h, w, c, device='cuda').uniform_(-1, 1)
-def run(tag, mode, N=50):
+def run(tag, mode, N=100):
     eng.launch_mode = mode
-    for _ in range(5): eng.step(real)
+    for _ in range(10): eng.step(real)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(N): eng.step(real)

@@ -55,7 +55,7 @@ def trial_steps(path, steps, warmup):
     b = bench_line(path)
     n = steps + warmup + 3 + 2               # (+ 2: the kernel-set check at the end of a run records and replays one step)
     if b and b['config'].get('launch_mode_trial_ms'):
-        n += len(b['config']['launch_mode_trial_ms']) * 30
+        n += len(b['config']['launch_mode_trial_ms']) * 2 * 70     # two passes of 10 + 60 steps per mode
     return n
 
 
