@@ -1,5 +1,8 @@
 """GPU parity tests: every C-ABI op against the oracle (oracle/restatement.py, oracle/mmd_oracle.c)
 and against the golden vectors generated from the reference.  The oracle is the checker only."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -506,6 +509,70 @@ def test_conv_with_an_addend_equals_conv_plus_addend(ops, case):
     for bad in (None, y0.data_ptr()):                    # no addend; the addend is the output
         rc = lib.mmdgan_conv2d_fwd_add(ctypes.byref(gm), x.data_ptr(), w.data_ptr(), None, None, 0, None, 0, bad, y0.data_ptr(), None)
         assert rc == -1 and b'addend' in lib.mmdgan_last_error()
+
+
+def test_random_gemm_shapes(ops):
+    """300 random dense-layer products through mmdgan_gemm - both operand forms, bias, scale, activation forward and its
+    derivative backward with the 3B-row wrap, the split-K licence (out_zeroed) on a zeroed output, the skinny-N MFMA route
+    (N = 16, K % 256 == 0) - against a float64 product of the same operands."""
+    rs = np.random.RandomState(20260929)
+    dims = [1, 2, 3, 5, 8, 16, 17, 31, 32, 48, 64, 65, 96, 100, 128, 192, 256, 384, 512, 1000, 1024, 2048, 4096, 8192]
+    bad = []
+    for i in range(300):
+        M, N, K = (int(dims[rs.randint(len(dims))]) for _ in range(3))
+        if rs.rand() < 0.2:
+            N, K = 16, int(rs.choice([1024, 2048, 4608, 8192, 18432]))
+            M = int(rs.choice([16, 48, 64, 128, 192, 256]))
+        if M * N > 4e6 or M * K > 16e6 or N * K > 16e6:
+            continue
+        ta, tb = bool(rs.rand() < 0.3), bool(rs.rand() < 0.3)
+        g = torch.Generator(device='cuda').manual_seed(1000 + i)
+        a = torch.randn((K, M) if ta else (M, K), device='cuda', generator=g)
+        b = torch.randn((N, K) if tb else (K, N), device='cuda', generator=g)
+        bias = torch.randn(N, device='cuda', generator=g)
+        sc = torch.tensor([0.7], device='cuda')
+        ref = ((a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double())) * 0.7 + bias.double()
+        mode = i % 3
+        if mode == 0:                                    # forward form
+            got = ops.gemm(a, b, ta, tb, bias=bias, scale=sc, act='lrelu')
+            want = torch.where(ref > 0, ref, 0.1 * ref)
+        elif mode == 1:                                  # linear, into a zeroed output: the launch may split K and accumulate
+            out = torch.zeros(M, N, device='cuda')
+            got = ops.gemm(a, b, ta, tb, bias=bias, scale=sc, out=out, out_zeroed=True)
+            want = ref
+        else:                                            # backward form, the operand holding 2/3 of the rows where M allows
+            rows = 2 * M // 3 if (M % 3 == 0 and M >= 3) else M
+            y = torch.randn(rows, N, device='cuda', generator=g)
+            full = torch.cat([y, y[rows - (M - rows):]], 0) if rows < M else y
+            got = ops.gemm(a, b, ta, tb, bias=bias, scale=sc, act='lrelu', dact_of=y, dact_rows=rows if rows < M else 0)
+            want = ref * torch.where(full > 0, 1.0, 0.1).double()
+        err = float((got.double() - want).abs().max() / (want.abs().max() + 1e-30))
+        if not err <= 2e-5:                              # (fp32 sums of up to 18432 terms against float64)
+            bad.append(((M, N, K, ta, tb, mode), err))
+    assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize('where', ['this process', 'production selection'])
+def test_random_conv_geometries(where):
+    """150 random geometries (tests/conv_fuzz.py, fixed seed: channels 3 ... 512, sizes 4 ... 64 also non-square, batches
+    1 ... 200, kernels 1 / 2 / 3 / 4 / 5, strides 1 / 2) plus a 96-case sweep of the Winograd kernels' channel classes at
+    sizes with many work items per workgroup, through the library's dispatch: adjointness of the three kernels,
+    caller-transformed weights against the library's own transform, the fused epilogues (with the 3B-row wrap) against
+    the linear launch finished in torch, batch independence.  Once under this process's
+    thresholds and once in a subprocess with no MMDGAN_* variable set - the selection bench.py runs."""
+    import json
+    import subprocess
+    import conv_fuzz
+    if where == 'this process':
+        out = conv_fuzz.run(20260929, 150)
+    else:
+        env = {k: v for k, v in os.environ.items() if not k.startswith('MMDGAN_')}
+        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), 'conv_fuzz.py'), '20260929', '150'], env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        assert out['env'] == []
+    assert out['cases'] == 150 + 96 and not out['bad'], out['bad'][:5]
 
 
 WINO2_CASES = [(16, 16, 16, 64, 128, 4, 2), (30, 12, 12, 32, 64, 4, 2), (6, 8, 16, 64, 64, 4, 2), (9, 4, 4, 128, 64, 4, 2),
