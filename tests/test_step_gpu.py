@@ -291,6 +291,67 @@ def test_step_matches_oracle_mfma_path(loss_type):
                 assert np.abs(v - ref).max() <= 2.5 * 5e-4, (step, n)
 
 
+def random_dcgan(seed):
+    """a DCGAN-SN pair of the reference's family (configs._dcgan: my_test_*.py) with drawn width, depth, image size, first-layer
+    batch norm, loss, batch and launch mode: (architecture, loss, batch, launch mode)"""
+    import configs
+    rs = np.random.RandomState(1000 + seed)
+    n_stage = int(rs.choice([2, 3]))
+    base = int(rs.choice([4, 6])) if n_stage == 3 else int(rs.choice([4, 8]))
+    image = base * 2 ** n_stage
+    width = int(rs.choice([16, 32, 48, 64]))
+    arch = configs._dcgan(base, bool(rs.rand() < 0.5), n_stage, image, float(np.power(64.0, 1.0 / (2 * n_stage + 2))), width=width)
+    arch['code'] = [(int(rs.choice([32, 64, 100])), 'linear')]
+    if rs.rand() < 0.4:                                  # spectral norm on G's transposed layers too (math_func.py:512-528)
+        for d in arch['generator'][1:-1]:
+            d.update({'w_nm': 's', 'act_k': 1.0})
+    loss = str(rs.choice(['rep', 'rmb', 'mmd_g', 'hinge']))
+    return arch, loss, int(rs.choice([8, 12, 16, 24])), str(rs.choice(['eager', 'plan', 'graph']))
+
+
+@pytest.mark.parametrize('seed', [0, 3, 6, 7, 8, 9])      # (plan, graph and eager; 16 - 48 pixels; widths 16 - 64; SN in G)
+def test_step_on_random_architectures(seed):
+    """the hand-scheduled engine on architectures nobody tuned it for: width 16 ... 64 (thin, direct, implicit-GEMM and
+    Winograd kernels in mixtures that the shipped dicts do not produce), two or three stages, 16 ... 64 pixel images, a
+    batch-normalised or plain first G layer, spectral norm in G or not, four losses, odd batches, every launch mode.  Three
+    teacher-forced steps against the fp64 oracle: images, scores, losses at 1e-4, all gradients by the one rule."""
+    from mmdgan_hip.engine import GanEngine
+    arch, loss, B, mode = random_dcgan(seed)
+    c, h, w = arch['input'][0]
+    lr = (5e-4, 2e-4)
+    eng = GanEngine(arch, loss, lr, batch_size=B, seed=seed, launch_mode=mode)
+    ora = R.OracleGan(arch, loss, lr, dtype=torch.float64, params=eng.get_variables())
+    rs = np.random.RandomState(seed)
+    last = eng.dis.specs[-1].scope
+    pairwise = loss not in ('hinge', 'logistic')
+    for step in range(3):
+        z = rs.randn(B, arch['code'][0][0]).astype(np.float32)
+        real = rs.uniform(-1, 1, (B, c, h, w)).astype(np.float32)
+        prev_vars = {k: v.numpy().copy() for k, v in ora.params.items()}
+        eng.set_variables(prev_vars)
+        zt, rt = torch.tensor(z, dtype=torch.float64), torch.tensor(real, dtype=torch.float64)
+        lg, ld, stats, upd, gd, gg, (gen, s_x, s_gen) = ora.grads(zt, rt)
+        ora.step(zt, rt)
+        eng.step(nhwc(real), torch.as_tensor(z).cuda())
+        what = (seed, loss, B, mode, step)
+        fake = np.transpose(eng.buf['dis_in'][B:].cpu().numpy(), (0, 3, 1, 2))
+        assert close(fake, gen.detach().numpy(), RTOL, 0.0), what
+        scores = eng.buf[last + '#y'].cpu().numpy()
+        sscale = max(float(s_x.detach().abs().max()), float(s_gen.detach().abs().max()))
+        assert np.abs(scores[:B] - s_x.detach().numpy()).max() <= RTOL * sscale and \
+            np.abs(scores[B:] - s_gen.detach().numpy()).max() <= RTOL * sscale, what
+        losses = eng.losses.cpu().numpy().astype(np.float64)
+        escale = max(float(max(losses[2:5])), 1e-30) if pairwise else 1.0
+        assert abs(losses[0] - float(lg)) <= RTOL * abs(float(lg)) + 1e-5 * escale, (what, losses[0], float(lg))
+        assert abs(losses[1] - float(ld)) <= RTOL * abs(float(ld)) + 1e-5 * escale, (what, losses[1], float(ld))
+        if step == 0:
+            continue                                     # un-normalised SN start vectors: rounding noise (SURVEY A.5 #1)
+        grads = eng.get_variables(grad=True)
+        ref_g = {n: g.numpy() for n, g in list(gd.items()) + list(gg.items())}
+        assert_grads_within_fp32_floor(grads, ref_g, fp32_floor(arch, loss, lr, prev_vars, z, real, eng),
+                                       skip=(last + '/bias/bias',) if pairwise else (), what=what)
+
+
 @pytest.mark.parametrize('config,loss,B,mode', [('cifar', 'rep', 8, 'eager'), ('cifar', 'rep', 64, 'eager'),
                                                 ('cifar', 'rep', 64, 'plan'), ('stl', 'rep', 8, 'eager'),
                                                 ('stl', 'rmb', 64, 'plan'), ('celeba', 'rep', 8, 'eager'),
