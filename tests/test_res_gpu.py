@@ -310,6 +310,87 @@ def test_step_on_the_shipped_resnet_architecture():
                                        fp32_floor(arch, 'rep', tuple(lr), prev_vars, z, real, eng), skip=zero, what=step)
 
 
+def random_resnet(seed):
+    """a residual pair with drawn block kinds, widths, scaling methods, activations and batch norm placement: the layer
+    dicts layer_func.py:1687-1842 accepts, in combinations no fixture holds.  (architecture, loss, batch, launch mode)"""
+    rs = np.random.RandomState(2000 + seed)
+    ak = float(np.power(64.0, 0.125))
+    k = [3, 3, 1]
+    w = int(rs.choice([16, 32, 64]))
+    img = int(rs.choice([16, 32]))
+    base = img // 4
+    up = str(rs.choice(['unpool', 'unpool', 'ps', 'bil']))
+    # (no 'max' here: which element of a window is the maximum is decided like a relu's sign - two evaluations differ where two
+    # candidates lie within rounding - and the oracle takes the engine's relu / lrelu decisions as an input but not its argmax
+    # ones: one such window moved every G gradient of a drawn pair by 3e-3 at its third step.  'max' has its own reference
+    # fixture, step_tiny_res_max_rep.)
+    down = str(rs.choice(['avg', 'avg', 'ps']))
+    act_d = str(rs.choice(['relu', 'lrelu']))
+    gbn = bool(rs.rand() < 0.7)
+    gen = [{'name': 'l1', 'out': 2 * w * base * base, 'op': 'd', 'out_reshape': [2 * w, base, base]}]
+    ch = 2 * w
+    for i in range(2):
+        out = ch if up == 'ps' and i == 0 else max(ch // 2, 8)
+        blk = {'name': 'l%d_res' % (i + 2), 'type': 'res', 'out': out, 'act': 'relu', 'kernel': k, 'scale': [up, 2]}
+        if gbn:
+            blk['act_nm'] = 'bn'
+        gen.append(blk)
+        ch = out
+    if gbn:
+        gen.append({'name': 'l4_bn', 'op': 'i', 'act': 'relu', 'act_nm': 'bn'})
+    gen.append({'name': 'l5_t', 'out': 3, 'act': 'tanh'})
+    first = 'res' if down == 'ps' else 'res_v1'          # (a res_v1 block cannot shuffle down: layer_func.py:1767)
+    dis = [{'name': 'l1_res', 'type': first, 'out': w, 'act': act_d, 'act_k': ak, 'w_nm': 's', 'kernel': k, 'scale': [down, -2]},
+           {'name': 'l2_res', 'type': 'res', 'out': 2 * w, 'act': act_d, 'act_k': ak, 'w_nm': 's', 'kernel': k, 'scale': [down, -2]},
+           # ('ps' down-sampling moves each 2x2 block into the channels AFTER the block's last kernel: 4 x its `out`)
+           {'name': 'l3_res', 'type': 'res_i', 'out': 2 * w * (4 if down == 'ps' else 1), 'act': act_d, 'act_k': ak, 'w_nm': 's',
+            'out_reshape': [base * base * 2 * w * (4 if down == 'ps' else 1)]},
+           {'name': 'l4_s', 'out': 16, 'op': 'd', 'act_k': ak, 'w_nm': 's'}]
+    arch = {'input': [(3, img, img)], 'code': [(int(rs.choice([24, 64])), 'linear')], 'generator': gen, 'discriminator': dis}
+    return arch, str(rs.choice(['rep', 'rmb', 'mmd_g'])), int(rs.choice([6, 8, 12, 16])), str(rs.choice(['eager', 'plan']))
+
+
+@pytest.mark.parametrize('seed', [0, 4, 5, 7, 9, 11])
+def test_step_on_random_residual_architectures(seed):
+    """the primitive-op engine on drawn residual pairs (widths 16 ... 64 at 16 / 32 pixels; 'unpool' / 'ps' / 'bil'
+    up-sampling, 'avg' / 'ps' down-sampling; relu / lrelu; batch norm in G or not; three losses; eager issue and the
+    launch plan; branch sums and gradient fan-ins on conv epilogues wherever the lowering finds them): three teacher-forced
+    steps against the fp64 oracle - losses at 1e-4, all gradients by the one rule."""
+    from mmdgan_hip.tape import TapeEngine
+    arch, loss, B, mode = random_resnet(seed)
+    c, h, w = arch['input'][0]
+    lr = (5e-4, 2e-4)
+    eng = TapeEngine(arch, loss, lr, batch_size=B, seed=seed, launch_mode=mode)
+    ora = R.OracleGan(arch, loss, lr, dtype=torch.float64, params=eng.get_variables())
+    rs = np.random.RandomState(seed)
+    for step in range(3):
+        z = rs.randn(B, arch['code'][0][0]).astype(np.float32)
+        real = rs.uniform(-1, 1, (B, c, h, w)).astype(np.float32)
+        prev_vars = {k: v.numpy().copy() for k, v in ora.params.items()}
+        eng.set_variables(prev_vars)
+        zt, rt = torch.tensor(z, dtype=torch.float64), torch.tensor(real, dtype=torch.float64)
+        lg, ld, stats, upd, gd, gg, (gen, s_x, s_gen) = ora.grads(zt, rt)
+        ora.step(zt, rt)
+        eng.step(nhwc(real), torch.as_tensor(z).cuda())
+        what = (seed, loss, B, mode, step)
+        fake = np.transpose(eng._dis_in[B:].cpu().numpy(), (0, 3, 1, 2))
+        assert close(fake, gen.detach().numpy(), RTOL, 0.0), what
+        losses = eng.losses.cpu().numpy().astype(np.float64)
+        escale = float(max(losses[2:5]))
+        assert abs(losses[0] - float(lg)) <= RTOL * abs(float(lg)) + 1e-5 * escale, (what, losses[0], float(lg))
+        assert abs(losses[1] - float(ld)) <= RTOL * abs(float(ld)) + 1e-5 * escale, (what, losses[1], float(ld))
+        if step == 0:
+            continue
+        grads = eng.get_variables(grad=True)
+        ref_g = {n: g.numpy() for n, g in list(gd.items()) + list(gg.items())}
+        zero = set()                                     # analytically zero: biases in front of a batch norm / behind score differences
+        for net in ('gen', 'dis'):
+            gscale = max(float(np.abs(ref_g[n]).max()) for n in grads if n.startswith(net))
+            zero |= {n for n in grads if n.startswith(net) and np.abs(ref_g[n]).max() <= 1e-9 * gscale}
+        assert len(zero) <= 8, zero
+        assert_grads_within_fp32_floor(grads, ref_g, fp32_floor(arch, loss, lr, prev_vars, z, real, eng), skip=zero, what=what)
+
+
 def test_batch_norm_in_the_discriminator_takes_the_primitive_op_engine():
     """batch norm in D couples the rows of the batch, which the hand-scheduled engine's 3B-row backward pass does not
     model: GanEngine refuses such a dict, SNGan.init_net routes it to the primitive-op engine, and that engine's step
