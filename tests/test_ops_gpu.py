@@ -136,6 +136,30 @@ def test_next_row_losses_match_oracle(ops, B, d, loss_type):
         assert torch.equal(h[slot], out['grads'][src]), (loss_type, slot)
 
 
+def test_losses_at_random_sizes(ops):
+    """every loss of the pairwise kernel and the two score losses at 48 drawn (batch, score width) pairs - batches 2 ... 400
+    that are no tile multiple, widths 1 ... 48 - against the restatement in float64 with autograd: both losses, the kernel
+    means, all four gradient blocks.  (The fixed cases above pin the reference's own sizes; this walks the ragged ones.)"""
+    rs = np.random.RandomState(77)
+    for i in range(48):
+        B, d = int(rs.randint(2, 401)), int(rs.randint(1, 49))
+        loss_type = ('rep', 'rmb', 'mmd_g', 'mgb', 'hinge', 'logistic')[i % 6]
+        spread = float(rs.choice([0.05, 0.3, 0.8]))
+        s_gen = (rs.randn(B, d) * spread).astype(np.float32)
+        s_x = (rs.randn(B, d) * spread + 0.2 * spread).astype(np.float32)
+        sg = torch.tensor(s_gen, dtype=torch.float64, requires_grad=True)
+        sx = torch.tensor(s_x, dtype=torch.float64, requires_grad=True)
+        lg, ld, _ = R.gan_loss(sg, sx, loss_type, B)
+        g = list(torch.autograd.grad(lg, [sg, sx], retain_graph=True, allow_unused=True))
+        g += list(torch.autograd.grad(ld, [sg, sx], allow_unused=True))
+        g = [np.zeros((B, d)) if t is None else t.numpy() for t in g]
+        out = ops.mmd_loss(dev(s_gen), dev(s_x), loss_type, need_grads=True)
+        try:
+            _check_loss_against(out, float(lg.detach()), float(ld.detach()), g, loss_type not in ('hinge', 'logistic'))
+        except AssertionError as e:
+            raise AssertionError((B, d, loss_type, spread)) from e
+
+
 MIX = golden('lossmix_*.npz')
 
 
@@ -911,6 +935,38 @@ def test_sn_helpers_and_adam(ops):
         opt.apply(params, {'a': torch.tensor(gs[0]), 'b': torch.tensor(gs[1])})
     assert rel_err(dp[0].cpu().numpy(), params['a'].numpy()) <= 1e-6
     assert rel_err(dp[1].cpu().numpy(), params['b'].numpy()) <= 1e-6
+
+
+def test_batch_norm_at_random_shapes(ops):
+    """batch norm forward (training and inference) and backward at 30 drawn (rows, features) pairs - feature counts that are no
+    multiple of 4 (the scalar kernels), a handful of rows, tens of thousands - against float64 autograd"""
+    rs = np.random.RandomState(5)
+    for i in range(30):
+        C = int(rs.choice([1, 3, 5, 7, 8, 12, 16, 31, 32, 48, 64, 100, 128, 200, 256, 512, 1000]))
+        rows = int(rs.choice([2, 3, 9, 64, 100, 1000, 4096, 10000, 40000]))
+        if rows * C > 4e6:
+            continue
+        act = ('relu', 'lrelu', 'linear', 'tanh')[i % 4]
+        x = (rs.randn(rows, C) * 1.3 + 0.3).astype(np.float32)
+        gamma, beta = rs.uniform(0.5, 1.5, C).astype(np.float32), (rs.randn(C) * 0.2).astype(np.float32)
+        mm, mv = (rs.randn(C) * 0.1).astype(np.float32), rs.uniform(0.5, 2, C).astype(np.float32)
+        dy = rs.randn(rows, C).astype(np.float32)
+        xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+        gt = torch.tensor(gamma, dtype=torch.float64, requires_grad=True)
+        bt = torch.tensor(beta, dtype=torch.float64, requires_grad=True)
+        mean = xt.mean(0)
+        var = ((xt - mean) ** 2).mean(0)
+        yt = R._act((xt - mean) / torch.sqrt(var + R.BN_EPS) * gt + bt, act)
+        gx, gg, gb = torch.autograd.grad((yt * torch.tensor(dy, dtype=torch.float64)).sum(), [xt, gt, bt])
+        y, smean, sinv, nmm, nmv = ops.bn_fwd_train(dev(x), dev(gamma), dev(beta), dev(mm), dev(mv), act=act, unbiased=False)
+        tag = (rows, C, act)
+        assert rel_err(y.cpu().numpy(), yt.detach().numpy()) <= RTOL, tag
+        assert rel_err(nmv.cpu().numpy(), mv * 0.99 + var.detach().numpy() * 0.01) <= 1e-5, tag
+        dx, dgamma, dbeta = ops.bn_bwd(dev(x), y, dev(dy), dev(gamma), smean, sinv, act=act)
+        gscale = float(np.abs(gx.numpy()).max())
+        assert np.abs(dx.cpu().numpy() - gx.numpy()).max() <= RTOL * gscale + 1e-6 * gscale, tag
+        assert rel_err(dgamma.cpu().numpy(), gg.numpy()) <= RTOL + 1e-6, tag
+        assert rel_err(dbeta.cpu().numpy(), gb.numpy()) <= RTOL + 1e-6, tag
 
 
 def test_power_iterations_of_many_kernels_in_six_launches(ops):
