@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the oracle's torch-CPU steps run fastest on a few dozen threads, not on all 128 of the GPU box's (bench.py's thread sweep:
+# 16 threads 180 img/s, 128 threads 23) - before torch is imported, and inherited by the tests' subprocesses
+os.environ.setdefault('OMP_NUM_THREADS', '32')
 os.environ.setdefault('MMDGAN_WINO_MIN_TILES', '32')     # let the small parity cases reach the Winograd kernels
 os.environ.setdefault('MMDGAN_WINO2', '2')               # ... and the F(2x2,2x2) stride-2 kernels in both directions
 
