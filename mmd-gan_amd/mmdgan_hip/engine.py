@@ -1150,6 +1150,7 @@ class GanEngine:
             self._plan = None
         if self._plan is None:
             self._plan_collectives = []
+            self._handle.forget_workspace_users()        # (step start: every stream of the previous step has been joined)
             ops.check(lib.mmdgan_plan_begin(), 'plan_begin')
             self._recording = True
             try:

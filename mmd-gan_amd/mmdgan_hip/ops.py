@@ -67,6 +67,14 @@ class Handle:
             with self:
                 check(lib.mmdgan_set_workspace(self.workspace.data_ptr(), workspace_bytes), 'set_workspace')
 
+    def forget_workspace_users(self):
+        """call with the handle current, at a point where every stream that used the workspace has been joined (a step's
+        start): the two halves have no owner again.  A launch plan recorded from here holds no ordering against streams of
+        the past - a half last used on, say, a hipGraph capture's warm-up stream would otherwise put a wait for that dead
+        stream (event record + wait, re-issued by every replay) into the plan: 0.07 ms per CIFAR step."""
+        if self.workspace is not None:
+            check(self._lib.mmdgan_set_workspace(self.workspace.data_ptr(), self.workspace.numel()), 'set_workspace')
+
     def __enter__(self):
         stack = getattr(_current_handles, 'stack', None)
         if stack is None:

@@ -1447,6 +1447,7 @@ class TapeEngine:
         if self._plan is not None and self._plan_stream != main:
             self._drop_plan()
         if self._plan is None:
+            self._handle.forget_workspace_users()        # (GanEngine._plan_step)
             ops.check(lib.mmdgan_plan_begin(), 'plan_begin')
             try:
                 self._step_body()
