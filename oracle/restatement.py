@@ -482,12 +482,19 @@ def sn_power_iteration(w, x, spec):
 # ---------------------------------------------------------------------------
 # forward pass of one net (layer_func.py:870-928, 946-966, 1646-1685, 2078-2100)
 # ---------------------------------------------------------------------------
-def _act(x, name, mask=None):
+def _act(x, name, mask=None, audit=None):
     """mask (tests only, see net_forward): the SIGN DECISIONS of another evaluation of the same layer (bool tensor, True where that
     evaluation's output was positive).  relu / lrelu then take their slope from it instead of from x - the two differ only
     where a pre-activation lies within rounding of zero.  An fp32 run of this oracle forced to an fp32 kernel's masks is the
-    floor the kernel's gradients are measured against: what fp32 arithmetic loses against fp64 under the SAME decisions."""
+    floor the kernel's gradients are measured against: what fp32 arithmetic loses against fp64 under the SAME decisions.
+    audit (a list): receives, per forced activation, (how many decisions differ from this evaluation's own, the largest
+    |pre-activation| among those as a fraction of the layer's largest) - the caller's proof that the forced decisions differ
+    from the natural ones at knife edges only."""
     if mask is not None and name in ('relu', 'lrelu'):
+        if audit is not None:
+            differ = (x > 0) != mask
+            n = int(differ.sum())
+            audit.append((n, float(x.detach().abs()[differ].max() / x.detach().abs().max()) if n else 0.0))
         lo = 0.0 if name == 'relu' else LRELU_ALPHA
         return x * torch.where(mask, torch.ones((), dtype=x.dtype), torch.full((), lo, dtype=x.dtype))
     if name == 'linear':
@@ -509,8 +516,10 @@ def net_forward(specs, params, x, is_training=True, collect=None, masks=None):
     # the sign decisions another evaluation took there (_act)
     mask_iter = iter(masks[specs[0]['scope'].split('/')[0]]) if masks is not None else None
 
+    audit = masks.get('audit') if masks is not None else None
+
     def act(t, name):
-        return _act(t, name, next(mask_iter) if (mask_iter is not None and name in ('relu', 'lrelu')) else None)
+        return _act(t, name, next(mask_iter) if (mask_iter is not None and name in ('relu', 'lrelu')) else None, audit)
 
     def batch_norm(t, prefix):                                # layer_func.py:953-966, SURVEY A.4
         axis_shape, dims = [1, -1, 1, 1], [0, 2, 3]

@@ -122,6 +122,30 @@ def note_knife_edge_retry(what):
                   % (what,), KnifeEdgeRetry)
 
 
+KNIFE_EDGE_MARGIN = 1e-5        # |pre-activation| / the layer's largest: fp32 sums land within ~1e-7 of the scale of their terms
+KNIFE_EDGE_MAX = 8              # decisions per step that may differ (about one element per million is that close to zero)
+
+
+def with_audit(masks_per_step):
+    """the engine's sign decisions of each step with a fresh 'audit' list attached (oracle/restatement.py:_act fills it)"""
+    return [dict(m, audit=[]) for m in masks_per_step]
+
+
+def assert_knife_edges_only(audited, what=''):
+    """what makes the comparison "under the engine's sign decisions" legitimate: the decisions forced on the fp64 evaluation
+    differ from the ones it would have taken itself in a handful of elements, each with a pre-activation within fp32
+    resolution of zero.  A kernel fault that moved a sign anywhere else fails here.  Returns (differing decisions, the
+    largest relative |pre-activation| among them)."""
+    total, worst = 0, 0.0
+    for step, m in enumerate(audited):
+        n = sum(a[0] for a in m['audit'])
+        assert n <= KNIFE_EDGE_MAX, (what, 'step %d: %d sign decisions differ from the fp64 evaluation' % (step, n))
+        total += n
+        worst = max([worst] + [a[1] for a in m['audit']])
+    assert worst <= KNIFE_EDGE_MARGIN, (what, 'a differing sign decision at %.2e of its layer\'s scale: not a knife edge' % worst)
+    return total, worst
+
+
 def max_err(got, ref, gscale=0.0):
     """max|got - ref| / (max|ref| + 1e-6 * gscale): the ENTRY-wise companion of l2_err - a localised fault (one wrong border
     row, one bad tile, one phase of a composed convolution) that an L2 norm over a whole kernel dilutes shows up here"""

@@ -296,8 +296,8 @@ def test_forced_activation_masks_are_a_no_op_on_the_oracles_own_decisions():
         seen = {'gen': [], 'dis': []}
         orig = R._act
 
-        def spy(x, name, mask=None):
-            y = orig(x, name, mask)
+        def spy(x, name, mask=None, audit=None):
+            y = orig(x, name, mask, audit)
             if name in ('relu', 'lrelu'):
                 seen[spy.net].append((y.detach() > 0))
             return y
@@ -315,8 +315,15 @@ def test_forced_activation_masks_are_a_no_op_on_the_oracles_own_decisions():
         forced = ora.grads(z, real, masks=seen)
         for a, b in zip(list(plain[4].values()) + list(plain[5].values()), list(forced[4].values()) + list(forced[5].values())):
             assert float((a - b).abs().max()) <= 1e-12 * max(float(a.abs().max()), 1e-30)
+        audited = dict(seen, audit=[])                   # the audit of forced decisions (helpers.assert_knife_edges_only): none differ
+        ora.grads(z, real, masks=audited)
+        assert len(audited['audit']) == len(seen['gen']) + len(seen['dis']) and all(a == (0, 0.0) for a in audited['audit'])
         flipped = {k: [m.clone() for m in v] for k, v in seen.items()}
         flipped['dis'][0].view(-1)[::7] ^= True
+        flipped['audit'] = []
         other = ora.grads(z, real, masks=flipped)
+        n_forced = int(flipped['dis'][0].numel() + 6) // 7
+        first_d = flipped['audit'][len(seen['gen'])]      # (the layers above see other inputs now: their counts are whatever)
+        assert first_d[0] == n_forced and first_d[1] > 1e-3   # ... and these are no knife edges
         name = next(iter(plain[4]))
         assert float((other[4][name] - plain[4][name]).abs().max()) > 1e-6 * float(plain[4][name].abs().max())
