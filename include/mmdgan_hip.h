@@ -269,7 +269,10 @@ int mmdgan_dot(const float *a, const float *b, long n, float *out, void *stream)
  *   moving_variance updated with the unbiased variance when the input is 4-D (fused kernel).
  * fwd: y = act((x - mean)/sqrt(var+eps) * gamma + beta); writes save_mean/save_invstd [C] and
  *      new_moving_mean/var (may alias the inputs' storage: all reads precede all writes).
- * bwd: dx, dgamma, dbeta from dy (gradient w.r.t. y, i.e. AFTER the activation), y.
+ * bwd: dx, dgamma, dbeta from dy (gradient w.r.t. y, i.e. AFTER the activation), y.  y may be NULL for act linear / relu /
+ *      lrelu when beta is given: the derivative needs the SIGN of the forward value only, and the entry recomputes that value
+ *      from x with the operations of the forward entry, bit for bit (a third less traffic than reading y back); beta is
+ *      not read otherwise and may be NULL then.
  * workspace: mmdgan_bn_workspace_bytes(C) bytes of device scratch (2*C fp64 totals, accumulated with atomics).  The
  * entries zero it themselves, unless mmdgan_set_outputs_prezeroed(1) is in force: then it must be zero on entry and
  * distinct per call within a step (the forward and the backward call of a layer need separate totals).
@@ -282,8 +285,8 @@ int mmdgan_bn_fwd_train(const float *x, long rows, int C, const float *gamma, co
 int mmdgan_bn_fwd_infer(const float *x, long rows, int C, const float *gamma, const float *beta, float eps,
                         int act, const float *moving_mean, const float *moving_var, float *y, void *stream);
 int mmdgan_bn_bwd(const float *x, const float *y, const float *dy, long rows, int C, const float *gamma,
-                  const float *save_mean, const float *save_invstd, int act, float *dx, float *dgamma,
-                  float *dbeta, void *workspace, void *stream);
+                  const float *beta, const float *save_mean, const float *save_invstd, int act, float *dx,
+                  float *dgamma, float *dbeta, void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Spectral normalisation helpers (math_func.py:639-672).  The linear maps themselves are the

@@ -516,6 +516,7 @@ class GanEngine:
         # round 4: dependencies that put a marker / barrier packet into the MAIN queue (~6 us of idle queue each) moved off it
         # where another ordering already covers them (MMDGAN_QUEUE_OPT=0: the round-3 placement)
         self._queue_opt = settings.on('MMDGAN_QUEUE_OPT') and self._side_wgrad
+        self._bn_resign = settings.on('MMDGAN_BN_RESIGN')
         if ops._workspace is None:
             ops.set_workspace(device=self.device)                        # the default handle's (eval paths, stand-alone ops)
         # this engine's own library state (include/mmdgan_hip.h "Handles"): workspace, prezeroed mode, launch plan
@@ -608,11 +609,13 @@ class GanEngine:
         # batch-norm statistics are accumulated with fp64 atomics into per-layer totals ([forward | backward] x 2C),
         # which must be zero when the layer runs: one flat buffer, one memset per step
         bn = [(s.scope, s.out if s.op == 'd' else s.channels) for net in (self.gen, self.dis) for s in net.specs if s.bn]
-        self._bn_flat = torch.zeros(max(1, sum(4 * c for _, c in bn)), dtype=torch.float64, device=dev)
+        lib = ops.require_device()
+        n64 = {c: lib.mmdgan_bn_workspace_bytes(c) // 8 for _, c in bn}      # doubles per call (the totals, several slots of them)
+        self._bn_flat = torch.zeros(max(1, sum(2 * n64[c] for _, c in bn)), dtype=torch.float64, device=dev)
         self._bn_totals, off = {}, 0
         for scope, c in bn:
-            self._bn_totals[scope] = (self._bn_flat[off:off + 2 * c], self._bn_flat[off + 2 * c:off + 4 * c])
-            off += 4 * c
+            self._bn_totals[scope] = (self._bn_flat[off:off + n64[c]], self._bn_flat[off + n64[c]:off + 2 * n64[c]])
+            off += 2 * n64[c]
         if bn:
             self._zero_each_step.append(self._bn_flat)
         for net in (self.gen, self.dis):
@@ -915,9 +918,12 @@ class GanEngine:
                 raw, y = b[s.scope + '#raw'], b[s.scope + '#y']
                 C = raw.shape[-1]
                 draw = b[s.scope + '#dz']
-                ops.bn_bwd(raw.view(-1, C), y.view(-1, C), dz.view(-1, C), net.p(s.scope + '/BN/BN/gamma'), b[s.scope + '#mean'],
-                           b[s.scope + '#invstd'], act=s.act, dgamma=net.g(s.scope + '/BN/BN/gamma'),
-                           dbeta=net.g(s.scope + '/BN/BN/beta'), out=draw.view(-1, C), workspace=self._bn_totals[s.scope][1])
+                # (relu / lrelu / linear: the activation's sign is recomputed from the pre-BN values instead of reading y back)
+                resign = self._bn_resign and s.act in ('linear', 'relu', 'lrelu')
+                ops.bn_bwd(raw.view(-1, C), None if resign else y.view(-1, C), dz.view(-1, C), net.p(s.scope + '/BN/BN/gamma'),
+                           b[s.scope + '#mean'], b[s.scope + '#invstd'], act=s.act, dgamma=net.g(s.scope + '/BN/BN/gamma'),
+                           dbeta=net.g(s.scope + '/BN/BN/beta'), out=draw.view(-1, C), workspace=self._bn_totals[s.scope][1],
+                           beta=net.p(s.scope + '/BN/BN/beta') if resign else None)
                 dz = draw
             dz = dz.view(_native_shape(s.op_out_ref, B))
 

@@ -394,14 +394,18 @@ def bn_fwd_infer(x2d, gamma, beta, moving_mean, moving_var, act='linear', eps=1e
     return y
 
 
-def bn_bwd(x2d, y2d, dy2d, gamma, save_mean, save_invstd, act='linear', dgamma=None, dbeta=None, out=None, workspace=None):
+def bn_bwd(x2d, y2d, dy2d, gamma, save_mean, save_invstd, act='linear', dgamma=None, dbeta=None, out=None, workspace=None,
+           beta=None):
+    """y2d None (act linear / relu / lrelu, beta given): the activation's sign is recomputed from x2d, bitwise the forward
+    entry's decision - the output is not read back"""
     lib = require_device()
     rows, C = x2d.shape
     dx = out if out is not None else torch.empty_like(x2d)
     dgamma = dgamma if dgamma is not None else torch.empty(C, device=x2d.device, dtype=torch.float32)
     dbeta = dbeta if dbeta is not None else torch.empty(C, device=x2d.device, dtype=torch.float32)
     ws = workspace if workspace is not None else _bn_workspace(C, x2d.device)
-    check(lib.mmdgan_bn_bwd(_p(x2d), _p(y2d), _p(dy2d), rows, C, _p(gamma), _p(save_mean), _p(save_invstd), act_id(act),
+    check(lib.mmdgan_bn_bwd(_p(x2d), _p(y2d) if y2d is not None else None, _p(dy2d), rows, C, _p(gamma),
+                            _p(beta) if beta is not None else None, _p(save_mean), _p(save_invstd), act_id(act),
                             _p(dx), _p(dgamma), _p(dbeta), ws.data_ptr(), _stream()), 'bn_bwd')
     return dx, dgamma, dbeta
 

@@ -627,6 +627,7 @@ class TapeEngine:
         self._sn_zeroed = False                                          # inside step(): the power iteration's targets are zeroed
         self._exchange_pending = False
         self._fuse_fanin = settings.on('MMDGAN_TAPE_FUSE_ADD')
+        self._bn_resign = settings.on('MMDGAN_BN_RESIGN')
         self._d_has_bn = bool(self.dis.bns)
         lib = ops.require_device()
         # side streams on hardware queues of their own (streams.py): the power iterations run under G's forward pass,
@@ -1154,8 +1155,10 @@ class TapeEngine:
                     ws, gg, gb = p['_ws_bwd'], net.g(pre + '/BN/gamma'), net.g(pre + '/BN/beta')
                 else:                                                    # a second pass through the same op
                     ws, gg, gb = p['_ws_bwd2'], p['_gg2'], p['_gb2']
-                ops.bn_bwd(a.reshape(-1, c), y.reshape(-1, c), dy.reshape(-1, c), net.p(pre + '/BN/gamma'), mean, invstd,
-                           act=p['act'], dgamma=gg, dbeta=gb, out=dx.view(-1, c), workspace=ws)
+                resign = self._bn_resign and p['act'] in ('linear', 'relu', 'lrelu')      # (GanEngine._backward_gen)
+                ops.bn_bwd(a.reshape(-1, c), None if resign else y.reshape(-1, c), dy.reshape(-1, c), net.p(pre + '/BN/gamma'), mean,
+                           invstd, act=p['act'], dgamma=gg, dbeta=gb, out=dx.view(-1, c), workspace=ws,
+                           beta=net.p(pre + '/BN/beta') if resign else None)
                 if param_grads:
                     self._exchange(net, p)
                 if vin != 0 or need_input_grad:

@@ -874,6 +874,40 @@ def test_colsum_dot_layout(ops):
     assert np.array_equal(ops.nhwc_to_nchw(y).cpu().numpy(), t)
 
 
+def _check_bn_bwd_without_y(ops, x, dy, gamma, beta, smean, sinv, act, dx, dgamma, dbeta):
+    """mmdgan_bn_bwd with y = NULL (what the engines call): the sign of relu / lrelu recomputed from x must be the forward
+    entry's decision at EVERY element - one differing decision moves that element of dx by its whole |dy| - so the result
+    equals the one computed from y up to the order of the fp64 atomics; tanh needs y itself and is refused"""
+    if act == 'tanh':
+        with pytest.raises(ValueError):
+            ops.bn_bwd(x, None, dy, gamma, smean, sinv, act=act, beta=beta)
+        return
+    dx2, dgamma2, dbeta2 = ops.bn_bwd(x, None, dy, gamma, smean, sinv, act=act, beta=beta)
+    assert rel_err(dx2.cpu().numpy(), dx.cpu().numpy()) <= 1e-6
+    assert rel_err(dgamma2.cpu().numpy(), dgamma.cpu().numpy()) <= 1e-6
+    assert rel_err(dbeta2.cpu().numpy(), dbeta.cpu().numpy()) <= 1e-6
+
+
+def test_batch_norm_backward_without_y_at_exact_zeros(ops):
+    """forward values that are EXACTLY zero (x at the batch mean, beta = 0) and denormal-small ones: relu / lrelu output 0 or
+    -0 there, the derivative taken from y says "not positive", and so must the recomputed sign"""
+    for act in ('relu', 'lrelu'):
+        for C in (4, 7):                                 # the float4 and the scalar kernels
+            x = np.zeros((3, C), np.float32)
+            x[:, :] = np.array([1.5, 2.0, 1.0], np.float32)[:, None]       # mean 1.5 exactly: row 0 sits on it
+            x[:, 1] *= 1e-20                                               # ... and a column whose values vanish against eps
+            gamma, beta = np.ones(C, np.float32), np.zeros(C, np.float32)
+            beta[2] = 1e-42                                                # a denormal forward value
+            dy = np.ones((3, C), np.float32)
+            z = np.zeros(C, np.float32)
+            y, smean, sinv, _, _ = ops.bn_fwd_train(dev(x), dev(gamma), dev(beta), dev(z), dev(z + 1), act=act)
+            assert (y[0].cpu().numpy()[[0, 3]] == 0).all()
+            ref = ops.bn_bwd(dev(x), y, dev(dy), dev(gamma), smean, sinv, act=act)
+            got = ops.bn_bwd(dev(x), None, dev(dy), dev(gamma), smean, sinv, act=act, beta=dev(beta))
+            for r, g in zip(ref, got):
+                assert np.array_equal(r.cpu().numpy(), g.cpu().numpy()), (act, C)
+
+
 @pytest.mark.parametrize('rows,C,act,four_d', [(64 * 64, 256, 'relu', True), (64 * 1024, 64, 'relu', True),
                                                (64, 2304, 'relu', False), (100, 7, 'linear', True)])
 def test_batch_norm(ops, rows, C, act, four_d):
@@ -898,6 +932,7 @@ def test_batch_norm(ops, rows, C, act, four_d):
     assert rel_err(dx.cpu().numpy(), gx.numpy()) <= RTOL
     assert rel_err(dgamma.cpu().numpy(), gg.numpy()) <= RTOL
     assert rel_err(dbeta.cpu().numpy(), gb.numpy()) <= RTOL
+    _check_bn_bwd_without_y(ops, dev(x), dev(dy), dev(gamma), dev(beta), smean, sinv, act, dx, dgamma, dbeta)
     yi = ops.bn_fwd_infer(dev(x), dev(gamma), dev(beta), dev(mm), dev(mv), act=act)
     ref = R._act((torch.tensor(x, dtype=torch.float64) - torch.tensor(mm, dtype=torch.float64))
                  / torch.sqrt(torch.tensor(mv, dtype=torch.float64) + R.BN_EPS) * gt.detach() + bt.detach(), act)
@@ -963,6 +998,7 @@ def test_batch_norm_at_random_shapes(ops):
         assert rel_err(y.cpu().numpy(), yt.detach().numpy()) <= RTOL, tag
         assert rel_err(nmv.cpu().numpy(), mv * 0.99 + var.detach().numpy() * 0.01) <= 1e-5, tag
         dx, dgamma, dbeta = ops.bn_bwd(dev(x), y, dev(dy), dev(gamma), smean, sinv, act=act)
+        _check_bn_bwd_without_y(ops, dev(x), dev(dy), dev(gamma), dev(beta), smean, sinv, act, dx, dgamma, dbeta)
         gscale = float(np.abs(gx.numpy()).max())
         assert np.abs(dx.cpu().numpy() - gx.numpy()).max() <= RTOL * gscale + 1e-6 * gscale, tag
         assert rel_err(dgamma.cpu().numpy(), gg.numpy()) <= RTOL + 1e-6, tag
