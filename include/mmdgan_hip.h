@@ -315,8 +315,9 @@ int mmdgan_sn_wgrad_fixup(float *g_inout, const float *dsigma_dw, const float *d
  * form 2: dense, w [C,K]: u [1,K] = x [1,C] w        form 3: dense: u [1,C] = x [1,K] w^T
  * (a conv kernel in 'sn_paper' mode is the dense form on its [R*R*C, K] view).  xb has x's shape.
  * col: scratch of 2 * P*Q * R*R*C floats per convolution kernel (the patch matrices), unused for the dense forms.
- * u, xb and dsigma are accumulated into: the entry zeroes them first unless mmdgan_set_outputs_prezeroed(1) says the
- * caller did.  `layers` is a HOST array, read during the call. */
+ * u, xb and dsigma are accumulated into, and so is the half of col that holds a PRODUCT (form 0: the second half, y W^T;
+ * form 1: the first, x W^T) when that product has few tiles - ceil(P*Q / 64) * ceil(R*R*C / 64) < 128: the entry zeroes them
+ * first unless mmdgan_set_outputs_prezeroed(1) says the caller did.  `layers` is a HOST array, read during the call. */
 typedef struct mmdgan_sn_layer {
     const float *w;
     float *x, *u, *un, *xb, *col, *dsigma, *sigma, *scale, *xb_norm;

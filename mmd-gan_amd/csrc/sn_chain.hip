@@ -240,8 +240,14 @@ struct PhaseBuilder {
     void gemm(int p, const float *A, int sam, int sak, const float *B, int sbk, int sbn, float *C, int M, int N, int K, bool split) {
         const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
         int ks = 1;
-        if (split && tiles < 128) {
-            ks = (int)(256 / tiles);
+        if (split && tiles < 512) {
+            // parts: ~256 workgroups per product, or up to ~1024 where the OUTPUT is small (every part adds M x N atomics: at most
+            // 2^19 of them) - a stage lasts as long as its longest chain of dependent reduction steps, and the products with few
+            // output tiles and thousands of reduction elements (u = patches . W of a 4 x 4 image: 8 tiles, K = 4608) were those
+            // chains; cutting EVERY product 1024 ways instead cost the ResNet-SN config, with its many mid-sized products, 0.07 ms
+            const long by_atomics = (1L << 19) / ((long)M * N);
+            const long hi = 1024 / tiles < by_atomics ? 1024 / tiles : by_atomics, lo = tiles < 128 ? 256 / tiles : 1;
+            ks = (int)(hi > lo ? hi : lo);
             const int kmax = (K + 63) / 64;                          // >= 64 reduction elements per part
             if (ks > kmax) ks = kmax;
             if (ks < 1) ks = 1;
@@ -322,6 +328,15 @@ extern "C" int mmdgan_sn_power_iteration(const mmdgan_sn_layer *layers, int n_la
                     zero_output(L.xb, sizeof(float) * nx, st) != hipSuccess)
                     return check_launch("sn_power_iteration memset");
             }
+            // the patch matrix that is a PRODUCT (y W^T of form 0, x W^T of form 1) is split over workgroups like the others: 16
+            // rows x 4608 columns over K = 512 for D's last conv are 72 tiles of 32 dependent reduction steps otherwise, and that
+            // one product was the length of its whole stage (48 and 52 us for stages 0 and 4 of CIFAR's discriminator)
+            // - for the kernels where that is the case (few tiles, many steps: below 128 tiles, the rule mmdgan_hip.h states):
+            // zeroing the 19 MB patch matrix of a 64 x 64 image to cut an 8-step product in two costs more than it saves
+            const bool split_patches = conv && ((pq + 63) / 64) * ((r2c + 63) / 64) < 128;
+            if (split_patches && (L.form == 1 || update) &&
+                zero_output(L.form == 1 ? L.col : L.col + pq * r2c, sizeof(float) * pq * r2c, st) != hipSuccess)
+                return check_launch("sn_power_iteration memset");
             const int R2C = (int)r2c, PQ = (int)pq, K = L.K;
             double *acc = reinterpret_cast<double *>(L.norm_acc);
             float *col2 = conv ? L.col + pq * r2c : nullptr;
@@ -332,13 +347,13 @@ extern "C" int mmdgan_sn_power_iteration(const mmdgan_sn_layer *layers, int n_la
                 pb.norm(2, L.u, nu, L.un, L.sigma, L.scale, L.act_k, acc);
                 if (update) {
                     pb.gemm(4, L.col, 1, R2C, L.un, K, 1, L.dsigma, R2C, K, PQ, true);          // patches^T . y  (HWIO layout)
-                    pb.gemm(4, L.un, K, 1, L.w, 1, K, col2, PQ, R2C, K, false);                 // y W^T
+                    pb.gemm(4, L.un, K, 1, L.w, 1, K, col2, PQ, R2C, K, split_patches);         // y W^T
                     pb.fold(5, SN_COL2IM, col2, L.xb, d);
                     pb.norm(6, L.xb, nx, L.x, L.xb_norm, nullptr, 0.f, acc + 1);
                 }
                 break;
             case 1:                                                    // F = conv2d_dgrad: x [P*Q, K] -> u [H,W,C]
-                pb.gemm(0, L.x, K, 1, L.w, 1, K, L.col, PQ, R2C, K, false);
+                pb.gemm(0, L.x, K, 1, L.w, 1, K, L.col, PQ, R2C, K, split_patches);
                 pb.fold(1, SN_COL2IM, L.col, L.u, d);
                 pb.norm(2, L.u, nu, L.un, L.sigma, L.scale, L.act_k, acc);
                 if (update) {

@@ -662,6 +662,9 @@ class GanEngine:
                 layers = [(s, sn_chain_layer(net, s, self.buf)) for s in net.specs if s.sn]
                 self._sn_chains[id(net)] = (ops.SnChains([L for _, L in layers if L is not None], dev),
                                             [s for s, L in layers if L is None])
+                # the patch matrices that hold split products: zeroed with the step's scratch
+                self._zero_each_step += self._sn_chains[id(net)][0].zero_each_step
+            self._zeroed_ptrs = {t.data_ptr() for t in self._zero_each_step}
 
     # ---------------------------------------------------------------------------------------
     # spectral norm: one power-iteration step per D layer (math_func.py:661-672)
@@ -1086,7 +1089,7 @@ class GanEngine:
             small = [t for t in self._zero_each_step if not any(t is a for a in arenas)]
             self._sn_zero = []
             if self._queue_opt and self._sn_fused:
-                sn_flat = [net.sn_scratch.flat for net in (self.gen, self.dis)]
+                sn_flat = [net.sn_scratch.flat for net in (self.gen, self.dis)] + [t for c in self._sn_chains.values() for t in c[0].zero_each_step]
                 self._sn_zero = [t for t in small if any(t is f for f in sn_flat)]
                 small = [t for t in small if not any(t is f for f in sn_flat)]
             if small:

@@ -433,7 +433,18 @@ class SnChains:
     def __init__(self, layers, device):
         self.keep = list(layers)
         self.table = (SnLayer * max(1, len(self.keep)))()
-        self.cols = []
+        # the patch scratch of every convolution kernel in ONE buffer.  The half of it that receives a product (form 0: the
+        # second, form 1: the first) is accumulated into by several workgroups when the product has few tiles (the rule of
+        # include/mmdgan_hip.h): `zero_each_step` lists those halves - in prezeroed mode the caller zeroes them with the step's
+        # other accumulation targets
+        sizes = []
+        for L in self.keep:
+            if int(L['form']) <= 1:
+                P, Q = out_hw(int(L['H']), int(L['W']), int(L['stride']))
+                sizes.append((P * Q, int(L['R']) ** 2 * int(L['C'])))
+        self.col_flat = torch.zeros(max(4, sum((2 * pq * r2c + 3) // 4 * 4 for pq, r2c in sizes)), device=device, dtype=torch.float32)
+        self.zero_each_step = []
+        col_off = 0
         self.norm_acc = torch.zeros(4 * max(1, len(self.keep)), device=device, dtype=torch.float32)
         for i, (t, L) in enumerate(zip(self.table, self.keep)):
             t.norm_acc = self.norm_acc.data_ptr() + 16 * i
@@ -443,10 +454,12 @@ class SnChains:
             for k in ('H', 'W', 'C', 'K', 'R', 'stride'):
                 setattr(t, k, int(L.get(k, 1)))
             if t.form <= 1:
-                P, Q = out_hw(t.H, t.W, t.stride)
-                col = torch.empty(2 * P * Q * t.R * t.R * t.C, device=device, dtype=torch.float32)
-                self.cols.append(col)
-                t.col = col.data_ptr()
+                pq, r2c = sizes.pop(0)
+                t.col = self.col_flat.data_ptr() + 4 * col_off
+                if -(-pq // 64) * -(-r2c // 64) < 128:
+                    half = col_off + (pq * r2c if t.form == 0 else 0)
+                    self.zero_each_step.append(self.col_flat[half:half + pq * r2c])
+                col_off += (2 * pq * r2c + 3) // 4 * 4
 
     def run(self, update=True, stream=None):
         if self.keep:

@@ -1332,7 +1332,7 @@ class TapeEngine:
         main = ops._stream()
         # everything the step accumulates into that is not a gradient arena (power-iteration targets, <G, W> scalars,
         # batch-norm totals of the backward pass, folded-kernel gradients): one small launch, first thing
-        ops.memset_zero_multi([self._zero_scratch])
+        ops.memset_zero_multi([self._zero_scratch] + [t for c in self._sn_chains.values() for t in c[0].zero_each_step])
         lib.mmdgan_set_outputs_prezeroed(1)
         self._sn_zeroed = True
         try:

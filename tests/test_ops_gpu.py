@@ -1069,6 +1069,7 @@ def test_power_iterations_of_many_kernels_in_six_launches(ops):
     for L in layers:                                     # garbage in the accumulators: the entry zeroes them itself
         for k in ('u', 'xb', 'dsigma'):
             L[k].fill_(float('nan'))
+    chains.col_flat.fill_(float('nan'))                  # the entry zeroes what it accumulates into: whatever was there before
     chains.run(update=False)
     check(False)
     chains.run(update=True)
@@ -1078,6 +1079,9 @@ def test_power_iterations_of_many_kernels_in_six_launches(ops):
         L['x'].copy_(x_old)
         for k in ('u', 'xb', 'dsigma'):
             L[k].zero_()
+    chains.col_flat.fill_(float('nan'))                  # (the patch matrices that hold split products too - and only those)
+    for t in chains.zero_each_step:
+        t.zero_()
     lib.mmdgan_set_outputs_prezeroed(1)
     try:
         chains.run(update=True)
