@@ -548,7 +548,7 @@ class NetForward:
         run = TapeEngine.__new__(TapeEngine)
         run.device, run._bufs, run._wino, run._in_step, run._sn_zeroed = self.device, {}, {}, False, False
         run._folded = {k.scope: [None, None] for k in self.net.kernels}
-        run._graphs, run._fusions, run._out_buffer = {}, {}, None
+        run._graphs, run._fusions, run._out_buffer, run._ready_wait = {}, {}, None, None
         self._run = run
 
     def __call__(self, x_nhwc, is_training=False):
@@ -627,6 +627,8 @@ class TapeEngine:
         self._sn_zeroed = False                                          # inside step(): the power iteration's targets are zeroed
         self._exchange_pending = False
         self._fuse_fanin = settings.on('MMDGAN_TAPE_FUSE_ADD')
+        self._ready_wait = None
+        self._early_d_adam = settings.on('MMDGAN_EARLY_D_ADAM')
         self._bn_resign = settings.on('MMDGAN_BN_RESIGN')
         self._d_has_bn = bool(self.dis.bns)
         lib = ops.require_device()
@@ -689,6 +691,7 @@ class TapeEngine:
                 if p['kind'] == 'bn':
                     c = net.shapes[p['out']][0]
                     sizes.append((p, '_ws_bwd', max(lib.mmdgan_bn_workspace_bytes(c) // 4, 4)))
+                    sizes.append((p, '_ws_fwd', max(lib.mmdgan_bn_workspace_bytes(c) // 4, 4)))   # (one memset per BN layer otherwise)
                     if net is self.dis:                # the loss_gen pass through a D with batch norm: totals of its own
                         sizes += [(p, '_ws_bwd2', max(lib.mmdgan_bn_workspace_bytes(c) // 4, 4)), (p, '_gg2', c), (p, '_gb2', c)]
             for k in net.kernels:                          # weight gradients of the folded 4x4 kernels (atomics)
@@ -900,6 +903,9 @@ class TapeEngine:
             key = (tag, net.name, i)
             out_shape = _native(net.shapes[p['out']], n)
             addend = vals[fused_addend[i]] if i in fused_addend else None     # a branch sum riding on this launch
+            if self._ready_wait is not None and kind in ('conv', 'gconv', 'upconv', 'convdown', 'tconv'):
+                ops.event_wait(self._ready_wait, ops._stream())          # this step's composed / transformed weights (_step_body)
+                self._ready_wait = None
             if kind == 'reshape':
                 y = a.reshape(out_shape)
             elif kind in ('dense', 'conv'):
@@ -947,10 +953,19 @@ class TapeEngine:
                 x2, y2 = a.reshape(-1, c), y.view(-1, c)
                 if training:
                     mean, invstd = self._buf(key + ('mean',), [c]), self._buf(key + ('invstd',), [c])
-                    ws = self._buf(key + ('ws',), [max(lib.mmdgan_bn_workspace_bytes(c) // 4, 4)])
                     p['_saved'] = (mean, invstd)
-                    ops.bn_fwd_train(x2, gamma, beta, mm, mv, act=p['act'], unbiased=a.dim() == 4, new_moving_mean=mm,
-                                     new_moving_var=mv, out=y2, save_mean=mean, save_invstd=invstd, workspace=ws)
+                    # inside a step the totals lie in the scratch the step zeroed with its first launch (the entry's own
+                    # memset was 5 us on the main stream in front of every batch norm: 9 of them in the ResNet-SN generator)
+                    zeroed = self._in_step and torch.is_tensor(p.get('_ws_fwd'))
+                    ws = p['_ws_fwd'] if zeroed else self._buf(key + ('ws',), [max(lib.mmdgan_bn_workspace_bytes(c) // 4, 4)])
+                    if zeroed:
+                        lib.mmdgan_set_outputs_prezeroed(1)
+                    try:
+                        ops.bn_fwd_train(x2, gamma, beta, mm, mv, act=p['act'], unbiased=a.dim() == 4, new_moving_mean=mm,
+                                         new_moving_var=mv, out=y2, save_mean=mean, save_invstd=invstd, workspace=ws)
+                    finally:
+                        if zeroed:
+                            lib.mmdgan_set_outputs_prezeroed(0)
                 else:
                     ops.bn_fwd_infer(x2, gamma, beta, mm, mv, act=p['act'], out=y2)
             elif kind == 'act':
@@ -1346,6 +1361,8 @@ class TapeEngine:
                     ops.memset_zero_multi([self.gen.grads, self.dis.grads])
                     self._transform_weights(self.dis)
                     ops.event_record(_EV_DIS_READY, self._wg_raw)
+                    # (the step counts and bias-corrected learning rates of both updates need no gradient: here, not at the tail)
+                    ops.adam_prepare_multi([(self.dis.opt, self.lr_d), (self.gen.opt, self.lr_g)])
                 ops.stream_wait(self._sn_raw, main)
                 with torch.cuda.stream(self._sn_stream):                 # depend on the weights only; G's first
                     if any(k.sn for k in self.gen.kernels):
@@ -1353,7 +1370,9 @@ class TapeEngine:
                         ops.event_record(_EV_GEN_SN_READY, self._sn_raw)
                         ops.event_wait(_EV_GEN_SN_READY, main)
                     self._sn_all(self.dis)
-                ops.event_wait(_EV_GEN_READY, main)
+                # (G's composed / transformed weights are waited for where its first convolution starts - _forward: a dense
+                # first layer and its batch norm run beside the transforms, which themselves wait for the previous step's Adam)
+                self._ready_wait = _EV_GEN_READY
             else:
                 ops.memset_zero_multi([self.gen.grads, self.dis.grads])
                 self._compose_weights(self.gen)
@@ -1370,6 +1389,7 @@ class TapeEngine:
             # G's output goes straight into the fake half of D's input (my_sngan.py:278: D sees [real ; fake]); the real half
             # IS the batch buffer
             gvals = self._forward(self.gen, self._static_z, True, 'g', out_buffer=self._dis_in[B:])
+            self._ready_wait = None                                      # (no convolution in G: _EV_DIS_READY below is later on the same stream)
             if self._side:
                 ops.stream_wait(main, self._sn_raw)
                 ops.event_wait(_EV_DIS_READY, main)
@@ -1395,6 +1415,13 @@ class TapeEngine:
                 else:
                     d_in = self._backward(self.dis, dvals, ds[2 * B:3 * B], 'bg', rows=(B, 2 * B), param_grads=False,
                                           need_input_grad=True)
+            d_early = self._side and self._early_d_adam and not self._dp_active()
+            if d_early:
+                # D's gradients are complete once the weight-gradient stream has drained what it holds now and the main stream
+                # has reached this point; nothing in G's backward pass reads D's weights: D's Adam runs beside it, not at the tail
+                ops.stream_wait(self._wg_raw, main)
+                with torch.cuda.stream(self._wg_stream):
+                    self.dis.opt.step(self.lr_d, grad_scale=1.0)
             self._backward(self.gen, gvals, d_in, 'gb', param_grads=True)
             if self._side:
                 ops.stream_wait(main, self._wg_raw)
@@ -1405,7 +1432,8 @@ class TapeEngine:
             ops.stream_wait(main, self._sn_raw)
             self._exchange_pending = False
         gs = 1.0 / self.world
-        self.dis.opt.step(self.lr_d, grad_scale=gs)
+        if not d_early:
+            self.dis.opt.step(self.lr_d, grad_scale=gs)
         self.gen.opt.step(self.lr_g, grad_scale=gs)
 
     def step(self, real_nhwc=None, z=None, uni=None):
