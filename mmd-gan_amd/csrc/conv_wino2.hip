@@ -22,6 +22,14 @@
 #include "wino_weight.h"
 
 
+// Ablation hooks for tools/wino2_ablate.sh (what each part of wino2_kernel costs): a bit mask, 0 in the library build - every
+// test below is a compile-time constant, the shipped code object is the one without them.  1: patch loads of the main loop,
+// 2: B-fragment loads, 4: A-fragment reads, 8: input transform + V stores, 16: stage barrier, 32: epilogue operand loads,
+// 64: epilogue stores, 128: the whole epilogue (the accumulators are summed into a store that never happens).
+#ifndef W2_ABLATE
+#define W2_ABLATE 0
+#endif
+
 namespace mmdgan {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -327,14 +335,16 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
 #pragma unroll
                     for (int m = 0; m < NM; ++m)
                         if (m < nm) {
-                            if (h == 0) W2_ALOAD(1, cur, g, 1, m)
+                            if (W2_ABLATE & 4) {}
+                            else if (h == 0) W2_ALOAD(1, cur, g, 1, m)
                             else if (g + 1 < 4) W2_ALOAD(0, cur, g + 1, 0, m)
                         }
                     if (h == 0) {
 #pragma unroll
                         for (int m = 0; m < NM; ++m)
                             if (m < nm) {
-                                if (g + 1 < 4) W2_BLOAD((g + 1) & 1, g + 1, m, boff_cur)
+                                if (W2_ABLATE & 2) {}
+                                else if (g + 1 < 4) W2_BLOAD((g + 1) & 1, g + 1, m, boff_cur)
                                 else W2_BLOAD(0, 0, m, boff_nxt)
                             }
                     }
@@ -349,23 +359,23 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
                                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[m], 0, 0, 0);
                             }
                         // stage L+1 -> LDS (groups 0, 1: one channel pair each), stage L+2 -> registers (group 2: one patch row per step)
-                        if (g == 0 && q == 1) W2_VSTORE_PAIR(nxt, 0, x, z)
-                        else if (g == 1 && q == 1) W2_VSTORE_PAIR(nxt, 1, y, w)
-                        else if (g == 2 && q == 0) W2_XLOAD_ROW(0)
-                        else if (g == 2 && q == 1) W2_XLOAD_ROW(1)
-                        else if (g == 2 && q == 2) { W2_XLOAD_ROW(2) advance_load(); }
+                        if (g == 0 && q == 1) { if (!(W2_ABLATE & 8)) W2_VSTORE_PAIR(nxt, 0, x, z) }
+                        else if (g == 1 && q == 1) { if (!(W2_ABLATE & 8)) W2_VSTORE_PAIR(nxt, 1, y, w) }
+                        else if (g == 2 && q == 0) { if (!(W2_ABLATE & 1)) W2_XLOAD_ROW(0) }
+                        else if (g == 2 && q == 1) { if (!(W2_ABLATE & 1)) W2_XLOAD_ROW(1) }
+                        else if (g == 2 && q == 2) { if (!(W2_ABLATE & 1)) W2_XLOAD_ROW(2) advance_load(); }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
-            __syncthreads();
+            if (!(W2_ABLATE & 16)) __syncthreads();
             par ^= 1;
             boff_cur = boff_nxt;
         }
         // ---- output transform + epilogue in the V buffer the last stage has just released (the other one holds the next
         // item's first stage): Ms[f][tile][k 32], one column block at a time
         float *Ms = smem + (par ^ 1) * V_FLOATS;
-        if (ep.dact) {
+        if (ep.dact && !(W2_ABLATE & 32)) {
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -376,6 +386,16 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
                     dv[c][i2][1] = bufld4(rd, dact_off(o + arow));
                 }
         }
+        if (W2_ABLATE & 128) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int m = 0; m < NM; ++m)
+                if (m < nm) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc += acc[m][r];
+                }
+            if (sacc == 1.2345e33f) bufst4(ro, ob_it[0], make_float4(sacc, 0.f, 0.f, 0.f));
+        } else
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             if (cb == c) {
@@ -407,14 +427,14 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
                         float4 v = make_float4(z[a].x + z[a + 1].x, z[a].y + z[a + 1].y, z[a].z + z[a + 1].z, z[a].w + z[a + 1].w);
                         v.x = v.x * sc + bv.x; v.y = v.y * sc + bv.y; v.z = v.z * sc + bv.z; v.w = v.w * sc + bv.w;
                         if (ep.dact) {
-                            const float4 yv = dv[c][i2][a];
+                            const float4 yv = (W2_ABLATE & 32) ? make_float4(1.f, -1.f, 1.f, -1.f) : dv[c][i2][a];
                             v.x *= act_bwd_from_out(yv.x, ep.act); v.y *= act_bwd_from_out(yv.y, ep.act);
                             v.z *= act_bwd_from_out(yv.z, ep.act); v.w *= act_bwd_from_out(yv.w, ep.act);
                         } else {
                             v.x = act_fwd(v.x, ep.act); v.y = act_fwd(v.y, ep.act);
                             v.z = act_fwd(v.z, ep.act); v.w = act_fwd(v.w, ep.act);
                         }
-                        bufst4(ro, ob + a * arow + b * bcol + (unsigned)(ch * 4), v);
+                        if (!(W2_ABLATE & 64) || v.x == 1.2345e33f) bufst4(ro, ob + a * arow + b * bcol + (unsigned)(ch * 4), v);
                     }
                 }
             }
