@@ -803,7 +803,9 @@ class GanEngine:
             if s.sn and not (self._sn_fused and waited):
                 # a layer waits for ITS power iteration only, not for both chains (measured: no difference at CIFAR B=64, where
                 # the chains finish under G's forward pass; tried with it: D's real half as a separate half-batch pass on the
-                # parameter-gradient stream underneath G's forward pass - 3.05 instead of 2.33 ms per step, dropped)
+                # parameter-gradient stream underneath G's forward pass - 3.05 instead of 2.33 ms per step, dropped; again in round 4 with
+                # the reduction-split launches and the split-K head: 1.92 instead of 1.87 ms - a half-batch pass of D takes 230-250 us
+                # against 325 for the whole batch, more than G's forward pass leaves idle)
                 ops.event_wait(_EV_SN0 + (0 if self._sn_fused else i), main)
                 waited = True
             scale = self._scales[s.scope]
