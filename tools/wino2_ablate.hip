@@ -59,6 +59,11 @@ int main(int argc, char **argv) {
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         tot += ms; if (ms < best) best = ms;
     }
+    std::vector<float> o((size_t)(dgrad ? nx : ny));
+    (void)hipMemcpy(o.data(), out, o.size() * 4, hipMemcpyDeviceToHost);
+    double cs = 0, ca = 0;
+    for (size_t i = 0; i < o.size(); ++i) { cs += o[i] * (double)(1 + (i % 7)); ca += fabs((double)o[i]); }
+    printf("  output checksum %.9e  sum|.| %.9e\n", cs, ca);
     const double gflop = 2.0 * N * H * H * C * 16.0 * K / (dgrad ? 1 : 4) / 1e9 * (dgrad ? 1 : 4);
     printf("ablate %3d  grid %4d | N=%d H=%d C=%d K=%d %s: %ld items  %.2f us (best of 5 x 50: %.2f)  [%s]\n", W2_ABLATE, grid,
            N, H, C, K, dgrad ? "dgrad" : "fwd", nitems, tot / 250 * 1e3, best / 50 * 1e3, hipGetErrorString(hipGetLastError()));
