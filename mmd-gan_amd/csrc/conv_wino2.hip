@@ -42,7 +42,7 @@ constexpr int V_FLOATS = 9 * FSV;
 constexpr int MS_FLOATS = 9 * 32 * 32;       // epilogue exchange buffer (one column block at a time), Ms[f][tile][k 32]
 static_assert(MS_FLOATS <= V_FLOATS, "the epilogue buffer is the V buffer the last stage released");
 constexpr int SMEM_FLOATS = 2 * V_FLOATS;
-constexpr int OB_SLOTS = 4;             // items whose output offsets are live at once: the load cursor runs up to TWO items ahead (2-stage items)
+constexpr int OB_SLOTS = 4;             // ring of items whose output offsets are kept (two are live at once, see the kernel)
 constexpr size_t LDS_BYTES = sizeof(float) * SMEM_FLOATS + sizeof(unsigned) * 32 * OB_SLOTS + sizeof(int) * 4;
 constexpr int NM = 5;                   // frequencies per wave (the waves with the odd frequencies use 4)
 
@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void wino2_weight_kernel(const float *__restri
 
 // PERSISTENT and CONTINUOUS: the grid is (at most) two workgroups per CU, every workgroup walks a contiguous run of work
 // items (tile block, phase, column block), and the stages of ALL its items form one software pipeline: while stage L is
-// multiplied, stage L+1 goes registers -> LDS and stage L+2 global -> registers, across item boundaries.  An item of the
+// multiplied, stage L+1 goes global -> registers (under the first MFMA group) -> LDS (under the last two), across item
+// boundaries (until round 4 stage L+2 was in registers as well: a stage deeper, four registers more, 0-1.3 % slower).  An item of the
 // launch this was built for (the 3B-row input-gradient of D l2: 1536 items) is only four stages long; as one workgroup per
 // item (round 2) each paid a serial prologue (patch load -> transform -> barrier), and its epilogue's stores sat in front
 // of the next workgroup's first loads.  Now the only thing between two items is the epilogue (accumulators -> LDS -> output
@@ -98,12 +99,12 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
                                                        const float *__restrict__ U, float *__restrict__ out) {
     using namespace wino2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // [item % OB_SLOTS][tile]: output byte offset of the tile.  A ring of FOUR items, not two: the load cursor is two STAGES
-    // ahead of the multiply, which for items of two stages (64 reduction channels, e.g. the 64 -> 64 first block of the
-    // ResNet-SN discriminator) is a whole item - finishing item i+1's loads during item i's last stage it enters item i+2
-    // BEFORE item i's epilogue has read its offsets.  (With two slots that epilogue stored item i's tiles at item i+2's
-    // addresses: wrong input-gradients whenever a workgroup walked three or more such items - found by the parity test at
-    // the ResNet config's own batch, tests/test_production_gpu.py.)
+    // [item % OB_SLOTS][tile]: output byte offset of the tile.  The load cursor is one stage ahead of the multiply: it enters
+    // item i+1 during item i's last stage, before item i's epilogue has read its offsets - two slots are in use at a time.
+    // The ring stays at FOUR: with the two-stage-deep pipeline of rounds 3-4 the cursor of a two-stage item (64 reduction
+    // channels, e.g. the 64 -> 64 first block of the ResNet-SN discriminator) was a whole item further, and a ring of two
+    // stored item i's tiles at item i+2's addresses (found by the parity test at the ResNet config's own batch,
+    // tests/test_production_gpu.py); the spare slots cost 256 bytes.
     unsigned *obase = reinterpret_cast<unsigned *>(smem + SMEM_FLOATS);
     int *wgctl = reinterpret_cast<int *>(obase + 32 * OB_SLOTS);
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
     const __amdgpu_buffer_rsrc_t rd = make_rsrc(ep.dact ? ep.dact : x, wraps ? ep.wrap_from * 4 : (long)P.N * P.OH * P.OW * P.Ko * 4);
     auto dact_off = [&](unsigned o) { return (o >= wrap_from ? o - wrap_sub : o) | (o & kOOB); };   // (a missing tile stays out of range)
 
-    // ---- the LOAD cursor (stage L+2: global -> registers): item, segment, channel block; per thread the tile it loads
+    // ---- the LOAD cursor (stage L+1: global -> registers): item, segment, channel block; per thread the tile it loads
     int l_it = 0, l_seg = 0, l_cs = 0, l_phase = 0;
     int ty = 0, tx = 0, tn = 0;
     bool tile_ok = false;
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
     // A fragments of k-pairs 2H, 2H+1 of group G from buffer BUF into slot SL
 #define W2_ALOAD(SL, BUF, G, H, M) fa[SL][M] = *reinterpret_cast<const float2 *>((BUF) + abase + 2 * (M) * FSV + (G) * 2 * ROW + 2 * (H));
 
-    // ---- fill the pipeline: stage 0 -> LDS, stage 1 -> registers, B fragments of stage 0 / group 0
+    // ---- fill the pipeline: stage 0 -> LDS, B fragments of stage 0 / group 0
     enter_item();
     b_item();
     unsigned boff_cur = stage_boff();
@@ -297,8 +298,6 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
     for (int m = 0; m < NM; ++m)
         if (m < nm) W2_BLOAD(0, 0, m, boff_cur)
     W2_VSTORE_PAIR(smem, 0, x, z) W2_VSTORE_PAIR(smem, 1, y, w)
-    W2_XLOAD_ROW(0) W2_XLOAD_ROW(1) W2_XLOAD_ROW(2)          // (nstages >= 2: stage 1 exists)
-    advance_load();
     __syncthreads();
     int par = 0;
 
@@ -358,12 +357,13 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
                                 const float b = q == 0 ? fb[g & 1][m].x : q == 1 ? fb[g & 1][m].y : q == 2 ? fb[g & 1][m].z : fb[g & 1][m].w;
                                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[m], 0, 0, 0);
                             }
-                        // stage L+1 -> LDS (groups 0, 1: one channel pair each), stage L+2 -> registers (group 2: one patch row per step)
-                        if (g == 0 && q == 1) { if (!(W2_ABLATE & 8)) W2_VSTORE_PAIR(nxt, 0, x, z) }
-                        else if (g == 1 && q == 1) { if (!(W2_ABLATE & 8)) W2_VSTORE_PAIR(nxt, 1, y, w) }
-                        else if (g == 2 && q == 0) { if (!(W2_ABLATE & 1)) W2_XLOAD_ROW(0) }
-                        else if (g == 2 && q == 1) { if (!(W2_ABLATE & 1)) W2_XLOAD_ROW(1) }
-                        else if (g == 2 && q == 2) { if (!(W2_ABLATE & 1)) W2_XLOAD_ROW(2) advance_load(); }
+                        // stage L+1: global -> registers under group 0 (one patch row per step), registers -> LDS under groups 2 and 3
+                        // (one channel pair each): nothing of it lives in registers across the stage barrier or the epilogue
+                        if (g == 0 && q == 0) { if (!(W2_ABLATE & 1)) W2_XLOAD_ROW(0) }
+                        else if (g == 0 && q == 1) { if (!(W2_ABLATE & 1)) W2_XLOAD_ROW(1) }
+                        else if (g == 0 && q == 2) { if (!(W2_ABLATE & 1)) W2_XLOAD_ROW(2) advance_load(); }
+                        else if (g == 2 && q == 1) { if (!(W2_ABLATE & 8)) W2_VSTORE_PAIR(nxt, 0, x, z) }
+                        else if (g == 3 && q == 1) { if (!(W2_ABLATE & 8)) W2_VSTORE_PAIR(nxt, 1, y, w) }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
