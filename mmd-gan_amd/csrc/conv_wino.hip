@@ -145,20 +145,20 @@ __global__ __launch_bounds__(256, WINO_WAVES) void wino_kernel(int N, int H, int
         fb[FL][cb] = bufld4s(ru, ubase, (unsigned)(4 * wave + (FL)) * ufreq + (unsigned)(S) * ustage + cb * 512);
 #define WINO_ALOAD(SL, BUF, FL) fa[SL] = *reinterpret_cast<const float4 *>((BUF) + abase + (FL) * FSV);
 
-    // prologue: tile 0 -> LDS, tile 1 -> registers, B fragments of stage 0
+    // prologue: tile 0 -> LDS, B fragments of stage 0
     WINO_XLOAD(s_begin)
 #pragma unroll
     for (int fl = 0; fl < 4; ++fl) WINO_BLOAD(fl, s_begin)
     WINO_ROWPASS
     WINO_VSTORE(smem, 0) WINO_VSTORE(smem, 1) WINO_VSTORE(smem, 2) WINO_VSTORE(smem, 3)
-    WINO_XLOAD(s_begin + 1)
     __syncthreads();
     // A stage = 8 channels = 4 MFMA k-pairs.  The wave walks its four frequencies one after the other: the A fragments of a
     // frequency are ONE ds_read_b128 (fetched while the previous frequency is multiplied), its B fragments ONE 16-byte
     // load per column block, refilled for the next stage right after the last MFMA that reads them (3/4 of a stage ahead
     // of their use) - a quarter of the LDS / vector-memory instructions of the one-dword-per-MFMA form.  Every accumulator
-    // still sees its k-pairs in ascending order (bitwise the same sums).  The transform + LDS stores of tile s+1 and the
-    // global loads of tile s+2 sit behind individual MFMA groups (sched_barrier keeps hipcc from re-clumping them).
+    // still sees its k-pairs in ascending order (bitwise the same sums).  The global loads of tile s+1 sit behind the
+    // first MFMA group, its transform + LDS stores behind the last two (sched_barrier keeps hipcc from re-clumping them): one
+    // stage ahead, nothing in registers across the barrier (two stages ahead until round 4: CIFAR step 1.855 -> 1.843 ms).
     const int abase = wino::voff(4 * wave) + kh * ROW + l31 * 4;
     for (int s = s_begin; s < nstages; ++s) {
         const float *cur = smem + ((s - s_begin) & 1) * VF;
@@ -177,12 +177,12 @@ __global__ __launch_bounds__(256, WINO_WAVES) void wino_kernel(int N, int H, int
                     acc[fl][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[fl][cb], 0, 0, 0);
                 }
                 if (q == 3) WINO_BLOAD(fl, sn)
-                // tile s+1: row pass, then one frequency column per group; tile s+2: activations
-                if (fl == 0 && q == 0) { WINO_ROWPASS WINO_VSTORE(nxt, 0) }
-                else if (fl == 0 && q == 2) WINO_VSTORE(nxt, 1)
-                else if (fl == 1 && q == 0) WINO_VSTORE(nxt, 2)
-                else if (fl == 1 && q == 2) WINO_VSTORE(nxt, 3)
-                else if (fl == 2 && q == 0) WINO_XLOAD(s + 2)
+                // tile s+1: activations, then row pass and one frequency column per half-group
+                if (fl == 0 && q == 0) WINO_XLOAD(s + 1)
+                else if (fl == 2 && q == 0) { WINO_ROWPASS WINO_VSTORE(nxt, 0) }
+                else if (fl == 2 && q == 2) WINO_VSTORE(nxt, 1)
+                else if (fl == 3 && q == 0) WINO_VSTORE(nxt, 2)
+                else if (fl == 3 && q == 2) WINO_VSTORE(nxt, 3)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
