@@ -519,6 +519,10 @@ def net_forward(specs, params, x, is_training=True, collect=None, masks=None):
     audit = masks.get('audit') if masks is not None else None
 
     def act(t, name):
+        if collect is not None and name in ('relu', 'lrelu'):
+            # graph-attached PRE-activations in evaluation order (oracle/make_golden.py measures and repairs the fixtures'
+            # activation margin on them: a relu's exact-zero outputs hide how close to zero their inputs were)
+            collect.setdefault('pre_acts', []).append(t)
         return _act(t, name, next(mask_iter) if (mask_iter is not None and name in ('relu', 'lrelu')) else None, audit)
 
     def batch_norm(t, prefix):                                # layer_func.py:953-966, SURVEY A.4

@@ -73,3 +73,8 @@ def pytest_terminal_summary(terminalreporter):
     terminalreporter.write_line('knife-edge retries (fallback to the engine\'s sign decisions): %d' % n)
     for what in helpers.KNIFE_EDGE_RETRIES:
         terminalreporter.write_line('  knife-edge retry: ' + what)
+    # ... and how often a gradient needed the escape clause of helpers.assert_grads_within_fp32_floor (above the plain 1e-4 L2 /
+    # 1e-3 entry-wise bars, inside twice the fp32 oracle's own loss)
+    terminalreporter.write_line('gradient tensors that took the fp32-floor clause: %d' % len(helpers.FLOOR_CLAUSE_USES))
+    for what in helpers.FLOOR_CLAUSE_USES:
+        terminalreporter.write_line('  fp32-floor clause: ' + what)

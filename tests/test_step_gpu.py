@@ -187,19 +187,20 @@ def test_free_run_from_warm_start_matches_reference(tag, engine):
                 # bias in front of a batch norm) are rounding noise in every implementation: 1e-6 of the net's scale
                 if close(g, ref, RTOL, 1e-6 * gscale[n[:3]]):
                     continue
-                # a relu / lrelu output within fp32 resolution of zero (the fixtures report their margin: ~1e-7 of the layer's
-                # scale - about one element in a million) is decided differently by an fp32 and an fp64 evaluation of the
-                # SAME algebra, and every gradient below that element moves by up to 1e-2.  The reference then is the
-                # restatement's fp64 trajectory under the engine's sign decisions - same bar.  ('gsn_rep' holds such an element
-                # in every run; 'rep' in one run in a hundred - 300 runs per launch mode, eager and plan alike: the atomics'
-                # order decides one element, the deviating runs agree with each other bit for bit in which)
+                # a relu / lrelu output within fp32 resolution of zero is decided differently by an fp32 and an fp64 evaluation of
+                # the SAME algebra, and every gradient below that element moves by up to 1e-2.  Through round 4 the warm-start
+                # fixtures held such elements (margins 7e-9 .. 1e-7 of the layer's scale; 'gsn_rep' took the path below in every
+                # run).  Since round 5 their recorded inputs are moved off every knife edge when they are generated
+                # (oracle/make_golden.py:_repair_step_inputs, `act_margin` >= 1e-5 asserted there and in
+                # tests/test_oracle_golden.py), so the path below - the restatement's fp64 trajectory under the engine's sign
+                # decisions as the reference - is now a FAILURE of these tests unless TEST_ALLOW_KNIFE_EDGE=1.
                 if forced is None:
                     audited = with_audit(masks_per_step)
                     forced, flipped = oracle_trajectory(fx, arch, str(fx['sn_mode']), torch.float64, step, audited), True
                     # ... which is a legitimate reference only if those decisions differ from the fp64 run's own at knife edges
                     n_diff, margin = assert_knife_edges_only(audited, (tag, engine, step))
                     note_knife_edge_retry('test_free_run_from_warm_start_matches_reference[%s-%s] step %d: %d decision(s), |pre-activation| '
-                                          '<= %.1e of the layer scale' % (tag, engine, step, n_diff, margin))
+                                          '<= %.1e of the layer scale' % (tag, engine, step, n_diff, margin), allowed=False)
                 assert close(g, forced[n], RTOL, 1e-6 * gscale[n[:3]]), (step, n, np.abs(g - forced[n]).max(), np.abs(ref).max())
     final_ref = oracle_trajectory(fx, arch, str(fx['sn_mode']), torch.float64, None, masks_per_step, want='final') if flipped else None
     pre = 'step%d/' % (n_steps - 1)
