@@ -66,6 +66,11 @@ extern "C" {
 #define MMDGAN_LOSS_FLAG_GRADS_DIS_FIRST 0x100
 
 const char *mmdgan_last_error(void);
+/* ABI version of this header: bumped whenever an entry's argument list, a workspace size or a calling rule changes
+ * (200: rounds 1-4 - although mmdgan_bn_bwd gained `beta` and mmdgan_bn_workspace_bytes grew in round 4 without a bump;
+ * 500: round 5 - mmdgan_wgrad_defer / mmdgan_wgrad_flush, BN workspace documented as [slots][2][C]).  A caller compares
+ * mmdgan_version() of the library it loaded with the MMDGAN_VERSION it was built against (mmdgan_hip/_lib.py does). */
+#define MMDGAN_VERSION 500
 int mmdgan_version(void);
 /* Which kernel a convolution call takes is decided by the geometry and by a handful of process-wide switches (environment
  * variables MMDGAN_*, read once: csrc/tuning.h lists them with their defaults - the defaults are the configuration the
@@ -106,6 +111,18 @@ int mmdgan_set_workspace(void *ptr, size_t bytes);
  * conv2d_dgrad split their reduction (and so accumulate) only for batch-1 geometries (N == 1, the
  * spectral-norm power iteration) and gemm splits only when the call carries MMDGAN_ACT_FLAG_OUT_ZEROED.  Default 0. */
 int mmdgan_set_outputs_prezeroed(int on);
+/* Deferred slab reduction.  The Winograd-domain weight gradients (mmdgan_conv2d_wgrad* on 3x3 / stride-1 and 4x4 /
+ * stride-2 geometries with a workspace) write one partial result per split of the pixel range into workspace slabs and sum
+ * them in a second, bandwidth-only launch.  With on = 1 that launch is not issued: the NEXT such weight-gradient call on the
+ * same stream sums the previous call's slabs in the prologue of its own kernel (every workgroup its 1/grid share; the two
+ * calls' slabs lie in different parts of the workspace), so a chain of weight gradients - a backward pass - carries no
+ * reduction launches except the last.  The sums are bit-identical in both modes.  Under on = 1 the outputs (dw, dbias,
+ * dot_gw) of such a call are complete only once one of these has been issued behind it: the stream's next slab
+ * weight-gradient call, any other workspace user of that stream, mmdgan_wgrad_flush(), or mmdgan_wgrad_defer(0) (which
+ * flushes).  A reader on another stream must be ordered behind that point.  Per handle; default 0.  (TF autodiff of
+ * layer_func.py:914 is what the chain replaces.) */
+int mmdgan_wgrad_defer(int on);
+int mmdgan_wgrad_flush(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Launch plans: take the host out of a static step.  The reference's step is one `sess.run` of a fixed graph
@@ -273,9 +290,12 @@ int mmdgan_dot(const float *a, const float *b, long n, float *out, void *stream)
  *      lrelu when beta is given: the derivative needs the SIGN of the forward value only, and the entry recomputes that value
  *      from x with the operations of the forward entry, bit for bit (a third less traffic than reading y back); beta is
  *      not read otherwise and may be NULL then.
- * workspace: mmdgan_bn_workspace_bytes(C) bytes of device scratch (2*C fp64 totals, accumulated with atomics).  The
+ * workspace: mmdgan_bn_workspace_bytes(C) bytes of device scratch - fp64 totals [slots][2][C], accumulated with atomics,
+ * the number of slots a function of C (up to 8): ALWAYS size it with mmdgan_bn_workspace_bytes, never as 2*C doubles.  The
  * entries zero it themselves, unless mmdgan_set_outputs_prezeroed(1) is in force: then it must be zero on entry and
  * distinct per call within a step (the forward and the backward call of a layer need separate totals).
+ * bwd with y == NULL recomputes the forward value from x, gamma, beta, save_mean and save_invstd: those five must still hold
+ * what the forward call read / wrote (no optimiser step on gamma / beta and no in-place change of x between the two calls).
  * ---------------------------------------------------------------------------------------------- */
 size_t mmdgan_bn_workspace_bytes(int C);
 int mmdgan_bn_fwd_train(const float *x, long rows, int C, const float *gamma, const float *beta, float eps,

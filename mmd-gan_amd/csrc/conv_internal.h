@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 #include "tuning.h"
+#include "slab_reduce.h"
 
 namespace mmdgan {
 
@@ -88,8 +89,10 @@ int wino_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, fl
                const float *wdot = nullptr, float *dot = nullptr, bool *dot_done = nullptr);
 // dw[n] = sum of nsplit slabs of n floats; dbias[k] = sum of nsplit rows of k floats (k = 0: none); dot[0] += <dw, wdot>.
 // conv_wino2.hip
-void slab_reduce(const float *part, int nsplit, size_t n, float *dw, const float *dbpart, int k, float *dbias, hipStream_t st,
-                 const float *wdot = nullptr, float *dot = nullptr);
+// Issued right away as a stand-alone pass, or - under mmdgan_wgrad_defer - left to the prologue of the stream's next slab
+// weight-gradient launch (slab_reduce.h).  Returns 0 or an error code.
+int slab_reduce(const float *part, int nsplit, size_t n, float *dw, const float *dbpart, int k, float *dbias, hipStream_t st,
+                const float *wdot = nullptr, float *dot = nullptr);
 
 // Winograd F(2x2,2x2) for 4x4 / stride-2 layers and their input-gradient (conv_wino2.hip); U = 36*C*K floats
 // out = epilogue(sum of nslabs partial results, `total` floats each): the second pass of a reduction-split Winograd launch

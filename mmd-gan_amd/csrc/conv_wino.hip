@@ -595,10 +595,13 @@ static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 template <bool DBIAS>
 __global__ __launch_bounds__(winos::NT) void wino_wgrad_slab_kernel(int N, int H, int W, int C, int K, const float *__restrict__ x,
                                                                     const float *__restrict__ dy, float *__restrict__ part,
-                                                                    float *__restrict__ dbpart, int stages_per_split) {
+                                                                    float *__restrict__ dbpart, int stages_per_split, SlabReduceArgs prev) {
     using namespace winos;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+    // the previous weight-gradient launch of this stream left its slabs un-summed (mmdgan_wgrad_defer): this workgroup's share first
+    slab_reduce_share(prev, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z, tid, NT,
+                      reinterpret_cast<double *>(smem));
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wv & 3, fh = wv >> 2;                       // 32-column quarter of the 128, frequency rows 2fh, 2fh + 1
     const int TH = H >> 1, TW = W >> 1;
@@ -815,7 +818,8 @@ int wino_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, fl
         const int sps = (nst + split - 1) / split;
         split = (nst + sps - 1) / sps;                                  // every slab gets written
         const size_t n = 9 * (size_t)d.C * d.K;
-        if (float *part = (float *)workspace_acquire(sizeof(float) * (n + d.K) * split, st)) {
+        SlabReduceArgs prev{};
+        if (float *part = (float *)wgrad_slabs_acquire(sizeof(float) * (n + d.K) * split, st, &prev)) {
             static bool cap_raised = false;
             if (!cap_raised) {
                 (void)hipFuncSetAttribute((const void *)wino_wgrad_slab_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)winos::LDS_BYTES);
@@ -826,11 +830,11 @@ int wino_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, fl
             const dim3 grid(d.C / winos::BC, d.K / winos::BK, split);
             if (dbias)
                 hipLaunchKernelGGL(wino_wgrad_slab_kernel<true>, grid, dim3(winos::NT), winos::LDS_BYTES, st, d.N, d.H, d.W, d.C, d.K, x, dy, part,
-                                   dbpart, sps);
+                                   dbpart, sps, prev);
             else
                 hipLaunchKernelGGL(wino_wgrad_slab_kernel<false>, grid, dim3(winos::NT), winos::LDS_BYTES, st, d.N, d.H, d.W, d.C, d.K, x, dy, part,
-                                   dbpart, sps);
-            slab_reduce(part, split, n, dw, dbpart, dbias ? d.K : 0, dbias, st, wdot, dot);
+                                   dbpart, sps, prev);
+            if (int rc = slab_reduce(part, split, n, dw, dbpart, dbias ? d.K : 0, dbias, st, wdot, dot)) return rc;
             if (dbias_done) *dbias_done = dbias != nullptr;
             if (dot_done) *dot_done = wdot != nullptr;
             return check_launch("conv2d_wgrad(winograd)");

@@ -643,10 +643,13 @@ static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 template <bool PART, bool DBIAS>
 __global__ __launch_bounds__(wino2w::NT) void wino2_wgrad_kernel(int N, int H, int W, int C, int K, const float *__restrict__ x,
                                                                  const float *__restrict__ dy, float *__restrict__ dw,
-                                                                 float *__restrict__ dbpart, int stages_per_split) {
+                                                                 float *__restrict__ dbpart, int stages_per_split, SlabReduceArgs prev) {
     using namespace wino2w;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+    // the previous weight-gradient launch of this stream left its slabs un-summed (mmdgan_wgrad_defer): this workgroup's share first
+    slab_reduce_share(prev, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z, tid, NT,
+                      reinterpret_cast<double *>(smem));
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wv & 1, wk = wv >> 1;                                   // 32-channel half of the 64, 32-column quarter of the 128
     const int P = H >> 1, Q = W >> 1, TH = P >> 1, TW = Q >> 1;
@@ -818,59 +821,37 @@ __global__ __launch_bounds__(wino2w::NT) void wino2_wgrad_kernel(int N, int H, i
         }
 }
 
-// dw[e] = sum over the splits' slabs (fixed order: deterministic).  One float4 per thread and trip, eight slab loads in flight.
+// dw[e] = sum over the splits' slabs in a fixed order (slab_reduce.h: deterministic, and the same bits as the prologue form).
 // Elements n4 .. n4 + k4 - 1 are the bias gradient: partial rows [split][K] -> dbias.
 // wdot (optional): dot[0] += <dw, wdot> on the way - the scalar the spectral-norm fix-up of this gradient needs
 // (mmdgan_conv2d_wgrad_sn): one atomic per workgroup instead of a separate pass over dw and the kernel.
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float4 *__restrict__ part, int nsplit, long n4, float4 *__restrict__ dw,
-                                                          const float4 *__restrict__ dbpart, long k4, float4 *__restrict__ dbias,
-                                                          const float4 *__restrict__ wdot, float *__restrict__ dot) {
+__global__ __launch_bounds__(256) void slab_reduce_kernel(SlabReduceArgs a) {
     __shared__ double red[4];
-    double acc = 0;
-    const long stride = (long)gridDim.x * 256;
-    for (long e0 = (long)blockIdx.x * 256 + threadIdx.x; e0 < n4 + k4; e0 += stride) {
-        long e = e0, slab = n4;
-        const float4 *src = part;
-        float4 *dst = dw;
-        const bool is_w = e < n4;
-        if (!is_w) { e -= n4; src = dbpart; slab = k4; dst = dbias; }
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        int s = 0;
-        for (; s + 8 <= nsplit; s += 8) {
-            float4 v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = src[(long)(s + q) * slab + e];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { a.x += v[q].x; a.y += v[q].y; a.z += v[q].z; a.w += v[q].w; }
-        }
-        for (; s < nsplit; ++s) {
-            const float4 b = src[(long)s * slab + e];
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-        }
-        dst[e] = a;
-        if (wdot && is_w) {
-            const float4 wv = wdot[e];
-            acc += (double)a.x * wv.x + (double)a.y * wv.y + (double)a.z * wv.z + (double)a.w * wv.w;
-        }
-    }
-    if (wdot) {                                            // (kernel-uniform)
-        acc = wave_sum(acc);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-        __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(dot, (float)(red[0] + red[1] + red[2] + red[3]));
-    }
+    slab_reduce_share<2>(a, blockIdx.x, gridDim.x, threadIdx.x, 256, red);   // (a small register footprint: it runs beside MFMA kernels)
 }
 
-void slab_reduce(const float *part, int nsplit, size_t n, float *dw, const float *dbpart, int k, float *dbias, hipStream_t st,
-                 const float *wdot, float *dot) {
-    const long n4 = (long)(n / 4), k4 = k / 4;
-    long blocks = (n4 + k4 + 255) / 256;
+void slab_reduce_launch(const SlabReduceArgs &a, hipStream_t st) {
+    const long total = a.n4 + a.k4;
+    long blocks = (total + 63) / 64;                    // >= one 1 KB run per workgroup
     // at most 512 workgroups: this pass runs on the weight-gradient stream beside the main stream's launches, and more of its
     // small workgroups cost those launches more than they save here (CIFAR step, cap 2048 / 1024 / 512 / 256 / 128: 1.931 / 1.919 /
     // 1.910 / 1.922 / 1.966 ms; CelebA flat down to 512)
     if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float4 *)part, nsplit, n4, (float4 *)dw,
-                       (const float4 *)dbpart, k4, (float4 *)dbias, (const float4 *)wdot, dot);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+}
+
+static SlabReduceArgs slab_args(const float *part, int nsplit, size_t n, float *dw, const float *dbpart, int k, float *dbias,
+                                const float *wdot, float *dot) {
+    SlabReduceArgs a;
+    a.part = (const float4 *)part; a.nsplit = nsplit; a.n4 = (long)(n / 4); a.dw = (float4 *)dw;
+    a.dbpart = (const float4 *)dbpart; a.k4 = k / 4; a.dbias = (float4 *)dbias; a.wdot = (const float4 *)wdot; a.dot = dot;
+    return a;
+}
+// what a slab weight-gradient launch leaves behind: summed right away by the stand-alone pass, or - mmdgan_wgrad_defer - by
+// the prologue of the next weight-gradient launch on this stream (core.hip)
+int slab_reduce(const float *part, int nsplit, size_t n, float *dw, const float *dbpart, int k, float *dbias, hipStream_t st,
+                const float *wdot, float *dot) {
+    return wgrad_slabs_release(slab_args(part, nsplit, n, dw, dbpart, k, dbias, wdot, dot), st);
 }
 
 // MMDGAN_WINO2_WGRAD=0 keeps the stride-2 weight gradients on the direct implicit-GEMM kernel, =1 uses this one;
@@ -911,27 +892,28 @@ int wino2_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, f
     }
     if (dbias_done) *dbias_done = false;
     const dim3 grid(d.C / wino2w::BC, d.K / wino2w::BK, 4 * split);
-    if (float *part = (float *)workspace_acquire(sizeof(float) * (n + d.K) * split, st)) {
+    SlabReduceArgs prev{};
+    if (float *part = (float *)wgrad_slabs_acquire(sizeof(float) * (n + d.K) * split, st, &prev)) {
         float *dbpart = part + n * split;
         if (dbias)
             hipLaunchKernelGGL((wino2_wgrad_kernel<true, true>), grid, dim3(wino2w::NT), wino2w::LDS_BYTES, st, d.N, d.H, d.W, d.C, d.K, x, dy, part,
-                               dbpart, sps);
+                               dbpart, sps, prev);
         else
             hipLaunchKernelGGL((wino2_wgrad_kernel<true, false>), grid, dim3(wino2w::NT), wino2w::LDS_BYTES, st, d.N, d.H, d.W, d.C, d.K, x, dy, part,
-                               dbpart, sps);
-        slab_reduce(part, split, n, dw, dbpart, dbias ? d.K : 0, dbias, st, wdot, dot);
+                               dbpart, sps, prev);
+        if (int rc = slab_reduce(part, split, n, dw, dbpart, dbias ? d.K : 0, dbias, st, wdot, dot)) return rc;
         if (dbias_done) *dbias_done = dbias != nullptr;
         if (dot_done) *dot_done = wdot != nullptr;
         return check_launch("conv2d_wgrad(winograd 2x2)");
     }
     if (split == 1) {                           // one slab: straight into dw
         hipLaunchKernelGGL((wino2_wgrad_kernel<true, false>), grid, dim3(wino2w::NT), wino2w::LDS_BYTES, st, d.N, d.H, d.W, d.C, d.K, x, dy, dw,
-                           (float *)nullptr, sps);
+                           (float *)nullptr, sps, SlabReduceArgs{});
         return check_launch("conv2d_wgrad(winograd 2x2)");
     }
     if (zero_output(dw, sizeof(float) * n, st) != hipSuccess) return check_launch("conv2d_wgrad memset");
     hipLaunchKernelGGL((wino2_wgrad_kernel<false, false>), grid, dim3(wino2w::NT), wino2w::LDS_BYTES, st, d.N, d.H, d.W, d.C, d.K, x, dy, dw,
-                       (float *)nullptr, sps);
+                       (float *)nullptr, sps, SlabReduceArgs{});
     return check_launch("conv2d_wgrad(winograd 2x2)");
 }
 

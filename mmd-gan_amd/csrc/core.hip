@@ -1,5 +1,6 @@
 // error state, version, device probe, handles (workspace / prezeroed mode / launch plans / events)
 #include "common.h"
+#include "slab_reduce.h"
 #include "tuning.h"
 
 #include <cxxabi.h>
@@ -44,6 +45,15 @@ struct mmdgan_handle {
     size_t ws_bytes = 0;
     bool prezeroed = false;
     struct WsSlot { bool used = false; hipStream_t st = nullptr; } ws_slot[2];   // halves of the workspace: their latest users
+    // mmdgan_wgrad_defer: the slab reduction the last weight-gradient launch left for the next one on its stream
+    bool defer = false;
+    struct Pending {
+        bool active = false;
+        mmdgan::SlabReduceArgs args{};
+        hipStream_t st = nullptr;
+        int half = 0, sub = 0;         // where its slabs lie: half of the workspace, ping-pong part of that half
+    } pending;
+    int acq_half = 0, acq_sub = -1;    // what the last wgrad_slabs_acquire handed out (sub -1: an ordinary workspace_acquire)
     std::unique_ptr<mmdgan::Plan> recording;
     std::vector<std::unique_ptr<mmdgan::Plan>> plans;      // plan id = index (destroyed plans leave a null slot)
     std::vector<hipEvent_t> pool;                          // round-robin pool of the un-recorded stream_wait calls
@@ -71,21 +81,73 @@ void *workspace(size_t need) {
 // weight gradients beside them) then never touch each other's partial sums and need no ordering.  Whoever must take a half
 // (or the whole buffer) after ANOTHER stream is ordered behind that stream first (event record + wait, recorded into a
 // plan like any dependency), so concurrent chains serialise there instead of corrupting each other.
+static int ws_half_for(const mmdgan_handle &h, hipStream_t st) {
+    return (h.ws_slot[0].used && h.ws_slot[0].st == st) ? 0 : (h.ws_slot[1].used && h.ws_slot[1].st == st) ? 1
+         : !h.ws_slot[0].used ? 0 : !h.ws_slot[1].used ? 1 : 0;
+}
+static bool ws_take(mmdgan_handle &h, int i, hipStream_t st) {           // slot i goes to `st`, behind its previous user
+    mmdgan_handle::WsSlot &s = h.ws_slot[i];
+    if (s.used && s.st != st && mmdgan_stream_wait((void *)st, (void *)s.st) != MMDGAN_OK) return false;
+    s.used = true;
+    s.st = st;
+    return true;
+}
 void *workspace_acquire(size_t need, hipStream_t st) {
     mmdgan_handle &h = cur();
     if (!h.ws || need > h.ws_bytes) return nullptr;
     const size_t half = (h.ws_bytes / 2) & ~(size_t)255;
-    auto take = [&](int i) -> bool {                       // slot i goes to `st`, behind its previous user
-        mmdgan_handle::WsSlot &s = h.ws_slot[i];
-        if (s.used && s.st != st && mmdgan_stream_wait((void *)st, (void *)s.st) != MMDGAN_OK) return false;
-        s.used = true;
-        s.st = st;
-        return true;
-    };
-    if (need > half) return (take(0) && take(1)) ? h.ws : nullptr;
-    int i = (h.ws_slot[0].used && h.ws_slot[0].st == st) ? 0 : (h.ws_slot[1].used && h.ws_slot[1].st == st) ? 1
-          : !h.ws_slot[0].used ? 0 : !h.ws_slot[1].used ? 1 : 0;
-    return take(i) ? (char *)h.ws + (size_t)i * half : nullptr;
+    h.acq_sub = -1;
+    if (need > half) {
+        if (h.pending.active && wgrad_flush_pending() != 0) return nullptr;
+        return (ws_take(h, 0, st) && ws_take(h, 1, st)) ? h.ws : nullptr;
+    }
+    const int i = ws_half_for(h, st);
+    // un-summed slabs in the half this request gets: their stand-alone pass goes first (on their own stream; ws_take orders
+    // `st` behind that stream if it is another one)
+    if (h.pending.active && h.pending.half == i && wgrad_flush_pending() != 0) return nullptr;
+    h.acq_half = i;
+    return ws_take(h, i, st) ? (char *)h.ws + (size_t)i * half : nullptr;
+}
+bool wgrad_deferred() { return cur().defer; }
+int wgrad_flush_pending() {
+    mmdgan_handle &h = cur();
+    if (!h.pending.active) return 0;
+    h.pending.active = false;
+    slab_reduce_launch(h.pending.args, h.pending.st);
+    return check_launch("slab reduction (deferred)");
+}
+void *wgrad_slabs_acquire(size_t need, hipStream_t st, SlabReduceArgs *prev) {
+    mmdgan_handle &h = cur();
+    *prev = SlabReduceArgs{};
+    if (!h.ws) return nullptr;
+    const size_t half = (h.ws_bytes / 2) & ~(size_t)255, part = (half / 2) & ~(size_t)255;
+    if (!h.defer || need > part) return workspace_acquire(need, st);       // (flushes what is pending in its way)
+    if (h.pending.active && h.pending.st != st && wgrad_flush_pending() != 0) return nullptr;
+    const int i = ws_half_for(h, st);
+    if (h.pending.active && h.pending.half != i && wgrad_flush_pending() != 0) return nullptr;   // (a stream keeps its half: not expected)
+    int sub = 0;
+    if (h.pending.active) {                                // same stream, same half: the caller's prologue sums it
+        *prev = h.pending.args;
+        sub = 1 - h.pending.sub;
+        h.pending.active = false;
+    }
+    if (!ws_take(h, i, st)) return nullptr;
+    h.acq_half = i;
+    h.acq_sub = sub;
+    return (char *)h.ws + (size_t)i * half + (size_t)sub * part;
+}
+int wgrad_slabs_release(const SlabReduceArgs &mine, hipStream_t st) {
+    mmdgan_handle &h = cur();
+    if (h.defer && h.acq_sub >= 0) {
+        h.pending.active = true;
+        h.pending.args = mine;
+        h.pending.st = st;
+        h.pending.half = h.acq_half;
+        h.pending.sub = h.acq_sub;
+        return 0;
+    }
+    slab_reduce_launch(mine, st);
+    return check_launch("slab reduction");
 }
 // Dependency events: hipEventDisableTiming.  (Round 4 A/B on the CIFAR step, eager / plan ms: plain 1.895 / 1.887,
 // + hipEventDisableSystemFence 1.888 / 1.885, + hipEventReleaseToDevice 1.892 / 1.891 - inside the run-to-run spread, so the
@@ -108,7 +170,7 @@ hipError_t memset_async(void *p, int value, size_t bytes, hipStream_t st) {
 using namespace mmdgan;
 
 extern "C" const char *mmdgan_last_error(void) { return mmdgan::g_err; }
-extern "C" int mmdgan_version(void) { return 200; }
+extern "C" int mmdgan_version(void) { return MMDGAN_VERSION; }
 // "name=value ..." of every kernel-selection switch of this process (csrc/tuning.h), the ones off their default marked '*'
 extern "C" long mmdgan_tuning_describe(char *buf, size_t cap) {
     const Tuning &t = tuning(), &d = tuning_defaults();
@@ -160,8 +222,19 @@ extern "C" int mmdgan_set_workspace(void *ptr, size_t bytes) {
     cur().ws = ptr;
     cur().ws_bytes = ptr ? bytes : 0;
     cur().ws_slot[0] = cur().ws_slot[1] = mmdgan_handle::WsSlot();
+    cur().pending.active = false;      // (slabs of a buffer that is being replaced or re-registered: nothing to sum)
     return MMDGAN_OK;
 }
+// Deferred slab reduction of the Winograd-domain weight gradients (slab_reduce.h).  on = 1: a slab weight-gradient launch no
+// longer appends its reduction pass; the NEXT such launch on the same stream sums the slabs in its prologue.  dw / dbias /
+// dot of a call are therefore complete only after the stream's next weight-gradient call, after mmdgan_wgrad_flush(), after
+// any other workspace user of that stream, or after mmdgan_wgrad_defer(0) - all of which issue what is pending.
+extern "C" int mmdgan_wgrad_defer(int on) {
+    cur().defer = on != 0;                     // (issue-time state, like the workspace bookkeeping: a recorded step replays the
+    return on ? MMDGAN_OK : (wgrad_flush_pending() ? MMDGAN_E_LAUNCH : MMDGAN_OK);   // launches that were chosen under it)
+}
+extern "C" int mmdgan_wgrad_flush(void) { return wgrad_flush_pending() ? MMDGAN_E_LAUNCH : MMDGAN_OK; }
+
 extern "C" int mmdgan_set_outputs_prezeroed(int on) {
     const bool v = on != 0;
     if (plan_recording()) {            // a mode switch inside a recorded step is part of the step

@@ -26,6 +26,8 @@ SIGNATURES = {
     'mmdgan_make_current': (_I, [_P]),
     'mmdgan_set_workspace': (_I, [_P, ctypes.c_size_t]),
     'mmdgan_set_outputs_prezeroed': (_I, [_I]),
+    'mmdgan_wgrad_defer': (_I, [_I]),
+    'mmdgan_wgrad_flush': (_I, []),
     'mmdgan_plan_begin': (_I, []),
     'mmdgan_plan_mark': (_I, []),
     'mmdgan_plan_end': (_I, [ctypes.POINTER(_I)]),
@@ -94,6 +96,8 @@ SIGNATURES = {
     'mmdgan_u8_records_to_nhwc': (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
 }
 
+ABI_VERSION = 500           # include/mmdgan_hip.h: MMDGAN_VERSION this binding was written against
+
 _lib = None
 
 
@@ -121,6 +125,10 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)        # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
+    got = lib.mmdgan_version()
+    if got != ABI_VERSION:              # a stale .so against a newer binding (or the reverse): shifted arguments, no diagnostics
+        raise HipLibraryError('libmmdgan_hip.so at %s reports ABI version %d, this binding needs %d - rebuild it with '
+                              '`python mmd-gan_amd/build_ext.py --force`' % (LIB_PATH, got, ABI_VERSION))
     _lib = lib
     return lib
 

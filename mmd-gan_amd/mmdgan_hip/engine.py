@@ -477,6 +477,7 @@ class GanEngine:
         self.score_size = self.dis.specs[-1].out
         self.global_step = 0
         self.dist_group = dist_group
+        settings.warn_unknown()                                          # (a switch of an earlier round would be ignored in silence)
         self._dp_force = settings.on('MMDGAN_DP_FORCE')
         self.world, self.rank = 1, 0
         if dist_group is not None:
@@ -512,6 +513,7 @@ class GanEngine:
         self._sn_raw = [st.cuda_stream for st in self._sn_streams]
         self._gen_tail_on_main = int(settings.get('MMDGAN_GEN_TAIL_MAIN')) if settings.on('MMDGAN_SIDE_WGRAD') else 0
         self._early_d_adam = settings.on('MMDGAN_EARLY_D_ADAM')
+        self._wgrad_defer = settings.on('MMDGAN_WGRAD_DEFER')
         self._side_wgrad = settings.on('MMDGAN_SIDE_WGRAD')
         # round 4: dependencies that put a marker / barrier packet into the MAIN queue (~6 us of idle queue each) moved off it
         # where another ordering already covers them (MMDGAN_QUEUE_OPT=0: the round-3 placement)
@@ -860,6 +862,7 @@ class GanEngine:
                 else:                                                        # bias gradient (and <G, W>) ride on the wgrad launch
                     ops.conv2d_wgrad(x_in, dz_main, s.R, s.stride, out=gw, dbias=gb, w=w if s.sn else None, dot=dot)
                 if s.sn and not net.opt.fold_fixup:                          # data-parallel replicas fix up before the exchange
+                    ops.wgrad_flush()                                        # (the fix-up reads the summed gradient and <G, W>)
                     ops.sn_wgrad_fixup(gw.view(-1), net.state[s.scope + '#dsigma'].view(-1), dot, net.state[s.scope + '#sigma'], scale)
             self._on_wg_stream(param_grads, s)
             if li > 0:
@@ -905,6 +908,7 @@ class GanEngine:
             fn()
 
     def _join_wg_stream(self):
+        ops.wgrad_flush()                    # the last slab weight gradient of the pass: its reduction as a stand-alone launch
         if self._side_wgrad:
             ops.stream_wait(ops._stream(), self._wg_raw)
 
@@ -946,6 +950,7 @@ class GanEngine:
                 else:                                                        # tc: W[R,R,Cout,Cin]; y = dgrad(v, W)
                     ops.conv2d_wgrad(dz, x_in, s.R, s.stride, out=gw, w=w if s.sn else None, dot=dot)
                 if s.sn and not net.opt.fold_fixup:
+                    ops.wgrad_flush()
                     ops.sn_wgrad_fixup(gw.view(-1), net.state[s.scope + '#dsigma'].view(-1), dot, net.state[s.scope + '#sigma'], scale)
             if li < self._gen_tail_on_main and li > 0:
                 # the tail of G's backward pass: the input-gradient chain of the main stream ends at layer 1 while the
@@ -1006,6 +1011,7 @@ class GanEngine:
         if bucket is None:
             return
         _, lo, hi = bucket
+        ops.wgrad_flush()                    # (a slab weight gradient of the bucket may still be waiting for its reduction)
         # the bucket is complete once the parameter-gradient stream has drained what it holds now (and the main stream
         # has reached this point, for gradients that stay there)
         if self._side_wgrad:
@@ -1098,6 +1104,9 @@ class GanEngine:
                 ops.memset_zero_multi(small)
             self._in_step = True
             self._d_updated_early = False
+            # the Winograd-domain weight gradients of the backward pass form a chain on the weight-gradient stream: each sums
+            # its predecessor's slabs in its own prologue instead of a bandwidth-only launch in between (mmdgan_wgrad_defer)
+            ops.wgrad_defer(self._wgrad_defer)
             self._forward(z, real)
             if arenas and not (self._queue_opt and self._wino):
                 # (with transformed weights in the step the main stream has already waited for _EV_WINO_DIS, recorded behind
@@ -1108,6 +1117,7 @@ class GanEngine:
                 # D's gradients are complete once the parameter-gradient stream has drained what it holds now and
                 # the main stream has reached this point (thin layers); nothing in G's backward pass reads D's
                 # weights, so D's Adam runs there, beside G's backward pass, instead of at the tail of the step
+                ops.wgrad_flush()
                 ops.stream_wait(self._wg_raw, main)
                 with torch.cuda.stream(self._wg_stream):
                     self.dis.opt.step(self.lr_d, grad_scale=1.0)
@@ -1117,6 +1127,7 @@ class GanEngine:
             self._update()
         finally:
             self._in_step = False
+            lib.mmdgan_wgrad_defer(0)
             lib.mmdgan_set_outputs_prezeroed(0)
 
     def step(self, real_nhwc=None, z=None, uni=None):

@@ -57,7 +57,7 @@ class Handle:
     `with handle:` makes it the calling thread's current handle and restores the handle that was current before (a
     per-thread stack: constructing or stepping another engine inside the block does not strand the outer one)."""
 
-    def __init__(self, workspace_bytes=128 << 20, device=None):
+    def __init__(self, workspace_bytes=256 << 20, device=None):
         lib = require_device()
         h = ctypes.c_void_p()
         check(lib.mmdgan_create(ctypes.byref(h)), 'create')
@@ -94,6 +94,18 @@ class Handle:
             self._lib.mmdgan_destroy(self._h)
         except Exception:
             pass
+
+
+def wgrad_defer(on):
+    """mmdgan_wgrad_defer on the current handle: the slab weight gradients leave their reduction to the prologue of the next
+    weight-gradient launch of their stream (on) / issue it themselves (off; turning it off issues what is pending)"""
+    check(require_device().mmdgan_wgrad_defer(1 if on else 0), 'wgrad_defer')
+
+
+def wgrad_flush():
+    """issue the slab reduction the last weight-gradient launch left behind (mmdgan_wgrad_flush): after this call, stream
+    order behind the weight gradients' stream sees their complete dw / dbias / <G, W>"""
+    check(require_device().mmdgan_wgrad_flush(), 'wgrad_flush')
 
 
 def tuning():

@@ -21,6 +21,8 @@ else is a way to reproduce an A/B that DESIGN.md quotes, or a debugging aid.
   MMDGAN_TAPE_JOINT    0   D's two backward passes separately instead of one 3B-row pass
   MMDGAN_TAPE_FUSE_ADD 0   branch sums / gradient fan-ins as axpby passes instead of conv epilogues
   MMDGAN_BN_RESIGN     0   batch-norm backward reads the activated output back instead of recomputing its sign from the input
+  MMDGAN_WGRAD_DEFER   0   every slab weight gradient followed by its own reduction launch instead of leaving it to the next
+                           weight-gradient launch's prologue (mmdgan_wgrad_defer; round 5)
 """
 import os
 
@@ -28,7 +30,7 @@ _DEFAULTS = {
     'MMDGAN_LAUNCH_MODE': None, 'MMDGAN_SIDE_WGRAD': '1', 'MMDGAN_SN_STREAMS': '2', 'MMDGAN_SN_FUSED': '1',
     'MMDGAN_EARLY_D_ADAM': '1', 'MMDGAN_GEN_TAIL_MAIN': '2', 'MMDGAN_QUEUE_OPT': '1', 'MMDGAN_DP_BACKEND': None,
     'MMDGAN_DP_BUCKET_MB': '8', 'MMDGAN_DP_FORCE': '0', 'MMDGAN_TAPE_STREAMS': '1', 'MMDGAN_TAPE_COMPOSE': '1',
-    'MMDGAN_TAPE_JOINT': '1', 'MMDGAN_TAPE_FUSE_ADD': '1', 'MMDGAN_BN_RESIGN': '1',
+    'MMDGAN_TAPE_JOINT': '1', 'MMDGAN_TAPE_FUSE_ADD': '1', 'MMDGAN_BN_RESIGN': '1', 'MMDGAN_WGRAD_DEFER': '1',
 }
 
 
@@ -53,3 +55,20 @@ def unknown():
            'MMDGAN_WINO_WGRAD', 'MMDGAN_WINO_WGRAD_SLAB', 'MMDGAN_WINO2', 'MMDGAN_WINO2_KSPLIT', 'MMDGAN_WINO2_KSPLIT_BELOW',
            'MMDGAN_WINO2_WGRAD', 'MMDGAN_WINO2_WGRAD_MIN_TILES', 'MMDGAN_WGRAD_CUS', 'MMDGAN_GEMM_SKINNY'}
     return sorted(k for k in os.environ if k.startswith('MMDGAN_') and k not in _DEFAULTS and k not in lib)
+
+
+_warned = False
+
+
+def warn_unknown():
+    """one line on stderr, once per process, when the environment holds MMDGAN_* switches nothing reads - a switch of an
+    earlier round (MMDGAN_HIP_GRAPH, MMDGAN_TILE, ...) would otherwise be ignored in silence (the engines call this when they
+    are constructed)"""
+    global _warned
+    names = unknown()
+    if names and not _warned:
+        import sys
+        _warned = True
+        sys.stderr.write('mmdgan_hip: ignoring unknown environment switch(es) %s - see mmdgan_hip/settings.py and '
+                         'csrc/tuning.h for the ones that exist\n' % ', '.join(names))
+    return names

@@ -598,6 +598,7 @@ class TapeEngine:
             import torch.distributed as tdist
             self.world = tdist.get_world_size(dist_group)
             self.rank = tdist.get_rank(dist_group)
+        settings.warn_unknown()                                          # (a switch of an earlier round would be ignored in silence)
         self._dp_force = settings.on('MMDGAN_DP_FORCE')
         # who carries the gradient exchange (dist.choose_dp_backend, as GanEngine): the library's own RCCL communicator under
         # an nccl group - its collectives are plan nodes, so a data-parallel step replays from one C call - else torch.distributed

@@ -1090,6 +1090,100 @@ def test_power_iterations_of_many_kernels_in_six_launches(ops):
     check(True)
 
 
+def test_deferred_slab_reduction_gives_the_same_bits(ops):
+    """mmdgan_wgrad_defer: a chain of slab weight gradients on one stream, each summing its predecessor's slabs in its own
+    prologue (quad form: >= 8 slabs; plain form: fewer), the last one flushed - dw, the bias gradient and <dw, w> are
+    BIT-identical to the same calls with their own reduction launches (the dot to rounding: it is accumulated with one atomic
+    per workgroup in both forms).  Also: another workspace user on the stream (a thin-layer weight gradient), a call on a
+    second stream and mmdgan_wgrad_defer(0) each issue what is pending; a workspace too small for two sets of slabs falls
+    back to a launch per call; the outputs of a deferred call are NOT complete before one of those."""
+    rs = np.random.RandomState(5)
+    # (N, H, C, K, R, stride): 56 / 14 / 3 slabs on the 4x4 stride-2 kernel, 28 / 7 / 2 on the 3x3 one, then a thin layer
+    chain = [(32, 16, 128, 128, 3, 1), (32, 16, 64, 128, 4, 2), (16, 16, 128, 256, 4, 2), (32, 8, 256, 256, 3, 1),
+             (32, 8, 256, 512, 4, 2), (64, 4, 512, 512, 3, 1), (8, 32, 64, 128, 4, 2)]
+    data = []
+    for (N, H, C, K, R_, s) in chain:
+        P = H // s
+        data.append((dev(rs.randn(N, H, H, C).astype(np.float32)), dev(rs.randn(N, P, P, K).astype(np.float32)),
+                     dev(rs.randn(R_, R_, C, K).astype(np.float32)), R_, s, K))
+
+    def run(defer, extra=None):
+        outs = []
+        ops.wgrad_defer(defer)
+        try:
+            for i, (x, dy, w, R_, s, K) in enumerate(data):
+                dw = torch.full_like(w, float('nan'))
+                db = torch.full((K,), float('nan'), device='cuda')
+                dot = torch.zeros(1, device='cuda')
+                if i % 2:
+                    ops.conv2d_wgrad(x, dy, R_, s, out=dw, dbias=db, w=w, dot=dot)
+                else:
+                    ops.conv2d_wgrad(x, dy, R_, s, out=dw, dbias=db)
+                outs.append((dw, db, dot))
+                if extra is not None:
+                    extra(i, outs)
+            ops.wgrad_flush()
+        finally:
+            ops.wgrad_defer(False)
+        torch.cuda.synchronize()
+        return outs
+
+    def same(a, b, what):
+        for i, ((dw, db, dot), (dw2, db2, dot2)) in enumerate(zip(a, b)):
+            assert torch.isfinite(dw).all() and torch.isfinite(db).all(), (what, i)
+            assert torch.equal(dw, dw2) and torch.equal(db, db2), (what, i)
+            assert abs(dot.item() - dot2.item()) <= 1e-5 * float((dw.double() * data[i][2].double()).abs().sum()), (what, i)
+
+    ops.set_workspace(256 << 20)
+    try:
+        base = run(False)
+        # (the base itself - a launch per reduction - is what test_conv2d_dgrad_and_wgrad and the Winograd tests hold to fp64)
+        same(run(True), base, 'deferred chain')
+        same(run(True), base, 'deferred chain, again')
+        # a deferred call's outputs are incomplete until something is issued behind it
+        ops.wgrad_defer(True)
+        try:
+            x, dy, w, R_, s, K = data[1]
+            dw = torch.full_like(w, float('nan'))
+            ops.conv2d_wgrad(x, dy, R_, s, out=dw)
+            torch.cuda.synchronize()
+            assert torch.isnan(dw).all()
+            ops.wgrad_flush()
+            torch.cuda.synchronize()
+            assert torch.equal(dw, base[1][0])
+        finally:
+            ops.wgrad_defer(False)
+        # another workspace user of the stream in the middle of the chain (D's first, thin layer): it issues what is pending
+        xt, dyt = dev(rs.randn(32, 32, 32, 3).astype(np.float32)), dev(rs.randn(32, 32, 32, 64).astype(np.float32))
+        thin = ops.conv2d_wgrad(xt, dyt, 3, 1)
+
+        def thin_in_between(i, outs):
+            if i == 2:
+                got = ops.conv2d_wgrad(xt, dyt, 3, 1)
+                torch.cuda.synchronize()
+                assert torch.equal(outs[2][0], base[2][0]) and torch.equal(got, thin)
+        same(run(True, thin_in_between), base, 'thin layer in between')
+        # a second stream takes over in the middle: the first stream's pending reduction is issued on the first stream
+        side = torch.cuda.Stream()
+
+        def switch_stream(i, outs):
+            if i == 3:
+                x, dy, w, R_, s, K = data[0]
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    d2 = ops.conv2d_wgrad(x, dy, R_, s)
+                    ops.wgrad_flush()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                assert torch.equal(d2, base[0][0]) and torch.equal(outs[3][0], base[3][0])
+        same(run(True, switch_stream), base, 'second stream')
+        # a workspace with room for ONE set of slabs only: every call sums its own (no prologue form), same bits
+        ops.set_workspace(80 << 20)
+        same(run(True), base, 'small workspace')
+    finally:
+        ops.require_device().mmdgan_set_workspace(None, 0)
+
+
 def test_segmented_adam_folds_the_spectral_norm_fixup(ops):
     """mmdgan_adam_segments + mmdgan_conv2d_wgrad_sn: the gradient arena keeps the RAW gradient of a spectrally normalised
     kernel plus the scalar <G, W>; the optimiser reads  scale * G - (scale / sigma) * <G, W> * dsigma/dW  (SURVEY A.2).
