@@ -624,6 +624,11 @@ int wino2_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, cons
 // fetching its own dY words from global memory 114 / 110 / 99 us; dY through LDS, six waves, operand prefetch 100 / 89 / 90 us
 // - a 32 x 64 tile moves 17 flop per byte of L2 traffic and spends as many VALU cycles producing V as MFMA cycles using
 // it; 64 x 128 doubles both ratios.
+// -DWG_ABLATE=<mask> (tools/wgrad_ablate.hip; 0 in the library): leave parts of wino2_wgrad_kernel out to see what they cost -
+// 1 patch loads, 2 input transform + V stores, 4 dY loads + stores, 8 operand reads from LDS, 16 the stage barrier, 32 the slab stores
+#ifndef WG_ABLATE
+#define WG_ABLATE 0
+#endif
 namespace wino2w {
 constexpr int BT = 16;                        // tiles per stage = 8 MFMA k-pairs
 constexpr int BC = 64, BK = 128;              // workgroup tile
@@ -676,6 +681,7 @@ __global__ __launch_bounds__(wino2w::NT) void wino2_wgrad_kernel(int N, int H, i
     }
     float4 rin[3][3];
     auto xload = [&]() {
+        if ((WG_ABLATE & 1) && pstage > s0 + 1) { ++pstage; return; }
         if (xprod) {
             const bool ok = n < N && pstage < s1;          // beyond the batch (ragged last stage) or the split: no traffic
             if (cq == 0)          // byte offset of dY pixel (2ty, 2tx), channel 0, of this tile (the dY producers add the rest)
@@ -702,6 +708,7 @@ __global__ __launch_bounds__(wino2w::NT) void wino2_wgrad_kernel(int N, int H, i
     };
     auto vstore = [&](float *buf) {           // V[f = 3i + j][k-pair][c half][tile parity][4 channels of the quad]
         if (!xprod) return;
+        if ((WG_ABLATE & 2) && pstage > s0 + 2) return;
         float4 X[3][3];
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
@@ -723,6 +730,7 @@ __global__ __launch_bounds__(wino2w::NT) void wino2_wgrad_kernel(int N, int H, i
     const unsigned dyrow = (unsigned)(Q * K * 4), dypix = (unsigned)(K * 4);
     float4 rdyv[DYV];
     auto dyload = [&](int stage) {            // needs dyoff[stage], written at least one barrier ago
+        if ((WG_ABLATE & 4) && stage > s0 + 1) return;
 #pragma unroll
         for (int it = 0; it < DYV; ++it) {
             const int e = tid + it * NT;
@@ -736,6 +744,7 @@ __global__ __launch_bounds__(wino2w::NT) void wino2_wgrad_kernel(int N, int H, i
     const bool dosum = DBIAS && blockIdx.x == 0 && par == 0;
     float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
     auto dystore = [&](float *buf) {          // (tiles beyond the split were not loaded: zeros)
+        if ((WG_ABLATE & 4) && pstage > s0 + 3) return;
 #pragma unroll
         for (int it = 0; it < DYV; ++it) {
             const int e = tid + it * NT;
@@ -762,6 +771,7 @@ __global__ __launch_bounds__(wino2w::NT) void wino2_wgrad_kernel(int N, int H, i
     const int dbase = kh * DYT + wk * 32 + l31;              // + 2 kp * DYT + pixel * BK
     float fa[9], dv[4];
     auto opload = [&](const float *cur, const float *dcur, int kp) {     // operands of k-pair kp: 9 + 4 LDS words
+        if ((WG_ABLATE & 8) && (cur != Vs || kp)) return;
 #pragma unroll
         for (int f = 0; f < 9; ++f) fa[f] = cur[abase + f * FS + kp * 128];
 #pragma unroll
@@ -788,7 +798,7 @@ __global__ __launch_bounds__(wino2w::NT) void wino2_wgrad_kernel(int N, int H, i
             else if (kp == 4) xload();                        // tile s+2 -> registers (and its dY offsets)
             else if (kp == 6) dystore(dnxt);
         }
-        __syncthreads();
+        if (!(WG_ABLATE & 16)) __syncthreads();
     }
 
     if (DBIAS && dosum) {                      // (workgroup-uniform) 16 threads per channel quad -> one partial row of the split
@@ -815,6 +825,7 @@ __global__ __launch_bounds__(wino2w::NT) void wino2_wgrad_kernel(int N, int H, i
             for (int r = 0; r < 16; ++r) {
                 const float val = (acc[3 * u + v][r] + acc[3 * u + v + 1][r]) + (acc[3 * u + 3 + v][r] + acc[3 * u + 4 + v][r]);
                 float *d1 = dt + (long)((r & 3) + 8 * (r >> 2)) * K;
+                if ((WG_ABLATE & 32) && val != 1.2345e33f) continue;
                 if (PART) *d1 = val;
                 else atomicAdd(d1, val);
             }
