@@ -345,6 +345,11 @@ typedef struct mmdgan_sn_layer {
     float act_k;
     int form;
     int H, W, C, K, R, stride;
+    float *x_out;        /* NULL: x is updated in place.  Else the normalised F^T(un) goes HERE and x is only read - with `sigma`
+                          * pointed at a shadow too, a caller can run the iteration of step t+1 as soon as step t's optimiser
+                          * has written W (beside the rest of step t) and commit x / sigma at the start of step t+1, so that
+                          * both read between steps exactly as if the iteration had run inside step t+1 (math_func.py:661-672,
+                          * 739-744: UPDATE_OPS semantics; version 500) */
 } mmdgan_sn_layer;
 int mmdgan_sn_power_iteration(const mmdgan_sn_layer *layers, int n_layers, int update, void *stream);
 

@@ -349,7 +349,7 @@ extern "C" int mmdgan_sn_power_iteration(const mmdgan_sn_layer *layers, int n_la
                     pb.gemm(4, L.col, 1, R2C, L.un, K, 1, L.dsigma, R2C, K, PQ, true);          // patches^T . y  (HWIO layout)
                     pb.gemm(4, L.un, K, 1, L.w, 1, K, col2, PQ, R2C, K, split_patches);         // y W^T
                     pb.fold(5, SN_COL2IM, col2, L.xb, d);
-                    pb.norm(6, L.xb, nx, L.x, L.xb_norm, nullptr, 0.f, acc + 1);
+                    pb.norm(6, L.xb, nx, L.x_out ? L.x_out : L.x, L.xb_norm, nullptr, 0.f, acc + 1);
                 }
                 break;
             case 1:                                                    // F = conv2d_dgrad: x [P*Q, K] -> u [H,W,C]
@@ -360,7 +360,7 @@ extern "C" int mmdgan_sn_power_iteration(const mmdgan_sn_layer *layers, int n_la
                     pb.fold(4, SN_IM2COL, L.un, col2, d);
                     pb.gemm(5, col2, 1, R2C, L.x, K, 1, L.dsigma, R2C, K, PQ, true);            // patches(y)^T . x
                     pb.gemm(5, col2, R2C, 1, L.w, K, 1, L.xb, PQ, K, R2C, true);                // conv(y, W)
-                    pb.norm(6, L.xb, nx, L.x, L.xb_norm, nullptr, 0.f, acc + 1);
+                    pb.norm(6, L.xb, nx, L.x_out ? L.x_out : L.x, L.xb_norm, nullptr, 0.f, acc + 1);
                 }
                 break;
             case 2:                                                    // dense: u [1,K] = x [1,C] W
@@ -369,7 +369,7 @@ extern "C" int mmdgan_sn_power_iteration(const mmdgan_sn_layer *layers, int n_la
                 if (update) {
                     pb.gemm(4, L.x, 1, R2C, L.un, K, 1, L.dsigma, R2C, K, 1, false);            // x^T y
                     pb.gemm(4, L.un, K, 1, L.w, 1, K, L.xb, 1, R2C, K, true);                   // y W^T
-                    pb.norm(6, L.xb, nx, L.x, L.xb_norm, nullptr, 0.f, acc + 1);
+                    pb.norm(6, L.xb, nx, L.x_out ? L.x_out : L.x, L.xb_norm, nullptr, 0.f, acc + 1);
                 }
                 break;
             default:                                                   // dense: u [1,C] = x [1,K] W^T
@@ -378,7 +378,7 @@ extern "C" int mmdgan_sn_power_iteration(const mmdgan_sn_layer *layers, int n_la
                 if (update) {
                     pb.gemm(4, L.un, 1, R2C, L.x, K, 1, L.dsigma, R2C, K, 1, false);            // y^T x
                     pb.gemm(4, L.un, R2C, 1, L.w, K, 1, L.xb, 1, K, R2C, true);                 // y W
-                    pb.norm(6, L.xb, nx, L.x, L.xb_norm, nullptr, 0.f, acc + 1);
+                    pb.norm(6, L.xb, nx, L.x_out ? L.x_out : L.x, L.xb_norm, nullptr, 0.f, acc + 1);
                 }
                 break;
             }

@@ -36,6 +36,7 @@ from . import initializers, ops, settings
 # named event slots (mmdgan_event_record / _wait)
 _EV_WINO_GEN = 0                      # G's Winograd weights are ready
 _EV_WINO_DIS = 1                      # D's
+_EV_AHEAD_KEPT = 2                    # the tail of the step has saved scale / dsigma of D as this step used them (_ahead_tail)
 _EV_SN0 = 8                           # + i: the power iteration of D layer i has produced its scale (i < 24)
 _EV_SN_GEN0 = 32                      # + i: ... of G layer i
 
@@ -197,11 +198,22 @@ class Network:
                 sn_entries += [(s.scope + '#u', self._sn_u_shape(s)), (s.scope + '#xb', self._sn_native_shape(s)),
                                (s.scope + '#dsigma', s.kernel_shape)]
         self.sn_scratch = _Arena(sn_entries, device)
+        # the power-iteration vectors and the spectral norms - what a step's UPDATE_OPS replace (math_func.py:661-672, 739-744) -
+        # lie in ONE flat buffer, with a shadow of the same layout beside it: an engine that runs the iteration of step t+1 at
+        # the tail of step t (GanEngine, "ahead") lets it write the shadow and commits it with one copy when step t+1 starts
+        self.sn_live = _Arena([e for s in specs if s.sn for e in ((s.scope + '/kernel/SN/in_rand', self._sn_native_shape(s)),
+                                                                  (s.scope + '#sigma', [1]))], device)
+        self.sn_shadow = self.sn_live.like()
+        # act_k / sigma of every normalised kernel, one flat buffer as well.  `readout` (set by an engine that runs the next step's
+        # iteration at the tail of this one): {state key: tensor} - copies of scale and dsigma/dW AS THE LAST STEP USED THEM, for
+        # whoever inspects that step's gradients afterwards (effective_grad)
+        self.sn_scales = _Arena([(s.scope + '#scale', [1]) for s in specs if s.sn], device)
+        self.readout = None
         for s in specs:
             if s.sn:
-                self.state[s.scope + '/kernel/SN/in_rand'] = torch.zeros(self._sn_native_shape(s), device=device)
-                for k in ('sigma', 'scale'):
-                    self.state[s.scope + '#' + k] = torch.zeros(1, device=device)
+                self.state[s.scope + '#scale'] = self.sn_scales.view(s.scope + '#scale')
+                self.state[s.scope + '/kernel/SN/in_rand'] = self.sn_live.view(s.scope + '/kernel/SN/in_rand')
+                self.state[s.scope + '#sigma'] = self.sn_live.view(s.scope + '#sigma')
                 for k in ('dsigma', 'u', 'xb'):
                     self.state[s.scope + '#' + k] = self.sn_scratch.view(s.scope + '#' + k)
                 i = sn_specs.index(s)
@@ -231,8 +243,9 @@ class Network:
         s = self._spec_of(name)
         if not (s.sn and name.endswith('/kernel/kernel') and self.opt.fold_fixup):
             return g.clone()
-        sc, sigma = self.state[s.scope + '#scale'], self.state[s.scope + '#sigma']
-        return sc * g - (sc / sigma) * self.state[s.scope + '#dot'] * self.state[s.scope + '#dsigma'].view(g.shape)
+        st = self.state if self.readout is None else self.readout
+        sc, sigma = st[s.scope + '#scale'], self.state[s.scope + '#sigma']
+        return sc * g - (sc / sigma) * self.state[s.scope + '#dot'] * st[s.scope + '#dsigma'].view(g.shape)
 
     def effective_grads_flat(self):
         """the whole gradient arena with every fix-up applied (tests / inspection)"""
@@ -422,15 +435,19 @@ def sn_power_iteration(net, s, b, update=True, out_zeroed=True):
     return scale
 
 
-def sn_chain_layer(net, s, b):
+def sn_chain_layer(net, s, b, shadow=False):
     """the power iteration of layer `s` as ops.SnChains describes it (same tensors as sn_power_iteration), or None for a
-    kernel with a unit dimension (math_func.py:702-704: no iteration, sigma = ||w||)"""
+    kernel with a unit dimension (math_func.py:702-704: no iteration, sigma = ||w||).  shadow: the new vector and the
+    spectral norm go to the net's shadow buffer (Network.sn_shadow) instead of replacing the live ones"""
     w = net.p(s.scope + '/kernel/kernel')
     if (s.op == 'd' or s.pim) and 1 in (int(np.prod(w.shape[:-1])), w.shape[-1]):
         return None
     L = dict(w=w, x=net.state[s.scope + '/kernel/SN/in_rand'], sigma=net.state[s.scope + '#sigma'],
              scale=net.state[s.scope + '#scale'], dsigma=net.state[s.scope + '#dsigma'], u=b[s.scope + '#u'],
              un=b[s.scope + '#un'], xb=b[s.scope + '#xb'], xb_norm=b[s.scope + '#xbnorm'], act_k=s.act_k)
+    if shadow:
+        L['x_out'] = net.sn_live.view(s.scope + '/kernel/SN/in_rand', net.sn_shadow)
+        L['sigma'] = net.sn_live.view(s.scope + '#sigma', net.sn_shadow)
     if s.op == 'd' or s.pim:                             # ('sn_paper': the conv kernel as its [R*R*C, K] matrix)
         L.update(form=2 if s.use_u else 3, C=int(np.prod(w.shape[:-1])), K=w.shape[-1])
     else:
@@ -659,9 +676,22 @@ class GanEngine:
         # MMDGAN_SN_FUSED=0: one chain of launches per layer, dealt to the power-iteration streams
         self._sn_fused = settings.on('MMDGAN_SN_FUSED') and len(self._sn_streams) > 0
         self._sn_chains = {}
+        # "ahead": D's power iterations and D's Winograd weight transform of step t+1 run at the tail of step t, behind D's early
+        # Adam and beside G's backward pass, instead of at the head of step t+1 beside G's small forward kernels (_step_body)
+        self._ahead = (self._sn_fused and settings.on('MMDGAN_STEP_AHEAD') and self._side_wgrad and self._early_d_adam and
+                       self._queue_opt and any(s.sn for s in self.dis.specs) and
+                       all(sn_chain_layer(self.dis, s, self.buf) is not None for s in self.dis.specs if s.sn))
+        self._ahead_valid = False
+        if self._ahead:
+            self._sn_prev = (torch.zeros_like(self.dis.sn_scales.flat), torch.zeros_like(self.dis.sn_scratch.flat))
+            self._sn_readout = {}
+            for s in self.dis.specs:
+                if s.sn:
+                    self._sn_readout[s.scope + '#scale'] = self.dis.sn_scales.view(s.scope + '#scale', self._sn_prev[0])
+                    self._sn_readout[s.scope + '#dsigma'] = self.dis.sn_scratch.view(s.scope + '#dsigma', self._sn_prev[1])
         if self._sn_fused:
             for net in (self.gen, self.dis):
-                layers = [(s, sn_chain_layer(net, s, self.buf)) for s in net.specs if s.sn]
+                layers = [(s, sn_chain_layer(net, s, self.buf, shadow=self._ahead and net is self.dis)) for s in net.specs if s.sn]
                 self._sn_chains[id(net)] = (ops.SnChains([L for _, L in layers if L is not None], dev),
                                             [s for s, L in layers if L is None])
                 # the patch matrices that hold split products: zeroed with the step's scratch
@@ -741,6 +771,7 @@ class GanEngine:
         """D(x) in INFERENCE mode (my_sngan.py:558-560, `self.Dis(..., is_training=False)`): spectral norms from the stored
         power-iteration vectors WITHOUT updating them (UPDATE_OPS run in training sessions only); [n, d] scores.
         Rows are independent in inference, so the batch is walked in chunks of the engine's 2B-row buffers."""
+        self._sync_ahead(invalidate=True)                # (writes sigma / scale of D and the chains' scratch)
         scales = {s.scope: (sn_power_iteration(self.dis, s, self.buf, update=False, out_zeroed=False) if s.sn else None)
                   for s in self.dis.specs}
         outs = []
@@ -771,6 +802,17 @@ class GanEngine:
                 chains, single = self._sn_chains[id(net)]
                 for s in net.specs:
                     self._scales[s.scope] = net.state[s.scope + '#scale'] if s.sn else None
+                if net is self.dis and self._ahead:
+                    if self._ahead_inline():
+                        # (a captured hipGraph is one step, closed: the iteration runs here, at the head of its own step, through
+                        # the same shadow + commit; nothing is pending between steps)
+                        self._ahead_tail(behind=None, keep=False, inline=True)
+                    # this step's iteration ran at the tail of the previous step (_ahead_tail; step() primes the first one):
+                    # scale, dsigma/dW and D's transformed weights are in place, the new vectors and the spectral norms wait in
+                    # the shadow - one copy makes them the live ones, behind that tail on the same stream
+                    ops.copy(net.sn_live.flat, net.sn_shadow, stream=self._sn_raw[0])
+                    ops.event_record(ev0, self._sn_raw[0])
+                    continue
                 if any(s.sn for s in net.specs):
                     with torch.cuda.stream(self._sn_streams[0]):
                         chains.run(update=True)
@@ -994,6 +1036,62 @@ class GanEngine:
     # ---------------------------------------------------------------------------------------
     # data-parallel gradient exchange (the reference's dormant tower helper, graph_func.py:69-94)
     # ---------------------------------------------------------------------------------------
+    # ---------------------------------------------------------------------------------------
+    # the step boundary, pipelined (VERDICT r04 "next" #2): D's power iterations and D's Winograd weight transform depend on
+    # D's weights only, and those are final as soon as D's early Adam has run - ~270 us before the step ends
+    # ---------------------------------------------------------------------------------------
+    def _dis_sn_zero(self):
+        """what D's power iterations accumulate into: zeroed in front of them"""
+        return [self.dis.sn_scratch.flat] + list(self._sn_chains[id(self.dis)][0].zero_each_step)
+
+    def _ahead_inline(self):
+        return self.launch_mode == 'graph' and self.dist_group is None
+
+    def _ahead_tail(self, behind=None, prezeroed=True, keep=True, inline=False):
+        """D's power iteration and transformed weights FOR THE NEXT STEP, on the first power-iteration stream behind D's Adam
+        of this one (`behind`: the stream that Adam was issued on).  The iteration reads the live vectors and writes scale,
+        dsigma/dW (read next by the next step's Adam) and - into the shadow - the new vectors and the spectral norms, which the
+        next step's head commits: between steps `in_rand` and sigma read as if the iteration ran inside the next step
+        (math_func.py:661-672, 739-744)."""
+        if not self._ahead or (self._ahead_inline() and not inline):
+            return
+        sn0 = self._sn_raw[0]
+        if behind is not None and behind != sn0:
+            ops.stream_wait(sn0, behind)
+        with torch.cuda.stream(self._sn_streams[0]):
+            if keep:
+                # scale and dsigma/dW as this step's Adam read them, for effective_grad() (tests, inspection): the iteration
+                # below replaces them.  23 MB for CIFAR's D, on this side stream beside G's backward pass
+                ops.copy(self._sn_prev[0], self.dis.sn_scales.flat, stream=sn0)
+                ops.copy(self._sn_prev[1], self.dis.sn_scratch.flat, stream=sn0)
+                ops.event_record(_EV_AHEAD_KEPT, sn0)
+            if prezeroed:
+                ops.memset_zero_multi(self._dis_sn_zero(), stream=sn0)
+            self._sn_chains[id(self.dis)][0].run(update=True)
+            self._wino_jobs[1].run(stream=sn0)
+        self._ahead_valid = not inline
+        self.dis.readout = self._sn_readout if keep else None
+
+    def _prime_ahead(self):
+        """the tail a previous step would have left: before the first step, and after anything that changed D's weights or
+        vectors from outside (set_variables, load_state_dict, a snapshot restored).  Issued eagerly, outside any recording."""
+        if not self._ahead or self._ahead_valid or self._ahead_inline():
+            return
+        with self._handle:
+            # (the live values are where the commit of the next step's head takes them FROM the shadow: the un-touched entries
+            # of the shadow must equal the live ones)
+            self.dis.sn_shadow.copy_(self.dis.sn_live.flat)
+            self._ahead_tail(behind=ops._stream(), prezeroed=False, keep=False)
+            ops.stream_wait(ops._stream(), self._sn_raw[0])
+
+    def _sync_ahead(self, invalidate=False):
+        """before anything outside a step touches D's weights or power-iteration state: the tail of the last step may still be
+        running on its side stream.  invalidate: what it produced no longer belongs to the state (the next step primes again)."""
+        if self._ahead:
+            ops.stream_wait(ops._stream(), self._sn_raw[0])
+            if invalidate:
+                self._ahead_valid = False
+
     def _dp_active(self):
         return self.dist_group is not None and (self.world > 1 or self._dp_force)   # MMDGAN_DP_FORCE=1: one-rank plumbing test
 
@@ -1043,6 +1141,7 @@ class GanEngine:
             with torch.cuda.stream(self._comm_stream):
                 self.dis.opt.step(self.lr_d, grad_scale=1.0 / self.world)
             self._d_updated_early = True
+            self._ahead_tail(behind=self._comm_raw)
 
     def _issue_collective(self, net, lo, hi):
         if self._dp_backend == 'capi':
@@ -1082,7 +1181,8 @@ class GanEngine:
                     self._wino_jobs[0].run()
                     ops.event_record(_EV_WINO_GEN, self._wg_raw)
                     ops.memset_zero_multi(list(arenas))
-                    self._wino_jobs[1].run()
+                    if not self._ahead:
+                        self._wino_jobs[1].run()
                     # (the step counts and bias-corrected learning rates of both updates: no gradient needed, so here)
                     ops.adam_prepare_multi([(self.dis.opt, self.lr_d), (self.gen.opt, self.lr_g)])
                     ops.event_record(_EV_WINO_DIS, self._wg_raw)
@@ -1100,6 +1200,8 @@ class GanEngine:
                 sn_flat = [net.sn_scratch.flat for net in (self.gen, self.dis)] + [t for c in self._sn_chains.values() for t in c[0].zero_each_step]
                 self._sn_zero = [t for t in small if any(t is f for f in sn_flat)]
                 small = [t for t in small if not any(t is f for f in sn_flat)]
+                if self._ahead:                          # D's scratch is zeroed where D's iteration runs: _ahead_tail
+                    self._sn_zero = [t for t in self._sn_zero if not any(t is f for f in self._dis_sn_zero())]
             if small:
                 ops.memset_zero_multi(small)
             self._in_step = True
@@ -1122,8 +1224,11 @@ class GanEngine:
                 with torch.cuda.stream(self._wg_stream):
                     self.dis.opt.step(self.lr_d, grad_scale=1.0)
                 self._d_updated_early = True
+                self._ahead_tail(behind=self._wg_raw)
             self._backward_gen(dz, z)
             self._join_wg_stream()
+            if self._ahead and self._d_updated_early and not self._ahead_inline():
+                ops.event_wait(_EV_AHEAD_KEPT, main)     # (readers of the last step's scale / dsigma follow the main stream)
             self._update()
         finally:
             self._in_step = False
@@ -1145,6 +1250,7 @@ class GanEngine:
         if (self.lr_d, self.lr_g) != self._baked_lr:     # a captured graph / recorded plan holds the learning rates by value
             self._baked_lr = (self.lr_d, self.lr_g)
             self._drop_recordings()
+        self._prime_ahead()
         with self._handle:                               # this engine's workspace / prezeroed mode / plans
             if mode == 'eager':
                 # the batch goes straight into the first half of D's input buffer (one copy, not two)
@@ -1204,13 +1310,16 @@ class GanEngine:
             self._step_body(self._static_z, self._static_real)
         torch.cuda.current_stream().wait_stream(s)
         self._restore(snap)
+        self._prime_ahead()
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             self._step_body(self._static_z, self._static_real)
         self._restore(snap)
+        self._prime_ahead()
         self._graph.replay()
 
     def _snapshot(self):
+        self._sync_ahead()
         out = []
         for net in (self.gen, self.dis):
             out.append([net.params.clone(), net.adam_m.clone(), net.adam_v.clone(), net.opt.step_counter.clone(),
@@ -1219,12 +1328,14 @@ class GanEngine:
         return out
 
     def _restore(self, snap):
+        self._sync_ahead()
         for net, (p, m, v, t, st) in zip((self.gen, self.dis), snap):
             net.params.copy_(p); net.adam_m.copy_(m); net.adam_v.copy_(v); net.opt.step_counter.copy_(t)
             for k, val in st.items():
                 net.state[k].copy_(val)
         if snap[-1] is not None:
             self._loss.state.copy_(snap[-1])
+        self._ahead_valid = False
 
     # ---------------------------------------------------------------------------------------
     # reference-layout import / export (checkpoint keys follow TF scopes)
@@ -1236,6 +1347,8 @@ class GanEngine:
         return self.gen if name.startswith('gen/') else self.dis
 
     def set_variables(self, values):
+        self._sync_ahead(invalidate=True)
+        self.dis.readout = None
         for k, v in values.items():
             self._net_of(k).set_variable(k, v)
 

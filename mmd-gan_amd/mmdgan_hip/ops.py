@@ -433,12 +433,13 @@ def sn_norm(v, normalise=True, out_norm=None, out_v=None):
 
 class SnLayer(ctypes.Structure):
     _fields_ = [(k, ctypes.c_void_p) for k in ('w', 'x', 'u', 'un', 'xb', 'col', 'dsigma', 'sigma', 'scale', 'xb_norm', 'norm_acc')] + \
-               [('act_k', ctypes.c_float), ('form', ctypes.c_int)] + [(k, ctypes.c_int) for k in ('H', 'W', 'C', 'K', 'R', 'stride')]
+               [('act_k', ctypes.c_float), ('form', ctypes.c_int)] + [(k, ctypes.c_int) for k in ('H', 'W', 'C', 'K', 'R', 'stride')] + \
+               [('x_out', ctypes.c_void_p)]
 
 
 class SnChains:
     """mmdgan_sn_power_iteration: one power-iteration step of many kernels, every stage of all chains as one launch.
-    layers: dicts with the tensors w, x, u, un, xb, dsigma, sigma, scale, xb_norm (col is allocated here), act_k, form
+    layers: dicts with the tensors w, x, u, un, xb, dsigma, sigma, scale, xb_norm, optionally x_out (col is allocated here), act_k, form
     (0 conv2d_fwd, 1 conv2d_dgrad, 2 x W, 3 x W^T) and the conv geometry H, W, C, K, R, stride (dense: C, K).
     Pointers are taken once: the tensors stay where they are for the life of an engine."""
 
@@ -460,7 +461,7 @@ class SnChains:
         self.norm_acc = torch.zeros(4 * max(1, len(self.keep)), device=device, dtype=torch.float32)
         for i, (t, L) in enumerate(zip(self.table, self.keep)):
             t.norm_acc = self.norm_acc.data_ptr() + 16 * i
-            for k in ('w', 'x', 'u', 'un', 'xb', 'dsigma', 'sigma', 'scale', 'xb_norm'):
+            for k in ('w', 'x', 'u', 'un', 'xb', 'dsigma', 'sigma', 'scale', 'xb_norm', 'x_out'):
                 setattr(t, k, L[k].data_ptr() if L.get(k) is not None else None)
             t.act_k, t.form = float(L['act_k']), int(L['form'])
             for k in ('H', 'W', 'C', 'K', 'R', 'stride'):
