@@ -117,9 +117,9 @@ int mmdgan_set_outputs_prezeroed(int on);
  * same stream sums the previous call's slabs in the prologue of its own kernel (every workgroup its 1/grid share; the two
  * calls' slabs lie in different parts of the workspace), so a chain of weight gradients - a backward pass - carries no
  * reduction launches except the last.  The sums are bit-identical in both modes.  Under on = 1 the outputs (dw, dbias,
- * dot_gw) of such a call are complete only once one of these has been issued behind it: the stream's next slab
- * weight-gradient call, any other workspace user of that stream, mmdgan_wgrad_flush(), or mmdgan_wgrad_defer(0) (which
- * flushes).  A reader on another stream must be ordered behind that point.  Per handle; default 0.  (TF autodiff of
+ * dot_gw) of such a call are complete only once one of these has been issued behind it: the next mmdgan_conv2d_wgrad* call
+ * (a slab one on the same stream carries the sum in its prologue, any other issues the stand-alone pass first), any other
+ * workspace user of that stream, mmdgan_wgrad_flush(), or mmdgan_wgrad_defer(0) (which flushes).  A reader on another stream must be ordered behind that point.  Per handle; default 0.  (TF autodiff of
  * layer_func.py:914 is what the chain replaces.) */
 int mmdgan_wgrad_defer(int on);
 int mmdgan_wgrad_flush(void);

@@ -171,6 +171,9 @@ static int wgrad_impl(const mmdgan_conv_geom *g, const float *x, const float *dy
         if (rcw == 0 && wdot && !dot_done) rcw = mmdgan_dot(dw, wdot, nw, dot, stream);
         return rcw;
     }
+    // (not a slab kernel: it has no prologue for the slabs a previous call left behind under mmdgan_wgrad_defer - they are
+    // summed by the stand-alone pass now, so that "complete behind the next weight-gradient call" holds for every geometry)
+    if (wgrad_flush_pending()) return MMDGAN_E_LAUNCH;
     int rc = 1;
     bool dot_done = false;
     if (!force_direct() && igemm_wgrad_ok(d)) rc = igemm_wgrad(d, x, dy, dw, dbias, (hipStream_t)stream);   // sums dy on the way

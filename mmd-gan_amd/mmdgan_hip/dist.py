@@ -88,6 +88,8 @@ def average_(flat, group=None, bucket_bytes=DEFAULT_BUCKET_BYTES):
 
 def broadcast_state(eng, group=None, src=0):
     """make every replica start from rank `src`'s weights, Adam moments, SN vectors and BN stats."""
+    if hasattr(eng, 'touch'):
+        eng.touch()                                      # (raw writes into the engine's tensors: GanEngine.touch)
     for net in (eng.gen, eng.dis):
         for t in (net.params, net.adam_m, net.adam_v, net.opt.step_counter):
             tdist.broadcast(t, src=src, group=group)

@@ -1084,6 +1084,13 @@ class GanEngine:
             self._ahead_tail(behind=ops._stream(), prezeroed=False, keep=False)
             ops.stream_wait(ops._stream(), self._sn_raw[0])
 
+    def touch(self):
+        """call BEFORE writing this engine's weight / state tensors directly (net.params, net.state[...] - set_variables and
+        load_state_dict do it themselves): waits for the side-stream tail of the last step and discards what it prepared for
+        the next one from the old weights (D's spectral norms, dsigma/dW, transformed weights); the next step prepares again"""
+        self._sync_ahead(invalidate=True)
+        self.dis.readout = None
+
     def _sync_ahead(self, invalidate=False):
         """before anything outside a step touches D's weights or power-iteration state: the tail of the last step may still be
         running on its side stream.  invalidate: what it produced no longer belongs to the state (the next step primes again)."""
@@ -1265,6 +1272,11 @@ class GanEngine:
                         self._graph.replay()
                 else:
                     self._plan_step()
+        if self._ahead and not self._ahead_inline():
+            # (host-side facts about what the step just issued - set here, not inside the recorded body: a replayed plan or
+            # graph runs the tail's launches without running _ahead_tail)
+            self._ahead_valid = True
+            self.dis.readout = self._sn_readout
         self.global_step += 1                                                # tied to the D update, my_sngan.py:424
 
     def _plan_step(self):

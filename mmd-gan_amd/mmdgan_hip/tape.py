@@ -630,6 +630,8 @@ class TapeEngine:
         self._fuse_fanin = settings.on('MMDGAN_TAPE_FUSE_ADD')
         self._ready_wait = None
         self._early_d_adam = settings.on('MMDGAN_EARLY_D_ADAM')
+        self._wgrad_defer = settings.on('MMDGAN_WGRAD_DEFER')
+        self._wg_after = []
         self._bn_resign = settings.on('MMDGAN_BN_RESIGN')
         self._d_has_bn = bool(self.dis.bns)
         lib = ops.require_device()
@@ -1207,6 +1209,31 @@ class TapeEngine:
                 raise AssertionError(kind)
         return grads.get(0)
 
+    # ---- deferred slab reductions (mmdgan_wgrad_defer): a Winograd-domain weight gradient leaves its slabs to the prologue of
+    # the NEXT weight-gradient launch of its stream.  What has to read the finished gradient (the adjoint of a folded scaling op,
+    # a spectral-norm fix-up under data parallelism) is queued here and issued behind that next launch - or behind a flush.
+    def _wgrad(self, *args, after=None, **kw):
+        ops.conv2d_wgrad(*args, **kw)                    # (sums the previous call's slabs first, or they were flushed before it)
+        self._wgrad_run_after()
+        if after is not None:
+            self._wg_after.append(after)
+
+    def _wgrad_run_after(self):
+        todo, self._wg_after = self._wg_after, []
+        for fn in todo:
+            fn()
+
+    def _wgrad_flush(self):
+        """every weight gradient issued so far is complete in stream order behind this call"""
+        if self._wg_after or self._wgrad_defer:
+            if self._side and self._wg_after:            # the queued readers belong on the weight-gradient stream
+                with torch.cuda.stream(self._wg_stream):
+                    ops.wgrad_flush()
+                    self._wgrad_run_after()
+            else:
+                ops.wgrad_flush()
+                self._wgrad_run_after()
+
     def _param_grads(self, net, p, a, dy, w, scale):
         """weight / bias gradient of one dense / conv-like primitive from its input `a` and output gradient `dy`"""
         kind, k = p['kind'], p['k']
@@ -1215,30 +1242,39 @@ class TapeEngine:
         gb = net.g(k.bias_name) if k.bias_name is not None else None
         dot = net.sn[k.scope]['dot'] if k.sn else None
         dot_done = False
+        tail = (lambda: self._sn_grad_tail(net, k, gw, w, scale, True)) if (k.sn and not net.opt.fold_fixup) else None
         if kind == 'dense':
             if gb is not None:
                 ops.colsum(dy.reshape(n, -1), out=gb)
             ops.gemm(a.reshape(n, -1), dy.reshape(n, -1), trans_a=True, out=gw)
         elif kind == 'conv':                                             # (<G, W> rides on the weight-gradient launch)
-            ops.conv2d_wgrad(a, dy, k.R, k.stride, out=gw, dbias=gb, w=w if k.sn else None, dot=dot)
-            dot_done = True
+            self._wgrad(a, dy, k.R, k.stride, out=gw, dbias=gb, w=w if k.sn else None, dot=dot, after=tail)
+            return
         elif kind == 'gconv':                                            # 'VALID' / dilated
             self._gconv_wgrad(k, a, dy, ('pg', net.name, k.scope), out=gw, dbias=gb, w=w if k.sn else None, dot=dot)
+            self._wgrad_run_after()                                      # (the launch above carried or followed the previous reduction)
+            if tail is not None:
+                ops.wgrad_flush()
             dot_done = True
         elif kind == 'tconv':                                            # W[R,R,out,in]: roles swapped
             if gb is not None:
                 ops.colsum(dy.reshape(-1, dy.shape[-1]), out=gb)
-            ops.conv2d_wgrad(dy, a, k.R, k.stride, out=gw, w=w if k.sn else None, dot=dot)
-            dot_done = True
+            self._wgrad(dy, a, k.R, k.stride, out=gw, w=w if k.sn else None, dot=dot, after=tail)
+            return
         else:                                                            # a 4x4 kernel with the block's scaling op folded in
             g4 = self._folded[k.scope][1]
+
+            def unfold():                                                # the adjoint of the fold reads the FINISHED 4x4 gradient
+                ops.compose_scaled_conv_grad(g4, k.fold, out=gw)
+                if k.sn:
+                    self._sn_grad_tail(net, k, gw, w, scale, False)
             if kind == 'convdown':
-                ops.conv2d_wgrad(a, dy, 4, 2, out=g4, dbias=gb)
+                self._wgrad(a, dy, 4, 2, out=g4, dbias=gb, after=unfold)
             else:                                                        # transposed form: roles swapped
                 if gb is not None:
                     ops.colsum(dy.reshape(-1, dy.shape[-1]), out=gb)
-                ops.conv2d_wgrad(dy, a, 4, 2, out=g4)
-            ops.compose_scaled_conv_grad(g4, k.fold, out=gw)
+                self._wgrad(dy, a, 4, 2, out=g4, after=unfold)
+            return
         if k.sn:
             self._sn_grad_tail(net, k, gw, w, scale, dot_done)
 
@@ -1318,6 +1354,7 @@ class TapeEngine:
         if bucket is None:
             return
         _, lo, hi = bucket
+        self._wgrad_flush()                              # (a gradient of the bucket may still be waiting for its reduction)
         from . import dist as mdist
         capi = self._dp_backend == 'capi'
 
@@ -1400,6 +1437,7 @@ class TapeEngine:
             self._loss.launch(scores, self.losses)
             ds = self._loss.grads.view(4 * B, -1)   # [dLd/ds_x ; dLd/ds_gen ; dLg/ds_gen ; dLg/ds_x]
             lib.mmdgan_set_outputs_prezeroed(1)     # gradient arenas and the scratch were zeroed at step start
+            ops.wgrad_defer(self._wgrad_defer)      # the weight gradients of the backward pass as a chain (engine.py:_step_body)
             if self._d_joint:
                 # loss_dis (2B rows) and loss_gen (the fake half again) through D together, 3B rows per launch
                 d_in = self._backward(self.dis, dvals, ds[:3 * B], 'bd', param_grads=True, need_input_grad=True, extra_rows=B)
@@ -1417,6 +1455,7 @@ class TapeEngine:
                     d_in = self._backward(self.dis, dvals, ds[2 * B:3 * B], 'bg', rows=(B, 2 * B), param_grads=False,
                                           need_input_grad=True)
             d_early = self._side and self._early_d_adam and not self._dp_active()
+            self._wgrad_flush()                                          # D's last weight gradient: its reduction, and what waits for it
             if d_early:
                 # D's gradients are complete once the weight-gradient stream has drained what it holds now and the main stream
                 # has reached this point; nothing in G's backward pass reads D's weights: D's Adam runs beside it, not at the tail
@@ -1424,9 +1463,12 @@ class TapeEngine:
                 with torch.cuda.stream(self._wg_stream):
                     self.dis.opt.step(self.lr_d, grad_scale=1.0)
             self._backward(self.gen, gvals, d_in, 'gb', param_grads=True)
+            self._wgrad_flush()
             if self._side:
                 ops.stream_wait(main, self._wg_raw)
         finally:
+            self._wg_after = []
+            lib.mmdgan_wgrad_defer(0)
             lib.mmdgan_set_outputs_prezeroed(0)
             self._in_step = False
         if self._exchange_pending:

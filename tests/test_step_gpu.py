@@ -510,6 +510,7 @@ def test_dense_on_dense_generator_keeps_its_gradients_past_the_first_step():
 
 
 def _copy_engine_state(dst, src):
+    dst.touch()                                          # (raw writes into the engine's tensors: GanEngine.touch)
     for nd, ns in ((dst.gen, src.gen), (dst.dis, src.dis)):
         for a, b in ((nd.params, ns.params), (nd.adam_m, ns.adam_m), (nd.adam_v, ns.adam_v),
                      (nd.opt.step_counter, ns.opt.step_counter)):
