@@ -157,6 +157,84 @@ __global__ __launch_bounds__(256) void gemm_skinny16_kernel(const float *__restr
     atomicAdd(C + (size_t)(m0 + om) * ldc + on, v);
 }
 
+// Short reductions over a long panel (round 5).  G's first layer [B,128] x [128,8192], its weight gradient z^T [128,B] x
+// dz [B,8192] and the weight gradient of D's head x^T [8192,2B] x dz [2B,16] have K <= 128: the tiled kernel above walks them
+// in 16-deep steps with a barrier and a global-load round trip each (20-26 us for ~0.1 GFLOP and 4 MB).  Here a workgroup
+// takes a 32-column (64-row) piece of the long dimension, fetches its WHOLE K extent of both operands at once - every load
+// of the launch is in flight together: one memory round trip - and multiplies out of LDS.
+//   npanel: C[M,N] = act(scale * op(A) B + bias), M a multiple of 64 (<= 256), K <= 128, B [K,N] row-major; TRANSA: A is [K,M]
+//   mpanel: C[M,16] = A^T B, A [K,M] row-major, B [K,16]
+constexpr int GP_KMAX = 128;
+// npanel: one wave = 16 rows x 16 columns x the whole K on v_mfma_f32_16x16x4_f32, operands straight from global memory into
+// the MFMA registers (every load of the wave issued before the first multiply), four waves = 64 rows; grid (N / 16, M / 64).
+// (First cut of the round: operands through LDS, a scalar k-loop - 17.8 us alone against 15.8 for the tiled kernel: the loop
+// waited for every LDS read.)
+template <bool TRANSA>
+__global__ __launch_bounds__(256) void gemm_npanel_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
+                                                          const float *__restrict__ bias, const float *__restrict__ scale, int act,
+                                                          float *__restrict__ C, int ldc, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.y * 64 + wave * 16, n0 = blockIdx.x * 16;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // lane (row, kq) holds A[m0 + row][16 u + 4 kq + j] and B[16 u + 4 kq + j][n0 + row], j = 0..3, u = 0 .. K/16 - 1 (+ a 4-deep
+    // tail when K % 16 != 0: K is a multiple of 4)
+    const int nblk = (K + 15) >> 4;
+    float a[GP_KMAX / 16][4], b[GP_KMAX / 16][4];
+#pragma unroll
+    for (int u = 0; u < GP_KMAX / 16; ++u) {
+        if (u < nblk) {
+            const int k = 16 * u + 4 * kq;
+            const bool ok = k < K;                         // (K % 4 == 0: a quad is inside or outside as a whole)
+            if (TRANSA) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[u][j] = ok ? A[(size_t)(k + j) * lda + m0 + row] : 0.f;
+            } else {
+                const float4 v = ok ? *reinterpret_cast<const float4 *>(A + (size_t)(m0 + row) * lda + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                a[u][0] = v.x; a[u][1] = v.y; a[u][2] = v.z; a[u][3] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[u][j] = ok ? B[(size_t)(k + j) * ldb + n0 + row] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < GP_KMAX / 16; ++u) {
+        if (u < nblk) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], b[u][j], acc, 0, 0, 0);
+        }
+    }
+    // accumulator layout of 16x16x4: register r of lane (col = lane & 15, group = lane >> 4) is C[4 * group + r][col]
+    const float sc = scale ? scale[0] : 1.f;
+    const float bv = bias ? bias[n0 + row] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) C[(size_t)(m0 + 4 * kq + r) * ldc + n0 + row] = act_fwd(acc[r] * sc + bv, act);
+}
+
+__global__ __launch_bounds__(256) void gemm_mpanel16_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
+                                                            float *__restrict__ C, int ldc, int K) {
+    __shared__ __attribute__((aligned(16))) float As[GP_KMAX * 64];             // [k][64 rows of M]
+    __shared__ __attribute__((aligned(16))) float Bs[GP_KMAX * 16];             // [k][16]
+    const int tid = threadIdx.x, m0 = blockIdx.x * 64;
+    for (int e = tid; e < K * 16; e += 256) {
+        const int k = e >> 4, q = e & 15;
+        *reinterpret_cast<float4 *>(&As[k * 64 + 4 * q]) = *reinterpret_cast<const float4 *>(A + (size_t)k * lda + m0 + 4 * q);
+    }
+    for (int e = tid; e < K * 4; e += 256) {
+        const int k = e >> 2, q = e & 3;
+        *reinterpret_cast<float4 *>(&Bs[k * 16 + 4 * q]) = *reinterpret_cast<const float4 *>(B + (size_t)k * ldb + 4 * q);
+    }
+    __syncthreads();
+    const int m = tid >> 2, nq = tid & 3;                  // one row, four columns
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < K; ++k) {
+        const float a = As[k * 64 + m];
+        const float4 b = *reinterpret_cast<const float4 *>(&Bs[k * 16 + 4 * nq]);
+        acc.x = fmaf(a, b.x, acc.x); acc.y = fmaf(a, b.y, acc.y); acc.z = fmaf(a, b.z, acc.z); acc.w = fmaf(a, b.w, acc.w);
+    }
+    *reinterpret_cast<float4 *>(C + (size_t)(m0 + m) * ldc + 4 * nq) = acc;
+}
+
 }  // namespace mmdgan
 
 using namespace mmdgan;
@@ -192,6 +270,21 @@ extern "C" int mmdgan_gemm(int transA, int transB, int M, int N, int K, const fl
             ksplit = (K + kchunk - 1) / kchunk;
             if (!out_zeroed && zero_output(C, sizeof(float) * (size_t)M * ldc, st) != hipSuccess) return check_launch("gemm memset");
             hipLaunchKernelGGL(gemm_skinny16_kernel, dim3(M / 16, ksplit), dim3(256), 0, st, A, lda, B, ldb, bias, scale, C, ldc, K, kchunk);
+            return check_launch("gemm");
+        }
+    }
+    auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
+    if (tuning().gemm_panel && !transB && !dact_of && K <= GP_KMAX && K % 4 == 0 && al16(A) && al16(B) && al16(C) && lda % 4 == 0 &&
+        ldb % 4 == 0 && ldc % 4 == 0) {
+        if (M % 64 == 0 && M <= 256 && N % 16 == 0 && N >= 2048) {
+            if (transA)
+                hipLaunchKernelGGL(gemm_npanel_kernel<true>, dim3(N / 16, M / 64), dim3(256), 0, st, A, lda, B, ldb, bias, scale, act, C, ldc, K);
+            else
+                hipLaunchKernelGGL(gemm_npanel_kernel<false>, dim3(N / 16, M / 64), dim3(256), 0, st, A, lda, B, ldb, bias, scale, act, C, ldc, K);
+            return check_launch("gemm");
+        }
+        if (transA && N == 16 && M % 64 == 0 && M >= 2048 && !bias && !scale && act == MMDGAN_ACT_LINEAR) {
+            hipLaunchKernelGGL(gemm_mpanel16_kernel, dim3(M / 64), dim3(256), 0, st, A, lda, B, ldb, C, ldc, K);
             return check_launch("gemm");
         }
     }

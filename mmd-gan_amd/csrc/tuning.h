@@ -25,10 +25,11 @@ struct Tuning {
     long wino2_wgrad_min_tiles;  // MMDGAN_WINO2_WGRAD_MIN_TILES=n   ... from n tiles on (256)
     int wgrad_cus;               // MMDGAN_WGRAD_CUS=n           workgroups (= CUs) the one-round weight-gradient kernels size their grid for (224)
     int gemm_skinny;             // MMDGAN_GEMM_SKINNY=0         D's head product on the tiled kernel, not the skinny-N MFMA one
+    int gemm_panel;              // MMDGAN_GEMM_PANEL=0          short-K dense products (G's first layer, the dense weight gradients) on the tiled kernel
 };
 
 inline const Tuning &tuning_defaults() {
-    static const Tuning d = {0, 0, 1, -1, 385, 1, 1, 1, 1, 384, 1, 256, 224, 1};
+    static const Tuning d = {0, 0, 1, -1, 385, 1, 1, 1, 1, 384, 1, 256, 224, 1, 1};
     return d;
 }
 
@@ -52,6 +53,7 @@ inline const Tuning &tuning() {
         const int cus = geti("MMDGAN_WGRAD_CUS", v.wgrad_cus);
         v.wgrad_cus = cus > 0 ? cus : v.wgrad_cus;
         v.gemm_skinny = geti("MMDGAN_GEMM_SKINNY", v.gemm_skinny) != 0;
+        v.gemm_panel = geti("MMDGAN_GEMM_PANEL", v.gemm_panel) != 0;
         return v;
     }();
     return t;

@@ -862,6 +862,26 @@ def test_gemm(ops, M, N, K, ta, tb):
         assert rel_err(c3.cpu().numpy(), ref * np.where(full > 0, 1.0, 0.1)) <= RTOL
 
 
+@pytest.mark.parametrize('M,N,K,ta', [(64, 8192, 128, False), (128, 8192, 64, True), (64, 2048, 128, False), (192, 4096, 84, True),
+                                       (64, 12288, 100, False), (128, 2048, 64, False), (256, 16384, 8, True)])
+def test_gemm_short_reduction_panels(ops, M, N, K, ta):
+    """the whole-K panel kernels (csrc/gemm.hip: gemm_npanel_kernel - G's first layer and its weight gradient;
+    gemm_mpanel16_kernel - the weight gradient of D's head) against fp64, with and without bias / scale / activation"""
+    rs = np.random.RandomState(M + N + K)
+    a = rs.randn(*((K, M) if ta else (M, K))).astype(np.float32)
+    b = rs.randn(K, N).astype(np.float32)
+    bias = rs.randn(N).astype(np.float32)
+    ref = (a.T if ta else a).astype(np.float64) @ b.astype(np.float64)
+    assert rel_err(ops.gemm(dev(a), dev(b), ta, False).cpu().numpy(), ref) <= RTOL
+    assert rel_err(ops.gemm(dev(a), dev(b), ta, False, bias=dev(bias), scale=dev([0.7]), act='lrelu').cpu().numpy(),
+                   np.where(ref * 0.7 + bias > 0, 1.0, 0.1) * (ref * 0.7 + bias)) <= RTOL
+    # the transposed problem: long M, sixteen columns (A^T B with A [K, M])
+    b16 = rs.randn(K, 16).astype(np.float32)
+    a_t = rs.randn(K, N).astype(np.float32)
+    got = ops.gemm(dev(a_t), dev(b16), True, False)
+    assert rel_err(got.cpu().numpy(), a_t.T.astype(np.float64) @ b16.astype(np.float64)) <= RTOL
+
+
 def test_colsum_dot_layout(ops):
     rs = np.random.RandomState(0)
     x = rs.randn(5000, 70).astype(np.float32)
