@@ -186,7 +186,7 @@ extern "C" long mmdgan_tuning_describe(char *buf, size_t cap) {
     add("wino_wgrad_slab", t.wino_wgrad_slab, d.wino_wgrad_slab); add("wino2", t.wino2, d.wino2);
     add("wino2_ksplit", t.wino2_ksplit, d.wino2_ksplit); add("wino2_ksplit_below", t.wino2_ksplit_below, d.wino2_ksplit_below);
     add("wino2_wgrad", t.wino2_wgrad, d.wino2_wgrad); add("wino2_wgrad_min_tiles", t.wino2_wgrad_min_tiles, d.wino2_wgrad_min_tiles);
-    add("wgrad_cus", t.wgrad_cus, d.wgrad_cus); add("gemm_skinny", t.gemm_skinny, d.gemm_skinny); add("gemm_panel", t.gemm_panel, d.gemm_panel);
+    add("wgrad_cus", t.wgrad_cus, d.wgrad_cus); add("gemm_skinny", t.gemm_skinny, d.gemm_skinny); add("gemm_panel", t.gemm_panel, d.gemm_panel); add("mmd_d16", t.mmd_d16, d.mmd_d16);
     if (buf && cap > 0) {
         const size_t n = out.size() < cap - 1 ? out.size() : cap - 1;
         memcpy(buf, out.data(), n);

@@ -23,6 +23,7 @@
 // Per-block partial sums go to the workspace; the last block to arrive (agent-scope release /
 // acquire, placement independent) reduces them in block order and writes the 8 output scalars.
 #include "common.h"
+#include "tuning.h"
 
 namespace mmdgan {
 
@@ -67,10 +68,12 @@ __device__ __forceinline__ void gauss(float D, float &K, float &G) {
     }
 }
 
-template <int LT>
+// DFIX: the score width as a compile-time constant (16 in every shipped architecture: my_test_cifar.py:37) - the dot products
+// and the gradient update unroll, their LDS reads batch; 0: any d <= 256 at run time.
+template <int LT, int DFIX>
 __global__ __launch_bounds__(256) void mmd_kernel(MmdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int d = a.d, ld = d + 1;
+    const int d = DFIX ? DFIX : a.d, ld = d + 1;
     float *tx = smem;                       // [64][ld]
     float *ty = tx + kMmdTile * ld;         // [64][ld]
     float *rx = ty + kMmdTile * ld;         // [4][d]   this block's rows of s_gen
@@ -223,22 +226,23 @@ __global__ __launch_bounds__(256) void mmd_kernel(MmdArgs a) {
         for (int q = 0; q < kNumSums; ++q) {
             double t = 0;
             for (int w = 0; w < kMmdRows; ++w) t += bsum[w * kNumSums + q];
-            a.partials[(size_t)blockIdx.x * kNumSums + q] = t;
+            // 8-byte agent-scope atomics on BOTH sides of the hand-off (write-through stores here, L1-bypassing loads in the last
+            // block): the 48 bytes of a block need no L2 write-back and no L1 invalidate - the release / acquire fence pair of
+            // rounds 1-4 was ~3.4 us of a 14 us launch at B = 64 (MI355X_MICROARCH.md, "valid forms")
+            __hip_atomic_store(a.partials + (size_t)blockIdx.x * kNumSums + q, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         s_ticket = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (s_ticket != gridDim.x - 1) return;
-    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
     if (wave == 0) {
         double tot[kNumSums];
 #pragma unroll
         for (int q = 0; q < kNumSums; ++q) {
             double t = 0;
-            for (int b = lane; b < (int)gridDim.x; b += 64) t += a.partials[(size_t)b * kNumSums + q];
+            for (int b = lane; b < (int)gridDim.x; b += 64)
+                t += __hip_atomic_load(a.partials + (size_t)b * kNumSums + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             tot[q] = wave_sum(t);
         }
         if (lane == 0) {
@@ -332,14 +336,14 @@ static int launch_pairwise(const float *s_gen, const float *s_x, int B, int d, i
     if (zero_output(a.counter, 64, st) != hipSuccess) return check_launch("mmd_loss memset");
     const int blocks = (B + kMmdRows - 1) / kMmdRows;
     const size_t lds = mmd_lds_bytes(d);
-    void (*kern)(MmdArgs) = loss_type == MMDGAN_LOSS_REP ? mmd_kernel<MMDGAN_LOSS_REP>
-                          : loss_type == MMDGAN_LOSS_RMB ? mmd_kernel<MMDGAN_LOSS_RMB>
-                          : loss_type == MMDGAN_LOSS_MMD_G ? mmd_kernel<MMDGAN_LOSS_MMD_G> : mmd_kernel<MMDGAN_LOSS_MGB>;
-    static bool attr_set[4] = {false, false, false, false};
-    if (!attr_set[loss_type] && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set[loss_type] = true;
-    }
+    void (*kern)(MmdArgs);
+    if (d == 16 && tuning().mmd_d16)
+        kern = loss_type == MMDGAN_LOSS_REP ? mmd_kernel<MMDGAN_LOSS_REP, 16> : loss_type == MMDGAN_LOSS_RMB ? mmd_kernel<MMDGAN_LOSS_RMB, 16>
+             : loss_type == MMDGAN_LOSS_MMD_G ? mmd_kernel<MMDGAN_LOSS_MMD_G, 16> : mmd_kernel<MMDGAN_LOSS_MGB, 16>;
+    else
+        kern = loss_type == MMDGAN_LOSS_REP ? mmd_kernel<MMDGAN_LOSS_REP, 0> : loss_type == MMDGAN_LOSS_RMB ? mmd_kernel<MMDGAN_LOSS_RMB, 0>
+             : loss_type == MMDGAN_LOSS_MMD_G ? mmd_kernel<MMDGAN_LOSS_MMD_G, 0> : mmd_kernel<MMDGAN_LOSS_MGB, 0>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, a);
     return check_launch("mmd_loss");
 }

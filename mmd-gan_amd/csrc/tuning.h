@@ -25,11 +25,12 @@ struct Tuning {
     long wino2_wgrad_min_tiles;  // MMDGAN_WINO2_WGRAD_MIN_TILES=n   ... from n tiles on (256)
     int wgrad_cus;               // MMDGAN_WGRAD_CUS=n           workgroups (= CUs) the one-round weight-gradient kernels size their grid for (224)
     int gemm_skinny;             // MMDGAN_GEMM_SKINNY=0         D's head product on the tiled kernel, not the skinny-N MFMA one
+    int mmd_d16;               // MMDGAN_MMD_D16=0             the pairwise loss with d = 16 on the run-time-d instantiation of its kernel
     int gemm_panel;              // MMDGAN_GEMM_PANEL=0          short-K dense products (G's first layer, the dense weight gradients) on the tiled kernel
 };
 
 inline const Tuning &tuning_defaults() {
-    static const Tuning d = {0, 0, 1, -1, 385, 1, 1, 1, 1, 384, 1, 256, 224, 1, 1};
+    static const Tuning d = {0, 0, 1, -1, 385, 1, 1, 1, 1, 384, 1, 256, 224, 1, 1, 1};
     return d;
 }
 
@@ -54,6 +55,7 @@ inline const Tuning &tuning() {
         v.wgrad_cus = cus > 0 ? cus : v.wgrad_cus;
         v.gemm_skinny = geti("MMDGAN_GEMM_SKINNY", v.gemm_skinny) != 0;
         v.gemm_panel = geti("MMDGAN_GEMM_PANEL", v.gemm_panel) != 0;
+        v.mmd_d16 = geti("MMDGAN_MMD_D16", v.mmd_d16) != 0;
         return v;
     }();
     return t;

@@ -882,6 +882,7 @@ class GanEngine:
             # IS the first power-iteration stream)
             for st in (self._sn_raw[:1] if self._sn_fused else self._sn_raw):
                 ops.stream_wait(self._wg_raw, st)
+        held = None
         for li in range(len(specs) - 1, -1, -1):
             s = specs[li]
             x_in = b['dis_in'] if li == 0 else b[specs[li - 1].scope + '#y']
@@ -906,9 +907,22 @@ class GanEngine:
                 if s.sn and not net.opt.fold_fixup:                          # data-parallel replicas fix up before the exchange
                     ops.wgrad_flush()                                        # (the fix-up reads the summed gradient and <G, W>)
                     ops.sn_wgrad_fixup(gw.view(-1), net.state[s.scope + '#dsigma'].view(-1), dot, net.state[s.scope + '#sigma'], scale)
-            self._on_wg_stream(param_grads, s)
+            # D's dense head sits between the loss and the first convolution of the backward pass with nothing beside it: its
+            # parameter gradients wait for the NEXT layer's hand-over to the weight-gradient stream (one marker in the main queue -
+            # ~6 us of idle queue each - instead of two in a row; its input-gradient, which the main chain needs, goes first)
+            hold = self._queue_opt and self._side_wgrad and s.op == 'd' and li == len(specs) - 1 and li > 0
+            if held is not None:
+                fn, lj = held
+                held = None
+                self._on_wg_stream(lambda fn=fn, pg=param_grads: (fn(), pg()), s)
+                self._exchange(net, lj)
+            elif not hold:
+                self._on_wg_stream(param_grads, s)
+            if hold:
+                held = (param_grads, li)
             if li > 0:
-                self._exchange(net, li)
+                if not hold:
+                    self._exchange(net, li)
                 prev = specs[li - 1]
                 dprev, yprev = b[prev.scope + '#dz'], b[prev.scope + '#y']
                 if s.op == 'd':

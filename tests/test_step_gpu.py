@@ -584,7 +584,10 @@ def test_power_iteration_chains_on_two_streams_give_the_one_stream_result(monkey
         for _ in range(4):
             eng.step(real, z)
             torch.cuda.synchronize()
-            got.append({s.scope: (float(eng.dis.state[s.scope + '#sigma'].item()), eng.dis.state[s.scope + '#dsigma'].clone())
+            # (d sigma / dW as the step just run used it: with the next step's iteration at this step's tail, GanEngine._ahead_tail,
+            # the live buffer already holds the next one - Network.readout has the copy)
+            st = eng.dis.readout if eng.dis.readout is not None else eng.dis.state
+            got.append({s.scope: (float(eng.dis.state[s.scope + '#sigma'].item()), st[s.scope + '#dsigma'].clone())
                         for s in eng.dis.specs if s.sn})
         out[n_streams] = got
     for a, b in zip(out['1'], out['2']):
