@@ -298,6 +298,21 @@ int mmdgan_dot(const float *a, const float *b, long n, float *out, void *stream)
  * what the forward call read / wrote (no optimiser step on gamma / beta and no in-place change of x between the two calls).
  * ---------------------------------------------------------------------------------------------- */
 size_t mmdgan_bn_workspace_bytes(int C);
+/* A batch norm behind a convolution (layer_func.py:913-966): mmdgan_conv2d_fwd_stats / _dgrad_stats are mmdgan_conv2d_fwd /
+ * _dgrad (no dact_of) that ALSO accumulate the per-channel sums of their output and of its squares into `bn_totals`
+ * (mmdgan_bn_workspace_bytes(output channels) bytes; zeroed by the entry unless mmdgan_set_outputs_prezeroed(1)) - where the
+ * launch's last pass writes the output (the slab pass of a reduction-split Winograd launch) the sums are formed there, otherwise
+ * by the statistics pass of mmdgan_bn_fwd_train behind the convolution: the totals are the same for every geometry.
+ * mmdgan_bn_fwd_apply is mmdgan_bn_fwd_train with those totals given: it normalises, applies the activation and updates the
+ * moving statistics, and does not read x for the statistics again.  (version 500) */
+int mmdgan_conv2d_fwd_stats(const mmdgan_conv_geom *g, const float *x, const float *w, const float *bias, const float *scale,
+                            int act, float *y, void *bn_totals, void *stream);
+int mmdgan_conv2d_dgrad_stats(const mmdgan_conv_geom *g, const float *dy, const float *w, const float *bias, const float *scale,
+                              int act, float *dx, void *bn_totals, void *stream);
+int mmdgan_bn_fwd_apply(const float *x, long rows, int C, const float *gamma, const float *beta, float eps,
+                        float momentum, int unbiased_moving_var, int act, float *y, float *save_mean,
+                        float *save_invstd, const float *moving_mean, const float *moving_var,
+                        float *new_moving_mean, float *new_moving_var, void *workspace, void *stream);
 int mmdgan_bn_fwd_train(const float *x, long rows, int C, const float *gamma, const float *beta, float eps,
                         float momentum, int unbiased_moving_var, int act, float *y, float *save_mean,
                         float *save_invstd, const float *moving_mean, const float *moving_var,

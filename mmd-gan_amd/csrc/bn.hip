@@ -14,6 +14,8 @@
 #include "common.h"
 #include <stdint.h>
 
+#include "conv_internal.h"
+
 namespace mmdgan {
 
 // One workgroup per CU: kBnBlocks workgroups = (channel blocks of 64) x (row splits).
@@ -368,16 +370,28 @@ static void launch_partial_v4(dim3 grid, hipStream_t st, const float *x, const f
         hipLaunchKernelGGL((bn_partial_v4_kernel<MODE, 4>), grid, dim3(256), 0, st, x, y, dy, rows, C, rps, mean, invstd, gamma, beta, act, part);
 }
 
+int bn_slot_count(int C) { return bn_slots(C); }
+int bn_stats_pass(const float *x, long rows, int C, double *totals, hipStream_t st) {
+    long rps;
+    const int splits = bn_splits(rows, C, &rps);
+    if ((C % 4) == 0 && al16(x))
+        launch_partial_v4<0>(dim3((C + 63) / 64, splits), st, x, nullptr, nullptr, rows, C, rps, nullptr, nullptr, nullptr, nullptr, 0, totals);
+    else
+        hipLaunchKernelGGL(bn_partial_kernel<0>, dim3((C + 63) / 64, splits), dim3(256), 0, st, x, nullptr, nullptr, rows,
+                           C, rps, nullptr, nullptr, nullptr, nullptr, 0, totals);
+    return check_launch("bn statistics");
+}
+
 }  // namespace mmdgan
 
 using namespace mmdgan;
 
 extern "C" size_t mmdgan_bn_workspace_bytes(int C) { return C < 1 ? 0 : (size_t)bn_slots(C) * 2 * C * sizeof(double); }
 
-extern "C" int mmdgan_bn_fwd_train(const float *x, long rows, int C, const float *gamma, const float *beta, float eps,
-                                   float momentum, int unbiased_moving_var, int act, float *y, float *save_mean,
-                                   float *save_invstd, const float *moving_mean, const float *moving_var,
-                                   float *new_moving_mean, float *new_moving_var, void *workspace, void *stream) {
+static int bn_fwd_train_impl(const float *x, long rows, int C, const float *gamma, const float *beta, float eps,
+                             float momentum, int unbiased_moving_var, int act, float *y, float *save_mean,
+                             float *save_invstd, const float *moving_mean, const float *moving_var,
+                             float *new_moving_mean, float *new_moving_var, void *workspace, void *stream, bool have_totals) {
     MMDGAN_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && workspace, "bn_fwd_train: null pointer");
     MMDGAN_REQUIRE(rows >= 1 && C >= 1, "bn_fwd_train: bad shape");
     MMDGAN_REQUIRE(!new_moving_mean || (moving_mean && moving_var && new_moving_var), "bn_fwd_train: moving stats");
@@ -385,13 +399,15 @@ extern "C" int mmdgan_bn_fwd_train(const float *x, long rows, int C, const float
     long rps;
     const int splits = bn_splits(rows, C, &rps);
     double *part = (double *)workspace;
-    if (zero_output(part, sizeof(double) * bn_slots(C) * 2 * C, st) != hipSuccess) return check_launch("bn_fwd_train memset");
     const bool v4 = (C % 4) == 0 && al16(x) && al16(y) && al16(gamma) && al16(beta) && al16(save_mean) && al16(save_invstd);
-    if (v4)
-        launch_partial_v4<0>(dim3((C + 63) / 64, splits), st, x, nullptr, nullptr, rows, C, rps, nullptr, nullptr, nullptr, nullptr, 0, part);
-    else
-        hipLaunchKernelGGL(bn_partial_kernel<0>, dim3((C + 63) / 64, splits), dim3(256), 0, st, x, nullptr, nullptr, rows,
-                           C, rps, nullptr, nullptr, nullptr, nullptr, 0, part);
+    if (!have_totals) {
+        if (zero_output(part, sizeof(double) * bn_slots(C) * 2 * C, st) != hipSuccess) return check_launch("bn_fwd_train memset");
+        if (v4)
+            launch_partial_v4<0>(dim3((C + 63) / 64, splits), st, x, nullptr, nullptr, rows, C, rps, nullptr, nullptr, nullptr, nullptr, 0, part);
+        else
+            hipLaunchKernelGGL(bn_partial_kernel<0>, dim3((C + 63) / 64, splits), dim3(256), 0, st, x, nullptr, nullptr, rows,
+                               C, rps, nullptr, nullptr, nullptr, nullptr, 0, part);
+    }
     const long total = rows * C;
     long blocks = ((v4 ? (total / 4 + kBnApplyInFlight - 1) / kBnApplyInFlight : total) + 255) / 256;
     if (blocks > (v4 ? kBnApplyBlocks : 4096)) blocks = v4 ? kBnApplyBlocks : 4096;
@@ -405,6 +421,21 @@ extern "C" int mmdgan_bn_fwd_train(const float *x, long rows, int C, const float
                            eps, momentum, unbiased_moving_var, act, y, save_mean, save_invstd, moving_mean, moving_var,
                            new_moving_mean, new_moving_var);
     return check_launch("bn_fwd_train");
+}
+extern "C" int mmdgan_bn_fwd_train(const float *x, long rows, int C, const float *gamma, const float *beta, float eps,
+                                   float momentum, int unbiased_moving_var, int act, float *y, float *save_mean,
+                                   float *save_invstd, const float *moving_mean, const float *moving_var,
+                                   float *new_moving_mean, float *new_moving_var, void *workspace, void *stream) {
+    return bn_fwd_train_impl(x, rows, C, gamma, beta, eps, momentum, unbiased_moving_var, act, y, save_mean, save_invstd, moving_mean,
+                             moving_var, new_moving_mean, new_moving_var, workspace, stream, false);
+}
+// ... with the totals of x already in `workspace` (mmdgan_conv2d_fwd_stats / _dgrad_stats produced x): normalise and update only
+extern "C" int mmdgan_bn_fwd_apply(const float *x, long rows, int C, const float *gamma, const float *beta, float eps,
+                                   float momentum, int unbiased_moving_var, int act, float *y, float *save_mean,
+                                   float *save_invstd, const float *moving_mean, const float *moving_var,
+                                   float *new_moving_mean, float *new_moving_var, void *workspace, void *stream) {
+    return bn_fwd_train_impl(x, rows, C, gamma, beta, eps, momentum, unbiased_moving_var, act, y, save_mean, save_invstd, moving_mean,
+                             moving_var, new_moving_mean, new_moving_var, workspace, stream, true);
 }
 
 extern "C" int mmdgan_bn_fwd_infer(const float *x, long rows, int C, const float *gamma, const float *beta, float eps,

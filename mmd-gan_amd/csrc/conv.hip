@@ -22,9 +22,13 @@ bool force_direct() { return tuning().force_direct != 0; }
 bool force_valu_thin() { return tuning().thin_valu != 0; }
 inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }    // also true for nullptr
 thread_local bool t_addend_applied = false;
+thread_local double *t_bn_totals = nullptr;
+thread_local bool t_bn_applied = false;
 }  // namespace
 namespace mmdgan {
 void addend_applied() { t_addend_applied = true; }
+double *bn_stats_request() { return t_bn_totals; }
+void bn_stats_applied() { t_bn_applied = true; }
 }
 
 namespace {
@@ -93,6 +97,35 @@ static int conv2d_fwd_impl(const mmdgan_conv_geom *g, const float *x, const floa
         return thinm_fwd(d, ep, x, w, y, (hipStream_t)stream);
     if (!force_direct() && (thin_fwd_in_ok(d) || thin_fwd_out_ok(d))) return thin_fwd(d, ep, x, w, y, (hipStream_t)stream);
     return direct_fwd(d, ep, x, w, y, (hipStream_t)stream);
+}
+
+// y = conv2d_fwd(...) and bn_totals += [sum y, sum y^2] per output channel (the layout of mmdgan_bn_workspace_bytes; the caller
+// zeroes it or runs under mmdgan_set_outputs_prezeroed(1)): what mmdgan_bn_fwd_apply normalises with - layer_func.py:953-966
+// behind a convolution, without a pass over y for the statistics where the launch's last pass can form them
+template <class F>
+static int with_bn_stats(double *totals, const float *out, long rows, int C, void *stream, const char *what, F &&launch) {
+    MMDGAN_REQUIRE(totals, "%s: null totals", what);
+    if (!outputs_prezeroed() && memset_async(totals, 0, sizeof(double) * bn_slot_count(C) * 2 * C, (hipStream_t)stream) != hipSuccess)
+        return check_launch("conv2d stats memset");
+    t_bn_totals = totals;
+    t_bn_applied = false;
+    const int rc = launch();
+    t_bn_totals = nullptr;
+    if (rc) return rc;
+    return t_bn_applied ? MMDGAN_OK : bn_stats_pass(out, rows, C, totals, (hipStream_t)stream);
+}
+extern "C" int mmdgan_conv2d_fwd_stats(const mmdgan_conv_geom *g, const float *x, const float *w, const float *bias,
+                                       const float *scale, int act, float *y, void *bn_totals, void *stream) {
+    if (int rc = validate(g, "conv2d_fwd_stats")) return rc;
+    const ConvDims d = conv_dims(*g);
+    return with_bn_stats((double *)bn_totals, y, (long)d.N * d.P * d.Q, d.K, stream, "conv2d_fwd_stats",
+                         [&]() { return conv2d_fwd_impl(g, x, w, bias, scale, act, nullptr, 0, nullptr, y, stream); });
+}
+extern "C" int mmdgan_conv2d_dgrad_stats(const mmdgan_conv_geom *g, const float *dy, const float *w, const float *bias,
+                                         const float *scale, int act, float *dx, void *bn_totals, void *stream) {
+    if (int rc = validate(g, "conv2d_dgrad_stats")) return rc;
+    return with_bn_stats((double *)bn_totals, dx, (long)g->N * g->H * g->W, g->C, stream, "conv2d_dgrad_stats",
+                         [&]() { return conv2d_dgrad_impl(g, dy, w, bias, scale, act, nullptr, 0, nullptr, dx, stream); });
 }
 
 extern "C" int mmdgan_conv2d_dgrad(const mmdgan_conv_geom *g, const float *dy, const float *w, const float *bias,

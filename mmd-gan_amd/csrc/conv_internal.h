@@ -36,6 +36,14 @@ struct ConvEpilogue {
     }
 };
 void addend_applied();        // conv.hip: the launch just issued applies ep.addend itself (thread-local note for the entry point)
+// Batch-norm statistics riding on a convolution (mmdgan_conv2d_*_stats): the entry asks for the per-channel sums of its output
+// and of its squares in the totals layout of bn.hip ([slot][2][C] fp64, atomics).  A launcher whose last pass writes the output
+// (the slab pass of a reduction-split Winograd launch) takes the request with bn_stats_request() and confirms with
+// bn_stats_applied(); otherwise the entry appends the statistics pass of bn.hip - every geometry gives the same totals.
+double *bn_stats_request();   // the totals the current call should accumulate into, or nullptr
+void bn_stats_applied();
+int bn_stats_pass(const float *x, long rows, int C, double *totals, hipStream_t st);   // bn.hip: totals += [sum x, sum x^2]
+int bn_slot_count(int C);     // bn.hip: copies of the totals (row split i adds into slot i % count)
 constexpr long kNoWrap = 0x7fffffffffffffffL;
 
 int direct_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, float *y, hipStream_t st);

@@ -511,7 +511,87 @@ __global__ __launch_bounds__(256) void slab_epilogue_kernel(const float4 *__rest
     }
 }
 
+// The same pass with batch-norm statistics on the way (mmdgan_conv2d_*_stats): out = epilogue(sum of the slabs) AND
+// totals += [sum out, sum out^2] per channel - the tensor a batch norm normalises next is summed while it is written instead
+// of being read again by a statistics launch.  The workgroup shape is bn.hip's (64 channels x a run of rows, sixteen row
+// lanes, fp64 sums, one atomic per channel and workgroup into slot blockIdx.y % slots); U rows of a thread in flight.
+template <int U>
+__global__ __launch_bounds__(256) void slab_epilogue_bn_kernel(const float *__restrict__ part, int ksplit, long total, long rows, int C,
+                                                              long rows_per_split, ConvEpilogue ep, float *__restrict__ out,
+                                                              double *__restrict__ totals, int slots) {
+    __shared__ double red[2][16][65];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cl * 4;
+    const long r0 = (long)blockIdx.y * rows_per_split;
+    long r1 = r0 + rows_per_split;
+    if (r1 > rows) r1 = rows;
+    const float sc = ep.scale ? ep.scale[0] : 1.f;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ep.bias) bv = *reinterpret_cast<const float4 *>(ep.bias + c);
+    double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+    for (long r = r0 + rl; r < r1; r += 16 * U) {
+        float4 v[U], p[U][7];                              // every slab of the thread's rows in flight at once (ksplit <= 8)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long rr = r + u * 16;
+            const bool ok = rr < r1;
+            v[u] = ok ? *reinterpret_cast<const float4 *>(part + rr * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 1; k < 8; ++k)
+                if (k < ksplit) p[u][k - 1] = ok ? *reinterpret_cast<const float4 *>(part + (long)k * total + rr * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int k = 1; k < 8; ++k)
+                if (k < ksplit) { v[u].x += p[u][k - 1].x; v[u].y += p[u][k - 1].y; v[u].z += p[u][k - 1].z; v[u].w += p[u][k - 1].w; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long rr = r + u * 16;
+            if (rr >= r1) continue;
+            float4 o;
+            o.x = act_fwd(v[u].x * sc + bv.x, ep.act); o.y = act_fwd(v[u].y * sc + bv.y, ep.act);
+            o.z = act_fwd(v[u].z * sc + bv.z, ep.act); o.w = act_fwd(v[u].w * sc + bv.w, ep.act);
+            *reinterpret_cast<float4 *>(out + rr * C + c) = o;
+            const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const double t = (double)ov[j]; sa[j] += t; sb[j] += t * t; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[0][rl][cl * 4 + j] = sa[j]; red[1][rl][cl * 4 + j] = sb[j]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, ch = threadIdx.x & 63;
+        double t = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[which][k][ch];
+        atomicAdd(totals + (size_t)(blockIdx.y % slots) * 2 * C + (size_t)which * C + blockIdx.x * 64 + ch, t);
+    }
+}
+
 int slab_epilogue(const float *slabs, int nslabs, long total, int Ko, const ConvEpilogue &ep, float *out, hipStream_t st) {
+    if (double *totals = bn_stats_request()) {
+        if (Ko % 64 == 0 && !ep.dact && !ep.addend && nslabs <= 8) {
+            const long rows = total / Ko;
+            const int cblocks = Ko / 64;
+            long splits = 512 / cblocks;                  // two workgroups per CU
+            if (splits < 1) splits = 1;
+            long rps = (rows + splits - 1) / splits;
+            if (rps < 16) rps = 16;
+            splits = (rows + rps - 1) / rps;
+            const dim3 grid((unsigned)cblocks, (unsigned)splits);
+            if (rps >= 32)
+                hipLaunchKernelGGL(slab_epilogue_bn_kernel<2>, grid, dim3(256), 0, st, slabs, nslabs, total, rows, Ko, rps, ep, out, totals,
+                                   bn_slot_count(Ko));
+            else
+                hipLaunchKernelGGL(slab_epilogue_bn_kernel<1>, grid, dim3(256), 0, st, slabs, nslabs, total, rows, Ko, rps, ep, out, totals,
+                                   bn_slot_count(Ko));
+            bn_stats_applied();
+            return check_launch("conv slab epilogue (+ batch-norm statistics)");
+        }
+    }
     const long n4 = total / 4;
     long blocks = (n4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;

@@ -64,6 +64,9 @@ SIGNATURES = {
     'mmdgan_dot': (_I, [_P, _P, _L, _P, _P]),
     'mmdgan_bn_workspace_bytes': (ctypes.c_size_t, [_I]),
     'mmdgan_bn_fwd_train': (_I, [_P, _L, _I, _P, _P, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'mmdgan_bn_fwd_apply': (_I, [_P, _L, _I, _P, _P, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'mmdgan_conv2d_fwd_stats': (_I, [_G, _P, _P, _P, _P, _I, _P, _P, _P]),
+    'mmdgan_conv2d_dgrad_stats': (_I, [_G, _P, _P, _P, _P, _I, _P, _P, _P]),
     'mmdgan_bn_fwd_infer': (_I, [_P, _L, _I, _P, _P, _F, _I, _P, _P, _P, _P]),
     'mmdgan_bn_bwd': (_I, [_P, _P, _P, _L, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     'mmdgan_sn_norm': (_I, [_P, _L, _P, _P, _P]),

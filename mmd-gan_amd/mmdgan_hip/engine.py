@@ -718,14 +718,18 @@ class GanEngine:
             # a long-K dense output is on the step's zero list (_alloc): only then may the launch split K
             zeroed = self._in_step and tgt.data_ptr() in self._zeroed_ptrs
             ops.gemm(x.reshape(n, -1), w, bias=bias, scale=scale, act=fused_act, out=tgt.view(n, -1), out_zeroed=zeroed)
+        # a batch norm behind a convolution: its statistics ride on the launch that writes the tensor (mmdgan_conv2d_*_stats)
+        totals = self._bn_totals[s.scope][0] if (s.bn and is_training and self._in_step and s.op != 'd') else None
+        if s.op == 'd':
+            pass
         elif s.op == 'c':
             # transformed weights only for a batch the library runs Winograd at (its thresholds count tiles)
             wino = self._wino.get(s.scope, (None, None, None))[0] if is_training and self._wino_fwd_ok(net, s, n) else None
-            ops.conv2d_fwd(x, w, s.stride, bias=bias, scale=scale, act=fused_act, out=tgt, wino=wino)
+            ops.conv2d_fwd(x, w, s.stride, bias=bias, scale=scale, act=fused_act, out=tgt, wino=wino, bn_totals=totals)
         else:
             wino = self._wino.get(s.scope, (None, None, None))[1] if n == self.B and is_training else None
             ops.conv2d_dgrad(x, w, (tgt.shape[1], tgt.shape[2]), s.stride, bias=bias, scale=scale, act=fused_act, out=tgt,
-                             wino=wino)
+                             wino=wino, bn_totals=totals)
         if s.bn:
             gamma, beta = net.p(s.scope + '/BN/BN/gamma'), net.p(s.scope + '/BN/BN/beta')
             mm, mv = net.state[s.scope + '/BN/BN/moving_mean'], net.state[s.scope + '/BN/BN/moving_variance']
@@ -733,7 +737,7 @@ class GanEngine:
             if is_training:                                  # moving statistics updated in place (UPDATE_OPS)
                 ops.bn_fwd_train(raw2d, gamma, beta, mm, mv, act=s.act, unbiased=tgt.dim() == 4, new_moving_mean=mm,
                                  new_moving_var=mv, out=y2d, save_mean=b[s.scope + '#mean'], save_invstd=b[s.scope + '#invstd'],
-                                 workspace=self._bn_totals[s.scope][0])
+                                 workspace=self._bn_totals[s.scope][0], have_totals=totals is not None)
             else:
                 ops.bn_fwd_infer(raw2d, gamma, beta, mm, mv, act=s.act, out=y2d)
         return y

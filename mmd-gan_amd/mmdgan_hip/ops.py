@@ -227,7 +227,7 @@ def out_hw(H, W, stride):
 
 # ------------------------------------------------------------------------------------------------
 def conv2d_fwd(x, w, stride, bias=None, scale=None, act='linear', dact_of=None, out=None, dact_batch=0,
-               out_zeroed=False, wino=None, addend=None):
+               out_zeroed=False, wino=None, addend=None, bn_totals=None):
     """x [N,H,W,C], w [R,R,C,K] -> y [N,P,Q,K] = act(scale*conv(x,w)+bias) (layer_func.py:913-916)
     wino: the tensor wino_transform(w, ...) made from w (the library then skips its own transform)
     addend: another tensor of y's shape, added last (mmdgan_conv2d_fwd_add)"""
@@ -239,6 +239,11 @@ def conv2d_fwd(x, w, stride, bias=None, scale=None, act='linear', dact_of=None, 
     y = out if out is not None else torch.empty((N, P, Q, K), device=x.device, dtype=torch.float32)
     g = geom(N, H, W, C, K, R, stride)
     flags = act_id(act) | (0x100 if out_zeroed else 0) | (0 if wino is None else 0x200)
+    if bn_totals is not None:          # + the batch-norm totals of y (mmdgan_conv2d_fwd_stats; bn_fwd_train(have_totals=True) follows)
+        assert addend is None and dact_of is None
+        check(lib.mmdgan_conv2d_fwd_stats(ctypes.byref(g), _p(x), _p(w if wino is None else wino), _p(bias), _p(scale), flags, _p(y),
+                                          bn_totals.data_ptr(), _stream()), 'conv2d_fwd_stats')
+        return y
     if addend is not None:
         assert tuple(addend.shape) == tuple(y.shape) and addend.is_contiguous()
         check(lib.mmdgan_conv2d_fwd_add(ctypes.byref(g), _p(x), _p(w if wino is None else wino), _p(bias), _p(scale), flags,
@@ -251,7 +256,7 @@ def conv2d_fwd(x, w, stride, bias=None, scale=None, act='linear', dact_of=None, 
 
 
 def conv2d_dgrad(dy, w, in_hw, stride, bias=None, scale=None, act='linear', dact_of=None, out=None, dact_batch=0,
-                 wino=None, out_zeroed=False, addend=None):
+                 wino=None, out_zeroed=False, addend=None, bn_totals=None):
     """dy [N,P,Q,K], w [R,R,C,K] -> dx [N,H,W,C]; forward form = tf.nn.conv2d_transpose (layer_func.py:926)
     out_zeroed: `out` is zero on entry - a launch with a linear epilogue may split its reduction over workgroups"""
     lib = require_device()
@@ -263,6 +268,11 @@ def conv2d_dgrad(dy, w, in_hw, stride, bias=None, scale=None, act='linear', dact
     dx = out if out is not None else torch.empty((N, H, W, C), device=dy.device, dtype=torch.float32)
     g = geom(N, H, W, C, K, R, stride)
     flags = act_id(act) | (0x100 if out_zeroed else 0) | (0 if wino is None else 0x200)
+    if bn_totals is not None:                            # + the batch-norm totals of dx (mmdgan_conv2d_dgrad_stats)
+        assert addend is None and dact_of is None
+        check(lib.mmdgan_conv2d_dgrad_stats(ctypes.byref(g), _p(dy), _p(w if wino is None else wino), _p(bias), _p(scale), flags,
+                                            _p(dx), bn_totals.data_ptr(), _stream()), 'conv2d_dgrad_stats')
+        return dx
     if addend is not None:                               # another tensor of dx's shape, added last (mmdgan_conv2d_dgrad_add)
         assert tuple(addend.shape) == tuple(dx.shape) and addend.is_contiguous()
         check(lib.mmdgan_conv2d_dgrad_add(ctypes.byref(g), _p(dy), _p(w if wino is None else wino), _p(bias), _p(scale), flags,
@@ -379,8 +389,10 @@ def _bn_workspace(C, device):
 
 
 def bn_fwd_train(x2d, gamma, beta, moving_mean, moving_var, act='linear', eps=1e-3, momentum=0.99, unbiased=True,
-                 new_moving_mean=None, new_moving_var=None, out=None, save_mean=None, save_invstd=None, workspace=None):
+                 new_moving_mean=None, new_moving_var=None, out=None, save_mean=None, save_invstd=None, workspace=None,
+                 have_totals=False):
     """x2d [rows, C].  Returns (y, save_mean, save_invstd, new_moving_mean, new_moving_var).
+    have_totals: `workspace` already holds the totals of x2d (conv2d_fwd / conv2d_dgrad with bn_totals=workspace wrote x2d)
     out / save_mean / save_invstd / workspace: caller-owned buffers (an engine's per-step ones; `workspace` holds the
     per-channel totals, mmdgan_bn_workspace_bytes(C)); new_moving_* may be the moving_* tensors themselves (in place)"""
     lib = require_device()
@@ -391,9 +403,10 @@ def bn_fwd_train(x2d, gamma, beta, moving_mean, moving_var, act='linear', eps=1e
     nmm = new_moving_mean if new_moving_mean is not None else torch.empty_like(mean)
     nmv = new_moving_var if new_moving_var is not None else torch.empty_like(mean)
     ws = workspace if workspace is not None else _bn_workspace(C, x2d.device)
-    check(lib.mmdgan_bn_fwd_train(_p(x2d), rows, C, _p(gamma), _p(beta), eps, momentum, int(unbiased), act_id(act), _p(y),
-                                  _p(mean), _p(invstd), _p(moving_mean), _p(moving_var), _p(nmm), _p(nmv),
-                                  ws.data_ptr(), _stream()), 'bn_fwd_train')
+    entry = lib.mmdgan_bn_fwd_apply if have_totals else lib.mmdgan_bn_fwd_train
+    check(entry(_p(x2d), rows, C, _p(gamma), _p(beta), eps, momentum, int(unbiased), act_id(act), _p(y),
+                _p(mean), _p(invstd), _p(moving_mean), _p(moving_var), _p(nmm), _p(nmv),
+                ws.data_ptr(), _stream()), 'bn_fwd_train')
     return y, mean, invstd, nmm, nmv
 
 

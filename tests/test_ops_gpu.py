@@ -1110,6 +1110,44 @@ def test_power_iterations_of_many_kernels_in_six_launches(ops):
     check(True)
 
 
+def test_batch_norm_statistics_ride_on_the_convolution(ops):
+    """mmdgan_conv2d_fwd_stats / _dgrad_stats + mmdgan_bn_fwd_apply: the convolution's output bit for bit what the plain entry
+    writes, and the batch norm behind it (normalised output, saved mean / inverse deviation, moving statistics) what
+    mmdgan_bn_fwd_train gives on that output - on geometries whose launch ends in the slab pass (the statistics are formed
+    there: G's transposed layers at batch 64, a 3x3 layer with few tiles) and on ones that take the separate statistics pass"""
+    rs = np.random.RandomState(9)
+    ops.set_workspace(256 << 20)
+    try:
+        #        N   H   C    K   R  s  transposed (the layer is the input-gradient form: G's 'tc' layers)
+        cases = [(64, 8, 256, 512, 4, 2, True), (64, 16, 128, 256, 4, 2, True), (64, 32, 64, 128, 4, 2, True),
+                 (32, 8, 128, 128, 3, 1, False), (16, 16, 64, 128, 4, 2, False), (8, 8, 24, 40, 3, 1, False)]
+        for (N, H, C, K, R_, st, tc) in cases:
+            P = H // st
+            w = dev((rs.randn(R_, R_, C, K) / np.sqrt(R_ * R_ * C)).astype(np.float32))
+            if tc:
+                x = dev(rs.randn(N, P, P, K).astype(np.float32))
+                ch = C
+                uw = ops.wino_transform(w, True) if ops.wino_eligible(N, H, H, C, K, R_, st, True) else None
+                run = lambda **kw: ops.conv2d_dgrad(x, w, (H, H), st, wino=uw, **kw)
+            else:
+                x = dev(rs.randn(N, H, H, C).astype(np.float32))
+                ch = K
+                uw = ops.wino_transform(w, False) if ops.wino_eligible(N, H, H, C, K, R_, st, False) else None
+                run = lambda **kw: ops.conv2d_fwd(x, w, st, wino=uw, **kw)
+            plain = run()
+            totals = torch.zeros(ops.require_device().mmdgan_bn_workspace_bytes(ch) // 8, dtype=torch.float64, device='cuda')
+            got = run(bn_totals=totals)
+            assert torch.equal(got, plain), (N, H, C, K, R_, st, tc)
+            gamma, beta = dev(rs.uniform(0.5, 1.5, ch).astype(np.float32)), dev(rs.randn(ch).astype(np.float32))
+            mm, mv = dev(rs.randn(ch).astype(np.float32)), dev(rs.uniform(0.5, 2, ch).astype(np.float32))
+            ref = ops.bn_fwd_train(plain.view(-1, ch), gamma, beta, mm, mv, act='relu')
+            out = ops.bn_fwd_train(got.view(-1, ch), gamma, beta, mm, mv, act='relu', workspace=totals, have_totals=True)
+            for a, b_, what in zip(out, ref, ('y', 'mean', 'invstd', 'moving mean', 'moving variance')):
+                assert rel_err(a.cpu().numpy(), b_.cpu().numpy()) <= 2e-6, (what, N, H, C, K, R_, st, tc)
+    finally:
+        ops.require_device().mmdgan_set_workspace(None, 0)
+
+
 def test_deferred_slab_reduction_gives_the_same_bits(ops):
     """mmdgan_wgrad_defer: a chain of slab weight gradients on one stream, each summing its predecessor's slabs in its own
     prologue (quad form: >= 8 slabs; plain form: fewer), the last one flushed - dw, the bias gradient and <dw, w> are
