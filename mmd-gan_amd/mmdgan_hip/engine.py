@@ -531,6 +531,7 @@ class GanEngine:
         self._gen_tail_on_main = int(settings.get('MMDGAN_GEN_TAIL_MAIN')) if settings.on('MMDGAN_SIDE_WGRAD') else 0
         self._early_d_adam = settings.on('MMDGAN_EARLY_D_ADAM')
         self._wgrad_defer = settings.on('MMDGAN_WGRAD_DEFER')
+        self._wg_after = []
         self._side_wgrad = settings.on('MMDGAN_SIDE_WGRAD')
         # round 4: dependencies that put a marker / barrier packet into the MAIN queue (~6 us of idle queue each) moved off it
         # where another ordering already covers them (MMDGAN_QUEUE_OPT=0: the round-3 placement)
@@ -558,6 +559,10 @@ class GanEngine:
         # replicas apply it BEFORE their all-reduce - sigma and dsigma/dW carry each replica's own atomics order in their last
         # bits, and replicas must stay bit-identical
         for net in (self.gen, self.dis):
+            # data-parallel replicas fix a normalised kernel's gradient up BEFORE the exchange, each with its own dsigma/dW (equal
+            # across replicas only up to the order of the power iteration's atomics): the all-reduce then hands every replica the
+            # same bits and the replicas stay bit-identical.  (Folding the fix-up into Adam behind the exchange - the raw sums and
+            # <G, W> are both in the arena - is the same mathematics, but lets those last bits of dsigma into the weights.)
             net.opt.fold_fixup = not self._dp_active()
         self._static_z = torch.zeros(self.B, self.code_size, device=self.device)
         # the real half of D's input buffer IS the batch buffer graph / plan replays read: a caller's batch is copied
@@ -908,9 +913,14 @@ class GanEngine:
                         ops.dot(gw.view(-1), w.view(-1), out=dot)
                 else:                                                        # bias gradient (and <G, W>) ride on the wgrad launch
                     ops.conv2d_wgrad(x_in, dz_main, s.R, s.stride, out=gw, dbias=gb, w=w if s.sn else None, dot=dot)
+                    self._wgrad_run_after()                                  # (that launch carried, or followed, the previous reduction)
                 if s.sn and not net.opt.fold_fixup:                          # data-parallel replicas fix up before the exchange
-                    ops.wgrad_flush()                                        # (the fix-up reads the summed gradient and <G, W>)
-                    ops.sn_wgrad_fixup(gw.view(-1), net.state[s.scope + '#dsigma'].view(-1), dot, net.state[s.scope + '#sigma'], scale)
+                    fix = lambda: ops.sn_wgrad_fixup(gw.view(-1), net.state[s.scope + '#dsigma'].view(-1), dot,
+                                                     net.state[s.scope + '#sigma'], scale)
+                    if s.op == 'd':
+                        fix()
+                    else:                # the fix-up reads the SUMMED gradient and <G, W>: behind the next weight-gradient launch, or a flush
+                        self._wg_after.append((fix, torch.cuda.current_stream()))
             # D's dense head sits between the loss and the first convolution of the backward pass with nothing beside it: its
             # parameter gradients wait for the NEXT layer's hand-over to the weight-gradient stream (one marker in the main queue -
             # ~6 us of idle queue each - instead of two in a row; its input-gradient, which the main chain needs, goes first)
@@ -954,6 +964,18 @@ class GanEngine:
                 self._exchange(net, li)
         return b['d_fake']                                                   # gradient w.r.t. G's last pre-activation
 
+    def _wgrad_run_after(self):
+        """what waits for a finished (summed) weight gradient - queued by param_grads under data parallelism - is issued on
+        the current stream; call behind a weight-gradient launch or a flush"""
+        todo, self._wg_after = self._wg_after, []
+        for fn, st in todo:                              # on the stream its gradient (and that gradient's reduction) was issued on
+            with torch.cuda.stream(st):
+                fn()
+
+    def _wgrad_flush(self):
+        ops.wgrad_flush()
+        self._wgrad_run_after()
+
     def _on_wg_stream(self, fn, spec):
         """run the parameter-gradient launches of one layer on the weight-gradient stream (ordered after
         everything issued so far on the current stream).  That includes the thin first / last layers, whose weight
@@ -968,7 +990,7 @@ class GanEngine:
             fn()
 
     def _join_wg_stream(self):
-        ops.wgrad_flush()                    # the last slab weight gradient of the pass: its reduction as a stand-alone launch
+        self._wgrad_flush()                    # the last slab weight gradient of the pass: its reduction as a stand-alone launch
         if self._side_wgrad:
             ops.stream_wait(ops._stream(), self._wg_raw)
 
@@ -1009,9 +1031,15 @@ class GanEngine:
                     ops.conv2d_wgrad(x_in, dz, s.R, s.stride, out=gw, dbias=gb, w=w if s.sn else None, dot=dot)
                 else:                                                        # tc: W[R,R,Cout,Cin]; y = dgrad(v, W)
                     ops.conv2d_wgrad(dz, x_in, s.R, s.stride, out=gw, w=w if s.sn else None, dot=dot)
+                if s.op != 'd':
+                    self._wgrad_run_after()
                 if s.sn and not net.opt.fold_fixup:
-                    ops.wgrad_flush()
-                    ops.sn_wgrad_fixup(gw.view(-1), net.state[s.scope + '#dsigma'].view(-1), dot, net.state[s.scope + '#sigma'], scale)
+                    fix = lambda: ops.sn_wgrad_fixup(gw.view(-1), net.state[s.scope + '#dsigma'].view(-1), dot,
+                                                     net.state[s.scope + '#sigma'], scale)
+                    if s.op == 'd':
+                        fix()
+                    else:
+                        self._wg_after.append((fix, torch.cuda.current_stream()))
             if li < self._gen_tail_on_main and li > 0:
                 # the tail of G's backward pass: the input-gradient chain of the main stream ends at layer 1 while the
                 # weight-gradient stream still holds the gradients of the layers above - the last layers' parameter gradients
@@ -1134,7 +1162,7 @@ class GanEngine:
         if bucket is None:
             return
         _, lo, hi = bucket
-        ops.wgrad_flush()                    # (a slab weight gradient of the bucket may still be waiting for its reduction)
+        self._wgrad_flush()                  # (a slab weight gradient of the bucket may still be waiting for its reduction)
         # the bucket is complete once the parameter-gradient stream has drained what it holds now (and the main stream
         # has reached this point, for gradients that stay there)
         if self._side_wgrad:
@@ -1244,7 +1272,7 @@ class GanEngine:
                 # D's gradients are complete once the parameter-gradient stream has drained what it holds now and
                 # the main stream has reached this point (thin layers); nothing in G's backward pass reads D's
                 # weights, so D's Adam runs there, beside G's backward pass, instead of at the tail of the step
-                ops.wgrad_flush()
+                self._wgrad_flush()
                 ops.stream_wait(self._wg_raw, main)
                 with torch.cuda.stream(self._wg_stream):
                     self.dis.opt.step(self.lr_d, grad_scale=1.0)
@@ -1257,6 +1285,7 @@ class GanEngine:
             self._update()
         finally:
             self._in_step = False
+            self._wg_after = []
             lib.mmdgan_wgrad_defer(0)
             lib.mmdgan_set_outputs_prezeroed(0)
 
