@@ -509,6 +509,7 @@ class GanEngine:
         # set to {} by a caller (bench.py under data parallelism): eager steps then leave three events in it - start / end of
         # G's last exchange bucket on the exchange stream and the point where the main stream starts waiting for it
         self.exchange_probe = None
+        self.bucket_probe = None             # a list (tools/scale_predict.py): eager steps append (name, bytes, event) per bucket
         # who carries the gradient exchange: 'torch' = torch.distributed on `dist_group` (RCCL through ProcessGroupNCCL; gloo in
         # the tests); 'capi' = the library's own RCCL communicator (mmdgan_comm_init / mmdgan_allreduce_bucket), whose
         # collectives are plan nodes like any launch - a data-parallel step then replays from one C call
@@ -1177,6 +1178,11 @@ class GanEngine:
             lib.mmdgan_plan_mark()                       # the collective is not the library's: a segment boundary
             self._plan_collectives.append((net, lo, hi))
         last = bucket is self._grad_buckets[id(net)][-1]
+        if self.bucket_probe is not None and not self._recording:
+            # tools/scale_predict.py: when (on the exchange stream, i.e. behind the gradients it waits for) each bucket is READY
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(self._comm_stream)
+            self.bucket_probe.append((net.name, 4 * (hi - lo), ev))
         probe = self.exchange_probe if (last and net is self.gen and not self._recording) else None
         if probe is not None:                            # tools/scale.sh: how long G's last bucket takes and how much of it is exposed
             probe['bucket_bytes'] = 4 * (hi - lo)
@@ -1209,6 +1215,10 @@ class GanEngine:
         gs = 1.0 / self.world
         main = ops._stream()
         if self._dp_active():
+            if self.bucket_probe is not None and not self._recording:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                self.bucket_probe.append(('main_ready', 0, ev))          # the main stream has nothing left but the updates
             if self.exchange_probe is not None and not self._recording:
                 self.exchange_probe['main_ready'] = torch.cuda.Event(enable_timing=True)
                 self.exchange_probe['main_ready'].record()       # the main stream has nothing left but Adam
@@ -1221,6 +1231,10 @@ class GanEngine:
         lib = ops.require_device()
         lib.mmdgan_set_outputs_prezeroed(1)
         main = ops._stream()
+        if self.bucket_probe is not None and not self._recording:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.bucket_probe.append(('step_start', 0, ev))
         try:
             # the two gradient arenas (61 MB of memset) are first touched in the backward pass: zero them
             # on the parameter-gradient stream, underneath the forward pass
