@@ -5,7 +5,7 @@
 #                                             r03_dominant_kernel_*.json of the same build (bench.py takes `traffic` from them)
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -19,7 +19,7 @@ import os
 import subprocess
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(ROOT, 'gpurun_out', tag), os.path.join(ROOT, 'profiles')
 os.makedirs(dst, exist_ok=True)
