@@ -394,7 +394,7 @@ extern "C" long mmdgan_plan_describe(int plan_id, char *buf, size_t cap) {
         size_t si = 0;
         while (si < streams.size() && streams[si] != k.st) ++si;
         if (si == streams.size()) streams.push_back(k.st);
-        const char *mangled = hipKernelNameRefByPtr(k.fn, k.st);
+        const char *mangled = hipKernelNameRefByPtr(k.fn, nullptr);      // (the null stream: the recorded one may be gone by now)
         (void)hipGetLastError();
         int status = 1;
         char *dem = mangled ? abi::__cxa_demangle(mangled, nullptr, nullptr, &status) : nullptr;

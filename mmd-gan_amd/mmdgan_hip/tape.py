@@ -1041,7 +1041,11 @@ class TapeEngine:
                         if q['kind'] in ('conv', 'convdown', 'upconv', 'tconv'):
                             addend[where[term]], alias[i] = other, term
                             break
-                        if q['kind'] == 'up' and uses.get(other, 0) == 1 and other != 0:
+                        # (in place into the OTHER term's buffer: only where the backward pass never reads that buffer as its
+                        # producer's output - a convolution's; an activation's, a max pool's or a batch norm's output is read back)
+                        qo = producer.get(other)
+                        if q['kind'] == 'up' and uses.get(other, 0) == 1 and other != 0 and qo is not None and \
+                                qo['kind'] in ('conv', 'convdown', 'upconv', 'tconv'):
                             addend[where[term]], alias[i] = other, other      # accumulated INTO the other term's buffer
                             break
             f = self._fusions[id(net)] = (addend, alias)
