@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void gemm_skinny16_kernel(const float *__restr
 // in 16-deep steps with a barrier and a global-load round trip each (20-26 us for ~0.1 GFLOP and 4 MB).  Here a workgroup
 // takes a 32-column (64-row) piece of the long dimension, fetches its WHOLE K extent of both operands at once - every load
 // of the launch is in flight together: one memory round trip - and multiplies out of LDS.
-//   npanel: C[M,N] = act(scale * op(A) B + bias), M a multiple of 64 (<= 256), K <= 128, B [K,N] row-major; TRANSA: A is [K,M]
+//   npanel: C[M,N] = act(scale * op(A) B + bias), M a multiple of 16 (<= 256), K <= 128, B [K,N] row-major; TRANSA: A is [K,M]
 //   mpanel: C[M,16] = A^T B, A [K,M] row-major, B [K,16]
 constexpr int GP_KMAX = 128;
 // npanel: one wave = 16 rows x 16 columns x the whole K on v_mfma_f32_16x16x4_f32, operands straight from global memory into
@@ -172,10 +172,11 @@ constexpr int GP_KMAX = 128;
 template <bool TRANSA>
 __global__ __launch_bounds__(256) void gemm_npanel_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
                                                           const float *__restrict__ bias, const float *__restrict__ scale, int act,
-                                                          float *__restrict__ C, int ldc, int K) {
+                                                          float *__restrict__ C, int ldc, int M, int K) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = lane & 15, kq = lane >> 4;
     const int m0 = blockIdx.y * 64 + wave * 16, n0 = blockIdx.x * 16;
+    if (m0 >= M) return;                                   // (M a multiple of 16: the last workgroup may have idle waves; no barrier below)
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     // lane (row, kq) holds A[m0 + row][16 u + 4 kq + j] and B[16 u + 4 kq + j][n0 + row], j = 0..3, u = 0 .. K/16 - 1 (+ a 4-deep
     // tail when K % 16 != 0: K is a multiple of 4)
@@ -276,11 +277,12 @@ extern "C" int mmdgan_gemm(int transA, int transB, int M, int N, int K, const fl
     auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
     if (tuning().gemm_panel && !transB && !dact_of && K <= GP_KMAX && K % 4 == 0 && al16(A) && al16(B) && al16(C) && lda % 4 == 0 &&
         ldb % 4 == 0 && ldc % 4 == 0) {
-        if (M % 64 == 0 && M <= 256 && N % 16 == 0 && N >= 2048) {
+        if (M % 16 == 0 && M <= 256 && N % 16 == 0 && N >= 2048) {
+            const dim3 grid(N / 16, (M + 63) / 64), block(M >= 64 ? 256 : M * 4);          // a wave per 16 rows
             if (transA)
-                hipLaunchKernelGGL(gemm_npanel_kernel<true>, dim3(N / 16, M / 64), dim3(256), 0, st, A, lda, B, ldb, bias, scale, act, C, ldc, K);
+                hipLaunchKernelGGL(gemm_npanel_kernel<true>, grid, block, 0, st, A, lda, B, ldb, bias, scale, act, C, ldc, M, K);
             else
-                hipLaunchKernelGGL(gemm_npanel_kernel<false>, dim3(N / 16, M / 64), dim3(256), 0, st, A, lda, B, ldb, bias, scale, act, C, ldc, K);
+                hipLaunchKernelGGL(gemm_npanel_kernel<false>, grid, block, 0, st, A, lda, B, ldb, bias, scale, act, C, ldc, M, K);
             return check_launch("gemm");
         }
         if (transA && N == 16 && M % 64 == 0 && M >= 2048 && !bias && !scale && act == MMDGAN_ACT_LINEAR) {

@@ -6,10 +6,13 @@ MMD statistic stays per-replica), gradients are AVERAGED
 shared.  SN vectors and BN moving statistics need no communication: they are deterministic
 functions of identical weights / per-replica statistics.
 
-Gradients live in one flat fp32 arena per network, so the exchange is a few large buckets.
-xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is bound by one link, so
-buckets are kept large (default 32 MiB) - latency, not bandwidth, is what many small buckets
-would pay.  The functions here are device-agnostic (tests run them on CPU tensors over gloo).
+Gradients live in one flat fp32 arena per network, cut into buckets in backward order.  The ENGINES exchange per-layer
+groups of MMDGAN_DP_BUCKET_MB = 8 MB (layer_buckets below; engine.py:_make_buckets) as soon as a group's lowest layer has its
+gradients, underneath the backward kernels still to come: xGMI is point-to-point (7 links x ~153 GB/s per GPU), a ring
+all-reduce is bound by one link, and below a few MB a collective is latency - 8 MB is where the two meet for these nets
+(DESIGN.md section 6 has the bucket table and the predicted exposure).  DEFAULT_BUCKET_BYTES (32 MiB) is only the default of
+the stand-alone helper allreduce_sum_async for callers that exchange a whole arena after the pass.  The functions here are
+device-agnostic (tests run them on CPU tensors over gloo).
 """
 import torch
 import torch.distributed as tdist

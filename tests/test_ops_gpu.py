@@ -863,7 +863,8 @@ def test_gemm(ops, M, N, K, ta, tb):
 
 
 @pytest.mark.parametrize('M,N,K,ta', [(64, 8192, 128, False), (128, 8192, 64, True), (64, 2048, 128, False), (192, 4096, 84, True),
-                                       (64, 12288, 100, False), (128, 2048, 64, False), (256, 16384, 8, True)])
+                                       (64, 12288, 100, False), (128, 2048, 64, False), (256, 16384, 8, True), (32, 16384, 128, False), (16, 2048, 64, True),
+                                       (80, 4096, 32, False)])
 def test_gemm_short_reduction_panels(ops, M, N, K, ta):
     """the whole-K panel kernels (csrc/gemm.hip: gemm_npanel_kernel - G's first layer and its weight gradient;
     gemm_mpanel16_kernel - the weight gradient of D's head) against fp64, with and without bias / scale / activation"""
