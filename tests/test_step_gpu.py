@@ -513,62 +513,67 @@ def test_pipelined_step_boundary_keeps_the_reference_semantics(monkeypatch):
     """GanEngine._ahead_tail: D's power iterations and Winograd weight transform of step t+1 run at the tail of step t and
     write the new vectors / spectral norms into a shadow that the next step's head commits.  Between steps everything a caller
     can read must be what an engine with the iteration inside its own step (MMDGAN_STEP_AHEAD=0) holds: losses, in_rand, sigma,
-    every gradient as Adam used it (Network.readout), every variable - over five steps, in eager issue and plan replay; and what
-    the tail prepared is discarded when the state is touched from outside (set_variables, discriminate, touch): the next step
-    then gives what an untouched twin gives."""
+    every gradient as Adam used it (Network.readout), every variable - from the warm-start fixture's state (gradients O(1e-2):
+    no rounding-noise regime, the two trajectories stay together), six steps, eager issue and plan replay; and what the tail
+    prepared is discarded when the state is touched from outside (discriminate, set_variables): the next step gives what an
+    untouched twin gives.  (Against the REFERENCE the default engine is held by test_free_run_from_warm_start_*.)"""
     from mmdgan_hip.engine import GanEngine
-    arch, B = mid_architecture(), 16
+    fx = load(golden('step_warm_rep.npz')[0])
+    arch = tiny_architecture()
+    B, lr = int(fx['B']), tuple(fx['lr'])
+    init = {k[len('init/'):]: v for k, v in fx.items() if k.startswith('init/')}
+    m = {k[len('adam_m/'):]: v for k, v in fx.items() if k.startswith('adam_m/')}
+    v2 = {k[len('adam_v/'):]: v for k, v in fx.items() if k.startswith('adam_v/')}
     rs = np.random.RandomState(4)
-    batches = [(torch.as_tensor(rs.uniform(-1, 1, (B, 32, 32, 3)).astype(np.float32)).cuda(),
-                torch.as_tensor(rs.randn(B, 64).astype(np.float32)).cuda()) for _ in range(6)]
+    batches = [(nhwc(fx['real'][k % 3] + (0.01 * rs.randn(*fx['real'][0].shape).astype(np.float32) if k >= 3 else 0)),
+                torch.as_tensor(fx['z'][k % 3]).cuda()) for k in range(7)]
 
-    def same(a, b, what, start):
-        """the two engines moved every variable the same way since `start` (the first steps' gradients are rounding noise that Adam
-        turns into lr-sized steps - SURVEY A.5 #1 - so single entries differ; the UPDATE agrees in norm, as in the plan / eager
-        twin test below), non-trainable state and spectral norms agree closely"""
+    def make(mode):
+        e = GanEngine(arch, 'rep', lr, batch_size=B, launch_mode=mode)
+        e.set_variables(init)
+        e.set_adam_state(m, v2, int(fx['adam_t']))
+        return e
+
+    def same(a, b, what):
         va, vb = a.get_variables(), b.get_variables()
         for n in va:
-            if 'in_rand' in n or '/moving_' in n:
-                scale = max(float(np.abs(vb[n]).max()), 1e-6)
-                assert float(np.abs(va[n] - vb[n]).max()) <= 1e-4 * scale, (what, n)
-        for net in ('gen', 'dis'):
-            ua = np.concatenate([(va[n] - start[n]).ravel() for n in va if n.startswith(net) and 'in_rand' not in n and '/moving_' not in n])
-            ub = np.concatenate([(vb[n] - start[n]).ravel() for n in va if n.startswith(net) and 'in_rand' not in n and '/moving_' not in n])
-            assert np.linalg.norm(ua - ub) <= 2e-2 * np.linalg.norm(ub) + 1e-9, (what, net, np.linalg.norm(ua - ub), np.linalg.norm(ub))
+            scale = max(float(np.abs(vb[n]).max()), 1e-6)
+            if n == a.dis.specs[-1].scope + '/bias/bias':    # analytically zero gradient (the loss sees score differences): Adam
+                assert float(np.abs(va[n] - vb[n]).max()) <= 3.5 * max(lr) * 7, (what, n)    # turns rounding noise into lr-sized steps
+                continue
+            assert float(np.abs(va[n] - vb[n]).max()) <= 1e-4 * scale + 1e-7, (what, n, float(np.abs(va[n] - vb[n]).max()), scale)
         sa, sb = a.sigmas(), b.sigmas()
         for k in sa:
-            assert abs(sa[k] - sb[k]) <= 1e-4 * abs(sb[k]), (what, k)
+            assert abs(sa[k] - sb[k]) <= 1e-5 * abs(sb[k]), (what, k)
 
     for mode in ('eager', 'plan'):
         monkeypatch.setenv('MMDGAN_STEP_AHEAD', '0')
-        ref = GanEngine(arch, 'rep', (5e-4, 2e-4), batch_size=B, seed=3, launch_mode=mode)
+        ref = make(mode)
         monkeypatch.delenv('MMDGAN_STEP_AHEAD')
-        eng = GanEngine(arch, 'rep', (5e-4, 2e-4), batch_size=B, seed=3, launch_mode=mode)
+        eng = make(mode)
         assert eng._ahead and not ref._ahead
-        start = ref.get_variables()
-        for k in range(5):
+        for k in range(6):
             ref.step(*batches[k])
             eng.step(*batches[k])
             torch.cuda.synchronize()
             lr_, le_ = ref.losses.cpu().numpy()[:5], eng.losses.cpu().numpy()[:5]
-            assert np.allclose(le_, lr_, rtol=1e-5, atol=2e-5 * float(max(lr_[2:5]))), (mode, k, le_, lr_)   # (losses: differences of the kernel means)
-            same(eng, ref, (mode, k), start)
-            if k >= 1:                                   # (step 0's gradients are rounding noise: SURVEY A.5 #1)
-                ga, gb = eng.get_variables(grad=True), ref.get_variables(grad=True)
-                for net in ('gen', 'dis'):               # (two free-running trajectories: in norm, like the updates)
-                    da = np.concatenate([ga[n].ravel() for n in ga if n.startswith(net)])
-                    db = np.concatenate([gb[n].ravel() for n in ga if n.startswith(net)])
-                    assert np.linalg.norm(da - db) <= 2e-2 * np.linalg.norm(db), (mode, k, net, np.linalg.norm(da - db) / np.linalg.norm(db))
+            assert np.allclose(le_, lr_, rtol=1e-4, atol=1e-6 * float(max(lr_[2:5]))), (mode, k, le_, lr_)
+            same(eng, ref, (mode, k))
+            ga, gb = eng.get_variables(grad=True), ref.get_variables(grad=True)
+            for net in ('gen', 'dis'):
+                da = np.concatenate([ga[n].ravel() for n in ga if n.startswith(net)])
+                db = np.concatenate([gb[n].ravel() for n in ga if n.startswith(net)])
+                assert np.linalg.norm(da - db) <= 2e-4 * np.linalg.norm(db), (mode, k, net, np.linalg.norm(da - db) / np.linalg.norm(db))
         # the state touched from outside between steps: a twin that is not touched must agree after the next step
-        twin = GanEngine(arch, 'rep', (5e-4, 2e-4), batch_size=B, seed=3, launch_mode=mode)
+        twin = make(mode)
         twin.load_state_dict(eng.state_dict())
-        scores = eng.discriminate(batches[5][0])             # inference between two training steps (spectral norms, no update)
+        scores = eng.discriminate(batches[6][0])             # inference between two training steps (spectral norms, no update)
         assert scores.shape[0] == B and not eng._ahead_valid
         eng.set_variables(eng.get_variables())               # ... and the variables written back
-        eng.step(*batches[5])
-        twin.step(*batches[5])
+        eng.step(*batches[6])
+        twin.step(*batches[6])
         torch.cuda.synchronize()
-        same(eng, twin, (mode, 'touched'), start)
+        same(eng, twin, (mode, 'touched'))
 
 
 def _copy_engine_state(dst, src):
