@@ -684,7 +684,14 @@ class GanEngine:
         self._sn_chains = {}
         # "ahead": D's power iterations and D's Winograd weight transform of step t+1 run at the tail of step t, behind D's early
         # Adam and beside G's backward pass, instead of at the head of step t+1 beside G's small forward kernels (_step_body)
-        self._ahead = (self._sn_fused and settings.on('MMDGAN_STEP_AHEAD') and self._side_wgrad and self._early_d_adam and
+        # Measured (interleaved A/B of the bench step, plan replay, profiles/r05_ab_step_ahead.txt): CelebA 64x64 B=128 13.40 against
+        # 13.52 ms with the tail, CIFAR 32x32 inside the spread (1.847 / 1.848), STL 48x48 3.705 against 3.677 - the side work moves
+        # from beside G's forward pass to beside G's backward pass, and which of the two it hurts less depends on the net:
+        # 'auto' (the default) pipelines from 64 x 64 images on, '1' / '0' force it.
+        c_, h_, w_ = self.in_shape_ref
+        want_ahead = settings.get('MMDGAN_STEP_AHEAD')
+        want_ahead = (h_ * w_ >= 64 * 64) if want_ahead == 'auto' else want_ahead not in (None, '0', '')
+        self._ahead = (self._sn_fused and want_ahead and self._side_wgrad and self._early_d_adam and
                        self._queue_opt and any(s.sn for s in self.dis.specs) and
                        all(sn_chain_layer(self.dis, s, self.buf) is not None for s in self.dis.specs if s.sn))
         self._ahead_valid = False

@@ -131,8 +131,9 @@ def test_step_matches_reference_golden(loss_type, launch_mode):
 
 
 @pytest.mark.parametrize('tag,engine', [('rep', 'dcgan'), ('rep', 'dcgan-plan'), ('rep_pim', 'dcgan'), ('rep_pim', 'dcgan-plan'),
-                                        ('gsn_rep', 'dcgan'), ('gsn_rep', 'dcgan-plan'), ('rep', 'tape'), ('res_rep', 'tape'), ('gsn_rep', 'tape')])
-def test_free_run_from_warm_start_matches_reference(tag, engine):
+                                        ('gsn_rep', 'dcgan'), ('gsn_rep', 'dcgan-plan'), ('rep', 'tape'), ('res_rep', 'tape'), ('gsn_rep', 'tape'),
+                                        ('rep', 'dcgan-ahead'), ('gsn_rep', 'dcgan-plan-ahead'), ('rep_pim', 'dcgan-plan-ahead')])
+def test_free_run_from_warm_start_matches_reference(tag, engine, monkeypatch):
     """three FREE-RUNNING steps from a state the reference code reached after 20 warm-up steps (variables, Adam
     moments, step count; tests/golden/step_warm_*.npz).  No step-0 noise regime here - the gradients are O(1e-2), Adam
     runs far above its eps - so every step is held to the 1e-4 bar against the reference's fp64 run: losses, the
@@ -146,12 +147,15 @@ def test_free_run_from_warm_start_matches_reference(tag, engine):
         from mmdgan_hip.tape import TapeEngine as Engine
     else:
         from mmdgan_hip.engine import GanEngine as Engine
-        kw['launch_mode'] = 'plan' if engine.endswith('-plan') else 'eager'
+        kw['launch_mode'] = 'plan' if '-plan' in engine else 'eager'
+        if engine.endswith('-ahead'):                    # D's power iterations of step t+1 at the tail of step t (the 64 x 64 configs' default)
+            monkeypatch.setenv('MMDGAN_STEP_AHEAD', '1')
     fx = load(golden('step_warm_%s.npz' % tag)[0])
     from tiny_arch import tiny_gsn_architecture
     arch = tiny_res_architecture() if tag.startswith('res_') else (tiny_gsn_architecture() if tag.startswith('gsn_') else tiny_architecture())
     B, lr = int(fx['B']), tuple(fx['lr'])
     eng = Engine(arch, str(fx['loss_type']), lr, batch_size=B, sn_mode=str(fx['sn_mode']), **kw)
+    assert not engine.endswith('-ahead') or eng._ahead
     init = {k[len('init/'):]: v for k, v in fx.items() if k.startswith('init/')}
     assert sorted(init) == sorted(eng.variable_names())
     eng.set_variables(init)
@@ -549,7 +553,7 @@ def test_pipelined_step_boundary_keeps_the_reference_semantics(monkeypatch):
     for mode in ('eager', 'plan'):
         monkeypatch.setenv('MMDGAN_STEP_AHEAD', '0')
         ref = make(mode)
-        monkeypatch.delenv('MMDGAN_STEP_AHEAD')
+        monkeypatch.setenv('MMDGAN_STEP_AHEAD', '1')         # (the default, 'auto', pipelines from 64 x 64 images on)
         eng = make(mode)
         assert eng._ahead and not ref._ahead
         for k in range(6):
@@ -566,6 +570,7 @@ def test_pipelined_step_boundary_keeps_the_reference_semantics(monkeypatch):
                 assert np.linalg.norm(da - db) <= 2e-4 * np.linalg.norm(db), (mode, k, net, np.linalg.norm(da - db) / np.linalg.norm(db))
         # the state touched from outside between steps: a twin that is not touched must agree after the next step
         twin = make(mode)
+        assert twin._ahead
         twin.load_state_dict(eng.state_dict())
         scores = eng.discriminate(batches[6][0])             # inference between two training steps (spectral norms, no update)
         assert scores.shape[0] == B and not eng._ahead_valid
