@@ -19,6 +19,8 @@ for p in (ROOT, PKG):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # (pytest.ini at the repo root: `timeout = 600` - with pytest-timeout installed a hung GPU test fails after ten minutes
+    # instead of holding the box until the caller's limit)
 
 
 def _gpu_usable():
