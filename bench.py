@@ -268,6 +268,17 @@ def main():
             sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % args.gpus)
     torch.cuda.set_device(local_rank)
     group = None
+    # stdout carries ONE JSON line.  RCCL prints a version banner to stdout when its first communicator comes up (rank 0), so
+    # until the line is due file descriptor 1 points at stderr
+    sys.stdout.flush()
+    _real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        sys.stdout.flush()
+        os.dup2(_real_stdout, 1)
+        print(line, flush=True)
+        os.dup2(2, 1)
     # MMDGAN_DP_FORCE=1 under torch.distributed.run with one rank: time the exchange plumbing on a 1-GPU box
     force_dp = os.environ.get('MMDGAN_DP_FORCE') == '1' and 'RANK' in os.environ
     if world > 1 or force_dp:
@@ -307,7 +318,7 @@ def main():
         # 400 untimed launches first (~40 ms): the shader clock and the power state need that long to settle - measured
         # 107-110 us per launch right after start-up against 97-98 us for the same launch at the end of a bench run
         probe = (dominant_kernel_probe_tape if tape else dominant_kernel_probe)(eng, reps=args.probe_reps, warm=args.probe_warm)
-        print(json.dumps({'dominant_kernel': probe, 'reps': args.probe_reps, 'warm': args.probe_warm}))
+        emit(json.dumps({'dominant_kernel': probe, 'reps': args.probe_reps, 'warm': args.probe_warm}))
         return
     # MMD-loss rel-err vs ref, untimed: at the engine's 5th step from its seeded initial variables (at the initial variables
     # themselves D's scores are ~1e-5 and both losses are exactly 0 on both sides; a few steps in they are O(0.1) and neither
@@ -486,7 +497,7 @@ def main():
         from mmdgan_hip import ops as _ops, settings as _settings
         out['config']['switches'] = {'library': {k: v for k, (v, dflt) in _ops.tuning().items() if not dflt},
                                      'host': _settings.describe(), 'unknown': _settings.unknown()}
-        print(json.dumps(out))
+        emit(json.dumps(out))
         if world == 1 and not args.no_cpu_baseline and gate_failed:
             sys.exit('bench.py: mmd_loss_rel_err is above its bar (see the JSON line): %r' % (rel_err,))
     if group is not None:
