@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [('cifar', 'rep', 64), ('stl', 'rmb', 64), ('celeba', 'rep', 128), ('lsun_resnet', 'rep', 32)]
 
 
-def run_in_default_env(config, loss, B, mode='plan', timeout=1500):
+def run_in_default_env(config, loss, B, mode='plan', timeout=480):
     env = {k: v for k, v in os.environ.items() if not k.startswith('MMDGAN_')}
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'shipped_step.py'), config, loss, str(B), mode],
                        env=env, capture_output=True, text=True, timeout=timeout)

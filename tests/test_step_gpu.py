@@ -820,7 +820,7 @@ def test_data_parallel_step_equals_the_mean_gradient_step(mode):
     res = {}
     for p in procs:
         try:
-            so, se = p.communicate(timeout=600)
+            so, se = p.communicate(timeout=240)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
@@ -902,7 +902,7 @@ def test_library_owned_rccl_exchange_is_part_of_the_plan(engine):
     env = dict(os.environ, MMDGAN_DP_FORCE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1',
                LOCAL_RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0', CAPI_CHILD_ENGINE=engine)
     r = subprocess.run([sys.executable, '-c', 'ROOT = %r\n' % root + _CAPI_CHILD], env=env, capture_output=True, text=True,
-                       timeout=600)
+                       timeout=240)
     assert r.returncode == 0, r.stderr[-3000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('RESULT ')][-1][7:])
     assert res['comm_size'] == 1 and res['segments'] == 1 and res['buckets'] >= 4, res
@@ -928,7 +928,7 @@ def test_data_parallel_exchange_runs_over_rccl(engine):
     env = dict(os.environ, MMDGAN_DP_FORCE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0',
                WORLD_SIZE='1', LOCAL_RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0', RCCL_CHILD_ENGINE=engine)
     r = subprocess.run([sys.executable, '-c', 'ROOT = %r\n' % root + _RCCL_CHILD], env=env, capture_output=True,
-                       text=True, timeout=600)
+                       text=True, timeout=240)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('RESULT ')]
     assert lines, (r.stdout[-2000:], r.stderr[-2000:])
