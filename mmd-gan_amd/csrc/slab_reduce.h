@@ -5,7 +5,7 @@
 //     stand-alone pass sat in the weight-gradient queue between two MFMA kernels and was starved of CUs by the main queue's
 //     persistent kernels (10 us alone, 22-58 us in the step: 243 us of that queue per CIFAR step, profiles/r04_step_timeline.txt);
 //     as a prologue it is ~130 KB of reads per workgroup and needs no fence: the kernel boundary publishes the slabs.
-// Both run slab_sum_elem below, so a gradient is bit-identical whichever launch summed it: the order of the additions is a
+// Both run slab_reduce_range below, so a gradient is bit-identical whichever launch summed it: the order of the additions is a
 // function of nsplit alone - nsplit >= 8: four interleaved partial sums (slabs s = q mod 4, ascending) combined as
 // (p0 + p1) + (p2 + p3); fewer slabs: one ascending sum.
 #pragma once
@@ -25,6 +25,7 @@ struct SlabReduceArgs {           // passed to kernels by value; nsplit == 0: no
     float *dot;
 };
 
+constexpr int kSlabLane = 14;     // slabs of an element per lane and pass in the quad form (x 4 lanes = 56: the largest split of a one-round grid)
 constexpr int kSlabQuadMin = 8;   // from this many slabs on, four lanes share an element (each a quarter of the slabs)
 
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -38,36 +39,52 @@ __device__ __forceinline__ double slab_reduce_range(const SlabReduceArgs &a, lon
     const long total = a.n4 + a.k4;
     if (e1 > total) e1 = total;
     if (a.nsplit >= kSlabQuadMin) {
-        const int q = tid & 3;
-        for (long base = e0; base < e1; base += nthreads >> 2) {             // (uniform trip count: the shuffles below need every lane)
-            long e = base + (tid >> 2);
-            const bool live = e < e1;
-            const bool is_w = e < a.n4;
-            const float4 *src = is_w ? a.part : a.dbpart;
-            const long slab = is_w ? a.n4 : a.k4;
-            if (!is_w) e -= a.n4;
-            float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (live) {
-                int s = q;
-                for (; s + 28 < a.nsplit; s += 32) {                         // eight loads in flight
-                    float4 v[8];
+        // two elements of the lane quad and up to fourteen slabs of each in flight per trip: a workgroup's share of a 56-slab
+        // reduction (~160 elements) is ONE round of loads (first cut: eight in flight, one element per trip - four dependent
+        // rounds, 5-6 us in front of every weight-gradient launch of a chain)
+        constexpr int H = U >= 4 ? 2 : 1;                                     // (the stand-alone pass keeps a small register footprint)
+        const int q = tid & 3, step = nthreads >> 2;
+        for (long base = e0; base < e1; base += H * step) {                  // (uniform trip count: the shuffles below need every lane)
+            float4 p[H];
+            bool live[H], isw[H];
+            long el[H];
+            for (int s0 = 0; s0 < a.nsplit; s0 += 4 * kSlabLane) {           // (chunks of 56 slabs: one pass for every shape of the step)
+                float4 v[H][kSlabLane];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = src[(long)(s + 4 * i) * slab + e];
+                for (int h = 0; h < H; ++h) {
+                    long e = base + h * step + (tid >> 2);
+                    live[h] = e < e1;
+                    isw[h] = e < a.n4;
+                    const float4 *src = isw[h] ? a.part : a.dbpart;
+                    const long slab = isw[h] ? a.n4 : a.k4;
+                    if (!isw[h]) e -= a.n4;
+                    el[h] = e;
+                    if (s0 == 0) p[h] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) p = f4add(p, v[i]);
+                    for (int i = 0; i < kSlabLane; ++i) {
+                        const int sl = s0 + q + 4 * i;
+                        if (live[h] && sl < a.nsplit) v[h][i] = src[(long)sl * slab + e];
+                    }
                 }
-                for (; s < a.nsplit; s += 4) p = f4add(p, src[(long)s * slab + e]);
+#pragma unroll
+                for (int h = 0; h < H; ++h)
+#pragma unroll
+                    for (int i = 0; i < kSlabLane; ++i)
+                        if (live[h] && s0 + q + 4 * i < a.nsplit) p[h] = f4add(p[h], v[h][i]);     // ascending s = q, q + 4, ...: the canonical order
             }
-            float4 o;                                                        // (p0 + p1) + (p2 + p3), the same bits in all four lanes
-            o.x = p.x + __shfl_xor(p.x, 1, 64); o.y = p.y + __shfl_xor(p.y, 1, 64);
-            o.z = p.z + __shfl_xor(p.z, 1, 64); o.w = p.w + __shfl_xor(p.w, 1, 64);
-            o.x += __shfl_xor(o.x, 2, 64); o.y += __shfl_xor(o.y, 2, 64);
-            o.z += __shfl_xor(o.z, 2, 64); o.w += __shfl_xor(o.w, 2, 64);
-            if (live && q == 0) {
-                (is_w ? a.dw : a.dbias)[e] = o;
-                if (a.wdot && is_w) {
-                    const float4 wv = a.wdot[e];
-                    acc += (double)o.x * wv.x + (double)o.y * wv.y + (double)o.z * wv.z + (double)o.w * wv.w;
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                float4 o;                                                    // (p0 + p1) + (p2 + p3), the same bits in all four lanes
+                o.x = p[h].x + __shfl_xor(p[h].x, 1, 64); o.y = p[h].y + __shfl_xor(p[h].y, 1, 64);
+                o.z = p[h].z + __shfl_xor(p[h].z, 1, 64); o.w = p[h].w + __shfl_xor(p[h].w, 1, 64);
+                o.x += __shfl_xor(o.x, 2, 64); o.y += __shfl_xor(o.y, 2, 64);
+                o.z += __shfl_xor(o.z, 2, 64); o.w += __shfl_xor(o.w, 2, 64);
+                if (live[h] && q == 0) {
+                    (isw[h] ? a.dw : a.dbias)[el[h]] = o;
+                    if (a.wdot && isw[h]) {
+                        const float4 wv = a.wdot[el[h]];
+                        acc += (double)o.x * wv.x + (double)o.y * wv.y + (double)o.z * wv.z + (double)o.w * wv.w;
+                    }
                 }
             }
         }
