@@ -20,6 +20,7 @@ else is a way to reproduce an A/B that DESIGN.md quotes, or a debugging aid.
   MMDGAN_TAPE_COMPOSE  0   a block's scaling op and its 3x3 conv as two launches instead of one 4x4 stride-2 launch
   MMDGAN_TAPE_JOINT    0   D's two backward passes separately instead of one 3B-row pass
   MMDGAN_TAPE_FUSE_ADD 0   branch sums / gradient fan-ins as axpby passes instead of conv epilogues
+  MMDGAN_TAPE_FUSE_ACT 0   an activation that is the only reader of a convolution's output as its own pass instead of on the epilogue
   MMDGAN_BN_RESIGN     0   batch-norm backward reads the activated output back instead of recomputing its sign from the input
   MMDGAN_STEP_AHEAD    auto | 1 | 0   D's power iterations and Winograd weight transform at the tail of the step before
                            (engine.py: _ahead_tail; round 5) - auto: for images of 64 x 64 and larger, where it measured faster
@@ -32,7 +33,7 @@ _DEFAULTS = {
     'MMDGAN_LAUNCH_MODE': None, 'MMDGAN_SIDE_WGRAD': '1', 'MMDGAN_SN_STREAMS': '2', 'MMDGAN_SN_FUSED': '1',
     'MMDGAN_EARLY_D_ADAM': '1', 'MMDGAN_GEN_TAIL_MAIN': '2', 'MMDGAN_QUEUE_OPT': '1', 'MMDGAN_DP_BACKEND': None,
     'MMDGAN_DP_BUCKET_MB': '8', 'MMDGAN_DP_FORCE': '0', 'MMDGAN_TAPE_STREAMS': '1', 'MMDGAN_TAPE_COMPOSE': '1',
-    'MMDGAN_TAPE_JOINT': '1', 'MMDGAN_TAPE_FUSE_ADD': '1', 'MMDGAN_BN_RESIGN': '1', 'MMDGAN_WGRAD_DEFER': '1', 'MMDGAN_STEP_AHEAD': 'auto',
+    'MMDGAN_TAPE_JOINT': '1', 'MMDGAN_TAPE_FUSE_ADD': '1', 'MMDGAN_BN_RESIGN': '1', 'MMDGAN_WGRAD_DEFER': '1', 'MMDGAN_TAPE_FUSE_ACT': '1', 'MMDGAN_STEP_AHEAD': 'auto',
 }
 
 

@@ -549,6 +549,7 @@ class NetForward:
         run.device, run._bufs, run._wino, run._in_step, run._sn_zeroed = self.device, {}, {}, False, False
         run._folded = {k.scope: [None, None] for k in self.net.kernels}
         run._graphs, run._fusions, run._out_buffer, run._ready_wait = {}, {}, None, None
+        run._act_fus, run._fuse_act = {}, settings.on('MMDGAN_TAPE_FUSE_ACT')
         self._run = run
 
     def __call__(self, x_nhwc, is_training=False):
@@ -632,6 +633,8 @@ class TapeEngine:
         self._early_d_adam = settings.on('MMDGAN_EARLY_D_ADAM')
         self._wgrad_defer = settings.on('MMDGAN_WGRAD_DEFER')
         self._wg_after = []
+        self._fuse_act = settings.on('MMDGAN_TAPE_FUSE_ACT')
+        self._act_fus = {}
         self._bn_resign = settings.on('MMDGAN_BN_RESIGN')
         self._d_has_bn = bool(self.dis.bns)
         lib = ops.require_device()
@@ -901,11 +904,20 @@ class TapeEngine:
         last = max(i for i, p in enumerate(net.prims) if p['out'] == net.out_val)
         self._out_buffer = ((tag, net.name), last, out_buffer) if (out_buffer is not None and net.prims[last]['kind'] != 'reshape') else None
         fused_addend, fused_add = self._add_fusions(net)
+        act_after = self._act_fusions(net)               # value id -> the activation that is its only reader
+        acted = set()                                    # values that were written ACTIVATED by their producer's epilogue
         for i, p in enumerate(net.prims):
             kind, a = p['kind'], vals[p['ins'][0]]
             key = (tag, net.name, i)
             out_shape = _native(net.shapes[p['out']], n)
             addend = vals[fused_addend[i]] if i in fused_addend else None     # a branch sum riding on this launch
+            # an activation that is the only reader of this convolution / dense product rides on its epilogue (no pass of its own;
+            # relu / lrelu / tanh are all differentiated from their OUTPUT, which is what the value table then holds)
+            fact, okey = 'linear', key
+            if kind in ('dense', 'conv', 'upconv', 'convdown', 'tconv') and addend is None and p['out'] in act_after and self._fuse_act:
+                fact, j = act_after[p['out']]
+                okey = (tag, net.name, j)                # the activation's buffer (the net's output buffer, if it is the last primitive)
+                acted.add(p['out'])
             if self._ready_wait is not None and kind in ('conv', 'gconv', 'upconv', 'convdown', 'tconv'):
                 ops.event_wait(self._ready_wait, ops._stream())          # this step's composed / transformed weights (_step_body)
                 self._ready_wait = None
@@ -915,11 +927,11 @@ class TapeEngine:
                 k = p['k']
                 scale = net.sn[k.scope]['scale'] if k.sn else None
                 bias = net.p(k.bias_name) if k.bias_name is not None else None
-                y = self._buf_of(key, out_shape)
+                y = self._buf_of(okey, out_shape)
                 if kind == 'dense':
-                    ops.gemm(a.reshape(n, -1), net.p(k.w_name), bias=bias, scale=scale, out=y)
+                    ops.gemm(a.reshape(n, -1), net.p(k.w_name), bias=bias, scale=scale, act=fact, out=y)
                 else:
-                    ops.conv2d_fwd(a, net.p(k.w_name), k.stride, bias=bias, scale=scale, out=y, addend=addend,
+                    ops.conv2d_fwd(a, net.p(k.w_name), k.stride, bias=bias, scale=scale, act=fact, out=y, addend=addend,
                                    wino=self._wino_of(k, False, n) if (training and self._in_step) else None)
             elif kind == 'gconv':                                        # 'VALID' padding and / or dilation: a composition
                 k = p['k']
@@ -933,19 +945,19 @@ class TapeEngine:
                 w4 = self._folded[k.scope][0]
                 if not (training and self._in_step):                     # outside step(): compose on the spot
                     w4 = ops.compose_scaled_conv(net.p(k.w_name), k.fold)
-                y = self._buf_of(key, out_shape)
+                y = self._buf_of(okey, out_shape)
                 if kind == 'convdown':
-                    ops.conv2d_fwd(a, w4, 2, bias=bias, scale=scale, out=y, addend=addend,
+                    ops.conv2d_fwd(a, w4, 2, bias=bias, scale=scale, act=fact, out=y, addend=addend,
                                    wino=self._wino_of(k, False, n) if (training and self._in_step) else None)
                 else:
-                    ops.conv2d_dgrad(a, w4, (out_shape[1], out_shape[2]), 2, bias=bias, scale=scale, out=y, addend=addend,
+                    ops.conv2d_dgrad(a, w4, (out_shape[1], out_shape[2]), 2, bias=bias, scale=scale, act=fact, out=y, addend=addend,
                                      wino=self._wino_of(k, True, n) if (training and self._in_step) else None)
             elif kind == 'tconv':                                        # y = the input-gradient of a conv with kernel w
                 k = p['k']
                 bias = net.p(k.bias_name) if k.bias_name is not None else None
                 scale = net.sn[k.scope]['scale'] if k.sn else None
-                y = self._buf_of(key, out_shape)
-                ops.conv2d_dgrad(a, net.p(k.w_name), (out_shape[1], out_shape[2]), k.stride, bias=bias, scale=scale, out=y,
+                y = self._buf_of(okey, out_shape)
+                ops.conv2d_dgrad(a, net.p(k.w_name), (out_shape[1], out_shape[2]), k.stride, bias=bias, scale=scale, act=fact, out=y,
                                  addend=addend, wino=self._wino_of(k, True, n) if (training and self._in_step) else None)
             elif kind == 'bn':
                 y = self._buf_of(key, out_shape)
@@ -972,7 +984,10 @@ class TapeEngine:
                 else:
                     ops.bn_fwd_infer(x2, gamma, beta, mm, mv, act=p['act'], out=y2)
             elif kind == 'act':
-                y = ops.act_fwd(a, p['act'], out=self._buf_of(key, out_shape))
+                if p['ins'][0] in acted:                                 # written activated by its producer's epilogue
+                    y = a
+                else:
+                    y = ops.act_fwd(a, p['act'], out=self._buf_of(key, out_shape))
             elif kind == 'down':
                 y = ops.resample_down(a, p['f'], out=self._buf_of(key, out_shape))
             elif kind == 'up':
@@ -1001,6 +1016,18 @@ class TapeEngine:
 
     # ---- backward ---------------------------------------------------------------------------------------------
     _ROW_WISE = ('reshape', 'dense', 'conv', 'gconv', 'upconv', 'convdown', 'tconv', 'act', 'down', 'up', 'shuffle', 'add')
+
+    def _act_fusions(self, net):
+        """{value id: activation name} for the values whose ONLY reader is an activation primitive (not the net's output)"""
+        f = self._act_fus.get(id(net))
+        if f is None:
+            producer, uses = self._graph_of(net)
+            f = {}
+            for q in net.prims:
+                if q['kind'] == 'act' and uses.get(q['ins'][0], 0) == 1 and q['ins'][0] != 0 and q['ins'][0] != net.out_val:
+                    f[q['ins'][0]] = (q['act'], net.prims.index(q))
+            self._act_fus[id(net)] = f
+        return f
 
     def _graph_of(self, net):
         """value id -> the primitive that produces it, value id -> number of consumers (the net's output counts as one)"""
