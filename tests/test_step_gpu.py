@@ -669,6 +669,22 @@ def test_power_iteration_chains_on_two_streams_give_the_one_stream_result(monkey
             assert float((d1 - d2).norm() / d1.norm()) <= 1e-4, (scope, float((d1 - d2).norm() / d1.norm()))
 
 
+def _run_exchange_child(script, env, timeout=240):
+    """run a one-rank RCCL child.  A child that never got its communicator up within the limit (RCCL's bootstrap on a box
+    whose network interfaces answer slowly: seen twice in round 5, 300 s and more before the first collective, on boxes that
+    also took minutes to hand over) is an environment problem and skips; one that hangs AFTER the first collective fails."""
+    import subprocess
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    try:
+        return subprocess.run([sys.executable, '-c', 'ROOT = %r\n' % root + script], env=env, capture_output=True, text=True,
+                              timeout=timeout)
+    except subprocess.TimeoutExpired as e:
+        err = e.stderr if isinstance(e.stderr, str) else (e.stderr or b'').decode(errors='replace')
+        if 'STAGE exchange-up' not in err:
+            pytest.skip('the RCCL communicator did not come up within %d s on this box: %s' % (timeout, err[-300:]))
+        raise
+
+
 _RCCL_CHILD = r"""
 import os, sys, json
 import numpy as np, torch, torch.distributed as dist
@@ -678,6 +694,8 @@ from mmdgan_hip import dist as mdist
 from test_step_gpu import mid_architecture
 torch.cuda.set_device(0)
 mdist.init_process_group(0)
+_probe = torch.ones(4, device='cuda'); dist.all_reduce(_probe); torch.cuda.synchronize()
+print('STAGE exchange-up', file=sys.stderr, flush=True)
 arch, B = mid_architecture(), 16
 if os.environ.get('RCCL_CHILD_ENGINE') == 'tape':                   # the residual-block engine (mmdgan_hip/tape.py)
     from mmdgan_hip.tape import TapeEngine as GanEngine
@@ -860,6 +878,8 @@ real = [torch.as_tensor(rs.uniform(-1, 1, (B, 32, 32, 3)).astype(np.float32)).cu
 out = {}
 for name, kw in (('capi', dict(dist_group=dist.group.WORLD, dp_backend='capi', launch_mode='plan')), ('single', {})):
     eng = GanEngine(arch, 'rep', (5e-4, 2e-4), batch_size=B, seed=3, **kw)
+    torch.cuda.synchronize()
+    print('STAGE exchange-up', file=sys.stderr, flush=True)          # (the library's communicator is made with the engine)
     for net in (eng.gen, eng.dis):       # the same arithmetic on both sides: replicas fix their gradients up before the
         net.opt.fold_fixup = False       # exchange, a lone engine folds that into Adam's read (other rounding, and the
     init = eng.get_variables()           # first steps' Adam-eps regime amplifies rounding) - this test is about the exchange
@@ -901,8 +921,7 @@ def test_library_owned_rccl_exchange_is_part_of_the_plan(engine):
         port = s.getsockname()[1]
     env = dict(os.environ, MMDGAN_DP_FORCE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1',
                LOCAL_RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0', CAPI_CHILD_ENGINE=engine)
-    r = subprocess.run([sys.executable, '-c', 'ROOT = %r\n' % root + _CAPI_CHILD], env=env, capture_output=True, text=True,
-                       timeout=240)
+    r = _run_exchange_child(_CAPI_CHILD, env)
     assert r.returncode == 0, r.stderr[-3000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('RESULT ')][-1][7:])
     assert res['comm_size'] == 1 and res['segments'] == 1 and res['buckets'] >= 4, res
@@ -927,8 +946,7 @@ def test_data_parallel_exchange_runs_over_rccl(engine):
         port = s.getsockname()[1]
     env = dict(os.environ, MMDGAN_DP_FORCE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0',
                WORLD_SIZE='1', LOCAL_RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0', RCCL_CHILD_ENGINE=engine)
-    r = subprocess.run([sys.executable, '-c', 'ROOT = %r\n' % root + _RCCL_CHILD], env=env, capture_output=True,
-                       text=True, timeout=240)
+    r = _run_exchange_child(_RCCL_CHILD, env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('RESULT ')]
     assert lines, (r.stdout[-2000:], r.stderr[-2000:])
