@@ -27,6 +27,7 @@ def init_process_group(local_rank=None, backend='nccl', **kwargs):
     (tools/dp_probe.py, one rank) - the engine instead issues its collectives on a stream it picked itself."""
     import os
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    pin_loopback()
     if backend != 'nccl':
         tdist.init_process_group(backend, **kwargs)
         return tdist.group.WORLD
@@ -34,6 +35,24 @@ def init_process_group(local_rank=None, backend='nccl', **kwargs):
         local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     tdist.init_process_group('nccl', device_id=torch.device('cuda', local_rank), **kwargs)
     return tdist.group.WORLD
+
+
+def pin_loopback(environ=None):
+    """a ONE-NODE job (the rendezvous address is this host's loopback) bootstraps over `lo`: without an interface named, gloo
+    resolves the host name and RCCL walks the other interfaces first - on a box whose name does not resolve or whose outer
+    interface answers slowly that is minutes before the first collective (round 5 saw 300 s and more, twice).  Only defaults:
+    GLOO_SOCKET_IFNAME / NCCL_SOCKET_IFNAME set by the user win, and a multi-node rendezvous address changes nothing.
+    Returns the names it set."""
+    import os
+    env = os.environ if environ is None else environ
+    if env.get('MASTER_ADDR', '127.0.0.1') not in ('127.0.0.1', 'localhost', '::1') or not os.path.isdir('/sys/class/net/lo'):
+        return []
+    done = []
+    for name in ('GLOO_SOCKET_IFNAME', 'NCCL_SOCKET_IFNAME'):
+        if name not in env:
+            env[name] = 'lo'
+            done.append(name)
+    return done
 
 
 def buckets(numel, bucket_bytes=DEFAULT_BUCKET_BYTES, elem_bytes=4):

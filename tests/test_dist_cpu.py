@@ -22,7 +22,7 @@ def _free_port():
 
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    tdist.init_process_group('gloo', rank=rank, world_size=world)
+    mdist.init_process_group(backend='gloo', rank=rank, world_size=world)       # (pins the bootstrap to `lo`: pin_loopback)
     try:
         g = torch.Generator().manual_seed(100 + rank)
         flat = torch.randn(100003, generator=g)                      # a gradient arena, different per replica
@@ -120,3 +120,16 @@ def test_buckets_cover_exactly():
         assert b[0][0] == 0 and b[-1][1] == n and all(x[1] == y[0] for x, y in zip(b, b[1:]))
         assert all(e - s <= 1024 for s, e in b)
     assert mdist.shard_of(10, 0, 3) == (0, 4) and mdist.shard_of(10, 2, 3) == (7, 10)
+
+
+def test_one_node_rendezvous_is_pinned_to_loopback_by_default_only():
+    """mdist.pin_loopback: a loopback rendezvous address names `lo` for gloo's and RCCL's bootstrap, a user's choice and a
+    multi-node address are left alone."""
+    if not os.path.isdir('/sys/class/net/lo'):
+        pytest.skip('no loopback interface here')
+    env = {'MASTER_ADDR': '127.0.0.1'}
+    assert mdist.pin_loopback(env) == ['GLOO_SOCKET_IFNAME', 'NCCL_SOCKET_IFNAME'] and env['NCCL_SOCKET_IFNAME'] == 'lo'
+    env = {'MASTER_ADDR': 'localhost', 'NCCL_SOCKET_IFNAME': 'eth0'}
+    assert mdist.pin_loopback(env) == ['GLOO_SOCKET_IFNAME'] and env['NCCL_SOCKET_IFNAME'] == 'eth0'
+    env = {'MASTER_ADDR': '10.0.0.7'}
+    assert mdist.pin_loopback(env) == [] and 'GLOO_SOCKET_IFNAME' not in env
