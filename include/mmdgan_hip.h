@@ -186,7 +186,10 @@ int mmdgan_allreduce_bucket(float *buf, size_t count, void *stream);
 /* ------------------------------------------------------------------------------------------------
  * Convolution family.  Geometry: input [N,H,W,C], kernel [R,R,C,K], stride, 'SAME' padding with
  * pad_before = max((ceil(H/stride)-1)*stride + R - H, 0)/2 (tf.nn.conv2d, layer_func.py:914),
- * output [N,P,Q,K], P = ceil(H/stride).
+ * output [N,P,Q,K], P = ceil(H/stride).  1 <= R <= 7, 1 <= stride <= 7.  A kernel SMALLER than its stride is accepted
+ * (a 1x1 stride-2 transposed conv is what a residual block on 'tc' has as its shortcut when its 'kernel' list says so,
+ * layer_func.py:1725-1745): taps skip input pixels, the input-gradient leaves the pixels no tap reaches at act(bias);
+ * those geometries run on the generic kernels (csrc/conv_direct.hip), the tiled families are built for R >= stride.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
     int N, H, W, C;    /* input  (NHWC) */

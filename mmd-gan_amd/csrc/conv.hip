@@ -12,12 +12,16 @@ namespace {
 int validate(const mmdgan_conv_geom *g, const char *what) {
     MMDGAN_REQUIRE(g, "%s: null geometry", what);
     MMDGAN_REQUIRE(g->N >= 1 && g->H >= 1 && g->W >= 1 && g->C >= 1 && g->K >= 1, "%s: bad shape", what);
-    MMDGAN_REQUIRE(g->R >= 1 && g->R <= 7 && g->stride >= 1 && g->stride <= g->R, "%s: bad kernel %d / stride %d", what,
+    MMDGAN_REQUIRE(g->R >= 1 && g->R <= 7 && g->stride >= 1 && g->stride <= 7, "%s: bad kernel %d / stride %d", what,
                    g->R, g->stride);
     return MMDGAN_OK;
 }
 // MMDGAN_FORCE_DIRECT=1 routes everything to the direct kernels (A/B debugging aid)
 bool force_direct() { return tuning().force_direct != 0; }
+// a kernel smaller than its stride (the 1x1 stride-2 transposed conv a residual block on 'tc' may have as its shortcut,
+// layer_func.py:1725-1745: taps that skip input pixels / output pixels no tap reaches): the generic direct kernels, whose
+// index arithmetic assumes nothing about R against the stride; the tiled families are built for R >= stride
+bool generic_only(const ConvDims &d) { return force_direct() || d.R < d.stride; }
 // MMDGAN_THIN_VALU=1 keeps the thin first/last layers on the VALU kernels (A/B against the MFMA ones)
 bool force_valu_thin() { return tuning().thin_valu != 0; }
 inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }    // also true for nullptr
@@ -89,6 +93,7 @@ static int conv2d_fwd_impl(const mmdgan_conv_geom *g, const float *x, const floa
                        "conv2d_fwd: MMDGAN_ACT_FLAG_W_WINOGRAD on a geometry mmdgan_wino_eligible() rejects");
         return d.R == 3 ? wino_fwd(d, ep, x, nullptr, w, y, (hipStream_t)stream) : wino2_fwd(d, ep, x, nullptr, w, y, (hipStream_t)stream);
     }
+    if (generic_only(d)) return direct_fwd(d, ep, x, w, y, (hipStream_t)stream);
     if (!force_direct() && wino2_fwd_ok(d)) return wino2_fwd(d, ep, x, w, nullptr, y, (hipStream_t)stream);
     if (!force_direct() && wino_fwd_ok(d)) return wino_fwd(d, ep, x, w, nullptr, y, (hipStream_t)stream);
     if (!force_direct() && igemm_fwd_ok(d)) return igemm_fwd(d, ep, x, w, y, (hipStream_t)stream);
@@ -158,6 +163,7 @@ static int conv2d_dgrad_impl(const mmdgan_conv_geom *g, const float *dy, const f
                        "conv2d_dgrad: MMDGAN_ACT_FLAG_W_WINOGRAD on a geometry mmdgan_wino_eligible() rejects");
         return d.R == 3 ? wino_dgrad(d, ep, dy, nullptr, w, dx, (hipStream_t)stream) : wino2_dgrad(d, ep, dy, nullptr, w, dx, (hipStream_t)stream);
     }
+    if (generic_only(d)) return direct_dgrad(d, ep, dy, w, dx, (hipStream_t)stream);
     if (!force_direct() && wino2_dgrad_ok(d)) return wino2_dgrad(d, ep, dy, w, nullptr, dx, (hipStream_t)stream);
     if (!force_direct() && wino_dgrad_ok(d)) return wino_dgrad(d, ep, dy, w, nullptr, dx, (hipStream_t)stream);
     if (!force_direct() && igemm_dgrad_ok(d)) return igemm_dgrad(d, ep, dy, w, dx, (hipStream_t)stream);
@@ -209,16 +215,17 @@ static int wgrad_impl(const mmdgan_conv_geom *g, const float *x, const float *dy
     if (wgrad_flush_pending()) return MMDGAN_E_LAUNCH;
     int rc = 1;
     bool dot_done = false;
-    if (!force_direct() && igemm_wgrad_ok(d)) rc = igemm_wgrad(d, x, dy, dw, dbias, (hipStream_t)stream);   // sums dy on the way
+    const bool generic = generic_only(d);
+    if (!generic && igemm_wgrad_ok(d)) rc = igemm_wgrad(d, x, dy, dw, dbias, (hipStream_t)stream);   // sums dy on the way
     else {
-        if (!force_direct() && !force_valu_thin() && thinm_wgrad_ok(d) && d.N > 1) {
+        if (!generic && !force_valu_thin() && thinm_wgrad_ok(d) && d.N > 1) {
             // (its reduction pass forms <dw, w> where it has the finished dw)
             if (wdot && zero_output(dot, sizeof(float), (hipStream_t)stream) != hipSuccess) return check_launch("conv2d_wgrad memset");
             rc = thinm_wgrad(d, x, dy, dw, (hipStream_t)stream, wdot, dot);
             dot_done = rc == 0;
         }
         if (rc > 0) {                                              // 1: no workspace registered -> VALU kernel
-            if (!force_direct() && thin_wgrad_ok(d)) rc = thin_wgrad(d, x, dy, dw, (hipStream_t)stream);
+            if (!generic && thin_wgrad_ok(d)) rc = thin_wgrad(d, x, dy, dw, (hipStream_t)stream);
             else rc = direct_wgrad(d, x, dy, dw, (hipStream_t)stream);
         }
         if (rc == 0 && dbias) rc = mmdgan_colsum(dy, (long)d.N * d.P * d.Q, d.K, dbias, stream);

@@ -180,6 +180,18 @@ class _Net:
             return self._emit('upconv', [x], out_ref, k=k)
         return self._emit('convdown', [x], [out, out_ref[1] // 2, out_ref[2] // 2], k=k)
 
+    def _tconv(self, scope, opname, d, index, x, bias_name):
+        """a transposed-conv kernel [R, R, out, in] of a layer or block (layer_func.py:590-600, 918-928)"""
+        c, h, w = self.shapes[x]
+        R, stride, out = _pick(d['kernel'], index), _pick(d['strides'], index), _pick(d['out'], index)
+        if _pick(d['dilation'], index) != 1 or _pick(d['padding'], index) != 'SAME':
+            raise NotImplementedError('{}: dilation / VALID are not built'.format(scope))
+        out_ref = [out, h * stride, w * stride]
+        k = _Kernel('{}/{}'.format(scope, opname), 'tc', [R, R, out, c], [c, h, w], out_ref, _pick(d['act'], index),
+                    _pick(d['w_nm'], index), _pick(d['act_k'], index), bias_name, stride, self.sn_mode, out=out)
+        self.kernels.append(k)
+        return self._emit('tconv', [x], out_ref, k=k)
+
     def _can_fold(self, d, index, x, method):
         c, h, w = self.shapes[x]
         return (self.compose and d['scale'] is not None and d['scale'][0] == method and abs(d['scale'][1]) == 2
@@ -243,23 +255,15 @@ class _Net:
         if d['in_reshape'] is not None:
             x = self._reshape(x, d['in_reshape'])
         if d['type'] in RES_TYPES:
-            if d['op'] != 'c':
-                raise NotImplementedError('{}: residual blocks are built for op "c"'.format(scope))
+            if d['op'] not in ('c', 'tc'):
+                raise NotImplementedError('{}: residual blocks are built for op "c" and "tc"'.format(scope))
             y = self._lower_res(d, scope, x, bn)
         elif d['type'] != 'default':
             raise NotImplementedError('{}: {} is not implemented.'.format(scope, d['type']))   # :2067
         elif d['op'] == 'i':                                             # identity kernel, then BN / activation
             y = self._bn_act(scope + '/BN', x, d['act']) if bn else self._emit('act', [x], self.shapes[x], act=d['act'])
         elif d['op'] == 'tc':                                            # transposed conv (layer_func.py:590-600, 918-928)
-            c, h, w = self.shapes[x]
-            R, stride, out = d['kernel'], d['strides'], d['out']
-            if d['dilation'] != 1 or d['padding'] != 'SAME':
-                raise NotImplementedError('{}: dilation / VALID are not built'.format(scope))
-            out_ref = [out, h * stride, w * stride]
-            k = _Kernel(scope + '/kernel', 'tc', [R, R, out, c], [c, h, w], out_ref, d['act'], d['w_nm'], d['act_k'],
-                        scope + '/bias/bias' if d['bias'] is not None else None, stride, self.sn_mode, out=out)
-            self.kernels.append(k)
-            y = self._emit('tconv', [x], out_ref, k=k)
+            y = self._tconv(scope, 'kernel', d, None, x, scope + '/bias/bias' if d['bias'] is not None else None)
             if bn:
                 y = self._bn_act(scope + '/BN', y, d['act'])
             elif d['act'] != 'linear':
@@ -305,7 +309,12 @@ class _Net:
                 r = self._bn_act(scope + '/BN_0', r, act)
             elif act != 'linear':
                 r = self._emit('act', [r], self.shapes[r], act=act)
-        if up and self._can_fold(d, 0, r, 'unpool'):
+        # op 'tc' (:1725-1727): kernel_0 and kernel_sc are transposed convs - they ARE the up-sampling, 'scale' was dropped in
+        # _lower (:1245-1247) - and kernel_1 stays a conv
+        tc = d['op'] == 'tc'
+        if tc:
+            r = self._tconv(scope, 'kernel_0', d, 0, r, scope + '/bias_0/bias' if bias else None)
+        elif up and self._can_fold(d, 0, r, 'unpool'):
             r = self._conv(scope, 'kernel_0', d, 0, r, scope + '/bias_0/bias' if bias else None, fold='unpool')
         else:
             if up:
@@ -322,7 +331,9 @@ class _Net:
             if down:
                 r = self._scale(r, d['scale'])
         s = x
-        if typ == 'res':
+        if tc and typ in ('res', 'res_v1'):                              # (no scaling op on either side: 'scale' is None)
+            s = self._tconv(scope, 'kernel_sc', d, 2, s, scope + '/bias_sc/bias')
+        elif typ == 'res':
             # a 1x1 conv commutes with nearest-neighbour up-sampling (exactly) and with average pooling (to rounding):
             # it runs on the small side of the scaling op, a quarter of the work
             commute = (self.compose and _pick(d['kernel'], 2) == 1 and _pick(d['strides'], 2) == 1

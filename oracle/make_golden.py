@@ -358,7 +358,8 @@ def make_layers(only=None):
 # 3. full G+D step on a width/8 CIFAR-shaped net, 3 consecutive steps
 # ---------------------------------------------------------------------------
 from tiny_arch import (tiny_architecture, tiny_gsn_architecture, tiny_res_architecture, tiny_res_ps_architecture,  # noqa: E402
-                       tiny_res_bil_architecture, tiny_res_max_architecture, tiny_res_bic_architecture)  # noqa: E402
+                       tiny_res_bil_architecture, tiny_res_max_architecture, tiny_res_bic_architecture,  # noqa: E402
+                       tiny_res_tc_architecture)  # noqa: E402
 
 
 def tf_adam_inplace(var, g, m, v, t, lr, b1=0.5, b2=0.999, eps=1e-8):
@@ -791,6 +792,11 @@ if __name__ == '__main__':
         make_step('rmb', sn_mode='sn_paper', arch_fn=tiny_gsn_architecture, tag='gsn_rmb_pim')
         make_step_warm('rep', arch_fn=tiny_gsn_architecture, tag='gsn_rep')
         sys.exit(0)
+    if '--only-tc' in sys.argv:                                      # transposed convs inside residual blocks (layer_func.py:1725-1727)
+        torch.manual_seed(0)
+        torch.set_num_threads(4)
+        make_step('rep', arch_fn=tiny_res_tc_architecture, tag='res_tc_rep', store_grads=True)
+        sys.exit(0)
     if '--only-valid' in sys.argv:
         torch.manual_seed(0)
         torch.set_num_threads(4)
@@ -823,6 +829,7 @@ if __name__ == '__main__':
     make_step('rep', arch_fn=tiny_res_bil_architecture, tag='res_bil_rep')
     make_step('rep', arch_fn=tiny_res_bic_architecture, tag='res_bic_rep')
     make_step('rep', arch_fn=tiny_res_max_architecture, tag='res_max_rep')
+    make_step('rep', arch_fn=tiny_res_tc_architecture, tag='res_tc_rep')
     make_step('rep', arch_fn=tiny_gsn_architecture, tag='gsn_rep')
     make_step('rmb', sn_mode='sn_paper', arch_fn=tiny_gsn_architecture, tag='gsn_rmb_pim')
     make_eval()

@@ -55,8 +55,8 @@ def layer_defaults(design):
         raise AttributeError('layer op {} not supported.'.format(d['op']))
     if d['type'] not in ('default',) + RES_TYPES:
         raise NotImplementedError('{} is not implemented.'.format(d['type']))
-    if d['type'] in RES_TYPES and d['op'] != 'c':
-        raise NotImplementedError('residual blocks are restated for op "c" only')
+    if d['type'] in RES_TYPES and d['op'] not in ('c', 'tc'):
+        raise NotImplementedError('residual blocks are restated for op "c" and "tc"')
     if d['scale'] is not None:
         assert isinstance(d['scale'], (list, tuple)), 'Value for key "scale" must be list or tuple.'   # :1250-1252
     return d
@@ -172,25 +172,37 @@ def bicubic_resize(x, size):
     return sum(cols[:, :, torch.as_tensor(iy[:, a])] * wy_t[:, a][:, None] for a in range(4))     # [n,c,oh,ow]
 
 
-def _kernel_spec(layer_scope, op_name, d, index, in_shape, sn_mode):
-    """one ParametricOperation of a block (Layer._add_kernel_, layer_func.py:1415-1452): a conv kernel with its own
-    spectral norm; variables live under <layer>/<op_name>/"""
-    sub = {'op': 'c', 'type': 'default', 'in_reshape': None, 'out_reshape': None}
+def _kernel_spec(layer_scope, op_name, d, index, in_shape, sn_mode, op='c'):
+    """one ParametricOperation of a block (Layer._add_kernel_, layer_func.py:1415-1452): a conv kernel - or, op='tc', a
+    transposed-conv kernel [k, k, out, in] (layer_func.py:590-600) - with its own spectral norm; variables live under
+    <layer>/<op_name>/"""
+    sub = {'op': op, 'type': 'default', 'in_reshape': None, 'out_reshape': None}
     for key in ('out', 'act', 'act_k', 'w_nm', 'kernel', 'strides', 'dilation', 'padding'):
         sub[key] = _pick(d[key], index)
     c, h, w = in_shape
-    ks = {'design': sub, 'scope': '{}/{}'.format(layer_scope, op_name), 'in_shape': list(in_shape),
-          'kernel_shape': [sub['kernel'], sub['kernel'], c, sub['out']],
-          'op_out_shape': [sub['out'], _same_out(h, sub['strides']), _same_out(w, sub['strides'])]}
+    if op == 'tc':
+        if sub['dilation'] != 1 or sub['padding'] != 'SAME':
+            raise NotImplementedError('{}/{}: dilation / VALID on a transposed conv are not restated'.format(layer_scope, op_name))
+        ks = {'design': sub, 'scope': '{}/{}'.format(layer_scope, op_name), 'in_shape': list(in_shape),
+              'kernel_shape': [sub['kernel'], sub['kernel'], sub['out'], c],
+              'op_out_shape': [sub['out'], h * sub['strides'], w * sub['strides']]}
+    else:
+        ks = {'design': sub, 'scope': '{}/{}'.format(layer_scope, op_name), 'in_shape': list(in_shape),
+              'kernel_shape': [sub['kernel'], sub['kernel'], c, sub['out']],
+              'op_out_shape': [sub['out'], _same_out(h, sub['strides']), _same_out(w, sub['strides'])]}
     if sub['w_nm'] == 's':
         if sn_mode in ('sn_paper', 'PIM', 'pim'):
-            num_in = int(np.prod(ks['kernel_shape'][:3]))
-            ks['use_u'] = num_in <= sub['out']
-            ks['sn_x_shape'] = [1, num_in] if ks['use_u'] else [1, sub['out']]
+            # layer_func.py:811-814: the kernel flattened to [k*k*shape[2], shape[3]] (a 'tc' kernel's last axis is the layer's INPUT)
+            num_in, num_out = int(np.prod(ks['kernel_shape'][:3])), ks['kernel_shape'][3]
+            ks['use_u'] = num_in <= num_out
+            ks['sn_x_shape'] = [1, num_in] if ks['use_u'] else [1, num_out]
             ks['pim'] = True
         else:
             ks['use_u'] = int(np.prod(in_shape)) <= int(np.prod(ks['op_out_shape']))
-            ks['sn_x_shape'] = [1] + (list(in_shape) if ks['use_u'] else list(ks['op_out_shape']))
+            if op == 'tc':                                   # math_func.py:512-528: the conv the layer is the transpose of
+                ks['sn_x_shape'] = [1] + (list(ks['op_out_shape']) if ks['use_u'] else list(in_shape))
+            else:
+                ks['sn_x_shape'] = [1] + (list(in_shape) if ks['use_u'] else list(ks['op_out_shape']))
         if not isinstance(sub['act_k'], (float, int)) or sub['act_k'] is False:
             raise ValueError('{}: w_nm="s" needs a numeric act_k'.format(ks['scope']))
     return ks
@@ -206,7 +218,8 @@ def _build_res(s, d, shape, sn_mode):
     cur = list(shape)
     if up:
         cur = _scaled_shape(cur, d['scale'])
-    res['k0'] = _kernel_spec(sc, 'kernel_0', d, 0, cur, sn_mode)
+    op = d['op']                                             # 'tc' (:1725-1727): kernel_0 and kernel_sc transposed, kernel_1 a conv
+    res['k0'] = _kernel_spec(sc, 'kernel_0', d, 0, cur, sn_mode, op)
     cur = res['k0']['op_out_shape']
     res['k1'] = _kernel_spec(sc, 'kernel_1', d, 1, cur, sn_mode)
     cur = res['k1']['op_out_shape']
@@ -216,7 +229,7 @@ def _build_res(s, d, shape, sn_mode):
     if d['type'] == 'res':
         if up:
             sc_shape = _scaled_shape(sc_shape, d['scale'])
-        res['ksc'] = _kernel_spec(sc, 'kernel_sc', d, 2, sc_shape, sn_mode)
+        res['ksc'] = _kernel_spec(sc, 'kernel_sc', d, 2, sc_shape, sn_mode, op)
         sc_shape = res['ksc']['op_out_shape']
         if down:
             sc_shape = _scaled_shape(sc_shape, d['scale'])
@@ -225,7 +238,7 @@ def _build_res(s, d, shape, sn_mode):
             if not down:
                 raise AttributeError('{}: res_v1 is only used with downsampling.'.format(sc))
             sc_shape = _scaled_shape(sc_shape, d['scale'])
-        res['ksc'] = _kernel_spec(sc, 'kernel_sc', d, 2, sc_shape, sn_mode)
+        res['ksc'] = _kernel_spec(sc, 'kernel_sc', d, 2, sc_shape, sn_mode, op)
         sc_shape = res['ksc']['op_out_shape']
     assert sc_shape == cur, '{}: Resnet shape {} and shortcut shape {} do not match.'.format(sc, cur, sc_shape)
     s['res'] = res
@@ -549,7 +562,10 @@ def net_forward(specs, params, x, is_training=True, collect=None, masks=None):
             w = w * (kd['act_k'] / sigma)
             if collect is not None:
                 collect[ks['scope'] + '/sigma'] = sigma.detach()
-        t = conv2d_same(t, w, kd['strides'])
+        if kd['op'] == 'tc':                                  # layer_func.py:918-928
+            t = conv2d_transpose_same(t, w, ks['op_out_shape'][1:], kd['strides'])
+        else:
+            t = conv2d_same(t, w, kd['strides'])
         if bias_name is not None:
             t = t + params[bias_name].reshape(1, -1, 1, 1)
         return t

@@ -138,3 +138,23 @@ def tiny_res_max_architecture():
                               {'name': 'l3_res', 'type': 'res_i', 'out': 32, 'act': 'relu', 'act_k': ak, 'w_nm': 's',
                                'out_reshape': [4 * 4 * 32]},
                               {'name': 'l4_s', 'out': 16, 'op': 'd', 'act_k': ak, 'w_nm': 's'}]}
+
+
+def tiny_res_tc_architecture():
+    """residual blocks built on TRANSPOSED convolutions (op 'tc' inside a block, layer_func.py:1725-1727: kernel_0 and the
+    shortcut's kernel_sc are transposed convs - they do the up-sampling, 'scale' is dropped for 'tc', :1245-1247 - and
+    kernel_1 is a conv): G = dense -> a 4x4/2 block with BN (4x4/2 shortcut) -> a spectrally normalised block whose
+    shortcut is a 1x1/2 transposed conv (a pixel every other position) -> an identity-shortcut block on 3x3/1 transposed
+    convs -> conv/tanh at 16x16.  'kernel' / 'strides' as per-kernel lists (Layer._update_design_, :1380-1395).
+    D is tiny_res_architecture()'s."""
+    ak = float(np.power(64.0, 0.125))
+    arch = tiny_res_architecture()
+    arch['generator'] = [{'name': 'l1', 'out': 32 * 4 * 4, 'op': 'd', 'out_reshape': [32, 4, 4]},
+                         {'name': 'l2_res', 'type': 'res', 'op': 'tc', 'out': 16, 'act': 'relu', 'act_nm': 'bn',
+                          'kernel': [4, 3, 4], 'strides': [2, 1, 2]},
+                         {'name': 'l3_res', 'type': 'res', 'op': 'tc', 'out': 8, 'act': 'lrelu', 'act_k': ak, 'w_nm': 's',
+                          'kernel': [4, 3, 1], 'strides': [2, 1, 2]},
+                         {'name': 'l4_res', 'type': 'res_i', 'op': 'tc', 'out': 8, 'act': 'relu', 'act_nm': 'bn',
+                          'kernel': 3, 'strides': 1},
+                         {'name': 'l5_t16', 'out': 3, 'act': 'tanh'}]
+    return arch

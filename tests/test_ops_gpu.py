@@ -599,6 +599,39 @@ def test_random_conv_geometries(where):
     assert out['cases'] == 150 + 96 and not out['bad'], out['bad'][:5]
 
 
+SPARSE_TAP_CASES = [(4, 16, 16, 16, 8, 1, 2), (3, 9, 12, 8, 8, 2, 3), (2, 8, 8, 64, 64, 1, 2), (5, 7, 7, 3, 16, 1, 3)]
+
+
+@pytest.mark.parametrize('case', SPARSE_TAP_CASES, ids=[str(c) for c in SPARSE_TAP_CASES])
+def test_conv2d_kernel_smaller_than_its_stride(ops, case):
+    """kernels smaller than their stride (the 1x1 stride-2 transposed conv a residual block on 'tc' can have as its shortcut,
+    layer_func.py:1725-1745): taps skip input pixels, the input-gradient leaves pixels no tap reaches at zero (+ bias).  All three
+    kernels and the fused epilogues against the oracle's conv and its autograd."""
+    N, H, W, C, K, ksz, s = case
+    x, w, b = conv_data(case, 5)
+    P, Q = -(-H // s), -(-W // s)
+    rs = np.random.RandomState(11)
+    dy = rs.randn(N, K, P, Q).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    yt = R.conv2d_same(xt, wt, s)
+    assert tuple(yt.shape[2:]) == (P, Q)
+    gx, gw = torch.autograd.grad((yt * torch.tensor(dy, dtype=torch.float64)).sum(), [xt, wt])
+    sc = np.float32(0.8)
+    ref = R._act(yt.detach() * float(sc) + torch.tensor(b, dtype=torch.float64).reshape(1, -1, 1, 1), 'lrelu').numpy()
+    y = ops.conv2d_fwd(nhwc(x), dev(w), s, bias=dev(b), scale=dev([sc]), act='lrelu')
+    assert rel_err(to_nchw(y), ref) <= RTOL
+    dx = ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s)
+    assert rel_err(to_nchw(dx), gx.numpy()) <= RTOL
+    bc = (rs.randn(C) * 0.1).astype(np.float32)                     # the transposed-conv forward form
+    y2 = ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s, bias=dev(bc), act='relu')
+    assert rel_err(to_nchw(y2), np.maximum(gx.numpy() + bc.reshape(1, -1, 1, 1), 0)) <= RTOL
+    dbias = torch.zeros(K, device='cuda')
+    dw = ops.conv2d_wgrad(nhwc(x), nhwc(dy), ksz, s, dbias=dbias)
+    assert rel_err(dw.cpu().numpy(), gw.numpy()) <= RTOL
+    assert rel_err(dbias.cpu().numpy(), dy.sum((0, 2, 3))) <= RTOL
+
+
 WINO2_CASES = [(16, 16, 16, 64, 128, 4, 2), (30, 12, 12, 32, 64, 4, 2), (6, 8, 16, 64, 64, 4, 2), (9, 4, 4, 128, 64, 4, 2),
                (33, 8, 8, 96, 192, 4, 2), (5, 12, 8, 64, 128, 4, 2), (9, 4, 4, 128, 256, 4, 2), (70, 8, 8, 64, 128, 4, 2)]
 

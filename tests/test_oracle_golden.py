@@ -121,17 +121,20 @@ def test_net_restatement_matches_reference(path):
 
 
 @pytest.mark.parametrize('loss_type', ['rep', 'rmb', 'rep_pim', 'res_rep', 'res_ps_rmb', 'res_bil_rep', 'res_bic_rep', 'res_max_rep',
-                                       'gsn_rep', 'gsn_rmb_pim'])
+                                       'res_tc_rep', 'gsn_rep', 'gsn_rmb_pim'])
 def test_full_step_restatement_matches_reference(loss_type):
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
     fx = load(golden('step_tiny_%s.npz' % loss_type)[0])
     from tiny_arch import (tiny_architecture, tiny_gsn_architecture, tiny_res_architecture, tiny_res_ps_architecture,
-                           tiny_res_bil_architecture, tiny_res_max_architecture, tiny_res_bic_architecture)
+                           tiny_res_bil_architecture, tiny_res_max_architecture, tiny_res_bic_architecture,
+                           tiny_res_tc_architecture)
     # 'res_': the ResNet-shaped pair - every kind of residual block of layer_func.py:1687-1842
     is_res = loss_type.startswith('res_')
     res_arch = {'res_rep': tiny_res_architecture, 'res_ps_rmb': tiny_res_ps_architecture, 'res_bil_rep': tiny_res_bil_architecture,
-                'res_max_rep': tiny_res_max_architecture, 'res_bic_rep': tiny_res_bic_architecture}
+                'res_max_rep': tiny_res_max_architecture, 'res_bic_rep': tiny_res_bic_architecture,
+                # transposed convs inside the blocks (layer_func.py:1725-1727), one of them spectrally normalised
+                'res_tc_rep': tiny_res_tc_architecture}
     # 'gsn_': spectral norm in the generator too, transposed-conv kernels included (math_func.py:512-528)
     arch = res_arch[loss_type]() if is_res else (tiny_gsn_architecture() if loss_type.startswith('gsn_') else tiny_architecture())
     # '_pim': FLAGS.SPECTRAL_NORM_MODE = 'sn_paper' in the reference run (layer_func.py:811-814)

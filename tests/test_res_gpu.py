@@ -13,7 +13,7 @@ from oracle import restatement as R
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
 from tiny_arch import (tiny_res_architecture, tiny_res_bil_architecture, tiny_res_max_architecture, tiny_res_bic_architecture,  # noqa: E402
-                       tiny_res_ps_architecture)
+                       tiny_res_ps_architecture, tiny_res_tc_architecture)
 
 pytestmark = pytest.mark.gpu
 
@@ -27,21 +27,24 @@ def close(got, ref, rtol, floor):
     return np.max(np.abs(got - ref)) <= rtol * np.max(np.abs(ref)) + floor
 
 
-@pytest.mark.parametrize('tag', ['res_rep', 'res_rep-plan', 'res_ps_rmb', 'res_bil_rep', 'res_bil_rep-plan', 'res_bic_rep', 'res_max_rep'])
+@pytest.mark.parametrize('tag', ['res_rep', 'res_rep-plan', 'res_ps_rmb', 'res_bil_rep', 'res_bil_rep-plan', 'res_bic_rep', 'res_max_rep',
+                                 'res_tc_rep', 'res_tc_rep-plan'])
 def test_res_step_matches_reference_golden(tag):
     """('-plan': the same steps issued through the engine's recorded launch plan - step 0 records while it runs, steps 1
     and 2 are replays from one C call)
     'res_rep': res / res_i / res_v1 blocks with 'avg' and 'unpool' scaling and an identity layer, rep loss;
     'res_ps_rmb': blocks whose scaling is periodic shuffling, rmb loss; 'res_bil_rep' / 'res_bic_rep': bilinear / bicubic
     resizing (x2, /2, /3);
-    'res_max_rep': max pooling, and scaling on plain (non-block) layers"""
+    'res_max_rep': max pooling, and scaling on plain (non-block) layers;
+    'res_tc_rep': transposed convolutions inside the blocks (layer_func.py:1725-1727: kernel_0 and kernel_sc transposed - 4x4/2,
+    1x1/2 and 3x3/1 ones - kernel_1 a conv), with batch norm, with spectral norm, with an identity shortcut"""
     from mmdgan_hip.tape import TapeEngine
     tag, launch_mode = (tag[:-len('-plan')], 'plan') if tag.endswith('-plan') else (tag, 'eager')
     fx = load(golden('step_tiny_%s.npz' % tag)[0])
     B = int(fx['B'])
     arch = {'res_rep': tiny_res_architecture, 'res_ps_rmb': tiny_res_ps_architecture,
             'res_bil_rep': tiny_res_bil_architecture, 'res_max_rep': tiny_res_max_architecture,
-            'res_bic_rep': tiny_res_bic_architecture}[tag]()
+            'res_bic_rep': tiny_res_bic_architecture, 'res_tc_rep': tiny_res_tc_architecture}[tag]()
     eng = TapeEngine(arch, str(fx['loss_type']), tuple(fx['lr']), batch_size=B, launch_mode=launch_mode)
     init = {k[len('init/'):]: v for k, v in fx.items() if k.startswith('init/')}
     assert sorted(init) == sorted(eng.variable_names())              # the reference's variable names, all of them
@@ -100,7 +103,8 @@ def test_res_step_matches_reference_golden(tag):
                 'res_ps_rmb': {'dis/l3_s/bias/bias', 'dis/l2_res/bias_1/bias', 'dis/l2_res/bias_sc/bias'},
                 'res_bil_rep': {'dis/l3_s/bias/bias', 'dis/l2_res/bias_1/bias', 'dis/l2_res/bias_sc/bias'},
                 'res_bic_rep': {'dis/l3_s/bias/bias', 'dis/l2_res/bias_1/bias', 'dis/l2_res/bias_sc/bias'},
-                'res_max_rep': {'dis/l4_s/bias/bias', 'dis/l3_res/bias_1/bias'}}[tag]
+                'res_max_rep': {'dis/l4_s/bias/bias', 'dis/l3_res/bias_1/bias'},
+                'res_tc_rep': {'dis/l4_s/bias/bias', 'dis/l3_res/bias_1/bias'}}[tag]
     assert expected <= noise and len(noise) <= 8, noise
     for n, v in final.items():
         if n in noise:
@@ -137,10 +141,21 @@ def mid_res_architecture():
                               {'name': 'l5', 'out': 16, 'op': 'd', 'act_k': ak, 'w_nm': 's'}]}
 
 
-@pytest.mark.parametrize('loss_type,sn_mode', [('rep', 'default'), ('rmb', 'sn_paper')])
-def test_res_step_matches_oracle_on_mfma_sized_blocks(loss_type, sn_mode):
+def mid_res_tc_architecture():
+    """mid_res_architecture() with G's blocks on transposed convolutions (layer_func.py:1725-1727): 4x4 stride-2 kernel_0 and
+    kernel_sc at 128 / 64 channels - the F(2x2,2x2) and MFMA input-gradient kernels carry them - kernel_1 a 3x3 conv"""
+    arch = mid_res_architecture()
+    tc = {'op': 'tc', 'kernel': [4, 3, 4], 'strides': [2, 1, 2]}
+    for d in arch['generator'][1:4]:
+        del d['scale']
+        d.update(tc)
+    return arch
+
+
+@pytest.mark.parametrize('loss_type,sn_mode,blocks', [('rep', 'default', 'c'), ('rmb', 'sn_paper', 'c'), ('rep', 'default', 'tc')])
+def test_res_step_matches_oracle_on_mfma_sized_blocks(loss_type, sn_mode, blocks):
     from mmdgan_hip.tape import TapeEngine
-    arch, B = mid_res_architecture(), 16
+    arch, B = (mid_res_tc_architecture() if blocks == 'tc' else mid_res_architecture()), 16
     eng = TapeEngine(arch, loss_type, (5e-4, 2e-4), batch_size=B, seed=3, sn_mode=sn_mode)
     ora = R.OracleGan(arch, loss_type, (5e-4, 2e-4), dtype=torch.float64, params=eng.get_variables(), sn_mode=sn_mode)
     rs = np.random.RandomState(42)
@@ -167,6 +182,10 @@ def test_res_step_matches_oracle_on_mfma_sized_blocks(loss_type, sn_mode):
         # analytically zero gradients: a bias whose only consumer is a batch norm (G's bias_sc feed the next block's
         # BN_0 / the identity layer's BN), and biases behind which only score differences matter (D's last two)
         noise = {last_bias, 'dis/l4/bias_1/bias', 'gen/l2/bias_sc/bias', 'gen/l3/bias_sc/bias', 'gen/l4/bias_sc/bias'}
+        if blocks == 'tc':
+            # a per-channel constant does not stay one through the NEXT block's transposed-conv shortcut (a 4x4/2 transposed conv
+            # of a constant image has a phase pattern and borders): only the last block's bias_sc, read by a batch norm alone, is noise
+            noise -= {'gen/l2/bias_sc/bias', 'gen/l3/bias_sc/bias'}
         for net in ('gen', 'dis'):
             gscale = max(float(ref_g[n].abs().max()) for n in grads if n.startswith(net))
             for n in noise:
@@ -356,8 +375,25 @@ def test_step_on_random_residual_architectures(seed):
     up-sampling, 'avg' / 'ps' down-sampling; relu / lrelu; batch norm in G or not; three losses; eager issue and the
     launch plan; branch sums and gradient fan-ins on conv epilogues wherever the lowering finds them): three teacher-forced
     steps against the fp64 oracle - losses at 1e-4, all gradients by the one rule."""
-    from mmdgan_hip.tape import TapeEngine
+    _check_drawn_residual_pair(seed, *random_resnet(seed))
+
+
+@pytest.mark.parametrize('seed', [1, 2, 3])
+def test_step_on_random_residual_architectures_with_transposed_blocks(seed):
+    """the drawn pairs again with G's blocks on transposed convolutions (op 'tc' inside a block, layer_func.py:1725-1727): kernel_0
+    4x4 stride 2, kernel_1 a 3x3 conv, the shortcut a 4x4, 2x2 or 1x1 stride-2 transposed conv (drawn) - with the drawn widths,
+    batch norm or not, loss, batch and launch mode"""
     arch, loss, B, mode = random_resnet(seed)
+    rs = np.random.RandomState(3000 + seed)
+    for d in arch['generator']:
+        if d.get('type') == 'res':
+            del d['scale']
+            d.update({'op': 'tc', 'kernel': [4, 3, int(rs.choice([4, 2, 1]))], 'strides': [2, 1, 2]})
+    _check_drawn_residual_pair(seed, arch, loss, B, mode)
+
+
+def _check_drawn_residual_pair(seed, arch, loss, B, mode):
+    from mmdgan_hip.tape import TapeEngine
     c, h, w = arch['input'][0]
     lr = (5e-4, 2e-4)
     eng = TapeEngine(arch, loss, lr, batch_size=B, seed=seed, launch_mode=mode)
