@@ -29,6 +29,16 @@
 #include "conv_internal.h"
 #include "bufload.h"
 
+// Ablation hooks (tools/thin_ablate.sh: what each part of the n2w kernel costs): a compile-time bit mask, 0 in the library build.
+// 1: the wide tensor's stores, 2: the patch gathers, 4: all MFMAs but the first of a tile (a VALU FMA keeps the operands live).
+// Round 5, D l1 forward at batch 128 (33.5 MB written), graph replay: 20.7 us shipped; 15.2 without the stores, 19.8 without the
+// gathers, 17.5 without the MFMAs, 11.1 without all three - launch, weight prologue, the LDS transposes and the epilogue's
+// arithmetic of two tiles per wave.  The stores' 5.5 us are 6 TB/s: the kernel is bound by its fixed latencies at this size
+// (131 072 pixels), not by the wide tensor's bandwidth (profiles/r05_thin_ablation.txt).
+#ifndef THIN_ABLATE
+#define THIN_ABLATE 0
+#endif
+
 namespace mmdgan {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -111,7 +121,8 @@ __global__ __launch_bounds__(256) void thinm_n2w_kernel(ConvDims d, ConvEpilogue
         if (!ok) mask = 0;
         const unsigned pixbase = (unsigned)(mm * Cn * 4);
 #pragma unroll
-        for (int jp = 0; jp < kJP; ++jp) bq[jp] = bufld1(rs, (mask & tbit[jp]) ? pixbase + (unsigned)delta[jp] : kOOB);
+        for (int jp = 0; jp < kJP; ++jp)
+            bq[jp] = (THIN_ABLATE & 2) ? (float)(mask & tbit[jp]) : bufld1(rs, (mask & tbit[jp]) ? pixbase + (unsigned)delta[jp] : kOOB);
     };
     const int tstep = gridDim.x * 4;
     float bnext[kJP];
@@ -131,7 +142,9 @@ __global__ __launch_bounds__(256) void thinm_n2w_kernel(ConvDims d, ConvEpilogue
 #pragma unroll
         for (int jp = 0; jp < kJP; ++jp)
 #pragma unroll
-            for (int wb = 0; wb < WB; ++wb) acc[wb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[wb][jp], b[jp], acc[wb], 0, 0, 0);
+            for (int wb = 0; wb < WB; ++wb)
+                if (!(THIN_ABLATE & 4) || jp == 0) acc[wb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[wb][jp], b[jp], acc[wb], 0, 0, 0);
+                else acc[wb][jp] += a[wb][jp] * b[jp];
         if constexpr (WB <= 2) {
             // The wide tensor is what this kernel moves (33.5 MB for D l1 at batch 128): its stores decide the time.
             // A lane holds one PIXEL's channel quads, so direct stores put 16 bytes at a 256-byte stride per lane - every
@@ -170,7 +183,7 @@ __global__ __launch_bounds__(256) void thinm_n2w_kernel(ConvDims d, ConvEpilogue
                         v.x = act_fwd(v.x, ep.act); v.y = act_fwd(v.y, ep.act);
                         v.z = act_fwd(v.z, ep.act); v.w = act_fwd(v.w, ep.act);
                     }
-                    *reinterpret_cast<float4 *>(out + o) = ep.add4(v, o);
+                    if (!(THIN_ABLATE & 1) || v.x == 123.456f) *reinterpret_cast<float4 *>(out + o) = ep.add4(v, o);
                 }
             }
             __builtin_amdgcn_wave_barrier();

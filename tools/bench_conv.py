@@ -22,8 +22,25 @@ LAYERS = [('D l2', 2 * B, 32, 32, 64, 128, 4, 2), ('D l3', 2 * B, 16, 16, 128, 1
           ('G l2 (tc)', B, 8, 8, 256, 512, 4, 2), ('G l3 (tc)', B, 16, 16, 128, 256, 4, 2),
           ('G l4 (tc)', B, 32, 32, 64, 128, 4, 2),
           ('D l1 thin', 2 * B, 32, 32, 3, 64, 3, 1), ('D l1 (B)', B, 32, 32, 3, 64, 3, 1), ('G l5 thin', B, 32, 32, 64, 3, 3, 1)]
-def timeit(fn, reps=20):
-    for _ in range(3): fn()
+def timeit(fn, reps=int(os.environ.get('BENCH_REPS', '20'))):
+    # BENCH_GRAPH=1: the launches captured into a hipGraph and replayed - a launch below ~25 us is otherwise timed at what the
+    # Python wrapper costs per call, not at what the kernel takes; BENCH_WARM: untimed launches first (the clocks ramp over ms)
+    for _ in range(int(os.environ.get('BENCH_WARM', '3'))): fn()
+    if os.environ.get('BENCH_GRAPH'):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            fn()
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(reps): fn()
+        torch.cuda.current_stream().wait_stream(side)
+        for _ in range(3): g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5): g.replay()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / (5 * reps)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps): fn()
