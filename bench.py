@@ -5,6 +5,8 @@ updates) of the CIFAR-10-shaped 32x32 DCGAN-SN at batch 64 per GPU (BASELINE.jso
 synthetic data resident in HBM.
 
     python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus N --steps K --warmup W          (no launcher: re-executes itself under torch.distributed.run,
+                                                            one rank per GPU, loopback rendezvous on a free port)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -47,12 +49,15 @@ def parse():
                     help='the timed region (exactly --steps steps between barriers) is run this many times; the line reports '
                          'the MEDIAN region and every region\'s ms/step (SURVEY 8(d): median of 5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--cpu-steps', type=int, default=5, help='timed CPU steps at the best thread count (at least 5)')
     ap.add_argument('--probe-only', action='store_true',
                     help='one step, then only the dominant-kernel probe (for rocprofv3: its kernel stats row is then '
                          'exactly the launches that roofline.dominant_kernel times)')
     ap.add_argument('--probe-reps', type=int, default=20)
     ap.add_argument('--probe-warm', type=int, default=400, help='untimed launches before the timed ones of --probe-only')
+    ap.add_argument('--rendezvous-only', action='store_true',
+                    help='bring the process group up (RCCL on GPUs, gloo without), all-reduce one number, print one JSON line '
+                         'and stop: what the launch path of --gpus N can be checked with on a box without N GPUs')
     ap.add_argument('--engine', default='auto', choices=['auto', 'tape'],
                     help="'tape': run a DCGAN config on the primitive-op engine too (it is what residual-block configs use)")
     args = ap.parse_args()
@@ -187,13 +192,14 @@ def cpu_model():
     return platform.processor() or 'unknown'
 
 
-def cpu_baseline(arch, lr, loss, B, steps, budget_s=45.0):
+def cpu_baseline(arch, lr, loss, B, steps, budget_s=60.0):
     """the oracle restatement (fp32 torch-CPU) of the same step on the host cores ("N = all host cores and
     N = 1, core count and CPU model printed"): a reported baseline, not the optimisation target.  A batch of 64 32x32
     images does not scale over torch-CPU's thread pool (128 threads measured SLOWER than one), so "all cores" alone is
-    not a baseline: the step is timed at threads in {1, 8, 16, 32, 64, all} - one un-warmed step each, cheapest first,
-    while the sample stays bounded (`budget_s`) - and `value` is the BEST of them over `steps` warmed steps, with the
-    count that gave it in `cores`; every count's rate is listed in `thread_sweep`."""
+    not a baseline: the step is timed at threads in {1, 8, 16, 32, 64, all} - one WARMED step each (a first step at a
+    new thread count pays oneDNN's primitive creation and the allocator: un-warmed sweeps picked different winners from
+    run to run), cheapest first, while the sample stays bounded (`budget_s`).  The best count then runs `steps` (>= 5)
+    more steps, each timed on its own: `value` is B over the MEDIAN step, `best` B over the fastest."""
     from oracle import restatement as R
     threads = torch.get_num_threads()
     rs = np.random.RandomState(1234)
@@ -201,15 +207,20 @@ def cpu_baseline(arch, lr, loss, B, steps, budget_s=45.0):
     z = torch.tensor(rs.randn(B, arch['code'][0][0]).astype(np.float32))
 
     def timed(n_threads, n_steps, warm):
+        """seconds of each of n_steps steps after `warm` untimed ones, and what the warm-up cost"""
         torch.set_num_threads(n_threads)
         try:
             gan = R.OracleGan(arch, loss, tuple(lr), dtype=torch.float32, seed=0)
+            t0 = time.perf_counter()
             for _ in range(warm):
                 gan.step(z, real)                       # warm-up (allocator, oneDNN primitive cache)
-            t0 = time.perf_counter()
+            t_warm = time.perf_counter() - t0
+            out = []
             for _ in range(n_steps):
+                t0 = time.perf_counter()
                 gan.step(z, real)
-            return time.perf_counter() - t0
+                out.append(time.perf_counter() - t0)
+            return out, t_warm
         finally:
             torch.set_num_threads(threads)
     what = 'G+D steps of the same %dx%d B=%d workload, oracle/restatement.py fp32 on torch-CPU' % (
@@ -221,19 +232,24 @@ def cpu_baseline(arch, lr, loss, B, steps, budget_s=45.0):
         if time.perf_counter() - t_start + 1.5 * last > budget_s and sweep:
             sweep[n] = None                              # not run: the sample would leave its bound
             continue
-        last = timed(n, 1, 0)
-        sweep[n] = B / last
+        t0 = time.perf_counter()
+        (dt1,), _ = timed(n, 1, 1)
+        last = time.perf_counter() - t0
+        sweep[n] = B / dt1
     best = max((n for n in sweep if sweep[n]), key=lambda n: sweep[n])
-    dt = timed(best, steps, 1)
-    sweep[best] = max(sweep[best], B * steps / dt)
-    return {'value': B * steps / dt, 'unit': 'images/sec', 'cores': best, 'kind': 'port', 'cpu_model': cpu_model(),
+    steps = max(5, steps)
+    per_step, _ = timed(best, steps, 1)
+    med = float(np.median(per_step))
+    return {'value': B / med, 'unit': 'images/sec', 'cores': best, 'kind': 'port', 'cpu_model': cpu_model(),
             'host_cpus': os.cpu_count(), 'torch_threads_default': threads,
-            'sample': '%d %s, %d threads = the best of the sweep (%.1f s); sweep = one un-warmed step per thread count'
-                      % (steps, what, best, dt),
+            'best': B / min(per_step), 'steps_ms': [round(t * 1e3, 1) for t in per_step],
+            'sample': '%d %s, each timed on its own after one warm step, %d threads = the best of the sweep; value = B / '
+                      'median step (%.3f s), best = B / fastest step; sweep = one warmed step per thread count'
+                      % (steps, what, best, med),
             'thread_sweep': {str(n): (None if v is None else round(v, 2)) for n, v in sorted(sweep.items())},
             'all_threads': None if sweep.get(threads) is None else {'value': sweep[threads], 'cores': threads},
             'single_thread': None if sweep.get(1) is None else {'value': sweep[1], 'unit': 'images/sec', 'cores': 1,
-                                                                 'sample': '1 %s, 1 thread, no warm-up' % what}}
+                                                                 'sample': '1 %s, 1 thread, after one warm step' % what}}
 
 
 def kernel_set_check(eng, config, loss, B):
@@ -258,14 +274,61 @@ def kernel_set_check(eng, config, loss, B):
             'differs_in': diff[:8] if diff else None, 'mmdgan_env': env}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher around it (the way the driver calls N = 1): the same command line
+    again under torch.distributed.run, one rank per GPU of this node, rendezvous over loopback on a port the kernel just
+    handed out.  The ranks inherit stdout, so rank 0's JSON line is this process's one line; the exit code is theirs."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')    # dmabuf IPC: what RCCL needs between the ranks of one node here
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
+    from mmdgan_hip import dist as mdist
+    mdist.pin_loopback(env)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def rendezvous_only(args, world, rank, local_rank):
+    """--rendezvous-only: the process group of an N-rank run comes up and carries one collective"""
+    import torch.distributed as dist
+    from mmdgan_hip import dist as mdist
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)                                        # gloo / RCCL banners go to stderr: stdout carries one line
+    gpu = torch.cuda.is_available() and torch.cuda.device_count() > local_rank
+    if gpu:
+        torch.cuda.set_device(local_rank)
+    group = mdist.init_process_group(local_rank, backend='nccl' if gpu else 'gloo')
+    t = torch.tensor([float(rank + 1)], device='cuda' if gpu else 'cpu')
+    dist.all_reduce(t, group=group)
+    ok = float(t.item()) == world * (world + 1) / 2
+    backend = dist.get_backend(group)
+    dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    if rank == 0:
+        print(json.dumps({'rendezvous': 'ok' if ok else 'wrong sum', 'n_gpus': world, 'asked': args.gpus,
+                          'backend': backend, 'sum': float(t.item())}), flush=True)
+    sys.exit(0 if ok else 1)
+
+
 def main():
     args = parse()
+    launched = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
+    if not launched and (args.gpus > 1 or os.environ.get('MMDGAN_DP_FORCE') == '1'):
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % args.gpus)
+        sys.exit('bench.py --gpus %d under a launcher that started %d rank(s): one rank per GPU' % (args.gpus, world))
+    if args.rendezvous_only:
+        rendezvous_only(args, world, rank, local_rank)
     torch.cuda.set_device(local_rank)
     group = None
     # stdout carries ONE JSON line.  RCCL prints a version banner to stdout when its first communicator comes up (rank 0), so
@@ -342,7 +405,8 @@ def main():
         # untimed: a few steps each way, keep the fastest launch mode (data-parallel: eager or plan, the slowest rank's
         # time decides so that every rank makes the same choice)
         modes = ('eager', 'plan') if (group is not None or tape) else ('eager', 'graph', 'plan')
-        for m in modes + modes:                          # two passes, the better one counts: one host hiccup must not pick the mode
+        passes = {m: [] for m in modes}
+        for m in modes + modes:                          # two passes: one host hiccup must not pick the mode
             eng.launch_mode = m
             for _ in range(10):
                 eng.step(real)
@@ -351,16 +415,23 @@ def main():
             for _ in range(60):                          # (25 steps under-measured the replay modes: a fixed ~1 ms start-up
                 eng.step(real)                           # per timed block - the same sequence at 100 steps: plan = eager)
             torch.cuda.synchronize()
-            trial[m] = min(trial.get(m, 1e9), (time.perf_counter() - t0) / 60)
+            passes[m].append((time.perf_counter() - t0) / 60)
         for m in modes:
             if group is not None:
                 import torch.distributed as dist
-                t = torch.tensor([trial[m]], device='cuda', dtype=torch.float64)
+                t = torch.tensor(passes[m], device='cuda', dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                trial[m] = float(t.item())
-        want = min(trial, key=trial.get)
+                passes[m] = [float(v) for v in t.tolist()]
+            trial[m] = min(passes[m])
+        # plan replay is ONE host call per step, eager issue ~90: where they tie on the GPU's clock (they do, to 0.2 %), the
+        # replay is the one a busy host cannot stretch - round 5's driver line had one region of five at +11 % under eager
+        # issue.  Another mode is taken only where it beats the plan by more than 1 % in BOTH passes.
+        want = 'plan'
+        better = [m for m in modes if m != 'plan' and all(a < 0.99 * b for a, b in zip(passes[m], passes['plan']))]
+        if better:
+            want = min(better, key=trial.get)
         if os.environ.get('BENCH_VERBOSE'):
-            print('launch-mode trial (ms/step):', {k: round(v * 1e3, 3) for k, v in trial.items()}, file=sys.stderr)
+            print('launch-mode trial (ms/step):', {k: [round(v * 1e3, 3) for v in vs] for k, vs in passes.items()}, file=sys.stderr)
     mode = want
     eng.launch_mode = mode
     for _ in range(3):                                   # capture / record outside the timed region
@@ -421,6 +492,7 @@ def main():
             'value': B * world * args.steps / dt, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
             'repeats': len(regions), 'ms_per_step_regions': [round(r[0] / args.steps * 1e3, 4) for r in regions],
+            'ms_per_step_min': round(min(r[0] for r in regions) / args.steps * 1e3, 4),
             'ms_per_step_spread': round((max(r[0] for r in regions) - min(r[0] for r in regions)) / args.steps * 1e3, 4),
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%s %dx%d %s, batch %d per GPU, %s loss, lr %g/%g, TF-Adam, one G+D step'

@@ -26,8 +26,14 @@ def init_process_group(local_rank=None, backend='nccl', **kwargs):
     stream does get a hardware queue of its own, but with it the same step measured 3.10 instead of 2.52 ms
     (tools/dp_probe.py, one rank) - the engine instead issues its collectives on a stream it picked itself."""
     import os
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    pin_loopback()
+    # pin the bootstrap to `lo` only for a rendezvous that IS this host's loopback: the address the launcher / user set, or the
+    # default taken here when nothing names one.  A caller that rendezvouses through init_method= / store= (possibly across
+    # hosts), or a job with more ranks than this node holds, is left alone.
+    elsewhere = ('init_method' in kwargs or 'store' in kwargs
+                 or int(os.environ.get('WORLD_SIZE', '1')) > int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1'))))
+    if not elsewhere:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        pin_loopback()
     if backend != 'nccl':
         tdist.init_process_group(backend, **kwargs)
         return tdist.group.WORLD

@@ -133,3 +133,41 @@ def test_one_node_rendezvous_is_pinned_to_loopback_by_default_only():
     assert mdist.pin_loopback(env) == ['GLOO_SOCKET_IFNAME'] and env['NCCL_SOCKET_IFNAME'] == 'eth0'
     env = {'MASTER_ADDR': '10.0.0.7'}
     assert mdist.pin_loopback(env) == [] and 'GLOO_SOCKET_IFNAME' not in env
+
+
+def test_bench_gpus_2_launches_itself_and_reaches_rendezvous():
+    """`python bench.py --gpus 2` with no launcher around it (the way the driver calls it): re-executes itself under
+    torch.distributed.run, both ranks meet (gloo here - no GPU) and carry one all-reduce; stdout is ONE JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--rendezvous-only'], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out == {'rendezvous': 'ok', 'n_gpus': 2, 'asked': 2, 'backend': 'gloo', 'sum': 3.0}
+
+
+def test_init_process_group_leaves_foreign_rendezvous_alone(monkeypatch):
+    """the loopback pin applies to a loopback rendezvous only - an init_method / store rendezvous (possibly on
+    another host) must not get GLOO/NCCL_SOCKET_IFNAME=lo"""
+    for k in ('MASTER_ADDR', 'GLOO_SOCKET_IFNAME', 'NCCL_SOCKET_IFNAME', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE'):
+        monkeypatch.delenv(k, raising=False)
+    seen = {}
+    monkeypatch.setattr(tdist, 'init_process_group', lambda backend, **kw: seen.update(backend=backend, **kw))
+    mdist.init_process_group(backend='gloo', init_method='tcp://10.1.2.3:29500', rank=0, world_size=2)
+    assert seen['init_method'].startswith('tcp://10.') and 'GLOO_SOCKET_IFNAME' not in os.environ and 'MASTER_ADDR' not in os.environ
+    monkeypatch.setenv('WORLD_SIZE', '16')
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '8')
+    monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
+    mdist.init_process_group(backend='gloo')
+    assert 'GLOO_SOCKET_IFNAME' not in os.environ
+    monkeypatch.setenv('WORLD_SIZE', '8')
+    mdist.init_process_group(backend='gloo')
+    assert os.environ.get('GLOO_SOCKET_IFNAME') == 'lo'
+    monkeypatch.delenv('GLOO_SOCKET_IFNAME')
+    monkeypatch.delenv('NCCL_SOCKET_IFNAME', raising=False)

@@ -64,3 +64,27 @@ def test_this_process_does_not_run_the_production_selection():
     assert os.environ.get('MMDGAN_WINO_MIN_TILES') == '32' and os.environ.get('MMDGAN_WINO2') == '2'
     out = shipped_step.run('cifar', 'rep', 8, 'plan', warm=2, check_grads=False)
     assert out['env'] != [] and out['launches'] > 50
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    """`MMDGAN_DP_FORCE=1 python bench.py --gpus 1` with no launcher: bench.py re-executes itself under
+    torch.distributed.run (the path `--gpus N` takes for N > 1), the one rank brings RCCL up, runs the data-parallel
+    step and prints ONE JSON line.  A box whose RCCL bootstrap never comes up skips (environment), as in test_step_gpu."""
+    import json
+    import subprocess
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    env = {k: v for k, v in os.environ.items()
+           if not k.startswith('MMDGAN_') and k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(MMDGAN_DP_FORCE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    try:
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '5', '--warmup', '5', '--repeats', '2',
+                            '--no-cpu-baseline', '--launch-mode', 'plan'], env=env, capture_output=True, text=True, timeout=300)
+    except subprocess.TimeoutExpired as e:
+        pytest.skip('bench.py under its own launcher did not finish in 300 s on this box (RCCL bootstrap): %r' % ((e.stderr or b'')[-300:],))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 1 and out['config']['parallelism'] == 'dp1' and out['config']['dp_backend'] in ('capi', 'torch'), out['config']
+    assert out['config']['exchange'] is not None and out['value'] > 0
