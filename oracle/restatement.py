@@ -501,13 +501,13 @@ def _act(x, name, mask=None, audit=None):
     where a pre-activation lies within rounding of zero.  An fp32 run of this oracle forced to an fp32 kernel's masks is the
     floor the kernel's gradients are measured against: what fp32 arithmetic loses against fp64 under the SAME decisions.
     audit (a list): receives, per forced activation, (how many decisions differ from this evaluation's own, the largest
-    |pre-activation| among those as a fraction of the layer's largest) - the caller's proof that the forced decisions differ
-    from the natural ones at knife edges only."""
+    |pre-activation| among those as a fraction of the layer's largest, the activation's element count) - the caller's proof
+    that the forced decisions differ from the natural ones at knife edges only."""
     if mask is not None and name in ('relu', 'lrelu'):
         if audit is not None:
             differ = (x > 0) != mask
             n = int(differ.sum())
-            audit.append((n, float(x.detach().abs()[differ].max() / x.detach().abs().max()) if n else 0.0))
+            audit.append((n, float(x.detach().abs()[differ].max() / x.detach().abs().max()) if n else 0.0, x.numel()))
         lo = 0.0 if name == 'relu' else LRELU_ALPHA
         return x * torch.where(mask, torch.ones((), dtype=x.dtype), torch.full((), lo, dtype=x.dtype))
     if name == 'linear':

@@ -77,6 +77,9 @@ def pytest_terminal_summary(terminalreporter):
         terminalreporter.write_line('  knife-edge retry: ' + what)
     # ... and how often a gradient needed the escape clause of helpers.assert_grads_within_fp32_floor (above the plain 1e-4 L2 /
     # 1e-3 entry-wise bars, inside twice the fp32 oracle's own loss)
+    terminalreporter.write_line('steps whose gradients were held against the audited fp64 evaluation: %d' % len(helpers.AUDITED_STEPS))
+    for what in helpers.AUDITED_STEPS:
+        terminalreporter.write_line('  audited step: ' + what)
     terminalreporter.write_line('gradient tensors that took the fp32-floor clause: %d' % len(helpers.FLOOR_CLAUSE_USES))
     for what in helpers.FLOOR_CLAUSE_USES:
         terminalreporter.write_line('  fp32-floor clause: ' + what)
