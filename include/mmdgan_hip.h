@@ -47,6 +47,14 @@ extern "C" {
  * produced from it (same dgrad flag as the call), for a geometry mmdgan_wino_eligible() accepts.  Lets a caller
  * whose weights change once per step transform them once, off the critical path, instead of inside every call. */
 #define MMDGAN_ACT_FLAG_W_WINOGRAD 0x200
+/* the same for a tensor mmdgan_wino_transform_algo(..., MMDGAN_WINO_F43, ...) produced: the call runs F(4x4,3x3)
+ * (geometry: mmdgan_wino_algo() == MMDGAN_WINO_F43).  One of the two flags, not both. */
+#define MMDGAN_ACT_FLAG_W_WINOGRAD43 0x400
+/* Winograd algorithms (mmdgan_wino_algo): which transformed-weight layout a geometry's call expects */
+#define MMDGAN_WINO_NONE 0
+#define MMDGAN_WINO_F23 1      /* F(2x2,3x3): 3x3 stride 1, 16 * C * K floats (csrc/conv_wino.hip) */
+#define MMDGAN_WINO_F22S2 2    /* F(2x2,2x2) on the 4 parity segments of 4x4 stride 2, 36 * C * K floats (csrc/conv_wino2.hip) */
+#define MMDGAN_WINO_F43 3      /* F(4x4,3x3): 3x3 stride 1 with H, W multiples of 4, 36 * C * K floats (csrc/conv_wino43.hip) */
 
 /* loss enum - math_func.py:2644-2647 */
 #define MMDGAN_LOSS_REP 0
@@ -68,9 +76,10 @@ extern "C" {
 const char *mmdgan_last_error(void);
 /* ABI version of this header: bumped whenever an entry's argument list, a workspace size or a calling rule changes
  * (200: rounds 1-4 - although mmdgan_bn_bwd gained `beta` and mmdgan_bn_workspace_bytes grew in round 4 without a bump;
- * 500: round 5 - mmdgan_wgrad_defer / mmdgan_wgrad_flush, BN workspace documented as [slots][2][C]).  A caller compares
+ * 500: round 5 - mmdgan_wgrad_defer / mmdgan_wgrad_flush, BN workspace documented as [slots][2][C];
+ * 600: round 6 - mmdgan_wino_algo / _algo_weight_bytes / _transform_algo, mmdgan_wino_job.algo, MMDGAN_ACT_FLAG_W_WINOGRAD43).  A caller compares
  * mmdgan_version() of the library it loaded with the MMDGAN_VERSION it was built against (mmdgan_hip/_lib.py does). */
-#define MMDGAN_VERSION 500
+#define MMDGAN_VERSION 600
 int mmdgan_version(void);
 /* Which kernel a convolution call takes is decided by the geometry and by a handful of process-wide switches (environment
  * variables MMDGAN_*, read once: csrc/tuning.h lists them with their defaults - the defaults are the configuration the
@@ -257,6 +266,16 @@ int mmdgan_conv2d_wgrad_sn(const mmdgan_conv_geom *g, const float *x, const floa
 int mmdgan_wino_eligible(const mmdgan_conv_geom *g, int dgrad);
 size_t mmdgan_wino_weight_bytes(const mmdgan_conv_geom *g);
 int mmdgan_wino_transform(const mmdgan_conv_geom *g, const float *w, int dgrad, float *u, void *stream);
+/* Round 6: a 3x3 / stride-1 geometry whose H and W are multiples of 4 can run F(4x4,3x3) (36 instead of 64 multiplies per
+ * 4x4 outputs; layer_func.py:912-916) - another transformed-weight layout, so the caller says which one it holds:
+ *   mmdgan_wino_algo(g, dgrad)                   MMDGAN_WINO_* the library prefers for conv2d_fwd / conv2d_dgrad of g
+ *   mmdgan_wino_algo_weight_bytes(g, algo)       size of that algorithm's transformed tensor (0: algo does not fit g's kernel)
+ *   mmdgan_wino_transform_algo(g, w, dgrad, algo, u)
+ * and pass u as `w` with MMDGAN_ACT_FLAG_W_WINOGRAD (F23, F22S2) or MMDGAN_ACT_FLAG_W_WINOGRAD43 (F43).  The three entries
+ * above keep their meaning (F23 for 3x3, F22S2 for 4x4 stride 2). */
+int mmdgan_wino_algo(const mmdgan_conv_geom *g, int dgrad);
+size_t mmdgan_wino_algo_weight_bytes(const mmdgan_conv_geom *g, int algo);
+int mmdgan_wino_transform_algo(const mmdgan_conv_geom *g, const float *w, int dgrad, int algo, float *u, void *stream);
 /* the same transform for MANY kernels in one launch (a training step re-transforms every eligible kernel of a network after
  * each weight update: one dispatch instead of one per kernel and form).  jobs is a HOST array, read during the call. */
 typedef struct mmdgan_wino_job {
@@ -264,6 +283,7 @@ typedef struct mmdgan_wino_job {
     float *u;            /* mmdgan_wino_weight_bytes() of the geometry */
     int C, K, R, stride; /* R = 3 / stride 1 or R = 4 / stride 2 */
     int dgrad;           /* 0: forward form, 1: input-gradient form */
+    int algo;            /* MMDGAN_WINO_* (0 = the default of the kernel size: F23 for 3x3, F22S2 for 4x4 stride 2) */
 } mmdgan_wino_job;
 int mmdgan_wino_transform_multi(const mmdgan_wino_job *jobs, int n_jobs, void *stream);
 

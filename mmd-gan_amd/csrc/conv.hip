@@ -82,8 +82,10 @@ static int conv2d_fwd_impl(const mmdgan_conv_geom *g, const float *x, const floa
     if (int rc = validate(g, "conv2d_fwd")) return rc;
     MMDGAN_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
     const bool out_zeroed = (act & MMDGAN_ACT_FLAG_OUT_ZEROED) != 0, w_wino = (act & MMDGAN_ACT_FLAG_W_WINOGRAD) != 0;
-    act &= ~(MMDGAN_ACT_FLAG_OUT_ZEROED | MMDGAN_ACT_FLAG_W_WINOGRAD);
+    const bool w_wino43 = (act & MMDGAN_ACT_FLAG_W_WINOGRAD43) != 0;
+    act &= ~(MMDGAN_ACT_FLAG_OUT_ZEROED | MMDGAN_ACT_FLAG_W_WINOGRAD | MMDGAN_ACT_FLAG_W_WINOGRAD43);
     MMDGAN_REQUIRE(act >= MMDGAN_ACT_LINEAR && act <= MMDGAN_ACT_TANH, "conv2d_fwd: unknown activation %d", act);
+    MMDGAN_REQUIRE(!(w_wino && w_wino43), "conv2d_fwd: MMDGAN_ACT_FLAG_W_WINOGRAD and MMDGAN_ACT_FLAG_W_WINOGRAD43 together");
     const ConvDims d = conv_dims(*g);
     long wf, ws;
     if (int rc = make_wrap(d.N, dact_of ? dact_batch : 0, (long)d.P * d.Q * d.K, "conv2d_fwd", &wf, &ws)) return rc;
@@ -93,7 +95,13 @@ static int conv2d_fwd_impl(const mmdgan_conv_geom *g, const float *x, const floa
                        "conv2d_fwd: MMDGAN_ACT_FLAG_W_WINOGRAD on a geometry mmdgan_wino_eligible() rejects");
         return d.R == 3 ? wino_fwd(d, ep, x, nullptr, w, y, (hipStream_t)stream) : wino2_fwd(d, ep, x, nullptr, w, y, (hipStream_t)stream);
     }
+    if (w_wino43) {
+        MMDGAN_REQUIRE(wino43_eligible(d, false), "conv2d_fwd: MMDGAN_ACT_FLAG_W_WINOGRAD43 on a geometry whose mmdgan_wino_algo() is not MMDGAN_WINO_F43");
+        return wino43_fwd(d, ep, x, nullptr, w, y, (hipStream_t)stream);
+    }
     if (generic_only(d)) return direct_fwd(d, ep, x, w, y, (hipStream_t)stream);
+    if (!force_direct() && wino43_eligible(d, false) && workspace(sizeof(float) * 36 * (size_t)d.C * d.K))
+        return wino43_fwd(d, ep, x, w, nullptr, y, (hipStream_t)stream);
     if (!force_direct() && wino2_fwd_ok(d)) return wino2_fwd(d, ep, x, w, nullptr, y, (hipStream_t)stream);
     if (!force_direct() && wino_fwd_ok(d)) return wino_fwd(d, ep, x, w, nullptr, y, (hipStream_t)stream);
     if (!force_direct() && igemm_fwd_ok(d)) return igemm_fwd(d, ep, x, w, y, (hipStream_t)stream);
@@ -152,8 +160,10 @@ static int conv2d_dgrad_impl(const mmdgan_conv_geom *g, const float *dy, const f
     if (int rc = validate(g, "conv2d_dgrad")) return rc;
     MMDGAN_REQUIRE(dy && w && dx, "conv2d_dgrad: null pointer");
     const bool out_zeroed = (act & MMDGAN_ACT_FLAG_OUT_ZEROED) != 0, w_wino = (act & MMDGAN_ACT_FLAG_W_WINOGRAD) != 0;
-    act &= ~(MMDGAN_ACT_FLAG_OUT_ZEROED | MMDGAN_ACT_FLAG_W_WINOGRAD);
+    const bool w_wino43 = (act & MMDGAN_ACT_FLAG_W_WINOGRAD43) != 0;
+    act &= ~(MMDGAN_ACT_FLAG_OUT_ZEROED | MMDGAN_ACT_FLAG_W_WINOGRAD | MMDGAN_ACT_FLAG_W_WINOGRAD43);
     MMDGAN_REQUIRE(act >= MMDGAN_ACT_LINEAR && act <= MMDGAN_ACT_TANH, "conv2d_dgrad: unknown activation %d", act);
+    MMDGAN_REQUIRE(!(w_wino && w_wino43), "conv2d_dgrad: MMDGAN_ACT_FLAG_W_WINOGRAD and MMDGAN_ACT_FLAG_W_WINOGRAD43 together");
     const ConvDims d = conv_dims(*g);
     long wf, ws;
     if (int rc = make_wrap(d.N, dact_of ? dact_batch : 0, (long)d.H * d.W * d.C, "conv2d_dgrad", &wf, &ws)) return rc;
@@ -163,7 +173,13 @@ static int conv2d_dgrad_impl(const mmdgan_conv_geom *g, const float *dy, const f
                        "conv2d_dgrad: MMDGAN_ACT_FLAG_W_WINOGRAD on a geometry mmdgan_wino_eligible() rejects");
         return d.R == 3 ? wino_dgrad(d, ep, dy, nullptr, w, dx, (hipStream_t)stream) : wino2_dgrad(d, ep, dy, nullptr, w, dx, (hipStream_t)stream);
     }
+    if (w_wino43) {
+        MMDGAN_REQUIRE(wino43_eligible(d, true), "conv2d_dgrad: MMDGAN_ACT_FLAG_W_WINOGRAD43 on a geometry whose mmdgan_wino_algo() is not MMDGAN_WINO_F43");
+        return wino43_dgrad(d, ep, dy, nullptr, w, dx, (hipStream_t)stream);
+    }
     if (generic_only(d)) return direct_dgrad(d, ep, dy, w, dx, (hipStream_t)stream);
+    if (!force_direct() && wino43_eligible(d, true) && workspace(sizeof(float) * 36 * (size_t)d.C * d.K))
+        return wino43_dgrad(d, ep, dy, w, nullptr, dx, (hipStream_t)stream);
     if (!force_direct() && wino2_dgrad_ok(d)) return wino2_dgrad(d, ep, dy, w, nullptr, dx, (hipStream_t)stream);
     if (!force_direct() && wino_dgrad_ok(d)) return wino_dgrad(d, ep, dy, w, nullptr, dx, (hipStream_t)stream);
     if (!force_direct() && igemm_dgrad_ok(d)) return igemm_dgrad(d, ep, dy, w, dx, (hipStream_t)stream);
@@ -178,7 +194,38 @@ static int conv2d_dgrad_impl(const mmdgan_conv_geom *g, const float *dy, const f
 extern "C" int mmdgan_wino_eligible(const mmdgan_conv_geom *g, int dgrad) {
     if (!g || g->N < 1 || g->H < 1 || g->W < 1 || g->C < 1 || g->K < 1 || g->R < 1 || g->stride < 1) return 0;
     const ConvDims d = conv_dims(*g);
-    return !force_direct() && (wino_eligible(d, dgrad != 0) || wino2_eligible(d, dgrad != 0)) ? 1 : 0;
+    return !force_direct() && (wino_eligible(d, dgrad != 0) || wino2_eligible(d, dgrad != 0) || wino43_eligible(d, dgrad != 0)) ? 1 : 0;
+}
+
+extern "C" int mmdgan_wino_algo(const mmdgan_conv_geom *g, int dgrad) {
+    if (!g || g->N < 1 || g->H < 1 || g->W < 1 || g->C < 1 || g->K < 1 || g->R < 1 || g->stride < 1 || force_direct()) return MMDGAN_WINO_NONE;
+    const ConvDims d = conv_dims(*g);
+    if (wino43_eligible(d, dgrad != 0)) return MMDGAN_WINO_F43;
+    if (wino_eligible(d, dgrad != 0)) return MMDGAN_WINO_F23;
+    if (wino2_eligible(d, dgrad != 0)) return MMDGAN_WINO_F22S2;
+    return MMDGAN_WINO_NONE;
+}
+
+extern "C" size_t mmdgan_wino_algo_weight_bytes(const mmdgan_conv_geom *g, int algo) {
+    if (!g) return 0;
+    const size_t ck = sizeof(float) * (size_t)g->C * g->K;
+    if (algo == MMDGAN_WINO_F23) return g->R == 3 ? 16 * ck : 0;
+    if (algo == MMDGAN_WINO_F43) return g->R == 3 ? 36 * ck : 0;
+    if (algo == MMDGAN_WINO_F22S2) return g->R == 4 ? 36 * ck : 0;
+    return 0;
+}
+
+extern "C" int mmdgan_wino_transform_algo(const mmdgan_conv_geom *g, const float *w, int dgrad, int algo, float *u, void *stream) {
+    if (algo != MMDGAN_WINO_F43) {
+        MMDGAN_REQUIRE(g && ((algo == MMDGAN_WINO_F23 && g->R == 3) || (algo == MMDGAN_WINO_F22S2 && g->R == 4) || algo == MMDGAN_WINO_NONE),
+                       "wino_transform_algo: algorithm %d does not fit the kernel size", algo);
+        return mmdgan_wino_transform(g, w, dgrad, u, stream);
+    }
+    if (int rc = validate(g, "wino_transform_algo")) return rc;
+    MMDGAN_REQUIRE(w && u, "wino_transform_algo: null pointer");
+    MMDGAN_REQUIRE(g->R == 3 && g->stride == 1, "wino_transform_algo: F(4x4,3x3) is for 3x3 stride-1 kernels (got %dx%d stride %d)", g->R, g->R,
+                   g->stride);
+    return wino43_transform(conv_dims(*g), w, dgrad != 0, u, (hipStream_t)stream);
 }
 
 extern "C" size_t mmdgan_wino_weight_bytes(const mmdgan_conv_geom *g) {

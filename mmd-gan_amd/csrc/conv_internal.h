@@ -89,6 +89,12 @@ int wino_transform(const ConvDims &d, const float *w, bool flip, float *U, hipSt
 int wino_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, const float *U, float *y, hipStream_t st);
 int wino_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, const float *U, float *dx, hipStream_t st);
 
+// Winograd F(4x4,3x3) for the same layers where H and W are multiples of 4 (conv_wino43.hip); U = 36 * C * K floats
+bool wino43_eligible(const ConvDims &d, bool dgrad);
+int wino43_transform(const ConvDims &d, const float *w, bool flip, float *U, hipStream_t st);
+int wino43_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, const float *U, float *y, hipStream_t st);
+int wino43_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, const float *U, float *dx, hipStream_t st);
+
 // in-place bias / activation / activation-derivative pass after a split-reduction launch (conv_wino.hip)
 int epilogue_pass(float *y, long total, int Ko, const ConvEpilogue &ep, hipStream_t st);
 bool wino_wgrad_ok(const ConvDims &d);

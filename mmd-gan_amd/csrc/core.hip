@@ -187,6 +187,8 @@ extern "C" long mmdgan_tuning_describe(char *buf, size_t cap) {
     add("wino2_ksplit", t.wino2_ksplit, d.wino2_ksplit); add("wino2_ksplit_below", t.wino2_ksplit_below, d.wino2_ksplit_below);
     add("wino2_wgrad", t.wino2_wgrad, d.wino2_wgrad); add("wino2_wgrad_min_tiles", t.wino2_wgrad_min_tiles, d.wino2_wgrad_min_tiles);
     add("wgrad_cus", t.wgrad_cus, d.wgrad_cus); add("gemm_skinny", t.gemm_skinny, d.gemm_skinny); add("gemm_panel", t.gemm_panel, d.gemm_panel); add("mmd_d16", t.mmd_d16, d.mmd_d16);
+    add("wino43", t.wino43, d.wino43); add("wino43_min_tiles", t.wino43_min_tiles, d.wino43_min_tiles);
+    add("wino43_ksplit_below", t.wino43_ksplit_below, d.wino43_ksplit_below);
     if (buf && cap > 0) {
         const size_t n = out.size() < cap - 1 ? out.size() : cap - 1;
         memcpy(buf, out.data(), n);

@@ -27,10 +27,13 @@ struct Tuning {
     int gemm_skinny;             // MMDGAN_GEMM_SKINNY=0         D's head product on the tiled kernel, not the skinny-N MFMA one
     int mmd_d16;               // MMDGAN_MMD_D16=0             the pairwise loss with d = 16 on the run-time-d instantiation of its kernel
     int gemm_panel;              // MMDGAN_GEMM_PANEL=0          short-K dense products (G's first layer, the dense weight gradients) on the tiled kernel
+    int wino43;                  // MMDGAN_WINO43=0|1|2          F(4x4,3x3) for 3x3 stride-1 (H, W multiples of 4): never | from wino43_min_tiles on (default) | every eligible shape
+    long wino43_min_tiles;       // MMDGAN_WINO43_MIN_TILES=n    ... from n 4x4 tiles on (128)
+    long wino43_ksplit_below;    // MMDGAN_WINO43_KSPLIT_BELOW=n its reduction split over workspace slabs for grids below n workgroups (256)
 };
 
 inline const Tuning &tuning_defaults() {
-    static const Tuning d = {0, 0, 1, -1, 385, 1, 1, 1, 1, 384, 1, 256, 224, 1, 1, 1};
+    static const Tuning d = {0, 0, 1, -1, 385, 1, 1, 1, 1, 384, 1, 256, 224, 1, 1, 1, 1, 128, 256};
     return d;
 }
 
@@ -56,6 +59,9 @@ inline const Tuning &tuning() {
         v.gemm_skinny = geti("MMDGAN_GEMM_SKINNY", v.gemm_skinny) != 0;
         v.gemm_panel = geti("MMDGAN_GEMM_PANEL", v.gemm_panel) != 0;
         v.mmd_d16 = geti("MMDGAN_MMD_D16", v.mmd_d16) != 0;
+        v.wino43 = geti("MMDGAN_WINO43", v.wino43);
+        v.wino43_min_tiles = getl("MMDGAN_WINO43_MIN_TILES", v.wino43_min_tiles);
+        v.wino43_ksplit_below = getl("MMDGAN_WINO43_KSPLIT_BELOW", v.wino43_ksplit_below);
         return v;
     }();
     return t;

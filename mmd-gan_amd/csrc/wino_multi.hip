@@ -11,7 +11,7 @@ struct WinoJobTable {
     const float *w[kWinoJobsMax];
     float *u[kWinoJobsMax];
     int C[kWinoJobsMax], K[kWinoJobsMax];
-    unsigned char kind[kWinoJobsMax];            // bit 0: input-gradient form, bit 1: 4x4 stride 2 (else 3x3)
+    unsigned char kind[kWinoJobsMax];            // bit 0: input-gradient form, bit 1: 4x4 stride 2 (else 3x3), bit 2: 3x3 as F(4x4,3x3)
     unsigned first_block[kWinoJobsMax + 1];      // prefix sums of the jobs' workgroup counts
     int n;
 };
@@ -27,7 +27,9 @@ __global__ __launch_bounds__(256) void wino_weight_multi_kernel(WinoJobTable t) 
     case 0: wino_weight_block<false>(tile, bx, by, t.w[j], t.u[j], C, K); break;
     case 1: wino_weight_block<true>(tile, bx, by, t.w[j], t.u[j], C, K); break;
     case 2: wino2_weight_block<false>(tile, bx, by, bz, t.w[j], t.u[j], C, K); break;
-    default: wino2_weight_block<true>(tile, bx, by, bz, t.w[j], t.u[j], C, K); break;
+    case 3: wino2_weight_block<true>(tile, bx, by, bz, t.w[j], t.u[j], C, K); break;
+    case 4: wino43_weight_block<false>(tile, bx, by, t.w[j], t.u[j], C, K); break;
+    default: wino43_weight_block<true>(tile, bx, by, t.w[j], t.u[j], C, K); break;
     }
 }
 
@@ -48,6 +50,12 @@ extern "C" int mmdgan_wino_transform_multi(const mmdgan_wino_job *jobs, int n_jo
             MMDGAN_REQUIRE((jb.R == 3 && jb.stride == 1) || (jb.R == 4 && jb.stride == 2),
                            "wino_transform_multi: job %d: 3x3 stride 1 or 4x4 stride 2 kernels only (got %dx%d stride %d)", i0 + i, jb.R,
                            jb.R, jb.stride);
+            const bool f43 = jb.algo == MMDGAN_WINO_F43;
+            MMDGAN_REQUIRE(jb.algo == MMDGAN_WINO_NONE || (jb.algo == MMDGAN_WINO_F23 && jb.R == 3) || (jb.algo == MMDGAN_WINO_F22S2 && jb.R == 4) ||
+                           (f43 && jb.R == 3), "wino_transform_multi: job %d: algorithm %d does not fit a %dx%d kernel", i0 + i, jb.algo, jb.R, jb.R);
+            if (f43)
+                MMDGAN_REQUIRE((jb.dgrad ? jb.K : jb.C) % 8 == 0 && (jb.dgrad ? jb.C : jb.K) % 32 == 0,
+                               "wino_transform_multi: job %d (F(4x4,3x3)): reduction-side channels must be a multiple of 8, output-side of 32", i0 + i);
             if (jb.R == 3)
                 MMDGAN_REQUIRE((jb.dgrad ? jb.K : jb.C) % 8 == 0,
                                "wino_transform_multi: job %d (3x3): the reduction-side channel count must be a multiple of 8", i0 + i);
@@ -55,7 +63,7 @@ extern "C" int mmdgan_wino_transform_multi(const mmdgan_wino_job *jobs, int n_jo
                 MMDGAN_REQUIRE(jb.C % 32 == 0 && jb.K % 32 == 0, "wino_transform_multi: job %d (4x4 stride 2): C and K must be multiples of 32",
                                i0 + i);
             t.w[i] = jb.w; t.u[i] = jb.u; t.C[i] = jb.C; t.K[i] = jb.K;
-            t.kind[i] = (unsigned char)((jb.dgrad ? 1 : 0) | (jb.R == 4 ? 2 : 0));
+            t.kind[i] = (unsigned char)((jb.dgrad ? 1 : 0) | (jb.R == 4 ? 2 : 0) | (f43 ? 4 : 0));
             t.first_block[i] = blocks;
             blocks += (unsigned)((jb.K + 31) / 32) * (unsigned)((jb.C + 31) / 32) * (jb.R == 4 ? 4u : 1u);
         }

@@ -115,4 +115,78 @@ __device__ __forceinline__ void wino_weight_block(float (*tile)[32][33], int bx,
     }
 }
 
+// ---- F(4x4,3x3) (conv_wino43.hip)
+// U[f][cr / 8][kh][ko][kp] = (G g G^T)[f], f = 6 i + j, with g = w[.][.][c][k] (cr = c, ko = k)            FLIP = false
+//                                                       or g = w[2-.][2-.][c][k] read as (cr = k, ko = c)  FLIP = true
+// where channel cr of its 8-channel stage sits on k half kh = (cr >> 1) & 1, k-pair kp = (cr & 1) + 2 * ((cr >> 2) & 1): the
+// channel pairs (0,1), (2,3), (4,5), (6,7) are the halves of the producers' 16-byte loads and one 8-byte store of V each
+// (conv_wino43.hip) - any one-to-one map of a stage's channels onto the MFMA's reduction index works as long as both operands use it.
+// G = [1 0 0; 1/3 1/3 1/3; -1/3 1/3 -1/3; -16/15 -8/15 -4/15; 1/15 -2/15 4/15; 0 0 1].
+// One workgroup of 256 threads = one 32 x 32 block of (c, k); the 36 frequencies go through 9 LDS planes in four passes.
+template <bool FLIP>
+__device__ __forceinline__ void wino43_weight_block(float (*tile)[32][33], int bx, int by, const float *__restrict__ w,
+                                                    float *__restrict__ U, int C, int K) {
+    const int c0 = by * 32, k0 = bx * 32;
+    const int tk = threadIdx.x & 31, tq = threadIdx.x >> 5;
+    const int Cr = FLIP ? K : C, Ko = FLIP ? C : K, cr0 = FLIP ? k0 : c0, ko0 = FLIP ? c0 : k0;
+    for (int pass = 0; pass < 4; ++pass) {
+        for (int cc = tq; cc < 32; cc += 8) {
+            const int c = c0 + cc, k = k0 + tk;
+            const bool ok = c < C && k < K;
+            float g[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    g[r][t] = ok ? w[((size_t)((FLIP ? 2 - r : r) * 3 + (FLIP ? 2 - t : t)) * C + c) * K + k] : 0.f;
+            float gg[6][3], u[6][6];
+            const float c13 = 1.f / 3.f, c115 = 1.f / 15.f;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                gg[0][t] = g[0][t];
+                gg[1][t] = c13 * (g[0][t] + g[1][t] + g[2][t]);
+                gg[2][t] = c13 * (g[1][t] - g[0][t] - g[2][t]);
+                gg[3][t] = -4.f * c115 * (4.f * g[0][t] + 2.f * g[1][t] + g[2][t]);
+                gg[4][t] = c115 * (g[0][t] - 2.f * g[1][t] + 4.f * g[2][t]);
+                gg[5][t] = g[2][t];
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                u[i][0] = gg[i][0];
+                u[i][1] = c13 * (gg[i][0] + gg[i][1] + gg[i][2]);
+                u[i][2] = c13 * (gg[i][1] - gg[i][0] - gg[i][2]);
+                u[i][3] = -4.f * c115 * (4.f * gg[i][0] + 2.f * gg[i][1] + gg[i][2]);
+                u[i][4] = c115 * (gg[i][0] - 2.f * gg[i][1] + 4.f * gg[i][2]);
+                u[i][5] = gg[i][2];
+            }
+#pragma unroll
+            for (int f = 0; f < 9; ++f) {
+                float v = 0.f;
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    if (p == pass) v = u[(9 * p + f) / 6][(9 * p + f) % 6];
+                tile[f][cc][tk] = v;
+            }
+        }
+        __syncthreads();
+        // thread = (output channel of the block tk, channel group of the block tq >> 1, k half tq & 1)
+        const int g8 = tq >> 1, kh = tq & 1;
+        const bool st_ok = cr0 + g8 * 8 < Cr && ko0 + tk < Ko;
+#pragma unroll
+        for (int f = 0; f < 9; ++f) {
+            if (!st_ok) break;
+            float4 v;
+            float *pv = reinterpret_cast<float *>(&v);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int crl = g8 * 8 + (q & 1) + 2 * kh + 4 * (q >> 1);
+                pv[q] = FLIP ? tile[f][tk][crl] : tile[f][crl][tk];
+            }
+            const size_t row = (((size_t)(pass * 9 + f)) * (Cr >> 3) + (cr0 >> 3) + g8) * 2 + kh;
+            *reinterpret_cast<float4 *>(U + (row * Ko + ko0 + tk) * 4) = v;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace mmdgan

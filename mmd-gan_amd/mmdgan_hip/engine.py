@@ -661,12 +661,11 @@ class GanEngine:
                     c, h, w = s.out, s.in_shape_ref[1] * s.stride, s.in_shape_ref[2] * s.stride
                 else:
                     continue
-                fw = ops.wino_eligible(nf, h, w, c, k, s.R, s.stride, False)
-                bw = ops.wino_eligible(nb, h, w, c, k, s.R, s.stride, True)
+                fw = ops.wino_algo(nf, h, w, c, k, s.R, s.stride, False)     # F(2x2,3x3) / F(4x4,3x3) / F(2x2,2x2) on 4 parity
+                bw = ops.wino_algo(nb, h, w, c, k, s.R, s.stride, True)      # segments: each with its own weight layout
                 if fw or bw:
-                    lead = (16,) if s.R == 3 else (4, 9)     # F(2x2,3x3) / F(2x2,2x2) on 4 parity segments
-                    self._wino[s.scope] = [torch.empty(lead + (c, k), device=dev) if fw else None,
-                                           torch.empty(lead + (k, c), device=dev) if bw else None, net]
+                    self._wino[s.scope] = [ops.wino_alloc(fw, c, k, False, dev) if fw else None,
+                                           ops.wino_alloc(bw, c, k, True, dev) if bw else None, net]
         self._wino_jobs = [ops.WinoTransforms([(net.p(scope + '/kernel/kernel'), u, dg) for scope, (uf, ub, net) in self._wino.items()
                                                if net is which for u, dg in ((uf, False), (ub, True)) if u is not None])
                            for which in (self.gen, self.dis)]
@@ -760,7 +759,7 @@ class GanEngine:
         if key not in self._wino_ok:
             c, h, w = s.in_shape_ref
             self._wino_ok[key] = s.scope in self._wino and self._wino[s.scope][0] is not None and \
-                ops.wino_eligible(n, h, w, c, s.out, s.R, s.stride, False)
+                ops.wino_algo(n, h, w, c, s.out, s.R, s.stride, False) == ops.wino_kind(self._wino[s.scope][0])
         return self._wino_ok[key]
 
     def generate(self, z, is_training=False):

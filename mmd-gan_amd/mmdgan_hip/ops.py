@@ -238,7 +238,7 @@ def conv2d_fwd(x, w, stride, bias=None, scale=None, act='linear', dact_of=None, 
     P, Q = out_hw(H, W, stride)
     y = out if out is not None else torch.empty((N, P, Q, K), device=x.device, dtype=torch.float32)
     g = geom(N, H, W, C, K, R, stride)
-    flags = act_id(act) | (0x100 if out_zeroed else 0) | (0 if wino is None else 0x200)
+    flags = act_id(act) | (0x100 if out_zeroed else 0) | wino_flag(wino)
     if bn_totals is not None:          # + the batch-norm totals of y (mmdgan_conv2d_fwd_stats; bn_fwd_train(have_totals=True) follows)
         assert addend is None and dact_of is None
         check(lib.mmdgan_conv2d_fwd_stats(ctypes.byref(g), _p(x), _p(w if wino is None else wino), _p(bias), _p(scale), flags, _p(y),
@@ -267,7 +267,7 @@ def conv2d_dgrad(dy, w, in_hw, stride, bias=None, scale=None, act='linear', dact
     assert out_hw(H, W, stride) == (P, Q)
     dx = out if out is not None else torch.empty((N, H, W, C), device=dy.device, dtype=torch.float32)
     g = geom(N, H, W, C, K, R, stride)
-    flags = act_id(act) | (0x100 if out_zeroed else 0) | (0 if wino is None else 0x200)
+    flags = act_id(act) | (0x100 if out_zeroed else 0) | wino_flag(wino)
     if bn_totals is not None:                            # + the batch-norm totals of dx (mmdgan_conv2d_dgrad_stats)
         assert addend is None and dact_of is None
         check(lib.mmdgan_conv2d_dgrad_stats(ctypes.byref(g), _p(dy), _p(w if wino is None else wino), _p(bias), _p(scale), flags,
@@ -283,27 +283,56 @@ def conv2d_dgrad(dy, w, in_hw, stride, bias=None, scale=None, act='linear', dact
     return dx
 
 
+WINO_NONE, WINO_F23, WINO_F22S2, WINO_F43 = 0, 1, 2, 3      # include/mmdgan_hip.h: MMDGAN_WINO_*
+_WINO_LEAD = {WINO_F23: (16,), WINO_F22S2: (4, 9), WINO_F43: (36,)}
+
+
 def wino_eligible(N, H, W, C, K, R, stride, dgrad):
-    """does conv2d_fwd (dgrad=False) / conv2d_dgrad (True) of this geometry run Winograd F(2x2,3x3)?"""
+    """does conv2d_fwd (dgrad=False) / conv2d_dgrad (True) of this geometry run one of the Winograd kernels?"""
     g = geom(N, H, W, C, K, R, stride)
     return bool(require_device().mmdgan_wino_eligible(ctypes.byref(g), int(dgrad)))
 
 
-def wino_transform(w, dgrad, out=None):
-    """w [3,3,C,K] -> [16,C,K] (forward) or [16,K,C] (input-gradient) transformed weights;
+def wino_algo(N, H, W, C, K, R, stride, dgrad):
+    """WHICH Winograd algorithm the library prefers for this geometry (mmdgan_wino_algo): WINO_NONE, WINO_F23 (F(2x2,3x3)),
+    WINO_F22S2 (4x4 stride 2) or WINO_F43 (F(4x4,3x3), H and W multiples of 4) - and with it the layout of the transformed
+    weights a call with `wino=` must hold"""
+    g = geom(N, H, W, C, K, R, stride)
+    return int(require_device().mmdgan_wino_algo(ctypes.byref(g), int(dgrad)))
+
+
+def wino_alloc(algo, C, K, dgrad, device):
+    """the (uninitialised) transformed-weight tensor of `algo` for a [R,R,C,K] kernel: [16 | 4,9 | 36] + (K,C if dgrad else C,K)"""
+    return torch.empty(_WINO_LEAD[algo] + ((K, C) if dgrad else (C, K)), device=device, dtype=torch.float32)
+
+
+def wino_kind(u):
+    """the algorithm a transformed-weight tensor belongs to, from its shape"""
+    return WINO_F22S2 if u.dim() == 4 else (WINO_F43 if u.shape[0] == 36 else WINO_F23)
+
+
+def wino_flag(wino):
+    """MMDGAN_ACT_FLAG_W_WINOGRAD / _W_WINOGRAD43 for a call that passes transformed weights"""
+    return 0 if wino is None else (0x400 if wino_kind(wino) == WINO_F43 else 0x200)
+
+
+def wino_transform(w, dgrad, out=None, algo=None):
+    """w [3,3,C,K] -> [16,C,K] (forward) or [16,K,C] (input-gradient) transformed weights, or [36,..] for algo=WINO_F43;
     w [4,4,C,K] (stride-2 layers) -> [4,9,C,K] or [4,9,K,C]"""
     lib = require_device()
     R, _, C, K = w.shape
-    lead = (16,) if R == 3 else (4, 9)
-    u = out if out is not None else torch.empty(lead + ((K, C) if dgrad else (C, K)), device=w.device, dtype=torch.float32)
+    if algo is None:
+        algo = wino_kind(out) if out is not None else (WINO_F23 if R == 3 else WINO_F22S2)
+    u = out if out is not None else wino_alloc(algo, C, K, dgrad, w.device)
+    assert wino_kind(u) == algo
     g = geom(1, 4, 4, C, K, R, 1 if R == 3 else 2)
-    check(lib.mmdgan_wino_transform(ctypes.byref(g), _p(w), int(dgrad), _p(u), _stream()), 'wino_transform')
+    check(lib.mmdgan_wino_transform_algo(ctypes.byref(g), _p(w), int(dgrad), int(algo), _p(u), _stream()), 'wino_transform')
     return u
 
 
 class WinoJob(ctypes.Structure):
     _fields_ = [('w', ctypes.c_void_p), ('u', ctypes.c_void_p), ('C', ctypes.c_int), ('K', ctypes.c_int), ('R', ctypes.c_int),
-                ('stride', ctypes.c_int), ('dgrad', ctypes.c_int)]
+                ('stride', ctypes.c_int), ('dgrad', ctypes.c_int), ('algo', ctypes.c_int)]
 
 
 class WinoTransforms:
@@ -316,6 +345,7 @@ class WinoTransforms:
         for j, (w, u, dgrad) in zip(self.table, self.keep):
             R, _, C, K = w.shape
             j.w, j.u, j.C, j.K, j.R, j.stride, j.dgrad = w.data_ptr(), u.data_ptr(), C, K, R, 1 if R == 3 else 2, int(bool(dgrad))
+            j.algo = wino_kind(u)
 
     def run(self, stream=None):
         if self.keep:

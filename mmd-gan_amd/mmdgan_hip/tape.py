@@ -683,16 +683,18 @@ class TapeEngine:
                     c, h, w, kout = k.out, k.out_ref[1], k.out_ref[2], k.in_ref[0]     # the layer's OUTPUT
                 table = {}
                 for dgrad in (False, True):
-                    u = None
-                    for n in batches:
+                    by_algo = {}                       # one transformed tensor per (direction, algorithm): F(4x4,3x3) and
+                    for n in batches:                  # F(2x2,3x3) lay the weights out differently (ops.wino_algo)
                         # the forward pass of a conv (= the backward pass of a tc layer) runs at one batch size only
                         single = (not dgrad) if as_conv else dgrad
-                        if (single and n != batches[0]) or not ops.wino_eligible(n, h, w, c, kout, R, stride, dgrad):
+                        if single and n != batches[0]:
                             continue
-                        if u is None:
-                            lead = (16,) if R == 3 else (4, 9)
-                            u = torch.empty(lead + ((kout, c) if dgrad else (c, kout)), device=self.device)
-                        table[(dgrad, n)] = u
+                        algo = ops.wino_algo(n, h, w, c, kout, R, stride, dgrad)
+                        if not algo:
+                            continue
+                        if algo not in by_algo:
+                            by_algo[algo] = ops.wino_alloc(algo, c, kout, dgrad, self.device)
+                        table[(dgrad, n)] = by_algo[algo]
                 if table:
                     self._wino[k.scope] = (net, k, table)
         # everything the backward pass accumulates into with atomics and that is not a gradient arena: one flat
@@ -1339,9 +1341,9 @@ class TapeEngine:
                 done = set()
                 src = self._folded[k.scope][0] if k.fold is not None else net.p(k.w_name)
                 for (dgrad, _), u in table.items():
-                    if dgrad not in done:
+                    if u.data_ptr() not in done:
                         jobs.append((src, u, dgrad))
-                        done.add(dgrad)
+                        done.add(u.data_ptr())
             self._wino_jobs[id(net)] = ops.WinoTransforms(jobs)
         self._wino_jobs[id(net)].run()
 

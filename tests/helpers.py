@@ -132,7 +132,7 @@ def note_knife_edge_retry(what, allowed=True):
 
 KNIFE_EDGE_MARGIN = 1e-5        # |pre-activation| / the layer's largest: fp32 sums land within ~1e-7 of the scale of their terms
 KNIFE_EDGE_MAX = 8              # decisions per step that may differ in a tiny net ...
-KNIFE_EDGE_PER_ELEMENT = 1e-5   # ... plus this share of the activations a step evaluates: a pre-activation of spread s = scale / 5
+KNIFE_EDGE_PER_ELEMENT = 2e-6   # ... plus this share of the activations a step evaluates: a pre-activation of spread s = scale / 5
 #                                 lies within d of zero with probability ~0.8 d / s = 4 d / scale; at fp32's d ~ 1e-6 of the scale
 #                                 that is 4 per million elements (a CIFAR step at batch 64 evaluates 34 M: ~140 expected).  The
 #                                 count is a plausibility bound only - what makes a differing decision legitimate is its MARGIN

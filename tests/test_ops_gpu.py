@@ -793,6 +793,89 @@ def test_conv2d_winograd_path(ops, case):
         ops.conv2d_fwd(nhwc(x), dev(np.zeros((5, 5, C, K), np.float32)), 1, wino=uf)
 
 
+W43_CASES = [(16, 16, 16, 128, 128, 3, 1), (32, 8, 8, 64, 128, 3, 1), (48, 4, 4, 256, 128, 3, 1), (9, 12, 12, 32, 64, 3, 1),
+             (6, 8, 12, 48, 96, 3, 1), (130, 4, 4, 64, 64, 3, 1), (6, 16, 16, 64, 32, 3, 1), (3, 24, 24, 128, 128, 3, 1)]
+
+
+@pytest.mark.parametrize('case', W43_CASES, ids=[str(c) for c in W43_CASES])
+def test_conv2d_winograd_f43_path(ops, case):
+    """3x3 / stride-1 layers whose H and W are multiples of 4 through F(4x4,3x3) (csrc/conv_wino43.hip; layer_func.py:912-916):
+    forward and input-gradient with weights transformed by the caller (MMDGAN_ACT_FLAG_W_WINOGRAD43) - full, ragged and
+    single tile blocks, H != W, channel counts that are not 32-multiples on the reduction side, bias / scale / activation,
+    the 3B-row dact wrap, an addend - then the reduction split over workspace slabs and the library's own transform.
+    Same fp64 oracle and norm-wise bar (1e-4) as the F(2x2,3x3) cases.  Element-wise (helpers.elementwise_err): every entry above
+    5 % of the tensor's scale within 1e-4 of ITSELF, the entries below within 5e-6 of the scale - F(4x4,3x3)'s transforms carry
+    constants up to 8 and its rounding is 3-5e-6 of the output scale whatever the entry's size (tools/wino43_gate.py,
+    profiles/r05_wino43_gate.txt; F(2x2,3x3): 5e-7, held to a 1e-6 floor)."""
+    N, H, W, C, K, ksz, s = case
+    x, w, b = conv_data(case, 4)
+    rs = np.random.RandomState(11)
+    dy = rs.randn(N, K, H, W).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64)
+    yt = R.conv2d_same(xt, wt, s)
+    gx, = torch.autograd.grad((yt * torch.tensor(dy, dtype=torch.float64)).sum(), [xt])
+    yt = yt.detach()
+    assert ops.wino_algo(N, H, W, C, K, ksz, s, False) == ops.WINO_F43       # (tests/conftest.py: MMDGAN_WINO43=2)
+    uf = ops.wino_transform(dev(w), False, algo=ops.WINO_F43)
+    assert uf.shape == (36, C, K) and ops.wino_kind(uf) == ops.WINO_F43
+    sc = np.float32(0.37)
+    bt = torch.tensor(b, dtype=torch.float64).reshape(1, -1, 1, 1)
+
+    def check_fwd(tag):
+        for act in ('linear', 'lrelu', 'tanh'):
+            ref = R._act(yt * float(sc) + bt, act).numpy()
+            y = ops.conv2d_fwd(nhwc(x), dev(w), s, bias=dev(b), scale=dev([sc]), act=act, wino=uf)
+            assert rel_err(to_nchw(y), ref) <= RTOL, (tag, act, rel_err(to_nchw(y), ref))
+            assert elementwise_err(to_nchw(y), ref, floor_frac=5e-2) <= RTOL, (tag, act, elementwise_err(to_nchw(y), ref, 5e-2))
+        y2 = ops.conv2d_fwd(nhwc(x), dev(w), s, bias=dev(b), scale=dev([sc]), act='tanh', wino=uf)
+        assert torch.equal(y, y2), tag                                       # no atomics: the same bits every run
+        y = ops.conv2d_fwd(nhwc(x), dev(w), s, wino=uf)                      # no bias, no scale
+        assert rel_err(to_nchw(y), yt.numpy()) <= RTOL, tag
+        print('F(4x4,3x3) %s %s: forward error %.2e of the output scale (entry-wise max)' % (case, tag, rel_err(to_nchw(y), yt.numpy())))
+        addend = rs.randn(N, K, H, W).astype(np.float32)
+        y = ops.conv2d_fwd(nhwc(x), dev(w), s, bias=dev(b), act='lrelu', wino=uf, addend=nhwc(addend))
+        assert rel_err(to_nchw(y), R._act(yt + bt, 'lrelu').numpy() + addend) <= RTOL, tag
+    check_fwd('caller-transformed')
+    dgrad_ok = ops.wino_algo(N, H, W, C, K, ksz, s, True) == ops.WINO_F43     # needs K % 8 == 0, K >= 32, C % 32 == 0
+    assert dgrad_ok == (C % 32 == 0 and K % 16 == 0)
+    ub = ops.wino_transform(dev(w), True, algo=ops.WINO_F43) if dgrad_ok else torch.zeros(36, K, C, device='cuda')
+
+    def check_dgrad(tag):
+        dx = ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s, wino=ub)
+        assert rel_err(to_nchw(dx), gx.numpy()) <= RTOL, tag
+        assert elementwise_err(to_nchw(dx), gx.numpy(), floor_frac=5e-2) <= RTOL, (tag, elementwise_err(to_nchw(dx), gx.numpy(), 5e-2))
+        if N % 3 == 0:                                   # [2B ; B] rows against 2B activations
+            B = N // 3
+            yprev = np.random.RandomState(5).randn(2 * B, C, H, W).astype(np.float32)
+            mask = np.where(np.concatenate([yprev, yprev[B:]], 0) > 0, 1.0, 0.1)
+            dx2 = ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s, scale=dev([0.5]), act='lrelu', dact_of=nhwc(yprev), dact_batch=2 * B,
+                                   wino=ub)
+            assert rel_err(to_nchw(dx2), 0.5 * gx.numpy() * mask) <= RTOL, tag
+    if dgrad_ok:
+        check_dgrad('caller-transformed')
+    else:
+        with pytest.raises(ValueError, match='WINOGRAD43'):
+            ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s, wino=ub)
+    # with a workspace: launches below one workgroup per CU (every case here) cut their channel reduction into slabs where
+    # the parts keep >= 64 channels; and the library's own route (no tensor handed in) transforms into the workspace
+    ops.set_workspace()
+    try:
+        check_fwd('workspace')
+        if dgrad_ok:
+            check_dgrad('workspace')
+        y = ops.conv2d_fwd(nhwc(x), dev(w), s, bias=dev(b), scale=dev([sc]), act='lrelu')
+        assert rel_err(to_nchw(y), R._act(yt * float(sc) + bt, 'lrelu').numpy()) <= RTOL
+        if dgrad_ok:
+            assert rel_err(to_nchw(ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s)), gx.numpy()) <= RTOL
+    finally:
+        ops.require_device().mmdgan_set_workspace(None, 0)
+    # a geometry F(4x4,3x3) does not take: H not a multiple of 4, or another kernel size
+    assert ops.wino_algo(N, 6, W, C, K, ksz, s, False) != ops.WINO_F43
+    with pytest.raises(ValueError, match='WINOGRAD43'):
+        ops.conv2d_fwd(nhwc(x[:, :, :2]), dev(w), s, wino=uf)
+
+
 def test_winograd_weight_transforms_of_many_kernels_in_one_launch(ops):
     """mmdgan_wino_transform_multi: 3x3 and 4x4 kernels, both forms, ragged 3x3 channel blocks, more jobs than one table
     holds (24) - every transformed tensor bit-equal to its one-kernel launch"""
@@ -807,6 +890,9 @@ def test_winograd_weight_transforms_of_many_kernels_in_one_launch(ops):
                     continue
                 want.append(ops.wino_transform(w, dgrad))
                 jobs.append((w, torch.full_like(want[-1], float('nan')), dgrad))
+                if R == 3 and (C if dgrad else K) % 32 == 0:        # ... and in the F(4x4,3x3) layout
+                    want.append(ops.wino_transform(w, dgrad, algo=ops.WINO_F43))
+                    jobs.append((w, torch.full_like(want[-1], float('nan')), dgrad))
     assert len(jobs) > 24
     ops.WinoTransforms(jobs).run()
     torch.cuda.synchronize()
