@@ -194,7 +194,7 @@ static int conv2d_dgrad_impl(const mmdgan_conv_geom *g, const float *dy, const f
 extern "C" int mmdgan_wino_eligible(const mmdgan_conv_geom *g, int dgrad) {
     if (!g || g->N < 1 || g->H < 1 || g->W < 1 || g->C < 1 || g->K < 1 || g->R < 1 || g->stride < 1) return 0;
     const ConvDims d = conv_dims(*g);
-    return !force_direct() && (wino_eligible(d, dgrad != 0) || wino2_eligible(d, dgrad != 0) || wino43_eligible(d, dgrad != 0)) ? 1 : 0;
+    return !force_direct() && (wino_eligible(d, dgrad != 0) || wino2_eligible(d, dgrad != 0)) ? 1 : 0;
 }
 
 extern "C" int mmdgan_wino_algo(const mmdgan_conv_geom *g, int dgrad) {

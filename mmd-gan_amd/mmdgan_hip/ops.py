@@ -288,7 +288,8 @@ _WINO_LEAD = {WINO_F23: (16,), WINO_F22S2: (4, 9), WINO_F43: (36,)}
 
 
 def wino_eligible(N, H, W, C, K, R, stride, dgrad):
-    """does conv2d_fwd (dgrad=False) / conv2d_dgrad (True) of this geometry run one of the Winograd kernels?"""
+    """does conv2d_fwd (dgrad=False) / conv2d_dgrad (True) of this geometry accept the tensors wino_transform() makes by
+    default - F(2x2,3x3) / F(2x2,2x2) on 4x4 stride 2?  (F(4x4,3x3) has its own query: wino_algo)"""
     g = geom(N, H, W, C, K, R, stride)
     return bool(require_device().mmdgan_wino_eligible(ctypes.byref(g), int(dgrad)))
 

@@ -296,6 +296,15 @@ CONV_CASES = [
 ]
 
 
+def ew_floor(ops, case, dgrad, base):
+    """floor_frac of helpers.elementwise_err for the kernel the LIBRARY picks for this geometry on its own: `base` (entries
+    above it are held to 1e-4 of themselves, the ones below to base * 1e-4 of the tensor's scale), 5e-2 where that is
+    F(4x4,3x3) - its transforms carry constants up to 8 and its rounding is 3-5e-6 of the output scale whatever the entry's
+    size (tools/wino43_gate.py; measured 1.4-4.9e-6 in test_conv2d_winograd_f43_path), against 5e-7 for F(2x2,3x3)"""
+    N, H, W, C, K, R, s = case
+    return 5e-2 if ops.wino_algo(N, H, W, C, K, R, s, dgrad) == ops.WINO_F43 else base
+
+
 def conv_data(case, seed=0):
     N, H, W, C, K, R, s = case
     rs = np.random.RandomState(seed)
@@ -317,7 +326,8 @@ def test_conv2d_fwd(ops, case):
         assert rel_err(to_nchw(y), ref) <= RTOL, act
         # ... and element by element: 1e-4 of EACH activation above 2 % of the tensor's scale (helpers.elementwise_err; the
         # absolute floor 2e-6 of the scale covers the longest reductions here, 4096 terms: measured 1.1e-6 at a zero crossing)
-        assert elementwise_err(to_nchw(y), ref, floor_frac=2e-2) <= RTOL, (act, elementwise_err(to_nchw(y), ref, 2e-2))
+        ff = ew_floor(ops, case, False, 2e-2)
+        assert elementwise_err(to_nchw(y), ref, floor_frac=ff) <= RTOL, (act, elementwise_err(to_nchw(y), ref, ff))
 
 
 @pytest.mark.parametrize('case', CONV_CASES, ids=[str(c) for c in CONV_CASES])
@@ -741,7 +751,8 @@ def test_conv2d_winograd_path(ops, case):
             ref = R._act(yt.detach() * float(sc) + torch.tensor(b, dtype=torch.float64).reshape(1, -1, 1, 1), act).numpy()
             y = ops.conv2d_fwd(nhwc(x), dev(w), s, bias=dev(b), scale=dev([sc]), act=act)
             assert rel_err(to_nchw(y), ref) <= RTOL, act
-            assert elementwise_err(to_nchw(y), ref) <= RTOL, (act, elementwise_err(to_nchw(y), ref))   # element by element
+            ff = ew_floor(ops, case, False, 1e-2)        # (with a workspace the library's own choice is F(4x4,3x3) where H, W % 4 == 0)
+            assert elementwise_err(to_nchw(y), ref, floor_frac=ff) <= RTOL, (act, elementwise_err(to_nchw(y), ref, ff))   # element by element
         dx = ops.conv2d_dgrad(nhwc(dy), dev(w), (H, W), s)
         assert rel_err(to_nchw(dx), gx.numpy()) <= RTOL
         if C % 32 == 0:        # weight gradient with the workspace: (K % 128 == 0) per-split slabs + one reduction pass, bias gradient fused
