@@ -72,7 +72,10 @@ def check(ops, torch, case, seed):
             for algo in algos:
                 u = ops.wino_transform(w, dgrad, algo=algo)
                 got = ops.conv2d_dgrad(dy, w, (H, W), s, wino=u) if dgrad else ops.conv2d_fwd(x, w, s, wino=u)
-                e = float((got - ref).abs().max() / (ref.abs().max() + 1e-30)) / 10.0      # bar 1e-5 on the same scale
+                # two routes to the same convolution: within 1e-5 of the tensor's scale, 3e-5 where one of them is F(4x4,3x3) (its
+                # own rounding is 3-5e-6 of the scale, up to 1e-5 at 512-channel reductions: tools/wino43_gate.py) - on the bar's scale
+                f43 = algo == ops.WINO_F43 or ops.wino_algo(N, H, W, C, K, R, s, dgrad) == ops.WINO_F43
+                e = float((got - ref).abs().max() / (ref.abs().max() + 1e-30)) / (30.0 if f43 else 10.0)
                 errs[name] = max(errs.get(name, 0.0), e)
     # the fused epilogues against the same launch with a linear epilogue, finished in torch: scale, bias, activation forward;
     # scale and activation derivative backward, the operand holding 2/3 of the images where the batch allows (the 3B-row
