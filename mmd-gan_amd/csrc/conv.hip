@@ -248,6 +248,16 @@ static int wgrad_impl(const mmdgan_conv_geom *g, const float *x, const float *dy
     MMDGAN_REQUIRE(x && dy && dw, "%s: null pointer", what);
     const ConvDims d = conv_dims(*g);
     const long nw = (long)d.R * d.R * d.C * d.K;
+    if (!force_direct() && wino43_wgrad_ok(d)) {             // F(4x4,3x3): 1 = no workspace for its slabs -> the kernels below
+        bool db_done = false, dot_done = false;
+        if (wdot && zero_output(dot, sizeof(float), (hipStream_t)stream) != hipSuccess) return check_launch("conv2d_wgrad memset");
+        int rcw = wino43_wgrad(d, x, dy, dw, dbias, &db_done, (hipStream_t)stream, wdot, dot, &dot_done);
+        if (rcw != 1) {
+            if (rcw == 0 && dbias && !db_done) rcw = mmdgan_colsum(dy, (long)d.N * d.P * d.Q, d.K, dbias, stream);
+            if (rcw == 0 && wdot && !dot_done) rcw = mmdgan_dot(dw, wdot, nw, dot, stream);
+            return rcw;
+        }
+    }
     if (!force_direct() && (wino_wgrad_ok(d) || wino2_wgrad_ok(d))) {
         bool db_done = false, dot_done = false;    // the slab kernels sum dy on the way, their reduction pass forms <dw, w>
         if (wdot && zero_output(dot, sizeof(float), (hipStream_t)stream) != hipSuccess) return check_launch("conv2d_wgrad memset");

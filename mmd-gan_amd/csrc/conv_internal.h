@@ -94,6 +94,11 @@ bool wino43_eligible(const ConvDims &d, bool dgrad);
 int wino43_transform(const ConvDims &d, const float *w, bool flip, float *U, hipStream_t st);
 int wino43_fwd(const ConvDims &d, const ConvEpilogue &ep, const float *x, const float *w, const float *U, float *y, hipStream_t st);
 int wino43_dgrad(const ConvDims &d, const ConvEpilogue &ep, const float *dy, const float *w, const float *U, float *dx, hipStream_t st);
+// ... and their weight gradient (conv_wino43w.hip): slabs in the workspace like the F(2x2,3x3) form; returns 1 when there is no
+// workspace for them (the caller takes another kernel)
+bool wino43_wgrad_ok(const ConvDims &d);
+int wino43_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, float *dbias, bool *dbias_done, hipStream_t st,
+                 const float *wdot = nullptr, float *dot = nullptr, bool *dot_done = nullptr);
 
 // in-place bias / activation / activation-derivative pass after a split-reduction launch (conv_wino.hip)
 int epilogue_pass(float *y, long total, int Ko, const ConvEpilogue &ep, hipStream_t st);

@@ -125,13 +125,15 @@ void *wgrad_slabs_acquire(size_t need, hipStream_t st, SlabReduceArgs *prev) {
     if (h.pending.active && h.pending.st != st && wgrad_flush_pending() != 0) return nullptr;
     const int i = ws_half_for(h, st);
     if (h.pending.active && h.pending.half != i && wgrad_flush_pending() != 0) return nullptr;   // (a stream keeps its half: not expected)
+    // take the half FIRST: if that fails (a stream_wait error) the pending reduction stays pending - the caller falls through to
+    // a non-slab kernel, whose own workspace request / the next flush still sums the previous layer's slabs
+    if (!ws_take(h, i, st)) return nullptr;
     int sub = 0;
     if (h.pending.active) {                                // same stream, same half: the caller's prologue sums it
         *prev = h.pending.args;
         sub = 1 - h.pending.sub;
         h.pending.active = false;
     }
-    if (!ws_take(h, i, st)) return nullptr;
     h.acq_half = i;
     h.acq_sub = sub;
     return (char *)h.ws + (size_t)i * half + (size_t)sub * part;
@@ -189,6 +191,7 @@ extern "C" long mmdgan_tuning_describe(char *buf, size_t cap) {
     add("wgrad_cus", t.wgrad_cus, d.wgrad_cus); add("gemm_skinny", t.gemm_skinny, d.gemm_skinny); add("gemm_panel", t.gemm_panel, d.gemm_panel); add("mmd_d16", t.mmd_d16, d.mmd_d16);
     add("wino43", t.wino43, d.wino43); add("wino43_min_tiles", t.wino43_min_tiles, d.wino43_min_tiles);
     add("wino43_ksplit_below", t.wino43_ksplit_below, d.wino43_ksplit_below);
+    add("wino43_wgrad", t.wino43_wgrad, d.wino43_wgrad); add("wino43_wgrad_min_tiles", t.wino43_wgrad_min_tiles, d.wino43_wgrad_min_tiles);
     if (buf && cap > 0) {
         const size_t n = out.size() < cap - 1 ? out.size() : cap - 1;
         memcpy(buf, out.data(), n);

@@ -694,6 +694,7 @@ class GanEngine:
                        self._queue_opt and any(s.sn for s in self.dis.specs) and
                        all(sn_chain_layer(self.dis, s, self.buf) is not None for s in self.dis.specs if s.sn))
         self._ahead_valid = False
+        self._tail_issued = False
         if self._ahead:
             self._sn_prev = (torch.zeros_like(self.dis.sn_scales.flat), torch.zeros_like(self.dis.sn_scratch.flat))
             self._sn_readout = {}
@@ -1123,6 +1124,7 @@ class GanEngine:
             self._sn_chains[id(self.dis)][0].run(update=True)
             self._wino_jobs[1].run(stream=sn0)
         self._ahead_valid = not inline
+        self._tail_issued = not inline                   # (the step body DID leave a tail: step() checks it, below)
         self.dis.readout = self._sn_readout if keep else None
 
     def _prime_ahead(self):
@@ -1234,6 +1236,7 @@ class GanEngine:
         self.gen.opt.step(self.lr_g, grad_scale=gs)
 
     def _step_body(self, z, real):
+        self._tail_issued = False                        # set by _ahead_tail; a replayed plan / graph keeps its recording's value
         lib = ops.require_device()
         lib.mmdgan_set_outputs_prezeroed(1)
         main = ops._stream()
@@ -1341,7 +1344,11 @@ class GanEngine:
                     self._plan_step()
         if self._ahead and not self._ahead_inline():
             # (host-side facts about what the step just issued - set here, not inside the recorded body: a replayed plan or
-            # graph runs the tail's launches without running _ahead_tail)
+            # graph runs the tail's launches without running _ahead_tail.)  The tail is issued where D's early Adam is; a
+            # schedule whose body - run or recorded - skipped it would commit a stale shadow next step: fail here instead
+            if not self._tail_issued:
+                raise RuntimeError('pipelined step boundary: the step body issued no tail for the next step '
+                                   '(D\'s early Adam did not run where _ahead_tail is issued)')
             self._ahead_valid = True
             self.dis.readout = self._sn_readout
         self.global_step += 1                                                # tied to the D update, my_sngan.py:424

@@ -9,6 +9,7 @@ os.environ.setdefault('OMP_NUM_THREADS', '32')
 os.environ.setdefault('MMDGAN_WINO_MIN_TILES', '32')     # let the small parity cases reach the Winograd kernels
 os.environ.setdefault('MMDGAN_WINO2', '2')               # ... and the F(2x2,2x2) stride-2 kernels in both directions
 os.environ.setdefault('MMDGAN_WINO43', '2')              # ... and F(4x4,3x3) wherever H and W are multiples of 4
+os.environ.setdefault('MMDGAN_WINO43_WGRAD_MIN_TILES', '64')   # ... its weight gradient from 64 tiles on (below: F(2x2,3x3) keeps its cases)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, 'mmd-gan_amd')

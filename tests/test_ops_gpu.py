@@ -887,6 +887,63 @@ def test_conv2d_winograd_f43_path(ops, case):
         ops.conv2d_fwd(nhwc(x[:, :, :2]), dev(w), s, wino=uf)
 
 
+W43W_CASES = [(16, 16, 16, 128, 128, 3, 1), (32, 8, 8, 64, 128, 3, 1), (130, 4, 4, 64, 64, 3, 1), (6, 20, 24, 32, 96, 3, 1),
+              (33, 8, 8, 64, 32, 3, 1), (3, 24, 24, 128, 128, 3, 1), (65, 4, 8, 256, 64, 3, 1), (4, 32, 32, 64, 64, 3, 1)]
+
+
+@pytest.mark.parametrize('case', W43W_CASES, ids=[str(c) for c in W43W_CASES])
+def test_conv2d_winograd_f43_weight_gradient(ops, case):
+    """the weight gradient of the same layers in the F(4x4,3x3) domain (csrc/conv_wino43w.hip; layer_func.py:912-916's kernels
+    under tf.gradients): dW = G^T [sum over 4x4 tiles (B^T d B) (.) (A dY A^T)] G with per-split slabs in the workspace and the
+    slab reduction - full and ragged windows of 8 tiles, tile ranges split over workgroups and not, H != W, one to eight
+    channel blocks a side; the bias gradient and the spectral-norm scalar <dW, W> riding along; bit-reproducible; the same bits
+    whether the reduction runs as its own pass or as the prologue of the next weight-gradient launch.  fp64 oracle, the
+    norm-wise 1e-4 bar of every conv test, and an entry-wise floor of 5e-6 of the tensor's scale (tools/wino43_gate.py measured
+    1.5-4e-6 for this transform pair against fp64; F(2x2,3x3): 5-9e-7)."""
+    N, H, W, C, K, ksz, s = case
+    x, w, _ = conv_data(case, 6)
+    rs = np.random.RandomState(13)
+    dy = rs.randn(N, K, H, W).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    gw, = torch.autograd.grad((R.conv2d_same(xt, wt, s) * torch.tensor(dy, dtype=torch.float64)).sum(), [wt])
+    gw, gb = gw.numpy(), dy.astype(np.float64).sum((0, 2, 3))
+    tun = ops.tuning()
+    assert tun['wino43_wgrad'][0] >= 1 and N * (H // 4) * (W // 4) >= tun['wino43_wgrad_min_tiles'][0], tun   # (tests/conftest.py)
+    ops.set_workspace()
+    try:
+        dw, db = torch.full((3, 3, C, K), float('nan'), device='cuda'), torch.full((K,), float('nan'), device='cuda')
+        ops.conv2d_wgrad(nhwc(x), nhwc(dy), ksz, s, out=dw, dbias=db)
+        err = rel_err(dw.cpu().numpy(), gw)
+        print('F(4x4,3x3) weight gradient %s: error %.2e of the tensor scale (entry-wise max)' % (case, err))
+        assert err <= RTOL
+        assert elementwise_err(dw.cpu().numpy(), gw, floor_frac=5e-2) <= RTOL, elementwise_err(dw.cpu().numpy(), gw, 5e-2)
+        assert rel_err(db.cpu().numpy(), gb) <= RTOL
+        assert torch.equal(dw, ops.conv2d_wgrad(nhwc(x), nhwc(dy), ksz, s))           # deterministic, with or without dbias
+        # <dW, W> on the way (mmdgan_conv2d_wgrad_sn)
+        dot = torch.full((1,), float('nan'), device='cuda')
+        dw2 = ops.conv2d_wgrad(nhwc(x), nhwc(dy), ksz, s, w=dev(w), dot=dot)
+        assert torch.equal(dw2, dw)
+        want = float((gw * w.astype(np.float64)).sum())
+        assert abs(float(dot.item()) - want) <= 1e-4 * max(abs(want), float(np.abs(gw).max()) * float(np.abs(w).max())), (dot.item(), want)
+        # the reduction as the prologue of the NEXT weight-gradient launch: a chain of three, the same bits
+        ops.wgrad_defer(True)
+        try:
+            outs = [torch.full((3, 3, C, K), float('nan'), device='cuda') for _ in range(3)]
+            dbs = [torch.full((K,), float('nan'), device='cuda') for _ in range(3)]
+            for o, b_ in zip(outs, dbs):
+                ops.conv2d_wgrad(nhwc(x), nhwc(dy), ksz, s, out=o, dbias=b_)
+            ops.wgrad_flush()
+        finally:
+            ops.wgrad_defer(False)
+        for o, b_ in zip(outs, dbs):
+            assert torch.equal(o, dw) and torch.equal(b_, db)
+    finally:
+        ops.require_device().mmdgan_set_workspace(None, 0)
+    # no workspace: no slabs - the call still answers (another kernel), same oracle
+    assert rel_err(ops.conv2d_wgrad(nhwc(x), nhwc(dy), ksz, s).cpu().numpy(), gw) <= RTOL
+
+
 def test_winograd_weight_transforms_of_many_kernels_in_one_launch(ops):
     """mmdgan_wino_transform_multi: 3x3 and 4x4 kernels, both forms, ragged 3x3 channel blocks, more jobs than one table
     holds (24) - every transformed tensor bit-equal to its one-kernel launch"""
