@@ -119,4 +119,12 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Workgroup barrier that publishes LDS only.  __syncthreads() is a workgroup-scope release / acquire fence + s_barrier, and on
+// gfx9-family parts the fence's release half is `s_waitcnt vmcnt(0)`: every global load a wave has in flight - the operands it
+// requested for a LATER stage - must land before the wave may even arrive at the barrier, which turns a prefetch across a
+// barrier into a blocking load (conv_wino43w.hip: the window was as long as a request's latency, tools/wino43w_trace.py).
+// Where waves of a workgroup hand each other data through LDS only, this is the barrier: the wave's own LDS accesses have
+// completed (lgkmcnt(0)), the compiler moves no memory access across it, global loads stay in flight.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 }  // namespace mmdgan

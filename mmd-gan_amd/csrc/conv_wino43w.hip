@@ -33,18 +33,19 @@ namespace w43w {
 constexpr int NT = 512;
 constexpr int BT = 8;                           // tiles per window = 4 MFMA k-pairs
 constexpr int BC = 32, BK = 32;                 // channels of x / of dy per workgroup
-constexpr int FS = 2 * 2 * 32 * 2;              // floats per frequency of one operand: [k half][k-pair pair][channel 32][2 k-pairs]
+constexpr int FS = 2 * 4 * 32;                  // floats per frequency of one operand: [k half][k-pair 4][channel 32]
 constexpr int OP_FLOATS = 36 * FS;              // V (or M) of one window
 constexpr int WIN_FLOATS = 2 * OP_FLOATS;       // V then M: 73,728 bytes
 constexpr int Z_FLOATS = 36 * 32 * 32;          // the epilogue's exchange buffer [f][c][k]
 static_assert(Z_FLOATS == 2 * WIN_FLOATS, "the exchange buffer is the double buffer");
-constexpr size_t LDS_BYTES = sizeof(float) * (Z_FLOATS + 4 * BK);      // + the four partial bias rows
+constexpr size_t LDS_BYTES = sizeof(float) * (Z_FLOATS + 16 * BK);     // + sixteen partial bias rows
 constexpr unsigned kPad = 0x40000000u;          // an out-of-image row / column / tile: keeps the offset out of range
 constexpr long kMaxBytes = 0x40000000L;         // ... for tensors below 1 GiB
 }  // namespace w43w
 
 // compile-time ablation masks (tools/wino43w_ablate.sh); 0 in the library build
 //   1: no patch / dY loads   2: no transforms, no operand stores   4: no MFMAs   8: no operand reads (LDS)   16: no epilogue
+//   32: no operand stores (the transforms stay)
 #ifndef W43W_ABLATE
 #define W43W_ABLATE 0
 #endif
@@ -81,6 +82,25 @@ __device__ __forceinline__ f32x2 w43w_fma(float c, f32x2 a, f32x2 b) { return __
         g2 = fmaf(4.f / 15.f, (m4), fmaf(-4.f / 15.f, (m3), p_ + (m5)));               \
     }
 
+#ifdef W43W_TRACE     // measurement builds only (tools/wino43w_trace.py): shader-clock stamps of one workgroup's windows
+__device__ long g_w43w_trace[8 * 256];
+#define W43W_STAMP(ROW, J) \
+    if (blockIdx.x == W43W_TRACE && lane == 0 && (J) < 256) g_w43w_trace[(ROW) * 256 + (J)] = (long)__builtin_readcyclecounter();
+#else
+#define W43W_STAMP(ROW, J)
+#endif
+
+typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 w43w_rsrc(const float *base, long bytes) {       // (what make_rsrc builds, as four SGPRs)
+    const unsigned long a = reinterpret_cast<unsigned long>(base);
+    u32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+    r.z = __builtin_amdgcn_readfirstlane((unsigned)bytes);
+    r.w = 0x00020000u;
+    return r;
+}
+
 struct W43wWalk {             // running (tx, ty, image) of a tile index advanced by the window's 8 tiles
     int tx, ty, n;
 };
@@ -97,6 +117,7 @@ __global__ __launch_bounds__(w43w::NT) void wino43_wgrad_kernel(int N, int H, in
     // the previous weight-gradient launch of this stream left its slabs un-summed (mmdgan_wgrad_defer): this workgroup's share first
     slab_reduce_share(prev, blockIdx.x, gridDim.x, tid, NT, reinterpret_cast<double *>(smem));
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (wave == 0) { W43W_STAMP(7, 0) }
     const int TH = H >> 2, TW = W >> 2;
     const int T = N * TH * TW;
     // The workgroups of one tile range (same x and dy, different channel blocks) sit next to each other on ONE XCD (hardware
@@ -113,180 +134,185 @@ __global__ __launch_bounds__(w43w::NT) void wino43_wgrad_kernel(int N, int H, in
     const int nw_all = (T + BT - 1) / BT;
     const int S = min(nw_all, w_begin + windows_per_split) - w_begin;          // windows of this workgroup (>= 1: the launcher's split)
     const int t_end = min(T, (w_begin + S) * BT);
-    float *dbsum = smem + Z_FLOATS;                                             // [kh 2 x pair 2][k 32]
+    float *dbsum = smem + Z_FLOATS;                                             // [producer wave 4 x tile of the wave 4][k 32]
 
     if (wave >= 4) {
-        // ------------------------------------------------------------ producers: lane = (channel l31, k half kh, k-pair pair pp)
-        // owns the window's tiles 4 pp + kh (k-pair 2 pp) and 4 pp + kh + 2 (k-pair 2 pp + 1): .x / .y of every f32x2 below
-        const bool is_m = wave >= 6;
-        const int pp = (wave - 4) & 1;
-        const int tl = 4 * pp + kh;
-        const int vd = (is_m ? OP_FLOATS : 0) + kh * 128 + pp * 64 + l31 * 2;
-        W43wWalk wa, wb;
-        {
-            const int ia = w_begin * BT + tl, ib = ia + 2;
-            wa = {ia % TW, (ia / TW) % TH, ia / (TW * TH)};
-            wb = {ib % TW, (ib / TW) % TH, ib / (TW * TH)};
-        }
-        const int s_tx = BT % TW, s_ty = (BT / TW) % TH, s_n = BT / (TW * TH);
-        auto advance = [&](W43wWalk &t) {
-            t.tx += s_tx;
-            const bool c1 = t.tx >= TW;
-            t.tx -= c1 ? TW : 0;
-            t.ty += s_ty + (c1 ? 1 : 0);
-            const bool c2 = t.ty >= TH;
-            t.ty -= c2 ? TH : 0;
-            t.n += s_n + (c2 ? 1 : 0);
+        // ------------------------------------------------------------ producers: two PAIRS of waves take alternate windows
+        // (pair g: windows g, g + 2, ...); within a pair wave h holds tiles 4 h .. 4 h + 3 of the window, lane = (tile, channel
+        // PAIR): the tile's 6x6 patch of input channels c0 + 2 cp, + 1 and its 4x4 output gradients of channels k0 + 2 cp, + 1
+        // as 8-byte loads (one vector-memory instruction costs the CU's address path ~16 cycles whatever it carries: with a
+        // dword per lane the 208 requests of a window took as long as its MFMAs - tools/wino43w_trace.py).  A pair has TWO
+        // windows per window of its own, and splits them by what the LDS double buffer allows:
+        //   duty window (the consumers multiply window w - 1): A dY A^T, all 72 operand stores of window w (8 bytes each, into
+        //                the buffer window w - 2 was read from), then the requests of window w + 2 into the registers just freed;
+        //   off window:  B^T d B of window w + 2, in place, as its patches arrive.
+        // Every SIMD carries the same transform work beside its consumer wave (VALU from the partner wave costs the MFMA stream
+        // about half of its own issue time, tools/mfma_valu_overlap.hip), and no window waits for a request's latency.
+        // (static priority for the producers: the consumer waves are the older ones and win every arbitration otherwise -
+        // D l3 at batch 128: 55.7 -> 52.2 us, tools/wino43w_ablate.sh)
+#ifndef W43W_PRODUCER_PRIO
+#define W43W_PRODUCER_PRIO 1
+#endif
+        __builtin_amdgcn_s_setprio(W43W_PRODUCER_PRIO);
+        const int g = (wave - 4) >> 1, hw = (wave - 4) & 1;
+        const int tl = 4 * hw + (lane >> 4), cp = lane & 15;        // tile of the window, channel pair
+        const int vd = (tl & 1) * 128 + (tl >> 1) * 32 + 2 * cp;     // [k half][k-pair][channel]: + f * FS (+ OP_FLOATS: M)
+        int id = (w_begin + g) * BT + tl;                            // this lane's tile of the pair's next window
+        int tx = id % TW, ty = (id / TW) % TH, tn = id / (TW * TH);
+        const int s_tx = (2 * BT) % TW, s_ty = ((2 * BT) / TW) % TH, s_n = (2 * BT) / (TW * TH);
+        // patch pixel (r, j) of a tile = image pixel (4 ty - 1 + r, 4 tx - 1 + j): the resource starts one row and one pixel
+        // BEFORE the tensor, so that pixel's offset is tilebase + r * rowbytes + j * pixbytes with a wave-uniform second part
+        // (the scalar offset of the load: no address arithmetic per load); the border rows / columns that lie outside the image
+        // take an out-of-range tilebase instead (nine variants per window: {top, middle, bottom} x {left, middle, right})
+        const unsigned xrow = (unsigned)(W * C * 4), xpix = (unsigned)(C * 4);
+        // (the requests are inline assembly with the destination tied to the register it replaces: through the builtin hipcc
+        // put half of a window's values into other registers and copied them at the end of the block - every copy a wait for
+        // its load, in front of the barrier.  The waits are therefore placed by hand: w43w_wait_x / _y below.)
+        const u32x4 rx = w43w_rsrc(x - ((long)W * C + C), (long)N * H * W * C * 4 + xrow + xpix);
+        const u32x4 rdy = w43w_rsrc(dy, (long)N * H * W * K * 4);
+        const unsigned yrow = (unsigned)(W * K * 4), ypix = (unsigned)(K * 4);
+        const unsigned xch = (unsigned)((c0 + 2 * cp) * 4), ych = (unsigned)((k0 + 2 * cp) * 4);
+        const bool dosum = DBIAS && c0 == 0;
+        f32x2 dbs = {0.f, 0.f};
+        f32x2 d[36], e[16];                             // the patch (raw, then B^T d B in place) and the raw output gradients
+#pragma unroll
+        for (int q = 0; q < 36; ++q) d[q] = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 16; ++q) e[q] = f32x2{0.f, 0.f};
+        unsigned var[3][3], ybase;                      // the offsets of the window being requested
+        auto request_begin = [&]() __attribute__((always_inline)) {
+            const bool ok = id < t_end;
+            const unsigned pix = __umul24(__umul24(tn, H) + 4 * ty, W) + 4 * tx;       // (every factor is below 2^24)
+            const unsigned xb = ok ? __umul24(pix, xpix) + xch : kPad;
+            ybase = ok ? __umul24(pix, ypix) + ych : kPad;
+            const bool top = ty > 0, bot = ty < TH - 1, lef = tx > 0, rig = tx < TW - 1;
+#pragma unroll
+            for (int rc = 0; rc < 3; ++rc)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc)
+                    var[rc][cc] = ((rc == 0 ? top : rc == 2 ? bot : true) && (cc == 0 ? lef : cc == 2 ? rig : true)) ? xb : kPad;
+            tx += s_tx;                                 // (advance: the next request's tile)
+            const bool c1 = tx >= TW;
+            tx -= c1 ? TW : 0;
+            ty += s_ty + (c1 ? 1 : 0);
+            const bool c2 = ty >= TH;
+            ty -= c2 ? TH : 0;
+            tn += s_n + (c2 ? 1 : 0);
+            id += 2 * BT;
         };
-        int ida = w_begin * BT + tl;                    // tile index of .x of the next window to be requested (.y: + 2)
-        if (!is_m) {
-            // ---------------------------------------------------------------- V = B^T d B of the patches
-            const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (long)N * H * W * C * 4);
-            const unsigned chb = (unsigned)((c0 + l31) * 4);
-            f32x2 da[36], db[36];
-            auto xload = [&](f32x2(&d)[36]) __attribute__((always_inline)) {   // the next window's two patches, then advance
-                if (W43W_ABLATE & 1) {
+#define W43W_XREQ(Q)                                                                                        \
+    if (W43W_ABLATE & 1) { float o = (float)(lane + (Q)); asm volatile("" : "+v"(o)); d[Q] = f32x2{o, o}; }   \
+    else asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(d[Q])                              \
+                      : "v"(var[(Q) / 6 == 0 ? 0 : (Q) / 6 == 5 ? 2 : 1][(Q) % 6 == 0 ? 0 : (Q) % 6 == 5 ? 2 : 1]), "s"(rx), \
+                        "s"((unsigned)((Q) / 6) * xrow + (unsigned)((Q) % 6) * xpix));
+#define W43W_YREQ(Q)                                                                                        \
+    if (W43W_ABLATE & 1) { float o = (float)(lane - (Q)); asm volatile("" : "+v"(o)); e[Q] = f32x2{o, o}; }   \
+    else asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(e[Q])                              \
+                      : "v"(ybase), "s"(rdy), "s"((unsigned)((Q) / 4) * yrow + (unsigned)((Q) % 4) * ypix));
+        // a wave's requests go out in the order 36 patch pixels, 16 gradient pixels, 36, 16, ...: the patches have landed when
+        // at most the 16 younger requests are outstanding, the gradients when at most the 36 younger ones are
+        auto wait_x = [&]() __attribute__((always_inline)) {
+            if (W43W_ABLATE & 1) return;
+            asm volatile("s_waitcnt vmcnt(16)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]), "+v"(d[8]),
+                         "+v"(d[9]), "+v"(d[10]), "+v"(d[11]), "+v"(d[12]), "+v"(d[13]), "+v"(d[14]), "+v"(d[15]), "+v"(d[16]), "+v"(d[17]));
+            asm volatile("" : "+v"(d[18]), "+v"(d[19]), "+v"(d[20]), "+v"(d[21]), "+v"(d[22]), "+v"(d[23]), "+v"(d[24]), "+v"(d[25]), "+v"(d[26]),
+                         "+v"(d[27]), "+v"(d[28]), "+v"(d[29]), "+v"(d[30]), "+v"(d[31]), "+v"(d[32]), "+v"(d[33]), "+v"(d[34]), "+v"(d[35]));
+        };
+        auto wait_y = [&](bool younger_patches) __attribute__((always_inline)) {
+            if (W43W_ABLATE & 1) return;
+            if (younger_patches)
+                asm volatile("s_waitcnt vmcnt(36)" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]),
+                             "+v"(e[8]), "+v"(e[9]), "+v"(e[10]), "+v"(e[11]), "+v"(e[12]), "+v"(e[13]), "+v"(e[14]), "+v"(e[15]));
+            else
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]),
+                             "+v"(e[8]), "+v"(e[9]), "+v"(e[10]), "+v"(e[11]), "+v"(e[12]), "+v"(e[13]), "+v"(e[14]), "+v"(e[15]));
+        };
+        auto request = [&]() __attribute__((always_inline)) {       // the pair's next window, then advance
+            request_begin();
 #pragma unroll
-                    for (int e = 0; e < 36; ++e) {
-                        float o = (float)(lane + e);
-                        asm volatile("" : "+v"(o));
-                        d[e] = f32x2{o, o};
-                    }
-                    return;
-                }
-                unsigned rowa[6], cola[6], rowb[6], colb[6];
-                const bool oka = ida < t_end, okb = ida + 2 < t_end;
+            for (int q = 0; q < 36; ++q) { W43W_XREQ(q) }
 #pragma unroll
-                for (int r = 0; r < 6; ++r) {
-                    const int ya = 4 * wa.ty - 1 + r, xa = 4 * wa.tx - 1 + r, yb = 4 * wb.ty - 1 + r, xb = 4 * wb.tx - 1 + r;
-                    rowa[r] = (oka && ya >= 0 && ya < H) ? (unsigned)((wa.n * H + ya) * W) * (unsigned)(C * 4) + chb : kPad;
-                    cola[r] = (xa >= 0 && xa < W) ? (unsigned)(xa * C * 4) : kPad;
-                    rowb[r] = (okb && yb >= 0 && yb < H) ? (unsigned)((wb.n * H + yb) * W) * (unsigned)(C * 4) + chb : kPad;
-                    colb[r] = (xb >= 0 && xb < W) ? (unsigned)(xb * C * 4) : kPad;
-                }
+            for (int q = 0; q < 16; ++q) { W43W_YREQ(q) }
+        };
+        // off window: V = B^T d B in place - along the columns of each patch row, then along the rows of each frequency column
+        auto transform_v = [&]() __attribute__((always_inline)) {
+            if (W43W_ABLATE & 2) return;
+            __builtin_amdgcn_sched_barrier(0);
+            wait_x();
 #pragma unroll
-                for (int r = 0; r < 6; ++r)
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        d[r * 6 + j].x = bufld1(rx, rowa[r] + cola[j]);
-                        d[r * 6 + j].y = bufld1(rx, rowb[r] + colb[j]);
-                    }
-                advance(wa);
-                advance(wb);
-                ida += BT;
-            };
-            auto transform_dump = [&](f32x2(&d)[36], float *buf) __attribute__((always_inline)) {
-                if (W43W_ABLATE & 2) return;
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < 6; ++r) {
-                    f32x2 t0, t1, t2, t3, t4, t5;
-                    W43W_BT6(d[r * 6 + 0], d[r * 6 + 1], d[r * 6 + 2], d[r * 6 + 3], d[r * 6 + 4], d[r * 6 + 5], t0, t1, t2, t3, t4, t5)
-                    d[r * 6 + 0] = t0; d[r * 6 + 1] = t1; d[r * 6 + 2] = t2; d[r * 6 + 3] = t3; d[r * 6 + 4] = t4; d[r * 6 + 5] = t5;
-                }
-#pragma unroll
-                for (int jj = 0; jj < 6; ++jj) {
-                    f32x2 v0, v1, v2, v3, v4, v5;
-                    W43W_BT6(d[0 + jj], d[6 + jj], d[12 + jj], d[18 + jj], d[24 + jj], d[30 + jj], v0, v1, v2, v3, v4, v5)
-                    *reinterpret_cast<f32x2 *>(buf + (0 + jj) * FS + vd) = v0;
-                    *reinterpret_cast<f32x2 *>(buf + (6 + jj) * FS + vd) = v1;
-                    *reinterpret_cast<f32x2 *>(buf + (12 + jj) * FS + vd) = v2;
-                    *reinterpret_cast<f32x2 *>(buf + (18 + jj) * FS + vd) = v3;
-                    *reinterpret_cast<f32x2 *>(buf + (24 + jj) * FS + vd) = v4;
-                    *reinterpret_cast<f32x2 *>(buf + (30 + jj) * FS + vd) = v5;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            // window j: the consumers multiply window j; its successor's operands are written during it, and the patches of the
-            // one after that are requested into the registers that were transformed a window ago (beyond the slice's last tile:
-            // out-of-range offsets - the loads return zeros without traffic, their window is never multiplied)
-            xload(da);
-            xload(db);
-            transform_dump(da, smem);
-            __syncthreads();
-            for (int j = 0;;) {
-                xload(da);
-                transform_dump(db, smem + ((j + 1) & 1) * WIN_FLOATS);
-                __syncthreads();
-                if (++j >= S) break;
-                xload(db);
-                transform_dump(da, smem + ((j + 1) & 1) * WIN_FLOATS);
-                __syncthreads();
-                if (++j >= S) break;
+            for (int r = 0; r < 6; ++r) {
+                f32x2 t0, t1, t2, t3, t4, t5;
+                W43W_BT6(d[r * 6 + 0], d[r * 6 + 1], d[r * 6 + 2], d[r * 6 + 3], d[r * 6 + 4], d[r * 6 + 5], t0, t1, t2, t3, t4, t5)
+                d[r * 6 + 0] = t0; d[r * 6 + 1] = t1; d[r * 6 + 2] = t2; d[r * 6 + 3] = t3; d[r * 6 + 4] = t4; d[r * 6 + 5] = t5;
             }
-        } else {
-            // ---------------------------------------------------------------- M = A dY A^T of the tiles' output gradients
-            const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, (long)N * H * W * K * 4);
-            const unsigned chb = (unsigned)((k0 + l31) * 4);
-            const unsigned rowbytes = (unsigned)(W * K * 4), pixbytes = (unsigned)(K * 4);
-            const bool dosum = DBIAS && c0 == 0;
-            f32x2 dbs = {0.f, 0.f};
-            f32x2 ea[16], eb[16];
-            auto yload = [&](f32x2(&d)[16]) __attribute__((always_inline)) {
-                if (W43W_ABLATE & 1) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        float o = (float)(lane + e);
-                        asm volatile("" : "+v"(o));
-                        d[e] = f32x2{o, o};
-                    }
-                    return;
-                }
-                const unsigned oa = ida < t_end ? (unsigned)((wa.n * H + 4 * wa.ty) * W + 4 * wa.tx) * pixbytes + chb : kPad;
-                const unsigned ob = ida + 2 < t_end ? (unsigned)((wb.n * H + 4 * wb.ty) * W + 4 * wb.tx) * pixbytes + chb : kPad;
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {           // (the pixel's part of the offset is wave-uniform: the scalar offset)
-                        d[a * 4 + b].x = bufld1s(rdy, oa, (unsigned)a * rowbytes + (unsigned)b * pixbytes);
-                        d[a * 4 + b].y = bufld1s(rdy, ob, (unsigned)a * rowbytes + (unsigned)b * pixbytes);
-                    }
-                advance(wa);
-                advance(wb);
-                ida += BT;
-            };
-            auto transform_dump = [&](f32x2(&d)[16], float *buf) __attribute__((always_inline)) {
-                if (W43W_ABLATE & 2) return;
-                __builtin_amdgcn_sched_barrier(0);
-                if (dosum) {
-                    f32x2 s = (d[0] + d[1]) + (d[2] + d[3]);
-#pragma unroll
-                    for (int a = 1; a < 4; ++a) s += (d[a * 4] + d[a * 4 + 1]) + (d[a * 4 + 2] + d[a * 4 + 3]);
-                    dbs += s;
-                }
-                f32x2 t[4][6];                              // t[a][j] = sum_b dY[a][b] A[j][b]
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-                    W43W_A4(d[a * 4 + 0], d[a * 4 + 1], d[a * 4 + 2], d[a * 4 + 3], t[a][0], t[a][1], t[a][2], t[a][3], t[a][4], t[a][5])
-#pragma unroll
-                for (int jj = 0; jj < 6; ++jj) {            // M[i][j] = sum_a A[i][a] t[a][j]
-                    f32x2 v0, v1, v2, v3, v4, v5;
-                    W43W_A4(t[0][jj], t[1][jj], t[2][jj], t[3][jj], v0, v1, v2, v3, v4, v5)
-                    *reinterpret_cast<f32x2 *>(buf + (0 + jj) * FS + vd) = v0;
-                    *reinterpret_cast<f32x2 *>(buf + (6 + jj) * FS + vd) = v1;
-                    *reinterpret_cast<f32x2 *>(buf + (12 + jj) * FS + vd) = v2;
-                    *reinterpret_cast<f32x2 *>(buf + (18 + jj) * FS + vd) = v3;
-                    *reinterpret_cast<f32x2 *>(buf + (24 + jj) * FS + vd) = v4;
-                    *reinterpret_cast<f32x2 *>(buf + (30 + jj) * FS + vd) = v5;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            yload(ea);
-            yload(eb);
-            transform_dump(ea, smem);
-            __syncthreads();
-            for (int j = 0;;) {
-                yload(ea);
-                transform_dump(eb, smem + ((j + 1) & 1) * WIN_FLOATS);
-                __syncthreads();
-                if (++j >= S) break;
-                yload(eb);
-                transform_dump(ea, smem + ((j + 1) & 1) * WIN_FLOATS);
-                __syncthreads();
-                if (++j >= S) break;
+            for (int jj = 0; jj < 6; ++jj) {
+                f32x2 v0, v1, v2, v3, v4, v5;
+                W43W_BT6(d[0 + jj], d[6 + jj], d[12 + jj], d[18 + jj], d[24 + jj], d[30 + jj], v0, v1, v2, v3, v4, v5)
+                d[0 + jj] = v0; d[6 + jj] = v1; d[12 + jj] = v2; d[18 + jj] = v3; d[24 + jj] = v4; d[30 + jj] = v5;
             }
-            // (the transforms beyond window S - 1 saw zeros: tiles >= t_end are out of range)
-            if (dosum) dbsum[((wave - 6) * 2 + kh) * BK + l31] = dbs.x + dbs.y;
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // duty window: both operands of the window to LDS, M = A dY A^T (+ the bias gradient's share of this tile) on the way,
+        // and the NEXT request of every register right behind its store: a vector-memory instruction holds the CU's address
+        // path for ~16 cycles, so the 52 of a wave go out between the stores and the transform instead of in a burst after them
+        auto dump_request = [&](float *buf, bool again) __attribute__((always_inline)) {
+            if (W43W_ABLATE & 2) { if (again) request(); return; }
+            __builtin_amdgcn_sched_barrier(0);
+            if (again) request_begin();
+#pragma unroll
+            for (int f = 0; f < 36; ++f) {
+                if (!(W43W_ABLATE & 32)) *reinterpret_cast<f32x2 *>(buf + f * FS + vd) = d[f];
+                else asm volatile("" ::"v"(d[f]));
+                if (again) { W43W_XREQ(f) }
+            }
+            wait_y(again);
+            if (dosum) dbs += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7])) + (((e[8] + e[9]) + (e[10] + e[11])) + ((e[12] + e[13]) + (e[14] + e[15])));
+            f32x2 t[4][6];                                  // t[a][j] = sum_b dY[a][b] A[j][b]
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                W43W_A4(e[a * 4 + 0], e[a * 4 + 1], e[a * 4 + 2], e[a * 4 + 3], t[a][0], t[a][1], t[a][2], t[a][3], t[a][4], t[a][5])
+            float *bm = buf + OP_FLOATS + vd;
+#pragma unroll
+            for (int jj = 0; jj < 6; ++jj) {                // M[i][j] = sum_a A[i][a] t[a][j]
+                f32x2 v0, v1, v2, v3, v4, v5;
+                W43W_A4(t[0][jj], t[1][jj], t[2][jj], t[3][jj], v0, v1, v2, v3, v4, v5)
+                if (W43W_ABLATE & 32) { asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5)); continue; }
+                *reinterpret_cast<f32x2 *>(bm + (0 + jj) * FS) = v0; *reinterpret_cast<f32x2 *>(bm + (6 + jj) * FS) = v1;
+                *reinterpret_cast<f32x2 *>(bm + (12 + jj) * FS) = v2; *reinterpret_cast<f32x2 *>(bm + (18 + jj) * FS) = v3;
+                *reinterpret_cast<f32x2 *>(bm + (24 + jj) * FS) = v4; *reinterpret_cast<f32x2 *>(bm + (30 + jj) * FS) = v5;
+            }
+            // (the gradients' requests LAST, behind a scheduling fence: issued while the old values were still being read they
+            // went into other registers and a copy per value - each a wait for its load - stood in front of the barrier)
+            __builtin_amdgcn_sched_barrier(0);
+            if (again) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { W43W_YREQ(q) }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // (beyond the slice's last tile: out-of-range offsets - the loads return zeros without traffic; such a window is
+        // stored into the idle buffer and never multiplied)
+        request();                                      // window g
+        transform_v();
+        if (g == 0) dump_request(smem, true);           // (and window 2 requested)
+        lds_barrier();
+        for (int i = 0; i < S; ++i) {                   // the consumers multiply window i
+            if (wave == 4) { W43W_STAMP(2, i) }
+            if (((i + 1) & 1) == g) {
+                dump_request(smem + ((i + 1) & 1) * WIN_FLOATS, true);
+                if (wave == 4) { W43W_STAMP(3, i) }
+            } else {
+                transform_v();
+                if (wave == 4) { W43W_STAMP(3, i) }
+            }
+            if (wave == 4) { W43W_STAMP(4, i) }
+            lds_barrier();
+        }
+        if (dosum) {
+            float *row = dbsum + (((wave - 4) * 4 + (lane >> 4)) * BK + 2 * cp);
+            row[0] = dbs.x;
+            row[1] = dbs.y;
         }
     } else {
         // ---------------------------------------------------------------- consumers: 9 frequencies x 32 c x 32 k
@@ -296,9 +322,11 @@ __global__ __launch_bounds__(w43w::NT) void wino43_wgrad_kernel(int N, int H, in
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[fl][r] = 0.f;
         const int f0 = 9 * wave;
-        const int obase = f0 * FS + kh * 128 + l31 * 2;     // + fl * FS + pair * 64 (+ OP_FLOATS: M)
-        __syncthreads();
+        const int obase = f0 * FS + kh * 128 + l31;         // + fl * FS + k-pair * 32 (+ OP_FLOATS: M)
+        lds_barrier();
+        if (wave == 0) { W43W_STAMP(7, 1) }
         for (int j = 0; j < S; ++j) {
+            if (wave == 0) { W43W_STAMP(0, j) }
             const float *cur = smem + (j & 1) * WIN_FLOATS + obase;
             // frequencies in pairs (the last one alone): consecutive MFMAs go to different accumulators, the operands of the
             // next pair are fetched while this one is multiplied
@@ -308,10 +336,11 @@ __global__ __launch_bounds__(w43w::NT) void wino43_wgrad_kernel(int N, int H, in
                     va[slot][0] = va[slot][1] = vb[slot][0] = vb[slot][1] = make_float2(1.f, 1.f);
                     return;
                 }
-                va[slot][0] = *reinterpret_cast<const float2 *>(cur + fl * FS);
-                va[slot][1] = *reinterpret_cast<const float2 *>(cur + fl * FS + 64);
-                vb[slot][0] = *reinterpret_cast<const float2 *>(cur + fl * FS + OP_FLOATS);
-                vb[slot][1] = *reinterpret_cast<const float2 *>(cur + fl * FS + OP_FLOATS + 64);
+                const float *p = cur + fl * FS;             // (conflict-free dwords; pairs of them are one ds_read2_b32)
+                va[slot][0] = make_float2(p[0], p[32]);
+                va[slot][1] = make_float2(p[64], p[96]);
+                vb[slot][0] = make_float2(p[OP_FLOATS], p[OP_FLOATS + 32]);
+                vb[slot][1] = make_float2(p[OP_FLOATS + 64], p[OP_FLOATS + 96]);
             };
             opload(0, 0);
             opload(1, 1);
@@ -337,8 +366,10 @@ __global__ __launch_bounds__(w43w::NT) void wino43_wgrad_kernel(int N, int H, in
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            __syncthreads();
+            if (wave == 0) { W43W_STAMP(1, j) }
+            lds_barrier();
         }
+        if (wave == 0) { W43W_STAMP(6, 0) }
         // the accumulators into the exchange buffer [f][c][k] (over the operand buffers: every wave is past the last window's
         // barrier, the producers' last store was a window earlier)
         if (!(W43W_ABLATE & 16)) {
@@ -353,9 +384,15 @@ __global__ __launch_bounds__(w43w::NT) void wino43_wgrad_kernel(int N, int H, in
     }
 
     // ---------------------------------------------------------------- G^T dU G + slab stores (all eight waves)
-    __syncthreads();
-    if (DBIAS && c0 == 0 && tid < BK)
-        dbpart[(long)bz * K + k0 + tid] = (dbsum[tid] + dbsum[BK + tid]) + (dbsum[2 * BK + tid] + dbsum[3 * BK + tid]);
+    if (wave == 0) { W43W_STAMP(6, 1) }
+    lds_barrier();
+    if (wave == 0) { W43W_STAMP(6, 2) }
+    if (DBIAS && c0 == 0 && tid < BK) {
+        float t = 0.f;                                  // (a fixed order: the bias gradient is bit-reproducible too)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += dbsum[q * BK + tid];
+        dbpart[(long)bz * K + k0 + tid] = t;
+    }
     if (W43W_ABLATE & 16) return;
     const int ok = tid & 31, oc = tid >> 5;             // this thread's output channel; its input channels are oc and oc + 16
     const long CK = (long)C * K;
@@ -380,7 +417,13 @@ __global__ __launch_bounds__(w43w::NT) void wino43_wgrad_kernel(int N, int H, in
             dst[(long)(r * 3 + 2) * CK] = o2;
         }
     }
+    if (wave == 0) { W43W_STAMP(6, 3) }
 }
+#ifdef W43W_TRACE
+extern "C" int mmdgan_w43w_trace(long *host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_w43w_trace), sizeof(long) * (n < 8 * 256 ? n : 8 * 256), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // MMDGAN_WINO43_WGRAD=0: never; 1 (default): from wino43_wgrad_min_tiles 4x4 tiles on; 2: every eligible shape (parity tests)
