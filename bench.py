@@ -107,8 +107,8 @@ def dominant_kernel_probe(eng, reps=20, warm=3):
 
 
 def dominant_kernel_probe_tape(eng, reps=20, warm=3):
-    """the residual-block configs: the kernel with the largest share of their step is `wino_wgrad_kernel`, the
-    Winograd-domain weight gradient of the blocks' 3x3 convolutions (profiles/*_resnet_kernel_stats.txt).  Timed here on
+    """the residual-block configs: the kernel family with the largest share of their step is the Winograd-domain weight
+    gradient of the blocks' 3x3 convolutions (profiles/*_resnet_kernel_stats.txt; since round 6 `wino43_wgrad_kernel`).  Timed here on
     the first un-folded 3x3 kernel of D whose channels are tile multiples, at D's batch 2B, on stand-alone buffers of
     its shapes (the kernel's time does not depend on the data).  FLOPs are the algorithmic ones of the weight gradient."""
     from mmdgan_hip import ops
@@ -134,10 +134,13 @@ def dominant_kernel_probe_tape(eng, reps=20, warm=3):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    return {'kernel': 'conv2d_wgrad(%s: %dx%dx%d -> %d 3x3, %d rows; %s F(2x2,3x3))' % (
-                k.scope, h, w, c, kout, n, 'wino_wgrad_slab_kernel + slab_reduce_kernel' if kout % 128 == 0 else 'wino_wgrad_kernel'),
+    f43 = ops.wgrad_algo(n, h, w, c, kout, 3, 1) == ops.WINO_F43       # (bench.py registers a workspace: the library's own choice)
+    which = ('wino43_wgrad_kernel + slab_reduce_kernel F(4x4,3x3)' if f43 else
+             ('wino_wgrad_slab_kernel + slab_reduce_kernel' if kout % 128 == 0 else 'wino_wgrad_kernel') + ' F(2x2,3x3)')
+    return {'kernel': 'conv2d_wgrad(%s: %dx%dx%d -> %d 3x3, %d rows; %s)' % (k.scope, h, w, c, kout, n, which),
             'alg_bytes_read': 4.0 * n * h * w * (c + kout), 'alg_bytes_write': 4.0 * 9 * c * kout,
-            'mfma_share': 16.0 / 36,                                   # F(2x2,3x3): 16 multiplies per 36 algorithmic ones
+            # MFMA multiplies issued per algorithmic one: F(4x4,3x3) 36 per 144, F(2x2,3x3) 16 per 36
+            'mfma_share': 36.0 / 144 if f43 else 16.0 / 36,
             'flops': flops, 'ms': ms, 'tflops': flops / ms / 1e9}
 
 

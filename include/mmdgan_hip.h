@@ -77,9 +77,10 @@ const char *mmdgan_last_error(void);
 /* ABI version of this header: bumped whenever an entry's argument list, a workspace size or a calling rule changes
  * (200: rounds 1-4 - although mmdgan_bn_bwd gained `beta` and mmdgan_bn_workspace_bytes grew in round 4 without a bump;
  * 500: round 5 - mmdgan_wgrad_defer / mmdgan_wgrad_flush, BN workspace documented as [slots][2][C];
- * 600: round 6 - mmdgan_wino_algo / _algo_weight_bytes / _transform_algo, mmdgan_wino_job.algo, MMDGAN_ACT_FLAG_W_WINOGRAD43).  A caller compares
+ * 600: round 6 - mmdgan_wino_algo / _algo_weight_bytes / _transform_algo, mmdgan_wino_job.algo, MMDGAN_ACT_FLAG_W_WINOGRAD43;
+ * 610: mmdgan_wgrad_algo, the F(4x4,3x3) weight gradient in the default selection).  A caller compares
  * mmdgan_version() of the library it loaded with the MMDGAN_VERSION it was built against (mmdgan_hip/_lib.py does). */
-#define MMDGAN_VERSION 600
+#define MMDGAN_VERSION 610
 int mmdgan_version(void);
 /* Which kernel a convolution call takes is decided by the geometry and by a handful of process-wide switches (environment
  * variables MMDGAN_*, read once: csrc/tuning.h lists them with their defaults - the defaults are the configuration the
@@ -276,6 +277,12 @@ int mmdgan_wino_transform(const mmdgan_conv_geom *g, const float *w, int dgrad, 
 int mmdgan_wino_algo(const mmdgan_conv_geom *g, int dgrad);
 size_t mmdgan_wino_algo_weight_bytes(const mmdgan_conv_geom *g, int algo);
 int mmdgan_wino_transform_algo(const mmdgan_conv_geom *g, const float *w, int dgrad, int algo, float *u, void *stream);
+/* The weight gradient needs no transformed tensor from the caller (both of its operands are activations); which algorithm
+ * mmdgan_conv2d_wgrad* takes for g WITH a workspace registered: MMDGAN_WINO_F43 (csrc/conv_wino43w.hip: 3x3 stride 1, H and W
+ * multiples of 4, C and K of 32, from MMDGAN_WINO43_WGRAD_MIN_TILES 4x4 tiles on), _F23, _F22S2 or _NONE (implicit GEMM /
+ * thin / direct kernels).  F(4x4,3x3) rounds at 1-4e-6 of the tensor's scale against F(2x2,3x3)'s 5-9e-7 (tools/wino43_gate.py):
+ * a test that holds an identity to fp32 rounding asks here which floor applies.  (tf.gradients of layer_func.py:912-916.) */
+int mmdgan_wgrad_algo(const mmdgan_conv_geom *g);
 /* the same transform for MANY kernels in one launch (a training step re-transforms every eligible kernel of a network after
  * each weight update: one dispatch instead of one per kernel and form).  jobs is a HOST array, read during the call. */
 typedef struct mmdgan_wino_job {

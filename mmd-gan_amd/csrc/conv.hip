@@ -206,6 +206,15 @@ extern "C" int mmdgan_wino_algo(const mmdgan_conv_geom *g, int dgrad) {
     return MMDGAN_WINO_NONE;
 }
 
+extern "C" int mmdgan_wgrad_algo(const mmdgan_conv_geom *g) {
+    if (!g || g->N < 1 || g->H < 1 || g->W < 1 || g->C < 1 || g->K < 1 || g->R < 1 || g->stride < 1 || force_direct()) return MMDGAN_WINO_NONE;
+    const ConvDims d = conv_dims(*g);
+    if (wino43_wgrad_ok(d)) return MMDGAN_WINO_F43;
+    if (wino_wgrad_ok(d)) return MMDGAN_WINO_F23;
+    if (wino2_wgrad_ok(d)) return MMDGAN_WINO_F22S2;
+    return MMDGAN_WINO_NONE;
+}
+
 extern "C" size_t mmdgan_wino_algo_weight_bytes(const mmdgan_conv_geom *g, int algo) {
     if (!g) return 0;
     const size_t ck = sizeof(float) * (size_t)g->C * g->K;

@@ -5,16 +5,16 @@
 //
 // i.e. per frequency f = 6 i + j a GEMM  dU_f[c][k] = sum_tiles V_f[tile][c] * M_f[tile][k]  whose reduction runs over the
 // 4x4 output tiles: 36 multiplies per tile and (c, k) instead of 144 direct, or 64 as F(2x2,3x3) tiles (conv_wino.hip).
-//   * one workgroup = 32 input channels x 32 output channels x ALL 36 frequencies x a slice of the tile range, EIGHT waves
-//     in three roles (one consumer and one producer on every SIMD - the matrix pipe and the VALU are separate pipes):
+//   * one workgroup = 32 input channels x 32 output channels x ALL 36 frequencies x a slice of the tile range (one round of
+//     workgroups, XCD-grouped by tile range), EIGHT waves, a consumer and a producer on every SIMD:
 //       waves 0-3 (consumers): 9 frequencies each = 9 accumulators of v_mfma_f32_32x32x2_f32; per window of 8 tiles (4 MFMA
-//                 k-pairs) 36 ds_read_b64 (both operands come from LDS - neither is a weight) and 36 MFMAs - nothing else;
-//       waves 4-5 (V producers): lane = (input channel, k half, k-pair pair) owns TWO tiles of the window: their 6x6 patches
-//                 as 72 dword loads two windows ahead (zero padding = the buffer range check, as in the forward kernel),
-//                 B^T d B on both tiles at once (packed f32x2), 36 conflict-free ds_write_b64;
-//       waves 6-7 (M producers): the same for the output gradients: 2 x 16 dword loads, A dY A^T, 36 ds_write_b64; the
-//                 workgroups of channel block 0 also add up what they load: the bias gradient rides along.
-//     One barrier per window, both operands double-buffered (2 x 72 KB).
+//                 k-pairs) 36 ds_read2_b32 (both operands come from LDS - neither is a weight) and 36 MFMAs - nothing else;
+//       waves 4-7 (producers): two PAIRS on alternate windows, lane = (tile, channel pair) for BOTH operands - the 6x6 patch
+//                 of two input channels and the 4x4 gradients of two output channels as 8-byte requests (zero padding = the
+//                 buffer range check), B^T d B and A dY A^T packed on the two channels, 72 conflict-free 8-byte LDS stores;
+//                 the workgroups of channel block 0 also add up the gradients they load: the bias gradient rides along.
+//                 (How the producers got this shape - three earlier cuts and what each measured - is at their code below.)
+//     One LDS-only barrier per window, both operands double-buffered (2 x 72 KB), operand layout [f][k half][k-pair][channel].
 //   * epilogue: G^T dU G needs all 36 frequencies of a (c, k) and they sit in four waves: the accumulators go through LDS
 //     ([36][32][32] = 144 KB over the operand buffers), every thread then owns two (c, k), reads their 36 values, applies the
 //     transform in registers and stores 9 values into the workgroup's slab of the library workspace [split][9][C][K]; the slab
@@ -90,7 +90,6 @@ __device__ long g_w43w_trace[8 * 256];
 #define W43W_STAMP(ROW, J)
 #endif
 
-typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x4 w43w_rsrc(const float *base, long bytes) {       // (what make_rsrc builds, as four SGPRs)
     const unsigned long a = reinterpret_cast<unsigned long>(base);
     u32x4 r;
@@ -100,10 +99,6 @@ __device__ __forceinline__ u32x4 w43w_rsrc(const float *base, long bytes) {     
     r.w = 0x00020000u;
     return r;
 }
-
-struct W43wWalk {             // running (tx, ty, image) of a tile index advanced by the window's 8 tiles
-    int tx, ty, n;
-};
 
 // x [N,H,W,C], dy [N,H,W,K] -> part [split][9][C][K] (+ dbpart [split][K]); H and W multiples of 4, C and K of 32
 template <bool DBIAS>
@@ -148,6 +143,14 @@ __global__ __launch_bounds__(w43w::NT) void wino43_wgrad_kernel(int N, int H, in
         //   off window:  B^T d B of window w + 2, in place, as its patches arrive.
         // Every SIMD carries the same transform work beside its consumer wave (VALU from the partner wave costs the MFMA stream
         // about half of its own issue time, tools/mfma_valu_overlap.hip), and no window waits for a request's latency.
+        // History (D l3 at batch 128, alone, with reduction + bias gradient; F(2x2,3x3) slab kernel 71.6 us; profiles/
+        // r06_wino43w_ablation.txt): (1) waves 4-5 transform the patches, 6-7 the gradients, dword requests, two windows ahead:
+        // 62.6 us - the window waited for the two SIMDs that held the patches; (2) every producer wave one tile of both
+        // operands, scalar fp32, three sets in flight: 56.1 (52.2 with the priority below); (3) this shape with the requests
+        // in a burst behind the stores: 53.9; (4) each request behind the store that frees its register, tied to it by inline
+        // assembly (through the builtin hipcc put half of a window's values into other registers and copied them in front of
+        // the barrier, each copy a wait for its load): 50.9.  A window is now ~4200 cycles against 2304 of MFMAs, bound by
+        // request throughput (53 KB per window and CU), not by latency or the transforms (tools/wino43w_trace.py).
         // (static priority for the producers: the consumer waves are the older ones and win every arbitration otherwise -
         // D l3 at batch 128: 55.7 -> 52.2 us, tools/wino43w_ablate.sh)
 #ifndef W43W_PRODUCER_PRIO
@@ -445,7 +448,8 @@ int wino43_wgrad(const ConvDims &d, const float *x, const float *dy, float *dw, 
     const long T = (long)d.N * (d.H / 4) * (d.W / 4);
     const int nw = (int)((T + BT - 1) / BT);
     const int nblk_c = d.C / BC, nblk = nblk_c * (d.K / BK);
-    int split = wgrad_cus() / nblk;                                 // one 8-wave workgroup per CU (144 KB of LDS), one round
+    const int cus = tuning().wino43_wgrad_cus > 0 ? tuning().wino43_wgrad_cus : wgrad_cus();
+    int split = cus / nblk;                                         // one 8-wave workgroup per CU (146 KB of LDS), one round
     if (split > nw / 4) split = nw / 4;                             // >= 4 windows (144 MFMAs per wave) per workgroup
     if (split < 1) split = 1;
     const int wps = (nw + split - 1) / split;

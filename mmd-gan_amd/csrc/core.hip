@@ -192,6 +192,7 @@ extern "C" long mmdgan_tuning_describe(char *buf, size_t cap) {
     add("wino43", t.wino43, d.wino43); add("wino43_min_tiles", t.wino43_min_tiles, d.wino43_min_tiles);
     add("wino43_ksplit_below", t.wino43_ksplit_below, d.wino43_ksplit_below);
     add("wino43_wgrad", t.wino43_wgrad, d.wino43_wgrad); add("wino43_wgrad_min_tiles", t.wino43_wgrad_min_tiles, d.wino43_wgrad_min_tiles);
+    add("wino43_wgrad_cus", t.wino43_wgrad_cus, d.wino43_wgrad_cus);
     if (buf && cap > 0) {
         const size_t n = out.size() < cap - 1 ? out.size() : cap - 1;
         memcpy(buf, out.data(), n);

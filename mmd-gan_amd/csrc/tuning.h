@@ -32,10 +32,11 @@ struct Tuning {
     long wino43_ksplit_below;    // MMDGAN_WINO43_KSPLIT_BELOW=n its reduction split over workspace slabs for grids below n workgroups (256)
     int wino43_wgrad;            // MMDGAN_WINO43_WGRAD=0|1|2    F(4x4,3x3) weight gradients: never | from wino43_wgrad_min_tiles on (default) | every eligible shape
     long wino43_wgrad_min_tiles; // MMDGAN_WINO43_WGRAD_MIN_TILES=n  ... from n 4x4 tiles on (128)
+    int wino43_wgrad_cus;        // MMDGAN_WINO43_WGRAD_CUS=n    workgroups that kernel sizes its one-round grid for (0: wgrad_cus)
 };
 
 inline const Tuning &tuning_defaults() {
-    static const Tuning d = {0, 0, 1, -1, 385, 1, 1, 1, 1, 384, 1, 256, 224, 1, 1, 1, 1, 128, 256, 1, 128};
+    static const Tuning d = {0, 0, 1, -1, 385, 1, 1, 1, 1, 384, 1, 256, 224, 1, 1, 1, 1, 128, 256, 1, 128, 0};
     return d;
 }
 
@@ -66,6 +67,7 @@ inline const Tuning &tuning() {
         v.wino43_ksplit_below = getl("MMDGAN_WINO43_KSPLIT_BELOW", v.wino43_ksplit_below);
         v.wino43_wgrad = geti("MMDGAN_WINO43_WGRAD", v.wino43_wgrad);
         v.wino43_wgrad_min_tiles = getl("MMDGAN_WINO43_WGRAD_MIN_TILES", v.wino43_wgrad_min_tiles);
+        v.wino43_wgrad_cus = geti("MMDGAN_WINO43_WGRAD_CUS", v.wino43_wgrad_cus);
         return v;
     }();
     return t;

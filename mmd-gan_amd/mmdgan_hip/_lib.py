@@ -60,6 +60,7 @@ SIGNATURES = {
     'mmdgan_wino_transform': (_I, [_G, _P, _I, _P, _P]),
     'mmdgan_wino_transform_multi': (_I, [_P, _I, _P]),
     'mmdgan_wino_algo': (_I, [_G, _I]),
+    'mmdgan_wgrad_algo': (_I, [_G]),
     'mmdgan_wino_algo_weight_bytes': (ctypes.c_size_t, [_G, _I]),
     'mmdgan_wino_transform_algo': (_I, [_G, _P, _I, _I, _P, _P]),
     'mmdgan_gemm': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P]),
@@ -102,7 +103,7 @@ SIGNATURES = {
     'mmdgan_u8_records_to_nhwc': (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
 }
 
-ABI_VERSION = 600           # include/mmdgan_hip.h: MMDGAN_VERSION this binding was written against
+ABI_VERSION = 610           # include/mmdgan_hip.h: MMDGAN_VERSION this binding was written against
 
 _lib = None
 

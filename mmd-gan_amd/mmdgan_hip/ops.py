@@ -302,6 +302,13 @@ def wino_algo(N, H, W, C, K, R, stride, dgrad):
     return int(require_device().mmdgan_wino_algo(ctypes.byref(g), int(dgrad)))
 
 
+def wgrad_algo(N, H, W, C, K, R, stride):
+    """which algorithm conv2d_wgrad takes for this geometry with a workspace registered (mmdgan_wgrad_algo): WINO_F43
+    (F(4x4,3x3), csrc/conv_wino43w.hip), WINO_F23, WINO_F22S2 or WINO_NONE - what a test's rounding floor depends on"""
+    g = geom(N, H, W, C, K, R, stride)
+    return int(require_device().mmdgan_wgrad_algo(ctypes.byref(g)))
+
+
 def wino_alloc(algo, C, K, dgrad, device):
     """the (uninitialised) transformed-weight tensor of `algo` for a [R,R,C,K] kernel: [16 | 4,9 | 36] + (K,C if dgrad else C,K)"""
     return torch.empty(_WINO_LEAD[algo] + ((K, C) if dgrad else (C, K)), device=device, dtype=torch.float32)

@@ -56,7 +56,7 @@ def unknown():
     """MMDGAN_* variables in the environment that nothing reads (a typo, or a switch of an earlier round)"""
     lib = {'MMDGAN_FORCE_DIRECT', 'MMDGAN_THIN_VALU', 'MMDGAN_WINO', 'MMDGAN_WINO_MIN_TILES', 'MMDGAN_WINO_KSPLIT_BELOW',
            'MMDGAN_WINO_WGRAD', 'MMDGAN_WINO_WGRAD_SLAB', 'MMDGAN_WINO2', 'MMDGAN_WINO2_KSPLIT', 'MMDGAN_WINO2_KSPLIT_BELOW',
-           'MMDGAN_WINO2_WGRAD', 'MMDGAN_WINO2_WGRAD_MIN_TILES', 'MMDGAN_WINO43', 'MMDGAN_WINO43_MIN_TILES', 'MMDGAN_WINO43_KSPLIT_BELOW', 'MMDGAN_WINO43_WGRAD', 'MMDGAN_WINO43_WGRAD_MIN_TILES', 'MMDGAN_WGRAD_CUS', 'MMDGAN_GEMM_SKINNY', 'MMDGAN_GEMM_PANEL', 'MMDGAN_MMD_D16'}
+           'MMDGAN_WINO2_WGRAD', 'MMDGAN_WINO2_WGRAD_MIN_TILES', 'MMDGAN_WINO43', 'MMDGAN_WINO43_MIN_TILES', 'MMDGAN_WINO43_KSPLIT_BELOW', 'MMDGAN_WINO43_WGRAD', 'MMDGAN_WINO43_WGRAD_MIN_TILES', 'MMDGAN_WINO43_WGRAD_CUS', 'MMDGAN_WGRAD_CUS', 'MMDGAN_GEMM_SKINNY', 'MMDGAN_GEMM_PANEL', 'MMDGAN_MMD_D16'}
     return sorted(k for k in os.environ if k.startswith('MMDGAN_') and k not in _DEFAULTS and k not in lib)
 
 

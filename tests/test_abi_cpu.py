@@ -54,7 +54,7 @@ def test_kernel_selection_switches_are_listed_in_one_place(monkeypatch):
     t = ops.tuning()
     assert set(t) == {'force_direct', 'thin_valu', 'wino', 'wino_min_tiles', 'wino_ksplit_below', 'wino_wgrad', 'wino_wgrad_slab',
                       'wino2', 'wino2_ksplit', 'wino2_ksplit_below', 'wino2_wgrad', 'wino2_wgrad_min_tiles', 'wgrad_cus', 'gemm_skinny',
-                      'gemm_panel', 'mmd_d16', 'wino43', 'wino43_min_tiles', 'wino43_ksplit_below', 'wino43_wgrad', 'wino43_wgrad_min_tiles'}
+                      'gemm_panel', 'mmd_d16', 'wino43', 'wino43_min_tiles', 'wino43_ksplit_below', 'wino43_wgrad', 'wino43_wgrad_min_tiles', 'wino43_wgrad_cus'}
     assert t['wino_min_tiles'] == (32, False) and t['wino2'] == (2, False) and t['wino43'] == (2, False)   # conftest's thresholds
     assert t['wgrad_cus'] == (224, True) and t['wino'] == (1, True) and t['wino43_wgrad'] == (1, True) and t['wino43_wgrad_min_tiles'] == (64, False)
     assert settings.describe() == {} or all(k.startswith('MMDGAN_') for k in settings.describe())

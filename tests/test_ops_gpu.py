@@ -488,7 +488,11 @@ def test_conv_shapes_of_every_config_at_their_bench_batch(ops, which):
             return float((a.double() * b.double()).sum())
         form, scale = dot(y, dy), float(y.double().norm() * dy.double().norm())
         e1, e2 = abs(dot(x, dx) - form) / scale, abs(dot(w, dw) - form) / scale
-        if not (e1 <= 1e-6 and e2 <= 1e-6):
+        # (a mis-addressed tile is an error of 1e-3 and up; rounding is what the bar leaves room for: 1e-6, and 5e-6 where the
+        # weight gradient takes F(4x4,3x3) - its transforms carry constants up to 8 and one accumulator takes up to 2048
+        # products: measured 2.8e-6 on CelebA's 16x16x256 layer at 384 rows, 1-1.6e-6 element-wise in its own parity test)
+        bar2 = 5e-6 if ops.wgrad_algo(N, H, W, C, K, R, s) == ops.WINO_F43 else 1e-6
+        if not (e1 <= 1e-6 and e2 <= bar2):
             bad.append(((cfg, N, H, W, C, K, R, s), e1, e2))
         del x, w, dy, y, dx, dw
     ops.require_device().mmdgan_set_workspace(None, 0)
