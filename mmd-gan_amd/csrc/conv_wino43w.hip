@@ -90,16 +90,6 @@ __device__ long g_w43w_trace[8 * 256];
 #define W43W_STAMP(ROW, J)
 #endif
 
-__device__ __forceinline__ u32x4 w43w_rsrc(const float *base, long bytes) {       // (what make_rsrc builds, as four SGPRs)
-    const unsigned long a = reinterpret_cast<unsigned long>(base);
-    u32x4 r;
-    r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
-    r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
-    r.z = __builtin_amdgcn_readfirstlane((unsigned)bytes);
-    r.w = 0x00020000u;
-    return r;
-}
-
 // x [N,H,W,C], dy [N,H,W,K] -> part [split][9][C][K] (+ dbpart [split][K]); H and W multiples of 4, C and K of 32
 template <bool DBIAS>
 __global__ __launch_bounds__(w43w::NT) void wino43_wgrad_kernel(int N, int H, int W, int C, int K, const float *__restrict__ x,
@@ -143,14 +133,14 @@ __global__ __launch_bounds__(w43w::NT) void wino43_wgrad_kernel(int N, int H, in
         //   off window:  B^T d B of window w + 2, in place, as its patches arrive.
         // Every SIMD carries the same transform work beside its consumer wave (VALU from the partner wave costs the MFMA stream
         // about half of its own issue time, tools/mfma_valu_overlap.hip), and no window waits for a request's latency.
-        // History (D l3 at batch 128, alone, with reduction + bias gradient; F(2x2,3x3) slab kernel 71.6 us; profiles/
+        // History (D l3 at batch 128, alone, with reduction + bias gradient; F(2x2,3x3) slab kernel 72 us; profiles/
         // r06_wino43w_ablation.txt): (1) waves 4-5 transform the patches, 6-7 the gradients, dword requests, two windows ahead:
         // 62.6 us - the window waited for the two SIMDs that held the patches; (2) every producer wave one tile of both
-        // operands, scalar fp32, three sets in flight: 56.1 (52.2 with the priority below); (3) this shape with the requests
-        // in a burst behind the stores: 53.9; (4) each request behind the store that frees its register, tied to it by inline
-        // assembly (through the builtin hipcc put half of a window's values into other registers and copied them in front of
-        // the barrier, each copy a wait for its load): 50.9.  A window is now ~4200 cycles against 2304 of MFMAs, bound by
-        // request throughput (53 KB per window and CU), not by latency or the transforms (tools/wino43w_trace.py).
+        // operands, scalar fp32, three sets in flight: 56.1 (52.2 with the priority below); (3) this shape, requests in a burst
+        // behind the stores: 53.9; (4) each request right behind the store that frees its register, as inline assembly tied to
+        // that register with hand-placed s_waitcnt: 50.9 - and WRONG under load (below: requests); (5) the same order through
+        // the builtin, the loop written without a merge of its two window kinds, the transform pinned in its window: 54.4,
+        // a window ~3600 cycles against 2304 of MFMAs (tools/wino43w_trace.py).
         // (static priority for the producers: the consumer waves are the older ones and win every arbitration otherwise -
         // D l3 at batch 128: 55.7 -> 52.2 us, tools/wino43w_ablate.sh)
 #ifndef W43W_PRODUCER_PRIO
@@ -168,20 +158,19 @@ __global__ __launch_bounds__(w43w::NT) void wino43_wgrad_kernel(int N, int H, in
         // (the scalar offset of the load: no address arithmetic per load); the border rows / columns that lie outside the image
         // take an out-of-range tilebase instead (nine variants per window: {top, middle, bottom} x {left, middle, right})
         const unsigned xrow = (unsigned)(W * C * 4), xpix = (unsigned)(C * 4);
-        // (the requests are inline assembly with the destination tied to the register it replaces: through the builtin hipcc
-        // put half of a window's values into other registers and copied them at the end of the block - every copy a wait for
-        // its load, in front of the barrier.  The waits are therefore placed by hand: w43w_wait_x / _y below.)
-        const u32x4 rx = w43w_rsrc(x - ((long)W * C + C), (long)N * H * W * C * 4 + xrow + xpix);
-        const u32x4 rdy = w43w_rsrc(dy, (long)N * H * W * K * 4);
+        // (The requests go through the compiler's builtin, which places the waits.  A cut with inline-assembly requests tied to the
+        // register they replace and hand-placed s_waitcnt was 5 % faster alone and WRONG under load: hipcc, which takes an asm's
+        // output for a finished value, copied registers whose request was still in flight - across the wait that named only half
+        // of them, and at the loop's merge point - so a cold or contended run multiplied stale values; found by the full GPU
+        // suite, reproduced by a stress run with a second stream, round 6.)
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(x - ((long)W * C + C), (long)N * H * W * C * 4 + xrow + xpix);
+        const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, (long)N * H * W * K * 4);
         const unsigned yrow = (unsigned)(W * K * 4), ypix = (unsigned)(K * 4);
         const unsigned xch = (unsigned)((c0 + 2 * cp) * 4), ych = (unsigned)((k0 + 2 * cp) * 4);
         const bool dosum = DBIAS && c0 == 0;
         f32x2 dbs = {0.f, 0.f};
         f32x2 d[36], e[16];                             // the patch (raw, then B^T d B in place) and the raw output gradients
-#pragma unroll
-        for (int q = 0; q < 36; ++q) d[q] = f32x2{0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < 16; ++q) e[q] = f32x2{0.f, 0.f};
+
         unsigned var[3][3], ybase;                      // the offsets of the window being requested
         auto request_begin = [&]() __attribute__((always_inline)) {
             const bool ok = id < t_end;
@@ -205,31 +194,12 @@ __global__ __launch_bounds__(w43w::NT) void wino43_wgrad_kernel(int N, int H, in
         };
 #define W43W_XREQ(Q)                                                                                        \
     if (W43W_ABLATE & 1) { float o = (float)(lane + (Q)); asm volatile("" : "+v"(o)); d[Q] = f32x2{o, o}; }   \
-    else asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(d[Q])                              \
-                      : "v"(var[(Q) / 6 == 0 ? 0 : (Q) / 6 == 5 ? 2 : 1][(Q) % 6 == 0 ? 0 : (Q) % 6 == 5 ? 2 : 1]), "s"(rx), \
-                        "s"((unsigned)((Q) / 6) * xrow + (unsigned)((Q) % 6) * xpix));
+    else d[Q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(                            \
+             rx, var[(Q) / 6 == 0 ? 0 : (Q) / 6 == 5 ? 2 : 1][(Q) % 6 == 0 ? 0 : (Q) % 6 == 5 ? 2 : 1],    \
+             (unsigned)((Q) / 6) * xrow + (unsigned)((Q) % 6) * xpix, 0));
 #define W43W_YREQ(Q)                                                                                        \
     if (W43W_ABLATE & 1) { float o = (float)(lane - (Q)); asm volatile("" : "+v"(o)); e[Q] = f32x2{o, o}; }   \
-    else asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(e[Q])                              \
-                      : "v"(ybase), "s"(rdy), "s"((unsigned)((Q) / 4) * yrow + (unsigned)((Q) % 4) * ypix));
-        // a wave's requests go out in the order 36 patch pixels, 16 gradient pixels, 36, 16, ...: the patches have landed when
-        // at most the 16 younger requests are outstanding, the gradients when at most the 36 younger ones are
-        auto wait_x = [&]() __attribute__((always_inline)) {
-            if (W43W_ABLATE & 1) return;
-            asm volatile("s_waitcnt vmcnt(16)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]), "+v"(d[8]),
-                         "+v"(d[9]), "+v"(d[10]), "+v"(d[11]), "+v"(d[12]), "+v"(d[13]), "+v"(d[14]), "+v"(d[15]), "+v"(d[16]), "+v"(d[17]));
-            asm volatile("" : "+v"(d[18]), "+v"(d[19]), "+v"(d[20]), "+v"(d[21]), "+v"(d[22]), "+v"(d[23]), "+v"(d[24]), "+v"(d[25]), "+v"(d[26]),
-                         "+v"(d[27]), "+v"(d[28]), "+v"(d[29]), "+v"(d[30]), "+v"(d[31]), "+v"(d[32]), "+v"(d[33]), "+v"(d[34]), "+v"(d[35]));
-        };
-        auto wait_y = [&](bool younger_patches) __attribute__((always_inline)) {
-            if (W43W_ABLATE & 1) return;
-            if (younger_patches)
-                asm volatile("s_waitcnt vmcnt(36)" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]),
-                             "+v"(e[8]), "+v"(e[9]), "+v"(e[10]), "+v"(e[11]), "+v"(e[12]), "+v"(e[13]), "+v"(e[14]), "+v"(e[15]));
-            else
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]),
-                             "+v"(e[8]), "+v"(e[9]), "+v"(e[10]), "+v"(e[11]), "+v"(e[12]), "+v"(e[13]), "+v"(e[14]), "+v"(e[15]));
-        };
+    else e[Q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rdy, ybase, (unsigned)((Q) / 4) * yrow + (unsigned)((Q) % 4) * ypix, 0));
         auto request = [&]() __attribute__((always_inline)) {       // the pair's next window, then advance
             request_begin();
 #pragma unroll
@@ -241,7 +211,6 @@ __global__ __launch_bounds__(w43w::NT) void wino43_wgrad_kernel(int N, int H, in
         auto transform_v = [&]() __attribute__((always_inline)) {
             if (W43W_ABLATE & 2) return;
             __builtin_amdgcn_sched_barrier(0);
-            wait_x();
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
                 f32x2 t0, t1, t2, t3, t4, t5;
@@ -254,6 +223,12 @@ __global__ __launch_bounds__(w43w::NT) void wino43_wgrad_kernel(int N, int H, in
                 W43W_BT6(d[0 + jj], d[6 + jj], d[12 + jj], d[18 + jj], d[24 + jj], d[30 + jj], v0, v1, v2, v3, v4, v5)
                 d[0 + jj] = v0; d[6 + jj] = v1; d[12 + jj] = v2; d[18 + jj] = v3; d[24 + jj] = v4; d[30 + jj] = v5;
             }
+            // (pin the results HERE: arithmetic is no memory access, and hipcc sank the whole transform across the barrier into
+            // the duty window - 5600 cycles there, 70 here, tools/wino43w_trace.py.  Volatile statements keep their order.)
+            asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]), "+v"(d[8]),
+                         "+v"(d[9]), "+v"(d[10]), "+v"(d[11]), "+v"(d[12]), "+v"(d[13]), "+v"(d[14]), "+v"(d[15]), "+v"(d[16]), "+v"(d[17]));
+            asm volatile("" : "+v"(d[18]), "+v"(d[19]), "+v"(d[20]), "+v"(d[21]), "+v"(d[22]), "+v"(d[23]), "+v"(d[24]), "+v"(d[25]), "+v"(d[26]),
+                         "+v"(d[27]), "+v"(d[28]), "+v"(d[29]), "+v"(d[30]), "+v"(d[31]), "+v"(d[32]), "+v"(d[33]), "+v"(d[34]), "+v"(d[35]));
             __builtin_amdgcn_sched_barrier(0);
         };
         // duty window: both operands of the window to LDS, M = A dY A^T (+ the bias gradient's share of this tile) on the way,
@@ -269,7 +244,6 @@ __global__ __launch_bounds__(w43w::NT) void wino43_wgrad_kernel(int N, int H, in
                 else asm volatile("" ::"v"(d[f]));
                 if (again) { W43W_XREQ(f) }
             }
-            wait_y(again);
             if (dosum) dbs += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7])) + (((e[8] + e[9]) + (e[10] + e[11])) + ((e[12] + e[13]) + (e[14] + e[15])));
             f32x2 t[4][6];                                  // t[a][j] = sum_b dY[a][b] A[j][b]
 #pragma unroll
@@ -300,17 +274,27 @@ __global__ __launch_bounds__(w43w::NT) void wino43_wgrad_kernel(int N, int H, in
         transform_v();
         if (g == 0) dump_request(smem, true);           // (and window 2 requested)
         lds_barrier();
-        for (int i = 0; i < S; ++i) {                   // the consumers multiply window i
+        // the consumers multiply window i.  The two window kinds alternate; pair 1 starts with a duty window (its window 1), pair 0
+        // with an off window - written as ONE loop body of (off, duty) with pair 1's first duty peeled off, so that no register
+        // of a window in flight has to change place where two paths meet
+        int i = 0;
+        if (g == 1) {
+            if (wave == 6) { W43W_STAMP(2, i) }
+            dump_request(smem + WIN_FLOATS, true);
+            lds_barrier();
+            ++i;
+        }
+        while (i < S) {
             if (wave == 4) { W43W_STAMP(2, i) }
-            if (((i + 1) & 1) == g) {
-                dump_request(smem + ((i + 1) & 1) * WIN_FLOATS, true);
-                if (wave == 4) { W43W_STAMP(3, i) }
-            } else {
-                transform_v();
-                if (wave == 4) { W43W_STAMP(3, i) }
-            }
+            transform_v();
             if (wave == 4) { W43W_STAMP(4, i) }
             lds_barrier();
+            if (++i >= S) break;
+            if (wave == 4) { W43W_STAMP(3, i) }
+            dump_request(smem + ((i + 1) & 1) * WIN_FLOATS, true);
+            if (wave == 4) { W43W_STAMP(4, i) }
+            lds_barrier();
+            ++i;
         }
         if (dosum) {
             float *row = dbsum + (((wave - 4) * 4 + (lane >> 4)) * BK + 2 * cp);

@@ -948,6 +948,42 @@ def test_conv2d_winograd_f43_weight_gradient(ops, case):
     assert rel_err(ops.conv2d_wgrad(nhwc(x), nhwc(dy), ksz, s).cpu().numpy(), gw) <= RTOL
 
 
+def test_conv2d_winograd_f43_weight_gradient_under_load(ops):
+    """the same kernel with the chip BUSY: 200 back-to-back launches per geometry, every other one with a forward convolution
+    running on a second stream, the first one right after a synchronise (cold caches), with and without the bias gradient -
+    every run bit-identical to the first and within the fp64 bar.  Round 6 shipped (for an hour) a version whose requests
+    were inline assembly with hand-placed waits: hipcc copied registers whose request was still in flight, so a cold or
+    contended run multiplied stale values - one run in ten wrong by 30-60 % on whole 32 x 32 blocks, never in a quiet
+    parity test.  This is the test that would have caught it (tools/scratch history: profiles/r06_wino43w_ablation.txt)."""
+    side = torch.cuda.Stream()
+    big, wb = torch.randn(64, 64, 64, 64, device='cuda'), torch.randn(3, 3, 64, 64, device='cuda')
+    ops.set_workspace(128 << 20)
+    try:
+        for (N, H, W, C, K) in [(4, 32, 32, 64, 64), (16, 16, 16, 128, 128), (48, 64, 64, 256, 32), (130, 4, 4, 64, 64), (33, 8, 8, 64, 32)]:
+            assert ops.wgrad_algo(N, H, W, C, K, 3, 1) == ops.WINO_F43
+            g = torch.Generator(device='cuda').manual_seed(N + C)
+            x = torch.empty(N, H, W, C, device='cuda').uniform_(-1, 1, generator=g)
+            dy = torch.randn(N, H, W, K, device='cuda', generator=g)
+            wz = torch.zeros(K, C, 3, 3, device='cuda', dtype=torch.float64, requires_grad=True)
+            gref, = torch.autograd.grad((torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), wz, padding=1) *
+                                         dy.permute(0, 3, 1, 2).double()).sum(), [wz])
+            want = gref.permute(2, 3, 1, 0).contiguous()
+            scale = float(want.abs().max())
+            db = torch.empty(K, device='cuda')
+            torch.cuda.synchronize()
+            first = ops.conv2d_wgrad(x, dy, 3, 1).clone()
+            assert float((first.double() - want).abs().max()) <= RTOL * scale, 'the first (cold) run'
+            for rep in range(200):
+                if rep % 2:
+                    with torch.cuda.stream(side):
+                        ops.conv2d_fwd(big, wb, 1)
+                dw = ops.conv2d_wgrad(x, dy, 3, 1, dbias=db if rep % 3 == 0 else None)
+                assert torch.equal(first, dw), ((N, H, W, C, K), rep, float((dw.double() - want).abs().max()) / scale)
+            torch.cuda.synchronize()
+    finally:
+        ops.require_device().mmdgan_set_workspace(None, 0)
+
+
 def test_winograd_weight_transforms_of_many_kernels_in_one_launch(ops):
     """mmdgan_wino_transform_multi: 3x3 and 4x4 kernels, both forms, ragged 3x3 channel blocks, more jobs than one table
     holds (24) - every transformed tensor bit-equal to its one-kernel launch"""
