@@ -44,12 +44,12 @@ try:
     S = max(j for j in range(256) if t[0][j]) + 1
     t0 = t[0][0]
     print('%d windows; cycles since the consumer\'s first window' % S)
-    print('window | consumer: start, MFMAs issued (d) | producer: start, requests issued (d), transformed + stored (d) | window length')
+    print('window | consumer: start, MFMAs issued (d) | producer wave 4: kind, start, done (d) | window length')
     for j in range(S):
         nxt = t[0][j + 1] if j + 1 < S else t[6][0]
-        print('%6d | %8d %8d (%5d) | %8d %8d (%5d) %8d (%5d) | %6d' % (
-            j, t[0][j] - t0, t[1][j] - t0, t[1][j] - t[0][j], t[2][j] - t0, t[3][j] - t0, t[3][j] - t[2][j], t[4][j] - t0, t[4][j] - t[3][j],
-            nxt - t[0][j]))
+        kind, ps = ('off: B^T d B ', t[2][j]) if t[2][j] else ('duty: stores + M + requests', t[3][j])
+        print('%6d | %8d %8d (%5d) | %-28s %8d %8d (%5d) | %6d' % (
+            j, t[0][j] - t0, t[1][j] - t0, t[1][j] - t[0][j], kind, ps - t0, t[4][j] - t0, t[4][j] - ps, nxt - t[0][j]))
     print('kernel entry %d; consumers past the first barrier %d' % (t[7][0] - t0, t[7][1] - t0))
     print('after the last window %d; exchange written %d; barrier passed %d; kernel end %d' % (t[6][0] - t0, t[6][1] - t0, t[6][2] - t0, t[6][3] - t0))
 finally:
