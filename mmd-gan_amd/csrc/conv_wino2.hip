@@ -126,6 +126,12 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(wino2::Params P, ConvEpil
     // 80.87 / 80.80 us, second workgroup 80.57 / 80.61, first workgroup 80.87 / 81.02, the five-accumulator waves 83.18 / 83.06;
     // CIFAR step 1.899 / 1.902 -> 1.883 / 1.899 ms.
     if (second) __builtin_amdgcn_s_setprio(1);
+#ifdef W2_SECOND_DELAY   // measurement builds only (tools/wino2_ablate.sh delay): the CU's second workgroup starts this many 10 ns ticks late
+    if (second) {
+        const long t0_ = (long)wall_clock64();
+        while ((long)wall_clock64() - t0_ < W2_SECOND_DELAY) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
     const int cb = wrole & 1, fq = wrole >> 1;           // this wave: column block cb, frequencies fq + 2m
     const int nm = fq == 0 ? 5 : 4;
     // ---- this workgroup's run of items: XCD x (speed assumption: workgroup b runs on XCD b % 8) gets a contiguous eighth of

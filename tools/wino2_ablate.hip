@@ -10,6 +10,13 @@ namespace mmdgan { void set_error(const char *, ...) {} bool outputs_prezeroed()
 void *workspace(size_t) { return nullptr; } void *workspace_acquire(size_t, hipStream_t) { return nullptr; }
 bool plan_recording() { return false; } void plan_push(std::function<void()> &&) {} void plan_note_collective() {}
 void addend_applied() {}
+void *wgrad_slabs_acquire(size_t, hipStream_t, SlabReduceArgs *) { return nullptr; }
+int wgrad_slabs_release(const SlabReduceArgs &, hipStream_t) { return 0; }
+bool wgrad_deferred() { return false; }
+int wgrad_flush_pending() { return 0; }
+double *bn_stats_request() { return nullptr; }
+void bn_stats_applied() {}
+int bn_slot_count(int) { return 1; }
 hipError_t memset_async(void *p, int v, size_t b, hipStream_t s) { return hipMemsetAsync(p, v, b, s); } }
 extern "C" int mmdgan_colsum(const float *, long, int, float *, void *) { return 0; }
 int main(int argc, char **argv) {
