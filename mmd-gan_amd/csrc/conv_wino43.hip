@@ -40,7 +40,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace w43 {
 constexpr int NT = 512;                     // 4 consumer + 4 producer waves
-constexpr int BC = 8;                       // reduction channels per stage = 4 MFMA k-pairs (the granularity of U)
+[[maybe_unused]] constexpr int BC = 8;      // reduction channels per stage = 4 MFMA k-pairs (the granularity of U)
 constexpr int BW = 16;                      // ... per WINDOW (one barrier, one V buffer) = two stages: a patch pixel is then 64
                                             // contiguous bytes - the CU's address path takes ~2 cycles per contiguous run whatever its
                                             // length, and at 32-byte runs (8 channels) that alone was 2450 cycles per 2304 of MFMAs
