@@ -139,14 +139,14 @@ __global__ __launch_bounds__(w43w::NT) void wino43_wgrad_kernel(int N, int H, in
         // operands, scalar fp32, three sets in flight: 56.1 (52.2 with the priority below); (3) this shape, requests in a burst
         // behind the stores: 53.9; (4) each request right behind the store that frees its register, as inline assembly tied to
         // that register with hand-placed s_waitcnt: 50.9 - and WRONG under load (below: requests); (5) the same order through
-        // the builtin, the loop written without a merge of its two window kinds, the transform pinned in its window: 54.4,
-        // a window ~3600 cycles against 2304 of MFMAs (tools/wino43w_trace.py).
-        // (static priority for the producers: the consumer waves are the older ones and win every arbitration otherwise -
-        // D l3 at batch 128: 55.7 -> 52.2 us, tools/wino43w_ablate.sh)
-#ifndef W43W_PRODUCER_PRIO
-#define W43W_PRODUCER_PRIO 1
-#endif
+        // the builtin, the loop written without a merge of its two window kinds, the transform pinned in its window: 54.4
+        // (a window ~3600 cycles against 2304 of MFMAs, tools/wino43w_trace.py); (6) without the producers' priority: 51.1.
+        // (No static priority: s_setprio 1 on the producers won 6 % on cut (2) of the history above and LOSES 4-8 % on the shipped
+        // form - D l3 53.1 vs 51.1 us, CelebA D l7 266 vs 244, ResNet 64x64 85.9 vs 79.6 - where the consumers are what a window
+        // waits for; -DW43W_PRODUCER_PRIO=n builds the variants, profiles/r06_wino43w_ablation.txt.)
+#ifdef W43W_PRODUCER_PRIO
         __builtin_amdgcn_s_setprio(W43W_PRODUCER_PRIO);
+#endif
         const int g = (wave - 4) >> 1, hw = (wave - 4) & 1;
         const int tl = 4 * hw + (lane >> 4), cp = lane & 15;        // tile of the window, channel pair
         const int vd = (tl & 1) * 128 + (tl >> 1) * 32 + 2 * cp;     // [k half][k-pair][channel]: + f * FS (+ OP_FLOATS: M)
