@@ -528,7 +528,11 @@ def test_pipelined_step_boundary_keeps_the_reference_semantics(monkeypatch):
     init = {k[len('init/'):]: v for k, v in fx.items() if k.startswith('init/')}
     m = {k[len('adam_m/'):]: v for k, v in fx.items() if k.startswith('adam_m/')}
     v2 = {k[len('adam_v/'):]: v for k, v in fx.items() if k.startswith('adam_v/')}
-    rs = np.random.RandomState(4)
+    # (the perturbed batches of steps 3-5 are not knife-edge-repaired like the fixture's own three: with seed 4 one relu input of G
+    # at step 4 lay within rounding of zero, and the two engines - whose sums differ in their last bits - decided it differently in
+    # one run of fifteen (G's gradients 1.7e-3 apart, then every variable below it); seed 7 did so in one run of four, seed 13 in
+    # none of a hundred: round 6, TEST_AHEAD_SEED to try others)
+    rs = np.random.RandomState(int(os.environ.get('TEST_AHEAD_SEED', '13')))
     batches = [(nhwc(fx['real'][k % 3] + (0.01 * rs.randn(*fx['real'][0].shape).astype(np.float32) if k >= 3 else 0)),
                 torch.as_tensor(fx['z'][k % 3]).cuda()) for k in range(7)]
 
@@ -545,7 +549,11 @@ def test_pipelined_step_boundary_keeps_the_reference_semantics(monkeypatch):
             if n == a.dis.specs[-1].scope + '/bias/bias':    # analytically zero gradient (the loss sees score differences): Adam
                 assert float(np.abs(va[n] - vb[n]).max()) <= 3.5 * max(lr) * 7, (what, n)    # turns rounding noise into lr-sized steps
                 continue
-            assert float(np.abs(va[n] - vb[n]).max()) <= 1e-4 * scale + 1e-7, (what, n, float(np.abs(va[n] - vb[n]).max()), scale)
+            # (a bias starts at zero and has only ever moved by Adam's lr-sized steps: where its gradient is small, m / sqrt(v) turns
+            # the rounding of the kernels' atomic sums - which differs between two engines, and between two runs - into a fraction
+            # of a step.  gen/l1/bias/bias: 1.6e-6 apart in one run of seven on a scale of 3.6e-3, round 6; 2 % of a step is allowed)
+            noise = 0.02 * max(lr) if (n.endswith('/bias/bias') or n.endswith('/BN/beta')) else 0.0      # (BN's beta starts at zero as well)
+            assert float(np.abs(va[n] - vb[n]).max()) <= 1e-4 * scale + 1e-7 + noise, (what, n, float(np.abs(va[n] - vb[n]).max()), scale)
         sa, sb = a.sigmas(), b.sigmas()
         for k in sa:
             assert abs(sa[k] - sb[k]) <= 1e-5 * abs(sb[k]), (what, k)
